@@ -1,0 +1,188 @@
+"""Synthetic albums/questions of a named shape.
+
+`SynthSpec(N, A, P, S, L, d)` maps BASELINE.json's "N QA pairs, A albums x P photos
+x S text streams x L tokens, hidden d" onto the reference's context tensor
+(model_v2.py:863-914): every text stream is photo-level like `pts`
+([N,A,P,L] tokens, flattened to [N,A,P*L] as model_v2.py:886), plus the photo
+stream `pis` [N,A,P]; hall = [N, K=S+1, M=A, JMAX=P*L, 2d], JQ=L, JA=5.
+Optionally `SA` extra album-level text streams ([N,A,L] like at/ad/when/where)
+are put in front, to exercise ragged per-modality lengths.
+
+Host-side (CPU torch tensors).  Consumers move them to the GPU themselves.
+There is no dataset in this environment: values are seeded random.
+"""
+from dataclasses import dataclass
+
+import torch
+
+
+@dataclass
+class SynthSpec:
+    N: int = 64          # QA pairs per batch (per GPU)
+    A: int = 1           # albums per QA pair (M)
+    P: int = 40          # photos per album (JI)
+    S: int = 5           # photo-level text streams
+    L: int = 30          # tokens per text sequence (JXP) and question length (JQ)
+    d: int = 512         # LSTM hidden size; w = 2d
+    SA: int = 0          # album-level text streams [N,A,L]
+    JA: int = 5          # answer tokens (main.py:80 answer_size_thres)
+    num_choice: int = 4  # model.py:353
+    text_in: int = 200   # word 100 + char-CNN 100 (README.MD:144-145)
+    img_in: int = 100    # image_trans_dim (README.MD:144)
+    dense: bool = True   # all lengths = max (roofline point; no padding to skip)
+    simiMatrix: int = 2
+    add_tanh: bool = True
+    use_question_att: bool = True
+    share_fw_bw: bool = True   # TF>=1.2 cell reuse
+    seed: int = 1234
+    weight_seed: int = 42
+
+    @property
+    def K(self):
+        return self.SA + self.S + 1
+
+    @property
+    def JMAX(self):
+        return max(self.P * self.L, self.L if self.SA else 0, self.P)
+
+    @property
+    def T(self):
+        return self.A * self.JMAX
+
+    @property
+    def w(self):
+        return 2 * self.d
+
+    def cfg(self):
+        return dict(simiMatrix=self.simiMatrix, add_tanh=self.add_tanh,
+                    use_question_att=self.use_question_att, use_eu_output=False,
+                    use_time_warp=False, hidden_size=self.d, num_choice=self.num_choice,
+                    share_fw_bw=self.share_fw_bw)
+
+
+CONFIGS = {
+    # BASELINE.json configs[0]: reference CPU-runnable plumbing case
+    "plumbing": dict(N=4, A=2, P=5, S=2, L=10, d=128),
+    # configs[1..3]: the metric shape
+    "metric": dict(N=64, A=1, P=40, S=5, L=30, d=512),
+    # configs[4]: long-album stress
+    "long_album": dict(N=32, A=1, P=120, S=6, L=60, d=1024),
+}
+
+
+def _lengths(gen, shape, lo, hi, dense, p_empty=0.0):
+    if dense:
+        return torch.full(shape, hi, dtype=torch.int64)
+    ln = torch.randint(lo, hi + 1, shape, generator=gen)
+    if p_empty > 0:
+        ln = torch.where(torch.rand(shape, generator=gen) < p_empty, torch.zeros_like(ln), ln)
+    return ln
+
+
+def _mask(ln, J):
+    return torch.arange(J)[None, :].expand(ln.numel(), J).reshape(*ln.shape, J) < ln[..., None]
+
+
+def _glorot(gen, fan_in, fan_out):
+    lim = (6.0 / (fan_in + fan_out)) ** 0.5
+    return (torch.rand(fan_in, fan_out, generator=gen) * 2 - 1) * lim
+
+
+def _trunc_normal(gen, shape, std=0.1):
+    """model_v2.py:88 tf.truncated_normal(stddev=0.1): resample beyond 2 sigma."""
+    x = torch.randn(shape, generator=gen)
+    bad = x.abs() > 2
+    while bad.any():
+        x = torch.where(bad, torch.randn(shape, generator=gen), x)
+        bad = x.abs() > 2
+    return x * std
+
+
+def att_feat_dim(simiMatrix, w):
+    return {1: 3 * w, 2: 2 * w, 3: 4 * w, 4: 0}[simiMatrix]
+
+
+def make_params(spec: SynthSpec, dtype=torch.float32):
+    """Random-init parameters under the reference's checkpoint names
+     mapped to the oracle's short keys."""
+    g = torch.Generator().manual_seed(spec.weight_seed)
+    d, w = spec.d, spec.w
+    p = {
+        "text_kernel": _glorot(g, spec.text_in + d, 4 * d),
+        "text_bias": torch.zeros(4 * d),
+        "image_kernel": _glorot(g, spec.img_in + d, 4 * d),
+        "image_bias": torch.zeros(4 * d),
+        "out_W": _trunc_normal(g, (5 * w, 1)),
+        "out_b": torch.zeros(1),
+    }
+    if not spec.share_fw_bw:
+        p["text_kernel_bw"] = _glorot(g, spec.text_in + d, 4 * d)
+        p["text_bias_bw"] = torch.zeros(4 * d)
+        p["image_kernel_bw"] = _glorot(g, spec.img_in + d, 4 * d)
+        p["image_bias_bw"] = torch.zeros(4 * d)
+    F = att_feat_dim(spec.simiMatrix, w)
+    if F:
+        p["att_W"] = _trunc_normal(g, (F, 1))
+        p["att_b"] = torch.zeros(1)
+        p["qatt_W"] = _trunc_normal(g, (F, 1))
+        p["qatt_b"] = torch.zeros(1)
+    return {k: v.to(dtype) for k, v in p.items()}
+
+
+def make_inputs(spec: SynthSpec, rank: int = 0, dtype=torch.float32):
+    """Encoder inputs in the oracle's `inputs` dict format (see
+    oracle/fvta_literal.py:fvta_forward docstring)."""
+    g = torch.Generator().manual_seed(spec.seed + rank)
+    N, A, P, L = spec.N, spec.A, spec.P, spec.L
+    dense = spec.dense
+    nphoto = _lengths(g, (N, A), 1, P, dense)                       # photos per album
+    photo_live = torch.arange(P)[None, None, :] < nphoto[..., None]  # [N,A,P]
+    ctx = []
+    for _ in range(spec.SA):
+        ln = _lengths(g, (N, A), 1, L, dense, 0.05)
+        ctx.append(dict(x=torch.randn(N, A, L, spec.text_in, generator=g).to(dtype),
+                        mask=_mask(ln, L), cell="text"))
+    for _ in range(spec.S):
+        ln = _lengths(g, (N, A, P), 1, L, dense, 0.05)
+        ln = torch.where(photo_live, ln, torch.zeros_like(ln))
+        ctx.append(dict(x=torch.randn(N, A, P, L, spec.text_in, generator=g).to(dtype),
+                        mask=_mask(ln, L), cell="text"))
+    ctx.append(dict(x=torch.randn(N, A, P, spec.img_in, generator=g).to(dtype),
+                    mask=photo_live.clone(), cell="image"))
+    qlen = _lengths(g, (N,), min(3, L), L, dense)
+    clen = _lengths(g, (N, spec.num_choice), 1, spec.JA, dense)
+    yidx = torch.randint(0, spec.num_choice, (N,), generator=g)
+    y = torch.zeros(N, spec.num_choice, dtype=torch.bool)
+    y[torch.arange(N), yidx] = True
+    return dict(
+        ctx=ctx,
+        q=dict(x=torch.randn(N, L, spec.text_in, generator=g).to(dtype), mask=_mask(qlen, L)),
+        choices=dict(x=torch.randn(N, spec.num_choice, spec.JA, spec.text_in, generator=g).to(dtype),
+                     mask=_mask(clen, spec.JA)),
+        y=y,
+    )
+
+
+def to_numpy(tree, dtype=None):
+    """torch tree -> numpy tree (for the literal oracle)."""
+    import numpy as np
+    if isinstance(tree, dict):
+        return {k: to_numpy(v, dtype) for k, v in tree.items()}
+    if isinstance(tree, list):
+        return [to_numpy(v, dtype) for v in tree]
+    if isinstance(tree, torch.Tensor):
+        a = tree.detach().cpu().numpy()
+        if dtype is not None and a.dtype.kind == "f":
+            a = a.astype(dtype)
+        return a
+    return tree
+
+
+def to_dtype(tree, dtype):
+    if isinstance(tree, dict):
+        return {k: to_dtype(v, dtype) for k, v in tree.items()}
+    if isinstance(tree, list):
+        return [to_dtype(v, dtype) for v in tree]
+    if isinstance(tree, torch.Tensor) and tree.is_floating_point():
+        return tree.to(dtype)
+    return tree

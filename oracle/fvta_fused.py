@@ -1,0 +1,255 @@
+"""CPU ORACLE (fused, differentiable) -- TEST INFRASTRUCTURE ONLY, NOT A PRODUCT PATH.
+
+PARITY UNPINNED (see oracle/fvta_literal.py header): the reference cannot run
+here and ships no vectors.  This is the second, independent restatement of the
+same reference math (PyTorch-CPU, autograd for gradients).  It differs from
+the literal oracle in *how* it computes, not *what*: the similarity logits use
+the bilinear decomposition of SURVEY.md section 3.5 (a GEMM plus rank-1 terms
+instead of the tile/concat/linear materialisation of model_v2.py:230-249).
+Agreement of the two restatements is checked in tests/test_oracle_cross.py.
+
+Only `tests/`, `__graft_entry__.smoke()` and bench.py's `cpu_baseline` leg may
+import this module.  It is also the "port" timed as the CPU baseline.
+"""
+import torch
+
+VERY_NEGATIVE_NUMBER = -1e30
+
+
+# ---------------------------------------------------------------- helpers ---
+def exp_mask(val, mask):
+    """utils.py:210-213."""
+    return val + (1 - mask.to(val.dtype)) * VERY_NEGATIVE_NUMBER
+
+
+def softmax(logits):
+    """model_v2.py:23-28."""
+    return torch.softmax(logits, dim=-1)
+
+
+def softsel(target, logits):
+    """model_v2.py:39-48."""
+    return (softmax(logits).unsqueeze(-1) * target).sum(dim=-2)
+
+
+def linear(x, W, b, add_tanh=False):
+    """model_v2.py:75-100."""
+    out = x @ W + b
+    return torch.tanh(out) if add_tanh else out
+
+
+def split_att_W(W, w, simiMatrix, feat_order="v2"):
+    """Split att_logits/W [F,1] (model_v2.py:242-248) into the per-channel
+    vectors of the bilinear form x[t,j] = sum_c U[c] h q + (Rh.h + R2.h^2) +
+    (Cq.q + C2.q^2) + b.  Returns (U, Rh, R2) with Cq/C2 = the q-side twins."""
+    W = W.reshape(-1)
+    z = torch.zeros(w, dtype=W.dtype)
+    if simiMatrix == 1:      # [h, q, h*q]
+        Wh, Wq, Whq = W[:w], W[w:2 * w], W[2 * w:]
+        return Whq, Wh, z, Wq, z
+    if simiMatrix == 2:      # v2: [h*q, (h-q)^2]; model.py:149: [(h-q)^2, h*q]
+        W1, W2 = (W[:w], W[w:]) if feat_order == "v2" else (W[w:], W[:w])
+        return W1 - 2 * W2, z, W2, z, W2
+    if simiMatrix == 3:      # [h, q, (h-q)^2, h*q]
+        Wh, Wq, W2, Whq = W[:w], W[w:2 * w], W[2 * w:3 * w], W[3 * w:]
+        return Whq - 2 * W2, Wh, W2, Wq, W2
+    raise ValueError("similarity matrix not implemented")
+
+
+def simi_logits(h, q, W, b, simiMatrix, add_tanh, feat_order="v2"):
+    """h[..., T, w], q[..., JQ, w] (broadcastable lead dims) -> x[..., T, JQ]."""
+    w = h.shape[-1]
+    if simiMatrix == 4:      # model_v2.py:250-254, eps from tf.nn.l2_normalize
+        hn = h * torch.rsqrt(torch.clamp((h * h).sum(-1, keepdim=True), min=1e-12))
+        qn = q * torch.rsqrt(torch.clamp((q * q).sum(-1, keepdim=True), min=1e-12))
+        return hn @ qn.transpose(-1, -2)
+    U, Rh, R2, Cq, C2 = split_att_W(W, w, simiMatrix, feat_order)
+    x = (h * U) @ q.transpose(-1, -2)
+    x = x + (h @ Rh + (h * h) @ R2).unsqueeze(-1) + (q @ Cq + (q * q) @ C2).unsqueeze(-2) + b.reshape(())
+    return torch.tanh(x) if add_tanh else x
+
+
+def attention(hinfo, hq, W=None, b=None, hinfo_mask=None, hq_mask=None, simiMatrix=1,
+              add_tanh=False, bidirect=False, feat_order="v2"):
+    """model_v2.py:125-201 / model.py:117-186."""
+    N, w = hinfo.shape[0], hinfo.shape[-1]
+    h = hinfo.reshape(N, -1, w)
+    a = simi_logits(h, hq, W, b, simiMatrix, add_tanh, feat_order)       # [N,V,JQ]
+    if hinfo_mask is not None and hq_mask is not None:
+        mask = hinfo_mask.reshape(N, -1)[:, :, None] & hq_mask[:, None, :]
+        a = exp_mask(a, mask)
+    h_a = softsel(h, a.amax(dim=2))
+    if bidirect:
+        q_a = (softmax(a).unsqueeze(-1) * hq[:, None, :, :]).sum(-2).mean(1)
+        h_a = torch.cat([h_a, q_a], 1)
+    return h_a, a
+
+
+def attention_3d(hinfo, hq, W=None, b=None, hinfo_mask=None, hq_mask=None, simiMatrix=1,
+                 add_tanh=False, time_warp_att=False, C=None):
+    """model_v2.py:210-298."""
+    N, K, w = hinfo.shape[0], hinfo.shape[1], hinfo.shape[-1]
+    h = hinfo.reshape(N, K, -1, w)
+    a = simi_logits(h, hq[:, None], W, b, simiMatrix, add_tanh)          # [N,K,T,JQ]
+    if hinfo_mask is not None and hq_mask is not None:
+        mask = hinfo_mask.reshape(N, K, -1)[..., None] & hq_mask[:, None, None, :]
+        a = exp_mask(a, mask)
+    amax = a.amax(dim=3)
+    if time_warp_att:
+        amax = (amax.unsqueeze(-1) * C[:, None]).sum(-1)
+    u = softsel(h, amax)
+    s = a.amax(dim=(3, 2))
+    return softsel(u, s), a
+
+
+# --------------------------------------------------------------- encoders ---
+def lstm_direction(x, seq_len, kernel, bias, reverse):
+    """[TF-internal] dynamic_rnn over BasicLSTMCell with sequence_length
+    (SURVEY 3.6).  `reverse` runs on reverse_sequence(x) and un-reverses the
+    outputs.  x[B,J,in] -> out[B,J,d], h_final[B,d]."""
+    B, J, din = x.shape
+    d = kernel.shape[1] // 4
+    Wx, Wh = kernel[:din], kernel[din:]
+    ar = torch.arange(J)
+    if reverse:
+        idx = torch.where(ar[None, :] < seq_len[:, None], seq_len[:, None] - 1 - ar[None, :], ar[None, :])
+        x = torch.gather(x, 1, idx[:, :, None].expand(B, J, din))
+    zx = x @ Wx + bias
+    c = x.new_zeros(B, d)
+    h = x.new_zeros(B, d)
+    outs = []
+    for t in range(J):
+        z = zx[:, t] + h @ Wh
+        i, j, f, o = z.split(d, dim=1)
+        nc = c * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+        nh = torch.tanh(nc) * torch.sigmoid(o)
+        live = (t < seq_len)[:, None]
+        c = torch.where(live, nc, c)
+        h = torch.where(live, nh, h)
+        outs.append(torch.where(live, nh, torch.zeros_like(nh)))
+    out = torch.stack(outs, 1)
+    if reverse:
+        out = torch.gather(out, 1, idx[:, :, None].expand(B, J, d))
+    return out, h
+
+
+def encode_stream(x, mask, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None):
+    """model_v2.py:694-826 (one bidirectional_dynamic_rnn call + concats)."""
+    if kernel_bw is None:
+        kernel_bw, bias_bw = kernel_fw, bias_fw
+    lead = x.shape[:-2]
+    J, din = x.shape[-2], x.shape[-1]
+    xf = x.reshape(-1, J, din)
+    ln = mask.reshape(-1, J).to(torch.int64).sum(1)
+    of, hf = lstm_direction(xf, ln, kernel_fw, bias_fw, False)
+    ob, hb = lstm_direction(xf, ln, kernel_bw, bias_bw, True)
+    hcat = torch.cat([of, ob], 2)
+    last = torch.cat([hf, hb], 1)
+    return hcat.reshape(*lead, J, hcat.shape[-1]), last.reshape(*lead, last.shape[-1])
+
+
+def context_tensor(streams, masks):
+    """model_v2.py:863-914."""
+    JMAX = max(s.shape[2] for s in streams)
+    hs = [torch.nn.functional.pad(s, (0, 0, 0, JMAX - s.shape[2])) for s in streams]
+    ms = [torch.nn.functional.pad(m, (0, JMAX - m.shape[2])) for m in masks]
+    return torch.stack(hs, 1), torch.stack(ms, 1)
+
+
+def time_warp_closed(hall, lq, WH_W, WH_b, WC_W, WC_b, warp_type=1, window_t=3.0):
+    """Closed form of model_v2.py:953-1009: because hall_t1 and
+    hall_t2 are the same expression (:979-980) the feature is [h^2, 0] and
+    h'[n,k,t] = h[n,k,t] * c[n,t] * count(t)."""
+    import math
+    N, K, w = hall.shape[0], hall.shape[1], hall.shape[-1]
+    h = hall.reshape(N, K, -1, w)
+    T = h.shape[2]
+    WHv = (h * h) @ WH_W[:w] + WH_b + lq[:, None, None, :]
+    c = torch.tanh((WHv @ WC_W + WC_b)[..., 0].sum(1))                 # [N,T]
+    ar = torch.arange(T)
+    if warp_type == 1:
+        cnt = torch.full((T,), float(T))
+    elif warp_type == 2:
+        cnt = torch.ones(T)
+    elif warp_type == 3:
+        cnt = (ar + 1).to(torch.float32)
+    elif warp_type == 4:
+        cnt = (T - ar).to(torch.float32)
+    elif warp_type == 5:
+        win = int(math.ceil(window_t))
+        cnt = (torch.minimum(ar + win, torch.tensor(T - 1)) - torch.clamp(ar - win, min=0) + 1).to(torch.float32)
+    else:
+        raise Exception("time warping type not implemented")
+    scale = (c * cnt.to(c.dtype)[None, :])
+    return (h * scale[:, None, :, None]).reshape(hall.shape), c
+
+
+def scorer(gq, g1, gch, W, b, use_eu_output=False, add_tanh=False):
+    """model_v2.py:1061-1079."""
+    g1t = g1[:, None, :].expand_as(gch)
+    gqt = gq[:, None, :].expand_as(gch)
+    feats = [gqt, g1t, gch, g1t * gch, gqt * gch]
+    if use_eu_output:
+        feats += [(g1t - gch) ** 2, (gqt - gch) ** 2]
+    logits = linear(torch.cat(feats, 2), W, b, add_tanh=(add_tanh and use_eu_output))[..., 0]
+    return logits, torch.softmax(logits, -1)
+
+
+def softmax_cross_entropy_mean(logits, y):
+    """model_v2.py:1088-1090."""
+    return -(y.to(logits.dtype) * torch.log_softmax(logits, -1)).sum(1).mean()
+
+
+def attention_gru_cell(inputs, state, Wg, bg, Wc, Wi, bi):
+    """attention_gru_cell.py:50-70."""
+    d = state.shape[1]
+    x, g = inputs[:, :d], inputs[:, d:d + 1]
+    r = torch.sigmoid(torch.cat([x, state], 1) @ Wg + bg) * (state @ Wc)
+    return (1 - g) * state + g * torch.tanh(r + x @ Wi + bi)
+
+
+# ------------------------------------------------------------- whole path ---
+def fvta_forward(params, inputs, cfg):
+    """Same contract as oracle.fvta_literal.fvta_forward, on torch tensors."""
+    def cell(name):
+        return (params[name + "_kernel"], params[name + "_bias"],
+                params.get(name + "_kernel_bw"), params.get(name + "_bias_bw"))
+
+    hq, lq = encode_stream(inputs["q"]["x"], inputs["q"]["mask"], *cell("text"))
+    _, lch = encode_stream(inputs["choices"]["x"], inputs["choices"]["mask"], *cell("text"))
+    hs, ms = [], []
+    for st in inputs["ctx"]:
+        h, _ = encode_stream(st["x"], st["mask"], *cell(st.get("cell", "text")))
+        m = st["mask"]
+        if h.dim() == 5:
+            N, M = h.shape[:2]
+            h = h.reshape(N, M, -1, h.shape[-1])
+            m = m.reshape(N, M, -1)
+        hs.append(h)
+        ms.append(m)
+    hall, hall_mask = context_tensor(hs, ms)
+    out = {"hq": hq, "lq": lq, "lchoices": lch, "hall_pre_warp": hall, "hall_mask": hall_mask}
+    if cfg.get("use_time_warp", False):
+        hall, c = time_warp_closed(hall, lq, params["WH_W"], params["WH_b"], params["WC_W"], params["WC_b"],
+                                   cfg.get("warp_type", 1), float(params.get("window_t", 3.0)))
+        out["c_warp"] = c
+    out["hall"] = hall
+    qmask = inputs["q"]["mask"]
+    g1, att = attention_3d(hall, hq, params.get("att_W"), params.get("att_b"), hall_mask, qmask,
+                           simiMatrix=cfg["simiMatrix"], add_tanh=cfg.get("add_tanh", False))
+    out["g1_all"], out["att_logits"] = g1, att
+    if cfg.get("use_question_att", False):
+        N = hq.shape[0]
+        gq, qatt = attention(hq, g1[:, None, :], params.get("qatt_W"), params.get("qatt_b"), qmask,
+                             torch.ones(N, 1, dtype=torch.bool), simiMatrix=cfg["simiMatrix"],
+                             add_tanh=cfg.get("add_tanh", False))
+        out["q_att_logits"] = qatt
+    else:
+        gq = lq
+    out["gq"] = gq
+    logits, yp = scorer(gq, g1, lch, params["out_W"], params["out_b"],
+                        cfg.get("use_eu_output", False), cfg.get("add_tanh", False))
+    out["logits"], out["yp"] = logits, yp
+    if inputs.get("y") is not None:
+        out["loss"] = softmax_cross_entropy_mean(logits, inputs["y"])
+    return out

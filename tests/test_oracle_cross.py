@@ -1,0 +1,100 @@
+"""The two independent CPU restatements (literal NumPy vs fused torch) agree."""
+import numpy as np
+import pytest
+import torch
+
+from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params, to_dtype, to_numpy
+from oracle import fvta_fused as F
+from oracle import fvta_literal as L
+
+
+def _run_both(spec, cfg_over=None, extra_params=None):
+    params = to_dtype(make_params(spec), torch.float64)
+    inputs = to_dtype(make_inputs(spec), torch.float64)
+    if extra_params:
+        params.update(extra_params)
+    cfg = spec.cfg()
+    cfg.update(cfg_over or {})
+    of = F.fvta_forward(params, inputs, cfg)
+    ol = L.fvta_forward(to_numpy(params), to_numpy(inputs), cfg)
+    return of, ol
+
+
+@pytest.mark.parametrize("simi,tanh,qatt", [(1, False, False), (2, True, True), (3, True, True), (4, False, True)])
+@pytest.mark.parametrize("dense", [True, False])
+def test_forward_agree_fp64(simi, tanh, qatt, dense):
+    spec = SynthSpec(N=3, A=2, P=3, S=2, L=5, d=8, SA=1, dense=dense, simiMatrix=simi, add_tanh=tanh,
+                     use_question_att=qatt, text_in=12, img_in=8)
+    of, ol = _run_both(spec)
+    for k in ["hq", "lq", "lchoices", "hall", "g1_all", "att_logits", "gq", "logits", "yp", "loss"]:
+        a = of[k].detach().numpy()
+        b = np.asarray(ol[k])
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9, err_msg=k)
+    assert (of["yp"].argmax(1).numpy() == ol["yp"].argmax(1)).all()
+
+
+def test_forward_agree_unshared_bw():
+    spec = SynthSpec(N=2, A=1, P=3, S=1, L=4, d=8, dense=False, share_fw_bw=False, text_in=12, img_in=8)
+    of, ol = _run_both(spec)
+    np.testing.assert_allclose(of["loss"].item(), ol["loss"], rtol=1e-10)
+    np.testing.assert_allclose(of["hall"].numpy(), ol["hall"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("warp_type", [1, 2, 3, 4, 5])
+def test_time_warp_closed_form_matches_literal(warp_type):
+    spec = SynthSpec(N=2, A=1, P=2, S=1, L=3, d=4, dense=False, text_in=8, img_in=8)
+    g = torch.Generator().manual_seed(7)
+    w = spec.w
+    extra = dict(WH_W=torch.randn(2 * w, w, generator=g, dtype=torch.float64) * 0.1,
+                 WH_b=torch.randn(w, generator=g, dtype=torch.float64) * 0.1,
+                 WC_W=torch.randn(w, 1, generator=g, dtype=torch.float64) * 0.1,
+                 WC_b=torch.randn(1, generator=g, dtype=torch.float64) * 0.1,
+                 window_t=1.3)
+    of, ol = _run_both(spec, dict(use_time_warp=True, warp_type=warp_type), extra)
+    np.testing.assert_allclose(of["hall"].numpy(), ol["hall"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(of["yp"].numpy(), ol["yp"], rtol=1e-9)
+
+
+def test_plumbing_config_fp32_agree():
+    """BASELINE.json configs[0] shape, fp32 both sides: <=1e-5."""
+    from fvta_memexqa_amd.synth import CONFIGS
+    spec = SynthSpec(dense=False, **CONFIGS["plumbing"])
+    params, inputs = make_params(spec), make_inputs(spec)
+    of = F.fvta_forward(params, inputs, spec.cfg())
+    ol = L.fvta_forward(to_numpy(params), to_numpy(inputs), spec.cfg())
+    np.testing.assert_allclose(of["yp"].numpy(), ol["yp"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(of["g1_all"].numpy(), ol["g1_all"], rtol=1e-4, atol=1e-5)
+    assert (of["yp"].argmax(1).numpy() == ol["yp"].argmax(1)).all()
+
+
+def test_attention_v1_feature_order():
+    """model.py:149 orders simiMatrix-2 features [(h-q)^2, h*q]; model_v2.py:245 the reverse."""
+    g = torch.Generator().manual_seed(3)
+    h = torch.randn(2, 5, 6, generator=g, dtype=torch.float64)
+    q = torch.randn(2, 3, 6, generator=g, dtype=torch.float64)
+    W = torch.randn(12, 1, generator=g, dtype=torch.float64)
+    b = torch.randn(1, generator=g, dtype=torch.float64)
+    hm = torch.rand(2, 5, generator=g) > 0.3
+    qm = torch.rand(2, 3, generator=g) > 0.3
+    for order in ("v1", "v2"):
+        ha, a = F.attention(h, q, W, b, hm, qm, simiMatrix=2, feat_order=order, bidirect=True)
+        hb, bl = L.attention(h.numpy(), q.numpy(), W.numpy(), b.numpy(), hm.numpy(), qm.numpy(), simiMatrix=2,
+                             feat_order=order, bidirect=True)
+        np.testing.assert_allclose(ha.numpy(), hb, rtol=1e-10)
+        np.testing.assert_allclose(a.numpy(), bl, rtol=1e-10)
+    # unmasked call (model.py:850-851 style: masks not both given)
+    ha, _ = F.attention(h, q, W, b, hm, None, simiMatrix=2)
+    hb, _ = L.attention(h.numpy(), q.numpy(), W.numpy(), b.numpy(), hm.numpy(), None, simiMatrix=2)
+    np.testing.assert_allclose(ha.numpy(), hb, rtol=1e-10)
+
+
+def test_attention_gru_cell_agree():
+    g = torch.Generator().manual_seed(5)
+    d, B = 6, 4
+    args = [torch.randn(B, d + 1, generator=g, dtype=torch.float64), torch.randn(B, d, generator=g, dtype=torch.float64),
+            torch.randn(2 * d, d, generator=g, dtype=torch.float64), torch.randn(d, generator=g, dtype=torch.float64),
+            torch.randn(d, d, generator=g, dtype=torch.float64), torch.randn(d, d, generator=g, dtype=torch.float64),
+            torch.randn(d, generator=g, dtype=torch.float64)]
+    a = F.attention_gru_cell(*args).numpy()
+    b = L.attention_gru_cell(*[x.numpy() for x in args])
+    np.testing.assert_allclose(a, b, rtol=1e-12)
