@@ -1,0 +1,99 @@
+"""ctypes binding of libfvta_hip.so (the C ABI declared in include/fvta_hip.h).
+
+No fallback: if the shared library is missing or a call fails, this raises.
+PyTorch is used by the callers only to own device memory and streams; every
+pointer handed over here is a raw device address.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfvta_hip.so")
+
+F32, BF16 = 0, 1
+
+
+class FvtaError(RuntimeError):
+    pass
+
+
+class AttnDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ("N", "K", "T", "JQ", "w", "simi", "feat_order", "add_tanh")]
+
+
+class LstmDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ("B", "J", "in_", "d", "share_fw_bw", "precision", "training", "reserved")]
+
+
+class ScorerDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ("N", "C", "w", "use_eu_output", "add_tanh")]
+
+
+P = c_void_p
+_SIGS = {
+    "fvta_version": (c_int, []),
+    "fvta_last_error": (c_char_p, []),
+    "fvta_attn_workspace_bytes": (c_size_t, [POINTER(AttnDesc)]),
+    "fvta_attn_saved_bytes": (c_size_t, [POINTER(AttnDesc)]),
+    "fvta_attn_fwd": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_attn_bwd": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P]),
+    "fvta_lstm_plan_bytes": (c_size_t, [POINTER(LstmDesc)]),
+    "fvta_lstm_saved_bytes": (c_size_t, [POINTER(LstmDesc)]),
+    "fvta_lstm_workspace_bytes": (c_size_t, [POINTER(LstmDesc)]),
+    "fvta_lstm_plan": (c_int, [POINTER(LstmDesc), P, P, P, P, c_int64, P, P]),
+    "fvta_bilstm_fwd": (c_int, [POINTER(LstmDesc), P, P, P, P, P, P, P, P, P, P]),
+    "fvta_bilstm_bwd": (c_int, [POINTER(LstmDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_lstm_last_state": (c_int, [POINTER(LstmDesc), P, P, c_int32, c_int32, P, P]),
+    "fvta_lstm_last_state_bwd": (c_int, [POINTER(LstmDesc), P, P, c_int32, c_int32, P, P]),
+    "fvta_scorer_ce_fwd": (c_int, [POINTER(ScorerDesc), P, P, P, P, P, P, P, P, P, P]),
+    "fvta_scorer_ce_bwd": (c_int, [POINTER(ScorerDesc), P, P, P, P, P, P, P, P, c_float, P, P, P, P, P, P]),
+    "fvta_attgru_fwd": (c_int, [c_int32, c_int32, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_attgru_bwd": (c_int, [c_int32, c_int32, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_adadelta_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P]),
+    "fvta_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float, P]),
+    "fvta_test_gemm": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Every entry point include/fvta_hip.h declares."""
+    return sorted(_SIGS)
+
+
+def load():
+    """Load the library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FvtaError(
+            "%s not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C fvta_memexqa_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().fvta_last_error()
+        raise FvtaError("%s failed (%d): %s" % (what, status, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

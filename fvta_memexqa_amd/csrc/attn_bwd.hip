@@ -1,0 +1,457 @@
+// Focal attention backward for gfx950 (gradient of model_v2.py:210-298 / 125-201).
+//
+// Because the logits are max-pooled over the question axis (model_v2.py:268),
+// only ONE (t, j) pair per context row carries gradient, so the backward needs
+// no GEMM: it is a single streaming pass (read h row, write dh row) with
+//   dh[t]  = p[t] r[k] g  +  dx[t] (Qs[jmax[t]] + Rh + 2 R2 h[t])
+//   dQs[j] += dx[t] h[t]   for j = jmax[t]
+// A workgroup sorts its chunk of rows by jmax so that every thread can keep
+// the dQs accumulator of the "current j" in registers and flush it once per j
+// into a private slab (no atomics, bitwise reproducible).
+//
+// Deviation: gradient through reduce_max goes to the FIRST arg-max
+// (TF splits exact ties) and fully masked (n,k) rows pass no gradient into the
+// masked logits.
+#include "attn_common.h"
+
+namespace fvta {
+
+__device__ __forceinline__ f32x4 ld4b(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+constexpr int BWD_CHMAX = 1024;  // rows per backward workgroup chunk (LDS sort capacity)
+
+struct AttnBwdWork {
+  float* coef;   // [N,K]  r / L
+  float* gu;     // [N,K]  g . u[k]
+  float* dss;    // [N,K]  ds[k] / (#t with amax == M)
+  float* slabs;  // [N*K][bsplit][RH][JP][w]   dQs partials
+  float* dctp;   // [N*K][bsplit][RH][JP]      d ct partials
+  float* rowp;   // [N*K][bsplit][RH][2][w]    d Rh, d R2 partials
+  float* pvec;   // [N][5][w]                  per-n parameter-vector partials
+  float* dctn;   // [N][JP]
+  size_t bytes;
+  size_t slab_bytes;
+};
+
+static inline int bwd_tpr(int W4) { return W4 < 256 ? W4 : 256; }
+static inline int bwd_rh(int W4) { return 256 / bwd_tpr(W4); }
+
+static AttnBwdWork bwd_work_view(const AttnShape& s, void* p) {
+  FvtaCarver c(p);
+  AttnBwdWork v;
+  const size_t nk = (size_t)s.N * s.K;
+  const int RH = bwd_rh(s.W4);
+  v.coef = c.take<float>(nk);
+  v.gu = c.take<float>(nk);
+  v.dss = c.take<float>(nk);
+  v.pvec = c.take<float>((size_t)s.N * VEC_COUNT * s.w);
+  v.dctn = c.take<float>((size_t)s.N * s.JP);
+  const size_t before = c.off;
+  v.slabs = c.take<float>(nk * s.bsplit * RH * s.JP * s.w);
+  v.dctp = c.take<float>(nk * s.bsplit * RH * s.JP);
+  v.rowp = c.take<float>(nk * s.bsplit * RH * 2 * s.w);
+  v.slab_bytes = c.off - before;
+  v.bytes = c.off;
+  return v;
+}
+
+// ---- per-(n,k) scalars.  grid N, 256 threads
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnShape s, AttnSaved sv, AttnBwdWork wk,
+                                                            const float* __restrict__ d_h_a) {
+  __shared__ float s_red[4];
+  __shared__ float s_gu[64];
+  __shared__ int s_ties[64];
+  __shared__ int s_ired[4];
+  const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int w = s.w, K = s.K, T = s.T;
+  const float* g = d_h_a + (size_t)n * w;
+  for (int k = 0; k < K; ++k) {
+    const float* u = sv.u + ((size_t)n * K + k) * w;
+    float acc = 0.f;
+    for (int c = tid; c < w; c += 256) acc += g[c] * u[c];
+    acc = wave_sum(acc);
+    const float M = sv.M[n * K + k];
+    const float* am = sv.amax + ((size_t)n * K + k) * T;
+    int ties = 0;
+    for (int t = tid; t < T; t += 256) ties += (am[t] == M) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ties += __shfl_xor(ties, o, 64);
+    __syncthreads();
+    if (lane == 0) {
+      s_red[wave] = acc;
+      s_ired[wave] = ties;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      s_gu[k] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+      s_ties[k] = s_ired[0] + s_ired[1] + s_ired[2] + s_ired[3];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mean = 0.f;
+    for (int k = 0; k < K; ++k) mean += sv.r[n * K + k] * s_gu[k];
+    for (int k = 0; k < K; ++k) {
+      const float r = sv.r[n * K + k];
+      wk.coef[n * K + k] = r / sv.L[n * K + k];
+      wk.gu[n * K + k] = s_gu[k];
+      const float ds = r * (s_gu[k] - mean);
+      wk.dss[n * K + k] = sv.allmasked[n * K + k] ? 0.f : ds / (float)max(1, s_ties[k]);
+    }
+  }
+}
+
+struct AttnBwdArgs {
+  AttnShape s;
+  AttnSaved sv;
+  AttnBwdWork wk;
+  const float* hinfo;
+  const float* d_h_a;
+  float* d_hinfo;
+  int accumulate;
+};
+
+// TPR threads cover one row (16 B each, G float4 per thread when w > 1024);
+// RH = 256/TPR row groups; a tile is TR rows, each thread holds TR/RH of them.
+template <int TPR, int G, int TR>
+__global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
+  constexpr int RH = 256 / TPR;
+  constexpr int RPT = TR / RH;
+  constexpr int WPR = TPR >= 64 ? TPR / 64 : 1;  // waves that share a row
+  __shared__ int s_rows[BWD_CHMAX];
+  __shared__ uint8_t s_j[BWD_CHMAX];
+  __shared__ int s_hist[4][65];
+  __shared__ float s_dot[4][TR];
+  __shared__ float s_pr[TR], s_dx[TR];
+  __shared__ int s_tt[TR], s_jj[TR];
+
+  const AttnShape& s = a.s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int cq = tid % TPR, rh = tid / TPR;
+  const int nk = blockIdx.y, n = nk / s.K, split = blockIdx.x;
+  const int T = s.T, w = s.w, JP = s.JP;
+  const int cnt = a.sv.cnt[nk];
+  const bool allm = a.sv.allmasked[nk] != 0;
+  int chunk = (cnt + s.bsplit - 1) / s.bsplit;
+  chunk = (chunk + TR - 1) / TR * TR;
+  const int r0 = split * chunk, r1 = min(cnt, r0 + chunk);
+  if (r0 >= r1) return;  // slabs were zeroed by the launcher
+  const int nrows = r1 - r0;
+  const int32_t* __restrict__ idx = a.sv.idx + (size_t)nk * T;
+  const float* __restrict__ amax = a.sv.amax + (size_t)nk * T;
+  const uint8_t* __restrict__ jmax = a.sv.jmax + (size_t)nk * T;
+
+  // ---- stable counting sort of the chunk's rows by jmax (4 waves, contiguous quarters)
+  for (int i = tid; i < 4 * 65; i += 256) (&s_hist[0][0])[i] = 0;
+  __syncthreads();
+  const int q = (nrows + 3) / 4;
+  const int b0 = wave * q, b1 = min(nrows, b0 + q);
+  for (int base = b0; base < b1; base += 64) {
+    const int i = base + lane;
+    const bool ok = i < b1;
+    const int key = ok ? (int)jmax[idx[r0 + i]] : -1;
+    unsigned long long todo = __ballot(ok);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int kv = __shfl(key, leader, 64);
+      const unsigned long long same = __ballot(ok && key == kv);
+      if (lane == leader) s_hist[wave][kv] += __popcll(same);
+      todo &= ~same;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int k = 0; k < 64; ++k)
+      for (int wv = 0; wv < 4; ++wv) {
+        const int c = s_hist[wv][k];
+        s_hist[wv][k] = run;
+        run += c;
+      }
+  }
+  __syncthreads();
+  for (int base = b0; base < b1; base += 64) {
+    const int i = base + lane;
+    const bool ok = i < b1;
+    const int t = ok ? idx[r0 + i] : 0;
+    const int key = ok ? (int)jmax[t] : -1;
+    unsigned long long todo = __ballot(ok);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int kv = __shfl(key, leader, 64);
+      const unsigned long long same = __ballot(ok && key == kv);
+      const int basepos = s_hist[wave][kv];
+      if (ok && key == kv) {
+        const int pos = basepos + __popcll(same & ((1ull << lane) - 1ull));
+        s_rows[pos] = t;
+        s_j[pos] = (uint8_t)kv;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane == leader) s_hist[wave][kv] = basepos + __popcll(same);
+      __builtin_amdgcn_wave_barrier();
+      todo &= ~same;
+    }
+  }
+  __syncthreads();
+
+  const float* __restrict__ hbase = a.hinfo + (size_t)nk * T * w;
+  float* __restrict__ dhbase = a.d_hinfo + (size_t)nk * T * w;
+  const float* __restrict__ Qs = a.sv.Qs + (size_t)n * s.W4 * JP * 4;
+  const float M = a.sv.M[nk];
+  const float coef = a.wk.coef[nk], gu = a.wk.gu[nk], dss = a.wk.dss[nk];
+  const size_t slot = ((size_t)nk * s.bsplit + split) * RH + rh;
+  float* __restrict__ slab = a.wk.slabs + slot * JP * w;
+  float* __restrict__ dctp = a.wk.dctp + slot * JP;
+  float* __restrict__ rowp = a.wk.rowp + slot * 2 * w;
+
+  f32x4 gv[G], rh4[G], r24[G], accq[G], accRh[G], accR2[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int c4 = cq + g * TPR;
+    gv[g] = ld4b(a.d_h_a + (size_t)n * w + 4 * c4);
+    rh4[g] = ld4b(a.sv.vecs + VEC_RH * w + 4 * c4);
+    r24[g] = ld4b(a.sv.vecs + VEC_R2 * w + 4 * c4);
+    accq[g] = accRh[g] = accR2[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  int cur_j = -1;
+  float acc_ct = 0.f;
+  auto flush = [&]() {
+    if (cur_j >= 0) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        *reinterpret_cast<f32x4*>(slab + (size_t)cur_j * w + 4 * (cq + g * TPR)) = accq[g];
+        accq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (cq == 0) dctp[cur_j] = acc_ct;
+      acc_ct = 0.f;
+    }
+  };
+
+  f32x4 hreg[RPT][G];
+  for (int tb = 0; tb < nrows; tb += TR) {
+    __syncthreads();
+    if (tid < TR) {
+      const int i = tb + tid;
+      s_tt[tid] = i < nrows ? s_rows[i] : -1;
+      s_jj[tid] = i < nrows ? (int)s_j[i] : 0;
+    }
+    __syncthreads();
+    float dot[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int t = s_tt[rh * RPT + i];
+      float dsum = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        hreg[i][g] = t >= 0 ? ld4b(hbase + (size_t)t * w + 4 * (cq + g * TPR)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 pdt = hreg[i][g] * gv[g];
+        dsum += (pdt[0] + pdt[1]) + (pdt[2] + pdt[3]);
+      }
+      dot[i] = dsum;
+    }
+    // reduce g.h over the TPR threads of each row
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      float v = dot[i];
+#pragma unroll
+      for (int o = 1; o < (TPR < 64 ? TPR : 64); o <<= 1) v += __shfl_xor(v, o, 64);
+      dot[i] = v;
+    }
+    if (TPR >= 64) {
+      if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) s_dot[wave][rh * RPT + i] = dot[i];
+    } else {
+      if (cq == 0)
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) s_dot[0][rh * RPT + i] = dot[i];
+    }
+    __syncthreads();
+    if (tid < TR) {
+      const int t = s_tt[tid];
+      float pr = 0.f, dx = 0.f;
+      if (t >= 0) {
+        float gh;
+        if (TPR >= 64) {
+          // row `tid` belongs to row group tid / RPT whose waves are [rg*WPR, rg*WPR + WPR)
+          const int rgp = tid / RPT;
+          gh = 0.f;
+#pragma unroll
+          for (int v = 0; v < WPR; ++v) gh += s_dot[rgp * WPR + v][tid];
+        } else {
+          gh = s_dot[0][tid];
+        }
+        const float am = amax[t];
+        pr = expf(am - M) * coef;
+        float damax = pr * (gh - gu) + (am == M ? dss : 0.f);
+        if (allm) damax = 0.f;
+        dx = s.add_tanh ? damax * (1.f - am * am) : damax;
+      }
+      s_pr[tid] = pr;
+      s_dx[tid] = dx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int row = rh * RPT + i;
+      const int t = s_tt[row];
+      if (t < 0) continue;
+      const int j = s_jj[row];
+      const float pr = s_pr[row], dx = s_dx[row];
+      if (j != cur_j) {
+        flush();
+        cur_j = j;
+      }
+      acc_ct += dx;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int c4 = cq + g * TPR;
+        const f32x4 h = hreg[i][g];
+        const f32x4 qs = ld4b(Qs + ((size_t)c4 * JP + j) * 4);
+        f32x4 dh = gv[g] * pr + (qs + rh4[g] + r24[g] * h * 2.f) * dx;
+        float* dst = dhbase + (size_t)t * w + 4 * c4;
+        if (a.accumulate) dh += ld4b(dst);
+        *reinterpret_cast<f32x4*>(dst) = dh;
+        accq[g] += h * dx;
+        accRh[g] += h * dx;
+        accR2[g] += h * h * dx;
+      }
+    }
+  }
+  flush();
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    *reinterpret_cast<f32x4*>(rowp + 4 * (cq + g * TPR)) = accRh[g];
+    *reinterpret_cast<f32x4*>(rowp + w + 4 * (cq + g * TPR)) = accR2[g];
+  }
+}
+
+// ---- fold slabs per n: d_hq and per-n parameter partials.  grid (N, ceil(w/256))
+__global__ __launch_bounds__(256) void attn_bwd_reduce_q_kernel(AttnShape s, AttnSaved sv, AttnBwdWork wk, int RH,
+                                                                const float* __restrict__ hq,
+                                                                float* __restrict__ d_hq, int accumulate) {
+  __shared__ float s_dct[64];
+  const int n = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  const int w = s.w, K = s.K, JP = s.JP, JQ = s.JQ;
+  const int nslot = K * s.bsplit * RH;
+  const size_t slot0 = (size_t)n * nslot;
+  if (threadIdx.x < JP) {
+    float acc = 0.f;
+    for (int sl = 0; sl < nslot; ++sl) acc += wk.dctp[(slot0 + sl) * JP + threadIdx.x];
+    s_dct[threadIdx.x] = acc;
+    if (blockIdx.y == 0) wk.dctn[(size_t)n * JP + threadIdx.x] = acc;
+  }
+  __syncthreads();
+  if (c >= w) return;
+  const float U = sv.vecs[VEC_U * w + c], Cq = sv.vecs[VEC_CQ * w + c], C2 = sv.vecs[VEC_C2 * w + c];
+  float pU = 0.f, pCq = 0.f, pC2 = 0.f;
+  for (int j = 0; j < JQ; ++j) {
+    float dQ = 0.f;
+    for (int sl = 0; sl < nslot; ++sl) dQ += wk.slabs[((slot0 + sl) * JP + j) * w + c];
+    const float qv = hq[((size_t)n * JQ + j) * w + c];
+    const float dct = s_dct[j];
+    const float dq = U * dQ + dct * (Cq + 2.f * C2 * qv);
+    float* dst = d_hq + ((size_t)n * JQ + j) * w + c;
+    *dst = accumulate ? *dst + dq : dq;
+    pU += dQ * qv;
+    pCq += dct * qv;
+    pC2 += dct * qv * qv;
+  }
+  float pRh = 0.f, pR2 = 0.f;
+  for (int sl = 0; sl < nslot; ++sl) {
+    pRh += wk.rowp[(slot0 + sl) * 2 * w + c];
+    pR2 += wk.rowp[(slot0 + sl) * 2 * w + w + c];
+  }
+  float* pv = wk.pvec + (size_t)n * VEC_COUNT * w;
+  pv[VEC_U * w + c] = pU;
+  pv[VEC_RH * w + c] = pRh;
+  pv[VEC_R2 * w + c] = pR2;
+  pv[VEC_CQ * w + c] = pCq;
+  pv[VEC_C2 * w + c] = pC2;
+}
+
+// ---- sum over n, map back to att_logits/W's layout.  grid ceil(w/256)
+__global__ __launch_bounds__(256) void attn_bwd_params_kernel(AttnShape s, AttnBwdWork wk, float* __restrict__ dW,
+                                                              float* __restrict__ db) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int w = s.w;
+  if (c < w) {
+    float v[VEC_COUNT] = {0, 0, 0, 0, 0};
+    for (int n = 0; n < s.N; ++n)
+#pragma unroll
+      for (int k = 0; k < VEC_COUNT; ++k) v[k] += wk.pvec[((size_t)n * VEC_COUNT + k) * w + c];
+    const float dU = v[VEC_U], dRh = v[VEC_RH], dR2 = v[VEC_R2], dCq = v[VEC_CQ], dC2 = v[VEC_C2];
+    if (s.simi == 1) {
+      dW[c] += dRh;
+      dW[w + c] += dCq;
+      dW[2 * w + c] += dU;
+    } else if (s.simi == 2) {
+      const float d1 = dU, d2 = -2.f * dU + dR2 + dC2;
+      dW[c] += s.feat_order == 0 ? d1 : d2;
+      dW[w + c] += s.feat_order == 0 ? d2 : d1;
+    } else if (s.simi == 3) {
+      dW[c] += dRh;
+      dW[w + c] += dCq;
+      dW[2 * w + c] += -2.f * dU + dR2 + dC2;
+      dW[3 * w + c] += dU;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float acc = 0.f;
+    for (int i = 0; i < s.N * s.JP; ++i) acc += wk.dctn[i];
+    db[0] += acc;
+  }
+}
+
+}  // namespace fvta
+
+using namespace fvta;
+
+size_t fvta_attn_bwd_workspace_bytes(const AttnShape& s) { return bwd_work_view(s, nullptr).bytes; }
+int fvta_attn_check_desc(const fvta_attn_desc* d);  // attn_fwd.hip
+
+extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const float* hq, const uint8_t* hmask,
+                             const uint8_t* qmask, const float* W, const float* b, const float* d_h_a,
+                             const void* saved, float* d_hinfo, float* d_hq, float* dW, float* db, int accumulate,
+                             void* workspace, fvta_stream_t stream_) {
+  if (int e = fvta_attn_check_desc(d)) return e;
+  FVTA_CHECK_ARG(hinfo && hq && d_h_a && saved && d_hinfo && d_hq && workspace, "attn_bwd: null pointer");
+  if (d->simi == 4) {
+    fvta_set_error("attn_bwd: simiMatrix 4 (cosine) backward is not built; forward only");
+    return FVTA_ERR_UNSUPPORTED;
+  }
+  FVTA_CHECK_ARG(dW && db, "attn_bwd: dW/db required");
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool use_mask = hmask && qmask;
+  const AttnShape s = attn_shape(d, use_mask);
+  AttnSaved sv = attn_saved_view(s, const_cast<void*>(saved));
+  AttnBwdWork wk = bwd_work_view(s, workspace);
+  const int RH = bwd_rh(s.W4);
+  FVTA_CHECK_HIP(hipMemsetAsync(wk.slabs, 0, wk.slab_bytes, stream));
+  if (!accumulate)
+    FVTA_CHECK_HIP(hipMemsetAsync(d_hinfo, 0, (size_t)s.N * s.K * s.T * s.w * sizeof(float), stream));
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(s.N), dim3(256), 0, stream, s, sv, wk, d_h_a);
+  AttnBwdArgs a;
+  a.s = s;
+  a.sv = sv;
+  a.wk = wk;
+  a.hinfo = hinfo;
+  a.d_h_a = d_h_a;
+  a.d_hinfo = d_hinfo;
+  a.accumulate = accumulate;
+  const dim3 grid(s.bsplit, s.N * s.K);
+  switch (s.w) {
+    case 64: hipLaunchKernelGGL((attn_bwd_main<16, 1, 32>), grid, dim3(256), 0, stream, a); break;
+    case 128: hipLaunchKernelGGL((attn_bwd_main<32, 1, 32>), grid, dim3(256), 0, stream, a); break;
+    case 256: hipLaunchKernelGGL((attn_bwd_main<64, 1, 32>), grid, dim3(256), 0, stream, a); break;
+    case 512: hipLaunchKernelGGL((attn_bwd_main<128, 1, 32>), grid, dim3(256), 0, stream, a); break;
+    case 1024: hipLaunchKernelGGL((attn_bwd_main<256, 1, 32>), grid, dim3(256), 0, stream, a); break;
+    case 2048: hipLaunchKernelGGL((attn_bwd_main<256, 2, 16>), grid, dim3(256), 0, stream, a); break;
+  }
+  FVTA_CHECK_LAUNCH("attn_bwd_main");
+  hipLaunchKernelGGL(attn_bwd_reduce_q_kernel, dim3(s.N, (s.w + 255) / 256), dim3(256), 0, stream, s, sv, wk, RH, hq,
+                     d_hq, accumulate);
+  hipLaunchKernelGGL(attn_bwd_params_kernel, dim3((s.w + 255) / 256), dim3(256), 0, stream, s, wk, dW, db);
+  FVTA_CHECK_LAUNCH("attn_bwd_reduce");
+  return FVTA_OK;
+}

@@ -1,0 +1,85 @@
+// Shared layout of the focal-attention kernels (forward + backward).
+#pragma once
+#include "fvta_common.h"
+
+namespace fvta {
+
+// Bilinear form of the similarity logits:
+//   x[t,j] = rs[t] * sum_c h[t,c] * Qs[j,c]  +  (Rh.h[t] + R2.h[t]^2)  +  ct[j]
+// with Qs[j,c] = U[c] q[j,c] (simi 1-3) or q[j,c]/|q[j]| (simi 4, rs = 1/|h|),
+// ct[j] = Cq.q[j] + C2.q[j]^2 + b.
+struct AttnShape {
+  int N, K, T, JQ, w;
+  int simi, feat_order, add_tanh, use_mask;
+  int W4;      // w / 4
+  int JT;      // 32-wide column tiles covering JQ
+  int JP;      // 32 * JT
+  int nsplit;  // workgroups per (n,k) in the forward main kernel
+  int bsplit;  // workgroups per (n,k) in the backward main kernel
+};
+
+inline AttnShape attn_shape(const fvta_attn_desc* d, bool use_mask) {
+  AttnShape s;
+  s.N = d->N; s.K = d->K; s.T = d->T; s.JQ = d->JQ; s.w = d->w;
+  s.simi = d->simi; s.feat_order = d->feat_order; s.add_tanh = d->add_tanh;
+  s.use_mask = use_mask ? 1 : 0;
+  s.W4 = d->w / 4;
+  s.JT = (d->JQ + 31) / 32;
+  s.JP = 32 * s.JT;
+  const int nk = d->N * d->K;
+  int ns = (3072 + nk - 1) / nk;
+  const int maxs = (d->T + 63) / 64;
+  if (ns > maxs) ns = maxs;
+  if (ns < 1) ns = 1;
+  s.nsplit = ns;
+  int bs = (1024 + nk - 1) / nk;
+  const int maxb = (d->T + 255) / 256;
+  if (bs > maxb) bs = maxb;
+  if (bs < 1) bs = 1;
+  s.bsplit = bs;
+  return s;
+}
+
+// per-channel vectors of the bilinear form, float [5][w]: U, Rh, R2, Cq, C2
+enum { VEC_U = 0, VEC_RH = 1, VEC_R2 = 2, VEC_CQ = 3, VEC_C2 = 4, VEC_COUNT = 5 };
+
+// "saved" buffer: forward state the backward needs (all device side)
+struct AttnSaved {
+  float* amax;     // [N,K,T] max_j of the masked (tanh'd) logits  (= a_logits_maxed, model_v2.py:268)
+  uint8_t* jmax;   // [N,K,T] first arg-max j
+  int32_t* idx;    // [N,K,T] compacted valid row list (identity when the row is fully masked)
+  int32_t* cnt;    // [N,K] rows in the list
+  int32_t* allmasked;  // [N,K] 1: no valid (t,j) pair -> softmax goes uniform over all T
+  float* M;        // [N,K] max_t amax  (= reduce_max [3,2], model_v2.py:278)
+  float* L;        // [N,K] sum_t exp(amax - M)
+  float* r;        // [N,K] softmax_k(M)
+  float* u;        // [N,K,w] inner softsel result
+  float* Qs;       // [N][W4][JP][4] pre-scaled question, MFMA-B friendly
+  float* ct;       // [N][JP]
+  float* vecs;     // [5][w]
+  uint64_t* qvalid;  // [N][JT<=2 -> 2] valid-j bit masks
+  size_t bytes;
+};
+
+inline AttnSaved attn_saved_view(const AttnShape& s, void* p) {
+  FvtaCarver c(p);
+  AttnSaved v;
+  const size_t nkt = (size_t)s.N * s.K * s.T, nk = (size_t)s.N * s.K;
+  v.amax = c.take<float>(nkt);
+  v.jmax = c.take<uint8_t>(nkt);
+  v.idx = c.take<int32_t>(nkt);
+  v.cnt = c.take<int32_t>(nk);
+  v.allmasked = c.take<int32_t>(nk);
+  v.M = c.take<float>(nk);
+  v.L = c.take<float>(nk);
+  v.r = c.take<float>(nk);
+  v.u = c.take<float>(nk * s.w);
+  v.Qs = c.take<float>((size_t)s.N * s.W4 * s.JP * 4);
+  v.ct = c.take<float>((size_t)s.N * s.JP);
+  v.vecs = c.take<float>((size_t)VEC_COUNT * s.w);
+  v.qvalid = c.take<uint64_t>((size_t)s.N * 2);
+  v.bytes = c.off;
+  return v;
+}
+
+}  // namespace fvta

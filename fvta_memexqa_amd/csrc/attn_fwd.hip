@@ -1,0 +1,505 @@
+// Focal attention forward for gfx950: model_v2.py:210-298 (attention_3d) and
+// 125-201 (attention, K = 1).
+//
+// The reference materialises tile(h) / tile(q) / concat as [N,K,T,JQ,2w] and
+// runs a 1-column matmul over it.  Here the logits are the bilinear form of
+// SURVEY.md 3.5, so one workgroup streams 32 context rows at a time ONCE from
+// HBM into registers, stages them through LDS as the A operand of an exact-fp32
+// MFMA (v_mfma_f32_32x32x2_f32) against the pre-scaled question (B operand
+// straight from L2), takes max_j, and folds the rows into an online softmax /
+// weighted-sum accumulator from the same registers.  Masked rows are never read.
+#include "attn_common.h"
+
+namespace fvta {
+
+__device__ __forceinline__ f32x4 ld4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// ---- per-channel vectors from att_logits/W (model_v2.py:242-248, model.py:146-151)
+__global__ void attn_vecs_kernel(const float* __restrict__ W, int w, int simi, int feat_order,
+                                 float* __restrict__ vecs) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= w) return;
+  float U = 0, Rh = 0, R2 = 0, Cq = 0, C2 = 0;
+  if (simi == 1) {  // [h, q, h*q]
+    Rh = W[c]; Cq = W[w + c]; U = W[2 * w + c];
+  } else if (simi == 2) {  // v2: [h*q, (h-q)^2]; model.py: [(h-q)^2, h*q]
+    const float W1 = feat_order == 0 ? W[c] : W[w + c];
+    const float W2 = feat_order == 0 ? W[w + c] : W[c];
+    U = W1 - 2.f * W2; R2 = W2; C2 = W2;
+  } else if (simi == 3) {  // [h, q, (h-q)^2, h*q]
+    Rh = W[c]; Cq = W[w + c];
+    const float W2 = W[2 * w + c];
+    U = W[3 * w + c] - 2.f * W2; R2 = W2; C2 = W2;
+  } else {  // cosine: row "term" slot carries sum h^2 for the norm
+    U = 1.f; R2 = 1.f;
+  }
+  vecs[VEC_U * w + c] = U;
+  vecs[VEC_RH * w + c] = Rh;
+  vecs[VEC_R2 * w + c] = R2;
+  vecs[VEC_CQ * w + c] = Cq;
+  vecs[VEC_C2 * w + c] = C2;
+}
+
+// ---- question side: Qs [N][W4][JP][4], ct [N][JP], valid-j bits.  grid N, 256 threads
+__global__ __launch_bounds__(256) void attn_prep_q_kernel(AttnShape s, AttnSaved sv, const float* __restrict__ hq,
+                                                          const uint8_t* __restrict__ qmask,
+                                                          const float* __restrict__ bptr) {
+  __shared__ float s_rq[64];
+  const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int w = s.w;
+  const float* q = hq + (size_t)n * s.JQ * w;
+  const float* Uv = sv.vecs + VEC_U * w;
+  const float* Cq = sv.vecs + VEC_CQ * w;
+  const float* C2 = sv.vecs + VEC_C2 * w;
+  const float bias = (s.simi == 4 || bptr == nullptr) ? 0.f : bptr[0];
+  for (int j = wave; j < s.JP; j += 4) {
+    float s1 = 0.f, s2 = 0.f;
+    if (j < s.JQ)
+      for (int c = lane; c < w; c += 64) {
+        const float v = q[(size_t)j * w + c];
+        s1 += Cq[c] * v + C2[c] * v * v;
+        s2 += v * v;
+      }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+      sv.ct[(size_t)n * s.JP + j] = (j < s.JQ && s.simi != 4) ? s1 + bias : 0.f;
+      s_rq[j] = rsqrtf(fmaxf(s2, 1e-12f));  // tf.nn.l2_normalize eps
+    }
+  }
+  if (tid == 0) {
+    uint64_t bits = 0;
+    for (int j = 0; j < s.JQ; ++j)
+      if (!s.use_mask || qmask[(size_t)n * s.JQ + j]) bits |= (1ull << j);
+    sv.qvalid[(size_t)n * 2] = bits;
+  }
+  __syncthreads();
+  float* Qs = sv.Qs + (size_t)n * s.W4 * s.JP * 4;
+  for (int u = tid; u < s.W4 * s.JP; u += 256) {
+    const int c4 = u / s.JP, j = u % s.JP;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (j < s.JQ) {
+      const f32x4 qv = ld4g(q + (size_t)j * w + 4 * c4);
+      if (s.simi == 4) {
+        o = qv * s_rq[j];
+      } else {
+        const f32x4 uv = ld4g(Uv + 4 * c4);
+        o = qv * uv;
+      }
+    }
+    *reinterpret_cast<f32x4*>(Qs + (size_t)u * 4) = o;
+  }
+}
+
+// ---- valid-row lists.  grid N*K, 256 threads.  Also resets amax/jmax of every t.
+__global__ __launch_bounds__(256) void attn_compact_kernel(AttnShape s, AttnSaved sv,
+                                                           const uint8_t* __restrict__ hmask) {
+  __shared__ int s_wcnt[4];
+  __shared__ int s_base;
+  const int nk = blockIdx.x, n = nk / s.K, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int T = s.T;
+  int32_t* idx = sv.idx + (size_t)nk * T;
+  float* amax = sv.amax + (size_t)nk * T;
+  uint8_t* jmax = sv.jmax + (size_t)nk * T;
+  const bool qany = sv.qvalid[(size_t)n * 2] != 0;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += 256) {
+    const int t = t0 + tid;
+    bool valid = false;
+    if (t < T) {
+      valid = s.use_mask ? (hmask[(size_t)nk * T + t] != 0) : true;
+      amax[t] = FVTA_NEG;
+      jmax[t] = 0;
+    }
+    const unsigned long long b = __ballot(valid);
+    if (lane == 0) s_wcnt[wave] = __popcll(b);
+    __syncthreads();
+    int off = s_base;
+    for (int v = 0; v < wave; ++v) off += s_wcnt[v];
+    if (valid) idx[off + __popcll(b & ((1ull << lane) - 1ull))] = t;
+    __syncthreads();
+    if (tid == 0) s_base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    __syncthreads();
+  }
+  const int cnt = s_base;
+  const bool allm = s.use_mask && (cnt == 0 || !qany);
+  if (allm)
+    for (int t = tid; t < T; t += 256) idx[t] = t;  // softmax goes uniform over ALL T
+  if (tid == 0) {
+    sv.cnt[nk] = allm ? T : cnt;
+    sv.allmasked[nk] = allm ? 1 : 0;
+  }
+}
+
+__global__ void fill_kernel(float* __restrict__ p, size_t n, float v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// ---- main kernel -----------------------------------------------------------
+struct AttnFwdArgs {
+  AttnShape s;
+  AttnSaved sv;
+  const float* hinfo;
+  float* a_logits;  // may be null
+  float* part;      // [N*K][nsplit][w+4] : m, l, -, -, u[w]
+};
+
+// w = 16 * SCW * NSC * NSLAB.  A wave owns NSC sub-chunks of SCW float4 columns
+// per slab; lane = (c4l = lane % SCW, rg = lane / SCW) holds rows rg + RGN*p.
+template <int SCW, int NSC, int NSLAB, int JT>
+__global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
+  constexpr int RGN = 64 / SCW;
+  constexpr int P = 32 / RGN;
+  constexpr int LDW = 4 * SCW + 4;
+  constexpr int SLAB4 = 4 * NSC * SCW;
+  __shared__ __attribute__((aligned(16))) float s_stage[4][32 * LDW];
+  __shared__ __attribute__((aligned(16))) float s_part[4][JT][1024];
+  __shared__ float s_rt[4][32];
+  __shared__ int s_t[32];
+  __shared__ float s_amax[32];
+  __shared__ float s_p[32];
+
+  const AttnShape& s = a.s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int c4l = lane % SCW, rg = lane / SCW;
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int nk = blockIdx.y, n = nk / s.K, split = blockIdx.x;
+  const int T = s.T, w = s.w, JP = s.JP;
+  const int cnt = a.sv.cnt[nk];
+  const bool allm = a.sv.allmasked[nk] != 0;
+  const int tiles_total = (cnt + 31) >> 5;
+  const int tiles_per = (tiles_total + s.nsplit - 1) / s.nsplit;
+  const int tile0 = split * tiles_per, tile1 = min(tiles_total, tile0 + tiles_per);
+  float* part = a.part + ((size_t)nk * s.nsplit + split) * (w + 4);
+  if (tile0 >= tile1) {
+    if (tid == 0) {
+      part[0] = -INFINITY;
+      part[1] = 0.f;
+    }
+    return;
+  }
+  const float* __restrict__ hbase = a.hinfo + (size_t)nk * T * w;
+  const int32_t* __restrict__ idx = a.sv.idx + (size_t)nk * T;
+  const float* __restrict__ Qs = a.sv.Qs + (size_t)n * s.W4 * JP * 4;
+  const float* __restrict__ ct = a.sv.ct + (size_t)n * JP;
+  const float* __restrict__ vRh = a.sv.vecs + VEC_RH * w;
+  const float* __restrict__ vR2 = a.sv.vecs + VEC_R2 * w;
+  const uint64_t qvalid = a.sv.qvalid[(size_t)n * 2];
+  const bool cosine = s.simi == 4;
+
+  f32x4 hreg[NSC][P];
+  f32x4 uacc[NSLAB][NSC];
+#pragma unroll
+  for (int sl = 0; sl < NSLAB; ++sl)
+#pragma unroll
+    for (int sc = 0; sc < NSC; ++sc) uacc[sl][sc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  float* stage = s_stage[wave];
+
+  auto load_slab = [&](int sl) {
+#pragma unroll
+    for (int sc = 0; sc < NSC; ++sc)
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int t = s_t[rg + RGN * p];
+        const int c4 = sl * SLAB4 + wave * (NSC * SCW) + sc * SCW + c4l;
+        hreg[sc][p] = t >= 0 ? ld4g(hbase + (size_t)t * w + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  };
+
+  for (int tile = tile0; tile < tile1; ++tile) {
+    __syncthreads();  // previous tile's readers of s_t / s_p are done
+    if (tid < 32) {
+      const int r = tile * 32 + tid;
+      s_t[tid] = r < cnt ? idx[r] : -1;
+    }
+    __syncthreads();
+    if (!allm) {
+      f32x16 acc[JT];
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+      float rtp[P];
+#pragma unroll
+      for (int p = 0; p < P; ++p) rtp[p] = 0.f;
+#pragma unroll 1
+      for (int sl = 0; sl < NSLAB; ++sl) {
+        load_slab(sl);
+#pragma unroll
+        for (int sc = 0; sc < NSC; ++sc) {
+          const int c4base = sl * SLAB4 + wave * (NSC * SCW) + sc * SCW;
+          const f32x4 rh4 = ld4g(vRh + 4 * (c4base + c4l));
+          const f32x4 r24 = ld4g(vR2 + 4 * (c4base + c4l));
+#pragma unroll
+          for (int p = 0; p < P; ++p) {
+            const f32x4 h = hreg[sc][p];
+            const f32x4 tmp = h * (rh4 + r24 * h);
+            rtp[p] += (tmp[0] + tmp[1]) + (tmp[2] + tmp[3]);
+            *reinterpret_cast<f32x4*>(&stage[(rg + RGN * p) * LDW + 4 * c4l]) = h;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int s4 = 0; s4 < SCW / 2; ++s4) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(&stage[l31 * LDW + 8 * s4 + 4 * hf]);
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+              const f32x4 bv = ld4g(Qs + ((size_t)(c4base + 2 * s4 + hf) * JP + jt * 32 + l31) * 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[jt], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      // partial scores of this wave's K-slice -> LDS
+#pragma unroll
+      for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_part[wave][jt][r * 64 + lane] = acc[jt][r];
+      // row terms: reduce over the SCW lanes that share a row
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        float v = rtp[p];
+#pragma unroll
+        for (int o = 1; o < SCW; o <<= 1) v += __shfl_xor(v, o, 64);
+        if (c4l == 0) s_rt[wave][rg + RGN * p] = v;
+      }
+      __syncthreads();
+      {
+        const int row = tid >> 3, jg = tid & 7;
+        const int t = s_t[row];
+        const float rt = (s_rt[0][row] + s_rt[1][row]) + (s_rt[2][row] + s_rt[3][row]);
+        const float rs = cosine ? rsqrtf(fmaxf(rt, 1e-12f)) : 1.f;
+        const int preg = (row & 3) + 4 * (row >> 3), phf = (row >> 2) & 1;
+        float best = -INFINITY;
+        int bestj = 0;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int jl = jg * 4 + e, j = jt * 32 + jl;
+            const int pi = preg * 64 + phf * 32 + jl;
+            float x = (s_part[0][jt][pi] + s_part[1][jt][pi]) + (s_part[2][jt][pi] + s_part[3][jt][pi]);
+            x = cosine ? x * rs : x + rt + ct[j];
+            const bool valid = (qvalid >> j) & 1ull;
+            if (a.a_logits && t >= 0 && j < s.JQ)
+              a.a_logits[((size_t)nk * T + t) * s.JQ + j] = valid ? (s.add_tanh ? tanhf(x) : x) : FVTA_NEG;
+            if (valid && x > best) {
+              best = x;
+              bestj = j;
+            }
+          }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+          const float ob = __shfl_xor(best, o, 64);
+          const int oj = __shfl_xor(bestj, o, 64);
+          if (ob > best || (ob == best && oj < bestj)) {
+            best = ob;
+            bestj = oj;
+          }
+        }
+        if (jg == 0) {
+          if (t >= 0) {
+            const float av = s.add_tanh ? tanhf(best) : best;
+            s_amax[row] = av;
+            a.sv.amax[(size_t)nk * T + t] = av;
+            a.sv.jmax[(size_t)nk * T + t] = (uint8_t)bestj;
+          } else {
+            s_amax[row] = -INFINITY;
+          }
+        }
+      }
+    } else {
+      if (tid < 32) s_amax[tid] = s_t[tid] >= 0 ? FVTA_NEG : -INFINITY;
+      load_slab(NSLAB - 1);
+    }
+    __syncthreads();
+    // online softmax over t (softsel inner, model_v2.py:278)
+    float mt = s_amax[0];
+#pragma unroll
+    for (int r = 1; r < 32; ++r) mt = fmaxf(mt, s_amax[r]);
+    const float m_new = fmaxf(m_run, mt);
+    const float scale = expf(m_run - m_new);
+    if (tid < 32) s_p[tid] = expf(s_amax[tid] - m_new);
+    __syncthreads();
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) lsum += s_p[r];
+    l_run = l_run * scale + lsum;
+    m_run = m_new;
+    float pr[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) pr[p] = s_p[rg + RGN * p];
+#pragma unroll
+    for (int k = 0; k < NSLAB; ++k) {
+      const int sl = NSLAB - 1 - k;  // the last slab is still in registers
+      if (k > 0) load_slab(sl);
+#pragma unroll
+      for (int sc = 0; sc < NSC; ++sc) {
+        f32x4 u = uacc[sl][sc] * scale;
+#pragma unroll
+        for (int p = 0; p < P; ++p) u += hreg[sc][p] * pr[p];
+        uacc[sl][sc] = u;
+      }
+    }
+  }
+  // fold the RGN row groups of each wave, store the partial (m, l, u)
+#pragma unroll
+  for (int sl = 0; sl < NSLAB; ++sl)
+#pragma unroll
+    for (int sc = 0; sc < NSC; ++sc) {
+      f32x4 u = uacc[sl][sc];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = u[e];
+#pragma unroll
+        for (int o = SCW; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        u[e] = v;
+      }
+      if (rg == 0) {
+        const int c4 = sl * SLAB4 + wave * (NSC * SCW) + sc * SCW + c4l;
+        *reinterpret_cast<f32x4*>(part + 4 + 4 * c4) = u;
+      }
+    }
+  if (tid == 0) {
+    part[0] = m_run;
+    part[1] = l_run;
+  }
+}
+
+// ---- merge: splits -> u[n,k], M, L; softmax over K; h_a.  grid N, 256 threads
+__global__ __launch_bounds__(256) void attn_merge_kernel(AttnShape s, AttnSaved sv, const float* __restrict__ part,
+                                                         float* __restrict__ h_a) {
+  __shared__ float s_M[64], s_L[64], s_r[64];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int w = s.w, K = s.K, ns = s.nsplit;
+  for (int k = tid; k < K; k += 256) {
+    const float* pp = part + ((size_t)(n * K + k) * ns) * (w + 4);
+    float M = -INFINITY;
+    for (int sp = 0; sp < ns; ++sp) M = fmaxf(M, pp[(size_t)sp * (w + 4)]);
+    float L = 0.f;
+    for (int sp = 0; sp < ns; ++sp) {
+      const float l = pp[(size_t)sp * (w + 4) + 1];
+      if (l > 0.f) L += l * expf(pp[(size_t)sp * (w + 4)] - M);
+    }
+    s_M[k] = M;
+    s_L[k] = L;
+    sv.M[n * K + k] = M;
+    sv.L[n * K + k] = L;
+  }
+  __syncthreads();
+  if (tid == 0) {  // outer softsel over K (model_v2.py:278)
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, s_M[k]);
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) {
+      s_r[k] = expf(s_M[k] - mx);
+      sum += s_r[k];
+    }
+    for (int k = 0; k < K; ++k) {
+      s_r[k] /= sum;
+      sv.r[n * K + k] = s_r[k];
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < w; c += 256) {
+    float ha = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float* pp = part + ((size_t)(n * K + k) * ns) * (w + 4);
+      float u = 0.f;
+      for (int sp = 0; sp < ns; ++sp) {
+        const float l = pp[(size_t)sp * (w + 4) + 1];
+        if (l > 0.f) u += pp[(size_t)sp * (w + 4) + 4 + c] * expf(pp[(size_t)sp * (w + 4)] - s_M[k]);
+      }
+      u /= s_L[k];
+      sv.u[((size_t)n * K + k) * w + c] = u;
+      ha += s_r[k] * u;
+    }
+    h_a[(size_t)n * w + c] = ha;
+  }
+}
+
+template <int SCW, int NSC, int NSLAB>
+static int launch_main(const AttnFwdArgs& a, hipStream_t stream) {
+  const dim3 grid(a.s.nsplit, a.s.N * a.s.K);
+  if (a.s.JT == 1)
+    hipLaunchKernelGGL((attn_fwd_main<SCW, NSC, NSLAB, 1>), grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((attn_fwd_main<SCW, NSC, NSLAB, 2>), grid, dim3(256), 0, stream, a);
+  return 0;
+}
+
+}  // namespace fvta
+
+using namespace fvta;
+
+int fvta_attn_check_desc(const fvta_attn_desc* d) {
+  FVTA_CHECK_ARG(d != nullptr, "attn: null descriptor");
+  FVTA_CHECK_ARG(d->N > 0 && d->K > 0 && d->K <= 64 && d->T > 0, "attn: bad N/K/T (%d,%d,%d), need K<=64", d->N, d->K,
+                 d->T);
+  FVTA_CHECK_ARG(d->JQ > 0 && d->JQ <= 64, "attn: JQ=%d unsupported (1..64)", d->JQ);
+  FVTA_CHECK_ARG(d->simi >= 1 && d->simi <= 4, "similarity matrix not implemented (simiMatrix=%d)", d->simi);
+  const int w = d->w;
+  FVTA_CHECK_ARG(w == 64 || w == 128 || w == 256 || w == 512 || w == 1024 || w == 2048,
+                 "attn: w=%d unsupported; pad the hidden size so that w is one of 64,128,256,512,1024,2048", w);
+  return FVTA_OK;
+}
+
+extern "C" size_t fvta_attn_saved_bytes(const fvta_attn_desc* d) {
+  if (fvta_attn_check_desc(d)) return 0;
+  return attn_saved_view(attn_shape(d, true), nullptr).bytes;
+}
+
+size_t fvta_attn_bwd_workspace_bytes(const AttnShape& s);  // attn_bwd.hip
+
+extern "C" size_t fvta_attn_workspace_bytes(const fvta_attn_desc* d) {
+  if (fvta_attn_check_desc(d)) return 0;
+  const AttnShape s = attn_shape(d, true);
+  const size_t fwd = fvta_align_up((size_t)s.N * s.K * s.nsplit * (s.w + 4) * sizeof(float), 256);
+  const size_t bwd = fvta_attn_bwd_workspace_bytes(s);
+  return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const float* hq, const uint8_t* hmask,
+                             const uint8_t* qmask, const float* W, const float* b, float* h_a, float* a_logits,
+                             void* saved, void* workspace, fvta_stream_t stream_) {
+  if (int e = fvta_attn_check_desc(d)) return e;
+  FVTA_CHECK_ARG(hinfo && hq && h_a && saved && workspace, "attn_fwd: null pointer");
+  FVTA_CHECK_ARG(d->simi == 4 || (W && b), "attn_fwd: W and b required for simiMatrix 1-3");
+  hipStream_t stream = (hipStream_t)stream_;
+  const bool use_mask = hmask && qmask;  // model_v2.py:146/233: only when BOTH masks are given
+  const AttnShape s = attn_shape(d, use_mask);
+  AttnSaved sv = attn_saved_view(s, saved);
+  hipLaunchKernelGGL(attn_vecs_kernel, dim3((s.w + 255) / 256), dim3(256), 0, stream, W, s.w, s.simi, s.feat_order,
+                     sv.vecs);
+  hipLaunchKernelGGL(attn_prep_q_kernel, dim3(s.N), dim3(256), 0, stream, s, sv, hq, qmask, b);
+  hipLaunchKernelGGL(attn_compact_kernel, dim3(s.N * s.K), dim3(256), 0, stream, s, sv, hmask);
+  FVTA_CHECK_LAUNCH("attn_prep");
+  if (a_logits && use_mask) {
+    const size_t n = (size_t)s.N * s.K * s.T * s.JQ;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a_logits, n, FVTA_NEG);
+  }
+  AttnFwdArgs a;
+  a.s = s;
+  a.sv = sv;
+  a.hinfo = hinfo;
+  a.a_logits = a_logits;
+  a.part = (float*)workspace;
+  switch (s.w) {
+    case 64: launch_main<4, 1, 1>(a, stream); break;
+    case 128: launch_main<8, 1, 1>(a, stream); break;
+    case 256: launch_main<16, 1, 1>(a, stream); break;
+    case 512: launch_main<16, 2, 1>(a, stream); break;
+    case 1024: launch_main<16, 4, 1>(a, stream); break;
+    case 2048: launch_main<16, 4, 2>(a, stream); break;
+  }
+  FVTA_CHECK_LAUNCH("attn_fwd_main");
+  hipLaunchKernelGGL(attn_merge_kernel, dim3(s.N), dim3(256), 0, stream, s, sv, a.part, h_a);
+  FVTA_CHECK_LAUNCH("attn_merge");
+  return FVTA_OK;
+}

@@ -1,0 +1,83 @@
+// Common device/host helpers for the FVTA gfx950 kernels.
+// Everything here is CDNA4-only (wave64, MFMA); there is no other backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/fvta_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+#define FVTA_WAVE 64
+#define FVTA_NEG (-1e30f)  // utils.py:205 VERY_NEGATIVE_NUMBER
+
+// ---- error plumbing (never throw across the C ABI) -------------------------
+void fvta_set_error(const char* fmt, ...);
+
+#define FVTA_CHECK_ARG(cond, ...)                 \
+  do {                                            \
+    if (!(cond)) {                                \
+      fvta_set_error(__VA_ARGS__);                \
+      return FVTA_ERR_INVALID_ARG;                \
+    }                                             \
+  } while (0)
+
+#define FVTA_CHECK_LAUNCH(what)                                                   \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      fvta_set_error("%s: launch failed: %s", what, hipGetErrorString(e__));      \
+      return FVTA_ERR_LAUNCH;                                                     \
+    }                                                                             \
+  } while (0)
+
+#define FVTA_CHECK_HIP(expr)                                                      \
+  do {                                                                            \
+    hipError_t e__ = (expr);                                                      \
+    if (e__ != hipSuccess) {                                                      \
+      fvta_set_error("%s failed: %s", #expr, hipGetErrorString(e__));             \
+      return FVTA_ERR_LAUNCH;                                                     \
+    }                                                                             \
+  } while (0)
+
+static inline size_t fvta_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Carve a caller-provided workspace into 256-byte aligned pieces.
+struct FvtaCarver {
+  char* base;
+  size_t off;
+  explicit FvtaCarver(void* p) : base((char*)p), off(0) {}
+  template <typename T>
+  T* take(size_t n) {
+    T* r = (T*)(base ? base + off : nullptr);
+    off = fvta_align_up(off + n * sizeof(T), 256);
+    return r;
+  }
+};
+
+// ---- device math ------------------------------------------------------------
+__device__ __forceinline__ float fvta_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// float -> bf16 (round to nearest even), as raw 16-bit
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // keep NaN a NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }

@@ -1,0 +1,728 @@
+// bi-LSTM modality encoders for gfx950.
+//
+// Replaces model_v2.py:652-661 (BasicLSTMCell cells), 694-823 (eight
+// bidirectional_dynamic_rnn calls) and 863-914 (tf.pad/tf.stack into `hall`):
+// every sequence that shares a cell runs in one call, length-sorted so that the
+// active rows of step t are a prefix; each step is one GEMM launch
+// [x_t | h_{t-1}] * kernel with the gate math fused into the MFMA epilogue, the
+// forward and the reversed direction side by side (blockIdx.z), and h_t stored
+// straight into the padded context-tensor rows.
+//
+// Semantics restated from TF 1.4: z=[x,h]*kernel+bias, split
+// i,j,f,o, c'=c*sig(f+1)+sig(i)*tanh(j), h'=tanh(c')*sig(o); rows past their
+// length emit zeros and keep their state; the reversed direction runs on
+// reverse_sequence(x, len) and its outputs are reversed back.
+#include "gemm_f32.h"
+
+namespace fvta {
+
+// ------------------------------------------------------------------ plan ----
+struct PlanHeader {
+  int64_t out_ld;
+  int32_t B, J, in, d;
+  int32_t pad[10];
+};
+
+struct PlanView {
+  PlanHeader* hdr;
+  int32_t* order;    // [B] sequence ids, longest first (stable)
+  int32_t* nactive;  // [J+1] sequences with len > t
+  int32_t* len;      // [B]
+  int32_t* seq_J;    // [B]
+  int64_t* x_off;    // [B]
+  int64_t* out_off;  // [B]
+  int64_t* xo;       // [2][J][B] element offset of x row for (dir,t,sorted i), -1 = inactive
+  int64_t* oo;       // [2][J][B] element offset of the output half-row
+  size_t bytes;
+};
+
+static PlanView plan_view(const fvta_lstm_desc* d, void* p) {
+  FvtaCarver c(p);
+  PlanView v;
+  v.hdr = c.take<PlanHeader>(1);
+  v.order = c.take<int32_t>(d->B);
+  v.nactive = c.take<int32_t>(d->J + 1);
+  v.len = c.take<int32_t>(d->B);
+  v.seq_J = c.take<int32_t>(d->B);
+  v.x_off = c.take<int64_t>(d->B);
+  v.out_off = c.take<int64_t>(d->B);
+  v.xo = c.take<int64_t>((size_t)2 * d->J * d->B);
+  v.oo = c.take<int64_t>((size_t)2 * d->J * d->B);
+  v.bytes = c.off;
+  return v;
+}
+
+// Stable counting sort by length, descending.  One 1024-thread workgroup; each
+// of the 16 waves owns a contiguous chunk of the sequences, so the order is
+// deterministic (no atomics decide a position).
+__global__ __launch_bounds__(1024) void plan_sort_kernel(PlanView v, const int32_t* __restrict__ len_in,
+                                                         const int32_t* __restrict__ seq_J_in,
+                                                         const int64_t* __restrict__ x_off_in,
+                                                         const int64_t* __restrict__ out_off_in,
+                                                         int64_t out_ld, int B, int J, int in, int d) {
+  extern __shared__ int32_t sh[];  // [16][J+1] per-wave histogram, then running bases
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int NW = 16, H = J + 1;
+  for (int i = tid; i < NW * H; i += 1024) sh[i] = 0;
+  if (tid == 0) {
+    v.hdr->out_ld = out_ld;
+    v.hdr->B = B;
+    v.hdr->J = J;
+    v.hdr->in = in;
+    v.hdr->d = d;
+  }
+  for (int b = tid; b < B; b += 1024) {
+    int L = len_in[b];
+    L = L < 0 ? 0 : (L > J ? J : L);
+    v.len[b] = L;
+    v.seq_J[b] = seq_J_in[b];
+    v.x_off[b] = x_off_in[b];
+    v.out_off[b] = out_off_in[b];
+  }
+  __syncthreads();
+  const int chunk = (B + NW - 1) / NW;
+  const int b0 = wave * chunk, b1 = min(B, b0 + chunk);
+  // pass 1: per-wave histogram (lane 0 of each distinct value adds the count)
+  for (int base = b0; base < b1; base += 64) {
+    const int b = base + lane;
+    const bool ok = b < b1;
+    const int L = ok ? v.len[b] : -1;
+    unsigned long long todo = __ballot(ok);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int Lv = __shfl(L, leader, 64);
+      const unsigned long long same = __ballot(ok && L == Lv);
+      if (lane == leader) sh[wave * H + Lv] += __popcll(same);
+      todo &= ~same;
+    }
+  }
+  __syncthreads();
+  // exclusive prefix over (L descending, wave ascending); thread 0 is enough (16*(J+1) adds)
+  if (tid == 0) {
+    int run = 0;
+    for (int L = J; L >= 0; --L) {
+      if (L < J) v.nactive[L] = run;  // sequences with len > L
+      for (int wv = 0; wv < NW; ++wv) {
+        const int c = sh[wv * H + L];
+        sh[wv * H + L] = run;
+        run += c;
+      }
+    }
+    v.nactive[J] = 0;
+  }
+  __syncthreads();
+  // pass 2: scatter, each wave walking its chunk in order
+  for (int base = b0; base < b1; base += 64) {
+    const int b = base + lane;
+    const bool ok = b < b1;
+    const int L = ok ? v.len[b] : -1;
+    unsigned long long todo = __ballot(ok);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int Lv = __shfl(L, leader, 64);
+      const unsigned long long same = __ballot(ok && L == Lv);
+      const int basepos = sh[wave * H + Lv];
+      if (ok && L == Lv) {
+        const unsigned long long lower = same & ((1ull << lane) - 1ull);
+        v.order[basepos + __popcll(lower)] = b;
+      }
+      // make sure every lane has read basepos before the leader bumps it
+      __builtin_amdgcn_wave_barrier();
+      if (lane == leader) sh[wave * H + Lv] = basepos + __popcll(same);
+      __builtin_amdgcn_wave_barrier();
+      todo &= ~same;
+    }
+  }
+}
+
+__global__ void plan_fill_kernel(PlanView v, int B, int J, int in, int d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y, dir = blockIdx.z;
+  if (i >= B) return;
+  const size_t idx = ((size_t)dir * J + t) * B + i;
+  if (i >= v.nactive[t]) {
+    v.xo[idx] = -1;
+    v.oo[idx] = -1;
+    return;
+  }
+  const int b = v.order[i];
+  const int L = v.len[b];
+  const int pos = dir ? (L - 1 - t) : t;
+  v.xo[idx] = v.x_off[b] + (int64_t)pos * in;
+  v.oo[idx] = v.out_off[b] + (int64_t)pos * v.hdr->out_ld + (int64_t)dir * d;
+}
+
+// rows t in [len, seq_J) of both halves are zero (dynamic_rnn zero_output)
+__global__ void pad_zero_kernel(PlanView v, float* __restrict__ out, int d) {
+  const int b = blockIdx.x;
+  const int L = v.len[b], Jb = v.seq_J[b];
+  const int64_t ld = v.hdr->out_ld;
+  const int w4 = (2 * d) / 4;
+  for (int t = L + blockIdx.y; t < Jb; t += gridDim.y) {
+    f32x4* row = reinterpret_cast<f32x4*>(out + v.out_off[b] + (int64_t)t * ld);
+    for (int c = threadIdx.x; c < w4; c += blockDim.x) row[c] = zero4();
+  }
+}
+
+// ------------------------------------------------------------- saved state --
+struct SavedView {
+  float* gates;  // [2][J][B][4][d] i, tanh(j), f, o activations (overwritten by dz in backward)
+  float* cs;     // [2][J][B][d] cell state after step t
+  size_t bytes;
+};
+static SavedView saved_view(const fvta_lstm_desc* d, void* p) {
+  FvtaCarver c(p);
+  SavedView s;
+  s.gates = c.take<float>((size_t)2 * d->J * d->B * 4 * d->d);
+  s.cs = c.take<float>((size_t)2 * d->J * d->B * d->d);
+  s.bytes = c.off;
+  return s;
+}
+
+struct WorkView {
+  float* cstate;   // [2][B][d] running cell state (inference) / dc (backward)
+  float* dh_rec;   // [2][B][d]
+  float* slabs;    // [NSPLIT][2 or 1][(in+d+1)][4d] split-K partials of dW
+  size_t bytes;
+};
+static int dw_tgroup(const fvta_lstm_desc* d) {
+  // steps per split-K slice of the weight-gradient GEMM: keep <= 16 slices per direction
+  int g = (d->J + 15) / 16;
+  return g < 1 ? 1 : g;
+}
+static int dw_nsplit(const fvta_lstm_desc* d) { return (d->J + dw_tgroup(d) - 1) / dw_tgroup(d); }
+static WorkView work_view(const fvta_lstm_desc* d, void* p) {
+  FvtaCarver c(p);
+  WorkView w;
+  w.cstate = c.take<float>((size_t)2 * d->B * d->d);
+  w.dh_rec = c.take<float>((size_t)2 * d->B * d->d);
+  w.slabs = c.take<float>((size_t)2 * dw_nsplit(d) * (d->in + d->d + 1) * 4 * d->d);
+  w.bytes = c.off;
+  return w;
+}
+
+// --------------------------------------------------------- forward step -----
+// grid (ceil(B/128), d/32, 2).  Block tile: 128 sorted sequences x (4 gates x 32
+// units); wave wv owns rows [32wv, 32wv+32) and all four gate tiles, so a lane
+// ends up with i,j,f,o of the same (row, unit) in its accumulators.
+using MmaStep = MmaF32<4, 1, 1, 4>;
+
+struct StepArgs {
+  PlanView plan;
+  const float* x;
+  float* out;
+  const float* W[2];
+  const float* bias[2];
+  float* gates;   // may be null (inference)
+  float* cs;      // may be null
+  float* cstate;  // used when cs is null
+  int t, B, J, in, d;
+};
+
+__global__ __launch_bounds__(256) void lstm_step_fwd_f32(StepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int64_t s_xo[MmaStep::BM];
+  __shared__ int64_t s_ho[MmaStep::BM];
+  const int tid = threadIdx.x;
+  const int dir = blockIdx.z;
+  const int m0 = blockIdx.x * MmaStep::BM;
+  const int nact = a.plan.nactive[a.t];
+  if (m0 >= nact) return;
+  const int u0 = blockIdx.y * 32;
+  const int d = a.d, in = a.in, t = a.t;
+  const int64_t out_ld = a.plan.hdr->out_ld;
+  const size_t trow = ((size_t)dir * a.J + t) * a.B;
+  if (tid < MmaStep::BM) {
+    const int i = m0 + tid;
+    int64_t xo = -1, oo = -1;
+    if (i < nact) {
+      xo = a.plan.xo[trow + i];
+      oo = a.plan.oo[trow + i];
+    }
+    s_xo[tid] = xo;
+    // h_{t-1} sits one output row before (fw) / after (bw) this step's row
+    s_ho[tid] = (oo < 0 || t == 0) ? -1 : (dir ? oo + out_ld : oo - out_ld);
+  }
+  __syncthreads();
+  const float* __restrict__ W = a.W[dir];
+  const float* __restrict__ x = a.x;
+  const float* __restrict__ hsrc = a.out;
+  const int K = (t == 0) ? in : in + d;
+
+  MmaStep mma;
+  mma.init(tid);
+  StageKContig<MmaStep::BM, MmaStep::BK, MmaStep::NT, MmaStep::LDA> sa;
+  StageMNContig<MmaStep::BN, MmaStep::BK, MmaStep::NT, MmaStep::LDB> sb;
+  auto fa = [&](int r, int k) -> f32x4 {
+    if (k >= K) return zero4();
+    if (k < in) {
+      const int64_t o = s_xo[r];
+      return o < 0 ? zero4() : ld4(x + o + k);
+    }
+    const int64_t o = s_ho[r];
+    return o < 0 ? zero4() : ld4(hsrc + o + (k - in));
+  };
+  auto fb = [&](int k, int c) -> f32x4 {
+    if (k >= K) return zero4();
+    const int g = c >> 5, u = c & 31;  // virtual column -> gate strip
+    return ld4(W + (size_t)k * (4 * d) + g * d + u0 + u);
+  };
+  gemm_mainloop(mma, sa, sb, fa, fb, 0, K, smem, tid);
+
+  // ---- fused gate epilogue ----
+  const float* __restrict__ bias = a.bias[dir];
+  const int u = u0 + mma.l31;
+  const float bi = bias[u], bj = bias[d + u], bf = bias[2 * d + u], bo = bias[3 * d + u];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = mma.row_of(0, r);
+    const int i = m0 + row;
+    if (i >= nact) continue;
+    const float ig = fvta_sigmoid(mma.acc[0][0][r] + bi);
+    const float jg = tanhf(mma.acc[0][1][r] + bj);
+    const float fg = fvta_sigmoid(mma.acc[0][2][r] + bf + 1.0f);  // forget_bias
+    const float og = fvta_sigmoid(mma.acc[0][3][r] + bo);
+    float cprev = 0.f;
+    if (t > 0) cprev = a.cs ? a.cs[(trow - a.B + i) * d + u] : a.cstate[((size_t)dir * a.B + i) * d + u];
+    const float c = cprev * fg + ig * jg;
+    const float h = tanhf(c) * og;
+    if (a.cs) {
+      a.cs[(trow + i) * d + u] = c;
+      float* g = a.gates + (trow + i) * (size_t)(4 * d) + u;
+      g[0] = ig;
+      g[d] = jg;
+      g[2 * d] = fg;
+      g[3 * d] = og;
+    } else {
+      a.cstate[((size_t)dir * a.B + i) * d + u] = c;
+    }
+    const int64_t oo = a.plan.oo[trow + i];
+    a.out[oo + u] = h;
+  }
+}
+
+// ------------------------------------------------------- backward pieces ----
+// (a) elementwise: dz_t from dh_t, dc_t and the saved activations; dz overwrites
+// the saved gates in place.  grid (ceil(nact_max*d/256)...): one thread per (i,u).
+struct GateBwdArgs {
+  PlanView plan;
+  const float* d_out;
+  float* gates;
+  const float* cs;
+  float* dc;      // [2][B][d]
+  float* dh_rec;  // [2][B][d]
+  int t, B, J, d;
+};
+__global__ void lstm_gate_bwd(GateBwdArgs a) {
+  const int dir = blockIdx.z;
+  const int d = a.d, t = a.t;
+  const int nact = a.plan.nactive[t];
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (int)(idx / d), u = (int)(idx % d);
+  if (i >= nact) return;
+  const size_t trow = ((size_t)dir * a.J + t) * a.B;
+  const int64_t oo = a.plan.oo[trow + i];
+  const size_t su = ((size_t)dir * a.B + i) * d + u;
+  // rows whose last step is t have never been written by a later step: dh_rec, dc are still 0
+  const float dh = a.d_out[oo + u] + a.dh_rec[su];
+  float* g = a.gates + (trow + i) * (size_t)(4 * d) + u;
+  const float ig = g[0], jg = g[d], fg = g[2 * d], og = g[3 * d];
+  const float c = a.cs[(trow + i) * d + u];
+  const float cprev = t > 0 ? a.cs[(trow - a.B + i) * d + u] : 0.f;
+  const float tc = tanhf(c);
+  const float dc = a.dc[su] + dh * og * (1.f - tc * tc);
+  g[0] = dc * jg * ig * (1.f - ig);
+  g[d] = dc * ig * (1.f - jg * jg);
+  g[2 * d] = dc * cprev * fg * (1.f - fg);
+  g[3 * d] = dh * tc * og * (1.f - og);
+  a.dc[su] = dc * fg;
+}
+
+// (b) [dx_t | dh_{t-1}] = dz_t * kernel^T.  grid (ceil(B/128), ceil((in+d)/128), 2)
+using MmaSq = MmaF32<2, 2, 2, 2>;
+struct StepBwdArgs {
+  PlanView plan;
+  const float* dz;  // = saved gates buffer
+  const float* W[2];
+  float* dx;        // may be null
+  float* dh_rec;
+  int t, B, J, in, d;
+};
+__global__ __launch_bounds__(256) void lstm_step_bwd_f32(StepBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, dir = blockIdx.z;
+  const int m0 = blockIdx.x * MmaSq::BM, n0 = blockIdx.y * MmaSq::BN;
+  const int nact = a.plan.nactive[a.t];
+  if (m0 >= nact) return;
+  const int d = a.d, in = a.in, t = a.t;
+  const int NN = in + d, K = 4 * d;
+  if (t == 0 && n0 >= in) return;  // dh_{-1} is not needed
+  if (a.dx == nullptr && n0 + MmaSq::BN <= in) return;
+  const size_t trow = ((size_t)dir * a.J + t) * a.B;
+  const float* __restrict__ dz = a.dz + trow * (size_t)K;
+  const float* __restrict__ W = a.W[dir];
+  MmaSq mma;
+  mma.init(tid);
+  StageKContig<MmaSq::BM, MmaSq::BK, MmaSq::NT, MmaSq::LDA> sa;
+  StageKContig<MmaSq::BN, MmaSq::BK, MmaSq::NT, MmaSq::LDB> sb;
+  auto fa = [&](int r, int k) -> f32x4 {
+    const int i = m0 + r;
+    return i < nact ? ld4(dz + (size_t)i * K + k) : zero4();
+  };
+  auto fb = [&](int r, int k) -> f32x4 {
+    const int n = n0 + r;
+    return n < NN ? ld4(W + (size_t)n * K + k) : zero4();
+  };
+  gemm_mainloop(mma, sa, sb, fa, fb, 0, K, smem, tid);
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = m0 + mma.row_of(ti, r);
+      if (i >= nact) continue;
+      const int64_t xo = a.plan.xo[trow + i];
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        const int n = n0 + mma.col_of(tj);
+        const float v = mma.acc[ti][tj][r];
+        if (n < in) {
+          // both directions add into the same dx row (at most two addends: order-free)
+          if (a.dx) atomicAdd(a.dx + xo + n, v);
+        } else if (n < NN && t > 0) {
+          a.dh_rec[((size_t)dir * a.B + i) * d + (n - in)] = v;
+        }
+      }
+    }
+}
+
+// (c) dkernel = [x | h_prev | 1]^T * dz over all steps: split-K slabs.
+// grid (ceil((in+d+1)/128), 4d/128, nsplit*ndirslab)
+struct DwArgs {
+  PlanView plan;
+  const float* x;
+  const float* out;
+  const float* dz;
+  float* slabs;
+  int B, J, in, d, tgroup, nsplit;
+};
+__global__ __launch_bounds__(256) void lstm_dw_f32(DwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * MmaSq::BM, n0 = blockIdx.y * MmaSq::BN;
+  const int split = blockIdx.z % a.nsplit, dir = blockIdx.z / a.nsplit;
+  const int d = a.d, in = a.in, MM = in + d + 1, N4 = 4 * d;
+  const int64_t out_ld = a.plan.hdr->out_ld;
+  MmaSq mma;
+  mma.init(tid);
+  StageMNContig<MmaSq::BM, MmaSq::BK, MmaSq::NT, MmaSq::LDA> sa;
+  StageMNContig<MmaSq::BN, MmaSq::BK, MmaSq::NT, MmaSq::LDB> sb;
+  const int t_begin = split * a.tgroup, t_end = min(a.J, t_begin + a.tgroup);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int nact = a.plan.nactive[t];
+    if (nact == 0) break;
+    const size_t trow = ((size_t)dir * a.J + t) * a.B;
+    const float* __restrict__ dz = a.dz + trow * (size_t)N4;
+    const int64_t* __restrict__ xo = a.plan.xo + trow;
+    const int64_t* __restrict__ oo = a.plan.oo + trow;
+    auto fa = [&](int k, int c) -> f32x4 {  // A[k = sorted row][m]
+      if (k >= nact) return zero4();
+      const int m = m0 + c;
+      if (m < in) return ld4(a.x + xo[k] + m);
+      if (m < in + d) {
+        if (t == 0) return zero4();
+        const int64_t ho = dir ? oo[k] + out_ld : oo[k] - out_ld;
+        return ld4(a.out + ho + (m - in));
+      }
+      return m == in + d ? f32x4{1.f, 0.f, 0.f, 0.f} : zero4();  // ones column -> dbias
+    };
+    auto fb = [&](int k, int c) -> f32x4 {
+      return k < nact ? ld4(dz + (size_t)k * N4 + n0 + c) : zero4();
+    };
+    gemm_mainloop(mma, sa, sb, fa, fb, 0, (nact + MmaSq::BK - 1) / MmaSq::BK * MmaSq::BK, smem, tid);
+  }
+  float* slab = a.slabs + (size_t)blockIdx.z * MM * N4;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + mma.row_of(ti, r);
+      if (m >= MM) continue;
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) slab[(size_t)m * N4 + n0 + mma.col_of(tj)] = mma.acc[ti][tj][r];
+    }
+}
+
+// sum the slabs in a fixed order into dkernel [in+d,4d] and dbias [4d] (accumulate)
+__global__ void lstm_dw_reduce(const float* __restrict__ slabs, int nslab, size_t slab_elems, int rowsW,
+                               int N4, float* __restrict__ dW, float* __restrict__ dbias) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= slab_elems) return;
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += slabs[(size_t)k * slab_elems + idx];
+  const size_t row = idx / N4;
+  if (row < (size_t)rowsW)
+    dW[idx] += s;
+  else
+    dbias[idx - (size_t)rowsW * N4] += s;
+}
+
+// ------------------------------------------------------------ last states ---
+__global__ void last_state_kernel(PlanView v, const float* __restrict__ out, int s0, int count, int d,
+                                  float* __restrict__ dst, const float* __restrict__ d_dst,
+                                  float* __restrict__ d_out) {
+  const int s = blockIdx.x;
+  if (s >= count) return;
+  const int b = s0 + s;
+  const int L = v.len[b];
+  const int64_t ld = v.hdr->out_ld;
+  const int64_t base = v.out_off[b];
+  for (int c = threadIdx.x; c < 2 * d; c += blockDim.x) {
+    const int64_t o = base + (c < d ? (int64_t)(L - 1) * ld : 0) + c;
+    if (dst) dst[(size_t)s * 2 * d + c] = L > 0 ? out[o] : 0.f;
+    if (d_out && L > 0) d_out[o] += d_dst[(size_t)s * 2 * d + c];
+  }
+}
+
+// ---------------------------------------------------------------- test gemm -
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void test_gemm_f32(int M, int N, int K, const float* __restrict__ A,
+                                                     const float* __restrict__ B, float* __restrict__ C) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * MmaSq::BM, n0 = blockIdx.y * MmaSq::BN;
+  MmaSq mma;
+  mma.init(tid);
+  const int Kp = (K + MmaSq::BK - 1) / MmaSq::BK * MmaSq::BK;
+  if (LAYOUT == 0) {  // A[M,K] k-contig, B[K,N] n-contig
+    StageKContig<MmaSq::BM, MmaSq::BK, MmaSq::NT, MmaSq::LDA> sa;
+    StageMNContig<MmaSq::BN, MmaSq::BK, MmaSq::NT, MmaSq::LDB> sb;
+    auto fa = [&](int r, int k) -> f32x4 { return (m0 + r < M && k < K) ? ld4(A + (size_t)(m0 + r) * K + k) : zero4(); };
+    auto fb = [&](int k, int c) -> f32x4 { return (k < K && n0 + c < N) ? ld4(B + (size_t)k * N + n0 + c) : zero4(); };
+    gemm_mainloop(mma, sa, sb, fa, fb, 0, Kp, smem, tid);
+  } else if (LAYOUT == 1) {  // A[M,K], B[N,K] both k-contig
+    StageKContig<MmaSq::BM, MmaSq::BK, MmaSq::NT, MmaSq::LDA> sa;
+    StageKContig<MmaSq::BN, MmaSq::BK, MmaSq::NT, MmaSq::LDB> sb;
+    auto fa = [&](int r, int k) -> f32x4 { return (m0 + r < M && k < K) ? ld4(A + (size_t)(m0 + r) * K + k) : zero4(); };
+    auto fb = [&](int r, int k) -> f32x4 { return (n0 + r < N && k < K) ? ld4(B + (size_t)(n0 + r) * K + k) : zero4(); };
+    gemm_mainloop(mma, sa, sb, fa, fb, 0, Kp, smem, tid);
+  } else {  // A[K,M], B[K,N] both k-major
+    StageMNContig<MmaSq::BM, MmaSq::BK, MmaSq::NT, MmaSq::LDA> sa;
+    StageMNContig<MmaSq::BN, MmaSq::BK, MmaSq::NT, MmaSq::LDB> sb;
+    auto fa = [&](int k, int c) -> f32x4 { return (k < K && m0 + c < M) ? ld4(A + (size_t)k * M + m0 + c) : zero4(); };
+    auto fb = [&](int k, int c) -> f32x4 { return (k < K && n0 + c < N) ? ld4(B + (size_t)k * N + n0 + c) : zero4(); };
+    gemm_mainloop(mma, sa, sb, fa, fb, 0, Kp, smem, tid);
+  }
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + mma.row_of(ti, r);
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) {
+        const int n = n0 + mma.col_of(tj);
+        if (m < M && n < N) C[(size_t)m * N + n] = mma.acc[ti][tj][r];
+      }
+    }
+}
+
+}  // namespace fvta
+
+using namespace fvta;
+
+// ================================================================== C ABI ===
+static int check_lstm_desc(const fvta_lstm_desc* d) {
+  FVTA_CHECK_ARG(d != nullptr, "lstm: null descriptor");
+  FVTA_CHECK_ARG(d->B > 0 && d->J > 0 && d->J <= 1024, "lstm: need B>0 and 0<J<=1024 (B=%d J=%d)", d->B, d->J);
+  FVTA_CHECK_ARG(d->in > 0 && d->in % 4 == 0, "lstm: input width must be a positive multiple of 4 (in=%d)", d->in);
+  FVTA_CHECK_ARG(d->d > 0 && d->d % 32 == 0, "lstm: hidden size must be a positive multiple of 32 (d=%d)", d->d);
+  FVTA_CHECK_ARG(d->precision == FVTA_F32, "lstm: precision %d not built", d->precision);
+  return FVTA_OK;
+}
+
+extern "C" size_t fvta_lstm_plan_bytes(const fvta_lstm_desc* d) { return plan_view(d, nullptr).bytes; }
+extern "C" size_t fvta_lstm_saved_bytes(const fvta_lstm_desc* d) {
+  return d->training ? saved_view(d, nullptr).bytes : 256;
+}
+extern "C" size_t fvta_lstm_workspace_bytes(const fvta_lstm_desc* d) { return work_view(d, nullptr).bytes; }
+
+extern "C" int fvta_lstm_plan(const fvta_lstm_desc* d, const int32_t* len, const int32_t* seq_J,
+                              const int64_t* x_off, const int64_t* out_off, int64_t out_ld, void* plan,
+                              fvta_stream_t stream_) {
+  if (int e = check_lstm_desc(d)) return e;
+  FVTA_CHECK_ARG(len && seq_J && x_off && out_off && plan, "lstm_plan: null pointer");
+  FVTA_CHECK_ARG(out_ld >= 2 * d->d && out_ld % 4 == 0, "lstm_plan: out_ld=%lld must be >= 2d and a multiple of 4",
+                 (long long)out_ld);
+  hipStream_t stream = (hipStream_t)stream_;
+  PlanView v = plan_view(d, plan);
+  const size_t sh = (size_t)16 * (d->J + 1) * sizeof(int32_t);
+  hipLaunchKernelGGL(plan_sort_kernel, dim3(1), dim3(1024), sh, stream, v, len, seq_J, x_off, out_off, out_ld,
+                     d->B, d->J, d->in, d->d);
+  FVTA_CHECK_LAUNCH("plan_sort");
+  hipLaunchKernelGGL(plan_fill_kernel, dim3((d->B + 255) / 256, d->J, 2), dim3(256), 0, stream, v, d->B, d->J,
+                     d->in, d->d);
+  FVTA_CHECK_LAUNCH("plan_fill");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const float* x, float* out,
+                               const float* kernel_fw, const float* bias_fw, const float* kernel_bw,
+                               const float* bias_bw, void* saved, void* workspace, fvta_stream_t stream_) {
+  if (int e = check_lstm_desc(d)) return e;
+  FVTA_CHECK_ARG(plan && x && out && kernel_fw && bias_fw && workspace, "bilstm_fwd: null pointer");
+  FVTA_CHECK_ARG(d->share_fw_bw || (kernel_bw && bias_bw), "bilstm_fwd: kernel_bw/bias_bw required");
+  FVTA_CHECK_ARG(!d->training || saved, "bilstm_fwd: training needs a saved buffer");
+  hipStream_t stream = (hipStream_t)stream_;
+  PlanView pv = plan_view(d, const_cast<void*>(plan));
+  WorkView wv = work_view(d, workspace);
+  StepArgs a;
+  a.plan = pv;
+  a.x = x;
+  a.out = out;
+  a.W[0] = kernel_fw;
+  a.bias[0] = bias_fw;
+  a.W[1] = d->share_fw_bw ? kernel_fw : kernel_bw;
+  a.bias[1] = d->share_fw_bw ? bias_fw : bias_bw;
+  if (d->training) {
+    SavedView sv = saved_view(d, saved);
+    a.gates = sv.gates;
+    a.cs = sv.cs;
+  } else {
+    a.gates = nullptr;
+    a.cs = nullptr;
+  }
+  a.cstate = wv.cstate;
+  a.B = d->B;
+  a.J = d->J;
+  a.in = d->in;
+  a.d = d->d;
+  hipLaunchKernelGGL(pad_zero_kernel, dim3(d->B, 4), dim3(256), 0, stream, pv, out, d->d);
+  FVTA_CHECK_LAUNCH("pad_zero");
+  const dim3 grid((d->B + MmaStep::BM - 1) / MmaStep::BM, d->d / 32, 2);
+  const size_t sh = MmaStep::LDS_FLOATS * sizeof(float);
+  for (int t = 0; t < d->J; ++t) {
+    a.t = t;
+    hipLaunchKernelGGL(lstm_step_fwd_f32, grid, dim3(256), sh, stream, a);
+  }
+  FVTA_CHECK_LAUNCH("lstm_step_fwd");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const float* x, const float* out,
+                               const float* d_out, const float* kernel_fw, const float* kernel_bw, void* saved,
+                               float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw,
+                               float* dbias_bw, void* workspace, fvta_stream_t stream_) {
+  if (int e = check_lstm_desc(d)) return e;
+  FVTA_CHECK_ARG(d->training, "bilstm_bwd: forward was not run with training=1");
+  FVTA_CHECK_ARG(plan && x && out && d_out && kernel_fw && saved && dkernel_fw && dbias_fw && workspace,
+                 "bilstm_bwd: null pointer");
+  FVTA_CHECK_ARG(d->share_fw_bw || (kernel_bw && dkernel_bw && dbias_bw), "bilstm_bwd: *_bw pointers required");
+  hipStream_t stream = (hipStream_t)stream_;
+  PlanView pv = plan_view(d, const_cast<void*>(plan));
+  SavedView sv = saved_view(d, saved);
+  WorkView wv = work_view(d, workspace);
+  const int B = d->B, J = d->J, in = d->in, dd = d->d;
+  FVTA_CHECK_HIP(hipMemsetAsync(wv.cstate, 0, (size_t)2 * B * dd * sizeof(float) * 2, stream));  // dc and dh_rec
+  GateBwdArgs g;
+  g.plan = pv;
+  g.d_out = d_out;
+  g.gates = sv.gates;
+  g.cs = sv.cs;
+  g.dc = wv.cstate;
+  g.dh_rec = wv.dh_rec;
+  g.B = B;
+  g.J = J;
+  g.d = dd;
+  StepBwdArgs s;
+  s.plan = pv;
+  s.dz = sv.gates;
+  s.W[0] = kernel_fw;
+  s.W[1] = d->share_fw_bw ? kernel_fw : kernel_bw;
+  s.dx = dx;
+  s.dh_rec = wv.dh_rec;
+  s.B = B;
+  s.J = J;
+  s.in = in;
+  s.d = dd;
+  const dim3 ggrid((unsigned)(((size_t)B * dd + 255) / 256), 1, 2);
+  const dim3 sgrid((B + MmaSq::BM - 1) / MmaSq::BM, (in + dd + MmaSq::BN - 1) / MmaSq::BN, 2);
+  const size_t sh = MmaSq::LDS_FLOATS * sizeof(float);
+  for (int t = J - 1; t >= 0; --t) {
+    g.t = t;
+    s.t = t;
+    hipLaunchKernelGGL(lstm_gate_bwd, ggrid, dim3(256), 0, stream, g);
+    if (t > 0 || dx) hipLaunchKernelGGL(lstm_step_bwd_f32, sgrid, dim3(256), sh, stream, s);
+  }
+  FVTA_CHECK_LAUNCH("lstm_step_bwd");
+  DwArgs w;
+  w.plan = pv;
+  w.x = x;
+  w.out = out;
+  w.dz = sv.gates;
+  w.slabs = wv.slabs;
+  w.B = B;
+  w.J = J;
+  w.in = in;
+  w.d = dd;
+  w.tgroup = dw_tgroup(d);
+  w.nsplit = dw_nsplit(d);
+  const int MM = in + dd + 1, N4 = 4 * dd;
+  const dim3 wgrid((MM + MmaSq::BM - 1) / MmaSq::BM, N4 / MmaSq::BN, 2 * w.nsplit);
+  hipLaunchKernelGGL(lstm_dw_f32, wgrid, dim3(256), sh, stream, w);
+  FVTA_CHECK_LAUNCH("lstm_dw");
+  const size_t slab_elems = (size_t)MM * N4;
+  const unsigned rgrid = (unsigned)((slab_elems + 255) / 256);
+  if (d->share_fw_bw) {
+    hipLaunchKernelGGL(lstm_dw_reduce, dim3(rgrid), dim3(256), 0, stream, wv.slabs, 2 * w.nsplit, slab_elems,
+                       in + dd, N4, dkernel_fw, dbias_fw);
+  } else {
+    hipLaunchKernelGGL(lstm_dw_reduce, dim3(rgrid), dim3(256), 0, stream, wv.slabs, w.nsplit, slab_elems, in + dd,
+                       N4, dkernel_fw, dbias_fw);
+    hipLaunchKernelGGL(lstm_dw_reduce, dim3(rgrid), dim3(256), 0, stream, wv.slabs + (size_t)w.nsplit * slab_elems,
+                       w.nsplit, slab_elems, in + dd, N4, dkernel_bw, dbias_bw);
+  }
+  FVTA_CHECK_LAUNCH("lstm_dw_reduce");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_lstm_last_state(const fvta_lstm_desc* d, const void* plan, const float* out, int32_t s0,
+                                    int32_t count, float* dst, fvta_stream_t stream) {
+  if (int e = check_lstm_desc(d)) return e;
+  FVTA_CHECK_ARG(plan && out && dst && s0 >= 0 && count > 0 && s0 + count <= d->B, "lstm_last_state: bad range");
+  PlanView pv = plan_view(d, const_cast<void*>(plan));
+  hipLaunchKernelGGL(last_state_kernel, dim3(count), dim3(256), 0, (hipStream_t)stream, pv, out, s0, count, d->d,
+                     dst, (const float*)nullptr, (float*)nullptr);
+  FVTA_CHECK_LAUNCH("last_state");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_lstm_last_state_bwd(const fvta_lstm_desc* d, const void* plan, const float* d_dst, int32_t s0,
+                                        int32_t count, float* d_out, fvta_stream_t stream) {
+  if (int e = check_lstm_desc(d)) return e;
+  FVTA_CHECK_ARG(plan && d_dst && d_out && s0 >= 0 && count > 0 && s0 + count <= d->B,
+                 "lstm_last_state_bwd: bad range");
+  PlanView pv = plan_view(d, const_cast<void*>(plan));
+  hipLaunchKernelGGL(last_state_kernel, dim3(count), dim3(256), 0, (hipStream_t)stream, pv, (const float*)nullptr,
+                     s0, count, d->d, (float*)nullptr, d_dst, d_out);
+  FVTA_CHECK_LAUNCH("last_state_bwd");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_test_gemm(int32_t precision, int32_t layout, int32_t M, int32_t N, int32_t K, const float* A,
+                              const float* B, float* C, fvta_stream_t stream_) {
+  FVTA_CHECK_ARG(precision == FVTA_F32, "test_gemm: precision %d not built", precision);
+  FVTA_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 4 == 0 && N % 4 == 0 && M % 4 == 0,
+                 "test_gemm: M,N,K must be positive multiples of 4");
+  hipStream_t stream = (hipStream_t)stream_;
+  const dim3 grid((M + MmaSq::BM - 1) / MmaSq::BM, (N + MmaSq::BN - 1) / MmaSq::BN);
+  const size_t sh = MmaSq::LDS_FLOATS * sizeof(float);
+  if (layout == 0)
+    hipLaunchKernelGGL(test_gemm_f32<0>, grid, dim3(256), sh, stream, M, N, K, A, B, C);
+  else if (layout == 1)
+    hipLaunchKernelGGL(test_gemm_f32<1>, grid, dim3(256), sh, stream, M, N, K, A, B, C);
+  else if (layout == 2)
+    hipLaunchKernelGGL(test_gemm_f32<2>, grid, dim3(256), sh, stream, M, N, K, A, B, C);
+  else
+    FVTA_CHECK_ARG(false, "test_gemm: layout %d", layout);
+  FVTA_CHECK_LAUNCH("test_gemm");
+  return FVTA_OK;
+}

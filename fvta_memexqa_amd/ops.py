@@ -1,0 +1,181 @@
+"""Thin host-side handles over the C ABI (include/fvta_hip.h).
+
+These classes own the descriptor + scratch/saved buffers of one kernel family
+and pass raw device pointers to libfvta_hip.so.  No arithmetic happens here and
+there is no CPU path: every call needs a GPU and the built library.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import F32, BF16, AttnDesc, LstmDesc, ScorerDesc, check, ptr, stream_ptr
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.FvtaError("fvta_memexqa_amd needs an MI355X (no GPU visible); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _f32c(t):
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "expected a contiguous float32 CUDA tensor"
+    return t
+
+
+def _bytes(n, dev):
+    return torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
+
+
+# ------------------------------------------------------------------ test hook
+def test_gemm(A, B, layout, precision=F32):
+    lib = _lib.load()
+    require_gpu()
+    if layout == 0:
+        M, K = A.shape
+        N = B.shape[1]
+    elif layout == 1:
+        M, K = A.shape
+        N = B.shape[0]
+    else:
+        K, M = A.shape
+        N = B.shape[1]
+    C = torch.empty(M, N, device=A.device, dtype=torch.float32)
+    check(lib.fvta_test_gemm(precision, layout, M, N, K, ptr(_f32c(A)), ptr(_f32c(B)), ptr(C), stream_ptr()), "test_gemm")
+    return C
+
+
+# ------------------------------------------------------------------- encoders
+class BiLstm:
+    """One bi-LSTM call group (all sequences sharing a cell): model_v2.py:694-823.
+
+    x_off/out_off: int64 [B] element offsets of each sequence's first row in the
+    x / out arenas; seq_J: padded length per sequence; out_ld: output row stride.
+    """
+
+    def __init__(self, B, J, in_dim, d, x_off, out_off, seq_J, out_ld, share_fw_bw=True, precision=F32,
+                 training=False):
+        self.lib = _lib.load()
+        self.dev = require_gpu()
+        self.desc = LstmDesc(B, J, in_dim, d, int(share_fw_bw), precision, int(training), 0)
+        self.B, self.J, self.in_dim, self.d = B, J, in_dim, d
+        self.x_off = x_off.to(self.dev, torch.int64).contiguous()
+        self.out_off = out_off.to(self.dev, torch.int64).contiguous()
+        self.seq_J = seq_J.to(self.dev, torch.int32).contiguous()
+        self.out_ld = int(out_ld)
+        r = ctypes.byref(self.desc)
+        self.plan = _bytes(self.lib.fvta_lstm_plan_bytes(r), self.dev)
+        self.saved = _bytes(self.lib.fvta_lstm_saved_bytes(r), self.dev)
+        self.work = _bytes(self.lib.fvta_lstm_workspace_bytes(r), self.dev)
+        self.training = training
+        self.share = share_fw_bw
+
+    def make_plan(self, lens):
+        lens = lens.to(self.dev, torch.int32).contiguous()
+        check(self.lib.fvta_lstm_plan(ctypes.byref(self.desc), ptr(lens), ptr(self.seq_J), ptr(self.x_off),
+                                      ptr(self.out_off), self.out_ld, ptr(self.plan), stream_ptr()), "fvta_lstm_plan")
+
+    def forward(self, x, out, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None):
+        check(self.lib.fvta_bilstm_fwd(ctypes.byref(self.desc), ptr(self.plan), ptr(_f32c(x)), ptr(_f32c(out)),
+                                       ptr(_f32c(kernel_fw)), ptr(_f32c(bias_fw)), ptr(kernel_bw), ptr(bias_bw),
+                                       ptr(self.saved), ptr(self.work), stream_ptr()), "fvta_bilstm_fwd")
+
+    def backward(self, x, out, d_out, kernel_fw, kernel_bw, dx, dk_fw, db_fw, dk_bw=None, db_bw=None):
+        check(self.lib.fvta_bilstm_bwd(ctypes.byref(self.desc), ptr(self.plan), ptr(x), ptr(out), ptr(_f32c(d_out)),
+                                       ptr(kernel_fw), ptr(kernel_bw), ptr(self.saved), ptr(dx), ptr(dk_fw),
+                                       ptr(db_fw), ptr(dk_bw), ptr(db_bw), ptr(self.work), stream_ptr()),
+              "fvta_bilstm_bwd")
+
+    def last_state(self, out, s0, count, dst):
+        check(self.lib.fvta_lstm_last_state(ctypes.byref(self.desc), ptr(self.plan), ptr(out), s0, count, ptr(dst),
+                                            stream_ptr()), "fvta_lstm_last_state")
+
+    def last_state_bwd(self, d_dst, s0, count, d_out):
+        check(self.lib.fvta_lstm_last_state_bwd(ctypes.byref(self.desc), ptr(self.plan), ptr(_f32c(d_dst)), s0, count,
+                                                ptr(d_out), stream_ptr()), "fvta_lstm_last_state_bwd")
+
+
+def bilstm_simple(x, lens, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None, training=False, precision=F32):
+    """x [B,J,in] dense, lens [B] -> out [B,J,2d], last [B,2d] (test/convenience form)."""
+    B, J, din = x.shape
+    d = kernel_fw.shape[1] // 4
+    ar = torch.arange(B, dtype=torch.int64)
+    op = BiLstm(B, J, din, d, ar * J * din, ar * J * 2 * d, torch.full((B,), J, dtype=torch.int32), 2 * d,
+                share_fw_bw=kernel_bw is None, precision=precision, training=training)
+    op.make_plan(lens)
+    out = torch.empty(B, J, 2 * d, device=x.device, dtype=torch.float32)
+    op.forward(x.contiguous(), out, kernel_fw, bias_fw, kernel_bw, bias_bw)
+    last = torch.empty(B, 2 * d, device=x.device, dtype=torch.float32)
+    op.last_state(out, 0, B, last)
+    return out, last, op
+
+
+# ------------------------------------------------------------------ attention
+class FocalAttention:
+    """attention_3d (model_v2.py:210-298) / attention (125-201, K=1) handle."""
+
+    def __init__(self, N, K, T, JQ, w, simi, add_tanh, feat_order=0):
+        self.lib = _lib.load()
+        self.dev = require_gpu()
+        self.desc = AttnDesc(N, K, T, JQ, w, simi, feat_order, int(add_tanh))
+        r = ctypes.byref(self.desc)
+        sb = self.lib.fvta_attn_saved_bytes(r)
+        if sb == 0:
+            raise _lib.FvtaError("attention: " + self.lib.fvta_last_error().decode())
+        self.saved = _bytes(sb, self.dev)
+        self.work = _bytes(self.lib.fvta_attn_workspace_bytes(r), self.dev)
+        self.N, self.K, self.T, self.JQ, self.w = N, K, T, JQ, w
+
+    def forward(self, hinfo, hq, hmask, qmask, W, b, want_logits=False):
+        h_a = torch.empty(self.N, self.w, device=self.dev, dtype=torch.float32)
+        a_logits = torch.empty(self.N, self.K, self.T, self.JQ, device=self.dev, dtype=torch.float32) if want_logits else None
+        check(self.lib.fvta_attn_fwd(ctypes.byref(self.desc), ptr(_f32c(hinfo)), ptr(_f32c(hq)), ptr(hmask), ptr(qmask),
+                                     ptr(W), ptr(b), ptr(h_a), ptr(a_logits), ptr(self.saved), ptr(self.work),
+                                     stream_ptr()), "fvta_attn_fwd")
+        return h_a, a_logits
+
+    def backward(self, hinfo, hq, hmask, qmask, W, b, d_h_a, d_hinfo, d_hq, dW, db, accumulate):
+        check(self.lib.fvta_attn_bwd(ctypes.byref(self.desc), ptr(hinfo), ptr(hq), ptr(hmask), ptr(qmask), ptr(W),
+                                     ptr(b), ptr(_f32c(d_h_a)), ptr(self.saved), ptr(d_hinfo), ptr(d_hq), ptr(dW),
+                                     ptr(db), int(accumulate), ptr(self.work), stream_ptr()), "fvta_attn_bwd")
+
+
+def as_mask_u8(m):
+    if m is None:
+        return None
+    return m.to(torch.uint8).contiguous()
+
+
+# --------------------------------------------------------------------- scorer
+def scorer_ce_fwd(gq, g1, gch, W, b, y=None, use_eu_output=False, add_tanh=False):
+    lib = _lib.load()
+    N, C, w = gch.shape
+    desc = ScorerDesc(N, C, w, int(use_eu_output), int(add_tanh))
+    logits = torch.empty(N, C, device=gq.device, dtype=torch.float32)
+    yp = torch.empty_like(logits)
+    loss = torch.zeros(1, device=gq.device, dtype=torch.float32) if y is not None else None
+    check(lib.fvta_scorer_ce_fwd(ctypes.byref(desc), ptr(_f32c(gq)), ptr(_f32c(g1)), ptr(_f32c(gch)), ptr(W), ptr(b),
+                                 ptr(y), ptr(logits), ptr(yp), ptr(loss), stream_ptr()), "fvta_scorer_ce_fwd")
+    return logits, yp, loss
+
+
+def scorer_ce_bwd(gq, g1, gch, W, b, y, logits, yp, loss_scale, dW, db, use_eu_output=False, add_tanh=False):
+    lib = _lib.load()
+    N, C, w = gch.shape
+    desc = ScorerDesc(N, C, w, int(use_eu_output), int(add_tanh))
+    dgq, dg1, dgch = torch.empty_like(gq), torch.empty_like(g1), torch.empty_like(gch)
+    check(lib.fvta_scorer_ce_bwd(ctypes.byref(desc), ptr(gq), ptr(g1), ptr(gch), ptr(W), ptr(b), ptr(y), ptr(logits),
+                                 ptr(yp), float(loss_scale), ptr(dgq), ptr(dg1), ptr(dgch), ptr(dW), ptr(db),
+                                 stream_ptr()), "fvta_scorer_ce_bwd")
+    return dgq, dg1, dgch
+
+
+# ----------------------------------------------------------------- optimisers
+def adadelta_step(var, grad, accum, accum_update, lr, rho=0.95, eps=1e-8, grad_scale=1.0):
+    check(_lib.load().fvta_adadelta_step(ptr(var), ptr(grad), ptr(accum), ptr(accum_update), var.numel(), lr, rho, eps,
+                                         grad_scale, stream_ptr()), "fvta_adadelta_step")
+
+
+def adam_step(var, grad, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    check(_lib.load().fvta_adam_step(ptr(var), ptr(grad), ptr(m), ptr(v), var.numel(), lr, beta1, beta2, eps, int(t),
+                                     grad_scale, stream_ptr()), "fvta_adam_step")

@@ -1,0 +1,197 @@
+/* fvta_hip.h -- C ABI of libfvta_hip.so: the FVTA hot path on MI355X (gfx950).
+ *
+ * The reference (JunweiLiang/FVTA_MemexQA) has no FFI/plugin layer: its hot path
+ * is a TensorFlow-1 graph built in model_v2.py and entered through one
+ * `sess.run` per step (trainer.py:36-38, tester.py:21).  This header is the
+ * boundary a maintainer would bind instead (ctypes stub in INTEGRATION.md).  Each
+ * entry point names the reference code it replaces (file:line in the reference
+ * repository).
+ *
+ * Conventions
+ *  - extern "C"; every call returns an int status (FVTA_OK or a negative
+ *    FVTA_ERR_*); nothing throws; fvta_last_error() gives the message.
+ *  - every buffer is a CALLER-OWNED DEVICE pointer, row-major, innermost =
+ *    hidden/feature axis, 16-byte aligned.  The library never allocates:
+ *    scratch is passed in (`*_bytes` queries size it) and may be reused
+ *    between calls; "saved" buffers carry forward state to the backward call.
+ *  - every call is asynchronous on the given hipStream_t, re-entrant, and
+ *    keeps no global state.
+ *  - masks are bytes (0 / non-0), as the reference feeds bool arrays
+ *    (model_v2.py:1171-1200).
+ */
+#ifndef FVTA_HIP_H
+#define FVTA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FVTA_OK 0
+#define FVTA_ERR_INVALID_ARG (-1)
+#define FVTA_ERR_LAUNCH (-2)
+#define FVTA_ERR_UNSUPPORTED (-3)
+
+#define FVTA_F32 0  /* exact fp32 arithmetic (v_mfma_f32_32x32x2_f32 + VALU) */
+#define FVTA_BF16 1 /* bf16 MFMA operands, fp32 accumulate (BASELINE.json configs[2]) */
+
+typedef void* fvta_stream_t; /* hipStream_t */
+
+int fvta_version(void);
+const char* fvta_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * Focal attention: model_v2.py:210-298 `attention_3d` (K modalities) and
+ * model_v2.py:125-201 / model.py:117-186 `attention` (call with K = 1),
+ * including the helpers they inline: `linear` 75-100, `exp_mask`
+ * utils.py:210-213, `softsel`/`softmax` model_v2.py:23-48.
+ *
+ *   hinfo [N,K,T,w]  hq [N,JQ,w]  hmask [N,K,T]  qmask [N,JQ]  (masks may
+ *   both be NULL = unmasked, model_v2.py:146/233)
+ *   W [F], b [1]: att_logits/{W,b}; F = 3w|2w|4w for simi 1|2|3 (feature
+ *   order of model_v2.py:242-248; feat_order=1 selects model.py:149's order
+ *   for simi 2); simi 4 (cosine, model_v2.py:250-254) takes W = b = NULL.
+ *   out: h_a [N,w]; a_logits [N,K,T,JQ] masked logits (NULL = not wanted;
+ *   only tester.py:34-36 `step_vis` reads them).
+ * ------------------------------------------------------------------------- */
+typedef struct fvta_attn_desc {
+  int32_t N, K, T, JQ, w;
+  int32_t simi;       /* 1..4 */
+  int32_t feat_order; /* 0: model_v2.py order, 1: model.py:149 order (simi 2 only) */
+  int32_t add_tanh;   /* model_v2.py:92-93 via linear(add_tanh=) */
+} fvta_attn_desc;
+
+size_t fvta_attn_workspace_bytes(const fvta_attn_desc* d);
+size_t fvta_attn_saved_bytes(const fvta_attn_desc* d);
+
+int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const float* hq, const uint8_t* hmask,
+                  const uint8_t* qmask, const float* W, const float* b, float* h_a, float* a_logits,
+                  void* saved, void* workspace, fvta_stream_t stream);
+
+/* Backward of fvta_attn_fwd given d_h_a [N,w].  d_hinfo [N,K,T,w] and d_hq
+ * [N,JQ,w] are ACCUMULATED INTO when accumulate != 0, else overwritten; dW [F]
+ * and db [1] are always accumulated into (they are slices of the flat gradient
+ * buffer).  Gradient routing through reduce_max goes to the first arg-max
+ * (model_v2.py:268,278; TF splits exact ties). */
+int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const float* hq, const uint8_t* hmask,
+                  const uint8_t* qmask, const float* W, const float* b, const float* d_h_a,
+                  const void* saved, float* d_hinfo, float* d_hq, float* dW, float* db, int accumulate,
+                  void* workspace, fvta_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * bi-LSTM modality encoders: model_v2.py:652-661 (cells), 667-678 (lengths),
+ * 694/732/747/760/774/789/802/823 (the eight bidirectional_dynamic_rnn calls)
+ * and the context-tensor assembly 863-914 (outputs are written straight into
+ * the padded `hall` layout, so tf.pad/tf.stack never happen).
+ *
+ * One call runs every sequence that shares a cell (all 7 text streams of
+ * model_v2.py:692-812 in ONE call; the photo stream in a second call with
+ * `cell_img`).  Sequence s reads x + x_off[s] (+ t*in) and writes
+ * out + out_off[s] (+ t*out_ld): forward half at [0,d), backward half at
+ * [d,2d) of each output row; rows t >= len[s] (up to seq_J[s]) are zeroed as
+ * dynamic_rnn does.
+ * ------------------------------------------------------------------------- */
+typedef struct fvta_lstm_desc {
+  int32_t B;           /* sequences */
+  int32_t J;           /* max padded steps over the call */
+  int32_t in;          /* input features, multiple of 4 */
+  int32_t d;           /* hidden size, multiple of 32 */
+  int32_t share_fw_bw; /* 1: TF>=1.2 cell reuse, one kernel for both directions */
+  int32_t precision;   /* FVTA_F32 | FVTA_BF16 */
+  int32_t training;    /* 1: keep gate activations for fvta_bilstm_bwd */
+  int32_t reserved;
+} fvta_lstm_desc;
+
+size_t fvta_lstm_plan_bytes(const fvta_lstm_desc* d);
+size_t fvta_lstm_saved_bytes(const fvta_lstm_desc* d);
+size_t fvta_lstm_workspace_bytes(const fvta_lstm_desc* d);
+
+/* Length-sorted schedule for one call (device side, no host sync).
+ * len [B] int32 (mask row sums, model_v2.py:667-678), seq_J [B] padded length
+ * of each sequence, x_off/out_off [B] element offsets, out_ld row stride. */
+int fvta_lstm_plan(const fvta_lstm_desc* d, const int32_t* len, const int32_t* seq_J, const int64_t* x_off,
+                   const int64_t* out_off, int64_t out_ld, void* plan, fvta_stream_t stream);
+
+/* kernel [in+d, 4d] gate order i,j,f,o; bias [4d]; forget_bias 1.0 added at
+ * run time (BasicLSTMCell).  kernel_bw/bias_bw ignored when
+ * share_fw_bw. */
+int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const float* x, float* out,
+                    const float* kernel_fw, const float* bias_fw, const float* kernel_bw,
+                    const float* bias_bw, void* saved, void* workspace, fvta_stream_t stream);
+
+/* d_out has out's layout.  dx (x's layout, may be NULL) is overwritten;
+ * dkernel / dbias are accumulated into. */
+int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const float* x, const float* out,
+                    const float* d_out, const float* kernel_fw, const float* kernel_bw, void* saved,
+                    float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
+                    void* workspace, fvta_stream_t stream);
+
+/* Final states = concat(fw .h at t=len-1, bw .h at t=0) of sequences
+ * [s0, s0+count): lq model_v2.py:697, lchoices 807-812.  dst [count, 2d]. */
+int fvta_lstm_last_state(const fvta_lstm_desc* d, const void* plan, const float* out, int32_t s0,
+                         int32_t count, float* dst, fvta_stream_t stream);
+/* d_out[...] += d_dst at the same places. */
+int fvta_lstm_last_state_bwd(const fvta_lstm_desc* d, const void* plan, const float* d_dst, int32_t s0,
+                             int32_t count, float* d_out, fvta_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Answer scorer + loss: model_v2.py:1053-1083 (logits/yp) and 1085-1096
+ * (softmax cross-entropy, mean over ALL N rows).
+ *   gq [N,w], g1 [N,w], gch [N,C,w], W [5w] (7w with use_eu_output), b [1],
+ *   y [N,C] bytes (NULL at test time) -> logits [N,C], yp [N,C], loss [1].
+ * ------------------------------------------------------------------------- */
+typedef struct fvta_scorer_desc {
+  int32_t N, C, w;
+  int32_t use_eu_output; /* model_v2.py:1071-1073 */
+  int32_t add_tanh;      /* only with use_eu_output */
+} fvta_scorer_desc;
+
+int fvta_scorer_ce_fwd(const fvta_scorer_desc* d, const float* gq, const float* g1, const float* gch,
+                       const float* W, const float* b, const uint8_t* y, float* logits, float* yp,
+                       float* loss, fvta_stream_t stream);
+/* d loss = loss_scale (a host scalar: 1 for a single GPU, 1/world under data
+ * parallelism).  dgq/dg1 [N,w], dgch [N,C,w] overwritten; dW, db accumulated. */
+int fvta_scorer_ce_bwd(const fvta_scorer_desc* d, const float* gq, const float* g1, const float* gch,
+                       const float* W, const float* b, const uint8_t* y, const float* logits,
+                       const float* yp, float loss_scale, float* dgq, float* dg1, float* dgch, float* dW,
+                       float* db, fvta_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * AttentionGRUCell.__call__: attention_gru_cell.py:50-70 (one step).
+ *   inputs [B,d+1] (last column = attention gate g), state [B,d],
+ *   Wg [2d,d] + bg [d] (gates), Wc [d,d] (candidate, no bias), Wi [d,d] + bi [d]
+ * ------------------------------------------------------------------------- */
+int fvta_attgru_fwd(int32_t B, int32_t d, const float* inputs, const float* state, const float* Wg,
+                    const float* bg, const float* Wc, const float* Wi, const float* bi, float* new_h,
+                    float* saved /* [B,3d]: r, hWc, h_hat */, fvta_stream_t stream);
+int fvta_attgru_bwd(int32_t B, int32_t d, const float* inputs, const float* state, const float* Wg,
+                    const float* Wc, const float* Wi, const float* saved, const float* d_new_h,
+                    float* d_inputs, float* d_state, float* dWg, float* dbg, float* dWc, float* dWi,
+                    float* dbi, void* workspace /* B*4d floats */, fvta_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Parameter update over the flat fp32 parameter buffer: trainer.py:16
+ * AdadeltaOptimizer(init_lr) (rho 0.95, eps 1e-8) and the commented-out
+ * AdamOptimizer of trainer.py:17.  grad_scale multiplies the gradient first
+ * (1/world after the RCCL sum).
+ * ------------------------------------------------------------------------- */
+int fvta_adadelta_step(float* var, const float* grad, float* accum, float* accum_update, int64_t n,
+                       float lr, float rho, float eps, float grad_scale, fvta_stream_t stream);
+int fvta_adam_step(float* var, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int32_t t, float grad_scale, fvta_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Test hooks (not part of the reference surface): the MFMA tile engines the
+ * LSTM kernels are built from, exposed as plain GEMMs so tests can check the
+ * fragment layouts in isolation.  layout 0: C=A[M,K]*B[K,N];
+ * 1: C=A[M,K]*B[N,K]^T; 2: C=A[K,M]^T*B[K,N].
+ * ------------------------------------------------------------------------- */
+int fvta_test_gemm(int32_t precision, int32_t layout, int32_t M, int32_t N, int32_t K, const float* A,
+                   const float* B, float* C, fvta_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FVTA_HIP_H */

@@ -1,0 +1,171 @@
+"""GPU parity (forward): HIP kernels through the C ABI vs the CPU oracle on seeded inputs.
+
+Tolerance: BASELINE.json north_star -> 1e-4 relative fp32 (bit-exact answer argmax)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _close(a, b, rtol=RTOL, atol=1e-5, msg=""):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=msg)
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(128, 128, 16), (200, 260, 72), (64, 36, 100), (712, 2048, 256)])
+def test_mfma_f32_gemm_layouts(layout, shape):
+    """fragment maps of the fp32 MFMA tile engine, asymmetric operands."""
+    from fvta_memexqa_amd import ops
+    M, N, K = shape
+    M, N, K = (M + 3) // 4 * 4, (N + 3) // 4 * 4, (K + 3) // 4 * 4
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + layout)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    ref = A.double() @ B.double()
+    Ad = (A if layout != 2 else A.t().contiguous()).cuda()
+    Bd = (B if layout != 1 else B.t().contiguous()).cuda()
+    C = ops.test_gemm(Ad, Bd, layout)
+    _close(C, ref, rtol=1e-5, atol=1e-4 * K ** 0.5)
+
+
+@pytest.mark.parametrize("B,J,din,d,dense,share", [(5, 6, 8, 32, False, True), (300, 9, 12, 64, False, True),
+                                                   (130, 5, 200, 128, True, False), (64, 30, 200, 512, False, True)])
+def test_bilstm_forward_matches_oracle(B, J, din, d, dense, share):
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    g = torch.Generator().manual_seed(B + J + d)
+    x = torch.randn(B, J, din, generator=g)
+    lens = torch.full((B,), J) if dense else torch.randint(0, J + 1, (B,), generator=g)
+    lim = (6.0 / (din + d + 4 * d)) ** 0.5
+    k_fw = (torch.rand(din + d, 4 * d, generator=g) * 2 - 1) * lim * 2
+    b_fw = torch.randn(4 * d, generator=g) * 0.1
+    k_bw = None if share else (torch.rand(din + d, 4 * d, generator=g) * 2 - 1) * lim * 2
+    b_bw = None if share else torch.randn(4 * d, generator=g) * 0.1
+    mask = torch.arange(J)[None, :] < lens[:, None]
+    ref_out, ref_last = F.encode_stream(x.double(), mask, k_fw.double(), b_fw.double(),
+                                        None if share else k_bw.double(), None if share else b_bw.double())
+    cu = lambda t: None if t is None else t.cuda()
+    for training in (False, True):
+        out, last, _ = ops.bilstm_simple(cu(x), lens, cu(k_fw), cu(b_fw), cu(k_bw), cu(b_bw), training=training)
+        _close(out, ref_out, msg="out training=%s" % training)
+        _close(last, ref_last, msg="last")
+
+
+def _att_case(N, K, T, JQ, w, simi, tanh, masked, seed, p_valid=0.6):
+    g = torch.Generator().manual_seed(seed)
+    h = torch.randn(N, K, T, w, generator=g) * 0.5
+    q = torch.randn(N, JQ, w, generator=g) * 0.5
+    F_ = {1: 3 * w, 2: 2 * w, 3: 4 * w, 4: 0}[simi]
+    W = torch.randn(F_, 1, generator=g) * 0.1 if F_ else None
+    b = torch.randn(1, generator=g) * 0.1 if F_ else None
+    if masked:
+        hm = torch.rand(N, K, T, generator=g) < p_valid
+        qm = torch.rand(N, JQ, generator=g) < 0.8
+        qm[:, 0] = True
+        hm[0, 0] = False                      # a fully masked modality
+        if N > 1:
+            qm[N - 1] = False                 # a padded batch row
+        if K > 1:
+            hm[0, 1] = False
+            hm[0, 1, T // 2] = True           # single valid row
+    else:
+        hm = qm = None
+    return h, q, W, b, hm, qm
+
+
+@pytest.mark.parametrize("N,K,T,JQ,w", [(2, 3, 50, 10, 64), (3, 2, 100, 30, 256), (2, 6, 333, 30, 1024),
+                                        (1, 2, 70, 60, 2048), (2, 1, 40, 33, 128), (2, 2, 64, 7, 512)])
+@pytest.mark.parametrize("simi,tanh", [(1, False), (2, True), (3, True), (4, False)])
+@pytest.mark.parametrize("masked", [True, False])
+def test_attention_3d_forward_matches_oracle(N, K, T, JQ, w, simi, tanh, masked):
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    h, q, W, b, hm, qm = _att_case(N, K, T, JQ, w, simi, tanh, masked, seed=N * 100 + T + w + simi)
+    dd = lambda t: None if t is None else t.double()
+    ref_ha, ref_a = F.attention_3d(dd(h), dd(q), dd(W), dd(b), hm, qm, simiMatrix=simi, add_tanh=tanh)
+    op = ops.FocalAttention(N, K, T, JQ, w, simi, tanh)
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    ha, a = op.forward(cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)),
+                       None if W is None else cu(W.reshape(-1)), cu(b), want_logits=True)
+    _close(ha, ref_ha, msg="h_a")
+    _close(a, ref_a, rtol=1e-4, atol=2e-5, msg="a_logits")
+
+
+def test_attention_1d_question_form():
+    """model_v2.py:1044: attention(hq, g1[:,None,:], q_mask, ones) == K=1, 'JQ'=1."""
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    g = torch.Generator().manual_seed(11)
+    N, JQ, w = 4, 9, 128
+    hq = torch.randn(N, JQ, w, generator=g) * 0.5
+    g1 = torch.randn(N, 1, w, generator=g) * 0.5
+    W = torch.randn(2 * w, 1, generator=g) * 0.1
+    b = torch.randn(1, generator=g) * 0.1
+    qm = torch.arange(JQ)[None, :] < torch.tensor([9, 4, 1, 0])[:, None]
+    ones = torch.ones(N, 1, dtype=torch.bool)
+    ref, ref_a = F.attention(hq.double(), g1.double(), W.double(), b.double(), qm, ones, simiMatrix=2, add_tanh=True)
+    op = ops.FocalAttention(N, 1, JQ, 1, w, 2, True)
+    ha, a = op.forward(hq.cuda(), g1.cuda(), ops.as_mask_u8(qm).cuda(), ops.as_mask_u8(ones).cuda(),
+                       W.reshape(-1).cuda(), b.cuda(), want_logits=True)
+    _close(ha, ref)
+    _close(a.reshape(N, JQ, 1), ref_a, atol=2e-5)
+
+
+@pytest.mark.parametrize("eu,tanh", [(False, False), (True, True)])
+def test_scorer_ce_forward_and_backward(eu, tanh):
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    g = torch.Generator().manual_seed(5)
+    N, C, w = 6, 4, 256
+    gq = (torch.randn(N, w, generator=g) * 0.5).double().requires_grad_()
+    g1 = (torch.randn(N, w, generator=g) * 0.5).double().requires_grad_()
+    gch = (torch.randn(N, C, w, generator=g) * 0.5).double().requires_grad_()
+    W = (torch.randn((7 if eu else 5) * w, 1, generator=g) * 0.1).double().requires_grad_()
+    b = (torch.randn(1, generator=g) * 0.1).double().requires_grad_()
+    y = torch.zeros(N, C, dtype=torch.bool)
+    y[torch.arange(N - 1), torch.randint(0, C, (N - 1,), generator=g)] = True   # last row = padded (all False)
+    logits, yp = F.scorer(gq, g1, gch, W, b, eu, tanh)
+    loss = F.softmax_cross_entropy_mean(logits, y)
+    loss.backward()
+    f = lambda t: t.detach().float().cuda().contiguous()
+    yd = ops.as_mask_u8(y).cuda()
+    l2, yp2, loss2 = ops.scorer_ce_fwd(f(gq), f(g1), f(gch), f(W).reshape(-1), f(b), yd, eu, tanh)
+    _close(l2, logits)
+    _close(yp2, yp)
+    _close(loss2, loss.reshape(1))
+    assert (yp2.argmax(1).cpu() == yp.argmax(1)).all()
+    dW = torch.zeros(W.numel(), device="cuda")
+    db = torch.zeros(1, device="cuda")
+    dgq, dg1, dgch = ops.scorer_ce_bwd(f(gq), f(g1), f(gch), f(W).reshape(-1), f(b), yd, l2, yp2, 1.0, dW, db, eu, tanh)
+    _close(dgq, gq.grad, atol=1e-6)
+    _close(dg1, g1.grad, atol=1e-6)
+    _close(dgch, gch.grad, atol=1e-6)
+    _close(dW, W.grad.reshape(-1), atol=1e-6)
+    _close(db, b.grad, atol=1e-6)
+
+
+def test_optimizer_steps_match_oracle():
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_literal as L
+    rng = np.random.default_rng(0)
+    n = 1000
+    var, grad = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    a, au = np.abs(rng.standard_normal(n)).astype(np.float32), np.abs(rng.standard_normal(n)).astype(np.float32) * 0.01
+    ev, ea, eau = L.adadelta_step(var.astype(np.float64), grad.astype(np.float64), a.astype(np.float64), au.astype(np.float64), 0.5)
+    tv, ta, tau = [torch.from_numpy(v.copy()).cuda() for v in (var, a, au)]
+    ops.adadelta_step(tv, torch.from_numpy(grad).cuda(), ta, tau, 0.5)
+    _close(tv, ev, atol=1e-6)
+    _close(ta, ea, atol=1e-6)
+    _close(tau, eau, atol=1e-6)
+    m, v = rng.standard_normal(n).astype(np.float32) * 0.1, np.abs(rng.standard_normal(n)).astype(np.float32) * 0.1
+    ev, em, evv = L.adam_step(var.astype(np.float64), grad.astype(np.float64), m.astype(np.float64), v.astype(np.float64), 3, 0.001)
+    tv, tm, tvv = [torch.from_numpy(x.copy()).cuda() for x in (var, m, v)]
+    ops.adam_step(tv, torch.from_numpy(grad).cuda(), tm, tvv, 3, 0.001)
+    _close(tv, ev, atol=1e-6)
+    _close(tm, em, atol=1e-6)
+    _close(tvv, evv, atol=1e-6)
