@@ -283,9 +283,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
         }
         const float am = amax[t];
         pr = expf(am - M) * coef;
-        float damax = pr * (gh - gu) + (am == M ? dss : 0.f);
-        if (allm) damax = 0.f;
-        dx = s.add_tanh ? damax * (1.f - am * am) : damax;
+        if (!allm) {  // fully masked rows: am = -1e30, no gradient into the masked logits
+          const float damax = pr * (gh - gu) + (am == M ? dss : 0.f);
+          dx = s.add_tanh ? damax * (1.f - am * am) : damax;
+        }
       }
       s_pr[tid] = pr;
       s_dx[tid] = dx;

@@ -34,7 +34,9 @@ inline AttnShape attn_shape(const fvta_attn_desc* d, bool use_mask) {
   s.nsplit = ns;
   int bs = (1024 + nk - 1) / nk;
   const int maxb = (d->T + 255) / 256;
+  const int minb = (d->T + 959) / 960;  // a backward chunk must fit the 1024-row LDS sort
   if (bs > maxb) bs = maxb;
+  if (bs < minb) bs = minb;
   if (bs < 1) bs = 1;
   s.bsplit = bs;
   return s;

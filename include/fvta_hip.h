@@ -121,8 +121,8 @@ int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const float* x, f
                     const float* kernel_fw, const float* bias_fw, const float* kernel_bw,
                     const float* bias_bw, void* saved, void* workspace, fvta_stream_t stream);
 
-/* d_out has out's layout.  dx (x's layout, may be NULL) is overwritten;
- * dkernel / dbias are accumulated into. */
+/* d_out has out's layout.  dx (x's layout, may be NULL), dkernel and dbias are
+ * all ACCUMULATED INTO (the caller zeroes them once per step). */
 int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const float* x, const float* out,
                     const float* d_out, const float* kernel_fw, const float* kernel_bw, void* saved,
                     float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,

@@ -1,0 +1,122 @@
+"""GPU parity (backward): HIP gradients vs torch autograd on the fp64 fused oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol=1e-4, atol=1e-5, msg=""):
+    a = a.detach().cpu().double().numpy()
+    b = b.detach().cpu().double().numpy()
+    scale = max(1.0, float(np.abs(b).max()))
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol * scale, err_msg=msg)
+
+
+@pytest.mark.parametrize("N,K,T,JQ,w", [(2, 3, 50, 10, 64), (3, 2, 100, 30, 256), (2, 6, 333, 30, 1024),
+                                        (1, 2, 70, 60, 2048), (2, 1, 1100, 5, 128), (2, 2, 64, 7, 512)])
+@pytest.mark.parametrize("simi,tanh", [(1, False), (2, True), (3, True)])
+@pytest.mark.parametrize("masked", [True, False])
+def test_attention_3d_backward_matches_autograd(N, K, T, JQ, w, simi, tanh, masked):
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    from tests.test_gpu_forward import _att_case
+    h, q, W, b, hm, qm = _att_case(N, K, T, JQ, w, simi, tanh, masked, seed=N * 100 + T + w + simi + 1)
+    if masked:
+        hm[0, 0, :3] = True   # keep every (n,k) with at least one valid row: the fully masked case is
+        if N > 1:              # covered separately (documented deviation for the masked-logit gradient)
+            qm[N - 1, :2] = True
+    g = torch.Generator().manual_seed(99)
+    gout = torch.randn(N, w, generator=g)
+    hd, qd, Wd, bd = [t.double().requires_grad_() for t in (h, q, W, b)]
+    ref_ha, _ = F.attention_3d(hd, qd, Wd, bd, hm, qm, simiMatrix=simi, add_tanh=tanh)
+    (ref_ha * gout.double()).sum().backward()
+
+    op = ops.FocalAttention(N, K, T, JQ, w, simi, tanh)
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    hc, qc, Wc, bc = cu(h), cu(q), cu(W.reshape(-1)), cu(b)
+    hmc, qmc = cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm))
+    ha, _ = op.forward(hc, qc, hmc, qmc, Wc, bc)
+    dh = torch.full_like(hc, 7.0)           # overwritten (accumulate=0)
+    dq = torch.full_like(qc, 7.0)
+    dW = torch.zeros_like(Wc)
+    db = torch.zeros(1, device="cuda")
+    op.backward(hc, qc, hmc, qmc, Wc, bc, cu(gout), dh, dq, dW, db, accumulate=False)
+    _close(dh, hd.grad, msg="d_hinfo")
+    _close(dq, qd.grad, msg="d_hq")
+    _close(dW, Wd.grad.reshape(-1), msg="dW")
+    _close(db, bd.grad, msg="db")
+    # accumulate mode adds on top
+    dh2 = torch.ones_like(hc)
+    dq2 = torch.ones_like(qc)
+    op.backward(hc, qc, hmc, qmc, Wc, bc, cu(gout), dh2, dq2, dW, db, accumulate=True)
+    _close(dh2 - 1.0, hd.grad, atol=2e-5, msg="d_hinfo accumulate")
+    _close(dq2 - 1.0, qd.grad, atol=2e-5, msg="d_hq accumulate")
+    _close(dW, 2 * Wd.grad.reshape(-1), atol=3e-5, msg="dW accumulates")
+
+
+def test_attention_backward_fully_masked_rows_direct_term():
+    """Fully masked (n,k): p = 1/T over all T; the direct term p*r*g still reaches d_hinfo."""
+    from fvta_memexqa_amd import ops
+    N, K, T, JQ, w = 1, 2, 40, 5, 64
+    g = torch.Generator().manual_seed(3)
+    h = torch.randn(N, K, T, w, generator=g)
+    q = torch.randn(N, JQ, w, generator=g)
+    W = torch.randn(2 * w, generator=g) * 0.1
+    b = torch.zeros(1)
+    hm = torch.zeros(N, K, T, dtype=torch.bool)        # both modalities empty -> r = 1/K
+    qm = torch.ones(N, JQ, dtype=torch.bool)
+    gout = torch.randn(N, w, generator=g)
+    op = ops.FocalAttention(N, K, T, JQ, w, 2, True)
+    cu = lambda t: t.cuda().contiguous()
+    op.forward(cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)), cu(W), cu(b))
+    dh = torch.zeros(N, K, T, w, device="cuda")
+    dq = torch.zeros(N, JQ, w, device="cuda")
+    dW = torch.zeros(2 * w, device="cuda")
+    db = torch.zeros(1, device="cuda")
+    op.backward(cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)), cu(W), cu(b), cu(gout), dh, dq, dW, db, False)
+    exp = (gout[:, None, None, :] / (K * T)).expand(N, K, T, w)
+    _close(dh, exp)
+    assert float(dW.abs().max()) == 0.0 and float(dq.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,J,din,d,dense,share,need_dx", [(5, 6, 8, 32, False, True, True),
+                                                           (300, 9, 12, 64, False, True, True),
+                                                           (130, 5, 200, 128, True, False, True),
+                                                           (70, 17, 100, 64, False, False, False),
+                                                           (64, 30, 200, 512, False, True, True)])
+def test_bilstm_backward_matches_autograd(B, J, din, d, dense, share, need_dx):
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    g = torch.Generator().manual_seed(B + J + d + 1)
+    x = torch.randn(B, J, din, generator=g)
+    lens = torch.full((B,), J) if dense else torch.randint(0, J + 1, (B,), generator=g)
+    lim = (6.0 / (din + d + 4 * d)) ** 0.5
+    mk = lambda: ((torch.rand(din + d, 4 * d, generator=g) * 2 - 1) * lim * 2, torch.randn(4 * d, generator=g) * 0.1)
+    k_fw, b_fw = mk()
+    k_bw, b_bw = (None, None) if share else mk()
+    mask = torch.arange(J)[None, :] < lens[:, None]
+    g_out = torch.randn(B, J, 2 * d, generator=g) * mask[:, :, None]
+    g_last = torch.randn(B, 2 * d, generator=g)
+    leaves = [t.double().requires_grad_() for t in (x, k_fw, b_fw)]
+    if not share:
+        leaves += [k_bw.double().requires_grad_(), b_bw.double().requires_grad_()]
+    ref_out, ref_last = F.encode_stream(leaves[0], mask, leaves[1], leaves[2], *(leaves[3:] if not share else []))
+    ((ref_out * g_out.double()).sum() + (ref_last * g_last.double()).sum()).backward()
+
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    xc, kf, bf, kb, bb = cu(x), cu(k_fw), cu(b_fw), cu(k_bw), cu(b_bw)
+    out, last, op = ops.bilstm_simple(xc, lens, kf, bf, kb, bb, training=True)
+    d_out = cu(g_out).clone()
+    op.last_state_bwd(cu(g_last), 0, B, d_out)
+    dx = torch.zeros_like(xc) if need_dx else None
+    dkf, dbf = torch.zeros_like(kf), torch.zeros_like(bf)
+    dkb, dbb = (None, None) if share else (torch.zeros_like(kb), torch.zeros_like(bb))
+    op.backward(xc, out, d_out, kf, kb, dx, dkf, dbf, dkb, dbb)
+    if need_dx:
+        _close(dx, leaves[0].grad, msg="dx")
+    _close(dkf, leaves[1].grad, msg="dkernel_fw")
+    _close(dbf, leaves[2].grad, msg="dbias_fw")
+    if not share:
+        _close(dkb, leaves[3].grad, msg="dkernel_bw")
+        _close(dbb, leaves[4].grad, msg="dbias_bw")
