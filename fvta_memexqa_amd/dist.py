@@ -1,0 +1,63 @@
+"""Data parallelism over QA pairs: one process per GPU, albums/questions sharded
+along the batch axis, ONE collective per training step -- a sum all-reduce of the flat fp32
+gradient buffer over RCCL/xGMI (backend "nccl" is RCCL on ROCm; "gloo" for the CPU tests).
+The reference has no distributed code at all; forward/inference needs no collective."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Join the process group described by RANK/WORLD_SIZE/MASTER_* (torch.distributed.run)."""
+    ws, rank, local = world()
+    if ws == 1:
+        return ws, rank, local
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=ws, **kw)
+    return ws, rank, local
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def shard_range(global_batch, ws, rank):
+    """Contiguous equal shards of the global batch (config 4: 512 -> 8 x 64)."""
+    if global_batch % ws:
+        raise ValueError("global batch %d is not divisible by world size %d" % (global_batch, ws))
+    per = global_batch // ws
+    return rank * per, (rank + 1) * per
+
+
+def allreduce_grads(flat_grad):
+    """Sum the single flat gradient bucket across ranks; returns the 1/world factor the optimiser
+    must apply so that the update equals the reference's global-batch mean (model_v2.py:1090)."""
+    if not is_dist():
+        return 1.0
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    return 1.0 / dist.get_world_size()
+
+
+def barrier():
+    if is_dist():
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    if not is_dist():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,440 @@
+"""Host-side mirror of the reference's `model_v2.py` surface for the FVTA hot path.
+
+What the reference builds as a TF-1 graph (model_v2.py:361-1096) is here a thin
+Python object that owns device buffers and calls the HIP kernels of
+libfvta_hip.so in order.  No arithmetic of the path runs in Python/PyTorch:
+torch owns memory, streams and `torch.distributed`.
+
+Surface kept from the reference:
+  get_model(config) -> Model                      model_v2.py:12-17
+  Model.loss / .yp / .logits / .global_step       model_v2.py:366, 1082-1095
+  Model.att_logits / .q_att_logits / .hall        model_v2.py:914, 1022, 1045 (vis)
+  parameter names of the TF checkpoint / weights.npz (main.py:578-588)
+
+Entry level: the ENCODER INPUTS (embedded token / photo features + masks), i.e.
+the tensors x* of model_v2.py:680-688.  The embedding front-end
+(model_v2.py:524-645) and get_feed_dict (1099-1565) are SURVEY 8f "next" rows.
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import F32, BF16
+
+SUPPORTED_W = (64, 128, 256, 512, 1024, 2048)
+
+
+def get_model(config):
+    """model_v2.py:12-17."""
+    return Model(config, "model_%s" % getattr(config, "modelname", "fvta"))
+
+
+def _cfg(config, name, default):
+    if isinstance(config, dict):
+        return config.get(name, default)
+    return getattr(config, name, default)
+
+
+def padded_hidden(d):
+    """Hidden size the kernels run at: w = 2*d_pad must be a supported width.
+    Zero-padded units are exact: their gates see z = 0 -> c = h = 0, and every
+    gradient into a padded parameter is 0."""
+    for w in SUPPORTED_W:
+        if 2 * d <= w:
+            return w // 2
+    raise ValueError("hidden_size %d too large (max %d)" % (d, SUPPORTED_W[-1] // 2))
+
+
+class ParamStore:
+    """All trainables in ONE flat fp32 device buffer (+ one flat gradient buffer):
+    a single RCCL all-reduce bucket and a single optimiser launch per step."""
+
+    def __init__(self, specs, device):
+        self.specs = specs  # name -> shape (padded)
+        self.offsets = {}
+        off = 0
+        for name, shape in specs.items():
+            self.offsets[name] = off
+            off += (int(np.prod(shape)) + 63) // 64 * 64  # 256-byte aligned slices
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+
+    def view(self, name, grad=False):
+        off, shape = self.offsets[name], self.specs[name]
+        buf = self.grad if grad else self.flat
+        return buf[off:off + int(np.prod(shape))].view(*shape)
+
+
+class _Layout:
+    """Per batch-shape cache: arenas, offset tables and kernel handles."""
+    pass
+
+
+class Model:
+    # reference checkpoint names
+    N_TEXT_K = "reader/text/utext/%s/basic_lstm_cell/kernel"
+    N_TEXT_B = "reader/text/utext/%s/basic_lstm_cell/bias"
+    N_IMG_K = "reader/image/uimage/%s/basic_lstm_cell/kernel"
+    N_IMG_B = "reader/image/uimage/%s/basic_lstm_cell/bias"
+    N_ATT_W, N_ATT_B = "attention/all/att_logits/W", "attention/all/att_logits/b"
+    N_QATT_W, N_QATT_B = "question_emb/question_att/att_logits/W", "question_emb/question_att/att_logits/b"
+    N_OUT_W, N_OUT_B = "output/choicelogits/W", "output/choicelogits/b"
+
+    def __init__(self, config, scope="model", text_in=None, img_in=None, device=None):
+        self.scope = scope
+        self.config = config
+        self.dev = device or ops.require_gpu()
+        self.d = int(_cfg(config, "hidden_size", 100))
+        self.dp = padded_hidden(self.d)
+        self.w, self.wp = 2 * self.d, 2 * self.dp
+        self.N = _cfg(config, "batch_size", None)
+        self.num_choice = int(_cfg(config, "num_choice", 4))      # model_v2.py:381 reads an undefined flag; model.py:353 says 4
+        self.simi = int(_cfg(config, "simiMatrix", 1))
+        self.add_tanh = bool(_cfg(config, "add_tanh", False))
+        self.use_question_att = bool(_cfg(config, "use_question_att", False))
+        self.use_eu_output = bool(_cfg(config, "use_eu_output", False))
+        self.share_fw_bw = bool(_cfg(config, "share_fw_bw", True))
+        self.precision = {"f32": F32, "bf16": BF16}[_cfg(config, "precision", "f32")]
+        if _cfg(config, "wd", None) not in (None, 0.0):
+            raise NotImplementedError("weight decay (--wd) is not built yet")
+        if float(_cfg(config, "keep_prob", 1.0)) != 1.0:
+            raise NotImplementedError("LSTM input dropout (--keep_prob < 1) is not built yet")
+        if _cfg(config, "use_time_warp", False) or _cfg(config, "use_time_warp_att", False):
+            raise NotImplementedError("time warp is not built yet")
+        if _cfg(config, "use_bidirection", False):
+            raise NotImplementedError("use_bidirection: the 3-D branch cannot run in the reference either (SURVEY 3.5)")
+        if self.simi not in (1, 2, 3, 4):
+            raise ValueError("similarity matrix not implemented")    # model_v2.py:255-257 (sys.exit there)
+        self.text_in = int(text_in if text_in is not None else _cfg(config, "text_in", 200))
+        self.img_in = int(img_in if img_in is not None else _cfg(config, "img_in", 100))
+        if self.text_in % 4 or self.img_in % 4:
+            raise ValueError("encoder input widths must be multiples of 4 (pad the embedding)")
+        self.global_step = 0                                            # model_v2.py:366
+        self.loss = self.yp = self.logits = None
+        self.att_logits = self.q_att_logits = self.hall = None
+        self._layouts = {}
+
+        dp, wp = self.dp, self.wp
+        F = {1: 3 * wp, 2: 2 * wp, 3: 4 * wp, 4: 0}[self.simi]
+        dirs = ["fw"] if self.share_fw_bw else ["fw", "bw"]
+        specs = {}
+        for dr in dirs:
+            specs[self.N_TEXT_K % dr] = (self.text_in + dp, 4 * dp)
+            specs[self.N_TEXT_B % dr] = (4 * dp,)
+        for dr in dirs:
+            specs[self.N_IMG_K % dr] = (self.img_in + dp, 4 * dp)
+            specs[self.N_IMG_B % dr] = (4 * dp,)
+        if F:
+            specs[self.N_ATT_W], specs[self.N_ATT_B] = (F,), (1,)
+            if self.use_question_att:
+                specs[self.N_QATT_W], specs[self.N_QATT_B] = (F,), (1,)
+        specs[self.N_OUT_W] = ((7 if self.use_eu_output else 5) * wp,)
+        specs[self.N_OUT_B] = (1,)
+        self.params = ParamStore(specs, self.dev)
+        self.init_parameters(int(_cfg(config, "weight_seed", 42)))
+
+    # ------------------------------------------------------------ parameters
+    def _pad_kernel(self, k, din):
+        """reference [din+d, 4d] -> padded [din+dp, 4dp] (gate blocks i,j,f,o kept apart)."""
+        d, dp = self.d, self.dp
+        out = torch.zeros(din + dp, 4 * dp, dtype=torch.float32)
+        for g in range(4):
+            out[:din, g * dp:g * dp + d] = k[:din, g * d:(g + 1) * d]
+            out[din:din + d, g * dp:g * dp + d] = k[din:, g * d:(g + 1) * d]
+        return out
+
+    def _unpad_kernel(self, kp, din):
+        d, dp = self.d, self.dp
+        out = torch.zeros(din + d, 4 * d, dtype=torch.float32)
+        for g in range(4):
+            out[:din, g * d:(g + 1) * d] = kp[:din, g * dp:g * dp + d]
+            out[din:, g * d:(g + 1) * d] = kp[din:din + d, g * dp:g * dp + d]
+        return out
+
+    def _pad_blocks(self, v, nblk, blk, blkp):
+        out = torch.zeros(nblk * blkp, dtype=torch.float32)
+        for g in range(nblk):
+            out[g * blkp:g * blkp + blk] = v[g * blk:(g + 1) * blk]
+        return out
+
+    def _pad_feat(self, v):
+        """[F*w] feature vectors (att W, scorer W): each w-block = [fw d | bw d] -> [fw dp | bw dp]."""
+        d, dp = self.d, self.dp
+        return self._pad_blocks(v.reshape(-1), v.numel() // d, d, dp)
+
+    def _unpad_feat(self, v):
+        d, dp = self.d, self.dp
+        n = v.numel() // dp
+        return torch.cat([v[g * dp:g * dp + d] for g in range(n)])
+
+    def set_weights(self, weights):
+        """weights: dict reference-name -> array in the REFERENCE's shapes
+        (main.py:578-588 `weights.npz` layout)."""
+        for name, val in weights.items():
+            if name not in self.params.specs:
+                continue
+            t = torch.as_tensor(np.asarray(val), dtype=torch.float32)
+            if name.endswith("basic_lstm_cell/kernel"):
+                din = self.text_in if "utext" in name else self.img_in
+                t = self._pad_kernel(t, din)
+            elif name.endswith("basic_lstm_cell/bias"):
+                t = self._pad_blocks(t, 4, self.d, self.dp)
+            elif name.endswith("/W"):
+                t = self._pad_feat(t)
+            self.params.view(name).copy_(t.reshape(self.params.specs[name]).to(self.dev))
+
+    def get_weights(self, grad=False):
+        """-> dict reference-name -> numpy array in the reference's shapes."""
+        out = {}
+        for name in self.params.specs:
+            t = self.params.view(name, grad=grad).detach().cpu()
+            if name.endswith("basic_lstm_cell/kernel"):
+                t = self._unpad_kernel(t, self.text_in if "utext" in name else self.img_in)
+            elif name.endswith("basic_lstm_cell/bias"):
+                t = torch.cat([t[g * self.dp:g * self.dp + self.d] for g in range(4)])
+            elif name.endswith("/W"):
+                t = self._unpad_feat(t).reshape(-1, 1)
+            out[name] = t.numpy()
+        return out
+
+    def init_parameters(self, seed=42):
+        """Reference initialisers: linear W ~ truncated_normal(0.1), b = 0
+        (model_v2.py:88-89); LSTM kernels Glorot-uniform, zero bias [TF default]."""
+        from .synth import _glorot, _trunc_normal
+        g = torch.Generator().manual_seed(seed)
+        wts = {}
+        for name, shape in self.params.specs.items():
+            if name.endswith("basic_lstm_cell/kernel"):
+                din = self.text_in if "utext" in name else self.img_in
+                wts[name] = _glorot(g, din + self.d, 4 * self.d)
+            elif name.endswith("/W"):
+                wts[name] = _trunc_normal(g, (shape[0] // self.dp * self.d, 1))
+        self.set_weights(wts)
+
+    def set_oracle_params(self, p):
+        """Parameters in the oracle's short-key format (fvta_memexqa_amd.synth.make_params)."""
+        m = {"text_kernel": self.N_TEXT_K % "fw", "text_bias": self.N_TEXT_B % "fw",
+             "text_kernel_bw": self.N_TEXT_K % "bw", "text_bias_bw": self.N_TEXT_B % "bw",
+             "image_kernel": self.N_IMG_K % "fw", "image_bias": self.N_IMG_B % "fw",
+             "image_kernel_bw": self.N_IMG_K % "bw", "image_bias_bw": self.N_IMG_B % "bw",
+             "att_W": self.N_ATT_W, "att_b": self.N_ATT_B, "qatt_W": self.N_QATT_W, "qatt_b": self.N_QATT_B,
+             "out_W": self.N_OUT_W, "out_b": self.N_OUT_B}
+        self.set_weights({m[k]: v for k, v in p.items() if k in m})
+
+    def get_oracle_grads(self):
+        g = self.get_weights(grad=True)
+        m = {self.N_TEXT_K % "fw": "text_kernel", self.N_TEXT_B % "fw": "text_bias",
+             self.N_TEXT_K % "bw": "text_kernel_bw", self.N_TEXT_B % "bw": "text_bias_bw",
+             self.N_IMG_K % "fw": "image_kernel", self.N_IMG_B % "fw": "image_bias",
+             self.N_IMG_K % "bw": "image_kernel_bw", self.N_IMG_B % "bw": "image_bias_bw",
+             self.N_ATT_W: "att_W", self.N_ATT_B: "att_b", self.N_QATT_W: "qatt_W", self.N_QATT_B: "qatt_b",
+             self.N_OUT_W: "out_W", self.N_OUT_B: "out_b"}
+        return {m[k]: v for k, v in g.items()}
+
+    # ---------------------------------------------------------------- layout
+    def _layout(self, shapes, training):
+        key = (tuple(shapes["ctx"]), shapes["q"], shapes["choices"], bool(training))
+        if key in self._layouts:
+            return self._layouts[key]
+        L = _Layout()
+        dev, wp, dp = self.dev, self.wp, self.dp
+        N, JQ = shapes["q"]
+        _, C, JA = shapes["choices"]
+        ctx = shapes["ctx"]  # tuple of (cell, dims) with dims = (N,M,J) or (N,M,JI,J)
+        K = len(ctx)
+        M = ctx[0][1][1]
+        per_album = [int(np.prod(dims[2:])) for _, dims in ctx]
+        JMAX = max(per_album)                                   # model_v2.py:869
+        T = M * JMAX
+        L.N, L.K, L.M, L.JMAX, L.T, L.JQ, L.C, L.JA = N, K, M, JMAX, T, JQ, C, JA
+        # ---- output arena rows: [hall N*K*T | hq N*JQ | hchoices N*C*JA]
+        L.row_hall, L.row_hq = 0, N * K * T
+        L.row_hch = L.row_hq + N * JQ
+        L.rows = L.row_hch + N * C * JA
+        L.arena = torch.zeros(L.rows, wp, dtype=torch.float32, device=dev)
+        L.d_arena = torch.zeros(L.rows, wp, dtype=torch.float32, device=dev) if training else None
+        L.hall = L.arena[:L.row_hq].view(N, K, T, wp)
+        L.hq = L.arena[L.row_hq:L.row_hch].view(N, JQ, wp)
+        L.hch = L.arena[L.row_hch:].view(N, C, JA, wp)
+        L.hall_mask = torch.zeros(N, K, M, JMAX, dtype=torch.uint8, device=dev)
+        # ---- sequence groups (text cell / image cell)
+        groups = {"text": [], "image": []}
+
+        def seq_rows(k, dims):
+            """first arena row of every sequence of context stream k"""
+            n = torch.arange(N).view(N, 1, 1)
+            m = torch.arange(M).view(1, M, 1)
+            if len(dims) == 3:
+                ji = torch.zeros(1, 1, 1, dtype=torch.int64)
+                step = 0
+            else:
+                ji = torch.arange(dims[2]).view(1, 1, -1)
+                step = dims[3]
+            return (((n * K + k) * M + m) * JMAX + ji * step).reshape(-1)
+
+        groups["text"].append(dict(name="q", count=N, J=JQ, rows=L.row_hq + torch.arange(N) * JQ))
+        groups["text"].append(dict(name="choices", count=N * C, J=JA, rows=L.row_hch + torch.arange(N * C) * JA))
+        L.ctx_slots = []
+        for k, (cell, dims) in enumerate(ctx):
+            J = dims[-1]
+            cnt = int(np.prod(dims[:-1]))
+            groups[cell].append(dict(name="ctx%d" % k, count=cnt, J=J, rows=seq_rows(k, dims)))
+            L.ctx_slots.append((cell, len(groups[cell]) - 1, dims))
+        L.groups = {}
+        for cell, segs in groups.items():
+            if not segs:
+                continue
+            din = self.text_in if cell == "text" else self.img_in
+            G = SimpleNamespace(segs=segs, din=din)
+            B = sum(s["count"] for s in segs)
+            Jmax = max(s["J"] for s in segs)
+            x_off, out_off, seq_J, pos = [], [], [], 0
+            s0 = 0
+            for s in segs:
+                s["x_elem0"] = pos
+                s["s0"] = s0
+                x_off.append(pos + torch.arange(s["count"], dtype=torch.int64) * s["J"] * din)
+                out_off.append(s["rows"].to(torch.int64) * wp)
+                seq_J.append(torch.full((s["count"],), s["J"], dtype=torch.int32))
+                pos += s["count"] * s["J"] * din
+                s0 += s["count"]
+            G.B, G.J = B, Jmax
+            G.x = torch.zeros(pos, dtype=torch.float32, device=dev)
+            G.dx = None
+            G.lens = torch.zeros(B, dtype=torch.int32, device=dev)
+            G.op = ops.BiLstm(B, Jmax, din, dp, torch.cat(x_off), torch.cat(out_off), torch.cat(seq_J), wp,
+                              share_fw_bw=self.share_fw_bw, precision=self.precision, training=training)
+            L.groups[cell] = G
+        L.q_mask = torch.zeros(N, JQ, dtype=torch.uint8, device=dev)
+        L.ones_mask = torch.ones(N, 1, dtype=torch.uint8, device=dev)
+        L.att = ops.FocalAttention(N, K, T, JQ, wp, self.simi, self.add_tanh)
+        L.qatt = ops.FocalAttention(N, 1, JQ, 1, wp, self.simi, self.add_tanh) if self.use_question_att else None
+        L.lq = torch.zeros(N, wp, dtype=torch.float32, device=dev)
+        L.lch = torch.zeros(N, C, wp, dtype=torch.float32, device=dev)
+        L.y = torch.zeros(N, C, dtype=torch.uint8, device=dev)
+        self._layouts[key] = L
+        return L
+
+    def seg_x(self, L, cell, si):
+        """arena view of a segment's encoder input, shaped [count, J, in]"""
+        G = L.groups[cell]
+        s = G.segs[si]
+        n = s["count"] * s["J"] * G.din
+        return G.x[s["x_elem0"]:s["x_elem0"] + n].view(s["count"], s["J"], G.din)
+
+    @staticmethod
+    def shapes_of(inputs):
+        return dict(ctx=tuple((st.get("cell", "text"), tuple(st["x"].shape[:-1])) for st in inputs["ctx"]),
+                    q=tuple(inputs["q"]["x"].shape[:-1]), choices=tuple(inputs["choices"]["x"].shape[:-1]))
+
+    def get_feed_dict(self, batch, is_train=False):
+        """model_v2.py:1099: here a batch already holds ENCODER inputs (the oracle
+        `inputs` dict, optionally with 'num_examples'); the token-id form of the
+        reference's feed dict needs the embedding front-end."""
+        if not (isinstance(batch, dict) and "ctx" in batch):
+            raise NotImplementedError("token-id batches need the embedding front-end (SURVEY.md 8f rank 1-2)")
+        return batch
+
+    def load_inputs(self, inputs, training=False):
+        """Copy encoder inputs (oracle `inputs` format, any device) into the arenas.
+        Host-side plumbing: masks -> lengths (model_v2.py:667-678) and the mask
+        pad/stack of model_v2.py:890-912."""
+        L = self._layout(self.shapes_of(inputs), training)
+        dev = self.dev
+
+        def put(cell, si, x, mask):
+            self.seg_x(L, cell, si).copy_(x.reshape(-1, x.shape[-2], x.shape[-1]).to(dev, torch.float32))
+            G = L.groups[cell]
+            s = G.segs[si]
+            G.lens[s["s0"]:s["s0"] + s["count"]] = mask.reshape(-1, mask.shape[-1]).to(dev).sum(1).to(torch.int32)
+
+        put("text", 0, inputs["q"]["x"], inputs["q"]["mask"])
+        put("text", 1, inputs["choices"]["x"], inputs["choices"]["mask"])
+        L.q_mask.copy_(inputs["q"]["mask"].to(dev, torch.uint8))
+        L.hall_mask.zero_()
+        for k, st in enumerate(inputs["ctx"]):
+            cell, si, dims = L.ctx_slots[k]
+            put(cell, si, st["x"], st["mask"])
+            m = st["mask"].to(dev, torch.uint8).reshape(L.N, L.M, -1)
+            L.hall_mask[:, k, :, :m.shape[2]] = m
+        if inputs.get("y") is not None:
+            L.y.copy_(inputs["y"].to(dev, torch.uint8))
+            L.has_y = True
+        else:
+            L.has_y = False
+        return L
+
+    # --------------------------------------------------------------- forward
+    def _cell_params(self, cell, grad=False):
+        kn, bn = (self.N_TEXT_K, self.N_TEXT_B) if cell == "text" else (self.N_IMG_K, self.N_IMG_B)
+        v = lambda n: self.params.view(n, grad)
+        if self.share_fw_bw:
+            return v(kn % "fw"), v(bn % "fw"), None, None
+        return v(kn % "fw"), v(bn % "fw"), v(kn % "bw"), v(bn % "bw")
+
+    def forward(self, L, want_logits=False):
+        """model_v2.py:649-1096 on the loaded batch.  Returns yp (device tensor)."""
+        P = self.params
+        for cell, G in L.groups.items():
+            G.op.make_plan(G.lens)
+            kf, bf, kb, bb = self._cell_params(cell)
+            G.op.forward(G.x, L.arena, kf, bf, kb, bb)                     # encoders + context tensor
+        T = L.groups["text"]
+        T.op.last_state(L.arena, T.segs[1]["s0"], T.segs[1]["count"], L.lch)   # lchoices :807-812
+        W = P.view(self.N_ATT_W) if self.simi != 4 else None
+        b = P.view(self.N_ATT_B) if self.simi != 4 else None
+        L.g1, att = L.att.forward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, W, b, want_logits)  # :1020
+        if self.use_question_att:                                           # :1044
+            Wq = P.view(self.N_QATT_W) if self.simi != 4 else None
+            bq = P.view(self.N_QATT_B) if self.simi != 4 else None
+            L.gq, qatt = L.qatt.forward(L.hq, L.g1.view(L.N, 1, self.wp), L.q_mask, L.ones_mask, Wq, bq, want_logits)
+        else:
+            T.op.last_state(L.arena, T.segs[0]["s0"], T.segs[0]["count"], L.lq)  # lq :697
+            L.gq, qatt = L.lq, None
+        L.logits, L.yp, L.loss_t = ops.scorer_ce_fwd(L.gq, L.g1, L.lch, P.view(self.N_OUT_W), P.view(self.N_OUT_B),
+                                                     L.y if L.has_y else None, self.use_eu_output, self.add_tanh)
+        self.logits, self.yp, self.loss = L.logits, L.yp, L.loss_t
+        self.hall = L.hall
+        if want_logits:
+            self.att_logits, self.q_att_logits = att, qatt
+        return L.yp
+
+    # -------------------------------------------------------------- backward
+    def backward(self, L, loss_scale=1.0, need_dx=False):
+        """Gradient of the mean cross-entropy into params.grad (accumulated)."""
+        P = self.params
+        dgq, dg1, dgch = ops.scorer_ce_bwd(L.gq, L.g1, L.lch, P.view(self.N_OUT_W), P.view(self.N_OUT_B), L.y, L.logits,
+                                           L.yp, loss_scale, P.view(self.N_OUT_W, True), P.view(self.N_OUT_B, True),
+                                           self.use_eu_output, self.add_tanh)
+        L.d_arena.zero_()
+        d_hall = L.d_arena[:L.row_hq].view(L.N, L.K, L.T, self.wp)
+        d_hq = L.d_arena[L.row_hq:L.row_hch].view(L.N, L.JQ, self.wp)
+        T = L.groups["text"]
+        if self.use_question_att:
+            # g1 feeds both the scorer and the question attention: accumulate its second gradient in place
+            # (the hq region of d_arena is still zero here, so accumulate mode is exact for it too)
+            L.qatt.backward(L.hq, L.g1.view(L.N, 1, self.wp), L.q_mask, L.ones_mask, P.view(self.N_QATT_W),
+                            P.view(self.N_QATT_B), dgq, d_hq.view(L.N, 1, L.JQ, self.wp), dg1.view(L.N, 1, self.wp),
+                            P.view(self.N_QATT_W, True), P.view(self.N_QATT_B, True), accumulate=True)
+        else:
+            T.op.last_state_bwd(dgq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
+        T.op.last_state_bwd(dgch.view(-1, self.wp), T.segs[1]["s0"], T.segs[1]["count"], L.d_arena)
+        L.att.backward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, P.view(self.N_ATT_W), P.view(self.N_ATT_B),
+                       dg1, d_hall, d_hq, P.view(self.N_ATT_W, True), P.view(self.N_ATT_B, True), accumulate=True)
+        for cell, G in L.groups.items():
+            kf, bf, kb, bb = self._cell_params(cell)
+            dkf, dbf, dkb, dbb = self._cell_params(cell, grad=True)
+            if need_dx:
+                if G.dx is None:
+                    G.dx = torch.zeros_like(G.x)
+                else:
+                    G.dx.zero_()
+            G.op.backward(G.x, L.arena, L.d_arena, kf, kb, G.dx if need_dx else None, dkf, dbf, dkb, dbb)
+
+    def zero_grad(self):
+        self.params.grad.zero_()
+

@@ -1,0 +1,143 @@
+"""GPU parity of the whole hot path (encoders -> context tensor -> attention -> scorer -> loss,
+forward AND backward AND one optimiser step) through the Model / Trainer / Tester mirror,
+against the CPU oracle.  Tolerance 1e-4 relative fp32, answer argmax bit-exact (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol=1e-4, atol=1e-5, msg=""):
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, np.float64)
+    b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, np.float64)
+    scale = max(1.0, float(np.abs(b).max()))
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol * scale, err_msg=msg)
+
+
+def _run(spec, check_grads=True):
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import make_inputs, make_params, to_dtype
+    from oracle import fvta_fused as F
+    params = make_params(spec)
+    inputs = make_inputs(spec)
+    cfg = spec.cfg()
+    # ---- oracle (fp64, autograd)
+    p64 = {k: v.double().requires_grad_() for k, v in params.items()}
+    ref = F.fvta_forward(p64, to_dtype(inputs, torch.float64), cfg)
+    ref["loss"].backward()
+    # ---- HIP path
+    model = Model(dict(cfg, batch_size=spec.N), text_in=spec.text_in, img_in=spec.img_in)
+    model.set_oracle_params(params)
+    L = model.load_inputs(inputs, training=True)
+    model.zero_grad()
+    yp = model.forward(L, want_logits=True)
+    d, dp = model.d, model.dp
+    unpad = lambda t: torch.cat([t[..., :d], t[..., dp:dp + d]], -1)
+    _close(unpad(model.hall).reshape(ref["hall"].shape), ref["hall"], msg="hall")
+    _close(unpad(L.hq), ref["hq"], msg="hq")
+    _close(unpad(L.lch), ref["lchoices"], msg="lchoices")
+    _close(unpad(L.g1), ref["g1_all"], msg="g1_all")
+    _close(unpad(L.gq), ref["gq"], msg="gq")
+    _close(model.att_logits, ref["att_logits"], atol=2e-5, msg="att_logits")
+    _close(model.logits, ref["logits"], msg="logits")
+    _close(yp, ref["yp"], msg="yp")
+    _close(model.loss, ref["loss"].reshape(1), msg="loss")
+    assert (yp.argmax(1).cpu() == ref["yp"].argmax(1)).all(), "answer argmax must be bit-exact"
+    if check_grads:
+        model.backward(L, need_dx=True)
+        grads = model.get_oracle_grads()
+        for k, v in p64.items():
+            if v.grad is None:      # e.g. qatt_W when use_question_att is off
+                continue
+            _close(grads[k].reshape(v.grad.shape), v.grad, rtol=2e-4, atol=2e-5, msg="grad " + k)
+    return model, L, ref
+
+
+@pytest.mark.parametrize("simi,tanh,qatt,share", [(2, True, True, True), (1, False, False, False), (3, True, True, True)])
+@pytest.mark.parametrize("dense", [False, True])
+def test_small_model_forward_backward(simi, tanh, qatt, share, dense):
+    from fvta_memexqa_amd.synth import SynthSpec
+    spec = SynthSpec(N=3, A=2, P=3, S=2, L=5, d=32, SA=1, dense=dense, simiMatrix=simi, add_tanh=tanh,
+                     use_question_att=qatt, share_fw_bw=share, text_in=12, img_in=8)
+    _run(spec)
+
+
+def test_hidden_size_padding_is_exact():
+    """hidden_size 20 (w=40) runs at the padded width 64; results equal the unpadded oracle."""
+    from fvta_memexqa_amd.synth import SynthSpec
+    spec = SynthSpec(N=2, A=1, P=3, S=2, L=4, d=20, dense=False, text_in=12, img_in=8)
+    model, L, _ = _run(spec)
+    assert model.dp == 32 and model.wp == 64
+
+
+def test_plumbing_config():
+    """BASELINE.json configs[0]: 2 albums x 5 photos x 2 text streams x 10 tokens, hidden 128, batch 4."""
+    from fvta_memexqa_amd.synth import CONFIGS, SynthSpec
+    _run(SynthSpec(dense=False, **CONFIGS["plumbing"]))
+
+
+def test_cosine_forward_only():
+    from fvta_memexqa_amd.synth import SynthSpec
+    spec = SynthSpec(N=2, A=1, P=3, S=2, L=4, d=32, dense=False, simiMatrix=4, add_tanh=False, text_in=12, img_in=8)
+    _run(spec, check_grads=False)
+
+
+def test_trainer_tester_mirror_and_update():
+    """Trainer.step -> (loss, None, None) and one Adadelta update equal to the oracle's;
+    Tester.step -> yp[:num_examples]."""
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params, to_dtype
+    from fvta_memexqa_amd.tester import Tester
+    from fvta_memexqa_amd.trainer import Trainer
+    from oracle import fvta_fused as F
+    from oracle import fvta_literal as Lit
+    spec = SynthSpec(N=4, A=1, P=3, S=2, L=5, d=32, dense=False, text_in=12, img_in=8)
+    params, inputs, cfg = make_params(spec), make_inputs(spec), spec.cfg()
+    p64 = {k: v.double().requires_grad_() for k, v in params.items()}
+    ref = F.fvta_forward(p64, to_dtype(inputs, torch.float64), cfg)
+    ref["loss"].backward()
+    model = Model(dict(cfg, batch_size=spec.N, init_lr=0.5), text_in=spec.text_in, img_in=spec.img_in)
+    model.set_oracle_params(params)
+    trainer = Trainer(model, dict(init_lr=0.5))
+    batch = dict(inputs, num_examples=3)
+    loss, summary, train_op = trainer.step(None, (None, batch))
+    assert summary is None and train_op is None
+    _close(torch.tensor([loss]), ref["loss"].reshape(1))
+    assert model.global_step == 1
+    new = model.get_weights()
+    names = {"text_kernel": Model.N_TEXT_K % "fw", "att_W": Model.N_ATT_W, "out_W": Model.N_OUT_W, "qatt_W": Model.N_QATT_W,
+             "image_kernel": Model.N_IMG_K % "fw", "out_b": Model.N_OUT_B}
+    for k, name in names.items():
+        v = p64[k]
+        exp, _, _ = Lit.adadelta_step(v.detach().numpy(), v.grad.numpy(), np.zeros_like(v.detach().numpy()),
+                                      np.zeros_like(v.detach().numpy()), 0.5)
+        _close(new[name].reshape(exp.shape), exp, rtol=2e-4, atol=2e-5, msg="updated " + k)
+    # tester on the ORIGINAL weights
+    model.set_oracle_params(params)
+    yp = Tester(model, None).step(None, (None, batch))
+    assert yp.shape == (3, 4)
+    _close(yp, ref["yp"][:3])
+
+
+def test_metric_shape_forward_vs_oracle_subset():
+    """BASELINE.json configs[1] shape (batch 64, 40 photos x 5 streams x 30 tok, h=512), ragged:
+    full forward on the GPU; the fp32 CPU oracle checks the first 2 QA pairs (it is batch-independent)."""
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import CONFIGS, SynthSpec, make_inputs, make_params
+    from oracle import fvta_fused as F
+    spec = SynthSpec(dense=False, **dict(CONFIGS["metric"], N=8))
+    params, inputs = make_params(spec), make_inputs(spec)
+    model = Model(dict(spec.cfg(), batch_size=spec.N), text_in=spec.text_in, img_in=spec.img_in)
+    model.set_oracle_params(params)
+    L = model.load_inputs(inputs)
+    yp = model.forward(L)
+    n = 2
+    sub = dict(ctx=[dict(x=s["x"][:n], mask=s["mask"][:n], cell=s["cell"]) for s in inputs["ctx"]],
+               q=dict(x=inputs["q"]["x"][:n], mask=inputs["q"]["mask"][:n]),
+               choices=dict(x=inputs["choices"]["x"][:n], mask=inputs["choices"]["mask"][:n]), y=inputs["y"][:n])
+    with torch.no_grad():
+        ref = F.fvta_forward(params, sub, spec.cfg())
+    _close(L.g1[:n], ref["g1_all"], rtol=1e-4, atol=2e-5, msg="g1")
+    _close(yp[:n], ref["yp"], rtol=1e-4, atol=1e-5, msg="yp")
+    assert (yp[:n].argmax(1).cpu() == ref["yp"].argmax(1)).all()
