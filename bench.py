@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the FVTA hot path on MI355X: QA-pairs/s for one training step
+(forward + backward + optimiser update) at BASELINE.json's metric shape
+(batch 64 per GPU, 40 photos x 5 text streams x 30 tokens, hidden 512).
+
+  python bench.py --gpus N --steps K --warmup W          (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One rank per GPU; albums/questions are sharded over ranks (weak scaling: 64 QA
+pairs per GPU), the only collective is the all-reduce of the flat gradient
+buffer.  Inputs (synthetic, seeded) are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the bi-LSTM
+step GEMM, MFMA bound); `roofline_attention` is the fused focal-attention
+kernel against HBM.  Kernel durations come from HIP events recorded on the
+launch stream inside the library (fvta_profile_*), live over the timed region.
+`cpu_baseline` times the CPU oracle ("port") on a bounded sample of the same
+workload on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_F32_TFLOPS = 157.3        # fp32 MFMA (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA
+
+
+def log(msg):
+    if os.environ.get("FVTA_BENCH_VERBOSE", "1") != "0":
+        print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="metric", choices=["metric", "plumbing", "long_album"])
+    ap.add_argument("--variant", default="dense", choices=["dense", "ragged"],
+                    help="dense: every length = max (no padding to skip; the headline). ragged: SURVEY 8d length distribution")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--optimizer", default="adam", choices=["adam", "adadelta"])
+    ap.add_argument("--batch", type=int, default=None, help="QA pairs per GPU (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="QA pairs in the CPU-baseline sample")
+    ap.add_argument("--forward-only", action="store_true", help="BASELINE.json configs[1] (inference) instead of the train step")
+    return ap.parse_args()
+
+
+def lstm_flops(spec, B, J, din, d):
+    """algorithmic flops of one bi-LSTM forward call, dense: 2 dirs x steps x 2*B*(in+d)*4d (h part absent at t=0)"""
+    return 2 * (J * 2.0 * B * (din + d) * 4 * d - 2.0 * B * d * 4 * d)
+
+
+def cpu_baseline(spec_kw, sample_n, forward_only):
+    """The CPU oracle (oracle/fvta_fused.py, torch-CPU fp32, all host cores) on `sample_n` QA pairs of
+    the same workload: 1 warm-up + 3 timed passes, median."""
+    from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params
+    from oracle import fvta_fused as F
+    torch.set_num_threads(host_cores())
+    spec = SynthSpec(**dict(spec_kw, N=sample_n))
+    params = {k: v.requires_grad_(not forward_only) for k, v in make_params(spec).items()}
+    inputs = make_inputs(spec)
+    times = []
+    for it in range(4):
+        t0 = time.perf_counter()
+        if forward_only:
+            with torch.no_grad():
+                F.fvta_forward(params, inputs, spec.cfg())
+        else:
+            for p in params.values():
+                p.grad = None
+            out = F.fvta_forward(params, inputs, spec.cfg())
+            out["loss"].backward()
+        dt = time.perf_counter() - t0
+        if it > 0:
+            times.append(dt)
+    med = statistics.median(times)
+    return dict(value=sample_n / med, unit="QA-pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d QA pairs of the same shape, %s, torch-CPU fp32 oracle, median of 3 (%.2f s each)"
+                       % (sample_n, "forward only" if forward_only else "forward+backward", med))
+
+
+def main():
+    args = parse()
+    from fvta_memexqa_amd import _lib, dist
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import CONFIGS, SynthSpec, make_inputs
+    from fvta_memexqa_amd.trainer import Trainer
+
+    ws, rank, local = dist.init()
+    if ws != args.gpus and ws > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, ws))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    lib = _lib.load()
+
+    kw = dict(CONFIGS[args.config], dense=(args.variant == "dense"))
+    if args.batch:
+        kw["N"] = args.batch
+    spec = SynthSpec(**kw)
+    cfg = dict(spec.cfg(), batch_size=spec.N, precision=args.precision, optimizer=args.optimizer,
+               init_lr=0.001 if args.optimizer == "adam" else 0.5)
+    model = Model(cfg, text_in=spec.text_in, img_in=spec.img_in, device=dev)
+    trainer = Trainer(model, cfg)
+    trainer.need_dx = True   # the real model trains its embeddings: gradients flow into the encoder inputs
+    log('model built; generating synthetic inputs')
+    inputs = make_inputs(spec, rank=rank)                      # synthetic, seed 1234+rank
+    L = model.load_inputs(inputs, training=not args.forward_only)   # resident in HBM from here on
+    del inputs
+    log('inputs resident in HBM; warm-up')
+
+    def step():
+        if args.forward_only:
+            model.forward(L)
+        else:
+            trainer.step_device(L)
+
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log('warm-up step %d done' % i)
+    lib.fvta_profile_enable(1)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    lib.fvta_profile_enable(0)
+    elapsed = dist.max_over_ranks(elapsed, dev)
+    log('timed region done: %.3f s for %d steps' % (elapsed, args.steps))
+
+    def collect(pid):
+        ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+        lib.fvta_profile_collect(pid, ctypes.byref(ms), ctypes.byref(n))
+        return ms.value, n.value
+
+    prof = {name: collect(pid) for name, pid in [("lstm_step_fwd", 1), ("lstm_step_bwd", 2), ("lstm_dw", 3),
+                                                 ("attn_fwd_main", 4), ("attn_bwd_main", 5)]}
+    if rank != 0:
+        return
+    total_qa = spec.N * ws * args.steps
+    value = total_qa / elapsed
+    # ---- roofline of the dominant kernel: bi-LSTM forward step (text cell), MFMA bound
+    T = L.groups["text"]
+    calls = args.steps
+    img = L.groups.get("image")
+    # text-cell call only (profile tag 0): the photo cell's 64-row launches are filed under tag 1.
+    # flops are the ALGORITHMIC ones of the reference's per-step [x,h]*kernel on the sequences' real lengths
+    lens = T.lens.float()
+    fl_text = float((2 * (lens * 2.0 * (spec.text_in + model.dp) * 4 * model.dp
+                          - (lens > 0).float() * 2.0 * model.dp * 4 * model.dp)).sum().item())
+    ms_f, n_f = prof["lstm_step_fwd"]
+    peak_tf = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+    roof = None
+    if n_f:
+        ach = fl_text * calls / (ms_f * 1e-3) / 1e12
+        roof = dict(kernel="lstm_step_fwd_%s" % args.precision, bound="mfma", achieved=round(ach, 2), peak=peak_tf,
+                    unit="TFLOP/s", frac=round(ach / peak_tf, 4), traffic=None,
+                    launches=n_f, avg_launch_ms=round(ms_f / n_f, 4))
+    # ---- attention kernel against HBM: algorithmic bytes = valid rows * w * 4 + question + output
+    valid_rows = int(L.hall_mask.sum().item())
+    att_bytes = (valid_rows * model.wp + spec.N * L.JQ * model.wp + spec.N * model.wp) * 4.0
+    ms_a, n_a = prof["attn_fwd_main"]
+    roof_att = None
+    if n_a:
+        # two attn_fwd_main launches per step when use_question_att (the question one is tiny); count the big one
+        per_step_ms = ms_a / args.steps
+        gbs = att_bytes / (per_step_ms * 1e-3) / 1e9
+        roof_att = dict(kernel="attn_fwd_main", bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                        frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, algorithmic_bytes=att_bytes,
+                        ms_per_step=round(per_step_ms, 4))
+    out = dict(
+        metric="QA-pairs/sec (fwd+bwd) at B=64, 40 photos x 5 streams x 30 tok, h=512" if args.config == "metric" and not args.forward_only
+        else "QA-pairs/sec (%s, config %s)" % ("fwd" if args.forward_only else "fwd+bwd", args.config),
+        value=round(value, 2), unit="QA-pairs/s", n_gpus=ws, steps=args.steps, warmup=args.warmup,
+        ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+        dtype=args.precision, data="synthetic",
+        config=dict(workload=("BASELINE.json configs[2] train step (fwd+bwd+%s)" % args.optimizer if not args.forward_only
+                              else "BASELINE.json configs[1] forward only") + ", shape '%s', %s lengths" % (args.config, args.variant),
+                    qa_pairs_per_gpu=spec.N, albums=spec.A, photos=spec.P, text_streams=spec.S, tokens=spec.L, hidden=spec.d,
+                    K=L.K, T=L.T, JQ=L.JQ, parallelism="dp%d (QA pairs sharded, flat-gradient all-reduce)" % ws),
+        roofline=roof, roofline_attention=roof_att,
+        kernel_ms_per_step={k: round(v[0] / args.steps, 4) for k, v in prof.items()},
+    )
+    if ws == 1 and not args.no_cpu_baseline:
+        log('timing the CPU oracle on %d cores' % host_cores())
+        out["cpu_baseline"] = cpu_baseline(kw, args.cpu_sample, args.forward_only)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

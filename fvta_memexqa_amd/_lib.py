@@ -53,6 +53,8 @@ _SIGS = {
     "fvta_adadelta_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P]),
     "fvta_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float, P]),
     "fvta_test_gemm": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),
+    "fvta_profile_enable": (c_int, [c_int32]),
+    "fvta_profile_collect": (c_int, [c_int32, POINTER(ctypes.c_double), POINTER(c_int64)]),
 }
 
 _lib = None
@@ -68,6 +70,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Import it FIRST so that our
+    # library binds to the SAME HIP runtime instance; loading ours first would pull in /opt/rocm's
+    # copy as a second runtime, which then sees no device.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise FvtaError(
             "%s not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "

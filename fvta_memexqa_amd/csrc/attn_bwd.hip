@@ -13,6 +13,7 @@
 // (TF splits exact ties) and fully masked (n,k) rows pass no gradient into the
 // masked logits.
 #include "attn_common.h"
+#include "fvta_prof.h"
 
 namespace fvta {
 
@@ -441,6 +442,7 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
   a.d_hinfo = d_hinfo;
   a.accumulate = accumulate;
   const dim3 grid(s.bsplit, s.N * s.K);
+  fvta_prof_begin(FVTA_PROF_ATTN_BWD_MAIN, stream);
   switch (s.w) {
     case 64: hipLaunchKernelGGL((attn_bwd_main<16, 1, 32>), grid, dim3(256), 0, stream, a); break;
     case 128: hipLaunchKernelGGL((attn_bwd_main<32, 1, 32>), grid, dim3(256), 0, stream, a); break;
@@ -449,6 +451,7 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
     case 1024: hipLaunchKernelGGL((attn_bwd_main<256, 1, 32>), grid, dim3(256), 0, stream, a); break;
     case 2048: hipLaunchKernelGGL((attn_bwd_main<256, 2, 16>), grid, dim3(256), 0, stream, a); break;
   }
+  fvta_prof_end(FVTA_PROF_ATTN_BWD_MAIN, 1, stream);
   FVTA_CHECK_LAUNCH("attn_bwd_main");
   hipLaunchKernelGGL(attn_bwd_reduce_q_kernel, dim3(s.N, (s.w + 255) / 256), dim3(256), 0, stream, s, sv, wk, RH, hq,
                      d_hq, accumulate);

@@ -9,6 +9,7 @@
 // straight from L2), takes max_j, and folds the rows into an online softmax /
 // weighted-sum accumulator from the same registers.  Masked rows are never read.
 #include "attn_common.h"
+#include "fvta_prof.h"
 
 namespace fvta {
 
@@ -490,6 +491,7 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
   a.hinfo = hinfo;
   a.a_logits = a_logits;
   a.part = (float*)workspace;
+  fvta_prof_begin(FVTA_PROF_ATTN_FWD_MAIN, stream);
   switch (s.w) {
     case 64: launch_main<4, 1, 1>(a, stream); break;
     case 128: launch_main<8, 1, 1>(a, stream); break;
@@ -498,6 +500,7 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
     case 1024: launch_main<16, 4, 1>(a, stream); break;
     case 2048: launch_main<16, 4, 2>(a, stream); break;
   }
+  fvta_prof_end(FVTA_PROF_ATTN_FWD_MAIN, 1, stream);
   FVTA_CHECK_LAUNCH("attn_fwd_main");
   hipLaunchKernelGGL(attn_merge_kernel, dim3(s.N), dim3(256), 0, stream, s, sv, a.part, h_a);
   FVTA_CHECK_LAUNCH("attn_merge");

@@ -13,6 +13,7 @@
 // length emit zeros and keep their state; the reversed direction runs on
 // reverse_sequence(x, len) and its outputs are reversed back.
 #include "gemm_f32.h"
+#include "fvta_prof.h"
 
 namespace fvta {
 
@@ -599,10 +600,12 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   FVTA_CHECK_LAUNCH("pad_zero");
   const dim3 grid((d->B + MmaStep::BM - 1) / MmaStep::BM, d->d / 32, 2);
   const size_t sh = MmaStep::LDS_FLOATS * sizeof(float);
+  fvta_prof_begin(FVTA_PROF_LSTM_STEP_FWD + 16 * d->reserved, stream);
   for (int t = 0; t < d->J; ++t) {
     a.t = t;
     hipLaunchKernelGGL(lstm_step_fwd_f32, grid, dim3(256), sh, stream, a);
   }
+  fvta_prof_end(FVTA_PROF_LSTM_STEP_FWD + 16 * d->reserved, d->J, stream);
   FVTA_CHECK_LAUNCH("lstm_step_fwd");
   return FVTA_OK;
 }
@@ -646,12 +649,14 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
   const dim3 ggrid((unsigned)(((size_t)B * dd + 255) / 256), 1, 2);
   const dim3 sgrid((B + MmaSq::BM - 1) / MmaSq::BM, (in + dd + MmaSq::BN - 1) / MmaSq::BN, 2);
   const size_t sh = MmaSq::LDS_FLOATS * sizeof(float);
+  fvta_prof_begin(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, stream);
   for (int t = J - 1; t >= 0; --t) {
     g.t = t;
     s.t = t;
     hipLaunchKernelGGL(lstm_gate_bwd, ggrid, dim3(256), 0, stream, g);
     if (t > 0 || dx) hipLaunchKernelGGL(lstm_step_bwd_f32, sgrid, dim3(256), sh, stream, s);
   }
+  fvta_prof_end(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, 2 * J, stream);
   FVTA_CHECK_LAUNCH("lstm_step_bwd");
   DwArgs w;
   w.plan = pv;
@@ -667,6 +672,7 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
   w.nsplit = dw_nsplit(d);
   const int MM = in + dd + 1, N4 = 4 * dd;
   const dim3 wgrid((MM + MmaSq::BM - 1) / MmaSq::BM, N4 / MmaSq::BN, 2 * w.nsplit);
+  fvta_prof_begin(FVTA_PROF_LSTM_DW + 16 * d->reserved, stream);
   hipLaunchKernelGGL(lstm_dw_f32, wgrid, dim3(256), sh, stream, w);
   FVTA_CHECK_LAUNCH("lstm_dw");
   const size_t slab_elems = (size_t)MM * N4;
@@ -680,6 +686,7 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
     hipLaunchKernelGGL(lstm_dw_reduce, dim3(rgrid), dim3(256), 0, stream, wv.slabs + (size_t)w.nsplit * slab_elems,
                        w.nsplit, slab_elems, in + dd, N4, dkernel_bw, dbias_bw);
   }
+  fvta_prof_end(FVTA_PROF_LSTM_DW + 16 * d->reserved, 1, stream);
   FVTA_CHECK_LAUNCH("lstm_dw_reduce");
   return FVTA_OK;
 }

@@ -307,7 +307,8 @@ class Model:
             G.dx = None
             G.lens = torch.zeros(B, dtype=torch.int32, device=dev)
             G.op = ops.BiLstm(B, Jmax, din, dp, torch.cat(x_off), torch.cat(out_off), torch.cat(seq_J), wp,
-                              share_fw_bw=self.share_fw_bw, precision=self.precision, training=training)
+                              share_fw_bw=self.share_fw_bw, precision=self.precision, training=training,
+                              prof_tag=0 if cell == "text" else 1)
             L.groups[cell] = G
         L.q_mask = torch.zeros(N, JQ, dtype=torch.uint8, device=dev)
         L.ones_mask = torch.ones(N, 1, dtype=torch.uint8, device=dev)

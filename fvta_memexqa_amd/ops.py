@@ -54,10 +54,10 @@ class BiLstm:
     """
 
     def __init__(self, B, J, in_dim, d, x_off, out_off, seq_J, out_ld, share_fw_bw=True, precision=F32,
-                 training=False):
+                 training=False, prof_tag=0):
         self.lib = _lib.load()
         self.dev = require_gpu()
-        self.desc = LstmDesc(B, J, in_dim, d, int(share_fw_bw), precision, int(training), 0)
+        self.desc = LstmDesc(B, J, in_dim, d, int(share_fw_bw), precision, int(training), int(prof_tag))
         self.B, self.J, self.in_dim, self.d = B, J, in_dim, d
         self.x_off = x_off.to(self.dev, torch.int64).contiguous()
         self.out_off = out_off.to(self.dev, torch.int64).contiguous()

@@ -101,7 +101,7 @@ typedef struct fvta_lstm_desc {
   int32_t share_fw_bw; /* 1: TF>=1.2 cell reuse, one kernel for both directions */
   int32_t precision;   /* FVTA_F32 | FVTA_BF16 */
   int32_t training;    /* 1: keep gate activations for fvta_bilstm_bwd */
-  int32_t reserved;
+  int32_t reserved;    /* profiling tag: this call's brackets are filed under id + 16*reserved */
 } fvta_lstm_desc;
 
 size_t fvta_lstm_plan_bytes(const fvta_lstm_desc* d);
@@ -190,6 +190,21 @@ int fvta_adam_step(float* var, const float* grad, float* m, float* v, int64_t n,
  * ------------------------------------------------------------------------- */
 int fvta_test_gemm(int32_t precision, int32_t layout, int32_t M, int32_t N, int32_t K, const float* A,
                    const float* B, float* C, fvta_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Opt-in measurement hook (bench.py): while enabled on the calling thread, the
+ * kernels below are bracketed by hipEvent pairs recorded on the launch stream.
+ * fvta_profile_collect synchronises on them and returns the summed elapsed
+ * milliseconds and the number of kernel launches they covered.  The LSTM ids
+ * bracket the whole per-step launch sequence of one call (J launches).
+ * ------------------------------------------------------------------------- */
+#define FVTA_PROF_LSTM_STEP_FWD 1 /* lstm_step_fwd_*  : J launches per fvta_bilstm_fwd */
+#define FVTA_PROF_LSTM_STEP_BWD 2 /* gate + step GEMM : 2J launches per fvta_bilstm_bwd */
+#define FVTA_PROF_LSTM_DW 3       /* weight-gradient GEMM + slab reduce */
+#define FVTA_PROF_ATTN_FWD_MAIN 4 /* attn_fwd_main */
+#define FVTA_PROF_ATTN_BWD_MAIN 5 /* attn_bwd_main */
+int fvta_profile_enable(int32_t on);
+int fvta_profile_collect(int32_t id, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }
