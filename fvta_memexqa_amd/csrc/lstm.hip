@@ -14,44 +14,11 @@
 // reverse_sequence(x, len) and its outputs are reversed back.
 #include "gemm_f32.h"
 #include "fvta_prof.h"
+#include "lstm_common.h"
 
 namespace fvta {
 
 // ------------------------------------------------------------------ plan ----
-struct PlanHeader {
-  int64_t out_ld;
-  int32_t B, J, in, d;
-  int32_t pad[10];
-};
-
-struct PlanView {
-  PlanHeader* hdr;
-  int32_t* order;    // [B] sequence ids, longest first (stable)
-  int32_t* nactive;  // [J+1] sequences with len > t
-  int32_t* len;      // [B]
-  int32_t* seq_J;    // [B]
-  int64_t* x_off;    // [B]
-  int64_t* out_off;  // [B]
-  int64_t* xo;       // [2][J][B] element offset of x row for (dir,t,sorted i), -1 = inactive
-  int64_t* oo;       // [2][J][B] element offset of the output half-row
-  size_t bytes;
-};
-
-static PlanView plan_view(const fvta_lstm_desc* d, void* p) {
-  FvtaCarver c(p);
-  PlanView v;
-  v.hdr = c.take<PlanHeader>(1);
-  v.order = c.take<int32_t>(d->B);
-  v.nactive = c.take<int32_t>(d->J + 1);
-  v.len = c.take<int32_t>(d->B);
-  v.seq_J = c.take<int32_t>(d->B);
-  v.x_off = c.take<int64_t>(d->B);
-  v.out_off = c.take<int64_t>(d->B);
-  v.xo = c.take<int64_t>((size_t)2 * d->J * d->B);
-  v.oo = c.take<int64_t>((size_t)2 * d->J * d->B);
-  v.bytes = c.off;
-  return v;
-}
 
 // Stable counting sort by length, descending.  One 1024-thread workgroup; each
 // of the 16 waves owns a contiguous chunk of the sequences, so the order is
@@ -166,41 +133,6 @@ __global__ void pad_zero_kernel(PlanView v, float* __restrict__ out, int d) {
 }
 
 // ------------------------------------------------------------- saved state --
-struct SavedView {
-  float* gates;  // [2][J][B][4][d] i, tanh(j), f, o activations (overwritten by dz in backward)
-  float* cs;     // [2][J][B][d] cell state after step t
-  size_t bytes;
-};
-static SavedView saved_view(const fvta_lstm_desc* d, void* p) {
-  FvtaCarver c(p);
-  SavedView s;
-  s.gates = c.take<float>((size_t)2 * d->J * d->B * 4 * d->d);
-  s.cs = c.take<float>((size_t)2 * d->J * d->B * d->d);
-  s.bytes = c.off;
-  return s;
-}
-
-struct WorkView {
-  float* cstate;   // [2][B][d] running cell state (inference) / dc (backward)
-  float* dh_rec;   // [2][B][d]
-  float* slabs;    // [NSPLIT][2 or 1][(in+d+1)][4d] split-K partials of dW
-  size_t bytes;
-};
-static int dw_tgroup(const fvta_lstm_desc* d) {
-  // steps per split-K slice of the weight-gradient GEMM: keep <= 16 slices per direction
-  int g = (d->J + 15) / 16;
-  return g < 1 ? 1 : g;
-}
-static int dw_nsplit(const fvta_lstm_desc* d) { return (d->J + dw_tgroup(d) - 1) / dw_tgroup(d); }
-static WorkView work_view(const fvta_lstm_desc* d, void* p) {
-  FvtaCarver c(p);
-  WorkView w;
-  w.cstate = c.take<float>((size_t)2 * d->B * d->d);
-  w.dh_rec = c.take<float>((size_t)2 * d->B * d->d);
-  w.slabs = c.take<float>((size_t)2 * dw_nsplit(d) * (d->in + d->d + 1) * 4 * d->d);
-  w.bytes = c.off;
-  return w;
-}
 
 // --------------------------------------------------------- forward step -----
 // grid (ceil(B/128), d/32, 2).  Block tile: 128 sorted sequences x (4 gates x 32
@@ -208,17 +140,6 @@ static WorkView work_view(const fvta_lstm_desc* d, void* p) {
 // ends up with i,j,f,o of the same (row, unit) in its accumulators.
 using MmaStep = MmaF32<4, 1, 1, 4>;
 
-struct StepArgs {
-  PlanView plan;
-  const float* x;
-  float* out;
-  const float* W[2];
-  const float* bias[2];
-  float* gates;   // may be null (inference)
-  float* cs;      // may be null
-  float* cstate;  // used when cs is null
-  int t, B, J, in, d;
-};
 
 __global__ __launch_bounds__(256) void lstm_step_fwd_f32(StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -270,50 +191,12 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_f32(StepArgs a) {
   };
   gemm_mainloop(mma, sa, sb, fa, fb, 0, K, smem, tid);
 
-  // ---- fused gate epilogue ----
-  const float* __restrict__ bias = a.bias[dir];
-  const int u = u0 + mma.l31;
-  const float bi = bias[u], bj = bias[d + u], bf = bias[2 * d + u], bo = bias[3 * d + u];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = mma.row_of(0, r);
-    const int i = m0 + row;
-    if (i >= nact) continue;
-    const float ig = fvta_sigmoid(mma.acc[0][0][r] + bi);
-    const float jg = tanhf(mma.acc[0][1][r] + bj);
-    const float fg = fvta_sigmoid(mma.acc[0][2][r] + bf + 1.0f);  // forget_bias
-    const float og = fvta_sigmoid(mma.acc[0][3][r] + bo);
-    float cprev = 0.f;
-    if (t > 0) cprev = a.cs ? a.cs[(trow - a.B + i) * d + u] : a.cstate[((size_t)dir * a.B + i) * d + u];
-    const float c = cprev * fg + ig * jg;
-    const float h = tanhf(c) * og;
-    if (a.cs) {
-      a.cs[(trow + i) * d + u] = c;
-      float* g = a.gates + (trow + i) * (size_t)(4 * d) + u;
-      g[0] = ig;
-      g[d] = jg;
-      g[2 * d] = fg;
-      g[3 * d] = og;
-    } else {
-      a.cstate[((size_t)dir * a.B + i) * d + u] = c;
-    }
-    const int64_t oo = a.plan.oo[trow + i];
-    a.out[oo + u] = h;
-  }
+  lstm_gate_epilogue(mma, a, dir, m0, u0, nact, trow);
 }
 
 // ------------------------------------------------------- backward pieces ----
 // (a) elementwise: dz_t from dh_t, dc_t and the saved activations; dz overwrites
 // the saved gates in place.  grid (ceil(nact_max*d/256)...): one thread per (i,u).
-struct GateBwdArgs {
-  PlanView plan;
-  const float* d_out;
-  float* gates;
-  const float* cs;
-  float* dc;      // [2][B][d]
-  float* dh_rec;  // [2][B][d]
-  int t, B, J, d;
-};
 __global__ void lstm_gate_bwd(GateBwdArgs a) {
   const int dir = blockIdx.z;
   const int d = a.d, t = a.t;
@@ -332,23 +215,25 @@ __global__ void lstm_gate_bwd(GateBwdArgs a) {
   const float cprev = t > 0 ? a.cs[(trow - a.B + i) * d + u] : 0.f;
   const float tc = tanhf(c);
   const float dc = a.dc[su] + dh * og * (1.f - tc * tc);
-  g[0] = dc * jg * ig * (1.f - ig);
-  g[d] = dc * ig * (1.f - jg * jg);
-  g[2 * d] = dc * cprev * fg * (1.f - fg);
-  g[3 * d] = dh * tc * og * (1.f - og);
+  const float dzi = dc * jg * ig * (1.f - ig), dzj = dc * ig * (1.f - jg * jg);
+  const float dzf = dc * cprev * fg * (1.f - fg), dzo = dh * tc * og * (1.f - og);
+  if (a.dzb) {  // bf16 engine: dz rows are only ever MFMA operands
+    bf16_t* z = a.dzb + (trow + i) * (size_t)(4 * d) + u;
+    z[0] = f2bf(dzi);
+    z[d] = f2bf(dzj);
+    z[2 * d] = f2bf(dzf);
+    z[3 * d] = f2bf(dzo);
+  } else {
+    g[0] = dzi;
+    g[d] = dzj;
+    g[2 * d] = dzf;
+    g[3 * d] = dzo;
+  }
   a.dc[su] = dc * fg;
 }
 
 // (b) [dx_t | dh_{t-1}] = dz_t * kernel^T.  grid (ceil(B/128), ceil((in+d)/128), 2)
 using MmaSq = MmaF32<2, 2, 2, 2>;
-struct StepBwdArgs {
-  PlanView plan;
-  const float* dz;  // = saved gates buffer
-  const float* W[2];
-  float* dx;        // may be null
-  float* dh_rec;
-  int t, B, J, in, d;
-};
 __global__ __launch_bounds__(256) void lstm_step_bwd_f32(StepBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, dir = blockIdx.z;
@@ -398,14 +283,6 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_f32(StepBwdArgs a) {
 
 // (c) dkernel = [x | h_prev | 1]^T * dz over all steps: split-K slabs.
 // grid (ceil((in+d+1)/128), 4d/128, nsplit*ndirslab)
-struct DwArgs {
-  PlanView plan;
-  const float* x;
-  const float* out;
-  const float* dz;
-  float* slabs;
-  int B, J, in, d, tgroup, nsplit;
-};
 __global__ __launch_bounds__(256) void lstm_dw_f32(DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -536,7 +413,7 @@ static int check_lstm_desc(const fvta_lstm_desc* d) {
   FVTA_CHECK_ARG(d->B > 0 && d->J > 0 && d->J <= 1024, "lstm: need B>0 and 0<J<=1024 (B=%d J=%d)", d->B, d->J);
   FVTA_CHECK_ARG(d->in > 0 && d->in % 4 == 0, "lstm: input width must be a positive multiple of 4 (in=%d)", d->in);
   FVTA_CHECK_ARG(d->d > 0 && d->d % 32 == 0, "lstm: hidden size must be a positive multiple of 32 (d=%d)", d->d);
-  FVTA_CHECK_ARG(d->precision == FVTA_F32, "lstm: precision %d not built", d->precision);
+  FVTA_CHECK_ARG(d->precision == FVTA_F32 || d->precision == FVTA_BF16, "lstm: unknown precision %d", d->precision);
   return FVTA_OK;
 }
 
@@ -601,9 +478,22 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   const dim3 grid((d->B + MmaStep::BM - 1) / MmaStep::BM, d->d / 32, 2);
   const size_t sh = MmaStep::LDS_FLOATS * sizeof(float);
   fvta_prof_begin(FVTA_PROF_LSTM_STEP_FWD + 16 * d->reserved, stream);
+  const bool bf = d->precision == FVTA_BF16;
+  a.Kp = kpad8(d);
+  a.Wt[0] = a.Wt[1] = nullptr;
+  if (bf) {  // refresh the bf16 weight shadows (the optimiser has just changed the fp32 masters)
+    const int ndir = d->share_fw_bw ? 1 : 2;
+    for (int i = 0; i < ndir; ++i)
+      launch_cvt_weights_bf16(a.W[i], wv.wt[i], wv.wb[i], d->in + d->d, a.Kp, 4 * d->d, stream);
+    a.Wt[0] = wv.wt[0];
+    a.Wt[1] = d->share_fw_bw ? wv.wt[0] : wv.wt[1];
+  }
   for (int t = 0; t < d->J; ++t) {
     a.t = t;
-    hipLaunchKernelGGL(lstm_step_fwd_f32, grid, dim3(256), sh, stream, a);
+    if (bf)
+      launch_step_fwd_bf16(a, grid, stream);
+    else
+      hipLaunchKernelGGL(lstm_step_fwd_f32, grid, dim3(256), sh, stream, a);
   }
   fvta_prof_end(FVTA_PROF_LSTM_STEP_FWD + 16 * d->reserved, d->J, stream);
   FVTA_CHECK_LAUNCH("lstm_step_fwd");
@@ -632,6 +522,8 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
   g.cs = sv.cs;
   g.dc = wv.cstate;
   g.dh_rec = wv.dh_rec;
+  const bool bf = d->precision == FVTA_BF16;
+  g.dzb = bf ? wv.dzb : nullptr;
   g.B = B;
   g.J = J;
   g.d = dd;
@@ -642,6 +534,9 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
   s.W[1] = d->share_fw_bw ? kernel_fw : kernel_bw;
   s.dx = dx;
   s.dh_rec = wv.dh_rec;
+  s.dzb = wv.dzb;
+  s.Wb[0] = wv.wb[0];
+  s.Wb[1] = d->share_fw_bw ? wv.wb[0] : wv.wb[1];
   s.B = B;
   s.J = J;
   s.in = in;
@@ -654,7 +549,12 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
     g.t = t;
     s.t = t;
     hipLaunchKernelGGL(lstm_gate_bwd, ggrid, dim3(256), 0, stream, g);
-    if (t > 0 || dx) hipLaunchKernelGGL(lstm_step_bwd_f32, sgrid, dim3(256), sh, stream, s);
+    if (t > 0 || dx) {
+      if (bf)
+        launch_step_bwd_bf16(s, sgrid, stream);
+      else
+        hipLaunchKernelGGL(lstm_step_bwd_f32, sgrid, dim3(256), sh, stream, s);
+    }
   }
   fvta_prof_end(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, 2 * J, stream);
   FVTA_CHECK_LAUNCH("lstm_step_bwd");
@@ -673,7 +573,11 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
   const int MM = in + dd + 1, N4 = 4 * dd;
   const dim3 wgrid((MM + MmaSq::BM - 1) / MmaSq::BM, N4 / MmaSq::BN, 2 * w.nsplit);
   fvta_prof_begin(FVTA_PROF_LSTM_DW + 16 * d->reserved, stream);
-  hipLaunchKernelGGL(lstm_dw_f32, wgrid, dim3(256), sh, stream, w);
+  w.dzb = wv.dzb;
+  if (bf)
+    launch_dw_bf16(w, wgrid, stream);
+  else
+    hipLaunchKernelGGL(lstm_dw_f32, wgrid, dim3(256), sh, stream, w);
   FVTA_CHECK_LAUNCH("lstm_dw");
   const size_t slab_elems = (size_t)MM * N4;
   const unsigned rgrid = (unsigned)((slab_elems + 255) / 256);
@@ -716,6 +620,17 @@ extern "C" int fvta_lstm_last_state_bwd(const fvta_lstm_desc* d, const void* pla
 
 extern "C" int fvta_test_gemm(int32_t precision, int32_t layout, int32_t M, int32_t N, int32_t K, const float* A,
                               const float* B, float* C, fvta_stream_t stream_) {
+  if (precision == FVTA_BF16) {
+    FVTA_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 8 == 0 && M % 8 == 0,
+                   "test_gemm(bf16): M,N,K must be positive multiples of 8");
+    const int e = test_gemm_bf16(layout, M, N, K, A, B, C, (hipStream_t)stream_);
+    if (e) {
+      fvta_set_error("test_gemm(bf16): layout %d not built", layout);
+      return e;
+    }
+    FVTA_CHECK_LAUNCH("test_gemm_bf16");
+    return FVTA_OK;
+  }
   FVTA_CHECK_ARG(precision == FVTA_F32, "test_gemm: precision %d not built", precision);
   FVTA_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 4 == 0 && N % 4 == 0 && M % 4 == 0,
                  "test_gemm: M,N,K must be positive multiples of 4");

@@ -1,0 +1,99 @@
+"""GPU checks of the bf16 MFMA engine (BASELINE.json configs[2]: bf16 compute / fp32 accumulate).
+
+The fragment maps are checked EXACTLY (operands pre-rounded to bf16, so only fp32 accumulation
+order differs).  The LSTM / whole-model results are compared with the fp64 oracle at a bf16
+tolerance (operands carry 8 significant bits): 3e-2 absolute on activations in [-1,1],
+and the fp32 engine remains the 1e-4 parity path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16 = 1
+
+
+def _close(a, b, rtol, atol, msg=""):
+    a = a.detach().cpu().double().numpy()
+    b = b.detach().cpu().double().numpy()
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=msg)
+
+
+@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("shape", [(128, 128, 32), (200, 264, 72), (64, 40, 104), (712, 2048, 256)])
+def test_mfma_bf16_gemm_layouts(layout, shape):
+    from fvta_memexqa_amd import ops
+    M, N, K = [(v + 7) // 8 * 8 for v in shape]
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + layout)
+    A = torch.randn(M, K, generator=g).bfloat16().float()     # asymmetric, exactly representable
+    B = torch.randn(K, N, generator=g).bfloat16().float()
+    ref = A.double() @ B.double()
+    Ad = (A if layout == 1 else A.t().contiguous()).cuda()
+    Bd = (B.t().contiguous() if layout == 1 else B).cuda()
+    C = ops.test_gemm(Ad, Bd, layout, precision=BF16)
+    _close(C, ref, rtol=1e-5, atol=1e-4 * K ** 0.5)
+
+
+@pytest.mark.parametrize("B,J,din,d,dense,share", [(5, 6, 8, 32, False, True), (300, 9, 12, 64, False, False),
+                                                   (130, 7, 100, 128, True, True), (64, 30, 200, 512, False, True)])
+def test_bilstm_bf16_forward_backward(B, J, din, d, dense, share):
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    g = torch.Generator().manual_seed(B + J + d + 5)
+    x = torch.randn(B, J, din, generator=g)
+    lens = torch.full((B,), J) if dense else torch.randint(0, J + 1, (B,), generator=g)
+    lim = (6.0 / (din + d + 4 * d)) ** 0.5
+    mk = lambda: ((torch.rand(din + d, 4 * d, generator=g) * 2 - 1) * lim, torch.randn(4 * d, generator=g) * 0.1)
+    k_fw, b_fw = mk()
+    k_bw, b_bw = (None, None) if share else mk()
+    mask = torch.arange(J)[None, :] < lens[:, None]
+    g_out = torch.randn(B, J, 2 * d, generator=g) * mask[:, :, None]
+    leaves = [t.double().requires_grad_() for t in (x, k_fw, b_fw)]
+    if not share:
+        leaves += [k_bw.double().requires_grad_(), b_bw.double().requires_grad_()]
+    ref_out, ref_last = F.encode_stream(leaves[0], mask, leaves[1], leaves[2], *(leaves[3:] if not share else []))
+    (ref_out * g_out.double()).sum().backward()
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    xc, kf, bf, kb, bb = cu(x), cu(k_fw), cu(b_fw), cu(k_bw), cu(b_bw)
+    out, last, op = ops.bilstm_simple(xc, lens, kf, bf, kb, bb, training=True, precision=BF16)
+    _close(out, ref_out, rtol=0, atol=3e-2, msg="out")
+    _close(last, ref_last, rtol=0, atol=3e-2, msg="last")
+    dx = torch.zeros_like(xc)
+    dkf, dbf = torch.zeros_like(kf), torch.zeros_like(bf)
+    dkb, dbb = (None, None) if share else (torch.zeros_like(kb), torch.zeros_like(bb))
+    op.backward(xc, out, cu(g_out), kf, kb, dx, dkf, dbf, dkb, dbb)
+
+    def rel(a, b, name, tol=4e-2):
+        a, b = a.detach().cpu().double(), b.detach().cpu().double()
+        err = (a - b).norm() / (b.norm() + 1e-30)
+        assert err < tol, "%s: relative L2 error %.4f" % (name, err)
+
+    rel(dx, leaves[0].grad, "dx")
+    rel(dkf, leaves[1].grad, "dkernel_fw")
+    rel(dbf, leaves[2].grad, "dbias_fw")
+    if not share:
+        rel(dkb, leaves[3].grad, "dkernel_bw")
+
+
+def test_model_bf16_matches_oracle_loosely_and_fp32_engine_closely():
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import CONFIGS, SynthSpec, make_inputs, make_params
+    from oracle import fvta_fused as F
+    spec = SynthSpec(dense=False, **CONFIGS["plumbing"])
+    params, inputs = make_params(spec), make_inputs(spec)
+    with torch.no_grad():
+        ref = F.fvta_forward({k: v.double() for k, v in params.items()},
+                             {k: v for k, v in __import__("fvta_memexqa_amd.synth", fromlist=["to_dtype"]).to_dtype(inputs, torch.float64).items()},
+                             spec.cfg())
+    outs = {}
+    for prec in ("f32", "bf16"):
+        model = Model(dict(spec.cfg(), batch_size=spec.N, precision=prec), text_in=spec.text_in, img_in=spec.img_in)
+        model.set_oracle_params(params)
+        L = model.load_inputs(inputs, training=True)
+        model.zero_grad()
+        outs[prec] = model.forward(L).cpu().double()
+        model.backward(L)
+        outs[prec + "_g"] = torch.from_numpy(model.get_oracle_grads()["text_kernel"]).double()
+    _close(outs["f32"], ref["yp"], rtol=1e-4, atol=1e-5, msg="fp32 engine")
+    _close(outs["bf16"], ref["yp"], rtol=0, atol=2e-2, msg="bf16 engine")
+    err = (outs["bf16_g"] - outs["f32_g"]).norm() / outs["f32_g"].norm()
+    assert err < 5e-2, "bf16 text_kernel gradient off by %.4f (relative L2)" % err
