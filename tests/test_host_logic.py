@@ -1,0 +1,74 @@
+"""Host-side logic that needs no GPU: synthetic spec shapes, hidden-size padding maps, parameter
+naming, product/oracle separation."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from fvta_memexqa_amd.synth import CONFIGS, SynthSpec, make_inputs, make_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_synth_shapes_match_survey_table():
+    m = SynthSpec(**CONFIGS["metric"])
+    assert (m.K, m.JMAX, m.T, m.w) == (6, 1200, 1200, 1024)          # hall [64,6,1,1200,1024]
+    p = SynthSpec(**CONFIGS["plumbing"])
+    assert (p.N, p.K, p.A, p.JMAX, p.w) == (4, 3, 2, 50, 256)        # hall [4,3,2,50,256]
+    s = SynthSpec(**CONFIGS["long_album"])
+    assert (s.K, s.T, s.w) == (7, 7200, 2048)                        # hall [32,7,1,7200,2048]
+
+
+def test_synth_inputs_are_seeded_and_ragged():
+    spec = SynthSpec(N=3, A=2, P=4, S=2, L=6, d=8, dense=False, text_in=8, img_in=4)
+    a, b = make_inputs(spec), make_inputs(spec)
+    assert torch.equal(a["ctx"][0]["x"], b["ctx"][0]["x"])
+    c = make_inputs(spec, rank=1)
+    assert not torch.equal(a["ctx"][0]["x"], c["ctx"][0]["x"])
+    m = a["ctx"][0]["mask"]
+    ln = m.sum(-1)
+    assert (m == (torch.arange(6) < ln[..., None])).all()            # prefix masks (model_v2.py:1346-1358)
+    assert a["y"].sum(1).eq(1).all()
+    dense = make_inputs(SynthSpec(N=2, A=1, P=3, S=1, L=4, d=8, dense=True, text_in=8, img_in=4))
+    assert dense["ctx"][0]["mask"].all() and dense["q"]["mask"].all()
+
+
+def test_param_shapes_follow_reference():
+    spec = SynthSpec(N=2, A=1, P=3, S=1, L=4, d=16, text_in=12, img_in=8, simiMatrix=2)
+    p = make_params(spec)
+    assert p["text_kernel"].shape == (12 + 16, 64) and p["image_kernel"].shape == (8 + 16, 64)
+    assert p["att_W"].shape == (2 * 32, 1) and p["out_W"].shape == (5 * 32, 1)
+    assert float(p["att_W"].abs().max()) <= 0.2 + 1e-6               # truncated normal, 2 sigma (model_v2.py:88)
+    assert float(p["text_bias"].abs().max()) == 0.0
+
+
+def test_padded_hidden_map():
+    from fvta_memexqa_amd.model_v2 import padded_hidden
+    assert [padded_hidden(d) for d in (20, 32, 50, 100, 128, 512, 1000)] == [32, 32, 64, 128, 128, 512, 1024]
+    with pytest.raises(ValueError):
+        padded_hidden(2000)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+    leg may touch it."""
+    pkg = os.path.join(ROOT, "fvta_memexqa_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"from oracle", bench)]
+    assert len(uses) == 1 and bench.rfind("def cpu_baseline", 0, uses[0]) > bench.rfind("def main", 0, uses[0])
+
+
+def test_no_reference_sources_in_repo():
+    for dirpath, dirs, files in os.walk(ROOT):
+        dirs[:] = [d for d in dirs if d not in (".git", "gpurun_out", "__pycache__")]
+        for f in files:
+            if f.endswith(".py") and f != os.path.basename(__file__):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*import tensorflow", src, flags=re.M), os.path.join(dirpath, f)
