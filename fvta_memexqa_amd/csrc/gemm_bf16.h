@@ -1,13 +1,21 @@
 // bf16 tile engine on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate).
 //
-// Block tile BM x BN, BK = 32 (two MFMA k-steps), one wave per SIMD.
-//  * "row" images (NN / NT products): As[BM][LDK], Bs[BN][LDK] with k contiguous
-//    (LDK = 40 elements = 80 B rows: conflict-free ds_read_b128 for the operand
-//    map lane l -> row l&31, k = 8(l>>5)+j).
-//  * "k-major" images (TN product, weight gradient): As[BK][LDM], Bs[BK][LDN]
-//    exactly as the sources lie in memory (m / n contiguous), consumed through
-//    ds_read_b64_tr_b16, the hardware transposing read; row stride BM+32
-//    elements (= 16 banks mod 64) keeps the four k-rows of a read apart.
+// Structure (MI355X guide, "glds + counted vmcnt + raw barrier"):
+//  * block tile 256 x 128, BK = 32, four waves stacked in M (wave tile 64 x 128 =
+//    2 x 4 MFMA tiles, 6 LDS fragments per 8 MFMAs), 256 threads;
+//  * operands go global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KiB per
+//    wave-instruction, no VGPR staging, no ds_write), three LDS stages of 24 KiB
+//    (72 KiB per workgroup -> two workgroups per CU), two tiles in flight behind a
+//    counted s_waitcnt vmcnt and ONE raw s_barrier per k-tile;
+//  * LDS images are unpadded (the DMA writes lane-linear) and XOR-swizzled in
+//    16-byte chunks; the swizzle is applied to the per-lane SOURCE address and to
+//    the fragment read address (never to the DMA destination);
+//  * out-of-range rows/columns come back as zeros from the buffer descriptor's
+//    range check (voffset sentinel), so there is no control flow around loads.
+// Two image kinds:
+//   "rows"    As[BM][32], Bs[BN][32]   (k contiguous)  -> ds_read_b128 fragments
+//   "k-major" As[32][BM], Bs[32][BN]   (m/n contiguous, as the weight-gradient
+//             operands lie in memory) -> ds_read_b64_tr_b16 fragments
 // C/D layout equals the fp32 engine's (dtype independent on gfx950).
 #pragma once
 #include "fvta_common.h"
@@ -17,45 +25,46 @@ namespace fvta {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
 union Pack8 {
-  bf16x8 s;  // 8 x 16-bit
+  bf16x8 s;
   bf16x8_t b;
-  f32x4 f;   // raw 16 bytes
+  f32x4 f;
 };
 
-__device__ __forceinline__ bf16x8 cvt8(const f32x4& lo, const f32x4& hi) {
-  bf16x8 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    r[i] = (short)f2bf(lo[i]);
-    r[i + 4] = (short)f2bf(hi[i]);
-  }
-  return r;
+constexpr unsigned GLDS_OOB = 0x80000000u;  // voffset sentinel: beyond any descriptor -> the load returns 0
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+// one wave-instruction: 64 lanes x 16 B from (rsrc + voff + soff) to LDS [dst, dst + 1 KiB) in lane order
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, bf16_t* dst, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)dst, 16, voff, soff, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WAVES_M_, int WAVES_N_, int TM_, int TN_>
-struct MmaBf16 {
-  static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, TM = TM_, TN = TN_;
-  static constexpr int BM = WAVES_M * TM * 32;
-  static constexpr int BN = WAVES_N * TN * 32;
-  static constexpr int BK = 32;
-  static constexpr int NT = WAVES_M * WAVES_N * 64;
-  static constexpr int LDK = BK + 8;   // row images
-  static constexpr int LDM = BM + 32;  // k-major images
-  static constexpr int LDN = BN + 32;
-  static constexpr int A_ELEMS = (BM * LDK > BK * LDM) ? BM * LDK : BK * LDM;
-  static constexpr int B_ELEMS = (BN * LDK > BK * LDN) ? BN * LDK : BK * LDN;
-  static constexpr int LDS_BYTES = 2 * (A_ELEMS + B_ELEMS) * 2;
+struct TileCfg {
+  static constexpr int BM = 256, BN = 128, BK = 32, STAGES = 3, NT = 256;
+  static constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;  // per stage
+  static constexpr int STAGE_ELEMS = A_ELEMS + B_ELEMS;
+  static constexpr int LDS_BYTES = STAGES * STAGE_ELEMS * 2;  // 73,728
+  static constexpr int A_GLDS = A_ELEMS * 2 / 1024 / 4;       // wave-instructions per wave per tile: 4
+  static constexpr int B_GLDS = B_ELEMS * 2 / 1024 / 4;       // 2
+};
 
+// ---- accumulators + fragment reads -------------------------------------------------------------
+struct MmaB {
+  static constexpr int TM = 2, TN = 4, WAVES_M = 4, WAVES_N = 1, BM = TileCfg::BM, BN = TileCfg::BN;
   f32x16 acc[TM][TN];
-  int wm, wn, l31, hf, lane;
+  int wave, lane, l31, hf;
 
   __device__ __forceinline__ void init(int tid) {
-    const int wave = tid >> 6;
+    wave = tid >> 6;
     lane = tid & 63;
-    wm = wave / WAVES_N;
-    wn = wave % WAVES_N;
     l31 = lane & 31;
     hf = lane >> 5;
 #pragma unroll
@@ -66,17 +75,22 @@ struct MmaBf16 {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  // row images: As[BM][LDK], Bs[BN][LDK]
+  // row images, 64-byte rows, chunk c of row r stored at chunk c ^ ((r >> 2) & 3)
   __device__ __forceinline__ void compute_rows(const bf16_t* __restrict__ As, const bf16_t* __restrict__ Bs) {
-    const bf16_t* ap = As + (wm * (TM * 32) + l31) * LDK + 8 * hf;
-    const bf16_t* bp = Bs + (wn * (TN * 32) + l31) * LDK + 8 * hf;
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
+    for (int ks = 0; ks < 2; ++ks) {
       Pack8 a[TM], b[TN];
+      const int c = 2 * ks + hf;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i].f = *reinterpret_cast<const f32x4*>(ap + i * 32 * LDK + ks * 16);
+      for (int i = 0; i < TM; ++i) {
+        const int r = wave * 64 + i * 32 + l31;
+        a[i].f = *reinterpret_cast<const f32x4*>(As + r * 32 + ((c ^ ((r >> 2) & 3)) << 3));
+      }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j].f = *reinterpret_cast<const f32x4*>(bp + j * 32 * LDK + ks * 16);
+      for (int j = 0; j < TN; ++j) {
+        const int r = j * 32 + l31;
+        b[j].f = *reinterpret_cast<const f32x4*>(Bs + r * 32 + ((c ^ ((r >> 2) & 3)) << 3));
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -85,15 +99,19 @@ struct MmaBf16 {
     }
   }
 
-  // one operand fragment from a k-major image via the transposing read:
-  // group g = lane>>4 reads the 4(k) x 16(m) blocks at k0 = kbase + 8(g>>1) (+4), m0 = mbase + 16(g&1);
-  // lane 4q+p of the group supplies row k0+q, columns m0+4p..+3 and receives column m0+(lane&15).
-  __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* img, int ld, int kbase, int mbase) const {
+  // k-major image [32][LD] (LD = 256 or 128 elements), chunk c of row k stored at c ^ ((k & 3) << 2).
+  // Transposing read: group g = lane>>4 reads the 4(k) x 16(m) blocks at k0 = kbase + 8(g>>1) (+4),
+  // m0 = mbase + 16(g&1); lane 4q+p of the group supplies row k0+q, columns m0+4p..+3 and receives
+  // column m0 + (lane&15).
+  template <int LD>
+  __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* img, int kbase, int mbase) const {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const bf16_t* p0 = img + (kbase + 8 * (g >> 1) + q) * ld + mbase + 16 * (g & 1) + 4 * p;
+    const int k0 = kbase + 8 * (g >> 1) + q;  // (k0 & 3) == q, also for k0 + 4
+    const int col = mbase + 16 * (g & 1) + 4 * p;
+    const int off = (((col >> 3) ^ (q << 2)) << 3) + (col & 7);
     typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p0 + 4 * ld));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + k0 * LD + off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + (k0 + 4) * LD + off));
     Pack8 r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -102,16 +120,14 @@ struct MmaBf16 {
     }
     return r.b;
   }
-
-  // k-major images: As[BK][LDM] (m contiguous), Bs[BK][LDN] (n contiguous)
   __device__ __forceinline__ void compute_kmajor(const bf16_t* __restrict__ As, const bf16_t* __restrict__ Bs) {
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
+    for (int ks = 0; ks < 2; ++ks) {
       bf16x8_t a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = tr_frag(As, LDM, ks * 16, wm * (TM * 32) + i * 32);
+      for (int i = 0; i < TM; ++i) a[i] = tr_frag<BM>(As, ks * 16, wave * 64 + i * 32);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = tr_frag(Bs, LDN, ks * 16, wn * (TN * 32) + j * 32);
+      for (int j = 0; j < TN; ++j) b[j] = tr_frag<BN>(Bs, ks * 16, j * 32);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -119,95 +135,79 @@ struct MmaBf16 {
     }
   }
 
-  __device__ __forceinline__ int row_of(int i, int r) const {
-    return wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-  }
-  __device__ __forceinline__ int col_of(int j) const { return wn * (TN * 32) + j * 32 + l31; }
+  __device__ __forceinline__ int row_of(int i, int r) const { return wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf; }
+  __device__ __forceinline__ int col_of(int j) const { return j * 32 + l31; }
 };
 
-// ---- register-staged tiles (8 bf16 = 16 B units) ----------------------------
-// Row image from a source that yields 8 consecutive k of row r as two fp32 quads (converted here)
-// or as 8 ready bf16.  fetch(r, k) -> bf16x8.
-template <int ROWS, int BK, int NT, int LD>
-struct StageRows {
-  static constexpr int UNITS = ROWS * BK / 8;
-  static constexpr int PER = (UNITS + NT - 1) / NT;
-  bf16x8 v[PER];
-  template <class F>
-  __device__ __forceinline__ void fetch(F&& f, int k0, int tid) {
+// ---- per-lane DMA source offsets ---------------------------------------------------------------
+// Row image of ROWS rows: wave-instruction n (0 .. ROWS/16-1) fills LDS chunks [64n, 64n+64): unit
+// U = 64n + lane -> row U>>2, physical chunk U&3, i.e. logical chunk (U&3) ^ ((row>>2)&3).
+// voff[j] (instruction n = wave*PER + j) = row * ld_bytes + 16 * logical chunk, or GLDS_OOB for rows
+// >= nrows.  The k position is added through the scalar offset at issue time.
+template <int PER>
+struct RowSrc {
+  unsigned voff[PER];
+  __device__ __forceinline__ void setup(int wave, int lane, int row0, int nrows, unsigned ld_bytes) {
 #pragma unroll
-    for (int p = 0; p < PER; ++p) {
-      const int u = tid + p * NT;
-      if (UNITS % NT == 0 || u < UNITS) v[p] = f(u / (BK / 8), k0 + (u % (BK / 8)) * 8);
+    for (int j = 0; j < PER; ++j) {
+      const int U = (wave * PER + j) * 64 + lane;
+      const int row = U >> 2, c = (U & 3) ^ ((row >> 2) & 3);
+      voff[j] = (row0 + row < nrows) ? (unsigned)(row0 + row) * ld_bytes + 16u * c : GLDS_OOB;
     }
   }
-  __device__ __forceinline__ void store(bf16_t* lds, int tid) const {
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, bf16_t* stage, int wave, unsigned soff) const {
 #pragma unroll
-    for (int p = 0; p < PER; ++p) {
-      const int u = tid + p * NT;
-      if (UNITS % NT == 0 || u < UNITS)
-        *reinterpret_cast<bf16x8*>(lds + (u / (BK / 8)) * LD + (u % (BK / 8)) * 8) = v[p];
-    }
+    for (int j = 0; j < PER; ++j) glds16(rsrc, stage + (wave * PER + j) * 512, voff[j], soff);
   }
 };
 
-// k-major image: fetch(k, c) -> 8 consecutive columns c..c+7 of source row k as bf16x8.
-template <int COLS, int BK, int NT, int LD>
-struct StageKMajor {
-  static constexpr int UNITS = COLS * BK / 8;
-  static constexpr int PER = (UNITS + NT - 1) / NT;
-  bf16x8 v[PER];
-  template <class F>
-  __device__ __forceinline__ void fetch(F&& f, int k0, int tid) {
+// k-major image [32][COLS]: unit U = 64n + lane -> k-row U / (COLS/8), physical chunk U % (COLS/8),
+// logical chunk pc ^ ((k&3)<<2).  voff = k * ld_bytes + (col0*2 + 16c) or GLDS_OOB for columns >= ncols.
+// The k position (k0 * ld_bytes) is the scalar offset; rows beyond the operand's end fall off the
+// descriptor (its size is exactly nrows * ld_bytes).
+template <int COLS, int PER>
+struct KMajorSrc {
+  unsigned voff[PER];
+  __device__ __forceinline__ void setup(int wave, int lane, int col0, int ncols, unsigned ld_bytes) {
+    constexpr int CPR = COLS / 8;
 #pragma unroll
-    for (int p = 0; p < PER; ++p) {
-      const int u = tid + p * NT;
-      if (UNITS % NT == 0 || u < UNITS) v[p] = f(k0 + u / (COLS / 8), (u % (COLS / 8)) * 8);
+    for (int j = 0; j < PER; ++j) {
+      const int U = (wave * PER + j) * 64 + lane;
+      const int k = U / CPR, c = (U % CPR) ^ ((k & 3) << 2);
+      voff[j] = (col0 + 8 * c < ncols) ? (unsigned)k * ld_bytes + 2u * (unsigned)col0 + 16u * c : GLDS_OOB;
     }
   }
-  __device__ __forceinline__ void store(bf16_t* lds, int tid) const {
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, bf16_t* stage, int wave, unsigned soff) const {
 #pragma unroll
-    for (int p = 0; p < PER; ++p) {
-      const int u = tid + p * NT;
-      if (UNITS % NT == 0 || u < UNITS)
-        *reinterpret_cast<bf16x8*>(lds + (u / (COLS / 8)) * LD + (u % (COLS / 8)) * 8) = v[p];
-    }
+    for (int j = 0; j < PER; ++j) glds16(rsrc, stage + (wave * PER + j) * 512, voff[j], soff);
   }
 };
 
-// Double-buffered main loop (same schedule as the fp32 engine).  KMAJOR picks the image kind.
-template <bool KMAJOR, class Mma, class SA, class SB, class FA, class FB>
-__device__ __forceinline__ void gemm_mainloop_bf16(Mma& mma, SA& sa, SB& sb, FA&& fa, FB&& fb, int k_begin, int k_end,
-                                                   bf16_t* smem, int tid) {
-  bf16_t* As[2] = {smem, smem + Mma::A_ELEMS};
-  bf16_t* Bs[2] = {smem + 2 * Mma::A_ELEMS, smem + 2 * Mma::A_ELEMS + Mma::B_ELEMS};
-  if (k_begin >= k_end) return;
-  sa.fetch(fa, k_begin, tid);
-  sb.fetch(fb, k_begin, tid);
-  sa.store(As[0], tid);
-  sb.store(Bs[0], tid);
-  __syncthreads();
-  int cur = 0;
-  for (int k0 = k_begin; k0 < k_end; k0 += Mma::BK) {
-    const bool more = (k0 + Mma::BK) < k_end;
-    if (more) {
-      sa.fetch(fa, k0 + Mma::BK, tid);
-      sb.fetch(fb, k0 + Mma::BK, tid);
-    }
-    if (KMAJOR)
-      mma.compute_kmajor(As[cur], Bs[cur]);
+// ---- the pipeline --------------------------------------------------------------------------------
+// issue(tile, a_stage, b_stage) starts the DMA of one k-tile; ntiles k-tiles are consumed.
+// Every wave issues exactly A_GLDS + B_GLDS = 6 wave-instructions per tile, so "all but the newest
+// tile have landed" is s_waitcnt vmcnt(6).  The barrier after the wait both publishes tile t to all
+// waves and retires every wave's reads of stage (t-1)%3, which the next issue overwrites.
+template <bool KMAJOR, class Issue>
+__device__ __forceinline__ void glds_mainloop(MmaB& mma, Issue&& issue, int ntiles, bf16_t* smem) {
+  auto a_stage = [&](int t) { return smem + (t % TileCfg::STAGES) * TileCfg::STAGE_ELEMS; };
+  if (ntiles <= 0) return;
+  issue(0, a_stage(0), a_stage(0) + TileCfg::A_ELEMS);
+  if (ntiles > 1) issue(1, a_stage(1), a_stage(1) + TileCfg::A_ELEMS);
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles)
+      wait_vmcnt<TileCfg::A_GLDS + TileCfg::B_GLDS>();
     else
-      mma.compute_rows(As[cur], Bs[cur]);
-    if (more) {
-      sa.store(As[cur ^ 1], tid);
-      sb.store(Bs[cur ^ 1], tid);
-    }
-    __syncthreads();
-    cur ^= 1;
+      wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < ntiles) issue(t + 2, a_stage(t + 2), a_stage(t + 2) + TileCfg::A_ELEMS);
+    const bf16_t* As = a_stage(t);
+    if (KMAJOR)
+      mma.compute_kmajor(As, As + TileCfg::A_ELEMS);
+    else
+      mma.compute_rows(As, As + TileCfg::A_ELEMS);
   }
 }
-
-__device__ __forceinline__ bf16x8 ld8h(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
-__device__ __forceinline__ bf16x8 zero8h() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
 
 }  // namespace fvta

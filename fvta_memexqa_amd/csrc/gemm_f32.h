@@ -68,8 +68,11 @@ struct MmaF32 {
   __device__ __forceinline__ int col_of(int j) const { return wn * (TN * 32) + j * 32 + l31; }
 };
 
-// Register-staged tile whose SOURCE rows are k-contiguous: fetch(r, k) returns
-// the 4 floats src[r][k..k+3] (zeros out of range).  Stored transposed.
+// Fetch protocol (both stage kinds): f(i, j, ok) returns an ALWAYS DEREFERENCEABLE pointer to
+// 4 floats and sets ok; the stage loads unconditionally and zeroes the value afterwards.  A load
+// under a data-dependent branch makes hipcc wait vmcnt(0) per load (serialised L2 round trips).
+//
+// Register-staged tile whose SOURCE rows are k-contiguous: f(r, k, ok) -> &src[r][k].  Stored transposed.
 template <int ROWS, int BK, int NT, int LD>
 struct StageKContig {
   static constexpr int UNITS = ROWS * BK / 4;
@@ -80,7 +83,12 @@ struct StageKContig {
 #pragma unroll
     for (int p = 0; p < PER; ++p) {
       const int u = tid + p * NT;
-      if (UNITS % NT == 0 || u < UNITS) v[p] = f(u / (BK / 4), k0 + (u % (BK / 4)) * 4);
+      if (UNITS % NT == 0 || u < UNITS) {
+        bool ok;
+        const float* src = f(u / (BK / 4), k0 + (u % (BK / 4)) * 4, ok);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+        v[p] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
   __device__ __forceinline__ void store(float* lds, int tid) const {
@@ -96,8 +104,7 @@ struct StageKContig {
   }
 };
 
-// Register-staged tile whose SOURCE rows are m/n-contiguous: fetch(k, c) returns
-// src[k][c..c+3].  Stored as is.
+// Register-staged tile whose SOURCE rows are m/n-contiguous: f(k, c, ok) -> &src[k][c].  Stored as is.
 template <int COLS, int BK, int NT, int LD>
 struct StageMNContig {
   static constexpr int UNITS = COLS * BK / 4;
@@ -108,7 +115,12 @@ struct StageMNContig {
 #pragma unroll
     for (int p = 0; p < PER; ++p) {
       const int u = tid + p * NT;
-      if (UNITS % NT == 0 || u < UNITS) v[p] = f(k0 + u / (COLS / 4), (u % (COLS / 4)) * 4);
+      if (UNITS % NT == 0 || u < UNITS) {
+        bool ok;
+        const float* src = f(k0 + u / (COLS / 4), (u % (COLS / 4)) * 4, ok);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+        v[p] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
   __device__ __forceinline__ void store(float* lds, int tid) const {

@@ -18,6 +18,8 @@
 
 namespace fvta {
 
+__device__ const float k_ones4[4] = {1.f, 0.f, 0.f, 0.f};  // the [x | h | 1] ones column (dbias)
+
 // ------------------------------------------------------------------ plan ----
 
 // Stable counting sort by length, descending.  One 1024-thread workgroup; each
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_f32(StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int64_t s_xo[MmaStep::BM];
   __shared__ int64_t s_ho[MmaStep::BM];
+  __shared__ int64_t s_oo[MmaStep::BM];
   const int tid = threadIdx.x;
   const int dir = blockIdx.z;
   const int m0 = blockIdx.x * MmaStep::BM;
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_f32(StepArgs a) {
       oo = a.plan.oo[trow + i];
     }
     s_xo[tid] = xo;
+    s_oo[tid] = oo;
     // h_{t-1} sits one output row before (fw) / after (bw) this step's row
     s_ho[tid] = (oo < 0 || t == 0) ? -1 : (dir ? oo + out_ld : oo - out_ld);
   }
@@ -175,23 +179,21 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_f32(StepArgs a) {
   mma.init(tid);
   StageKContig<MmaStep::BM, MmaStep::BK, MmaStep::NT, MmaStep::LDA> sa;
   StageMNContig<MmaStep::BN, MmaStep::BK, MmaStep::NT, MmaStep::LDB> sb;
-  auto fa = [&](int r, int k) -> f32x4 {
-    if (k >= K) return zero4();
-    if (k < in) {
-      const int64_t o = s_xo[r];
-      return o < 0 ? zero4() : ld4(x + o + k);
-    }
-    const int64_t o = s_ho[r];
-    return o < 0 ? zero4() : ld4(hsrc + o + (k - in));
+  auto fa = [&](int r, int k, bool& ok) -> const float* {  // 4 consecutive k of row r of [x | h_prev]
+    const bool isx = k < in;
+    const int64_t o = isx ? s_xo[r] : s_ho[r];
+    ok = (k < K) && (o >= 0);
+    const float* base = isx ? x + k : hsrc + (k - in);
+    return ok ? base + o : x;  // x itself is always dereferenceable
   };
-  auto fb = [&](int k, int c) -> f32x4 {
-    if (k >= K) return zero4();
+  auto fb = [&](int k, int c, bool& ok) -> const float* {
+    ok = k < K;
     const int g = c >> 5, u = c & 31;  // virtual column -> gate strip
-    return ld4(W + (size_t)k * (4 * d) + g * d + u0 + u);
+    return W + (size_t)(ok ? k : 0) * (4 * d) + g * d + u0 + u;
   };
   gemm_mainloop(mma, sa, sb, fa, fb, 0, K, smem, tid);
 
-  lstm_gate_epilogue(mma, a, dir, m0, u0, nact, trow);
+  lstm_gate_epilogue(mma, a, dir, m0, u0, nact, trow, s_oo);
 }
 
 // ------------------------------------------------------- backward pieces ----
@@ -210,10 +212,16 @@ __global__ void lstm_gate_bwd(GateBwdArgs a) {
   // rows whose last step is t have never been written by a later step: dh_rec, dc are still 0
   const float dh = a.d_out[oo + u] + a.dh_rec[su];
   float* g = a.gates + (trow + i) * (size_t)(4 * d) + u;
-  const float ig = g[0], jg = g[d], fg = g[2 * d], og = g[3 * d];
+  float ig, jg, fg, og;
+  if (a.gatesb) {
+    const bf16_t* gb = a.gatesb + (trow + i) * (size_t)(4 * d) + u;
+    ig = bf2f(gb[0]), jg = bf2f(gb[d]), fg = bf2f(gb[2 * d]), og = bf2f(gb[3 * d]);
+  } else {
+    ig = g[0], jg = g[d], fg = g[2 * d], og = g[3 * d];
+  }
   const float c = a.cs[(trow + i) * d + u];
   const float cprev = t > 0 ? a.cs[(trow - a.B + i) * d + u] : 0.f;
-  const float tc = tanhf(c);
+  const float tc = fvta_tanh(c);
   const float dc = a.dc[su] + dh * og * (1.f - tc * tc);
   const float dzi = dc * jg * ig * (1.f - ig), dzj = dc * ig * (1.f - jg * jg);
   const float dzf = dc * cprev * fg * (1.f - fg), dzo = dh * tc * og * (1.f - og);
@@ -251,13 +259,15 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_f32(StepBwdArgs a) {
   mma.init(tid);
   StageKContig<MmaSq::BM, MmaSq::BK, MmaSq::NT, MmaSq::LDA> sa;
   StageKContig<MmaSq::BN, MmaSq::BK, MmaSq::NT, MmaSq::LDB> sb;
-  auto fa = [&](int r, int k) -> f32x4 {
+  auto fa = [&](int r, int k, bool& ok) -> const float* {
     const int i = m0 + r;
-    return i < nact ? ld4(dz + (size_t)i * K + k) : zero4();
+    ok = i < nact;
+    return dz + (size_t)(ok ? i : 0) * K + k;
   };
-  auto fb = [&](int r, int k) -> f32x4 {
+  auto fb = [&](int r, int k, bool& ok) -> const float* {
     const int n = n0 + r;
-    return n < NN ? ld4(W + (size_t)n * K + k) : zero4();
+    ok = n < NN;
+    return W + (size_t)(ok ? n : 0) * K + k;
   };
   gemm_mainloop(mma, sa, sb, fa, fb, 0, K, smem, tid);
 #pragma unroll
@@ -302,19 +312,18 @@ __global__ __launch_bounds__(256) void lstm_dw_f32(DwArgs a) {
     const float* __restrict__ dz = a.dz + trow * (size_t)N4;
     const int64_t* __restrict__ xo = a.plan.xo + trow;
     const int64_t* __restrict__ oo = a.plan.oo + trow;
-    auto fa = [&](int k, int c) -> f32x4 {  // A[k = sorted row][m]
-      if (k >= nact) return zero4();
+    auto fa = [&](int k, int c, bool& ok) -> const float* {  // A[k = sorted row][m] of [x | h_prev | 1]
       const int m = m0 + c;
-      if (m < in) return ld4(a.x + xo[k] + m);
-      if (m < in + d) {
-        if (t == 0) return zero4();
-        const int64_t ho = dir ? oo[k] + out_ld : oo[k] - out_ld;
-        return ld4(a.out + ho + (m - in));
-      }
-      return m == in + d ? f32x4{1.f, 0.f, 0.f, 0.f} : zero4();  // ones column -> dbias
+      const int kk = k < nact ? k : 0;
+      const bool isx = m < in, ish = !isx && m < in + d;
+      const int64_t o = isx ? xo[kk] : (dir ? oo[kk] + out_ld : oo[kk] - out_ld);
+      ok = (k < nact) && (isx || (ish && t > 0) || m == in + d);
+      const float* src = isx ? a.x + o + m : a.out + o + (m - in);
+      return (ok && (isx || ish)) ? src : k_ones4;  // ones column -> dbias
     };
-    auto fb = [&](int k, int c) -> f32x4 {
-      return k < nact ? ld4(dz + (size_t)k * N4 + n0 + c) : zero4();
+    auto fb = [&](int k, int c, bool& ok) -> const float* {
+      ok = k < nact;
+      return dz + (size_t)(ok ? k : 0) * N4 + n0 + c;
     };
     gemm_mainloop(mma, sa, sb, fa, fb, 0, (nact + MmaSq::BK - 1) / MmaSq::BK * MmaSq::BK, smem, tid);
   }
@@ -374,20 +383,20 @@ __global__ __launch_bounds__(256) void test_gemm_f32(int M, int N, int K, const 
   if (LAYOUT == 0) {  // A[M,K] k-contig, B[K,N] n-contig
     StageKContig<MmaSq::BM, MmaSq::BK, MmaSq::NT, MmaSq::LDA> sa;
     StageMNContig<MmaSq::BN, MmaSq::BK, MmaSq::NT, MmaSq::LDB> sb;
-    auto fa = [&](int r, int k) -> f32x4 { return (m0 + r < M && k < K) ? ld4(A + (size_t)(m0 + r) * K + k) : zero4(); };
-    auto fb = [&](int k, int c) -> f32x4 { return (k < K && n0 + c < N) ? ld4(B + (size_t)k * N + n0 + c) : zero4(); };
+    auto fa = [&](int r, int k, bool& ok) -> const float* { ok = m0 + r < M && k < K; return ok ? A + (size_t)(m0 + r) * K + k : A; };
+    auto fb = [&](int k, int c, bool& ok) -> const float* { ok = k < K && n0 + c < N; return ok ? B + (size_t)k * N + n0 + c : B; };
     gemm_mainloop(mma, sa, sb, fa, fb, 0, Kp, smem, tid);
   } else if (LAYOUT == 1) {  // A[M,K], B[N,K] both k-contig
     StageKContig<MmaSq::BM, MmaSq::BK, MmaSq::NT, MmaSq::LDA> sa;
     StageKContig<MmaSq::BN, MmaSq::BK, MmaSq::NT, MmaSq::LDB> sb;
-    auto fa = [&](int r, int k) -> f32x4 { return (m0 + r < M && k < K) ? ld4(A + (size_t)(m0 + r) * K + k) : zero4(); };
-    auto fb = [&](int r, int k) -> f32x4 { return (n0 + r < N && k < K) ? ld4(B + (size_t)(n0 + r) * K + k) : zero4(); };
+    auto fa = [&](int r, int k, bool& ok) -> const float* { ok = m0 + r < M && k < K; return ok ? A + (size_t)(m0 + r) * K + k : A; };
+    auto fb = [&](int r, int k, bool& ok) -> const float* { ok = n0 + r < N && k < K; return ok ? B + (size_t)(n0 + r) * K + k : B; };
     gemm_mainloop(mma, sa, sb, fa, fb, 0, Kp, smem, tid);
   } else {  // A[K,M], B[K,N] both k-major
     StageMNContig<MmaSq::BM, MmaSq::BK, MmaSq::NT, MmaSq::LDA> sa;
     StageMNContig<MmaSq::BN, MmaSq::BK, MmaSq::NT, MmaSq::LDB> sb;
-    auto fa = [&](int k, int c) -> f32x4 { return (k < K && m0 + c < M) ? ld4(A + (size_t)k * M + m0 + c) : zero4(); };
-    auto fb = [&](int k, int c) -> f32x4 { return (k < K && n0 + c < N) ? ld4(B + (size_t)k * N + n0 + c) : zero4(); };
+    auto fa = [&](int k, int c, bool& ok) -> const float* { ok = k < K && m0 + c < M; return ok ? A + (size_t)k * M + m0 + c : A; };
+    auto fb = [&](int k, int c, bool& ok) -> const float* { ok = k < K && n0 + c < N; return ok ? B + (size_t)k * N + n0 + c : B; };
     gemm_mainloop(mma, sa, sb, fa, fb, 0, Kp, smem, tid);
   }
 #pragma unroll
@@ -418,9 +427,7 @@ static int check_lstm_desc(const fvta_lstm_desc* d) {
 }
 
 extern "C" size_t fvta_lstm_plan_bytes(const fvta_lstm_desc* d) { return plan_view(d, nullptr).bytes; }
-extern "C" size_t fvta_lstm_saved_bytes(const fvta_lstm_desc* d) {
-  return d->training ? saved_view(d, nullptr).bytes : 256;
-}
+extern "C" size_t fvta_lstm_saved_bytes(const fvta_lstm_desc* d) { return saved_view(d, nullptr).bytes; }
 extern "C" size_t fvta_lstm_workspace_bytes(const fvta_lstm_desc* d) { return work_view(d, nullptr).bytes; }
 
 extern "C" int fvta_lstm_plan(const fvta_lstm_desc* d, const int32_t* len, const int32_t* seq_J,
@@ -448,7 +455,7 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   if (int e = check_lstm_desc(d)) return e;
   FVTA_CHECK_ARG(plan && x && out && kernel_fw && bias_fw && workspace, "bilstm_fwd: null pointer");
   FVTA_CHECK_ARG(d->share_fw_bw || (kernel_bw && bias_bw), "bilstm_fwd: kernel_bw/bias_bw required");
-  FVTA_CHECK_ARG(!d->training || saved, "bilstm_fwd: training needs a saved buffer");
+  FVTA_CHECK_ARG(saved, "bilstm_fwd: saved buffer required (size it with fvta_lstm_saved_bytes)");
   hipStream_t stream = (hipStream_t)stream_;
   PlanView pv = plan_view(d, const_cast<void*>(plan));
   WorkView wv = work_view(d, workspace);
@@ -460,14 +467,12 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   a.bias[0] = bias_fw;
   a.W[1] = d->share_fw_bw ? kernel_fw : kernel_bw;
   a.bias[1] = d->share_fw_bw ? bias_fw : bias_bw;
-  if (d->training) {
-    SavedView sv = saved_view(d, saved);
-    a.gates = sv.gates;
-    a.cs = sv.cs;
-  } else {
-    a.gates = nullptr;
-    a.cs = nullptr;
-  }
+  SavedView sv = saved_view(d, saved);
+  a.gates = sv.gates;  // null when not training
+  a.gatesb = sv.gatesb;
+  a.cs = sv.cs;
+  a.xs = sv.xs;        // null for the fp32 engine
+  a.hs = sv.hs;
   a.cstate = wv.cstate;
   a.B = d->B;
   a.J = d->J;
@@ -480,18 +485,23 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   fvta_prof_begin(FVTA_PROF_LSTM_STEP_FWD + 16 * d->reserved, stream);
   const bool bf = d->precision == FVTA_BF16;
   a.Kp = kpad8(d);
+  {
+    const char* e = getenv("FVTA_DEBUG_SKIP");
+    a.dbg = e ? atoi(e) : 0;
+  }
   a.Wt[0] = a.Wt[1] = nullptr;
   if (bf) {  // refresh the bf16 weight shadows (the optimiser has just changed the fp32 masters)
     const int ndir = d->share_fw_bw ? 1 : 2;
     for (int i = 0; i < ndir; ++i)
-      launch_cvt_weights_bf16(a.W[i], wv.wt[i], wv.wb[i], d->in + d->d, a.Kp, 4 * d->d, stream);
+      launch_cvt_weights_bf16(a.W[i], wv.wt[i], wv.wb[i], d->in, in_internal(d), d->d, stream);
     a.Wt[0] = wv.wt[0];
     a.Wt[1] = d->share_fw_bw ? wv.wt[0] : wv.wt[1];
+    launch_cvt_x_bf16(pv, x, sv.xs, d->B, d->J, d->in, in_internal(d), stream);
   }
   for (int t = 0; t < d->J; ++t) {
     a.t = t;
     if (bf)
-      launch_step_fwd_bf16(a, grid, stream);
+      launch_step_fwd_bf16(a, stream);
     else
       hipLaunchKernelGGL(lstm_step_fwd_f32, grid, dim3(256), sh, stream, a);
   }
@@ -519,6 +529,7 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
   g.plan = pv;
   g.d_out = d_out;
   g.gates = sv.gates;
+  g.gatesb = sv.gatesb;
   g.cs = sv.cs;
   g.dc = wv.cstate;
   g.dh_rec = wv.dh_rec;
@@ -535,6 +546,7 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
   s.dx = dx;
   s.dh_rec = wv.dh_rec;
   s.dzb = wv.dzb;
+  s.in_i = in_internal(d);
   s.Wb[0] = wv.wb[0];
   s.Wb[1] = d->share_fw_bw ? wv.wb[0] : wv.wb[1];
   s.B = B;
@@ -551,7 +563,7 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
     hipLaunchKernelGGL(lstm_gate_bwd, ggrid, dim3(256), 0, stream, g);
     if (t > 0 || dx) {
       if (bf)
-        launch_step_bwd_bf16(s, sgrid, stream);
+        launch_step_bwd_bf16(s, stream);
       else
         hipLaunchKernelGGL(lstm_step_bwd_f32, sgrid, dim3(256), sh, stream, s);
     }
@@ -574,14 +586,23 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
   const dim3 wgrid((MM + MmaSq::BM - 1) / MmaSq::BM, N4 / MmaSq::BN, 2 * w.nsplit);
   fvta_prof_begin(FVTA_PROF_LSTM_DW + 16 * d->reserved, stream);
   w.dzb = wv.dzb;
+  w.in_i = in_internal(d);
+  w.xs = sv.xs;
+  w.hs = sv.hs;
   if (bf)
-    launch_dw_bf16(w, wgrid, stream);
+    launch_dw_bf16(w, stream);
   else
     hipLaunchKernelGGL(lstm_dw_f32, wgrid, dim3(256), sh, stream, w);
   FVTA_CHECK_LAUNCH("lstm_dw");
-  const size_t slab_elems = (size_t)MM * N4;
+  const size_t slab_elems = bf ? (size_t)kpad8(d) * N4 : (size_t)MM * N4;
   const unsigned rgrid = (unsigned)((slab_elems + 255) / 256);
-  if (d->share_fw_bw) {
+  if (bf) {  // slabs are in the engine's internal row order: x rows, ones row (dbias), zero pad, h rows
+    const int ndir = d->share_fw_bw ? 1 : 2;
+    for (int i = 0; i < ndir; ++i)
+      launch_dw_reduce_bf16(wv.slabs + (size_t)i * w.nsplit * slab_elems, d->share_fw_bw ? 2 * w.nsplit : w.nsplit,
+                            in, in_internal(d), dd, i == 0 ? dkernel_fw : dkernel_bw, i == 0 ? dbias_fw : dbias_bw,
+                            stream);
+  } else if (d->share_fw_bw) {
     hipLaunchKernelGGL(lstm_dw_reduce, dim3(rgrid), dim3(256), 0, stream, wv.slabs, 2 * w.nsplit, slab_elems,
                        in + dd, N4, dkernel_fw, dbias_fw);
   } else {

@@ -1,261 +1,337 @@
 // bi-LSTM step kernels on the bf16 MFMA engine (BASELINE.json configs[2]: bf16
-// compute, fp32 accumulate).  Same decomposition and epilogues as lstm.hip; the
-// operands are rounded to bf16 on their way into LDS, everything the cell state
-// touches (gates, c, h, dz, accumulators, weight-gradient slabs) stays fp32
-// except the stored gate-gradient rows dz, which are bf16 (they are only ever
-// consumed as MFMA operands).
+// compute, fp32 accumulate).  Same decomposition and epilogues as lstm.hip.
+//
+// Every MFMA operand is a DENSE bf16 matrix per (direction, step) in sorted-row
+// order, the layout gates / cs / dz already use:
+//   xs [2][J][B][in_i]  x at the position that (dir, t) visits, then a 1.0 column
+//                       (its weight-gradient row is dbias), zero padded so that
+//                       in_i is a multiple of 32 (k-tiles are wholly x or wholly h);
+//   hs [2][J][B][d]     h_t, written by the gate epilogue next to the fp32 h;
+//   dz [2][J][B][4d]    gate pre-activation gradients;
+//   wt [4d][in_i+d], wb [in_i+d][4d]  kernel shadows in that internal row order.
+// Active rows of a step are a prefix and nest across steps, so row i of step t-1
+// IS the h_{t-1} of row i of step t: no gathers anywhere, every tile streams
+// through the DMA pipeline of gemm_bf16.h.  grid.x (row tile) is padded to a
+// multiple of 8 so that the workgroups sharing a row tile share an XCD's L2.
+// Gates, c, h, accumulators and weight-gradient slabs stay fp32; the saved gate
+// activations are bf16 in this engine.
 #include "gemm_bf16.h"
-#include "gemm_f32.h"
 #include "lstm_common.h"
 
 namespace fvta {
 
-// ---- weight shadows: kernel [K][N4] fp32 -> wb [K][N4] bf16 and wt [N4][Kp] bf16 (zero padded)
+static inline int pad8(int v) { return (v + 7) / 8 * 8; }
+
+template <class K>
+static void allow_big_lds(K kernel, int bytes) {  // > 64 KB of dynamic LDS must be opted into, per kernel symbol
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+// ---- weight shadows in the internal row order [x rows | ones row | zero pad | h rows] -----------
+// kernel [in+d][N4] fp32 -> wb [in_i+d][N4] bf16, wt [N4][in_i+d] bf16.  grid (N4/32, (in_i+d)/32), 256 threads
 __global__ void cvt_weights_kernel(const float* __restrict__ W, bf16_t* __restrict__ wt, bf16_t* __restrict__ wb,
-                                   int K, int Kp, int N4) {
+                                   int in, int in_i, int d) {
   __shared__ float tile[32][33];
+  const int N4 = 4 * d, Ki = in_i + d;
   const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int r = ty; r < 32; r += 8) {
     const int k = k0 + r, n = n0 + tx;
-    const float v = (k < K && n < N4) ? W[(size_t)k * N4 + n] : 0.f;
+    const int src = k < in ? k : (k >= in_i ? in + (k - in_i) : -1);  // internal row -> kernel row
+    const float v = src >= 0 ? W[(size_t)src * N4 + n] : 0.f;
     tile[r][tx] = v;
-    if (k < K && n < N4) wb[(size_t)k * N4 + n] = f2bf(v);
+    wb[(size_t)k * N4 + n] = f2bf(v);
   }
   __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int n = n0 + r, k = k0 + tx;
-    if (n < N4 && k < Kp) wt[(size_t)n * Kp + k] = f2bf(tile[tx][r]);
+  for (int r = ty; r < 32; r += 8) wt[(size_t)(n0 + r) * Ki + k0 + tx] = f2bf(tile[tx][r]);
+}
+
+void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int in, int in_i, int d, hipStream_t s) {
+  hipLaunchKernelGGL(cvt_weights_kernel, dim3(4 * d / 32, (in_i + d) / 32), dim3(256), 0, s, W, wt, wb, in, in_i, d);
+}
+
+// ---- input shadow: xs[dir][t][i][:] for every active (dir, t, i).  grid (ceil(B/4), J, 2) -------
+__global__ void cvt_x_kernel(PlanView pv, const float* __restrict__ x, bf16_t* __restrict__ xs, int B, int J, int in,
+                             int in_i) {
+  const int t = blockIdx.y, dir = blockIdx.z;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= pv.nactive[t]) return;
+  const size_t idx = ((size_t)dir * J + t) * B + i;
+  const float* src = x + pv.xo[idx];
+  bf16_t* dst = xs + idx * in_i;
+  for (int c = lane * 4; c < in_i; c += 256) {
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = c + e;
+      o[e] = k < in ? (short)f2bf(src[k]) : (k == in ? (short)0x3f80 : (short)0);  // ones column at `in`
+    }
+    *reinterpret_cast<bf16x4*>(dst + c) = o;
   }
 }
 
-void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int K, int Kp, int N4, hipStream_t s) {
-  hipLaunchKernelGGL(cvt_weights_kernel, dim3((N4 + 31) / 32, (Kp + 31) / 32), dim3(256), 0, s, W, wt, wb, K, Kp, N4);
+void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, int J, int in, int in_i, hipStream_t s) {
+  hipLaunchKernelGGL(cvt_x_kernel, dim3((B + 3) / 4, J, 2), dim3(256), 0, s, pv, x, xs, B, J, in, in_i);
 }
 
 // ------------------------------------------------------------ forward step --
-using MmaStepB = MmaBf16<4, 1, 1, 4>;
-
-__global__ __launch_bounds__(256) void lstm_step_fwd_bf16(StepArgs a) {
+// z = [xs_t | hs_{t-1}] * wt^T over the 4 gate strips of 32 units.  grid (pad8(ceil(B/256)), d/32, 2)
+__global__ __launch_bounds__(256, 2) void lstm_step_fwd_bf16(StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
-  __shared__ int64_t s_xo[MmaStepB::BM];
-  __shared__ int64_t s_ho[MmaStepB::BM];
+  int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + TileCfg::STAGES * TileCfg::STAGE_ELEMS);  // [256], same array
   const int tid = threadIdx.x;
   const int dir = blockIdx.z;
-  const int m0 = blockIdx.x * MmaStepB::BM;
+  const int m0 = blockIdx.x * TileCfg::BM;
   const int nact = a.plan.nactive[a.t];
   if (m0 >= nact) return;
   const int u0 = blockIdx.y * 32;
-  const int d = a.d, in = a.in, t = a.t;
-  const int64_t out_ld = a.plan.hdr->out_ld;
+  const int d = a.d, t = a.t, in_i = a.Kp - a.d;
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
-  if (tid < MmaStepB::BM) {
-    const int i = m0 + tid;
-    int64_t xo = -1, oo = -1;
-    if (i < nact) {
-      xo = a.plan.xo[trow + i];
-      oo = a.plan.oo[trow + i];
-    }
-    s_xo[tid] = xo;
-    s_ho[tid] = (oo < 0 || t == 0) ? -1 : (dir ? oo + out_ld : oo - out_ld);
-  }
-  __syncthreads();
-  const bf16_t* __restrict__ Wt = a.Wt[dir];
-  const float* __restrict__ x = a.x;
-  const float* __restrict__ hsrc = a.out;
-  const int K = (t == 0) ? in : in + d;
-  const int Kp = a.Kp;
+  s_oo[tid] = (m0 + tid < nact) ? a.plan.oo[trow + m0 + tid] : -1;
 
-  MmaStepB mma;
+  MmaB mma;
   mma.init(tid);
-  StageRows<MmaStepB::BM, MmaStepB::BK, MmaStepB::NT, MmaStepB::LDK> sa;
-  StageRows<MmaStepB::BN, MmaStepB::BK, MmaStepB::NT, MmaStepB::LDK> sb;
-  auto quad = [&](int r, int k) -> f32x4 {  // 4 consecutive k of row r of [x | h_prev]; in % 4 == 0
-    if (k >= K) return zero4();
-    if (k < in) {
-      const int64_t o = s_xo[r];
-      return o < 0 ? zero4() : ld4(x + o + k);
-    }
-    const int64_t o = s_ho[r];
-    return o < 0 ? zero4() : ld4(hsrc + o + (k - in));
+  // A rows m0.. of xs[dir][t] (nact rows) and of hs[dir][t-1]; B rows = the 4 gate strips of wt
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xs + trow * in_i, (unsigned)nact * in_i * 2);
+  const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (t > 0 ? trow - a.B : trow) * d, (unsigned)nact * d * 2);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wt[dir], (unsigned)(4 * d) * a.Kp * 2);
+  RowSrc<TileCfg::A_GLDS> ax, ah;
+  RowSrc<TileCfg::B_GLDS> bw;
+  ax.setup(mma.wave, mma.lane, m0, nact, in_i * 2);
+  ah.setup(mma.wave, mma.lane, m0, nact, d * 2);
+#pragma unroll
+  for (int j = 0; j < TileCfg::B_GLDS; ++j) {  // B row r (0..127) = gate strip r>>5, unit u0 + (r&31)
+    const int U = (mma.wave * TileCfg::B_GLDS + j) * 64 + mma.lane;
+    const int r = U >> 2, c = (U & 3) ^ ((r >> 2) & 3);
+    bw.voff[j] = (unsigned)((r >> 5) * d + u0 + (r & 31)) * (unsigned)(a.Kp * 2) + 16u * c;
+  }
+  const int nx = in_i / 32, nt = (t == 0) ? nx : nx + d / 32;
+  auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
+    if (tile < nx)
+      ax.issue(rx, As, mma.wave, tile * 64);
+    else
+      ah.issue(rh, As, mma.wave, (tile - nx) * 64);
+    bw.issue(rw, Bs, mma.wave, tile * 64);
   };
-  auto fa = [&](int r, int k) -> bf16x8 { return cvt8(quad(r, k), quad(r, k + 4)); };
-  auto fb = [&](int c, int k) -> bf16x8 {  // virtual column c -> gate strip row of kernel^T
-    if (k >= K) return zero8h();
-    const int g = c >> 5, u = c & 31;
-    return ld8h(Wt + (size_t)(g * d + u0 + u) * Kp + k);
-  };
-  gemm_mainloop_bf16<false>(mma, sa, sb, fa, fb, 0, (K + MmaStepB::BK - 1) / MmaStepB::BK * MmaStepB::BK, smem_h, tid);
-  lstm_gate_epilogue(mma, a, dir, m0, u0, nact, trow);
+  if (!(a.dbg & 1)) glds_mainloop<false>(mma, issue, nt, smem_h);
+  __syncthreads();  // s_oo visible (and, with the k-loop skipped, written) before the epilogue reads it
+  if (!(a.dbg & 2)) lstm_gate_epilogue(mma, a, dir, m0, u0, nact, trow, s_oo);
 }
 
-void launch_step_fwd_bf16(const StepArgs& a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL(lstm_step_fwd_bf16, grid, dim3(256), MmaStepB::LDS_BYTES, s, a);
+static constexpr int FWD_LDS = TileCfg::LDS_BYTES + 256 * 8;
+
+void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s) {
+  allow_big_lds(lstm_step_fwd_bf16, FWD_LDS);
+  const dim3 grid(pad8((a.B + TileCfg::BM - 1) / TileCfg::BM), a.d / 32, 2);
+  hipLaunchKernelGGL(lstm_step_fwd_bf16, grid, dim3(256), FWD_LDS, s, a);
 }
 
 // ----------------------------------------------------------- backward step --
-using MmaSqB = MmaBf16<2, 2, 2, 2>;
-
-__global__ __launch_bounds__(256) void lstm_step_bwd_bf16(StepBwdArgs a) {
+// [dx_t | . | dh_{t-1}] = dz_t * wb^T : rows x (in_i + d), K = 4d.  grid (pad8(ceil(B/256)), (in_i+d)/128, 2)
+__global__ __launch_bounds__(256, 2) void lstm_step_bwd_bf16(StepBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   const int tid = threadIdx.x, dir = blockIdx.z;
-  const int m0 = blockIdx.x * MmaSqB::BM, n0 = blockIdx.y * MmaSqB::BN;
+  const int m0 = blockIdx.x * TileCfg::BM, n0 = blockIdx.y * TileCfg::BN;
   const int nact = a.plan.nactive[a.t];
   if (m0 >= nact) return;
-  const int d = a.d, in = a.in, t = a.t;
-  const int NN = in + d, K = 4 * d;
-  if (t == 0 && n0 >= in) return;
-  if (a.dx == nullptr && n0 + MmaSqB::BN <= in) return;
+  const int d = a.d, in = a.in, t = a.t, in_i = a.in_i;
+  const int NN = in_i + d, K = 4 * d;
+  if (t == 0 && n0 >= in_i) return;                       // dh_{-1} is not needed
+  if (a.dx == nullptr && n0 + TileCfg::BN <= in_i) return;  // nobody wants dx
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
-  const bf16_t* __restrict__ dz = a.dzb + trow * (size_t)K;
-  const bf16_t* __restrict__ Wb = a.Wb[dir];
-  MmaSqB mma;
+  MmaB mma;
   mma.init(tid);
-  StageRows<MmaSqB::BM, MmaSqB::BK, MmaSqB::NT, MmaSqB::LDK> sa;
-  StageRows<MmaSqB::BN, MmaSqB::BK, MmaSqB::NT, MmaSqB::LDK> sb;
-  auto fa = [&](int r, int k) -> bf16x8 {
-    const int i = m0 + r;
-    return i < nact ? ld8h(dz + (size_t)i * K + k) : zero8h();
+  const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + trow * (size_t)K, (unsigned)nact * K * 2);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir], (unsigned)NN * K * 2);
+  RowSrc<TileCfg::A_GLDS> az;
+  RowSrc<TileCfg::B_GLDS> bw;
+  az.setup(mma.wave, mma.lane, m0, nact, K * 2);
+  bw.setup(mma.wave, mma.lane, n0, NN, K * 2);
+  auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
+    az.issue(rz, As, mma.wave, tile * 64);
+    bw.issue(rw, Bs, mma.wave, tile * 64);
   };
-  auto fb = [&](int r, int k) -> bf16x8 {
-    const int n = n0 + r;
-    return n < NN ? ld8h(Wb + (size_t)n * K + k) : zero8h();
-  };
-  gemm_mainloop_bf16<false>(mma, sa, sb, fa, fb, 0, K, smem_h, tid);
+  glds_mainloop<false>(mma, issue, K / 32, smem_h);
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
+  for (int ti = 0; ti < MmaB::TM; ++ti)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = m0 + mma.row_of(ti, r);
       if (i >= nact) continue;
       const int64_t xo = a.plan.xo[trow + i];
 #pragma unroll
-      for (int tj = 0; tj < 2; ++tj) {
+      for (int tj = 0; tj < MmaB::TN; ++tj) {
         const int n = n0 + mma.col_of(tj);
         const float v = mma.acc[ti][tj][r];
         if (n < in) {
-          if (a.dx) atomicAdd(a.dx + xo + n, v);
-        } else if (n < NN && t > 0) {
-          a.dh_rec[((size_t)dir * a.B + i) * d + (n - in)] = v;
+          if (a.dx) atomicAdd(a.dx + xo + n, v);  // the two directions meet here: two addends, order-free
+        } else if (n >= in_i && n < NN && t > 0) {
+          a.dh_rec[((size_t)dir * a.B + i) * d + (n - in_i)] = v;
         }
       }
     }
 }
 
-void launch_step_bwd_bf16(const StepBwdArgs& a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL(lstm_step_bwd_bf16, grid, dim3(256), MmaSqB::LDS_BYTES, s, a);
+void launch_step_bwd_bf16(const StepBwdArgs& a, hipStream_t s) {
+  allow_big_lds(lstm_step_bwd_bf16, TileCfg::LDS_BYTES);
+  const dim3 grid(pad8((a.B + TileCfg::BM - 1) / TileCfg::BM), (a.in_i + a.d + TileCfg::BN - 1) / TileCfg::BN, 2);
+  hipLaunchKernelGGL(lstm_step_bwd_bf16, grid, dim3(256), TileCfg::LDS_BYTES, s, a);
 }
 
 // -------------------------------------------------------- weight gradient --
-__global__ __launch_bounds__(256) void lstm_dw_bf16(DwArgs a) {
+// slab(dir, split) [in_i+d][4d] = sum over the split's steps of [xs_t | hs_{t-1}]^T * dz_t.  Both operands
+// are k-major in memory: staged as they lie, read through the transposing LDS read.
+// grid (xtiles + htiles, 4d/128, 2*nsplit): m-tiles never mix x and h columns.
+__global__ __launch_bounds__(256, 2) void lstm_dw_bf16(DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   const int tid = threadIdx.x;
-  const int m0 = blockIdx.x * MmaSqB::BM, n0 = blockIdx.y * MmaSqB::BN;
+  const int d = a.d, in_i = a.in_i, N4 = 4 * d;
+  const int xtiles = (in_i + TileCfg::BM - 1) / TileCfg::BM;
+  const bool isx = (int)blockIdx.x < xtiles;
+  const int col0 = isx ? blockIdx.x * TileCfg::BM : (blockIdx.x - xtiles) * TileCfg::BM;  // within x / h columns
+  const int ncols = isx ? in_i : d;
+  const int n0 = blockIdx.y * TileCfg::BN;
   const int split = blockIdx.z % a.nsplit, dir = blockIdx.z / a.nsplit;
-  const int d = a.d, in = a.in, MM = in + d + 1, N4 = 4 * d;
-  const int64_t out_ld = a.plan.hdr->out_ld;
-  MmaSqB mma;
+  MmaB mma;
   mma.init(tid);
-  StageKMajor<MmaSqB::BM, MmaSqB::BK, MmaSqB::NT, MmaSqB::LDM> sa;
-  StageKMajor<MmaSqB::BN, MmaSqB::BK, MmaSqB::NT, MmaSqB::LDN> sb;
+  KMajorSrc<TileCfg::BM, TileCfg::A_GLDS> sa;
+  KMajorSrc<TileCfg::BN, TileCfg::B_GLDS> sb;
+  sa.setup(mma.wave, mma.lane, col0, ncols, (unsigned)ncols * 2);
+  sb.setup(mma.wave, mma.lane, n0, N4, (unsigned)N4 * 2);
   const int t_begin = split * a.tgroup, t_end = min(a.J, t_begin + a.tgroup);
   for (int t = t_begin; t < t_end; ++t) {
     const int nact = a.plan.nactive[t];
     if (nact == 0) break;
+    if (!isx && t == 0) continue;  // h_{-1} = 0
     const size_t trow = ((size_t)dir * a.J + t) * a.B;
-    const bf16_t* __restrict__ dz = a.dzb + trow * (size_t)N4;
-    const int64_t* __restrict__ xo = a.plan.xo + trow;
-    const int64_t* __restrict__ oo = a.plan.oo + trow;
-    auto quad = [&](int k, int m) -> f32x4 {  // A[k = sorted row][m..m+3] of [x | h_prev | 1]
-      if (m < in) return ld4(a.x + xo[k] + m);
-      if (m < in + d) {
-        if (t == 0) return zero4();
-        const int64_t ho = dir ? oo[k] + out_ld : oo[k] - out_ld;
-        return ld4(a.out + ho + (m - in));
-      }
-      return m == in + d ? f32x4{1.f, 0.f, 0.f, 0.f} : zero4();
+    const bf16_t* A = isx ? a.xs + trow * in_i : a.hs + (trow - a.B) * d;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(A, (unsigned)nact * ncols * 2);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + trow * (size_t)N4, (unsigned)nact * N4 * 2);
+    auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
+      sa.issue(ra, As, mma.wave, (unsigned)tile * 32u * ncols * 2u);
+      sb.issue(rz, Bs, mma.wave, (unsigned)tile * 32u * N4 * 2u);
     };
-    auto fa = [&](int k, int c) -> bf16x8 {
-      if (k >= nact) return zero8h();
-      return cvt8(quad(k, m0 + c), quad(k, m0 + c + 4));
-    };
-    auto fb = [&](int k, int c) -> bf16x8 { return k < nact ? ld8h(dz + (size_t)k * N4 + n0 + c) : zero8h(); };
-    gemm_mainloop_bf16<true>(mma, sa, sb, fa, fb, 0, (nact + MmaSqB::BK - 1) / MmaSqB::BK * MmaSqB::BK, smem_h, tid);
+    glds_mainloop<true>(mma, issue, (nact + 31) / 32, smem_h);
+    __builtin_amdgcn_s_barrier();  // every wave is done with the ring before the next step refills it
   }
-  float* slab = a.slabs + (size_t)blockIdx.z * MM * N4;
+  float* slab = a.slabs + (size_t)blockIdx.z * (in_i + d) * N4;
+  const int mrow0 = isx ? col0 : in_i + col0;
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
+  for (int ti = 0; ti < MmaB::TM; ++ti)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + mma.row_of(ti, r);
-      if (m >= MM) continue;
+      const int ml = mma.row_of(ti, r);
+      if (col0 + ml >= ncols) continue;
 #pragma unroll
-      for (int tj = 0; tj < 2; ++tj) slab[(size_t)m * N4 + n0 + mma.col_of(tj)] = mma.acc[ti][tj][r];
+      for (int tj = 0; tj < MmaB::TN; ++tj) slab[(size_t)(mrow0 + ml) * N4 + n0 + mma.col_of(tj)] = mma.acc[ti][tj][r];
     }
 }
 
-void launch_dw_bf16(const DwArgs& a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL(lstm_dw_bf16, grid, dim3(256), MmaSqB::LDS_BYTES, s, a);
+void launch_dw_bf16(const DwArgs& a, hipStream_t s) {
+  allow_big_lds(lstm_dw_bf16, TileCfg::LDS_BYTES);
+  const int xtiles = (a.in_i + TileCfg::BM - 1) / TileCfg::BM, htiles = (a.d + TileCfg::BM - 1) / TileCfg::BM;
+  const dim3 grid(xtiles + htiles, 4 * a.d / TileCfg::BN, 2 * a.nsplit);
+  hipLaunchKernelGGL(lstm_dw_bf16, grid, dim3(256), TileCfg::LDS_BYTES, s, a);
+}
+
+// slabs (internal row order) -> dkernel [in+d][4d] and dbias [4d], accumulated, fixed summation order
+__global__ void lstm_dw_reduce_bf16(const float* __restrict__ slabs, int nslab, int in, int in_i, int d,
+                                    float* __restrict__ dW, float* __restrict__ dbias) {
+  const int N4 = 4 * d;
+  const size_t slab_elems = (size_t)(in_i + d) * N4;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= slab_elems) return;
+  const int row = (int)(idx / N4), n = (int)(idx % N4);
+  if (row > in && row < in_i) return;  // zero pad rows
+  float s = 0.f;
+  for (int k = 0; k < nslab; ++k) s += slabs[(size_t)k * slab_elems + idx];
+  if (row < in)
+    dW[(size_t)row * N4 + n] += s;
+  else if (row == in)
+    dbias[n] += s;  // the ones column
+  else
+    dW[(size_t)(in + row - in_i) * N4 + n] += s;
+}
+
+void launch_dw_reduce_bf16(const float* slabs, int nslab, int in, int in_i, int d, float* dW, float* dbias,
+                           hipStream_t s) {
+  const size_t n = (size_t)(in_i + d) * 4 * d;
+  hipLaunchKernelGGL(lstm_dw_reduce_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, nslab, in, in_i, d, dW,
+                     dbias);
 }
 
 // ------------------------------------------------------------------ test gemm
 // layout 1: C = A[M,K] * B[N,K]^T (row images);  layout 2: C = A[K,M]^T * B[K,N] (k-major images, tr reads)
+__global__ void cvt_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = f2bf(src[i]);
+}
+
 template <int LAYOUT>
-__global__ __launch_bounds__(256) void test_gemm_bf16_kernel(int M, int N, int K, const float* __restrict__ A,
-                                                             const float* __restrict__ B, float* __restrict__ C) {
+__global__ __launch_bounds__(256, 2) void test_gemm_bf16_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
+                                                                const bf16_t* __restrict__ B, float* __restrict__ C) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   const int tid = threadIdx.x;
-  const int m0 = blockIdx.x * MmaSqB::BM, n0 = blockIdx.y * MmaSqB::BN;
-  MmaSqB mma;
+  const int m0 = blockIdx.x * TileCfg::BM, n0 = blockIdx.y * TileCfg::BN;
+  MmaB mma;
   mma.init(tid);
-  const int Kp = (K + MmaSqB::BK - 1) / MmaSqB::BK * MmaSqB::BK;
-  auto q = [&](const float* p, bool ok) -> f32x4 { return ok ? ld4(p) : zero4(); };
   if (LAYOUT == 1) {
-    StageRows<MmaSqB::BM, MmaSqB::BK, MmaSqB::NT, MmaSqB::LDK> sa;
-    StageRows<MmaSqB::BN, MmaSqB::BK, MmaSqB::NT, MmaSqB::LDK> sb;
-    auto fa = [&](int r, int k) -> bf16x8 {
-      const float* p = A + (size_t)(m0 + r) * K + k;
-      return cvt8(q(p, m0 + r < M && k < K), q(p + 4, m0 + r < M && k + 4 < K));
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(A, (unsigned)M * K * 2), rb = make_rsrc(B, (unsigned)N * K * 2);
+    RowSrc<TileCfg::A_GLDS> sa;
+    RowSrc<TileCfg::B_GLDS> sb;
+    sa.setup(mma.wave, mma.lane, m0, M, K * 2);
+    sb.setup(mma.wave, mma.lane, n0, N, K * 2);
+    auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
+      sa.issue(ra, As, mma.wave, tile * 64);
+      sb.issue(rb, Bs, mma.wave, tile * 64);
     };
-    auto fb = [&](int r, int k) -> bf16x8 {
-      const float* p = B + (size_t)(n0 + r) * K + k;
-      return cvt8(q(p, n0 + r < N && k < K), q(p + 4, n0 + r < N && k + 4 < K));
-    };
-    gemm_mainloop_bf16<false>(mma, sa, sb, fa, fb, 0, Kp, smem_h, tid);
+    glds_mainloop<false>(mma, issue, K / 32, smem_h);
   } else {
-    StageKMajor<MmaSqB::BM, MmaSqB::BK, MmaSqB::NT, MmaSqB::LDM> sa;
-    StageKMajor<MmaSqB::BN, MmaSqB::BK, MmaSqB::NT, MmaSqB::LDN> sb;
-    auto fa = [&](int k, int c) -> bf16x8 {
-      const float* p = A + (size_t)k * M + m0 + c;
-      return cvt8(q(p, k < K && m0 + c < M), q(p + 4, k < K && m0 + c + 4 < M));
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(A, (unsigned)K * M * 2), rb = make_rsrc(B, (unsigned)K * N * 2);
+    KMajorSrc<TileCfg::BM, TileCfg::A_GLDS> sa;
+    KMajorSrc<TileCfg::BN, TileCfg::B_GLDS> sb;
+    sa.setup(mma.wave, mma.lane, m0, M, (unsigned)M * 2);
+    sb.setup(mma.wave, mma.lane, n0, N, (unsigned)N * 2);
+    auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
+      sa.issue(ra, As, mma.wave, (unsigned)tile * 32u * M * 2u);
+      sb.issue(rb, Bs, mma.wave, (unsigned)tile * 32u * N * 2u);
     };
-    auto fb = [&](int k, int c) -> bf16x8 {
-      const float* p = B + (size_t)k * N + n0 + c;
-      return cvt8(q(p, k < K && n0 + c < N), q(p + 4, k < K && n0 + c + 4 < N));
-    };
-    gemm_mainloop_bf16<true>(mma, sa, sb, fa, fb, 0, Kp, smem_h, tid);
+    glds_mainloop<true>(mma, issue, (K + 31) / 32, smem_h);
   }
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
+  for (int ti = 0; ti < MmaB::TM; ++ti)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + mma.row_of(ti, r);
 #pragma unroll
-      for (int tj = 0; tj < 2; ++tj) {
+      for (int tj = 0; tj < MmaB::TN; ++tj) {
         const int n = n0 + mma.col_of(tj);
         if (m < M && n < N) C[(size_t)m * N + n] = mma.acc[ti][tj][r];
       }
     }
 }
 
+// Test hook only: rounds A and B to bf16 in stream-ordered temporaries (the one place the library allocates).
+// Row images need K % 32 == 0; k-major images take any K (rows past the end fall off the descriptor).
 int test_gemm_bf16(int layout, int M, int N, int K, const float* A, const float* B, float* C, hipStream_t s) {
-  const dim3 grid((M + MmaSqB::BM - 1) / MmaSqB::BM, (N + MmaSqB::BN - 1) / MmaSqB::BN);
-  if (layout == 1)
-    hipLaunchKernelGGL(test_gemm_bf16_kernel<1>, grid, dim3(256), MmaSqB::LDS_BYTES, s, M, N, K, A, B, C);
-  else if (layout == 2)
-    hipLaunchKernelGGL(test_gemm_bf16_kernel<2>, grid, dim3(256), MmaSqB::LDS_BYTES, s, M, N, K, A, B, C);
-  else
-    return FVTA_ERR_UNSUPPORTED;
+  if (layout != 1 && layout != 2) return FVTA_ERR_UNSUPPORTED;
+  if (layout == 1 && K % 32) return FVTA_ERR_UNSUPPORTED;
+  const size_t na = (size_t)M * K, nb = (size_t)N * K;
+  bf16_t *Ab = nullptr, *Bb = nullptr;
+  if (hipMallocAsync((void**)&Ab, na * 2, s) != hipSuccess || hipMallocAsync((void**)&Bb, nb * 2, s) != hipSuccess)
+    return FVTA_ERR_LAUNCH;
+  hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, s, A, Ab, na);
+  hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, B, Bb, nb);
+  const dim3 grid((M + TileCfg::BM - 1) / TileCfg::BM, (N + TileCfg::BN - 1) / TileCfg::BN);
+  if (layout == 1) {
+    allow_big_lds(test_gemm_bf16_kernel<1>, TileCfg::LDS_BYTES);
+    hipLaunchKernelGGL(test_gemm_bf16_kernel<1>, grid, dim3(256), TileCfg::LDS_BYTES, s, M, N, K, Ab, Bb, C);
+  } else {
+    allow_big_lds(test_gemm_bf16_kernel<2>, TileCfg::LDS_BYTES);
+    hipLaunchKernelGGL(test_gemm_bf16_kernel<2>, grid, dim3(256), TileCfg::LDS_BYTES, s, M, N, K, Ab, Bb, C);
+  }
+  (void)hipFreeAsync(Ab, s);
+  (void)hipFreeAsync(Bb, s);
   return FVTA_OK;
 }
 

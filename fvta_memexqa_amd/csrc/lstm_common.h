@@ -42,18 +42,37 @@ static inline PlanView plan_view(const fvta_lstm_desc* d, void* p) {
   return v;
 }
 
+// bf16 engine: internal input width = in + a ones column (dbias) + zero pad to a multiple of 32, so that
+// every 32-deep k-tile is wholly x or wholly h
+static inline int in_internal(const fvta_lstm_desc* d) { return (d->in + 1 + 31) / 32 * 32; }
+
 // ------------------------------------------------------------- saved state --
 struct SavedView {
   float* gates;  // [2][J][B][4][d] i, tanh(j), f, o activations (fp32 engine: overwritten by dz in backward)
+  bf16_t* gatesb;  // the same, bf16 (bf16 engine: the activations only scale bf16-MFMA operands in backward)
   float* cs;     // [2][J][B][d] cell state after step t
+  // bf16 engine: MFMA operand shadows, dense per (direction, step) in sorted-row order like gates/cs/dz
+  bf16_t* xs;    // [2][J][B][in_i] x at the position (dir, t) visits, a 1.0 column at `in` (dbias), zero pad
+  bf16_t* hs;    // [2][J][B][d]    h_t
   size_t bytes;
 };
 static inline SavedView saved_view(const fvta_lstm_desc* d, void* p) {
   FvtaCarver c(p);
   SavedView s;
-  s.gates = c.take<float>((size_t)2 * d->J * d->B * 4 * d->d);
-  s.cs = c.take<float>((size_t)2 * d->J * d->B * d->d);
-  s.bytes = c.off;
+  s.gates = s.cs = nullptr;
+  s.xs = s.hs = s.gatesb = nullptr;
+  if (d->training) {
+    if (d->precision == FVTA_BF16)
+      s.gatesb = c.take<bf16_t>((size_t)2 * d->J * d->B * 4 * d->d);
+    else
+      s.gates = c.take<float>((size_t)2 * d->J * d->B * 4 * d->d);
+    s.cs = c.take<float>((size_t)2 * d->J * d->B * d->d);
+  }
+  if (d->precision == FVTA_BF16) {
+    s.xs = c.take<bf16_t>((size_t)2 * d->J * d->B * in_internal(d));
+    s.hs = c.take<bf16_t>((size_t)2 * d->J * d->B * d->d);
+  }
+  s.bytes = c.off < 256 ? 256 : c.off;
   return s;
 }
 
@@ -63,15 +82,15 @@ static inline int dw_tgroup(const fvta_lstm_desc* d) {
   return g < 1 ? 1 : g;
 }
 static inline int dw_nsplit(const fvta_lstm_desc* d) { return (d->J + dw_tgroup(d) - 1) / dw_tgroup(d); }
-static inline int kpad8(const fvta_lstm_desc* d) { return (d->in + d->d + 7) / 8 * 8; }
+static inline int kpad8(const fvta_lstm_desc* d) { return in_internal(d) + d->d; }  // bf16 engine K
 
 struct WorkView {
   float* cstate;   // [2][B][d] running cell state (inference) / dc (backward)
   float* dh_rec;   // [2][B][d]
   float* slabs;    // [2*nsplit][(in+d+1)][4d] split-K partials of dW
   // bf16 engine only
-  bf16_t* wt[2];   // [4d][Kp]   kernel^T, k-contiguous rows (forward B operand)
-  bf16_t* wb[2];   // [in+d][4d] kernel, canonical layout (backward B operand)
+  bf16_t* wt[2];   // [4d][in_i+d]  kernel^T in the internal row order, k contiguous (forward B operand)
+  bf16_t* wb[2];   // [in_i+d][4d]  kernel in the internal row order (backward B operand)
   bf16_t* dzb;     // [2][J][B][4d] gate pre-activation gradients
   size_t bytes;
 };
@@ -80,13 +99,14 @@ static inline WorkView work_view(const fvta_lstm_desc* d, void* p) {
   WorkView w;
   w.cstate = c.take<float>((size_t)2 * d->B * d->d);
   w.dh_rec = c.take<float>((size_t)2 * d->B * d->d);
-  w.slabs = c.take<float>((size_t)2 * dw_nsplit(d) * (d->in + d->d + 1) * 4 * d->d);
+  const size_t slab_rows = d->precision == FVTA_BF16 ? (size_t)kpad8(d) : (size_t)(d->in + d->d + 1);
+  w.slabs = c.take<float>((size_t)2 * dw_nsplit(d) * slab_rows * 4 * d->d);
   w.wt[0] = w.wt[1] = w.wb[0] = w.wb[1] = nullptr;
   w.dzb = nullptr;
   if (d->precision == FVTA_BF16) {
     for (int i = 0; i < 2; ++i) {
       w.wt[i] = c.take<bf16_t>((size_t)4 * d->d * kpad8(d));
-      w.wb[i] = c.take<bf16_t>((size_t)(d->in + d->d) * 4 * d->d);
+      w.wb[i] = c.take<bf16_t>((size_t)kpad8(d) * 4 * d->d);
     }
     if (d->training) w.dzb = c.take<bf16_t>((size_t)2 * d->J * d->B * 4 * d->d);
   }
@@ -101,17 +121,22 @@ struct StepArgs {
   float* out;
   const float* W[2];
   const bf16_t* Wt[2];  // bf16 engine
+  const bf16_t* xs;     // bf16 engine
+  bf16_t* hs;           // bf16 engine
   const float* bias[2];
-  float* gates;   // may be null (inference)
+  float* gates;   // may be null (inference, bf16 engine)
+  bf16_t* gatesb; // bf16 engine, training
   float* cs;      // may be null
   float* cstate;  // used when cs is null
   int t, B, J, in, d, Kp;
+  int dbg;  // diagnostics only (FVTA_DEBUG_SKIP): 1 = skip the k-loop, 2 = skip the epilogue
 };
 
 struct GateBwdArgs {
   PlanView plan;
   const float* d_out;
   float* gates;
+  const bf16_t* gatesb;  // bf16 engine
   bf16_t* dzb;    // null: dz overwrites gates in place (fp32 engine)
   const float* cs;
   float* dc;      // [2][B][d]
@@ -127,7 +152,7 @@ struct StepBwdArgs {
   const bf16_t* Wb[2];  // bf16 engine
   float* dx;            // may be null
   float* dh_rec;
-  int t, B, J, in, d;
+  int t, B, J, in, d, in_i;
 };
 
 struct DwArgs {
@@ -136,56 +161,81 @@ struct DwArgs {
   const float* out;
   const float* dz;
   const bf16_t* dzb;
+  const bf16_t* xs;
+  const bf16_t* hs;
   float* slabs;
-  int B, J, in, d, tgroup, nsplit;
+  int B, J, in, d, tgroup, nsplit, in_i;
 };
 
 #ifdef __HIPCC__
-// Fused gate epilogue shared by both engines.  The block tile is 128 sorted sequences x
-// (4 gates x 32 units) and a wave owns 32 rows x all four gate tiles, so lane (col = lane&31)
-// holds z_i, z_j, z_f, z_o of the same (row, unit) in acc[0][0..3].
+// Fused gate epilogue shared by both engines.  The block tile is BM sorted sequences x
+// (4 gates x 32 units) and a wave owns TM*32 rows x all four gate tiles, so lane (col = lane&31)
+// holds z_i, z_j, z_f, z_o of the same (row, unit) in acc[ti][0..3].
 // BasicLSTMCell: c' = c*sig(f+1) + sig(i)*tanh(j); h' = tanh(c')*sig(o).
+// s_oo[row] = element offset of this step's output half-row (-1: inactive row), staged in LDS by
+// the caller so that the only global loads here (c_{t-1}) are unconditional and issued 16 at a
+// time (a load under a per-row branch would cost one serialised round trip per row).
 template <class Mma>
 __device__ __forceinline__ void lstm_gate_epilogue(const Mma& mma, const StepArgs& a, int dir, int m0, int u0,
-                                                   int nact, size_t trow) {
+                                                   int nact, size_t trow, const int64_t* s_oo) {
+  static_assert(Mma::TN == 4 && Mma::WAVES_N == 1, "wave tile must span the four gate strips");
   const int d = a.d, t = a.t;
   const float* __restrict__ bias = a.bias[dir];
   const int u = u0 + mma.l31;
   const float bi = bias[u], bj = bias[d + u], bf = bias[2 * d + u], bo = bias[3 * d + u];
+  const float* cprev_src = a.cs ? a.cs + (trow - a.B) * (size_t)d : a.cstate + (size_t)dir * a.B * d;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = mma.row_of(0, r);
-    const int i = m0 + row;
-    if (i >= nact) continue;
-    const float ig = fvta_sigmoid(mma.acc[0][0][r] + bi);
-    const float jg = tanhf(mma.acc[0][1][r] + bj);
-    const float fg = fvta_sigmoid(mma.acc[0][2][r] + bf + 1.0f);  // forget_bias
-    const float og = fvta_sigmoid(mma.acc[0][3][r] + bo);
-    float cprev = 0.f;
-    if (t > 0) cprev = a.cs ? a.cs[(trow - a.B + i) * d + u] : a.cstate[((size_t)dir * a.B + i) * d + u];
-    const float c = cprev * fg + ig * jg;
-    const float h = tanhf(c) * og;
-    if (a.cs) {
-      a.cs[(trow + i) * d + u] = c;
-      float* g = a.gates + (trow + i) * (size_t)(4 * d) + u;
-      g[0] = ig;
-      g[d] = jg;
-      g[2 * d] = fg;
-      g[3 * d] = og;
-    } else {
-      a.cstate[((size_t)dir * a.B + i) * d + u] = c;
+  for (int ti = 0; ti < Mma::TM; ++ti) {
+    float cp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = min(m0 + mma.row_of(ti, r), nact - 1);  // clamped: always a valid row
+      cp[r] = t > 0 ? cprev_src[(size_t)i * d + u] : 0.f;
     }
-    const int64_t oo = a.plan.oo[trow + i];
-    a.out[oo + u] = h;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = mma.row_of(ti, r);
+      const int i = m0 + row;
+      const float ig = fvta_sigmoid(mma.acc[ti][0][r] + bi);
+      const float jg = fvta_tanh(mma.acc[ti][1][r] + bj);
+      const float fg = fvta_sigmoid(mma.acc[ti][2][r] + bf + 1.0f);  // forget_bias
+      const float og = fvta_sigmoid(mma.acc[ti][3][r] + bo);
+      const float c = cp[r] * fg + ig * jg;
+      const float h = fvta_tanh(c) * og;
+      if (i < nact) {
+        if (a.cs) {
+          a.cs[(trow + i) * d + u] = c;
+          if (a.gatesb) {
+            bf16_t* g = a.gatesb + (trow + i) * (size_t)(4 * d) + u;
+            g[0] = f2bf(ig);
+            g[d] = f2bf(jg);
+            g[2 * d] = f2bf(fg);
+            g[3 * d] = f2bf(og);
+          } else {
+            float* g = a.gates + (trow + i) * (size_t)(4 * d) + u;
+            g[0] = ig;
+            g[d] = jg;
+            g[2 * d] = fg;
+            g[3 * d] = og;
+          }
+        } else {
+          a.cstate[((size_t)dir * a.B + i) * d + u] = c;
+        }
+        a.out[s_oo[row] + u] = h;
+        if (a.hs) a.hs[(trow + i) * d + u] = f2bf(h);  // bf16 shadow: next step's MFMA operand
+      }
+    }
   }
 }
 #endif
 
 // bf16 engine launchers (lstm_bf16.hip)
-void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int K, int Kp, int N4, hipStream_t s);
-void launch_step_fwd_bf16(const StepArgs& a, dim3 grid, hipStream_t s);
-void launch_step_bwd_bf16(const StepBwdArgs& a, dim3 grid, hipStream_t s);
-void launch_dw_bf16(const DwArgs& a, dim3 grid, hipStream_t s);
+void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int in, int in_i, int d, hipStream_t s);
+void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, int J, int in, int in_i, hipStream_t s);
+void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s);
+void launch_step_bwd_bf16(const StepBwdArgs& a, hipStream_t s);
+void launch_dw_bf16(const DwArgs& a, hipStream_t s);
+void launch_dw_reduce_bf16(const float* slabs, int nslab, int in, int in_i, int d, float* dW, float* dbias, hipStream_t s);
 int test_gemm_bf16(int layout, int M, int N, int K, const float* A, const float* B, float* C, hipStream_t s);
 
 }  // namespace fvta

@@ -111,8 +111,10 @@ class Model:
             raise ValueError("similarity matrix not implemented")    # model_v2.py:255-257 (sys.exit there)
         self.text_in = int(text_in if text_in is not None else _cfg(config, "text_in", 200))
         self.img_in = int(img_in if img_in is not None else _cfg(config, "img_in", 100))
-        if self.text_in % 4 or self.img_in % 4:
-            raise ValueError("encoder input widths must be multiples of 4 (pad the embedding)")
+        # encoder input widths are zero padded to a multiple of 8 (16-byte bf16 operand pieces); exact, like
+        # the hidden padding: padded input columns are 0 and their kernel rows stay 0
+        self.text_in_p = (self.text_in + 7) // 8 * 8
+        self.img_in_p = (self.img_in + 7) // 8 * 8
         self.global_step = 0                                            # model_v2.py:366
         self.loss = self.yp = self.logits = None
         self.att_logits = self.q_att_logits = self.hall = None
@@ -123,10 +125,10 @@ class Model:
         dirs = ["fw"] if self.share_fw_bw else ["fw", "bw"]
         specs = {}
         for dr in dirs:
-            specs[self.N_TEXT_K % dr] = (self.text_in + dp, 4 * dp)
+            specs[self.N_TEXT_K % dr] = (self.text_in_p + dp, 4 * dp)
             specs[self.N_TEXT_B % dr] = (4 * dp,)
         for dr in dirs:
-            specs[self.N_IMG_K % dr] = (self.img_in + dp, 4 * dp)
+            specs[self.N_IMG_K % dr] = (self.img_in_p + dp, 4 * dp)
             specs[self.N_IMG_B % dr] = (4 * dp,)
         if F:
             specs[self.N_ATT_W], specs[self.N_ATT_B] = (F,), (1,)
@@ -138,22 +140,26 @@ class Model:
         self.init_parameters(int(_cfg(config, "weight_seed", 42)))
 
     # ------------------------------------------------------------ parameters
-    def _pad_kernel(self, k, din):
-        """reference [din+d, 4d] -> padded [din+dp, 4dp] (gate blocks i,j,f,o kept apart)."""
+    def _pad_kernel(self, k, din, dinp):
+        """reference [din+d, 4d] -> padded [dinp+dp, 4dp] (input rows, zero rows, hidden rows; gate blocks
+        i,j,f,o kept apart)."""
         d, dp = self.d, self.dp
-        out = torch.zeros(din + dp, 4 * dp, dtype=torch.float32)
+        out = torch.zeros(dinp + dp, 4 * dp, dtype=torch.float32)
         for g in range(4):
             out[:din, g * dp:g * dp + d] = k[:din, g * d:(g + 1) * d]
-            out[din:din + d, g * dp:g * dp + d] = k[din:, g * d:(g + 1) * d]
+            out[dinp:dinp + d, g * dp:g * dp + d] = k[din:, g * d:(g + 1) * d]
         return out
 
-    def _unpad_kernel(self, kp, din):
+    def _unpad_kernel(self, kp, din, dinp):
         d, dp = self.d, self.dp
         out = torch.zeros(din + d, 4 * d, dtype=torch.float32)
         for g in range(4):
             out[:din, g * d:(g + 1) * d] = kp[:din, g * dp:g * dp + d]
-            out[din:, g * d:(g + 1) * d] = kp[din:din + d, g * dp:g * dp + d]
+            out[din:, g * d:(g + 1) * d] = kp[dinp:dinp + d, g * dp:g * dp + d]
         return out
+
+    def _din(self, name):
+        return (self.text_in, self.text_in_p) if "utext" in name else (self.img_in, self.img_in_p)
 
     def _pad_blocks(self, v, nblk, blk, blkp):
         out = torch.zeros(nblk * blkp, dtype=torch.float32)
@@ -179,8 +185,7 @@ class Model:
                 continue
             t = torch.as_tensor(np.asarray(val), dtype=torch.float32)
             if name.endswith("basic_lstm_cell/kernel"):
-                din = self.text_in if "utext" in name else self.img_in
-                t = self._pad_kernel(t, din)
+                t = self._pad_kernel(t, *self._din(name))
             elif name.endswith("basic_lstm_cell/bias"):
                 t = self._pad_blocks(t, 4, self.d, self.dp)
             elif name.endswith("/W"):
@@ -193,7 +198,7 @@ class Model:
         for name in self.params.specs:
             t = self.params.view(name, grad=grad).detach().cpu()
             if name.endswith("basic_lstm_cell/kernel"):
-                t = self._unpad_kernel(t, self.text_in if "utext" in name else self.img_in)
+                t = self._unpad_kernel(t, *self._din(name))
             elif name.endswith("basic_lstm_cell/bias"):
                 t = torch.cat([t[g * self.dp:g * self.dp + self.d] for g in range(4)])
             elif name.endswith("/W"):
@@ -288,7 +293,7 @@ class Model:
         for cell, segs in groups.items():
             if not segs:
                 continue
-            din = self.text_in if cell == "text" else self.img_in
+            din = self.text_in_p if cell == "text" else self.img_in_p
             G = SimpleNamespace(segs=segs, din=din)
             B = sum(s["count"] for s in segs)
             Jmax = max(s["J"] for s in segs)
@@ -348,7 +353,7 @@ class Model:
         dev = self.dev
 
         def put(cell, si, x, mask):
-            self.seg_x(L, cell, si).copy_(x.reshape(-1, x.shape[-2], x.shape[-1]).to(dev, torch.float32))
+            self.seg_x(L, cell, si)[:, :, :x.shape[-1]].copy_(x.reshape(-1, x.shape[-2], x.shape[-1]).to(dev, torch.float32))
             G = L.groups[cell]
             s = G.segs[si]
             G.lens[s["s0"]:s["s0"] + s["count"]] = mask.reshape(-1, mask.shape[-1]).to(dev).sum(1).to(torch.int32)
