@@ -214,8 +214,8 @@ __global__ void lstm_gate_bwd(GateBwdArgs a) {
   float* g = a.gates + (trow + i) * (size_t)(4 * d) + u;
   float ig, jg, fg, og;
   if (a.gatesb) {
-    const bf16_t* gb = a.gatesb + (trow + i) * (size_t)(4 * d) + u;
-    ig = bf2f(gb[0]), jg = bf2f(gb[d]), fg = bf2f(gb[2 * d]), og = bf2f(gb[3 * d]);
+    const bf16x4 pk = *reinterpret_cast<const bf16x4*>(a.gatesb + (trow + i) * (size_t)(4 * d) + 4 * u);
+    ig = bf2f((bf16_t)pk[0]), jg = bf2f((bf16_t)pk[1]), fg = bf2f((bf16_t)pk[2]), og = bf2f((bf16_t)pk[3]);
   } else {
     ig = g[0], jg = g[d], fg = g[2 * d], og = g[3 * d];
   }
@@ -226,11 +226,12 @@ __global__ void lstm_gate_bwd(GateBwdArgs a) {
   const float dzi = dc * jg * ig * (1.f - ig), dzj = dc * ig * (1.f - jg * jg);
   const float dzf = dc * cprev * fg * (1.f - fg), dzo = dh * tc * og * (1.f - og);
   if (a.dzb) {  // bf16 engine: dz rows are only ever MFMA operands
-    bf16_t* z = a.dzb + (trow + i) * (size_t)(4 * d) + u;
-    z[0] = f2bf(dzi);
-    z[d] = f2bf(dzj);
-    z[2 * d] = f2bf(dzf);
-    z[3 * d] = f2bf(dzo);
+    bf16x4 pk;  // unit-major [row][u][4]: the k order of wb matches
+    pk[0] = (short)f2bf(dzi);
+    pk[1] = (short)f2bf(dzj);
+    pk[2] = (short)f2bf(dzf);
+    pk[3] = (short)f2bf(dzo);
+    *reinterpret_cast<bf16x4*>(a.dzb + (trow + i) * (size_t)(4 * d) + 4 * u) = pk;
   } else {
     g[0] = dzi;
     g[d] = dzj;
@@ -547,6 +548,12 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
   s.dh_rec = wv.dh_rec;
   s.dzb = wv.dzb;
   s.in_i = in_internal(d);
+  int dbg = 0;
+  {
+    const char* e = getenv("FVTA_DEBUG_SKIP");
+    dbg = e ? atoi(e) : 0;
+  }
+  s.dbg = dbg;
   s.Wb[0] = wv.wb[0];
   s.Wb[1] = d->share_fw_bw ? wv.wb[0] : wv.wb[1];
   s.B = B;
@@ -560,7 +567,7 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
   for (int t = J - 1; t >= 0; --t) {
     g.t = t;
     s.t = t;
-    hipLaunchKernelGGL(lstm_gate_bwd, ggrid, dim3(256), 0, stream, g);
+    if (!(dbg & 512)) hipLaunchKernelGGL(lstm_gate_bwd, ggrid, dim3(256), 0, stream, g);
     if (t > 0 || dx) {
       if (bf)
         launch_step_bwd_bf16(s, stream);
@@ -589,7 +596,8 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
   w.in_i = in_internal(d);
   w.xs = sv.xs;
   w.hs = sv.hs;
-  if (bf)
+  if (dbg & 1024) {
+  } else if (bf)
     launch_dw_bf16(w, stream);
   else
     hipLaunchKernelGGL(lstm_dw_f32, wgrid, dim3(256), sh, stream, w);

@@ -7,7 +7,8 @@
 //                       (its weight-gradient row is dbias), zero padded so that
 //                       in_i is a multiple of 32 (k-tiles are wholly x or wholly h);
 //   hs [2][J][B][d]     h_t, written by the gate epilogue next to the fp32 h;
-//   dz [2][J][B][4d]    gate pre-activation gradients;
+//   dz [2][J][B][d][4]  gate pre-activation gradients, unit-major (so are the saved gate activations:
+//                       one 8-byte access per cell); wb's columns follow the same 4u+g order;
 //   wt [4d][in_i+d], wb [in_i+d][4d]  kernel shadows in that internal row order.
 // Active rows of a step are a prefix and nest across steps, so row i of step t-1
 // IS the h_{t-1} of row i of step t: no gathers anywhere, every tile streams
@@ -40,7 +41,7 @@ __global__ void cvt_weights_kernel(const float* __restrict__ W, bf16_t* __restri
     const int src = k < in ? k : (k >= in_i ? in + (k - in_i) : -1);  // internal row -> kernel row
     const float v = src >= 0 ? W[(size_t)src * N4 + n] : 0.f;
     tile[r][tx] = v;
-    wb[(size_t)k * N4 + n] = f2bf(v);
+    wb[(size_t)k * N4 + 4 * (n % d) + n / d] = f2bf(v);  // column g*d+u -> 4u+g: dz rows are unit-major
   }
   __syncthreads();
   for (int r = ty; r < 32; r += 8) wt[(size_t)(n0 + r) * Ki + k0 + tx] = f2bf(tile[tx][r]);
@@ -151,14 +152,19 @@ __global__ __launch_bounds__(256, 2) void lstm_step_bwd_bf16(StepBwdArgs a) {
     az.issue(rz, As, mma.wave, tile * 64);
     bw.issue(rw, Bs, mma.wave, tile * 64);
   };
-  glds_mainloop<false>(mma, issue, K / 32, smem_h);
+  if (!(a.dbg & 128)) glds_mainloop<false>(mma, issue, K / 32, smem_h);
+  if (a.dbg & 256) return;
+  const bool xpart = n0 < in;  // tile holds dx columns: fetch the x row offsets, unconditionally and up front
 #pragma unroll
-  for (int ti = 0; ti < MmaB::TM; ++ti)
+  for (int ti = 0; ti < MmaB::TM; ++ti) {
+    int64_t xos[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xos[r] = xpart ? a.plan.xo[trow + min(m0 + mma.row_of(ti, r), nact - 1)] : 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = m0 + mma.row_of(ti, r);
       if (i >= nact) continue;
-      const int64_t xo = a.plan.xo[trow + i];
+      const int64_t xo = xos[r];
 #pragma unroll
       for (int tj = 0; tj < MmaB::TN; ++tj) {
         const int n = n0 + mma.col_of(tj);
@@ -170,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step_bwd_bf16(StepBwdArgs a) {
         }
       }
     }
+  }
 }
 
 void launch_step_bwd_bf16(const StepBwdArgs& a, hipStream_t s) {
@@ -241,8 +248,9 @@ __global__ void lstm_dw_reduce_bf16(const float* __restrict__ slabs, int nslab, 
   const size_t slab_elems = (size_t)(in_i + d) * N4;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= slab_elems) return;
-  const int row = (int)(idx / N4), n = (int)(idx % N4);
-  if (row > in && row < in_i) return;  // zero pad rows
+  const int row = (int)(idx / N4), np = (int)(idx % N4);
+  const int n = (np & 3) * d + (np >> 2);  // slab columns follow dz's unit-major order 4u+g
+  if (row > in && row < in_i) return;     // zero pad rows
   float s = 0.f;
   for (int k = 0; k < nslab; ++k) s += slabs[(size_t)k * slab_elems + idx];
   if (row < in)

@@ -49,7 +49,7 @@ static inline int in_internal(const fvta_lstm_desc* d) { return (d->in + 1 + 31)
 // ------------------------------------------------------------- saved state --
 struct SavedView {
   float* gates;  // [2][J][B][4][d] i, tanh(j), f, o activations (fp32 engine: overwritten by dz in backward)
-  bf16_t* gatesb;  // the same, bf16 (bf16 engine: the activations only scale bf16-MFMA operands in backward)
+  bf16_t* gatesb;  // bf16 engine: [2][J][B][d][4] (unit-major, the four gates of a unit adjacent), bf16
   float* cs;     // [2][J][B][d] cell state after step t
   // bf16 engine: MFMA operand shadows, dense per (direction, step) in sorted-row order like gates/cs/dz
   bf16_t* xs;    // [2][J][B][in_i] x at the position (dir, t) visits, a 1.0 column at `in` (dbias), zero pad
@@ -91,7 +91,7 @@ struct WorkView {
   // bf16 engine only
   bf16_t* wt[2];   // [4d][in_i+d]  kernel^T in the internal row order, k contiguous (forward B operand)
   bf16_t* wb[2];   // [in_i+d][4d]  kernel in the internal row order (backward B operand)
-  bf16_t* dzb;     // [2][J][B][4d] gate pre-activation gradients
+  bf16_t* dzb;     // [2][J][B][d][4] gate pre-activation gradients, unit-major like gatesb (wb's k order matches)
   size_t bytes;
 };
 static inline WorkView work_view(const fvta_lstm_desc* d, void* p) {
@@ -153,6 +153,7 @@ struct StepBwdArgs {
   float* dx;            // may be null
   float* dh_rec;
   int t, B, J, in, d, in_i;
+  int dbg;
 };
 
 struct DwArgs {
@@ -190,7 +191,7 @@ __device__ __forceinline__ void lstm_gate_epilogue(const Mma& mma, const StepArg
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = min(m0 + mma.row_of(ti, r), nact - 1);  // clamped: always a valid row
-      cp[r] = t > 0 ? cprev_src[(size_t)i * d + u] : 0.f;
+      cp[r] = (t > 0 && !(a.dbg & 64)) ? cprev_src[(size_t)i * d + u] : 0.f;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -204,13 +205,15 @@ __device__ __forceinline__ void lstm_gate_epilogue(const Mma& mma, const StepArg
       const float h = fvta_tanh(c) * og;
       if (i < nact) {
         if (a.cs) {
-          a.cs[(trow + i) * d + u] = c;
-          if (a.gatesb) {
-            bf16_t* g = a.gatesb + (trow + i) * (size_t)(4 * d) + u;
-            g[0] = f2bf(ig);
-            g[d] = f2bf(jg);
-            g[2 * d] = f2bf(fg);
-            g[3 * d] = f2bf(og);
+          if (!(a.dbg & 16)) a.cs[(trow + i) * d + u] = c;
+          if (a.dbg & 8) {
+          } else if (a.gatesb) {  // unit-major [row][u][i,j,f,o]: one 8-byte store per lane, 256 B per half-wave
+            bf16x4 pk;
+            pk[0] = (short)f2bf(ig);
+            pk[1] = (short)f2bf(jg);
+            pk[2] = (short)f2bf(fg);
+            pk[3] = (short)f2bf(og);
+            *reinterpret_cast<bf16x4*>(a.gatesb + (trow + i) * (size_t)(4 * d) + 4 * u) = pk;
           } else {
             float* g = a.gates + (trow + i) * (size_t)(4 * d) + u;
             g[0] = ig;
@@ -221,8 +224,8 @@ __device__ __forceinline__ void lstm_gate_epilogue(const Mma& mma, const StepArg
         } else {
           a.cstate[((size_t)dir * a.B + i) * d + u] = c;
         }
-        a.out[s_oo[row] + u] = h;
-        if (a.hs) a.hs[(trow + i) * d + u] = f2bf(h);  // bf16 shadow: next step's MFMA operand
+        if (!(a.dbg & 4)) a.out[s_oo[row] + u] = h;
+        if (a.hs && !(a.dbg & 32)) a.hs[(trow + i) * d + u] = f2bf(h);  // bf16 shadow: next step's MFMA operand
       }
     }
   }
