@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
       float dsum = 0.f;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        hreg[i][g] = t >= 0 ? ld4b(hbase + (size_t)t * w + 4 * (cq + g * TPR)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 hv = ld4b(hbase + (size_t)max(t, 0) * w + 4 * (cq + g * TPR));  // unconditional, then zeroed
+        hreg[i][g] = t >= 0 ? hv : f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 pdt = hreg[i][g] * gv[g];
         dsum += (pdt[0] + pdt[1]) + (pdt[2] + pdt[3]);
       }
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
         const f32x4 qs = ld4b(Qs + ((size_t)c4 * JP + j) * 4);
         f32x4 dh = gv[g] * pr + (qs + rh4[g] + r24[g] * h * 2.f) * dx;
         float* dst = dhbase + (size_t)t * w + 4 * c4;
-        if (a.accumulate) dh += ld4b(dst);
+        if (a.accumulate == 1) dh += ld4b(dst);
         *reinterpret_cast<f32x4*>(dst) = dh;
         accq[g] += h * dx;
         accRh[g] += h * dx;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_q_kernel(AttnShape s, Att
     const float dct = s_dct[j];
     const float dq = U * dQ + dct * (Cq + 2.f * C2 * qv);
     float* dst = d_hq + ((size_t)n * JQ + j) * w + c;
-    *dst = accumulate ? *dst + dq : dq;
+    *dst = accumulate == 1 || accumulate == 2 ? *dst + dq : dq;
     pU += dQ * qv;
     pCq += dct * qv;
     pC2 += dct * qv * qv;

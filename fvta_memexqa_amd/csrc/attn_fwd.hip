@@ -206,7 +206,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
       for (int p = 0; p < P; ++p) {
         const int t = s_t[rg + RGN * p];
         const int c4 = sl * SLAB4 + wave * (NSC * SCW) + sc * SCW + c4l;
-        hreg[sc][p] = t >= 0 ? ld4g(hbase + (size_t)t * w + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // unconditional load from a clamped row, zeroed afterwards: a load under a per-lane branch would be
+        // waited for one at a time
+        const f32x4 v = ld4g(hbase + (size_t)max(t, 0) * w + 4 * c4);
+        hreg[sc][p] = t >= 0 ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
   };
 

@@ -119,6 +119,7 @@ class Model:
         self.loss = self.yp = self.logits = None
         self.att_logits = self.q_att_logits = self.hall = None
         self._layouts = {}
+        self._side = torch.cuda.Stream(device=self.dev)
 
         dp, wp = self.dp, self.wp
         F = {1: 3 * wp, 2: 2 * wp, 3: 4 * wp, 4: 0}[self.simi]
@@ -385,10 +386,18 @@ class Model:
     def forward(self, L, want_logits=False):
         """model_v2.py:649-1096 on the loaded batch.  Returns yp (device tensor)."""
         P = self.params
+        main = torch.cuda.current_stream()
         for cell, G in L.groups.items():
-            G.op.make_plan(G.lens)
-            kf, bf, kb, bb = self._cell_params(cell)
-            G.op.forward(G.x, L.arena, kf, bf, kb, bb)                     # encoders + context tensor
+            # the photo cell (few, short-batch, latency-bound launches) runs beside the text cell on a side
+            # HIP stream: the two write disjoint rows of the arena and meet again before the attention
+            side = self._side if (cell == "image" and "text" in L.groups) else None
+            if side is not None:
+                side.wait_stream(main)
+            with torch.cuda.stream(side if side is not None else main):
+                G.op.make_plan(G.lens)
+                kf, bf, kb, bb = self._cell_params(cell)
+                G.op.forward(G.x, L.arena, kf, bf, kb, bb)                 # encoders + context tensor
+        main.wait_stream(self._side)
         T = L.groups["text"]
         T.op.last_state(L.arena, T.segs[1]["s0"], T.segs[1]["count"], L.lch)   # lchoices :807-812
         W = P.view(self.N_ATT_W) if self.simi != 4 else None
@@ -416,7 +425,7 @@ class Model:
         dgq, dg1, dgch = ops.scorer_ce_bwd(L.gq, L.g1, L.lch, P.view(self.N_OUT_W), P.view(self.N_OUT_B), L.y, L.logits,
                                            L.yp, loss_scale, P.view(self.N_OUT_W, True), P.view(self.N_OUT_B, True),
                                            self.use_eu_output, self.add_tanh)
-        L.d_arena.zero_()
+        L.d_arena[L.row_hq:].zero_()   # hq / hchoices gradient rows; the hall rows are written by the attention backward
         d_hall = L.d_arena[:L.row_hq].view(L.N, L.K, L.T, self.wp)
         d_hq = L.d_arena[L.row_hq:L.row_hch].view(L.N, L.JQ, self.wp)
         T = L.groups["text"]
@@ -430,16 +439,21 @@ class Model:
             T.op.last_state_bwd(dgq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
         T.op.last_state_bwd(dgch.view(-1, self.wp), T.segs[1]["s0"], T.segs[1]["count"], L.d_arena)
         L.att.backward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, P.view(self.N_ATT_W), P.view(self.N_ATT_B),
-                       dg1, d_hall, d_hq, P.view(self.N_ATT_W, True), P.view(self.N_ATT_B, True), accumulate=True)
+                       dg1, d_hall, d_hq, P.view(self.N_ATT_W, True), P.view(self.N_ATT_B, True), accumulate=2)
+        main = torch.cuda.current_stream()
         for cell, G in L.groups.items():
             kf, bf, kb, bb = self._cell_params(cell)
             dkf, dbf, dkb, dbb = self._cell_params(cell, grad=True)
-            if need_dx:
-                if G.dx is None:
-                    G.dx = torch.zeros_like(G.x)
-                else:
+            if need_dx and G.dx is None:
+                G.dx = torch.zeros_like(G.x)
+            side = self._side if (cell == "image" and "text" in L.groups) else None
+            if side is not None:
+                side.wait_stream(main)      # d_arena is complete
+            with torch.cuda.stream(side if side is not None else main):
+                if need_dx:
                     G.dx.zero_()
-            G.op.backward(G.x, L.arena, L.d_arena, kf, kb, G.dx if need_dx else None, dkf, dbf, dkb, dbb)
+                G.op.backward(G.x, L.arena, L.d_arena, kf, kb, G.dx if need_dx else None, dkf, dbf, dkb, dbb)
+        main.wait_stream(self._side)            # both cells' gradients are in params.grad
 
     def zero_grad(self):
         self.params.grad.zero_()

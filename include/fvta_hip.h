@@ -70,10 +70,13 @@ int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const float* hq, 
                   const uint8_t* qmask, const float* W, const float* b, float* h_a, float* a_logits,
                   void* saved, void* workspace, fvta_stream_t stream);
 
-/* Backward of fvta_attn_fwd given d_h_a [N,w].  d_hinfo [N,K,T,w] and d_hq
- * [N,JQ,w] are ACCUMULATED INTO when accumulate != 0, else overwritten; dW [F]
- * and db [1] are always accumulated into (they are slices of the flat gradient
- * buffer).  Gradient routing through reduce_max goes to the first arg-max
+/* Backward of fvta_attn_fwd given d_h_a [N,w].  accumulate = 0: d_hinfo [N,K,T,w]
+ * and d_hq [N,JQ,w] are overwritten (masked rows of d_hinfo get zeros);
+ * 1: both are accumulated into; 2: d_hq is accumulated into and only the VALID
+ * rows of d_hinfo are written (plain stores, masked rows left untouched: the
+ * encoders never read them -- this is what the fused model uses, it saves the
+ * clear and the read-modify-write of the largest tensor of the step).  dW [F]
+ * and db [1] are always accumulated into (slices of the flat gradient buffer).  Gradient routing through reduce_max goes to the first arg-max
  * (model_v2.py:268,278; TF splits exact ties). */
 int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const float* hq, const uint8_t* hmask,
                   const uint8_t* qmask, const float* W, const float* b, const float* d_h_a,

@@ -1,0 +1,22 @@
+"""Times the focal attention forward / backward alone at the metric shape (diagnostics)."""
+import os, sys, time, torch
+sys.path.insert(0, os.getcwd())
+from fvta_memexqa_amd import ops
+N, K, T, JQ, w = 64, 6, 1200, 30, 1024
+g = torch.Generator(device="cuda").manual_seed(0)
+h = torch.randn(N, K, T, w, device="cuda", generator=g) * 0.5
+q = torch.randn(N, JQ, w, device="cuda", generator=g) * 0.5
+W = torch.randn(2 * w, device="cuda", generator=g) * 0.1
+b = torch.zeros(1, device="cuda")
+hm = torch.ones(N, K, T, dtype=torch.uint8, device="cuda"); hm[:, 5, 40:] = 0
+qm = torch.ones(N, JQ, dtype=torch.uint8, device="cuda")
+op = ops.FocalAttention(N, K, T, JQ, w, 2, True)
+def timeit(f, n=5):
+    f(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+print("attn fwd ms", round(timeit(lambda: op.forward(h, q, hm, qm, W, b)), 3), "dbg", os.environ.get("FVTA_DEBUG_SKIP"))
+if len(sys.argv) > 1:
+    gout = torch.randn(N, w, device="cuda", generator=g)
+    dh = torch.zeros_like(h); dq = torch.zeros_like(q); dW = torch.zeros_like(W); db = torch.zeros(1, device="cuda")
+    print("attn bwd ms", round(timeit(lambda: op.backward(h, q, hm, qm, W, b, gout, dh, dq, dW, db, True)), 3))
