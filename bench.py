@@ -58,11 +58,16 @@ def parse():
     ap.add_argument("--config", default="metric", choices=["metric", "plumbing", "long_album"])
     ap.add_argument("--variant", default="dense", choices=["dense", "ragged"],
                     help="dense: every length = max (no padding to skip; the headline). ragged: SURVEY 8d length distribution")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--precision", default="bf16", choices=["f32", "bf16"],
+                    help="bf16: BASELINE.json configs[2] (bf16 MFMA operands in the bi-LSTM, fp32 accumulate, fp32 attention); "
+                         "f32: exact-fp32 engine (the 1e-4 parity path)")
     ap.add_argument("--optimizer", default="adam", choices=["adam", "adadelta"])
     ap.add_argument("--batch", type=int, default=None, help="QA pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4, help="QA pairs in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="QA pairs in the CPU-baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=16,
+                    help="torch-CPU threads of the baseline; 16 is the fastest setting measured on the 2x EPYC 9575F host "
+                         "(64 threads: 3.5x slower, 128: 9.5x slower for this op mix; DESIGN.md section 5)")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE.json configs[1] (inference) instead of the train step")
     return ap.parse_args()
 
@@ -72,12 +77,12 @@ def lstm_flops(spec, B, J, din, d):
     return 2 * (J * 2.0 * B * (din + d) * 4 * d - 2.0 * B * d * 4 * d)
 
 
-def cpu_baseline(spec_kw, sample_n, forward_only):
+def cpu_baseline(spec_kw, sample_n, forward_only, threads):
     """The CPU oracle (oracle/fvta_fused.py, torch-CPU fp32, all host cores) on `sample_n` QA pairs of
     the same workload: 1 warm-up + 3 timed passes, median."""
     from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params
     from oracle import fvta_fused as F
-    torch.set_num_threads(host_cores())
+    torch.set_num_threads(max(1, min(threads, host_cores())))
     spec = SynthSpec(**dict(spec_kw, N=sample_n))
     params = {k: v.requires_grad_(not forward_only) for k, v in make_params(spec).items()}
     inputs = make_inputs(spec)
@@ -207,8 +212,8 @@ def main():
         kernel_ms_per_step={k: round(v[0] / args.steps, 4) for k, v in prof.items()},
     )
     if ws == 1 and not args.no_cpu_baseline:
-        log('timing the CPU oracle on %d cores' % host_cores())
-        out["cpu_baseline"] = cpu_baseline(kw, args.cpu_sample, args.forward_only)
+        log('timing the CPU oracle (%d threads of %d host CPUs)' % (args.cpu_threads, host_cores()))
+        out["cpu_baseline"] = cpu_baseline(kw, args.cpu_sample, args.forward_only, args.cpu_threads)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
