@@ -179,3 +179,28 @@ def adadelta_step(var, grad, accum, accum_update, lr, rho=0.95, eps=1e-8, grad_s
 def adam_step(var, grad, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     check(_lib.load().fvta_adam_step(ptr(var), ptr(grad), ptr(m), ptr(v), var.numel(), lr, beta1, beta2, eps, int(t),
                                      grad_scale, stream_ptr()), "fvta_adam_step")
+
+
+# ------------------------------------------------------------ AttentionGRUCell
+def attgru_fwd(inputs, state, Wg, bg, Wc, Wi, bi):
+    """attention_gru_cell.py:50-70, one step.  inputs [B,d+1] (last column = gate), state [B,d]."""
+    lib = _lib.load()
+    B, d = state.shape
+    new_h = torch.empty_like(state)
+    saved = torch.empty(B, 3 * d, device=state.device, dtype=torch.float32)
+    check(lib.fvta_attgru_fwd(B, d, ptr(_f32c(inputs)), ptr(_f32c(state)), ptr(_f32c(Wg)), ptr(_f32c(bg)), ptr(_f32c(Wc)),
+                              ptr(_f32c(Wi)), ptr(_f32c(bi)), ptr(new_h), ptr(saved), stream_ptr()), "fvta_attgru_fwd")
+    return new_h, saved
+
+
+def attgru_bwd(inputs, state, Wg, Wc, Wi, saved, d_new_h, dWg, dbg, dWc, dWi, dbi):
+    """Gradients of one AttentionGRUCell step; parameter gradients are accumulated into."""
+    lib = _lib.load()
+    B, d = state.shape
+    d_inputs = torch.empty_like(inputs)
+    d_state = torch.empty_like(state)
+    ws = torch.empty(B, 4 * d, device=state.device, dtype=torch.float32)
+    check(lib.fvta_attgru_bwd(B, d, ptr(inputs), ptr(state), ptr(Wg), ptr(Wc), ptr(Wi), ptr(saved), ptr(_f32c(d_new_h)),
+                              ptr(d_inputs), ptr(d_state), ptr(dWg), ptr(dbg), ptr(dWc), ptr(dWi), ptr(dbi), ptr(ws),
+                              stream_ptr()), "fvta_attgru_bwd")
+    return d_inputs, d_state
