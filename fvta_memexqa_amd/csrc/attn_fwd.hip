@@ -15,6 +15,25 @@ namespace fvta {
 
 __device__ __forceinline__ f32x4 ld4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// s_waitcnt vmcnt(n) for a loop-unrolled n (the switch folds after unrolling)
+__device__ __forceinline__ void wait_vmcnt_upto(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
 // ---- per-channel vectors from att_logits/W (model_v2.py:242-248, model.py:146-151)
 __global__ void attn_vecs_kernel(const float* __restrict__ W, int w, int simi, int feat_order,
                                  float* __restrict__ vecs) {
@@ -156,7 +175,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
   constexpr int LDW = 4 * SCW + 4;
   constexpr int SLAB4 = 4 * NSC * SCW;
   __shared__ __attribute__((aligned(16))) float s_stage[4][32 * LDW];
-  __shared__ __attribute__((aligned(16))) float s_part[4][JT][1024];
+  // per wave: the pre-scaled question fragments of the current sub-chunk, DMA'd from L2 ([s4][jt][lane][4],
+  // the exact order the MFMA B operands are read in); the same space later carries the wave's partial scores
+  constexpr int BQ = ((SCW / 2) * JT * 256 > JT * 1024) ? (SCW / 2) * JT * 256 : JT * 1024;
+  __shared__ __attribute__((aligned(16))) float s_bq[4][BQ];
+  // row-term vectors Rh, R2 of the bilinear form: LDS copies, so that no ordinary global load sits between
+  // the fragment DMAs and their counted waits (vmcnt retires in order)
+  __shared__ __attribute__((aligned(16))) float s_vec[2][16 * SCW * NSC * NSLAB];
   __shared__ float s_rt[4][32];
   __shared__ int s_t[32];
   __shared__ float s_amax[32];
@@ -166,7 +191,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int c4l = lane % SCW, rg = lane / SCW;
   const int l31 = lane & 31, hf = lane >> 5;
-  const int nk = blockIdx.y, n = nk / s.K, split = blockIdx.x;
+  // XCD-aware work mapping: blocks are dealt round-robin over the 8 XCDs, so block b and b+8 share an L2.
+  // Give each XCD a contiguous range of (n,k,split) items: the pre-scaled question of one n (w*32*4 B) is then
+  // re-read from ONE L2 by all K*nsplit workgroups of that n instead of thrashing all eight.
+  const int nitems = s.N * s.K * s.nsplit;
+  const int bid = blockIdx.x;
+  const int per = (nitems + 7) / 8;
+  const int item = (bid & 7) * per + (bid >> 3);
+  if (item >= nitems || (bid >> 3) >= per) return;
+  const int nk = item / s.nsplit, n = nk / s.K, split = item % s.nsplit;
   const int T = s.T, w = s.w, JP = s.JP;
   const int cnt = a.sv.cnt[nk];
   const bool allm = a.sv.allmasked[nk] != 0;
@@ -198,6 +231,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
     for (int sc = 0; sc < NSC; ++sc) uacc[sl][sc] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
   float* stage = s_stage[wave];
+  float* bq = s_bq[wave];
+  const __amdgpu_buffer_rsrc_t rq =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Qs), 0, (unsigned)(s.W4 * JP * 16), 0x00020000);
+  // direct-to-LDS copy of the question fragments of sub-chunk c4base (asynchronous; no VGPRs, no L2 latency
+  // inside the MFMA chain)
+  auto issue_b1 = [&](int c4base, int s4) {  // the JT blocks of MFMA group s4
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)(bq + (s4 * JT + jt) * 256), 16,
+                                               (unsigned)(((c4base + 2 * s4 + hf) * JP + jt * 32 + l31) * 16), 0, 0, 0);
+  };
+  auto issue_b = [&](int c4base) {
+#pragma unroll
+    for (int s4 = 0; s4 < SCW / 2; ++s4) issue_b1(c4base, s4);
+  };
+  for (int c = tid; c < w; c += 256) {
+    s_vec[0][c] = vRh[c];
+    s_vec[1][c] = vR2[c];
+  }
 
   auto load_slab = [&](int sl) {
 #pragma unroll
@@ -229,14 +281,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
       float rtp[P];
 #pragma unroll
       for (int p = 0; p < P; ++p) rtp[p] = 0.f;
+      issue_b(wave * (NSC * SCW));
 #pragma unroll 1
       for (int sl = 0; sl < NSLAB; ++sl) {
         load_slab(sl);
 #pragma unroll
         for (int sc = 0; sc < NSC; ++sc) {
           const int c4base = sl * SLAB4 + wave * (NSC * SCW) + sc * SCW;
-          const f32x4 rh4 = ld4g(vRh + 4 * (c4base + c4l));
-          const f32x4 r24 = ld4g(vR2 + 4 * (c4base + c4l));
+          const f32x4 rh4 = *reinterpret_cast<const f32x4*>(&s_vec[0][4 * (c4base + c4l)]);
+          const f32x4 r24 = *reinterpret_cast<const f32x4*>(&s_vec[1][4 * (c4base + c4l)]);
 #pragma unroll
           for (int p = 0; p < P; ++p) {
             const f32x4 h = hreg[sc][p];
@@ -245,17 +298,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
             *reinterpret_cast<f32x4*>(&stage[(rg + RGN * p) * LDW + 4 * c4l]) = h;
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          // sub-chunk 0 of a slab: its fragments were requested before the slab's row loads, which the
+          // row-term math above has already waited for (in-order retirement) -- nothing left in flight.
+          // later sub-chunks: their fragments were requested block by block during the previous MFMA
+          // chain; wait per block with a counted vmcnt.
+          if (sc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_wave_barrier();
+          const bool has_next = (sc + 1 < NSC) || (sl + 1 < NSLAB);
+          const int next_base = (sc + 1 < NSC) ? c4base + SCW : (sl + 1) * SLAB4 + wave * (NSC * SCW);
 #pragma unroll
           for (int s4 = 0; s4 < SCW / 2; ++s4) {
+            // younger than group s4's blocks: the rest of this sub-chunk's (7 - s4 groups) plus, when refilling,
+            // the s4 groups already re-requested for the next sub-chunk
+            if (sc != 0) wait_vmcnt_upto((has_next ? SCW / 2 - 1 : SCW / 2 - 1 - s4) * JT);
             const f32x4 av = *reinterpret_cast<const f32x4*>(&stage[l31 * LDW + 8 * s4 + 4 * hf]);
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
-              const f32x4 bv = ld4g(Qs + ((size_t)(c4base + 2 * s4 + hf) * JP + jt * 32 + l31) * 4);
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(&bq[(s4 * JT + jt) * 256 + lane * 4]);
 #pragma unroll
               for (int e = 0; e < 4; ++e)
                 acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[jt], 0, 0, 0);
             }
+            // group s4's fragments are in registers (the MFMAs above consumed them): refill its blocks with
+            // the next sub-chunk's, so the copy runs under the rest of this chain
+            asm volatile("" ::: "memory");
+            if (has_next) issue_b1(next_base, s4);
           }
           __builtin_amdgcn_wave_barrier();
         }
@@ -264,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
 #pragma unroll
       for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s_part[wave][jt][r * 64 + lane] = acc[jt][r];
+        for (int r = 0; r < 16; ++r) bq[jt * 1024 + r * 64 + lane] = acc[jt][r];
       // row terms: reduce over the SCW lanes that share a row
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -288,7 +355,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
           for (int e = 0; e < 4; ++e) {
             const int jl = jg * 4 + e, j = jt * 32 + jl;
             const int pi = preg * 64 + phf * 32 + jl;
-            float x = (s_part[0][jt][pi] + s_part[1][jt][pi]) + (s_part[2][jt][pi] + s_part[3][jt][pi]);
+            const int pj = jt * 1024 + pi;
+            float x = (s_bq[0][pj] + s_bq[1][pj]) + (s_bq[2][pj] + s_bq[3][pj]);
             x = cosine ? x * rs : x + rt + ct[j];
             const bool valid = (qvalid >> j) & 1ull;
             if (a.a_logits && t >= 0 && j < s.JQ)
@@ -430,7 +498,8 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnShape s, AttnSaved 
 
 template <int SCW, int NSC, int NSLAB>
 static int launch_main(const AttnFwdArgs& a, hipStream_t stream) {
-  const dim3 grid(a.s.nsplit, a.s.N * a.s.K);
+  const int nitems = a.s.nsplit * a.s.N * a.s.K;
+  const dim3 grid(((nitems + 7) / 8) * 8);
   if (a.s.JT == 1)
     hipLaunchKernelGGL((attn_fwd_main<SCW, NSC, NSLAB, 1>), grid, dim3(256), 0, stream, a);
   else
