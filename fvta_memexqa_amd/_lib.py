@@ -26,6 +26,10 @@ class LstmDesc(Structure):
     _fields_ = [(n, c_int32) for n in ("B", "J", "in_", "d", "share_fw_bw", "precision", "training", "reserved")]
 
 
+class TimewarpDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ("N", "K", "T", "w", "warp_type")] + [("window_t", c_float)]
+
+
 class ScorerDesc(Structure):
     _fields_ = [(n, c_int32) for n in ("N", "C", "w", "use_eu_output", "add_tanh")]
 
@@ -50,6 +54,9 @@ _SIGS = {
     "fvta_scorer_ce_bwd": (c_int, [POINTER(ScorerDesc), P, P, P, P, P, P, P, P, c_float, P, P, P, P, P, P]),
     "fvta_attgru_fwd": (c_int, [c_int32, c_int32, P, P, P, P, P, P, P, P, P, P]),
     "fvta_attgru_bwd": (c_int, [c_int32, c_int32, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_timewarp_workspace_bytes": (c_size_t, [POINTER(TimewarpDesc)]),
+    "fvta_timewarp_fwd": (c_int, [POINTER(TimewarpDesc), P, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_timewarp_bwd": (c_int, [POINTER(TimewarpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_adadelta_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P]),
     "fvta_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float, P]),
     "fvta_test_gemm": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_q_kernel(AttnShape s, Att
     const float dct = s_dct[j];
     const float dq = U * dQ + dct * (Cq + 2.f * C2 * qv);
     float* dst = d_hq + ((size_t)n * JQ + j) * w + c;
-    *dst = accumulate == 1 || accumulate == 2 ? *dst + dq : dq;
+    *dst = accumulate != 0 ? *dst + dq : dq;
     pU += dQ * qv;
     pCq += dct * qv;
     pC2 += dct * qv * qv;
@@ -431,7 +431,7 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
   AttnBwdWork wk = bwd_work_view(s, workspace);
   const int RH = bwd_rh(s.W4);
   FVTA_CHECK_HIP(hipMemsetAsync(wk.slabs, 0, wk.slab_bytes, stream));
-  if (!accumulate)
+  if (accumulate == 0 || accumulate == 3)
     FVTA_CHECK_HIP(hipMemsetAsync(d_hinfo, 0, (size_t)s.N * s.K * s.T * s.w * sizeof(float), stream));
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(s.N), dim3(256), 0, stream, s, sv, wk, d_h_a);
   AttnBwdArgs a;

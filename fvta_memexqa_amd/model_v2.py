@@ -83,6 +83,8 @@ class Model:
     N_ATT_W, N_ATT_B = "attention/all/att_logits/W", "attention/all/att_logits/b"
     N_QATT_W, N_QATT_B = "question_emb/question_att/att_logits/W", "question_emb/question_att/att_logits/b"
     N_OUT_W, N_OUT_B = "output/choicelogits/W", "output/choicelogits/b"
+    N_TW_WH_W, N_TW_WH_B = "time_warp/WH/W", "time_warp/WH/b"
+    N_TW_WC_W, N_TW_WC_B = "time_warp/WC/W", "time_warp/WC/b"
 
     def __init__(self, config, scope="model", text_in=None, img_in=None, device=None):
         self.scope = scope
@@ -103,8 +105,13 @@ class Model:
             raise NotImplementedError("weight decay (--wd) is not built yet")
         if float(_cfg(config, "keep_prob", 1.0)) != 1.0:
             raise NotImplementedError("LSTM input dropout (--keep_prob < 1) is not built yet")
-        if _cfg(config, "use_time_warp", False) or _cfg(config, "use_time_warp_att", False):
-            raise NotImplementedError("time warp is not built yet")
+        self.use_time_warp = bool(_cfg(config, "use_time_warp", False))
+        self.warp_type = int(_cfg(config, "warp_type", 1))
+        self.window_t = float(_cfg(config, "window_t", 3.0))     # time_warp_window_t, init 3.0 (model_v2.py:333); no gradient
+        if self.use_time_warp and self.warp_type not in (1, 2, 3, 4, 5):
+            raise Exception("time warping type not implemented")    # model_v2.py:341
+        if _cfg(config, "use_time_warp_att", False):
+            raise NotImplementedError("use_time_warp_att is not built yet")
         if _cfg(config, "use_bidirection", False):
             raise NotImplementedError("use_bidirection: the 3-D branch cannot run in the reference either (SURVEY 3.5)")
         if self.simi not in (1, 2, 3, 4):
@@ -135,6 +142,9 @@ class Model:
             specs[self.N_ATT_W], specs[self.N_ATT_B] = (F,), (1,)
             if self.use_question_att:
                 specs[self.N_QATT_W], specs[self.N_QATT_B] = (F,), (1,)
+        if self.use_time_warp:     # model_v2.py:986-989: WH [4d -> 2d], WC [2d -> 1]
+            specs[self.N_TW_WH_W], specs[self.N_TW_WH_B] = (2 * wp, wp), (wp,)
+            specs[self.N_TW_WC_W], specs[self.N_TW_WC_B] = (wp,), (1,)
         specs[self.N_OUT_W] = ((7 if self.use_eu_output else 5) * wp,)
         specs[self.N_OUT_B] = (1,)
         self.params = ParamStore(specs, self.dev)
@@ -178,6 +188,21 @@ class Model:
         n = v.numel() // dp
         return torch.cat([v[g * dp:g * dp + d] for g in range(n)])
 
+    def _pad_feat2d(self, m):
+        """[R*d, C*d] matrix whose rows AND columns are d-blocks (time_warp/WH/W) -> dp-blocks."""
+        d, dp = self.d, self.dp
+        R, C = m.shape[0] // d, m.shape[1] // d
+        out = torch.zeros(R * dp, C * dp, dtype=torch.float32)
+        for r in range(R):
+            for c in range(C):
+                out[r * dp:r * dp + d, c * dp:c * dp + d] = m[r * d:(r + 1) * d, c * d:(c + 1) * d]
+        return out
+
+    def _unpad_feat2d(self, m):
+        d, dp = self.d, self.dp
+        R, C = m.shape[0] // dp, m.shape[1] // dp
+        return torch.cat([torch.cat([m[r * dp:r * dp + d, c * dp:c * dp + d] for c in range(C)], 1) for r in range(R)], 0)
+
     def set_weights(self, weights):
         """weights: dict reference-name -> array in the REFERENCE's shapes
         (main.py:578-588 `weights.npz` layout)."""
@@ -189,7 +214,9 @@ class Model:
                 t = self._pad_kernel(t, *self._din(name))
             elif name.endswith("basic_lstm_cell/bias"):
                 t = self._pad_blocks(t, 4, self.d, self.dp)
-            elif name.endswith("/W"):
+            elif name == self.N_TW_WH_W:
+                t = self._pad_feat2d(t)
+            elif name.endswith("/W") or name == self.N_TW_WH_B:
                 t = self._pad_feat(t)
             self.params.view(name).copy_(t.reshape(self.params.specs[name]).to(self.dev))
 
@@ -202,6 +229,10 @@ class Model:
                 t = self._unpad_kernel(t, *self._din(name))
             elif name.endswith("basic_lstm_cell/bias"):
                 t = torch.cat([t[g * self.dp:g * self.dp + self.d] for g in range(4)])
+            elif name == self.N_TW_WH_W:
+                t = self._unpad_feat2d(t)
+            elif name == self.N_TW_WH_B:
+                t = self._unpad_feat(t)
             elif name.endswith("/W"):
                 t = self._unpad_feat(t).reshape(-1, 1)
             out[name] = t.numpy()
@@ -217,6 +248,8 @@ class Model:
             if name.endswith("basic_lstm_cell/kernel"):
                 din = self.text_in if "utext" in name else self.img_in
                 wts[name] = _glorot(g, din + self.d, 4 * self.d)
+            elif name == self.N_TW_WH_W:
+                wts[name] = _trunc_normal(g, (4 * self.d, 2 * self.d))
             elif name.endswith("/W"):
                 wts[name] = _trunc_normal(g, (shape[0] // self.dp * self.d, 1))
         self.set_weights(wts)
@@ -228,7 +261,10 @@ class Model:
              "image_kernel": self.N_IMG_K % "fw", "image_bias": self.N_IMG_B % "fw",
              "image_kernel_bw": self.N_IMG_K % "bw", "image_bias_bw": self.N_IMG_B % "bw",
              "att_W": self.N_ATT_W, "att_b": self.N_ATT_B, "qatt_W": self.N_QATT_W, "qatt_b": self.N_QATT_B,
-             "out_W": self.N_OUT_W, "out_b": self.N_OUT_B}
+             "out_W": self.N_OUT_W, "out_b": self.N_OUT_B, "WH_W": self.N_TW_WH_W, "WH_b": self.N_TW_WH_B,
+             "WC_W": self.N_TW_WC_W, "WC_b": self.N_TW_WC_B}
+        if "window_t" in p:
+            self.window_t = float(p["window_t"])
         self.set_weights({m[k]: v for k, v in p.items() if k in m})
 
     def get_oracle_grads(self):
@@ -238,7 +274,8 @@ class Model:
              self.N_IMG_K % "fw": "image_kernel", self.N_IMG_B % "fw": "image_bias",
              self.N_IMG_K % "bw": "image_kernel_bw", self.N_IMG_B % "bw": "image_bias_bw",
              self.N_ATT_W: "att_W", self.N_ATT_B: "att_b", self.N_QATT_W: "qatt_W", self.N_QATT_B: "qatt_b",
-             self.N_OUT_W: "out_W", self.N_OUT_B: "out_b"}
+             self.N_OUT_W: "out_W", self.N_OUT_B: "out_b", self.N_TW_WH_W: "WH_W", self.N_TW_WH_B: "WH_b",
+             self.N_TW_WC_W: "WC_W", self.N_TW_WC_B: "WC_b"}
         return {m[k]: v for k, v in g.items()}
 
     # ---------------------------------------------------------------- layout
@@ -322,6 +359,11 @@ class Model:
         L.qatt = ops.FocalAttention(N, 1, JQ, 1, wp, self.simi, self.add_tanh) if self.use_question_att else None
         L.lq = torch.zeros(N, wp, dtype=torch.float32, device=dev)
         L.lch = torch.zeros(N, C, wp, dtype=torch.float32, device=dev)
+        if self.use_time_warp:
+            L.tw = ops.TimeWarp(N, K, T, wp, self.warp_type, self.window_t)
+            L.warp_h = torch.zeros(N, K, T, wp, dtype=torch.float32, device=dev)
+            L.d_warp = torch.zeros(N, K, T, wp, dtype=torch.float32, device=dev) if training else None
+            L.d_lq = torch.zeros(N, wp, dtype=torch.float32, device=dev) if training else None
         L.y = torch.zeros(N, C, dtype=torch.uint8, device=dev)
         self._layouts[key] = L
         return L
@@ -402,7 +444,15 @@ class Model:
         T.op.last_state(L.arena, T.segs[1]["s0"], T.segs[1]["count"], L.lch)   # lchoices :807-812
         W = P.view(self.N_ATT_W) if self.simi != 4 else None
         b = P.view(self.N_ATT_B) if self.simi != 4 else None
-        L.g1, att = L.att.forward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, W, b, want_logits)  # :1020
+        ctx = L.hall
+        if self.use_time_warp:                                              # :953-1009, WQ = lq (:970)
+            T.op.last_state(L.arena, T.segs[0]["s0"], T.segs[0]["count"], L.lq)
+            L.tw.forward(L.hall, L.lq, P.view(self.N_TW_WH_W), P.view(self.N_TW_WH_B), P.view(self.N_TW_WC_W),
+                         P.view(self.N_TW_WC_B), L.warp_h)
+            ctx = self.warp_h = L.warp_h
+            self.C = L.tw.c                                                 # c[n,t]; the reference's C[n,t,t'] = c[n,t]
+        L.ctx = ctx
+        L.g1, att = L.att.forward(ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, W, b, want_logits)  # :1020
         if self.use_question_att:                                           # :1044
             Wq = P.view(self.N_QATT_W) if self.simi != 4 else None
             bq = P.view(self.N_QATT_B) if self.simi != 4 else None
@@ -438,8 +488,20 @@ class Model:
         else:
             T.op.last_state_bwd(dgq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
         T.op.last_state_bwd(dgch.view(-1, self.wp), T.segs[1]["s0"], T.segs[1]["count"], L.d_arena)
-        L.att.backward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, P.view(self.N_ATT_W), P.view(self.N_ATT_B),
-                       dg1, d_hall, d_hq, P.view(self.N_ATT_W, True), P.view(self.N_ATT_B, True), accumulate=2)
+        if self.use_time_warp:
+            # attention gradient w.r.t. the warped tensor (masked rows zeroed: the warp backward walks every row),
+            # then through the warp into the hall rows of the arena and into lq -> the question encoder's last state
+            L.att.backward(L.ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, P.view(self.N_ATT_W), P.view(self.N_ATT_B),
+                           dg1, L.d_warp, d_hq, P.view(self.N_ATT_W, True), P.view(self.N_ATT_B, True), accumulate=3)
+            L.d_lq.zero_()
+            L.tw.backward(L.hall, L.lq, P.view(self.N_TW_WH_W), P.view(self.N_TW_WH_B), P.view(self.N_TW_WC_W),
+                          P.view(self.N_TW_WC_B), L.d_warp, d_hall, L.d_lq, P.view(self.N_TW_WH_W, True),
+                          P.view(self.N_TW_WH_B, True), P.view(self.N_TW_WC_W, True), P.view(self.N_TW_WC_B, True))
+            T.op.last_state_bwd(L.d_lq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
+        else:
+            L.att.backward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, P.view(self.N_ATT_W),
+                           P.view(self.N_ATT_B), dg1, d_hall, d_hq, P.view(self.N_ATT_W, True), P.view(self.N_ATT_B, True),
+                           accumulate=2)
         main = torch.cuda.current_stream()
         for cell, G in L.groups.items():
             kf, bf, kb, bb = self._cell_params(cell)

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, AttnDesc, LstmDesc, ScorerDesc, check, ptr, stream_ptr
+from ._lib import F32, BF16, AttnDesc, LstmDesc, ScorerDesc, TimewarpDesc, check, ptr, stream_ptr
 
 
 def require_gpu():
@@ -204,3 +204,30 @@ def attgru_bwd(inputs, state, Wg, Wc, Wi, saved, d_new_h, dWg, dbg, dWc, dWi, db
                               ptr(d_inputs), ptr(d_state), ptr(dWg), ptr(dbg), ptr(dWc), ptr(dWi), ptr(dbi), ptr(ws),
                               stream_ptr()), "fvta_attgru_bwd")
     return d_inputs, d_state
+
+
+# ------------------------------------------------------------------ time warp
+class TimeWarp:
+    """model_v2.py:953-1009 (closed form): warp_h = hall * c[n,t] * cnt(t)."""
+
+    def __init__(self, N, K, T, w, warp_type, window_t=3.0):
+        self.lib = _lib.load()
+        self.dev = require_gpu()
+        self.desc = TimewarpDesc(N, K, T, w, int(warp_type), float(window_t))
+        nb = self.lib.fvta_timewarp_workspace_bytes(ctypes.byref(self.desc))
+        if nb == 0:
+            raise Exception(self.lib.fvta_last_error().decode())     # "time warping type not implemented" (model_v2.py:341)
+        self.work = _bytes(nb, self.dev)
+        self.c = torch.empty(N, T, device=self.dev, dtype=torch.float32)
+        self.scale = torch.empty(N, T, device=self.dev, dtype=torch.float32)
+
+    def forward(self, hall, lq, WH_W, WH_b, WC_W, WC_b, warp_h):
+        check(self.lib.fvta_timewarp_fwd(ctypes.byref(self.desc), ptr(_f32c(hall)), ptr(_f32c(lq)), ptr(WH_W), ptr(WH_b),
+                                         ptr(WC_W), ptr(WC_b), ptr(_f32c(warp_h)), ptr(self.c), ptr(self.scale),
+                                         ptr(self.work), stream_ptr()), "fvta_timewarp_fwd")
+
+    def backward(self, hall, lq, WH_W, WH_b, WC_W, WC_b, d_warp, d_hall, d_lq, dWH_W, dWH_b, dWC_W, dWC_b):
+        check(self.lib.fvta_timewarp_bwd(ctypes.byref(self.desc), ptr(hall), ptr(lq), ptr(WH_W), ptr(WH_b), ptr(WC_W),
+                                         ptr(WC_b), ptr(self.c), ptr(_f32c(d_warp)), ptr(d_hall), ptr(d_lq), ptr(dWH_W),
+                                         ptr(dWH_b), ptr(dWC_W), ptr(dWC_b), ptr(self.work), stream_ptr()),
+              "fvta_timewarp_bwd")

@@ -75,7 +75,8 @@ int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const float* hq, 
  * 1: both are accumulated into; 2: d_hq is accumulated into and only the VALID
  * rows of d_hinfo are written (plain stores, masked rows left untouched: the
  * encoders never read them -- this is what the fused model uses, it saves the
- * clear and the read-modify-write of the largest tensor of the step).  dW [F]
+ * clear and the read-modify-write of the largest tensor of the step); 3: d_hq
+ * accumulated into, d_hinfo overwritten with zeros on masked rows.  dW [F]
  * and db [1] are always accumulated into (slices of the flat gradient buffer).  Gradient routing through reduce_max goes to the first arg-max
  * (model_v2.py:268,278; TF splits exact ties). */
 int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const float* hq, const uint8_t* hmask,
@@ -173,6 +174,32 @@ int fvta_attgru_bwd(int32_t B, int32_t d, const float* inputs, const float* stat
                     const float* Wc, const float* Wi, const float* saved, const float* d_new_h,
                     float* d_inputs, float* d_state, float* dWg, float* dbg, float* dWc, float* dWi,
                     float* dbi, void* workspace /* B*4d floats */, fvta_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Time warp of the context tensor: model_v2.py:953-1009 with the indicator of
+ * time_indication_func (301-341), in the closed form the reference's expression
+ * reduces to:  warp_h[n,k,t,:] = hall[n,k,t,:] * c[n,t] * cnt(t).
+ *   hall / warp_h / d_* [N,K,T,w]; lq [N,w] (WQ = lq, model_v2.py:970);
+ *   WH_W [2w,w] (only its first w rows ever meet a non-zero feature), WH_b [w],
+ *   WC_W [w], WC_b [1]: time_warp/{WH,WC}/{W,b}; window_t: time_warp_window_t
+ *   (no gradient: tf.ceil, model_v2.py:335).  c_out / scale_out [N,T] are kept
+ *   by the caller for the backward call.
+ * ------------------------------------------------------------------------- */
+typedef struct fvta_timewarp_desc {
+  int32_t N, K, T, w;
+  int32_t warp_type; /* 1 all, 2 current, 3 past, 4 future, 5 past-future window */
+  float window_t;
+} fvta_timewarp_desc;
+
+size_t fvta_timewarp_workspace_bytes(const fvta_timewarp_desc* d);
+int fvta_timewarp_fwd(const fvta_timewarp_desc* d, const float* hall, const float* lq, const float* WH_W,
+                      const float* WH_b, const float* WC_W, const float* WC_b, float* warp_h, float* c_out,
+                      float* scale_out, void* workspace, fvta_stream_t stream);
+/* d_hall is overwritten; d_lq and the parameter gradients are accumulated into. */
+int fvta_timewarp_bwd(const fvta_timewarp_desc* d, const float* hall, const float* lq, const float* WH_W,
+                      const float* WH_b, const float* WC_W, const float* WC_b, const float* c_saved,
+                      const float* d_warp, float* d_hall, float* d_lq, float* dWH_W, float* dWH_b, float* dWC_W,
+                      float* dWC_b, void* workspace, fvta_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Parameter update over the flat fp32 parameter buffer: trainer.py:16

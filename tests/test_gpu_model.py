@@ -141,3 +141,33 @@ def test_metric_shape_forward_vs_oracle_subset():
     _close(L.g1[:n], ref["g1_all"], rtol=1e-4, atol=2e-5, msg="g1")
     _close(yp[:n], ref["yp"], rtol=1e-4, atol=1e-5, msg="yp")
     assert (yp[:n].argmax(1).cpu() == ref["yp"].argmax(1)).all()
+
+
+@pytest.mark.parametrize("warp_type", [1, 5])
+def test_model_with_time_warp(warp_type):
+    """The published FVTA flag set adds --use_time_warp (README.MD:144-147): forward and gradients vs the oracle."""
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params, to_dtype
+    from oracle import fvta_fused as F
+    spec = SynthSpec(N=3, A=2, P=3, S=2, L=5, d=32, SA=1, dense=False, text_in=12, img_in=8)
+    params, inputs = make_params(spec), make_inputs(spec)
+    g = torch.Generator().manual_seed(17)
+    w = spec.w
+    params.update(WH_W=torch.randn(2 * w, w, generator=g) * 0.05, WH_b=torch.randn(w, generator=g) * 0.05,
+                  WC_W=torch.randn(w, 1, generator=g) * 0.1, WC_b=torch.randn(1, generator=g) * 0.05)
+    cfg = dict(spec.cfg(), use_time_warp=True, warp_type=warp_type, window_t=1.4)
+    p64 = {k: v.double().requires_grad_() for k, v in params.items()}
+    ref = F.fvta_forward(dict(p64, window_t=1.4), to_dtype(inputs, torch.float64), cfg)
+    ref["loss"].backward()
+    model = Model(dict(cfg, batch_size=spec.N), text_in=spec.text_in, img_in=spec.img_in)
+    model.set_oracle_params(params)
+    L = model.load_inputs(inputs, training=True)
+    model.zero_grad()
+    yp = model.forward(L)
+    model.backward(L)
+    _close(yp, ref["yp"], msg="yp")
+    _close(model.warp_h.reshape(ref["hall"].shape), ref["hall"], msg="warp_h")
+    grads = model.get_oracle_grads()
+    for k, v in p64.items():
+        if v.grad is not None:
+            _close(grads[k].reshape(v.grad.shape), v.grad, rtol=2e-4, atol=2e-5, msg="grad " + k)
