@@ -123,6 +123,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   __shared__ uint8_t s_j[BWD_CHMAX];
   __shared__ int s_hist[4][65];
   __shared__ float s_dot[4][TR];
+  __shared__ float s_nrm[4][TR];
+  __shared__ float s_self[TR];
   __shared__ float s_pr[TR], s_dx[TR];
   __shared__ int s_tt[TR], s_jj[TR];
 
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   float* __restrict__ dhbase = a.d_hinfo + (size_t)nk * T * w;
   const float* __restrict__ Qs = a.sv.Qs + (size_t)n * s.W4 * JP * 4;
   const float M = a.sv.M[nk];
+  const bool cosine = s.simi == 4;
   const float coef = a.wk.coef[nk], gu = a.wk.gu[nk], dss = a.wk.dss[nk];
   const size_t slot = ((size_t)nk * s.bsplit + split) * RH + rh;
   float* __restrict__ slab = a.wk.slabs + slot * JP * w;
@@ -237,19 +240,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
       s_jj[tid] = i < nrows ? (int)s_j[i] : 0;
     }
     __syncthreads();
-    float dot[RPT];
+    float dot[RPT], nrm[RPT];
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int t = s_tt[rh * RPT + i];
-      float dsum = 0.f;
+      float dsum = 0.f, nsum = 0.f;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const f32x4 hv = ld4b(hbase + (size_t)max(t, 0) * w + 4 * (cq + g * TPR));  // unconditional, then zeroed
         hreg[i][g] = t >= 0 ? hv : f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 pdt = hreg[i][g] * gv[g];
         dsum += (pdt[0] + pdt[1]) + (pdt[2] + pdt[3]);
+        if (cosine) {
+          const f32x4 hh = hreg[i][g] * hreg[i][g];
+          nsum += (hh[0] + hh[1]) + (hh[2] + hh[3]);
+        }
       }
       dot[i] = dsum;
+      nrm[i] = nsum;
     }
     // reduce g.h over the TPR threads of each row
 #pragma unroll
@@ -258,40 +266,62 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
 #pragma unroll
       for (int o = 1; o < (TPR < 64 ? TPR : 64); o <<= 1) v += __shfl_xor(v, o, 64);
       dot[i] = v;
+      if (cosine) {
+        float u = nrm[i];
+#pragma unroll
+        for (int o = 1; o < (TPR < 64 ? TPR : 64); o <<= 1) u += __shfl_xor(u, o, 64);
+        nrm[i] = u;
+      }
     }
     if (TPR >= 64) {
       if (lane == 0)
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) s_dot[wave][rh * RPT + i] = dot[i];
+        for (int i = 0; i < RPT; ++i) {
+          s_dot[wave][rh * RPT + i] = dot[i];
+          s_nrm[wave][rh * RPT + i] = nrm[i];
+        }
     } else {
       if (cq == 0)
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) s_dot[0][rh * RPT + i] = dot[i];
+        for (int i = 0; i < RPT; ++i) {
+          s_dot[0][rh * RPT + i] = dot[i];
+          s_nrm[0][rh * RPT + i] = nrm[i];
+        }
     }
     __syncthreads();
     if (tid < TR) {
       const int t = s_tt[tid];
-      float pr = 0.f, dx = 0.f;
+      float pr = 0.f, dx = 0.f, self = 0.f;
       if (t >= 0) {
-        float gh;
+        float gh, hh = 0.f;
         if (TPR >= 64) {
           // row `tid` belongs to row group tid / RPT whose waves are [rg*WPR, rg*WPR + WPR)
           const int rgp = tid / RPT;
           gh = 0.f;
 #pragma unroll
-          for (int v = 0; v < WPR; ++v) gh += s_dot[rgp * WPR + v][tid];
+          for (int v = 0; v < WPR; ++v) {
+            gh += s_dot[rgp * WPR + v][tid];
+            hh += s_nrm[rgp * WPR + v][tid];
+          }
         } else {
           gh = s_dot[0][tid];
+          hh = s_nrm[0][tid];
         }
         const float am = amax[t];
         pr = expf(am - M) * coef;
         if (!allm) {  // fully masked rows: am = -1e30, no gradient into the masked logits
           const float damax = pr * (gh - gu) + (am == M ? dss : 0.f);
           dx = s.add_tanh ? damax * (1.f - am * am) : damax;
+          if (cosine) {  // x = (h.qn) * rh with rh = rsqrt(max(|h|^2, eps)) (model_v2.py:250-254): am IS x
+            const float rhn = rsqrtf(fmaxf(hh, 1e-12f));
+            self = hh > 1e-12f ? -damax * am * rhn * rhn : 0.f;  // d/dh of the normaliser
+            dx = damax * rhn;                                      // coefficient of qn[j] (and of h in dQs)
+          }
         }
       }
       s_pr[tid] = pr;
       s_dx[tid] = dx;
+      s_self[tid] = self;
     }
     __syncthreads();
 #pragma unroll
@@ -300,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
       const int t = s_tt[row];
       if (t < 0) continue;
       const int j = s_jj[row];
-      const float pr = s_pr[row], dx = s_dx[row];
+      const float pr = s_pr[row], dx = s_dx[row], self = s_self[row];
       if (j != cur_j) {
         flush();
         cur_j = j;
@@ -311,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
         const int c4 = cq + g * TPR;
         const f32x4 h = hreg[i][g];
         const f32x4 qs = ld4b(Qs + ((size_t)c4 * JP + j) * 4);
-        f32x4 dh = gv[g] * pr + (qs + rh4[g] + r24[g] * h * 2.f) * dx;
+        f32x4 dh = cosine ? gv[g] * pr + qs * dx + h * self : gv[g] * pr + (qs + rh4[g] + r24[g] * h * 2.f) * dx;
         float* dst = dhbase + (size_t)t * w + 4 * c4;
         if (a.accumulate == 1) dh += ld4b(dst);
         *reinterpret_cast<f32x4*>(dst) = dh;
@@ -373,6 +403,45 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_q_kernel(AttnShape s, Att
   pv[VEC_C2 * w + c] = pC2;
 }
 
+// ---- cosine similarity (simi 4): d_hq from the dqn slabs; qn = q * rq, rq = rsqrt(max(|q|^2, eps)).
+// grid N*JQ, 256 threads
+__global__ __launch_bounds__(256) void attn_bwd_cosine_q_kernel(AttnShape s, AttnBwdWork wk, int RH,
+                                                                const float* __restrict__ hq,
+                                                                float* __restrict__ d_hq, int accumulate) {
+  __shared__ float s_red[2][4];
+  const int n = blockIdx.x / s.JQ, j = blockIdx.x % s.JQ, tid = threadIdx.x;
+  const int w = s.w, JP = s.JP;
+  const int nslot = s.K * s.bsplit * RH;
+  const size_t slot0 = (size_t)n * nslot;
+  const float* q = hq + ((size_t)n * s.JQ + j) * w;
+  float qq = 0.f, qd = 0.f;
+  for (int c = tid; c < w; c += 256) {
+    float dQ = 0.f;
+    for (int sl = 0; sl < nslot; ++sl) dQ += wk.slabs[((slot0 + sl) * JP + j) * w + c];
+    const float qv = q[c];
+    qq += qv * qv;
+    qd += qv * dQ;
+  }
+  qq = wave_sum(qq);
+  qd = wave_sum(qd);
+  if ((tid & 63) == 0) {
+    s_red[0][tid >> 6] = qq;
+    s_red[1][tid >> 6] = qd;
+  }
+  __syncthreads();
+  qq = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+  qd = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+  const float rq = rsqrtf(fmaxf(qq, 1e-12f));
+  const float proj = qq > 1e-12f ? qd * rq * rq : 0.f;  // (qn . dqn) rq, folded
+  for (int c = tid; c < w; c += 256) {
+    float dQ = 0.f;
+    for (int sl = 0; sl < nslot; ++sl) dQ += wk.slabs[((slot0 + sl) * JP + j) * w + c];
+    const float dq = (dQ - proj * q[c]) * rq;
+    float* dst = d_hq + ((size_t)n * s.JQ + j) * w + c;
+    *dst = accumulate != 0 ? *dst + dq : dq;
+  }
+}
+
 // ---- sum over n, map back to att_logits/W's layout.  grid ceil(w/256)
 __global__ __launch_bounds__(256) void attn_bwd_params_kernel(AttnShape s, AttnBwdWork wk, float* __restrict__ dW,
                                                               float* __restrict__ db) {
@@ -419,11 +488,7 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
                              void* workspace, fvta_stream_t stream_) {
   if (int e = fvta_attn_check_desc(d)) return e;
   FVTA_CHECK_ARG(hinfo && hq && d_h_a && saved && d_hinfo && d_hq && workspace, "attn_bwd: null pointer");
-  if (d->simi == 4) {
-    fvta_set_error("attn_bwd: simiMatrix 4 (cosine) backward is not built; forward only");
-    return FVTA_ERR_UNSUPPORTED;
-  }
-  FVTA_CHECK_ARG(dW && db, "attn_bwd: dW/db required");
+  FVTA_CHECK_ARG(d->simi == 4 || (dW && db), "attn_bwd: dW/db required");
   hipStream_t stream = (hipStream_t)stream_;
   const bool use_mask = hmask && qmask;
   const AttnShape s = attn_shape(d, use_mask);
@@ -454,9 +519,13 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
   }
   fvta_prof_end(FVTA_PROF_ATTN_BWD_MAIN, 1, stream);
   FVTA_CHECK_LAUNCH("attn_bwd_main");
-  hipLaunchKernelGGL(attn_bwd_reduce_q_kernel, dim3(s.N, (s.w + 255) / 256), dim3(256), 0, stream, s, sv, wk, RH, hq,
-                     d_hq, accumulate);
-  hipLaunchKernelGGL(attn_bwd_params_kernel, dim3((s.w + 255) / 256), dim3(256), 0, stream, s, wk, dW, db);
+  if (s.simi == 4) {
+    hipLaunchKernelGGL(attn_bwd_cosine_q_kernel, dim3(s.N * s.JQ), dim3(256), 0, stream, s, wk, RH, hq, d_hq, accumulate);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_reduce_q_kernel, dim3(s.N, (s.w + 255) / 256), dim3(256), 0, stream, s, sv, wk, RH, hq,
+                       d_hq, accumulate);
+    hipLaunchKernelGGL(attn_bwd_params_kernel, dim3((s.w + 255) / 256), dim3(256), 0, stream, s, wk, dW, db);
+  }
   FVTA_CHECK_LAUNCH("attn_bwd_reduce");
   return FVTA_OK;
 }

@@ -472,6 +472,13 @@ class Model:
     def backward(self, L, loss_scale=1.0, need_dx=False):
         """Gradient of the mean cross-entropy into params.grad (accumulated)."""
         P = self.params
+        cos = self.simi == 4      # cosine similarity has no att_logits/{W,b}
+        aW, ab = (None, None) if cos else (P.view(self.N_ATT_W), P.view(self.N_ATT_B))
+        daW, dab = (None, None) if cos else (P.view(self.N_ATT_W, True), P.view(self.N_ATT_B, True))
+        if self.use_question_att and not cos:
+            qW, qb, dqW, dqb = P.view(self.N_QATT_W), P.view(self.N_QATT_B), P.view(self.N_QATT_W, True), P.view(self.N_QATT_B, True)
+        else:
+            qW = qb = dqW = dqb = None
         dgq, dg1, dgch = ops.scorer_ce_bwd(L.gq, L.g1, L.lch, P.view(self.N_OUT_W), P.view(self.N_OUT_B), L.y, L.logits,
                                            L.yp, loss_scale, P.view(self.N_OUT_W, True), P.view(self.N_OUT_B, True),
                                            self.use_eu_output, self.add_tanh)
@@ -482,25 +489,23 @@ class Model:
         if self.use_question_att:
             # g1 feeds both the scorer and the question attention: accumulate its second gradient in place
             # (the hq region of d_arena is still zero here, so accumulate mode is exact for it too)
-            L.qatt.backward(L.hq, L.g1.view(L.N, 1, self.wp), L.q_mask, L.ones_mask, P.view(self.N_QATT_W),
-                            P.view(self.N_QATT_B), dgq, d_hq.view(L.N, 1, L.JQ, self.wp), dg1.view(L.N, 1, self.wp),
-                            P.view(self.N_QATT_W, True), P.view(self.N_QATT_B, True), accumulate=True)
+            L.qatt.backward(L.hq, L.g1.view(L.N, 1, self.wp), L.q_mask, L.ones_mask, qW, qb, dgq,
+                            d_hq.view(L.N, 1, L.JQ, self.wp), dg1.view(L.N, 1, self.wp), dqW, dqb, accumulate=True)
         else:
             T.op.last_state_bwd(dgq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
         T.op.last_state_bwd(dgch.view(-1, self.wp), T.segs[1]["s0"], T.segs[1]["count"], L.d_arena)
         if self.use_time_warp:
             # attention gradient w.r.t. the warped tensor (masked rows zeroed: the warp backward walks every row),
             # then through the warp into the hall rows of the arena and into lq -> the question encoder's last state
-            L.att.backward(L.ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, P.view(self.N_ATT_W), P.view(self.N_ATT_B),
-                           dg1, L.d_warp, d_hq, P.view(self.N_ATT_W, True), P.view(self.N_ATT_B, True), accumulate=3)
+            L.att.backward(L.ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, L.d_warp, d_hq, daW, dab,
+                           accumulate=3)
             L.d_lq.zero_()
             L.tw.backward(L.hall, L.lq, P.view(self.N_TW_WH_W), P.view(self.N_TW_WH_B), P.view(self.N_TW_WC_W),
                           P.view(self.N_TW_WC_B), L.d_warp, d_hall, L.d_lq, P.view(self.N_TW_WH_W, True),
                           P.view(self.N_TW_WH_B, True), P.view(self.N_TW_WC_W, True), P.view(self.N_TW_WC_B, True))
             T.op.last_state_bwd(L.d_lq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
         else:
-            L.att.backward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, P.view(self.N_ATT_W),
-                           P.view(self.N_ATT_B), dg1, d_hall, d_hq, P.view(self.N_ATT_W, True), P.view(self.N_ATT_B, True),
+            L.att.backward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, d_hall, d_hq, daW, dab,
                            accumulate=2)
         main = torch.cuda.current_stream()
         for cell, G in L.groups.items():

@@ -15,7 +15,7 @@ def _close(a, b, rtol=1e-4, atol=1e-5, msg=""):
 
 @pytest.mark.parametrize("N,K,T,JQ,w", [(2, 3, 50, 10, 64), (3, 2, 100, 30, 256), (2, 6, 333, 30, 1024),
                                         (1, 2, 70, 60, 2048), (2, 1, 1100, 5, 128), (2, 2, 64, 7, 512)])
-@pytest.mark.parametrize("simi,tanh", [(1, False), (2, True), (3, True)])
+@pytest.mark.parametrize("simi,tanh", [(1, False), (2, True), (3, True), (4, False)])
 @pytest.mark.parametrize("masked", [True, False])
 def test_attention_3d_backward_matches_autograd(N, K, T, JQ, w, simi, tanh, masked):
     from fvta_memexqa_amd import ops
@@ -28,31 +28,34 @@ def test_attention_3d_backward_matches_autograd(N, K, T, JQ, w, simi, tanh, mask
             qm[N - 1, :2] = True
     g = torch.Generator().manual_seed(99)
     gout = torch.randn(N, w, generator=g)
-    hd, qd, Wd, bd = [t.double().requires_grad_() for t in (h, q, W, b)]
+    hd, qd = h.double().requires_grad_(), q.double().requires_grad_()
+    Wd, bd = (None, None) if W is None else (W.double().requires_grad_(), b.double().requires_grad_())
     ref_ha, _ = F.attention_3d(hd, qd, Wd, bd, hm, qm, simiMatrix=simi, add_tanh=tanh)
     (ref_ha * gout.double()).sum().backward()
 
     op = ops.FocalAttention(N, K, T, JQ, w, simi, tanh)
     cu = lambda t: None if t is None else t.cuda().contiguous()
-    hc, qc, Wc, bc = cu(h), cu(q), cu(W.reshape(-1)), cu(b)
+    hc, qc, Wc, bc = cu(h), cu(q), (None if W is None else cu(W.reshape(-1))), cu(b)
     hmc, qmc = cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm))
     ha, _ = op.forward(hc, qc, hmc, qmc, Wc, bc)
     dh = torch.full_like(hc, 7.0)           # overwritten (accumulate=0)
     dq = torch.full_like(qc, 7.0)
-    dW = torch.zeros_like(Wc)
-    db = torch.zeros(1, device="cuda")
+    dW = None if Wc is None else torch.zeros_like(Wc)
+    db = None if Wc is None else torch.zeros(1, device="cuda")
     op.backward(hc, qc, hmc, qmc, Wc, bc, cu(gout), dh, dq, dW, db, accumulate=False)
     _close(dh, hd.grad, msg="d_hinfo")
     _close(dq, qd.grad, msg="d_hq")
-    _close(dW, Wd.grad.reshape(-1), msg="dW")
-    _close(db, bd.grad, msg="db")
+    if Wd is not None:
+        _close(dW, Wd.grad.reshape(-1), msg="dW")
+        _close(db, bd.grad, msg="db")
     # accumulate mode adds on top
     dh2 = torch.ones_like(hc)
     dq2 = torch.ones_like(qc)
     op.backward(hc, qc, hmc, qmc, Wc, bc, cu(gout), dh2, dq2, dW, db, accumulate=True)
     _close(dh2 - 1.0, hd.grad, atol=2e-5, msg="d_hinfo accumulate")
     _close(dq2 - 1.0, qd.grad, atol=2e-5, msg="d_hq accumulate")
-    _close(dW, 2 * Wd.grad.reshape(-1), atol=3e-5, msg="dW accumulates")
+    if Wd is not None:
+        _close(dW, 2 * Wd.grad.reshape(-1), atol=3e-5, msg="dW accumulates")
 
 
 def test_attention_backward_fully_masked_rows_direct_term():

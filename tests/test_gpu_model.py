@@ -77,10 +77,11 @@ def test_plumbing_config():
     _run(SynthSpec(dense=False, **CONFIGS["plumbing"]))
 
 
-def test_cosine_forward_only():
+def test_cosine_similarity_model():
+    """simiMatrix 4 (README.MD:87 ablation): no att_logits parameters, forward and backward."""
     from fvta_memexqa_amd.synth import SynthSpec
     spec = SynthSpec(N=2, A=1, P=3, S=2, L=4, d=32, dense=False, simiMatrix=4, add_tanh=False, text_in=12, img_in=8)
-    _run(spec, check_grads=False)
+    _run(spec)
 
 
 def test_trainer_tester_mirror_and_update():
