@@ -166,6 +166,7 @@ def main():
     prof = {name: collect(pid) for name, pid in [("lstm_step_fwd", 1), ("lstm_step_bwd", 2), ("lstm_dw", 3),
                                                  ("attn_fwd_main", 4), ("attn_bwd_main", 5)]}
     if rank != 0:
+        dist.shutdown()
         return
     total_qa = spec.N * ws * args.steps
     value = total_qa / elapsed
@@ -217,6 +218,7 @@ def main():
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
+    dist.shutdown()
 
 
 if __name__ == "__main__":

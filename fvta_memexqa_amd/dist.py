@@ -15,7 +15,7 @@ def world():
 def init(backend=None):
     """Join the process group described by RANK/WORLD_SIZE/MASTER_* (torch.distributed.run)."""
     ws, rank, local = world()
-    if ws == 1:
+    if ws == 1 and os.environ.get("FVTA_DIST_FORCE", "0") != "1":   # FVTA_DIST_FORCE=1: exercise the collective path with one rank
         return ws, rank, local
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -30,7 +30,7 @@ def init(backend=None):
 
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("FVTA_DIST_FORCE", "0") == "1")
 
 
 def shard_range(global_batch, ws, rank):
@@ -61,3 +61,8 @@ def max_over_ranks(value, device):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
