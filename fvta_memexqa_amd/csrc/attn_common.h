@@ -30,6 +30,8 @@ inline AttnShape attn_shape(const fvta_attn_desc* d, bool use_mask) {
   int ns = (3072 + nk - 1) / nk;
   const int maxs = (d->T + 63) / 64;
   if (ns > maxs) ns = maxs;
+  const int mins = (d->T + 1007) / 1008;  // the 16-row forward kernel keeps a split's row list (<= 1024) in LDS
+  if (ns < mins) ns = mins;
   if (ns < 1) ns = 1;
   s.nsplit = ns;
   int bs = (1024 + nk - 1) / nk;

@@ -166,23 +166,29 @@ struct AttnFwdArgs {
   float* part;      // [N*K][nsplit][w+4] : m, l, -, -, u[w]
 };
 
-// w = 16 * SCW * NSC * NSLAB.  A wave owns NSC sub-chunks of SCW float4 columns
-// per slab; lane = (c4l = lane % SCW, rg = lane / SCW) holds rows rg + RGN*p.
-template <int SCW, int NSC, int NSLAB, int JT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
+// w = 4 * SCW * NSC * NW * NSLAB.  A workgroup is NW waves; a wave owns NSC
+// sub-chunks of SCW float4 columns per slab; lane = (c4l = lane % SCW,
+// rg = lane / SCW) holds rows rg + RGN*p.  The 32 x (w / NSLAB) row slab lives in
+// registers (NSC * P float4 per lane) between the score pass and the weighted
+// sum, so NSC * P is kept <= 16: wide rows use 8 waves, not more sub-chunks.
+template <int SCW, int NSC, int NSLAB, int JT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_main(AttnFwdArgs a) {
+  constexpr int NT = NW * 64;
   constexpr int RGN = 64 / SCW;
   constexpr int P = 32 / RGN;
   constexpr int LDW = 4 * SCW + 4;
-  constexpr int SLAB4 = 4 * NSC * SCW;
-  __shared__ __attribute__((aligned(16))) float s_stage[4][32 * LDW];
+  constexpr int SLAB4 = NW * NSC * SCW;
+  static_assert(NSC * P <= 16, "row slab must fit the register file without scratch");
+  constexpr bool COUNTED = !(NW == 8 && JT == 2);
+  __shared__ __attribute__((aligned(16))) float s_stage[NW][32 * LDW];
   // per wave: the pre-scaled question fragments of the current sub-chunk, DMA'd from L2 ([s4][jt][lane][4],
   // the exact order the MFMA B operands are read in); the same space later carries the wave's partial scores
   constexpr int BQ = ((SCW / 2) * JT * 256 > JT * 1024) ? (SCW / 2) * JT * 256 : JT * 1024;
-  __shared__ __attribute__((aligned(16))) float s_bq[4][BQ];
+  __shared__ __attribute__((aligned(16))) float s_bq[NW][BQ];
   // row-term vectors Rh, R2 of the bilinear form: LDS copies, so that no ordinary global load sits between
   // the fragment DMAs and their counted waits (vmcnt retires in order)
-  __shared__ __attribute__((aligned(16))) float s_vec[2][16 * SCW * NSC * NSLAB];
-  __shared__ float s_rt[4][32];
+  __shared__ __attribute__((aligned(16))) float s_vec[2][4 * SLAB4 * NSLAB];
+  __shared__ float s_rt[NW][32];
   __shared__ int s_t[32];
   __shared__ float s_amax[32];
   __shared__ float s_p[32];
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
 #pragma unroll
     for (int s4 = 0; s4 < SCW / 2; ++s4) issue_b1(c4base, s4);
   };
-  for (int c = tid; c < w; c += 256) {
+  for (int c = tid; c < w; c += NT) {
     s_vec[0][c] = vRh[c];
     s_vec[1][c] = vR2[c];
   }
@@ -310,7 +316,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
           for (int s4 = 0; s4 < SCW / 2; ++s4) {
             // younger than group s4's blocks: the rest of this sub-chunk's (7 - s4 groups) plus, when refilling,
             // the s4 groups already re-requested for the next sub-chunk
-            if (sc != 0) wait_vmcnt_upto((has_next ? SCW / 2 - 1 : SCW / 2 - 1 - s4) * JT);
+            // (the counted form assumes the DMAs are the only VMEM traffic of the chain, i.e. a kernel
+            // without scratch; the one shape at the 256-VGPR limit drains everything at group 0 instead)
+            if (sc != 0) {
+              if (COUNTED) wait_vmcnt_upto((has_next ? SCW / 2 - 1 : SCW / 2 - 1 - s4) * JT);
+              else if (s4 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             const f32x4 av = *reinterpret_cast<const f32x4*>(&stage[l31 * LDW + 8 * s4 + 4 * hf]);
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
@@ -319,9 +330,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
               for (int e = 0; e < 4; ++e)
                 acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc[jt], 0, 0, 0);
             }
-            // group s4's fragments are in registers (the MFMAs above consumed them): refill its blocks with
-            // the next sub-chunk's, so the copy runs under the rest of this chain
-            asm volatile("" ::: "memory");
+            // refill group s4's blocks with the next sub-chunk's, so the copy runs under the rest of this
+            // chain.  The explicit lgkmcnt(0) is load-bearing: the MFMAs above only need the fragments at
+            // execution, so without it the compiler issues the DMA right behind the ds_reads, and under LDS
+            // queueing the DMA write can overtake them (write-after-read on the block).
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (has_next) issue_b1(next_base, s4);
           }
           __builtin_amdgcn_wave_barrier();
@@ -341,10 +354,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
         if (c4l == 0) s_rt[wave][rg + RGN * p] = v;
       }
       __syncthreads();
-      {
+      if (tid < 256) {
         const int row = tid >> 3, jg = tid & 7;
         const int t = s_t[row];
-        const float rt = (s_rt[0][row] + s_rt[1][row]) + (s_rt[2][row] + s_rt[3][row]);
+        float rt = (s_rt[0][row] + s_rt[1][row]) + (s_rt[2][row] + s_rt[3][row]);
+        if (NW == 8) rt += (s_rt[4][row] + s_rt[5][row]) + (s_rt[6][row] + s_rt[7][row]);
         const float rs = cosine ? rsqrtf(fmaxf(rt, 1e-12f)) : 1.f;
         const int preg = (row & 3) + 4 * (row >> 3), phf = (row >> 2) & 1;
         float best = -INFINITY;
@@ -357,6 +371,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
             const int pi = preg * 64 + phf * 32 + jl;
             const int pj = jt * 1024 + pi;
             float x = (s_bq[0][pj] + s_bq[1][pj]) + (s_bq[2][pj] + s_bq[3][pj]);
+            if (NW == 8) x += (s_bq[4][pj] + s_bq[5][pj]) + (s_bq[6][pj] + s_bq[7][pj]);
             x = cosine ? x * rs : x + rt + ct[j];
             const bool valid = (qvalid >> j) & 1ull;
             if (a.a_logits && t >= 0 && j < s.JQ)
@@ -444,6 +459,222 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_main(AttnFwdArgs a) {
   }
 }
 
+// ---- main kernel, 16-row tiles (JQ <= 32, w <= 1024) -------------------------
+// The shape the metric runs.  Differences from the kernel above, all aimed at keeping HBM busy:
+//  * the pre-scaled question slice of a wave (w/NW channels x 32 j) is loop-invariant per workgroup, so it
+//    lives in registers (2*NB float4) as the B operand of v_mfma_f32_16x16x4_f32 -- no per-tile question traffic;
+//  * context rows never pass through VGPRs on the way in: each wave DMAs its channel slice of the next 16-row
+//    tile global -> LDS (buffer_load ... lds) in exactly the lane order of the MFMA A operand, double buffered,
+//    one tile ahead, and waits for it with a counted vmcnt.  The LDS read-back (NB float4 per lane) is kept in
+//    registers and doubles as the operand of the weighted sum, so a row is read from HBM once and LDS once;
+//  * a wave only ever touches the LDS bytes it DMA'd itself, so the tile buffers need no barrier; the two
+//    barriers per tile are the cross-wave reduction of the partial scores.
+template <int NB, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(AttnFwdArgs a) {
+  constexpr int NT = NW * 64;
+  constexpr int CAP = 1024;          // rows of one split (LDS index list)
+  constexpr int WAVE_F = NB * 256;   // floats per wave per tile buffer: NB blocks of [64 lanes][4]
+  constexpr int TPRW = NT / 16;      // post-processing threads per row
+  constexpr int JPT = 32 / TPRW;     // j columns per post-processing thread
+  __shared__ __attribute__((aligned(16))) float s_tile[2][NW * WAVE_F];
+  __shared__ __attribute__((aligned(16))) float s_part[NW][512];  // [jt][r][lane] partial scores
+  __shared__ __attribute__((aligned(16))) float s_vec[2][NW * NB * 16];
+  __shared__ int s_idx[CAP];
+  __shared__ float s_rt[NW][16];
+  __shared__ float s_ct[32];
+  __shared__ float s_amax[16];
+
+  const AttnShape& s = a.s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int nitems = s.N * s.K * s.nsplit;
+  const int bid = blockIdx.x;
+  const int per = (nitems + 7) / 8;
+  const int item = (bid & 7) * per + (bid >> 3);  // XCD-contiguous items, see attn_fwd_main
+  if (item >= nitems || (bid >> 3) >= per) return;
+  const int nk = item / s.nsplit, n = nk / s.K, split = item % s.nsplit;
+  const int T = s.T, w = s.w, JP = s.JP;
+  const int cnt = a.sv.cnt[nk];
+  const bool allm = a.sv.allmasked[nk] != 0;
+  const int tiles_total = (cnt + 15) >> 4;
+  const int tiles_per = (tiles_total + s.nsplit - 1) / s.nsplit;
+  const int tile0 = split * tiles_per, tile1 = min(tiles_total, tile0 + tiles_per);
+  float* part = a.part + ((size_t)nk * s.nsplit + split) * (w + 4);
+  if (tile0 >= tile1) {
+    if (tid == 0) {
+      part[0] = -INFINITY;
+      part[1] = 0.f;
+    }
+    return;
+  }
+  const float* __restrict__ hbase = a.hinfo + (size_t)nk * T * w;
+  const int32_t* __restrict__ idx = a.sv.idx + (size_t)nk * T;
+  const float* __restrict__ Qs = a.sv.Qs + (size_t)n * s.W4 * JP * 4;
+  const uint64_t qvalid = a.sv.qvalid[(size_t)n * 2];
+  const bool cosine = s.simi == 4;
+
+  for (int r = tid; r < (tile1 - tile0) * 16; r += NT) {
+    const int gr = tile0 * 16 + r;
+    s_idx[r] = gr < cnt ? idx[gr] : -1;
+  }
+  for (int c = tid; c < w; c += NT) {
+    s_vec[0][c] = a.sv.vecs[VEC_RH * w + c];
+    s_vec[1][c] = a.sv.vecs[VEC_R2 * w + c];
+  }
+  if (tid < 32) s_ct[tid] = a.sv.ct[(size_t)n * JP + tid];
+  // B operand of block i, j tile jt, k step e: Qs[channel 16*(NB*wave+i) + 4*kq + e][16*jt + l15]
+  f32x4 breg[NB][2];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+      breg[i][jt] = ld4g(Qs + ((size_t)(4 * (NB * wave + i) + kq) * JP + 16 * jt + l15) * 4);
+  f32x4 frag[NB], uacc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) uacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const __amdgpu_buffer_rsrc_t rh =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hbase), 0, (unsigned)((size_t)T * w * 4), 0x00020000);
+  __syncthreads();  // s_idx / s_vec / s_ct visible; also drains the loads above before the counted waits start
+
+  // lane (row l15, k quarter kq) fetches 4 consecutive channels of its row per block: the 1 KB a DMA
+  // instruction lands in LDS is [lane][4], the A operand order of four consecutive k steps
+  auto issue = [&](int tile, int buf) {
+    const int t = s_idx[(tile - tile0) * 16 + l15];
+    const unsigned voff = (unsigned)max(t, 0) * (unsigned)(w * 4) + (unsigned)((16 * NB * wave + 4 * kq) * 4);
+    float* dst = &s_tile[buf][wave * WAVE_F];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (__attribute__((address_space(3))) void*)(dst + i * 256), 16,
+                                               voff + i * 64, 0, 0, 0);
+  };
+
+  issue(tile0, 0);
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int buf = (tile - tile0) & 1;
+    const bool more = tile + 1 < tile1;
+    // the other buffer was last read (by this wave only) two tiles ago; make that explicit before overwriting
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (more) {
+      issue(tile + 1, buf ^ 1);
+      wait_vmcnt_upto(NB);  // in-order retirement: everything but the NB copies just issued has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const float* tb = &s_tile[buf][wave * WAVE_F];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) frag[i] = *reinterpret_cast<const f32x4*>(tb + i * 256 + lane * 4);
+    if (!allm) {
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      float rtp = 0.f;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int c0 = 16 * (NB * wave + i) + 4 * kq;
+        const f32x4 rh4 = *reinterpret_cast<const f32x4*>(&s_vec[0][c0]);
+        const f32x4 r24 = *reinterpret_cast<const f32x4*>(&s_vec[1][c0]);
+        const f32x4 h = frag[i];
+        const f32x4 tmp = h * (rh4 + r24 * h);
+        rtp += (tmp[0] + tmp[1]) + (tmp[2] + tmp[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[e], breg[i][0][e], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[e], breg[i][1][e], acc[1], 0, 0, 0);
+        }
+      }
+      // D layout of 16x16x4: lane -> column j = l15, rows 4*kq + r
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_part[wave][(jt * 4 + r) * 64 + lane] = acc[jt][r];
+      rtp += __shfl_xor(rtp, 16, 64);
+      rtp += __shfl_xor(rtp, 32, 64);
+      if (lane < 16) s_rt[wave][lane] = rtp;
+      __syncthreads();
+      {
+        const int row = tid / TPRW, jl = tid % TPRW;
+        const int t = s_idx[(tile - tile0) * 16 + row];
+        float rt = 0.f;
+#pragma unroll
+        for (int v = 0; v < NW; ++v) rt += s_rt[v][row];
+        const float rs = cosine ? rsqrtf(fmaxf(rt, 1e-12f)) : 1.f;
+        float best = -INFINITY;
+        int bestj = 0;
+#pragma unroll
+        for (int q = 0; q < JPT; ++q) {
+          const int j = jl + q * TPRW;
+          const int pi = ((j >> 4) * 4 + (row & 3)) * 64 + (j & 15) + 16 * (row >> 2);
+          float x = 0.f;
+#pragma unroll
+          for (int v = 0; v < NW; ++v) x += s_part[v][pi];
+          x = cosine ? x * rs : x + rt + s_ct[j];
+          const bool valid = (qvalid >> j) & 1ull;
+          if (a.a_logits && t >= 0 && j < s.JQ)
+            a.a_logits[((size_t)nk * T + t) * s.JQ + j] = valid ? (s.add_tanh ? tanhf(x) : x) : FVTA_NEG;
+          if (valid && x > best) {
+            best = x;
+            bestj = j;
+          }
+        }
+#pragma unroll
+        for (int o = 1; o < TPRW; o <<= 1) {
+          const float ob = __shfl_xor(best, o, 64);
+          const int oj = __shfl_xor(bestj, o, 64);
+          if (ob > best || (ob == best && oj < bestj)) {
+            best = ob;
+            bestj = oj;
+          }
+        }
+        if (jl == 0) {
+          if (t >= 0) {
+            const float av = s.add_tanh ? tanhf(best) : best;
+            s_amax[row] = av;
+            a.sv.amax[(size_t)nk * T + t] = av;
+            a.sv.jmax[(size_t)nk * T + t] = (uint8_t)bestj;
+          } else {
+            s_amax[row] = -INFINITY;
+          }
+        }
+      }
+    } else {
+      __syncthreads();  // the previous tile's readers of s_amax are done
+      if (tid < 16) s_amax[tid] = s_idx[(tile - tile0) * 16 + tid] >= 0 ? FVTA_NEG : -INFINITY;
+    }
+    __syncthreads();
+    // online softmax over t (softsel inner, model_v2.py:278); lane l holds row l15 of the tile
+    const float am = s_amax[l15];
+    float mt = am;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) mt = fmaxf(mt, __shfl_xor(mt, o, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float scale = expf(m_run - m_new);
+    const float pr = expf(am - m_new);
+    float lsum = pr;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) lsum += __shfl_xor(lsum, o, 64);
+    l_run = l_run * scale + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) uacc[i] = uacc[i] * scale + frag[i] * pr;
+  }
+  // fold the 16 row lanes, store the partial (m, l, u)
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    f32x4 u = uacc[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = u[e];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+      u[e] = v;
+    }
+    if (l15 == 0) *reinterpret_cast<f32x4*>(part + 4 + 16 * (NB * wave + i) + 4 * kq) = u;
+  }
+  if (tid == 0) {
+    part[0] = m_run;
+    part[1] = l_run;
+  }
+}
+
 // ---- merge: splits -> u[n,k], M, L; softmax over K; h_a.  grid N, 256 threads
 __global__ __launch_bounds__(256) void attn_merge_kernel(AttnShape s, AttnSaved sv, const float* __restrict__ part,
                                                          float* __restrict__ h_a) {
@@ -496,14 +727,15 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnShape s, AttnSaved 
   }
 }
 
-template <int SCW, int NSC, int NSLAB>
+// JT = 1 (JQ <= 32) and JT = 2 shapes; the JT = 2 shape of a wide row halves SCW to keep LDS under 160 KB
+template <int SCW1, int NSC1, int SCW2, int NSC2, int NSLAB, int NW>
 static int launch_main(const AttnFwdArgs& a, hipStream_t stream) {
   const int nitems = a.s.nsplit * a.s.N * a.s.K;
   const dim3 grid(((nitems + 7) / 8) * 8);
   if (a.s.JT == 1)
-    hipLaunchKernelGGL((attn_fwd_main<SCW, NSC, NSLAB, 1>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((attn_fwd_main<SCW1, NSC1, NSLAB, 1, NW>), grid, dim3(NW * 64), 0, stream, a);
   else
-    hipLaunchKernelGGL((attn_fwd_main<SCW, NSC, NSLAB, 2>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((attn_fwd_main<SCW2, NSC2, NSLAB, 2, NW>), grid, dim3(NW * 64), 0, stream, a);
   return 0;
 }
 
@@ -564,13 +796,25 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
   a.a_logits = a_logits;
   a.part = (float*)workspace;
   fvta_prof_begin(FVTA_PROF_ATTN_FWD_MAIN, stream);
+  const bool rows16 = s.JT == 1 && s.w <= 1024;
+  if (rows16) {
+    const int nitems = s.nsplit * s.N * s.K;
+    const dim3 grid(((nitems + 7) / 8) * 8);
+    switch (s.w) {
+      case 64: hipLaunchKernelGGL((attn_fwd_rows16<1, 4>), grid, dim3(256), 0, stream, a); break;
+      case 128: hipLaunchKernelGGL((attn_fwd_rows16<2, 4>), grid, dim3(256), 0, stream, a); break;
+      case 256: hipLaunchKernelGGL((attn_fwd_rows16<4, 4>), grid, dim3(256), 0, stream, a); break;
+      case 512: hipLaunchKernelGGL((attn_fwd_rows16<8, 4>), grid, dim3(256), 0, stream, a); break;
+      case 1024: hipLaunchKernelGGL((attn_fwd_rows16<8, 8>), grid, dim3(512), 0, stream, a); break;
+    }
+  } else
   switch (s.w) {
-    case 64: launch_main<4, 1, 1>(a, stream); break;
-    case 128: launch_main<8, 1, 1>(a, stream); break;
-    case 256: launch_main<16, 1, 1>(a, stream); break;
-    case 512: launch_main<16, 2, 1>(a, stream); break;
-    case 1024: launch_main<16, 4, 1>(a, stream); break;
-    case 2048: launch_main<16, 4, 2>(a, stream); break;
+    case 64: launch_main<4, 1, 4, 1, 1, 4>(a, stream); break;
+    case 128: launch_main<8, 1, 8, 1, 1, 4>(a, stream); break;
+    case 256: launch_main<16, 1, 16, 1, 1, 4>(a, stream); break;
+    case 512: launch_main<16, 2, 16, 2, 1, 4>(a, stream); break;
+    case 1024: launch_main<16, 2, 8, 4, 1, 8>(a, stream); break;
+    case 2048: launch_main<16, 2, 8, 4, 2, 8>(a, stream); break;
   }
   fvta_prof_end(FVTA_PROF_ATTN_FWD_MAIN, 1, stream);
   FVTA_CHECK_LAUNCH("attn_fwd_main");

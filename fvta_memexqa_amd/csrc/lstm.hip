@@ -564,6 +564,30 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
   const dim3 sgrid((B + MmaSq::BM - 1) / MmaSq::BM, (in + dd + MmaSq::BN - 1) / MmaSq::BN, 2);
   const size_t sh = MmaSq::LDS_FLOATS * sizeof(float);
   fvta_prof_begin(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, stream);
+  if (bf && !(dbg & 2048)) {
+    // bf16 engine: ONE launch per step -- dh_{t} = dz_{t+1} * wb_h^T in the k-loop, the gate gradient
+    // (dz_t, dc) as its epilogue -- and a single batched dx = dz * wb_x^T over all steps afterwards
+    FusedBwdArgs f;
+    f.plan = pv;
+    f.Wb[0] = wv.wb[0];
+    f.Wb[1] = d->share_fw_bw ? wv.wb[0] : wv.wb[1];
+    f.gatesb = sv.gatesb;
+    f.cs = sv.cs;
+    f.d_out = d_out;
+    f.dzb = wv.dzb;
+    f.dc = wv.cstate;
+    f.dx = dx;
+    f.B = B;
+    f.J = J;
+    f.in = in;
+    f.d = dd;
+    f.in_i = in_internal(d);
+    for (int t = J - 1; t >= 0; --t) {
+      f.t = t;
+      launch_bwd_fused_bf16(f, stream);
+    }
+    if (dx) launch_dx_bf16(f, stream);
+  } else
   for (int t = J - 1; t >= 0; --t) {
     g.t = t;
     s.t = t;

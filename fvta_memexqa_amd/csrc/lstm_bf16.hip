@@ -185,6 +185,135 @@ void launch_step_bwd_bf16(const StepBwdArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(lstm_step_bwd_bf16, grid, dim3(256), TileCfg::LDS_BYTES, s, a);
 }
 
+// ------------------------------------------------- fused backward step (bf16) --
+// Step t of the backward recurrence in ONE launch: the k-loop computes dh_t(rec) = dz_{t+1} * wb_h^T for a
+// 256-row x 128-unit tile (rows beyond step t+1's active prefix fall off the descriptor and read as 0),
+// the epilogue adds the upstream d_out, runs the gate gradient and writes dz_t (packed, unit-major) and
+// the running dc.  No dh round trip through HBM, no separate elementwise launch.
+// grid (pad8(ceil(B/256)), d/128 (ceil), 2)
+__global__ __launch_bounds__(256, 2) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
+  int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + TileCfg::STAGES * TileCfg::STAGE_ELEMS);
+  const int tid = threadIdx.x, dir = blockIdx.z;
+  const int m0 = blockIdx.x * TileCfg::BM, u0 = blockIdx.y * TileCfg::BN;
+  const int t = a.t, d = a.d, K = 4 * d;
+  const int nact = a.plan.nactive[t];
+  if (m0 >= nact) return;
+  const int nnext = (t + 1 < a.J) ? a.plan.nactive[t + 1] : 0;
+  const size_t trow = ((size_t)dir * a.J + t) * a.B;
+  s_oo[tid] = a.plan.oo[trow + min(m0 + tid, nact - 1)];  // clamped: always a valid row
+  MmaB mma;
+  mma.init(tid);
+  if (m0 < nnext) {
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + (trow + a.B) * (size_t)K, (unsigned)nnext * K * 2);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir] + (size_t)a.in_i * K, (unsigned)d * K * 2);  // the h rows of wb
+    RowSrc<TileCfg::A_GLDS> az;
+    RowSrc<TileCfg::B_GLDS> bw;
+    az.setup(mma.wave, mma.lane, m0, nnext, K * 2);
+    bw.setup(mma.wave, mma.lane, u0, d, K * 2);
+    auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
+      az.issue(rz, As, mma.wave, tile * 64);
+      bw.issue(rw, Bs, mma.wave, tile * 64);
+    };
+    glds_mainloop<false>(mma, issue, K / 32, smem_h);
+  }
+  __syncthreads();
+  const float* __restrict__ cs_t = a.cs + trow * d;
+  const float* __restrict__ cs_p = a.cs + (trow - a.B) * d;  // step t-1 (unused at t == 0)
+  float* __restrict__ dcs = a.dc + (size_t)dir * a.B * d;
+#pragma unroll
+  for (int ti = 0; ti < MmaB::TM; ++ti)
+#pragma unroll 2
+    for (int r = 0; r < 16; ++r) {
+      const int row = mma.row_of(ti, r);
+      const int i = m0 + row, ic = min(i, nact - 1);
+      const int64_t oo = s_oo[min(row, nact - 1 - m0)];
+      // unconditional loads of the four column tiles of this row, then math, then guarded stores
+      bf16x4 gp[MmaB::TN];
+      float c[MmaB::TN], cp[MmaB::TN], dcv[MmaB::TN], dout[MmaB::TN];
+#pragma unroll
+      for (int tj = 0; tj < MmaB::TN; ++tj) {
+        const int u = min(u0 + mma.col_of(tj), d - 1);
+        gp[tj] = *reinterpret_cast<const bf16x4*>(a.gatesb + (trow + ic) * (size_t)K + 4 * u);
+        c[tj] = cs_t[(size_t)ic * d + u];
+        cp[tj] = t > 0 ? cs_p[(size_t)ic * d + u] : 0.f;
+        dcv[tj] = dcs[(size_t)ic * d + u];
+        dout[tj] = a.d_out[oo + u];
+      }
+#pragma unroll
+      for (int tj = 0; tj < MmaB::TN; ++tj) {
+        const int u = u0 + mma.col_of(tj);
+        const float ig = bf2f((bf16_t)gp[tj][0]), jg = bf2f((bf16_t)gp[tj][1]), fg = bf2f((bf16_t)gp[tj][2]),
+                    og = bf2f((bf16_t)gp[tj][3]);
+        const float dh = dout[tj] + mma.acc[ti][tj][r];
+        const float tc = fvta_tanh(c[tj]);
+        const float dc = dcv[tj] + dh * og * (1.f - tc * tc);
+        bf16x4 pk;
+        pk[0] = (short)f2bf(dc * jg * ig * (1.f - ig));
+        pk[1] = (short)f2bf(dc * ig * (1.f - jg * jg));
+        pk[2] = (short)f2bf(dc * cp[tj] * fg * (1.f - fg));
+        pk[3] = (short)f2bf(dh * tc * og * (1.f - og));
+        if (i < nact && u < d) {
+          *reinterpret_cast<bf16x4*>(a.dzb + (trow + i) * (size_t)K + 4 * u) = pk;
+          dcs[(size_t)i * d + u] = dc * fg;
+        }
+      }
+    }
+}
+
+void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
+  allow_big_lds(lstm_bwd_fused_bf16, FWD_LDS);
+  const dim3 grid(pad8((a.B + TileCfg::BM - 1) / TileCfg::BM), (a.d + TileCfg::BN - 1) / TileCfg::BN, 2);
+  hipLaunchKernelGGL(lstm_bwd_fused_bf16, grid, dim3(256), FWD_LDS, s, a);
+}
+
+// dx = dz * wb_x^T for every (direction, step) at once.  grid (pad8(ceil(B/256)), ceil(in/128), 2*J)
+__global__ __launch_bounds__(256, 2) void lstm_dx_bf16(FusedBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
+  const int tid = threadIdx.x;
+  const int t = blockIdx.z % a.J, dir = blockIdx.z / a.J;
+  const int m0 = blockIdx.x * TileCfg::BM, n0 = blockIdx.y * TileCfg::BN;
+  const int nact = a.plan.nactive[t];
+  if (m0 >= nact) return;
+  const int d = a.d, K = 4 * d, in = a.in;
+  const size_t trow = ((size_t)dir * a.J + t) * a.B;
+  MmaB mma;
+  mma.init(tid);
+  const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + trow * (size_t)K, (unsigned)nact * K * 2);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir], (unsigned)in * K * 2);  // the x rows of wb
+  RowSrc<TileCfg::A_GLDS> az;
+  RowSrc<TileCfg::B_GLDS> bw;
+  az.setup(mma.wave, mma.lane, m0, nact, K * 2);
+  bw.setup(mma.wave, mma.lane, n0, in, K * 2);
+  auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
+    az.issue(rz, As, mma.wave, tile * 64);
+    bw.issue(rw, Bs, mma.wave, tile * 64);
+  };
+  glds_mainloop<false>(mma, issue, K / 32, smem_h);
+#pragma unroll
+  for (int ti = 0; ti < MmaB::TM; ++ti) {
+    int64_t xos[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xos[r] = a.plan.xo[trow + min(m0 + mma.row_of(ti, r), nact - 1)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = m0 + mma.row_of(ti, r);
+      if (i >= nact) continue;
+#pragma unroll
+      for (int tj = 0; tj < MmaB::TN; ++tj) {
+        const int n = n0 + mma.col_of(tj);
+        if (n < in) atomicAdd(a.dx + xos[r] + n, mma.acc[ti][tj][r]);  // fw and bw meet at a position: two addends
+      }
+    }
+  }
+}
+
+void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
+  allow_big_lds(lstm_dx_bf16, TileCfg::LDS_BYTES);
+  const dim3 grid(pad8((a.B + TileCfg::BM - 1) / TileCfg::BM), (a.in + TileCfg::BN - 1) / TileCfg::BN, 2 * a.J);
+  hipLaunchKernelGGL(lstm_dx_bf16, grid, dim3(256), TileCfg::LDS_BYTES, s, a);
+}
+
 // -------------------------------------------------------- weight gradient --
 // slab(dir, split) [in_i+d][4d] = sum over the split's steps of [xs_t | hs_{t-1}]^T * dz_t.  Both operands
 // are k-major in memory: staged as they lie, read through the transposing LDS read.

@@ -237,6 +237,19 @@ void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int in, int
 void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, int J, int in, int in_i, hipStream_t s);
 void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s);
 void launch_step_bwd_bf16(const StepBwdArgs& a, hipStream_t s);
+struct FusedBwdArgs {
+  PlanView plan;
+  const bf16_t* Wb[2];
+  const bf16_t* gatesb;
+  const float* cs;
+  const float* d_out;
+  bf16_t* dzb;
+  float* dc;  // [2][B][d]
+  float* dx;  // lstm_dx only
+  int t, B, J, in, d, in_i;
+};
+void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s);
+void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s);
 void launch_dw_bf16(const DwArgs& a, hipStream_t s);
 void launch_dw_reduce_bf16(const float* slabs, int nslab, int in, int in_i, int d, float* dW, float* dbias, hipStream_t s);
 int test_gemm_bf16(int layout, int M, int N, int K, const float* A, const float* B, float* C, hipStream_t s);
