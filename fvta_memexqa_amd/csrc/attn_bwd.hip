@@ -114,7 +114,8 @@ struct AttnBwdArgs {
 
 // TPR threads cover one row (16 B each, G float4 per thread when w > 1024);
 // RH = 256/TPR row groups; a tile is TR rows, each thread holds TR/RH of them.
-template <int TPR, int G, int TR>
+// COS: cosine similarity (simi 4) -- a compile-time flag so that the bilinear shapes do not carry its registers.
+template <int TPR, int G, int TR, bool COS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   constexpr int RH = 256 / TPR;
   constexpr int RPT = TR / RH;
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   float* __restrict__ dhbase = a.d_hinfo + (size_t)nk * T * w;
   const float* __restrict__ Qs = a.sv.Qs + (size_t)n * s.W4 * JP * 4;
   const float M = a.sv.M[nk];
-  const bool cosine = s.simi == 4;
+  constexpr bool cosine = COS;
   const float coef = a.wk.coef[nk], gu = a.wk.gu[nk], dss = a.wk.dss[nk];
   const size_t slot = ((size_t)nk * s.bsplit + split) * RH + rh;
   float* __restrict__ slab = a.wk.slabs + slot * JP * w;
@@ -278,14 +279,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
           s_dot[wave][rh * RPT + i] = dot[i];
-          s_nrm[wave][rh * RPT + i] = nrm[i];
+          if (cosine) s_nrm[wave][rh * RPT + i] = nrm[i];
         }
     } else {
       if (cq == 0)
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
           s_dot[0][rh * RPT + i] = dot[i];
-          s_nrm[0][rh * RPT + i] = nrm[i];
+          if (cosine) s_nrm[0][rh * RPT + i] = nrm[i];
         }
     }
     __syncthreads();
@@ -301,11 +302,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
 #pragma unroll
           for (int v = 0; v < WPR; ++v) {
             gh += s_dot[rgp * WPR + v][tid];
-            hh += s_nrm[rgp * WPR + v][tid];
+            if (cosine) hh += s_nrm[rgp * WPR + v][tid];
           }
         } else {
           gh = s_dot[0][tid];
-          hh = s_nrm[0][tid];
+          if (cosine) hh = s_nrm[0][tid];
         }
         const float am = amax[t];
         pr = expf(am - M) * coef;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
       }
       s_pr[tid] = pr;
       s_dx[tid] = dx;
-      s_self[tid] = self;
+      if (cosine) s_self[tid] = self;
     }
     __syncthreads();
 #pragma unroll
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
       const int t = s_tt[row];
       if (t < 0) continue;
       const int j = s_jj[row];
-      const float pr = s_pr[row], dx = s_dx[row], self = s_self[row];
+      const float pr = s_pr[row], dx = s_dx[row], self = cosine ? s_self[row] : 0.f;
       if (j != cur_j) {
         flush();
         cur_j = j;
@@ -346,8 +347,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
         if (a.accumulate == 1) dh += ld4b(dst);
         *reinterpret_cast<f32x4*>(dst) = dh;
         accq[g] += h * dx;
-        accRh[g] += h * dx;
-        accR2[g] += h * h * dx;
+        if (!cosine) {
+          accRh[g] += h * dx;
+          accR2[g] += h * h * dx;
+        }
       }
     }
   }
@@ -510,12 +513,21 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
   const dim3 grid(s.bsplit, s.N * s.K);
   fvta_prof_begin(FVTA_PROF_ATTN_BWD_MAIN, stream);
   switch (s.w) {
-    case 64: hipLaunchKernelGGL((attn_bwd_main<16, 1, 32>), grid, dim3(256), 0, stream, a); break;
-    case 128: hipLaunchKernelGGL((attn_bwd_main<32, 1, 32>), grid, dim3(256), 0, stream, a); break;
-    case 256: hipLaunchKernelGGL((attn_bwd_main<64, 1, 32>), grid, dim3(256), 0, stream, a); break;
-    case 512: hipLaunchKernelGGL((attn_bwd_main<128, 1, 32>), grid, dim3(256), 0, stream, a); break;
-    case 1024: hipLaunchKernelGGL((attn_bwd_main<256, 1, 32>), grid, dim3(256), 0, stream, a); break;
-    case 2048: hipLaunchKernelGGL((attn_bwd_main<256, 2, 16>), grid, dim3(256), 0, stream, a); break;
+#define FVTA_BWD_LAUNCH(TPR, G, TR)                                                                      \
+  do {                                                                                                   \
+    if (s.simi == 4) hipLaunchKernelGGL((attn_bwd_main<TPR, G, TR, true>), grid, dim3(256), 0, stream, a); \
+    else hipLaunchKernelGGL((attn_bwd_main<TPR, G, TR, false>), grid, dim3(256), 0, stream, a);           \
+  } while (0)
+    case 64: FVTA_BWD_LAUNCH(16, 1, 32); break;
+    case 128: FVTA_BWD_LAUNCH(32, 1, 32); break;
+    case 256: FVTA_BWD_LAUNCH(64, 1, 32); break;
+    case 512: FVTA_BWD_LAUNCH(128, 1, 32); break;
+    case 1024:  // (the cosine variant of the 32-row tile would spill: 16 rows)
+      if (s.simi == 4) hipLaunchKernelGGL((attn_bwd_main<256, 1, 16, true>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((attn_bwd_main<256, 1, 32, false>), grid, dim3(256), 0, stream, a);
+      break;
+    case 2048: FVTA_BWD_LAUNCH(256, 2, 16); break;
+#undef FVTA_BWD_LAUNCH
   }
   fvta_prof_end(FVTA_PROF_ATTN_BWD_MAIN, 1, stream);
   FVTA_CHECK_LAUNCH("attn_bwd_main");

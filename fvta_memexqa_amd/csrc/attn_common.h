@@ -59,6 +59,7 @@ struct AttnSaved {
   float* r;        // [N,K] softmax_k(M)
   float* u;        // [N,K,w] inner softsel result
   float* Qs;       // [N][W4][JP][4] pre-scaled question, MFMA-B friendly
+  uint16_t* Qh;    // [N][2][W4][JP][4] fp16 split of Qs: hi = rtz(Qs), lo = rtz((Qs - hi) * 2^11)  (16-row forward kernel)
   float* ct;       // [N][JP]
   float* vecs;     // [5][w]
   uint64_t* qvalid;  // [N][JT<=2 -> 2] valid-j bit masks
@@ -79,6 +80,7 @@ inline AttnSaved attn_saved_view(const AttnShape& s, void* p) {
   v.r = c.take<float>(nk);
   v.u = c.take<float>(nk * s.w);
   v.Qs = c.take<float>((size_t)s.N * s.W4 * s.JP * 4);
+  v.Qh = c.take<uint16_t>((size_t)s.N * 2 * s.W4 * s.JP * 4);
   v.ct = c.take<float>((size_t)s.N * s.JP);
   v.vecs = c.take<float>((size_t)VEC_COUNT * s.w);
   v.qvalid = c.take<uint64_t>((size_t)s.N * 2);

@@ -14,6 +14,31 @@
 namespace fvta {
 
 __device__ __forceinline__ f32x4 ld4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+// x[0..7] = (a0, a1) -> hi, lo fp16 pieces (see above); register pairs are concatenated, never re-packed
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_f16x2(float x0, float x1, half2v& hi, half2v& lo) {
+  hi = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+  const f32x2 x = {x0, x1}, hf = {(float)hi[0], (float)hi[1]};
+  const f32x2 r = (x - hf) * 2048.f;  // packed fp32 ops: one v_pk_add + one v_pk_mul per pair
+  lo = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(r[0], r[1]));
+}
+__device__ __forceinline__ half8 cat_h2(half2v a, half2v b, half2v c, half2v d) {
+  const half4v ab = __builtin_shufflevector(a, b, 0, 1, 2, 3), cd = __builtin_shufflevector(c, d, 0, 1, 2, 3);
+  return __builtin_shufflevector(ab, cd, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void split_f16x8(const f32x4 a0, const f32x4 a1, half8& hi, half8& lo) {
+  half2v h[4], l[4];
+  split_f16x2(a0[0], a0[1], h[0], l[0]);
+  split_f16x2(a0[2], a0[3], h[1], l[1]);
+  split_f16x2(a1[0], a1[1], h[2], l[2]);
+  split_f16x2(a1[2], a1[3], h[3], l[3]);
+  hi = cat_h2(h[0], h[1], h[2], h[3]);
+  lo = cat_h2(l[0], l[1], l[2], l[3]);
+}
+
 
 // s_waitcnt vmcnt(n) for a loop-unrolled n (the switch folds after unrolling)
 __device__ __forceinline__ void wait_vmcnt_upto(int n) {
@@ -108,6 +133,13 @@ __global__ __launch_bounds__(256) void attn_prep_q_kernel(AttnShape s, AttnSaved
       }
     }
     *reinterpret_cast<f32x4*>(Qs + (size_t)u * 4) = o;
+    // fp16 split of the same values for the 16-row forward kernel (see attn_fwd_rows16)
+    uint16_t* Qh = sv.Qh + (size_t)n * 2 * s.W4 * s.JP * 4;
+    half2v h0, l0, h1, l1;
+    split_f16x2(o[0], o[1], h0, l0);
+    split_f16x2(o[2], o[3], h1, l1);
+    *reinterpret_cast<half4v*>(Qh + (size_t)u * 4) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+    *reinterpret_cast<half4v*>(Qh + ((size_t)s.W4 * s.JP + u) * 4) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
   }
 }
 
@@ -164,6 +196,8 @@ struct AttnFwdArgs {
   const float* hinfo;
   float* a_logits;  // may be null
   float* part;      // [N*K][nsplit][w+4] : m, l, -, -, u[w]
+  int ipw;          // 16-row kernel: items per workgroup
+  int dbg;          // FVTA_ATTN_DBG experiment bits (diagnostics only)
 };
 
 // w = 4 * SCW * NSC * NW * NSLAB.  A workgroup is NW waves; a wave owns NSC
@@ -459,220 +493,344 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_main(AttnFw
   }
 }
 
-// ---- main kernel, 16-row tiles (JQ <= 32, w <= 1024) -------------------------
+// ---- main kernel, 16-row tiles (JQ <= 32, 128 <= w <= 1024) -------------------
 // The shape the metric runs.  Differences from the kernel above, all aimed at keeping HBM busy:
-//  * the pre-scaled question slice of a wave (w/NW channels x 32 j) is loop-invariant per workgroup, so it
-//    lives in registers (2*NB float4) as the B operand of v_mfma_f32_16x16x4_f32 -- no per-tile question traffic;
-//  * context rows never pass through VGPRs on the way in: each wave DMAs its channel slice of the next 16-row
-//    tile global -> LDS (buffer_load ... lds) in exactly the lane order of the MFMA A operand, double buffered,
-//    one tile ahead, and waits for it with a counted vmcnt.  The LDS read-back (NB float4 per lane) is kept in
-//    registers and doubles as the operand of the weighted sum, so a row is read from HBM once and LDS once;
+//  * the pre-scaled question slice of a wave (w/NW channels x 32 j) only changes with n, so it lives in
+//    registers as the MFMA B operand -- no per-tile question traffic;
+//  * context rows never pass through VGPRs on the way in: each wave DMAs its channel slice of a 16-row tile
+//    global -> LDS (buffer_load ... lds) in exactly the lane order of the MFMA A operand and waits for it with
+//    a counted vmcnt.  The LDS read-back (NB float4 per lane) is kept in registers and doubles as the operand
+//    of the weighted sum, so a row is read from HBM once and from LDS once -- and the tile's LDS buffer is free
+//    again the moment it has been read back, so two buffers carry a prefetch distance of TWO tiles;
 //  * a wave only ever touches the LDS bytes it DMA'd itself, so the tile buffers need no barrier; the two
-//    barriers per tile are the cross-wave reduction of the partial scores.
-template <int NB, int NW>
+//    barriers per tile are the cross-wave reduction of the partial scores;
+//  * a workgroup owns `ipw` consecutive (n,k,split) items and runs their tiles as ONE stream: the prefetch
+//    crosses item boundaries, so the short items of the metric shape (150 rows) do not pay a pipeline fill each;
+//  * the fp32 matrix pipe (64 flop/clk/SIMD) would cost as many cycles per tile as HBM takes to deliver it, so the
+//    dot products run on the fp16 pipe as a 3-term split: x = hi + lo with hi = rtz_f16(x) (11 bits, the
+//    remainder x - hi is exact in fp32) and lo = rtz_f16((x - hi) * 2^11) (the scaling keeps lo out of the fp16
+//    subnormals);  h.q = hi.hi + 2^-11 (hi.lo + lo.hi) with fp32 accumulation, every product exact.  What is
+//    dropped is lo.lo and the bits below 22: <= 3 * 2^-22 of |h||q| per product, the size of fp32 rounding in
+//    the reference's own summation.  Domain: |h|, |U q| < 65504 (encoder outputs are in (-1, 1));
+//    FVTA_ATTN_EXACT=1 routes to the fp32-MFMA kernel above;
+//  * all in-wave reductions are DPP row operations (no ds_bpermute round trips).
+constexpr int R16_CAP = 2048;            // rows of one workgroup's items (LDS row list, 16-bit ids)
+constexpr int R16_MAXT = R16_CAP / 16;   // tiles
+constexpr int R16_MAXI = 32;             // items
+
+// Workgroup barrier for LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which on gfx9 is
+// s_waitcnt vmcnt(0): it would drain every global->LDS copy in flight at each barrier and serialise the prefetch.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// RMODE: which row-term vector of the bilinear form sits in registers: 1 = Rh (simi 1: R2 = 0), 2 = R2 (simi 2
+// and 4: Rh = 0), 3 = R2 in registers + Rh read from LDS (simi 3).  (Both from LDS was 2x the tile's own LDS traffic.)
+template <int NB, int NW, int RMODE>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(AttnFwdArgs a) {
+  static_assert(NB % 2 == 0, "two 16-channel blocks feed one K = 32 MFMA");
   constexpr int NT = NW * 64;
-  constexpr int CAP = 1024;          // rows of one split (LDS index list)
+  constexpr int NM = NB / 2;         // MFMAs along K per wave
   constexpr int WAVE_F = NB * 256;   // floats per wave per tile buffer: NB blocks of [64 lanes][4]
-  constexpr int TPRW = NT / 16;      // post-processing threads per row
-  constexpr int JPT = 32 / TPRW;     // j columns per post-processing thread
+  constexpr int NPART = NW * 4;      // row-term partials per row
   __shared__ __attribute__((aligned(16))) float s_tile[2][NW * WAVE_F];
   __shared__ __attribute__((aligned(16))) float s_part[NW][512];  // [jt][r][lane] partial scores
-  __shared__ __attribute__((aligned(16))) float s_vec[2][NW * NB * 16];
-  __shared__ int s_idx[CAP];
-  __shared__ float s_rt[NW][16];
+  __shared__ __attribute__((aligned(16))) float s_vec[RMODE == 3 ? NW * NB * 16 : 4];  // Rh, mode 3 only
+  __shared__ uint16_t s_idx[R16_CAP];
+  __shared__ int s_tnk[R16_MAXT];
+  __shared__ uint8_t s_titem[R16_MAXT], s_iallm[R16_MAXI];
+  __shared__ int s_ink[R16_MAXI], s_int[R16_MAXI], s_it0[R16_MAXI], s_ifirst[R16_MAXI + 1];
+  __shared__ float s_rtp[NPART][16];
   __shared__ float s_ct[32];
-  __shared__ float s_amax[16];
+  __shared__ float s_cand_v[2][16];  // per j tile: row max of the raw logits and its j
+  __shared__ int s_cand_j[2][16];
 
   const AttnShape& s = a.s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, kq = lane >> 4;
-  const int nitems = s.N * s.K * s.nsplit;
-  const int bid = blockIdx.x;
-  const int per = (nitems + 7) / 8;
-  const int item = (bid & 7) * per + (bid >> 3);  // XCD-contiguous items, see attn_fwd_main
-  if (item >= nitems || (bid >> 3) >= per) return;
-  const int nk = item / s.nsplit, n = nk / s.K, split = item % s.nsplit;
   const int T = s.T, w = s.w, JP = s.JP;
-  const int cnt = a.sv.cnt[nk];
-  const bool allm = a.sv.allmasked[nk] != 0;
-  const int tiles_total = (cnt + 15) >> 4;
-  const int tiles_per = (tiles_total + s.nsplit - 1) / s.nsplit;
-  const int tile0 = split * tiles_per, tile1 = min(tiles_total, tile0 + tiles_per);
-  float* part = a.part + ((size_t)nk * s.nsplit + split) * (w + 4);
-  if (tile0 >= tile1) {
-    if (tid == 0) {
+  const int nitems = s.N * s.K * s.nsplit;
+  // XCD-contiguous workgroup order (see attn_fwd_main): the workgroups of one n share an L2
+  const int nwg = (nitems + a.ipw - 1) / a.ipw;
+  const int per = (nwg + 7) / 8;
+  const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (wg >= nwg || (int)(blockIdx.x >> 3) >= per) return;
+  const int item_lo = wg * a.ipw;
+  const int nit = min(nitems, item_lo + a.ipw) - item_lo;
+
+  // ---- the workgroup's tile stream: per item (nk, first tile, tiles), per tile its item and nk, per row its t
+  if (tid < nit) {
+    const int item = item_lo + tid;
+    const int nk = item / s.nsplit, split = item % s.nsplit;
+    const int cnt = a.sv.cnt[nk];
+    const int tiles_total = (cnt + 15) >> 4;
+    const int tiles_per = (tiles_total + s.nsplit - 1) / s.nsplit;
+    const int t0 = split * tiles_per, t1 = min(tiles_total, t0 + tiles_per);
+    s_ink[tid] = nk;
+    s_it0[tid] = t0;
+    s_int[tid] = max(0, t1 - t0);
+    s_iallm[tid] = a.sv.allmasked[nk] != 0;
+    if (t1 <= t0) {  // empty split
+      float* part = a.part + (size_t)item * (w + 4);
       part[0] = -INFINITY;
       part[1] = 0.f;
     }
-    return;
   }
-  const float* __restrict__ hbase = a.hinfo + (size_t)nk * T * w;
-  const int32_t* __restrict__ idx = a.sv.idx + (size_t)nk * T;
-  const float* __restrict__ Qs = a.sv.Qs + (size_t)n * s.W4 * JP * 4;
-  const uint64_t qvalid = a.sv.qvalid[(size_t)n * 2];
-  const bool cosine = s.simi == 4;
-
-  for (int r = tid; r < (tile1 - tile0) * 16; r += NT) {
-    const int gr = tile0 * 16 + r;
-    s_idx[r] = gr < cnt ? idx[gr] : -1;
-  }
-  for (int c = tid; c < w; c += NT) {
-    s_vec[0][c] = a.sv.vecs[VEC_RH * w + c];
-    s_vec[1][c] = a.sv.vecs[VEC_R2 * w + c];
-  }
-  if (tid < 32) s_ct[tid] = a.sv.ct[(size_t)n * JP + tid];
-  // B operand of block i, j tile jt, k step e: Qs[channel 16*(NB*wave+i) + 4*kq + e][16*jt + l15]
-  f32x4 breg[NB][2];
+  if (RMODE == 3)
+    for (int c = tid; c < w; c += NT) s_vec[c] = a.sv.vecs[VEC_RH * w + c];
+  f32x4 rreg[NB];  // the lane's 4 channels of every block
 #pragma unroll
   for (int i = 0; i < NB; ++i)
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-      breg[i][jt] = ld4g(Qs + ((size_t)(4 * (NB * wave + i) + kq) * JP + 16 * jt + l15) * 4);
-  f32x4 frag[NB], uacc[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) uacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
-  const __amdgpu_buffer_rsrc_t rh =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hbase), 0, (unsigned)((size_t)T * w * 4), 0x00020000);
-  __syncthreads();  // s_idx / s_vec / s_ct visible; also drains the loads above before the counted waits start
+    rreg[i] = ld4g(a.sv.vecs + (RMODE == 1 ? VEC_RH : VEC_R2) * w + 16 * (NB * wave + i) + 4 * kq);
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < nit; ++i) {
+      s_ifirst[i] = acc;
+      acc += s_int[i];
+    }
+    s_ifirst[nit] = acc;
+  }
+  __syncthreads();
+  const int G = s_ifirst[nit];
+  if (G == 0) return;
+  for (int it = 0; it < nit; ++it) {
+    const int nk = s_ink[it], g0 = s_ifirst[it], ntl = s_int[it], r0 = s_it0[it] * 16;
+    const int cnt = a.sv.cnt[nk];
+    const int32_t* __restrict__ idx = a.sv.idx + (size_t)nk * T;
+    for (int r = tid; r < ntl * 16; r += NT) s_idx[g0 * 16 + r] = (r0 + r < cnt) ? (uint16_t)idx[r0 + r] : (uint16_t)0xFFFF;
+    for (int tl = tid; tl < ntl; tl += NT) {
+      s_titem[g0 + tl] = (uint8_t)it;
+      s_tnk[g0 + tl] = nk;
+    }
+  }
+  __syncthreads();  // also drains every global load above before the counted waits start
 
+  const bool cosine = s.simi == 4;
+  half8 bhi[NM][2], blo[NM][2];
+  f32x4 frag[NB], uacc[NB];
+  float m_run = -INFINITY, l_run = 0.f;
+  uint64_t qvalid = 0;
+  int cur_n = -1;
+
+  // descriptor of the next tile to copy, fetched from LDS one iteration before it is used
+  int d_nk = 0;
+  unsigned d_voff = 0;
+  auto load_desc = [&](int g2) {
+    if (g2 < G) {
+      d_nk = s_tnk[g2];
+      const int t = s_idx[g2 * 16 + l15];
+      d_voff = (unsigned)(t == 0xFFFF ? 0 : t) * (unsigned)(w * 4) + (unsigned)((16 * NB * wave + 4 * kq) * 4);
+      if (a.dbg & 2) {  // EXPERIMENT (wrong results): fully contiguous 1 KB per copy instruction
+        const int t0 = s_idx[g2 * 16];
+        d_voff = (unsigned)(t0 == 0xFFFF ? 0 : t0) * (unsigned)(w * 4) + (unsigned)(wave * NB * 1024 + lane * 16);
+      }
+    }
+  };
   // lane (row l15, k quarter kq) fetches 4 consecutive channels of its row per block: the 1 KB a DMA
-  // instruction lands in LDS is [lane][4], the A operand order of four consecutive k steps
-  auto issue = [&](int tile, int buf) {
-    const int t = s_idx[(tile - tile0) * 16 + l15];
-    const unsigned voff = (unsigned)max(t, 0) * (unsigned)(w * 4) + (unsigned)((16 * NB * wave + 4 * kq) * 4);
+  // instruction lands in LDS is [lane][4]
+  auto issue = [&](int buf) {
+    const float* hb = a.hinfo + (size_t)__builtin_amdgcn_readfirstlane(d_nk) * T * w;
+    const __amdgpu_buffer_rsrc_t rh =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb), 0, (unsigned)((size_t)T * w * 4), 0x00020000);
     float* dst = &s_tile[buf][wave * WAVE_F];
 #pragma unroll
     for (int i = 0; i < NB; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (__attribute__((address_space(3))) void*)(dst + i * 256), 16,
-                                               voff + i * 64, 0, 0, 0);
+                                               d_voff + i * ((a.dbg & 2) ? 1024 : 64), 0, 0, 0);
   };
 
-  issue(tile0, 0);
-  for (int tile = tile0; tile < tile1; ++tile) {
-    const int buf = (tile - tile0) & 1;
-    const bool more = tile + 1 < tile1;
-    // the other buffer was last read (by this wave only) two tiles ago; make that explicit before overwriting
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (more) {
-      issue(tile + 1, buf ^ 1);
-      wait_vmcnt_upto(NB);  // in-order retirement: everything but the NB copies just issued has landed
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+  // FVTA_ATTN_DBG & 16: wave `dbg >> 8` of workgroup 0 stamps the shader clock at each phase boundary of its first
+  // 64 tiles into the (otherwise unused) tail of the workspace, 32 MiB in -- see tools/attn_phases.py
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.part) + (32u << 20));
+  const bool stamp = (a.dbg & 16) && wg == 0 && wave == ((a.dbg >> 8) & 7) && lane == 0;
+#define FVTA_STAMP(k) do { if (stamp && g < 64) stamps[g * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+  load_desc(0);
+  issue(0);
+  load_desc(1);
+  if (G > 1) issue(1);
+  load_desc(2);
+  for (int g = 0; g < G; ++g) {
+    const int buf = g & 1;
+    FVTA_STAMP(0);
+    const int it = s_titem[g];
+    const int nk = s_tnk[g], n = nk / s.K;
+    const bool first = g == s_ifirst[it], last = g + 1 == s_ifirst[it + 1];
+    // in-order retirement: everything but the NB copies of tile g+1 has landed
+    if (g + 1 < G) wait_vmcnt_upto(NB);
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FVTA_STAMP(1);
     const float* tb = &s_tile[buf][wave * WAVE_F];
 #pragma unroll
     for (int i = 0; i < NB; ++i) frag[i] = *reinterpret_cast<const f32x4*>(tb + i * 256 + lane * 4);
-    if (!allm) {
-      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-      float rtp = 0.f;
+    // the tile is in registers: its buffer takes tile g+2 (the explicit wait keeps the DMA behind the reads)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    FVTA_STAMP(8);
+    if (g + 2 < G) issue(buf);
+    FVTA_STAMP(9);
+    load_desc(g + 3);
+    FVTA_STAMP(2);
+    if (first) {
+      m_run = -INFINITY;
+      l_run = 0.f;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int c0 = 16 * (NB * wave + i) + 4 * kq;
-        const f32x4 rh4 = *reinterpret_cast<const f32x4*>(&s_vec[0][c0]);
-        const f32x4 r24 = *reinterpret_cast<const f32x4*>(&s_vec[1][c0]);
-        const f32x4 h = frag[i];
-        const f32x4 tmp = h * (rh4 + r24 * h);
-        rtp += (tmp[0] + tmp[1]) + (tmp[2] + tmp[3]);
+      for (int i = 0; i < NB; ++i) uacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (n != cur_n) {
+        // B operand of MFMA m, j tile jt: lane (col l15, k group kq) holds channels 32m + 4kq + (0..3) and
+        // 32m + 16 + 4kq + (0..3) of the wave's slice -- the channels the A lanes of the same k group hold.
+        // (ordinary loads: they retire behind the copies in flight, once per n)
+        cur_n = n;
+        // (buffer loads: one lane offset register + scalar offsets, instead of 32 hoisted 64-bit pointers)
+        constexpr int W4c = NW * NB * 4;
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t*>(a.sv.Qh + (size_t)n * 2 * W4c * 32 * 4), 0, (unsigned)(2 * W4c * 32 * 8), 0x00020000);
+        const int lane_off = ((4 * NB * wave + kq) * 32 + l15) * 8;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[e], breg[i][0][e], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[e], breg[i][1][e], acc[1], 0, 0, 0);
-        }
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+              typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+              const u32x2 x0 = __builtin_amdgcn_raw_buffer_load_b64(rq, lane_off, ((pc * W4c + 8 * m) * 32 + 16 * jt) * 8, 0);
+              const u32x2 x1 = __builtin_amdgcn_raw_buffer_load_b64(rq, lane_off, ((pc * W4c + 8 * m + 4) * 32 + 16 * jt) * 8, 0);
+              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+              const u32x4 xx = __builtin_shufflevector(x0, x1, 0, 1, 2, 3);
+              const half8 v = __builtin_bit_cast(half8, xx);
+              if (pc == 0) bhi[m][jt] = v;
+              else blo[m][jt] = v;
+            }
+        qvalid = a.sv.qvalid[(size_t)n * 2];
+        if (tid < 32) s_ct[tid] = a.sv.ct[(size_t)n * JP + tid];  // read after the next barrier
       }
-      // D layout of 16x16x4: lane -> column j = l15, rows 4*kq + r
+    }
+    const bool allm = s_iallm[it] != 0;  // (LDS: no ordinary global load may sit in the tile loop)
+    if (!allm) {
+      f32x4 ahh[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 axx[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 rt4 = {0.f, 0.f, 0.f, 0.f};  // row term h.(Rh + R2 h), 4-wide so that it stays two packed FMAs per block
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x4 h = frag[2 * m + q];
+          if (RMODE == 1) {
+            rt4 += h * rreg[2 * m + q];
+          } else if (RMODE == 2) {
+            rt4 += (h * h) * rreg[2 * m + q];
+          } else {
+            const f32x4 rh4 = *reinterpret_cast<const f32x4*>(&s_vec[16 * (NB * wave + 2 * m + q) + 4 * kq]);
+            rt4 += h * (rh4 + rreg[2 * m + q] * h);
+          }
+        }
+        half8 hi, lo;
+        split_f16x8(frag[2 * m], frag[2 * m + 1], hi, lo);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          ahh[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, bhi[m][jt], ahh[jt], 0, 0, 0);
+          axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, blo[m][jt], axx[jt], 0, 0, 0);
+          axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, bhi[m][jt], axx[jt], 0, 0, 0);
+        }
+        // keep the unrolled iterations apart: hoisting every LDS read and split to the top costs ~60 VGPRs
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const float rtp = (rt4[0] + rt4[1]) + (rt4[2] + rt4[3]);
+      // D layout of 16x16xK: lane -> column j = l15, rows 4*kq + r
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s_part[wave][(jt * 4 + r) * 64 + lane] = acc[jt][r];
-      rtp += __shfl_xor(rtp, 16, 64);
-      rtp += __shfl_xor(rtp, 32, 64);
-      if (lane < 16) s_rt[wave][lane] = rtp;
-      __syncthreads();
+        for (int r = 0; r < 4; ++r) s_part[wave][(jt * 4 + r) * 64 + lane] = ahh[jt][r] + axx[jt][r] * (1.f / 2048.f);
+      s_rtp[wave * 4 + kq][l15] = rtp;
+      FVTA_STAMP(3);
+      lds_barrier();
+      FVTA_STAMP(4);
       {
-        const int row = tid / TPRW, jl = tid % TPRW;
-        const int t = s_idx[(tile - tile0) * 16 + row];
+        // (row, j) of this thread: wave pw & 3 owns rows {pw, 4+pw, 8+pw, 12+pw} so that its 64 lanes read 64
+        // consecutive partial scores; with 8 waves the upper four take the second j tile
+        constexpr int JPT = NT == 512 ? 1 : 2;
+        const int pw = wave & 3, jt0 = NT == 512 ? wave >> 2 : 0;
+        const int row = 4 * kq + pw;
         float rt = 0.f;
 #pragma unroll
-        for (int v = 0; v < NW; ++v) rt += s_rt[v][row];
+        for (int v = 0; v < NPART / 16; ++v) rt += s_rtp[l15 * (NPART / 16) + v][row];
+        rt = row16_sum(rt);
         const float rs = cosine ? rsqrtf(fmaxf(rt, 1e-12f)) : 1.f;
         float best = -INFINITY;
         int bestj = 0;
 #pragma unroll
         for (int q = 0; q < JPT; ++q) {
-          const int j = jl + q * TPRW;
-          const int pi = ((j >> 4) * 4 + (row & 3)) * 64 + (j & 15) + 16 * (row >> 2);
+          const int jt = jt0 + q, j = l15 + 16 * jt;
+          const int pi = (jt * 4 + pw) * 64 + lane;
           float x = 0.f;
 #pragma unroll
           for (int v = 0; v < NW; ++v) x += s_part[v][pi];
           x = cosine ? x * rs : x + rt + s_ct[j];
           const bool valid = (qvalid >> j) & 1ull;
-          if (a.a_logits && t >= 0 && j < s.JQ)
-            a.a_logits[((size_t)nk * T + t) * s.JQ + j] = valid ? (s.add_tanh ? tanhf(x) : x) : FVTA_NEG;
+          if (a.a_logits && j < s.JQ) {
+            const int t = s_idx[g * 16 + row];
+            if (t != 0xFFFF) a.a_logits[((size_t)nk * T + t) * s.JQ + j] = valid ? (s.add_tanh ? tanhf(x) : x) : FVTA_NEG;
+          }
           if (valid && x > best) {
             best = x;
             bestj = j;
           }
         }
-#pragma unroll
-        for (int o = 1; o < TPRW; o <<= 1) {
-          const float ob = __shfl_xor(best, o, 64);
-          const int oj = __shfl_xor(bestj, o, 64);
-          if (ob > best || (ob == best && oj < bestj)) {
-            best = ob;
-            bestj = oj;
-          }
-        }
-        if (jl == 0) {
-          if (t >= 0) {
-            const float av = s.add_tanh ? tanhf(best) : best;
-            s_amax[row] = av;
-            a.sv.amax[(size_t)nk * T + t] = av;
-            a.sv.jmax[(size_t)nk * T + t] = (uint8_t)bestj;
-          } else {
-            s_amax[row] = -INFINITY;
-          }
+        row16_argmax(best, bestj);
+        if (l15 == 0) {
+          s_cand_v[jt0][row] = best;
+          s_cand_j[jt0][row] = bestj;
+          if (NT != 512) s_cand_v[1][row] = -INFINITY;
         }
       }
-    } else {
-      __syncthreads();  // the previous tile's readers of s_amax are done
-      if (tid < 16) s_amax[tid] = s_idx[(tile - tile0) * 16 + tid] >= 0 ? FVTA_NEG : -INFINITY;
     }
-    __syncthreads();
+    FVTA_STAMP(5);
+    if (!allm) lds_barrier();
+    FVTA_STAMP(6);
     // online softmax over t (softsel inner, model_v2.py:278); lane l holds row l15 of the tile
-    const float am = s_amax[l15];
-    float mt = am;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) mt = fmaxf(mt, __shfl_xor(mt, o, 64));
-    const float m_new = fmaxf(m_run, mt);
+    float am;
+    {
+      const int t = s_idx[g * 16 + l15];
+      if (allm) {
+        am = t != 0xFFFF ? FVTA_NEG : -INFINITY;
+      } else {
+        const float v0 = s_cand_v[0][l15], v1 = s_cand_v[1][l15];
+        const bool second = v1 > v0;  // ties keep the smaller j
+        const float best = second ? v1 : v0;
+        const int bestj = second ? s_cand_j[1][l15] : s_cand_j[0][l15];
+        am = t != 0xFFFF ? (s.add_tanh ? fvta_tanh(best) : best) : -INFINITY;
+        if (wave == 0 && kq == 0 && t != 0xFFFF) {
+          a.sv.amax[(size_t)nk * T + t] = am;
+          a.sv.jmax[(size_t)nk * T + t] = (uint8_t)bestj;
+        }
+      }
+    }
+    const float m_new = fmaxf(m_run, row16_max(am));
     const float scale = expf(m_run - m_new);
     const float pr = expf(am - m_new);
-    float lsum = pr;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) lsum += __shfl_xor(lsum, o, 64);
-    l_run = l_run * scale + lsum;
+    l_run = l_run * scale + row16_sum(pr);
     m_run = m_new;
+    if (scale != 1.f) {  // workgroup-uniform; the running max rarely moves after the first tiles of an item
 #pragma unroll
-    for (int i = 0; i < NB; ++i) uacc[i] = uacc[i] * scale + frag[i] * pr;
-  }
-  // fold the 16 row lanes, store the partial (m, l, u)
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    f32x4 u = uacc[i];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = u[e];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
-      u[e] = v;
+      for (int i = 0; i < NB; ++i) uacc[i] *= scale;
     }
-    if (l15 == 0) *reinterpret_cast<f32x4*>(part + 4 + 16 * (NB * wave + i) + 4 * kq) = u;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) uacc[i] += frag[i] * pr;
+    FVTA_STAMP(7);
+    if (last) {
+      // fold the 16 row lanes, store the item's partial (m, l, u)
+      float* part = a.part + (size_t)(item_lo + it) * (w + 4);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        f32x4 u = uacc[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u[e] = row16_sum(u[e]);
+        if (l15 == 0) *reinterpret_cast<f32x4*>(part + 4 + 16 * (NB * wave + i) + 4 * kq) = u;
+      }
+      if (tid == 0) {
+        part[0] = m_run;
+        part[1] = l_run;
+      }
+    }
   }
-  if (tid == 0) {
-    part[0] = m_run;
-    part[1] = l_run;
-  }
+#undef FVTA_STAMP
 }
 
 // ---- merge: splits -> u[n,k], M, L; softmax over K; h_a.  grid N, 256 threads
@@ -795,18 +953,39 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
   a.hinfo = hinfo;
   a.a_logits = a_logits;
   a.part = (float*)workspace;
+  a.ipw = 1;
+  {
+    const char* e = getenv("FVTA_ATTN_DBG");
+    a.dbg = e ? atoi(e) : 0;
+  }
   fvta_prof_begin(FVTA_PROF_ATTN_FWD_MAIN, stream);
-  const bool rows16 = s.JT == 1 && s.w <= 1024;
+  const char* exact = getenv("FVTA_ATTN_EXACT");
+  const bool rows16 = s.JT == 1 && s.w >= 128 && s.w <= 1024 && !(exact && exact[0] == '1');
   if (rows16) {
+    // a workgroup streams `ipw` consecutive items: about one workgroup per CU, bounded by its LDS row list
     const int nitems = s.nsplit * s.N * s.K;
-    const dim3 grid(((nitems + 7) / 8) * 8);
+    const int tiles_per_max = (((s.T + 15) / 16) + s.nsplit - 1) / s.nsplit;
+    int ipw = (nitems + 255) / 256;
+    if (ipw > R16_MAXT / tiles_per_max) ipw = R16_MAXT / tiles_per_max;
+    if (ipw > R16_MAXI) ipw = R16_MAXI;
+    if (ipw < 1) ipw = 1;
+    a.ipw = ipw;
+    const int nwg = (nitems + ipw - 1) / ipw;
+    const dim3 grid(((nwg + 7) / 8) * 8);
+    const int rmode = s.simi == 1 ? 1 : (s.simi == 3 ? 3 : 2);
+#define FVTA_R16(NB, NW)                                                                                          \
+  do {                                                                                                            \
+    if (rmode == 1) hipLaunchKernelGGL((attn_fwd_rows16<NB, NW, 1>), grid, dim3(NW * 64), 0, stream, a);          \
+    else if (rmode == 2) hipLaunchKernelGGL((attn_fwd_rows16<NB, NW, 2>), grid, dim3(NW * 64), 0, stream, a);     \
+    else hipLaunchKernelGGL((attn_fwd_rows16<NB, NW, 3>), grid, dim3(NW * 64), 0, stream, a);                     \
+  } while (0)
     switch (s.w) {
-      case 64: hipLaunchKernelGGL((attn_fwd_rows16<1, 4>), grid, dim3(256), 0, stream, a); break;
-      case 128: hipLaunchKernelGGL((attn_fwd_rows16<2, 4>), grid, dim3(256), 0, stream, a); break;
-      case 256: hipLaunchKernelGGL((attn_fwd_rows16<4, 4>), grid, dim3(256), 0, stream, a); break;
-      case 512: hipLaunchKernelGGL((attn_fwd_rows16<8, 4>), grid, dim3(256), 0, stream, a); break;
-      case 1024: hipLaunchKernelGGL((attn_fwd_rows16<8, 8>), grid, dim3(512), 0, stream, a); break;
+      case 128: FVTA_R16(2, 4); break;
+      case 256: FVTA_R16(4, 4); break;
+      case 512: FVTA_R16(4, 8); break;
+      case 1024: FVTA_R16(8, 8); break;
     }
+#undef FVTA_R16
   } else
   switch (s.w) {
     case 64: launch_main<4, 1, 4, 1, 1, 4>(a, stream); break;

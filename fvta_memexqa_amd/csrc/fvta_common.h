@@ -80,6 +80,49 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- DPP reductions over aligned groups of 16 lanes (one DPP row); every lane ends with the group's result.
+// quad_perm xor 1 / xor 2, then row_half_mirror / row_mirror (which pair a lane with the other quad / other half
+// once the smaller groups are uniform).  No LDS crossbar (ds_bpermute) round trips, unlike __shfl_xor.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<DPP_XOR1>(v);
+  v += dpp_f<DPP_XOR2>(v);
+  v += dpp_f<DPP_HALF_MIRROR>(v);
+  v += dpp_f<DPP_MIRROR>(v);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+  v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+  v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
+  return v;
+}
+// arg-max with first-index tie break
+template <int CTRL>
+__device__ __forceinline__ void dpp_argmax_step(float& best, int& bestj) {
+  const float ob = dpp_f<CTRL>(best);
+  const int oj = dpp_i<CTRL>(bestj);
+  if (ob > best || (ob == best && oj < bestj)) {
+    best = ob;
+    bestj = oj;
+  }
+}
+__device__ __forceinline__ void row16_argmax(float& best, int& bestj) {
+  dpp_argmax_step<DPP_XOR1>(best, bestj);
+  dpp_argmax_step<DPP_XOR2>(best, bestj);
+  dpp_argmax_step<DPP_HALF_MIRROR>(best, bestj);
+  dpp_argmax_step<DPP_MIRROR>(best, bestj);
+}
+
 // float -> bf16 (round to nearest even), as raw 16-bit
 __device__ __forceinline__ unsigned short f2bf(float f) {
   unsigned u = __float_as_uint(f);
