@@ -25,9 +25,9 @@ struct AttnBwdWork {
   float* coef;   // [N,K]  r / L
   float* gu;     // [N,K]  g . u[k]
   float* dss;    // [N,K]  ds[k] / (#t with amax == M)
-  float* slabs;  // [N*K][bsplit][RH][JP][w]   dQs partials
-  float* dctp;   // [N*K][bsplit][RH][JP]      d ct partials
-  float* rowp;   // [N*K][bsplit][RH][2][w]    d Rh, d R2 partials
+  float* slabs;  // [N*ng][bsplit][RH][JP][w]   dQs partials (ng = groups of gk consecutive k per n)
+  float* dctp;   // [N*ng][bsplit][RH][JP]      d ct partials
+  float* rowp;   // [N*ng][bsplit][RH][2][w]    d Rh, d R2 partials
   float* pvec;   // [N][5][w]                  per-n parameter-vector partials
   float* dctn;   // [N][JP]
   size_t bytes;
@@ -48,44 +48,37 @@ static AttnBwdWork bwd_work_view(const AttnShape& s, void* p) {
   v.pvec = c.take<float>((size_t)s.N * VEC_COUNT * s.w);
   v.dctn = c.take<float>((size_t)s.N * s.JP);
   const size_t before = c.off;
-  v.slabs = c.take<float>(nk * s.bsplit * RH * s.JP * s.w);
-  v.dctp = c.take<float>(nk * s.bsplit * RH * s.JP);
-  v.rowp = c.take<float>(nk * s.bsplit * RH * 2 * s.w);
+  const size_t ngr = (size_t)s.N * s.ng;
+  v.slabs = c.take<float>(ngr * s.bsplit * RH * s.JP * s.w);
+  v.dctp = c.take<float>(ngr * s.bsplit * RH * s.JP);
+  v.rowp = c.take<float>(ngr * s.bsplit * RH * 2 * s.w);
   v.slab_bytes = c.off - before;
   v.bytes = c.off;
   return v;
 }
 
-// ---- per-(n,k) scalars.  grid N, 256 threads
+// ---- per-(n,k) scalars.  grid N, 256 threads; a wave per k (no workgroup barrier inside the k loop)
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnShape s, AttnSaved sv, AttnBwdWork wk,
                                                             const float* __restrict__ d_h_a) {
-  __shared__ float s_red[4];
   __shared__ float s_gu[64];
   __shared__ int s_ties[64];
-  __shared__ int s_ired[4];
   const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int w = s.w, K = s.K, T = s.T;
   const float* g = d_h_a + (size_t)n * w;
-  for (int k = 0; k < K; ++k) {
+  for (int k = wave; k < K; k += 4) {
     const float* u = sv.u + ((size_t)n * K + k) * w;
     float acc = 0.f;
-    for (int c = tid; c < w; c += 256) acc += g[c] * u[c];
+    for (int c = lane; c < w; c += 64) acc += g[c] * u[c];
     acc = wave_sum(acc);
     const float M = sv.M[n * K + k];
     const float* am = sv.amax + ((size_t)n * K + k) * T;
     int ties = 0;
-    for (int t = tid; t < T; t += 256) ties += (am[t] == M) ? 1 : 0;
+    for (int t = lane; t < T; t += 64) ties += (am[t] == M) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ties += __shfl_xor(ties, o, 64);
-    __syncthreads();
     if (lane == 0) {
-      s_red[wave] = acc;
-      s_ired[wave] = ties;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      s_gu[k] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-      s_ties[k] = s_ired[0] + s_ired[1] + s_ired[2] + s_ired[3];
+      s_gu[k] = acc;
+      s_ties[k] = ties;
     }
   }
   __syncthreads();
@@ -128,14 +121,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   __shared__ float s_self[TR];
   __shared__ float s_pr[TR], s_dx[TR];
   __shared__ int s_tt[TR], s_jj[TR];
+  // the workgroup's group of consecutive k: per-k scalars, and the start of each k's rows in the concatenated list
+  __shared__ int s_kbase[17];
+  __shared__ float s_kM[16], s_kcoef[16], s_kgu[16], s_kdss[16];
+  __shared__ uint8_t s_kallm[16];
 
   const AttnShape& s = a.s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int cq = tid % TPR, rh = tid / TPR;
-  const int nk = blockIdx.y, n = nk / s.K, split = blockIdx.x;
+  const int grp = blockIdx.y, n = grp / s.ng, k0 = (grp % s.ng) * s.gk, split = blockIdx.x;
+  const int nkl = min(s.gk, s.K - k0);  // k's in this group
+  const int nk = n * s.K + k0;          // first (n,k) of the group; rows of the group are contiguous from here
   const int T = s.T, w = s.w, JP = s.JP;
-  const int cnt = a.sv.cnt[nk];
-  const bool allm = a.sv.allmasked[nk] != 0;
+  if (tid == 0) {
+    int run = 0;
+    for (int kl = 0; kl < nkl; ++kl) {
+      s_kbase[kl] = run;
+      run += a.sv.cnt[nk + kl];
+    }
+    s_kbase[nkl] = run;
+  }
+  if (tid < nkl) {
+    s_kM[tid] = a.sv.M[nk + tid];
+    s_kcoef[tid] = a.wk.coef[nk + tid];
+    s_kgu[tid] = a.wk.gu[nk + tid];
+    s_kdss[tid] = a.wk.dss[nk + tid];
+    s_kallm[tid] = a.sv.allmasked[nk + tid] != 0;
+  }
+  __syncthreads();
+  const int cnt = s_kbase[nkl];
   int chunk = (cnt + s.bsplit - 1) / s.bsplit;
   chunk = (chunk + TR - 1) / TR * TR;
   const int r0 = split * chunk, r1 = min(cnt, r0 + chunk);
@@ -144,6 +158,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   const int32_t* __restrict__ idx = a.sv.idx + (size_t)nk * T;
   const float* __restrict__ amax = a.sv.amax + (size_t)nk * T;
   const uint8_t* __restrict__ jmax = a.sv.jmax + (size_t)nk * T;
+  // row i of the concatenated list -> flat row (k - k0) * T + t of the group
+  auto flat_row = [&](int i) {
+    int kl = 0;
+    while (kl + 1 < nkl && i >= s_kbase[kl + 1]) ++kl;
+    return kl * T + idx[(size_t)kl * T + (i - s_kbase[kl])];
+  };
 
   // ---- stable counting sort of the chunk's rows by jmax (4 waves, contiguous quarters)
   for (int i = tid; i < 4 * 65; i += 256) (&s_hist[0][0])[i] = 0;
@@ -153,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   for (int base = b0; base < b1; base += 64) {
     const int i = base + lane;
     const bool ok = i < b1;
-    const int key = ok ? (int)jmax[idx[r0 + i]] : -1;
+    const int key = ok ? (int)jmax[flat_row(r0 + i)] : -1;
     unsigned long long todo = __ballot(ok);
     while (todo) {
       const int leader = __ffsll((long long)todo) - 1;
@@ -177,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   for (int base = b0; base < b1; base += 64) {
     const int i = base + lane;
     const bool ok = i < b1;
-    const int t = ok ? idx[r0 + i] : 0;
+    const int t = ok ? flat_row(r0 + i) : 0;
     const int key = ok ? (int)jmax[t] : -1;
     unsigned long long todo = __ballot(ok);
     while (todo) {
@@ -201,10 +221,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   const float* __restrict__ hbase = a.hinfo + (size_t)nk * T * w;
   float* __restrict__ dhbase = a.d_hinfo + (size_t)nk * T * w;
   const float* __restrict__ Qs = a.sv.Qs + (size_t)n * s.W4 * JP * 4;
-  const float M = a.sv.M[nk];
   constexpr bool cosine = COS;
-  const float coef = a.wk.coef[nk], gu = a.wk.gu[nk], dss = a.wk.dss[nk];
-  const size_t slot = ((size_t)nk * s.bsplit + split) * RH + rh;
+  const size_t slot = ((size_t)grp * s.bsplit + split) * RH + rh;
   float* __restrict__ slab = a.wk.slabs + slot * JP * w;
   float* __restrict__ dctp = a.wk.dctp + slot * JP;
   float* __restrict__ rowp = a.wk.rowp + slot * 2 * w;
@@ -308,10 +326,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
           gh = s_dot[0][tid];
           if (cosine) hh = s_nrm[0][tid];
         }
+        const int kl = t / T;
+        const float M = s_kM[kl];
         const float am = amax[t];
-        pr = expf(am - M) * coef;
-        if (!allm) {  // fully masked rows: am = -1e30, no gradient into the masked logits
-          const float damax = pr * (gh - gu) + (am == M ? dss : 0.f);
+        pr = expf(am - M) * s_kcoef[kl];
+        if (!s_kallm[kl]) {  // fully masked rows: am = -1e30, no gradient into the masked logits
+          const float damax = pr * (gh - s_kgu[kl]) + (am == M ? s_kdss[kl] : 0.f);
           dx = s.add_tanh ? damax * (1.f - am * am) : damax;
           if (cosine) {  // x = (h.qn) * rh with rh = rsqrt(max(|h|^2, eps)) (model_v2.py:250-254): am IS x
             const float rhn = rsqrtf(fmaxf(hh, 1e-12f));
@@ -369,7 +389,7 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_q_kernel(AttnShape s, Att
   __shared__ float s_dct[64];
   const int n = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
   const int w = s.w, K = s.K, JP = s.JP, JQ = s.JQ;
-  const int nslot = K * s.bsplit * RH;
+  const int nslot = s.ng * s.bsplit * RH;
   const size_t slot0 = (size_t)n * nslot;
   if (threadIdx.x < JP) {
     float acc = 0.f;
@@ -414,7 +434,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cosine_q_kernel(AttnShape s, Att
   __shared__ float s_red[2][4];
   const int n = blockIdx.x / s.JQ, j = blockIdx.x % s.JQ, tid = threadIdx.x;
   const int w = s.w, JP = s.JP;
-  const int nslot = s.K * s.bsplit * RH;
+  const int nslot = s.ng * s.bsplit * RH;
   const size_t slot0 = (size_t)n * nslot;
   const float* q = hq + ((size_t)n * s.JQ + j) * w;
   float qq = 0.f, qd = 0.f;
@@ -445,16 +465,34 @@ __global__ __launch_bounds__(256) void attn_bwd_cosine_q_kernel(AttnShape s, Att
   }
 }
 
-// ---- sum over n, map back to att_logits/W's layout.  grid ceil(w/256)
+// ---- sum over n, map back to att_logits/W's layout.  grid ceil(w/64) + 1; 256 threads = 64 channels x 4 n-groups
+// (fixed summation order: bitwise reproducible)
 __global__ __launch_bounds__(256) void attn_bwd_params_kernel(AttnShape s, AttnBwdWork wk, float* __restrict__ dW,
                                                               float* __restrict__ db) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int w = s.w;
-  if (c < w) {
-    float v[VEC_COUNT] = {0, 0, 0, 0, 0};
-    for (int n = 0; n < s.N; ++n)
+  __shared__ float s_p[4][VEC_COUNT][64];
+  __shared__ float s_b[4];
+  const int tid = threadIdx.x, w = s.w;
+  if (blockIdx.x == gridDim.x - 1) {  // the bias block
+    float acc = 0.f;
+    for (int i = tid; i < s.N * s.JP; i += 256) acc += wk.dctn[i];
+    acc = wave_sum(acc);
+    if ((tid & 63) == 0) s_b[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0 && db) db[0] += (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+    return;
+  }
+  const int cl = tid & 63, grp = tid >> 6, c = blockIdx.x * 64 + cl;
+  float v[VEC_COUNT] = {0, 0, 0, 0, 0};
+  if (c < w)
+    for (int n = grp; n < s.N; n += 4)
 #pragma unroll
       for (int k = 0; k < VEC_COUNT; ++k) v[k] += wk.pvec[((size_t)n * VEC_COUNT + k) * w + c];
+#pragma unroll
+  for (int k = 0; k < VEC_COUNT; ++k) s_p[grp][k][cl] = v[k];
+  __syncthreads();
+  if (grp == 0 && c < w) {
+#pragma unroll
+    for (int k = 0; k < VEC_COUNT; ++k) v[k] = (s_p[0][k][cl] + s_p[1][k][cl]) + (s_p[2][k][cl] + s_p[3][k][cl]);
     const float dU = v[VEC_U], dRh = v[VEC_RH], dR2 = v[VEC_R2], dCq = v[VEC_CQ], dC2 = v[VEC_C2];
     if (s.simi == 1) {
       dW[c] += dRh;
@@ -470,11 +508,6 @@ __global__ __launch_bounds__(256) void attn_bwd_params_kernel(AttnShape s, AttnB
       dW[2 * w + c] += -2.f * dU + dR2 + dC2;
       dW[3 * w + c] += dU;
     }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float acc = 0.f;
-    for (int i = 0; i < s.N * s.JP; ++i) acc += wk.dctn[i];
-    db[0] += acc;
   }
 }
 
@@ -510,7 +543,7 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
   a.d_h_a = d_h_a;
   a.d_hinfo = d_hinfo;
   a.accumulate = accumulate;
-  const dim3 grid(s.bsplit, s.N * s.K);
+  const dim3 grid(s.bsplit, s.N * s.ng);
   fvta_prof_begin(FVTA_PROF_ATTN_BWD_MAIN, stream);
   switch (s.w) {
 #define FVTA_BWD_LAUNCH(TPR, G, TR)                                                                      \
@@ -536,7 +569,7 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
   } else {
     hipLaunchKernelGGL(attn_bwd_reduce_q_kernel, dim3(s.N, (s.w + 255) / 256), dim3(256), 0, stream, s, sv, wk, RH, hq,
                        d_hq, accumulate);
-    hipLaunchKernelGGL(attn_bwd_params_kernel, dim3((s.w + 255) / 256), dim3(256), 0, stream, s, wk, dW, db);
+    hipLaunchKernelGGL(attn_bwd_params_kernel, dim3((s.w + 63) / 64 + 1), dim3(256), 0, stream, s, wk, dW, db);
   }
   FVTA_CHECK_LAUNCH("attn_bwd_reduce");
   return FVTA_OK;

@@ -16,6 +16,8 @@ struct AttnShape {
   int JP;      // 32 * JT
   int nsplit;  // workgroups per (n,k) in the forward main kernel
   int bsplit;  // workgroups per (n,k) in the backward main kernel
+  int gk;      // backward: consecutive k of one n that share a workgroup (and one dQs slab); > 1 only if bsplit == 1
+  int ng;      // backward: ceil(K / gk) groups per n
 };
 
 inline AttnShape attn_shape(const fvta_attn_desc* d, bool use_mask) {
@@ -41,6 +43,19 @@ inline AttnShape attn_shape(const fvta_attn_desc* d, bool use_mask) {
   if (bs < minb) bs = minb;
   if (bs < 1) bs = 1;
   s.bsplit = bs;
+  // short photo streams (the metric shape: 150 rows per (n,k)): one workgroup takes several k of the same n, whose
+  // rows are contiguous in [N,K,T,w] -- one slab, one sort, fewer flushes.  ~512 workgroups (2 per CU) when possible.
+  int gk = 1;
+  if (bs == 1 && d->T <= 512) {
+    gk = nk / 512;
+    const int cap = 1024 / d->T;  // BWD_CHMAX rows in the LDS sort
+    if (gk > cap) gk = cap;
+    if (gk > d->K) gk = d->K;
+    if (gk > 16) gk = 16;
+    if (gk < 1) gk = 1;
+  }
+  s.gk = gk;
+  s.ng = (d->K + gk - 1) / gk;
   return s;
 }
 

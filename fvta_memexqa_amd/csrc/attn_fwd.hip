@@ -97,6 +97,8 @@ __global__ __launch_bounds__(256) void attn_prep_q_kernel(AttnShape s, AttnSaved
   const float* Cq = sv.vecs + VEC_CQ * w;
   const float* C2 = sv.vecs + VEC_C2 * w;
   const float bias = (s.simi == 4 || bptr == nullptr) ? 0.f : bptr[0];
+  // grid (N, slices): slice 0 owns ct / the valid-j bits; the question norms are needed by every slice (cosine only)
+  if (blockIdx.y == 0 || s.simi == 4)
   for (int j = wave; j < s.JP; j += 4) {
     float s1 = 0.f, s2 = 0.f;
     if (j < s.JQ)
@@ -108,11 +110,11 @@ __global__ __launch_bounds__(256) void attn_prep_q_kernel(AttnShape s, AttnSaved
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
     if (lane == 0) {
-      sv.ct[(size_t)n * s.JP + j] = (j < s.JQ && s.simi != 4) ? s1 + bias : 0.f;
+      if (blockIdx.y == 0) sv.ct[(size_t)n * s.JP + j] = (j < s.JQ && s.simi != 4) ? s1 + bias : 0.f;
       s_rq[j] = rsqrtf(fmaxf(s2, 1e-12f));  // tf.nn.l2_normalize eps
     }
   }
-  if (tid == 0) {
+  if (tid == 0 && blockIdx.y == 0) {
     uint64_t bits = 0;
     for (int j = 0; j < s.JQ; ++j)
       if (!s.use_mask || qmask[(size_t)n * s.JQ + j]) bits |= (1ull << j);
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void attn_prep_q_kernel(AttnShape s, AttnSaved
   }
   __syncthreads();
   float* Qs = sv.Qs + (size_t)n * s.W4 * s.JP * 4;
-  for (int u = tid; u < s.W4 * s.JP; u += 256) {
+  for (int u = blockIdx.y * 256 + tid; u < s.W4 * s.JP; u += 256 * gridDim.y) {
     const int c4 = u / s.JP, j = u % s.JP;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (j < s.JQ) {
@@ -497,13 +499,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_main(AttnFw
 // The shape the metric runs.  Differences from the kernel above, all aimed at keeping HBM busy:
 //  * the pre-scaled question slice of a wave (w/NW channels x 32 j) only changes with n, so it lives in
 //    registers as the MFMA B operand -- no per-tile question traffic;
-//  * context rows never pass through VGPRs on the way in: each wave DMAs its channel slice of a 16-row tile
-//    global -> LDS (buffer_load ... lds) in exactly the lane order of the MFMA A operand and waits for it with
-//    a counted vmcnt.  The LDS read-back (NB float4 per lane) is kept in registers and doubles as the operand
-//    of the weighted sum, so a row is read from HBM once and from LDS once -- and the tile's LDS buffer is free
-//    again the moment it has been read back, so two buffers carry a prefetch distance of TWO tiles;
-//  * a wave only ever touches the LDS bytes it DMA'd itself, so the tile buffers need no barrier; the two
-//    barriers per tile are the cross-wave reduction of the partial scores;
+//  * context rows are loaded global -> VGPR directly in the lane order of the MFMA A operand (lane = row l15,
+//    k quarter kq: 4 consecutive channels of its row per 16-channel block), so they cross neither LDS nor a
+//    transposition; the same registers are the operand of the weighted sum, so a row is read once.  The
+//    registers are double buffered (the tile loop is unrolled by two) and the next tile's loads are issued
+//    before the current tile is touched -- the compiler's own counted vmcnt does the rest.
+//    (A global -> LDS DMA version of this kernel spent its time in the LDS: the copy's LDS write path plus the
+//    read-back saturated it at ~40% of the HBM roofline.)
 //  * a workgroup owns `ipw` consecutive (n,k,split) items and runs their tiles as ONE stream: the prefetch
 //    crosses item boundaries, so the short items of the metric shape (150 rows) do not pay a pipeline fill each;
 //  * the fp32 matrix pipe (64 flop/clk/SIMD) would cost as many cycles per tile as HBM takes to deliver it, so the
@@ -513,27 +515,25 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_main(AttnFw
 //    dropped is lo.lo and the bits below 22: <= 3 * 2^-22 of |h||q| per product, the size of fp32 rounding in
 //    the reference's own summation.  Domain: |h|, |U q| < 65504 (encoder outputs are in (-1, 1));
 //    FVTA_ATTN_EXACT=1 routes to the fp32-MFMA kernel above;
-//  * all in-wave reductions are DPP row operations (no ds_bpermute round trips).
-constexpr int R16_CAP = 2048;            // rows of one workgroup's items (LDS row list, 16-bit ids)
+//  * all in-wave reductions are DPP row operations (no ds_bpermute round trips), and the barriers are LDS-only.
+constexpr int R16_CAP = 1600;            // rows of one workgroup's items (LDS row list, 16-bit ids)
 constexpr int R16_MAXT = R16_CAP / 16;   // tiles
 constexpr int R16_MAXI = 32;             // items
 
 // Workgroup barrier for LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which on gfx9 is
-// s_waitcnt vmcnt(0): it would drain every global->LDS copy in flight at each barrier and serialise the prefetch.
+// s_waitcnt vmcnt(0): it would drain the row loads in flight at each barrier and serialise the prefetch.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// RMODE: which row-term vector of the bilinear form sits in registers: 1 = Rh (simi 1: R2 = 0), 2 = R2 (simi 2
-// and 4: Rh = 0), 3 = R2 in registers + Rh read from LDS (simi 3).  (Both from LDS was 2x the tile's own LDS traffic.)
+// RMODE: which row-term vectors of the bilinear form are non-zero: 1 = Rh (simi 1), 2 = R2 (simi 2 and 4),
+// 3 = both (simi 3).
 template <int NB, int NW, int RMODE>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(AttnFwdArgs a) {
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(AttnFwdArgs a) {
   static_assert(NB % 2 == 0, "two 16-channel blocks feed one K = 32 MFMA");
   constexpr int NT = NW * 64;
   constexpr int NM = NB / 2;         // MFMAs along K per wave
-  constexpr int WAVE_F = NB * 256;   // floats per wave per tile buffer: NB blocks of [64 lanes][4]
   constexpr int NPART = NW * 4;      // row-term partials per row
-  __shared__ __attribute__((aligned(16))) float s_tile[2][NW * WAVE_F];
   __shared__ __attribute__((aligned(16))) float s_part[NW][512];  // [jt][r][lane] partial scores
-  __shared__ __attribute__((aligned(16))) float s_vec[RMODE == 3 ? NW * NB * 16 : 4];  // Rh, mode 3 only
+  __shared__ __attribute__((aligned(16))) float s_vec[2][NW * NB * 16];
   __shared__ uint16_t s_idx[R16_CAP];
   __shared__ int s_tnk[R16_MAXT];
   __shared__ uint8_t s_titem[R16_MAXT], s_iallm[R16_MAXI];
@@ -542,6 +542,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(Attn
   __shared__ float s_ct[32];
   __shared__ float s_cand_v[2][16];  // per j tile: row max of the raw logits and its j
   __shared__ int s_cand_j[2][16];
+  // the lo pieces of the question (B operand of the hi.lo term): per wave, in MFMA lane order.  Only the hi
+  // pieces fit the register file next to the double-buffered rows; the LDS is otherwise idle in this kernel.
+  __shared__ __attribute__((aligned(16))) half8 s_blo[NW][NM * 2][64];
+  __shared__ __attribute__((aligned(16))) half8 s_bhi[NW][NM * 2][64];
 
   const AttnShape& s = a.s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -555,6 +559,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(Attn
   if (wg >= nwg || (int)(blockIdx.x >> 3) >= per) return;
   const int item_lo = wg * a.ipw;
   const int nit = min(nitems, item_lo + a.ipw) - item_lo;
+  const unsigned long long t_entry = __builtin_readcyclecounter();
 
   // ---- the workgroup's tile stream: per item (nk, first tile, tiles), per tile its item and nk, per row its t
   if (tid < nit) {
@@ -574,12 +579,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(Attn
       part[1] = 0.f;
     }
   }
-  if (RMODE == 3)
-    for (int c = tid; c < w; c += NT) s_vec[c] = a.sv.vecs[VEC_RH * w + c];
-  f32x4 rreg[NB];  // the lane's 4 channels of every block
-#pragma unroll
-  for (int i = 0; i < NB; ++i)
-    rreg[i] = ld4g(a.sv.vecs + (RMODE == 1 ? VEC_RH : VEC_R2) * w + 16 * (NB * wave + i) + 4 * kq);
+  for (int c = tid; c < w; c += NT) {
+    if (RMODE != 2) s_vec[0][c] = a.sv.vecs[VEC_RH * w + c];
+    if (RMODE != 1) s_vec[1][c] = a.sv.vecs[VEC_R2 * w + c];
+  }
   __syncthreads();
   if (tid == 0) {
     int acc = 0;
@@ -593,49 +596,40 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(Attn
   const int G = s_ifirst[nit];
   if (G == 0) return;
   for (int it = 0; it < nit; ++it) {
-    const int nk = s_ink[it], g0 = s_ifirst[it], ntl = s_int[it], r0 = s_it0[it] * 16;
-    const int cnt = a.sv.cnt[nk];
-    const int32_t* __restrict__ idx = a.sv.idx + (size_t)nk * T;
-    for (int r = tid; r < ntl * 16; r += NT) s_idx[g0 * 16 + r] = (r0 + r < cnt) ? (uint16_t)idx[r0 + r] : (uint16_t)0xFFFF;
+    const int nk = s_ink[it], g0 = s_ifirst[it], ntl = s_int[it];
     for (int tl = tid; tl < ntl; tl += NT) {
       s_titem[g0 + tl] = (uint8_t)it;
       s_tnk[g0 + tl] = nk;
     }
   }
-  __syncthreads();  // also drains every global load above before the counted waits start
+  __syncthreads();
+  // one flat pass over the stream's rows: every lookup independent (a per-item loop chains ~10 load latencies)
+  for (int r = tid; r < G * 16; r += NT) {
+    const int g = r >> 4, it = s_titem[g], nk = s_tnk[g];
+    const int lr = (s_it0[it] + g - s_ifirst[it]) * 16 + (r & 15);
+    s_idx[r] = lr < a.sv.cnt[nk] ? (uint16_t)a.sv.idx[(size_t)nk * T + lr] : (uint16_t)0xFFFF;
+  }
+  __syncthreads();
 
   const bool cosine = s.simi == 4;
-  half8 bhi[NM][2], blo[NM][2];
-  f32x4 frag[NB], uacc[NB];
+  f32x4 fragA[NB], fragB[NB], fragC[NB], uacc[NB];
   float m_run = -INFINITY, l_run = 0.f;
   uint64_t qvalid = 0;
   int cur_n = -1;
 
-  // descriptor of the next tile to copy, fetched from LDS one iteration before it is used
-  int d_nk = 0;
-  unsigned d_voff = 0;
-  auto load_desc = [&](int g2) {
-    if (g2 < G) {
-      d_nk = s_tnk[g2];
-      const int t = s_idx[g2 * 16 + l15];
-      d_voff = (unsigned)(t == 0xFFFF ? 0 : t) * (unsigned)(w * 4) + (unsigned)((16 * NB * wave + 4 * kq) * 4);
-      if (a.dbg & 2) {  // EXPERIMENT (wrong results): fully contiguous 1 KB per copy instruction
-        const int t0 = s_idx[g2 * 16];
-        d_voff = (unsigned)(t0 == 0xFFFF ? 0 : t0) * (unsigned)(w * 4) + (unsigned)(wave * NB * 1024 + lane * 16);
-      }
-    }
+  // lane (row l15, k quarter kq) loads 4 consecutive channels of its row per 16-channel block
+  auto tile_rsrc = [&](int g2) {
+    const int nk2 = __builtin_amdgcn_readfirstlane(s_tnk[g2]);
+    const float* hb = a.hinfo + (size_t)nk2 * T * w;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb), 0, (unsigned)((size_t)T * w * 4), 0x00020000);
   };
-  // lane (row l15, k quarter kq) fetches 4 consecutive channels of its row per block: the 1 KB a DMA
-  // instruction lands in LDS is [lane][4]
-  auto issue = [&](int buf) {
-    const float* hb = a.hinfo + (size_t)__builtin_amdgcn_readfirstlane(d_nk) * T * w;
-    const __amdgpu_buffer_rsrc_t rh =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb), 0, (unsigned)((size_t)T * w * 4), 0x00020000);
-    float* dst = &s_tile[buf][wave * WAVE_F];
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (__attribute__((address_space(3))) void*)(dst + i * 256), 16,
-                                               d_voff + i * ((a.dbg & 2) ? 1024 : 64), 0, 0, 0);
+  auto tile_voff = [&](int g2) {
+    const int t = s_idx[g2 * 16 + l15];
+    // (invalid rows of the last tile read row 0: finite data, weight 0)
+    return (t == 0xFFFF ? 0 : t) * (w * 4) + (16 * NB * wave + 4 * kq) * 4;
+  };
+  auto load_block = [&](const __amdgpu_buffer_rsrc_t rh, int voff, int i) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rh, voff + i * 64, 0, 0));
   };
 
   // FVTA_ATTN_DBG & 16: wave `dbg >> 8` of workgroup 0 stamps the shader clock at each phase boundary of its first
@@ -643,31 +637,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(Attn
   unsigned long long* stamps = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.part) + (32u << 20));
   const bool stamp = (a.dbg & 16) && wg == 0 && wave == ((a.dbg >> 8) & 7) && lane == 0;
 #define FVTA_STAMP(k) do { if (stamp && g < 64) stamps[g * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
-  load_desc(0);
-  issue(0);
-  load_desc(1);
-  if (G > 1) issue(1);
-  load_desc(2);
-  for (int g = 0; g < G; ++g) {
-    const int buf = g & 1;
+
+  auto tile = [&](const int g, f32x4 (&frag)[NB], f32x4 (&next)[NB]) {
     FVTA_STAMP(0);
     const int it = s_titem[g];
     const int nk = s_tnk[g], n = nk / s.K;
     const bool first = g == s_ifirst[it], last = g + 1 == s_ifirst[it + 1];
-    // in-order retirement: everything but the NB copies of tile g+1 has landed
-    if (g + 1 < G) wait_vmcnt_upto(NB);
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    FVTA_STAMP(1);
-    const float* tb = &s_tile[buf][wave * WAVE_F];
+    // prefetch distance TWO tiles (three register buffers): with one tile in flight the CU holds 64 KB of
+    // outstanding reads at best and ~32 KB on average -- half of what HBM latency x the CU's bandwidth share needs
+    if (g + 2 < G) {
+      const __amdgpu_buffer_rsrc_t rnext = tile_rsrc(g + 2);
+      const int vnext = tile_voff(g + 2);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) frag[i] = *reinterpret_cast<const f32x4*>(tb + i * 256 + lane * 4);
-    // the tile is in registers: its buffer takes tile g+2 (the explicit wait keeps the DMA behind the reads)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    FVTA_STAMP(8);
-    if (g + 2 < G) issue(buf);
-    FVTA_STAMP(9);
-    load_desc(g + 3);
-    FVTA_STAMP(2);
+      for (int i = 0; i < NB; ++i) next[i] = load_block(rnext, vnext, i);
+    }
+    FVTA_STAMP(1);
     if (first) {
       m_run = -INFINITY;
       l_run = 0.f;
@@ -676,9 +660,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(Attn
       if (n != cur_n) {
         // B operand of MFMA m, j tile jt: lane (col l15, k group kq) holds channels 32m + 4kq + (0..3) and
         // 32m + 16 + 4kq + (0..3) of the wave's slice -- the channels the A lanes of the same k group hold.
-        // (ordinary loads: they retire behind the copies in flight, once per n)
+        // (buffer loads: one lane offset register + scalar offsets)
         cur_n = n;
-        // (buffer loads: one lane offset register + scalar offsets, instead of 32 hoisted 64-bit pointers)
         constexpr int W4c = NW * NB * 4;
         const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<uint16_t*>(a.sv.Qh + (size_t)n * 2 * W4c * 32 * 4), 0, (unsigned)(2 * W4c * 32 * 8), 0x00020000);
@@ -695,14 +678,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(Attn
               typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
               const u32x4 xx = __builtin_shufflevector(x0, x1, 0, 1, 2, 3);
               const half8 v = __builtin_bit_cast(half8, xx);
-              if (pc == 0) bhi[m][jt] = v;
-              else blo[m][jt] = v;
+              if (pc == 0) s_bhi[wave][m * 2 + jt][lane] = v;
+              else s_blo[wave][m * 2 + jt][lane] = v;  // wave-private: written and read by this wave only
             }
         qvalid = a.sv.qvalid[(size_t)n * 2];
         if (tid < 32) s_ct[tid] = a.sv.ct[(size_t)n * JP + tid];  // read after the next barrier
       }
     }
-    const bool allm = s_iallm[it] != 0;  // (LDS: no ordinary global load may sit in the tile loop)
+    FVTA_STAMP(2);
+    const bool allm = s_iallm[it] != 0;
     if (!allm) {
       f32x4 ahh[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       f32x4 axx[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -711,23 +695,24 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(Attn
       for (int m = 0; m < NM; ++m) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+          const int c0 = 16 * (NB * wave + 2 * m + q) + 4 * kq;
           const f32x4 h = frag[2 * m + q];
           if (RMODE == 1) {
-            rt4 += h * rreg[2 * m + q];
+            rt4 += h * *reinterpret_cast<const f32x4*>(&s_vec[0][c0]);
           } else if (RMODE == 2) {
-            rt4 += (h * h) * rreg[2 * m + q];
+            rt4 += (h * h) * *reinterpret_cast<const f32x4*>(&s_vec[1][c0]);
           } else {
-            const f32x4 rh4 = *reinterpret_cast<const f32x4*>(&s_vec[16 * (NB * wave + 2 * m + q) + 4 * kq]);
-            rt4 += h * (rh4 + rreg[2 * m + q] * h);
+            rt4 += h * (*reinterpret_cast<const f32x4*>(&s_vec[0][c0]) + *reinterpret_cast<const f32x4*>(&s_vec[1][c0]) * h);
           }
         }
         half8 hi, lo;
         split_f16x8(frag[2 * m], frag[2 * m + 1], hi, lo);
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
-          ahh[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, bhi[m][jt], ahh[jt], 0, 0, 0);
-          axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, blo[m][jt], axx[jt], 0, 0, 0);
-          axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, bhi[m][jt], axx[jt], 0, 0, 0);
+          const half8 bh = s_bhi[wave][m * 2 + jt][lane];
+          ahh[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, bh, ahh[jt], 0, 0, 0);
+          axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, s_blo[wave][m * 2 + jt][lane], axx[jt], 0, 0, 0);
+          axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, bh, axx[jt], 0, 0, 0);
         }
         // keep the unrolled iterations apart: hoisting every LDS read and split to the top costs ~60 VGPRs
         __builtin_amdgcn_sched_barrier(0);
@@ -742,11 +727,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(Attn
       FVTA_STAMP(3);
       lds_barrier();
       FVTA_STAMP(4);
-      {
+      if (NT <= 512 || wave < 8) {
         // (row, j) of this thread: wave pw & 3 owns rows {pw, 4+pw, 8+pw, 12+pw} so that its 64 lanes read 64
-        // consecutive partial scores; with 8 waves the upper four take the second j tile
-        constexpr int JPT = NT == 512 ? 1 : 2;
-        const int pw = wave & 3, jt0 = NT == 512 ? wave >> 2 : 0;
+        // consecutive partial scores; with 8+ waves waves 4..7 take the second j tile
+        constexpr int JPT = NT >= 512 ? 1 : 2;
+        const int pw = wave & 3, jt0 = NT >= 512 ? wave >> 2 : 0;
         const int row = 4 * kq + pw;
         float rt = 0.f;
 #pragma unroll
@@ -764,10 +749,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(Attn
           for (int v = 0; v < NW; ++v) x += s_part[v][pi];
           x = cosine ? x * rs : x + rt + s_ct[j];
           const bool valid = (qvalid >> j) & 1ull;
-          if (a.a_logits && j < s.JQ) {
-            const int t = s_idx[g * 16 + row];
-            if (t != 0xFFFF) a.a_logits[((size_t)nk * T + t) * s.JQ + j] = valid ? (s.add_tanh ? tanhf(x) : x) : FVTA_NEG;
-          }
           if (valid && x > best) {
             best = x;
             bestj = j;
@@ -777,7 +758,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(Attn
         if (l15 == 0) {
           s_cand_v[jt0][row] = best;
           s_cand_j[jt0][row] = bestj;
-          if (NT != 512) s_cand_v[1][row] = -INFINITY;
+          if (NT < 512) s_cand_v[1][row] = -INFINITY;
         }
       }
     }
@@ -829,29 +810,56 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_rows16(Attn
         part[1] = l_run;
       }
     }
+  };
+
+  if (stamp) {
+    stamps[15] = t_entry;
+    stamps[14] = __builtin_readcyclecounter();
+  }
+  {
+    const __amdgpu_buffer_rsrc_t r0 = tile_rsrc(0);
+    const int v0 = tile_voff(0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) fragA[i] = load_block(r0, v0, i);
+    if (G > 1) {
+      const __amdgpu_buffer_rsrc_t r1 = tile_rsrc(1);
+      const int v1 = tile_voff(1);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) fragB[i] = load_block(r1, v1, i);
+    }
+  }
+  for (int g = 0; g < G; g += 3) {  // (tile, buffer of tile g, buffer that takes tile g + 2)
+    tile(g, fragA, fragC);
+    if (g + 1 < G) tile(g + 1, fragB, fragA);
+    if (g + 2 < G) tile(g + 2, fragC, fragB);
   }
 #undef FVTA_STAMP
 }
 
-// ---- merge: splits -> u[n,k], M, L; softmax over K; h_a.  grid N, 256 threads
+// ---- merge: splits -> u[n,k], M, L; softmax over K; h_a.  grid (N, w/256), 256 threads: one channel per thread
+constexpr int MERGE_MAXP = 2048;  // K * nsplit partials of one n whose weights are cached in LDS
 __global__ __launch_bounds__(256) void attn_merge_kernel(AttnShape s, AttnSaved sv, const float* __restrict__ part,
                                                          float* __restrict__ h_a) {
   __shared__ float s_M[64], s_L[64], s_r[64];
+  __shared__ float s_wt[MERGE_MAXP];  // exp(m_split - M_k) / L_k, 0 for empty splits
   const int n = blockIdx.x, tid = threadIdx.x;
   const int w = s.w, K = s.K, ns = s.nsplit;
+  const size_t pstride = (size_t)(w + 4);
   for (int k = tid; k < K; k += 256) {
-    const float* pp = part + ((size_t)(n * K + k) * ns) * (w + 4);
+    const float* pp = part + ((size_t)(n * K + k) * ns) * pstride;
     float M = -INFINITY;
-    for (int sp = 0; sp < ns; ++sp) M = fmaxf(M, pp[(size_t)sp * (w + 4)]);
+    for (int sp = 0; sp < ns; ++sp) M = fmaxf(M, pp[(size_t)sp * pstride]);
     float L = 0.f;
     for (int sp = 0; sp < ns; ++sp) {
-      const float l = pp[(size_t)sp * (w + 4) + 1];
-      if (l > 0.f) L += l * expf(pp[(size_t)sp * (w + 4)] - M);
+      const float l = pp[(size_t)sp * pstride + 1];
+      if (l > 0.f) L += l * expf(pp[(size_t)sp * pstride] - M);
     }
     s_M[k] = M;
     s_L[k] = L;
-    sv.M[n * K + k] = M;
-    sv.L[n * K + k] = L;
+    if (blockIdx.y == 0) {
+      sv.M[n * K + k] = M;
+      sv.L[n * K + k] = L;
+    }
   }
   __syncthreads();
   if (tid == 0) {  // outer softsel over K (model_v2.py:278)
@@ -864,25 +872,37 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnShape s, AttnSaved 
     }
     for (int k = 0; k < K; ++k) {
       s_r[k] /= sum;
-      sv.r[n * K + k] = s_r[k];
+      if (blockIdx.y == 0) sv.r[n * K + k] = s_r[k];
     }
   }
+  const bool cached = K * ns <= MERGE_MAXP;
+  if (cached)
+    for (int i = tid; i < K * ns; i += 256) {
+      const int k = i / ns;
+      const float* pp = part + ((size_t)n * K * ns + i) * pstride;
+      s_wt[i] = pp[1] > 0.f ? expf(pp[0] - s_M[k]) : 0.f;
+    }
   __syncthreads();
-  for (int c = tid; c < w; c += 256) {
-    float ha = 0.f;
-    for (int k = 0; k < K; ++k) {
-      const float* pp = part + ((size_t)(n * K + k) * ns) * (w + 4);
-      float u = 0.f;
-      for (int sp = 0; sp < ns; ++sp) {
-        const float l = pp[(size_t)sp * (w + 4) + 1];
-        if (l > 0.f) u += pp[(size_t)sp * (w + 4) + 4 + c] * expf(pp[(size_t)sp * (w + 4)] - s_M[k]);
+  const int c = blockIdx.y * 256 + tid;
+  if (c >= w) return;
+  float ha = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float* pp = part + ((size_t)(n * K + k) * ns) * pstride;
+    float u = 0.f;
+    for (int sp = 0; sp < ns; ++sp) {
+      float wt;
+      if (cached) {
+        wt = s_wt[k * ns + sp];
+      } else {
+        wt = pp[(size_t)sp * pstride + 1] > 0.f ? expf(pp[(size_t)sp * pstride] - s_M[k]) : 0.f;
       }
-      u /= s_L[k];
-      sv.u[((size_t)n * K + k) * w + c] = u;
-      ha += s_r[k] * u;
+      if (wt != 0.f) u += pp[(size_t)sp * pstride + 4 + c] * wt;  // (empty splits hold no vector)
     }
-    h_a[(size_t)n * w + c] = ha;
+    u /= s_L[k];
+    sv.u[((size_t)n * K + k) * w + c] = u;
+    ha += s_r[k] * u;
   }
+  h_a[(size_t)n * w + c] = ha;
 }
 
 // JT = 1 (JQ <= 32) and JT = 2 shapes; the JT = 2 shape of a wide row halves SCW to keep LDS under 160 KB
@@ -940,7 +960,7 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
   AttnSaved sv = attn_saved_view(s, saved);
   hipLaunchKernelGGL(attn_vecs_kernel, dim3((s.w + 255) / 256), dim3(256), 0, stream, W, s.w, s.simi, s.feat_order,
                      sv.vecs);
-  hipLaunchKernelGGL(attn_prep_q_kernel, dim3(s.N), dim3(256), 0, stream, s, sv, hq, qmask, b);
+  hipLaunchKernelGGL(attn_prep_q_kernel, dim3(s.N, s.W4 * s.JP >= 4096 ? 8 : 1), dim3(256), 0, stream, s, sv, hq, qmask, b);
   hipLaunchKernelGGL(attn_compact_kernel, dim3(s.N * s.K), dim3(256), 0, stream, s, sv, hmask);
   FVTA_CHECK_LAUNCH("attn_prep");
   if (a_logits && use_mask) {
@@ -960,14 +980,20 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
   }
   fvta_prof_begin(FVTA_PROF_ATTN_FWD_MAIN, stream);
   const char* exact = getenv("FVTA_ATTN_EXACT");
-  const bool rows16 = s.JT == 1 && s.w >= 128 && s.w <= 1024 && !(exact && exact[0] == '1');
+  // (the full logit tensor is an inspection output: only the general kernel writes it)
+  const bool rows16 = s.JT == 1 && s.w >= 128 && s.w <= 1024 && !a_logits && !(exact && exact[0] == '1');
   if (rows16) {
     // a workgroup streams `ipw` consecutive items: about one workgroup per CU, bounded by its LDS row list
     const int nitems = s.nsplit * s.N * s.K;
     const int tiles_per_max = (((s.T + 15) / 16) + s.nsplit - 1) / s.nsplit;
-    int ipw = (nitems + 255) / 256;
-    if (ipw > R16_MAXT / tiles_per_max) ipw = R16_MAXT / tiles_per_max;
-    if (ipw > R16_MAXI) ipw = R16_MAXI;
+    int cap = R16_MAXT / tiles_per_max;
+    if (cap > R16_MAXI) cap = R16_MAXI;
+    if (cap < 1) cap = 1;
+    int ipw = 1;
+    for (int rounds = 1;; ++rounds) {  // whole rounds of 256 workgroups: no half-empty last round
+      ipw = (nitems + 256 * rounds - 1) / (256 * rounds);
+      if (ipw <= cap) break;
+    }
     if (ipw < 1) ipw = 1;
     a.ipw = ipw;
     const int nwg = (nitems + ipw - 1) / ipw;
@@ -997,7 +1023,7 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
   }
   fvta_prof_end(FVTA_PROF_ATTN_FWD_MAIN, 1, stream);
   FVTA_CHECK_LAUNCH("attn_fwd_main");
-  hipLaunchKernelGGL(attn_merge_kernel, dim3(s.N), dim3(256), 0, stream, s, sv, a.part, h_a);
+  hipLaunchKernelGGL(attn_merge_kernel, dim3(s.N, (s.w + 255) / 256), dim3(256), 0, stream, s, sv, a.part, h_a);
   FVTA_CHECK_LAUNCH("attn_merge");
   return FVTA_OK;
 }

@@ -17,9 +17,10 @@ for _ in range(3):
     op.forward(h, q, hm, qm, W, b)
 torch.cuda.synchronize()
 st = op.work[(32 << 20):(32 << 20) + 64 * 16 * 8].view(torch.int64).view(64, 16).cpu()
-names = ["wait", "fragrd+issue", "mfma+rt", "bar1", "post", "bar2", "softmax+u"]
+names = ["issue_next", "first/B", "mfma+rt", "bar1", "post", "bar2", "softmax+u"]
 print("tile  " + "  ".join("%12s" % n for n in names) + "   total(next start - start)")
 for gi in range(2, 40):
     d = [(st[gi, k + 1] - st[gi, k]).item() for k in range(7)]
-    print("%4d  " % gi + "  ".join("%12d" % x for x in d) + "   %d" % (st[gi + 1, 0] - st[gi, 0]).item()
-          + "   [fragrd %d issue %d desc %d]" % ((st[gi, 8] - st[gi, 1]).item(), (st[gi, 9] - st[gi, 8]).item(), (st[gi, 2] - st[gi, 9]).item()))
+    print("%4d  " % gi + "  ".join("%12d" % x for x in d) + "   %d" % (st[gi + 1, 0] - st[gi, 0]).item())
+print("prologue cycles (entry -> tile loop):", (st[0, 14] - st[0, 15]).item(), " tile0 start - entry:", (st[0, 0] - st[0, 15]).item(),
+      " tiles 0..49:", (st[49, 0] - st[0, 0]).item())
