@@ -429,9 +429,10 @@ class Model:
         """model_v2.py:649-1096 on the loaded batch.  Returns yp (device tensor)."""
         P = self.params
         main = torch.cuda.current_stream()
-        for cell, G in L.groups.items():
-            # the photo cell (few, short-batch, latency-bound launches) runs beside the text cell on a side
-            # HIP stream: the two write disjoint rows of the arena and meet again before the attention
+        # the photo cell (few rows, one short latency-bound launch per photo) runs beside the text cell on a side
+        # HIP stream: the two write disjoint rows of the arena and meet again before the attention.  It is
+        # enqueued FIRST -- a side stream that waits for main after the text launches are queued runs after them.
+        for cell, G in sorted(L.groups.items(), key=lambda kv: kv[0] != "image"):
             side = self._side if (cell == "image" and "text" in L.groups) else None
             if side is not None:
                 side.wait_stream(main)
@@ -508,7 +509,7 @@ class Model:
             L.att.backward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, d_hall, d_hq, daW, dab,
                            accumulate=2)
         main = torch.cuda.current_stream()
-        for cell, G in L.groups.items():
+        for cell, G in sorted(L.groups.items(), key=lambda kv: kv[0] != "image"):   # side-stream cell first, see forward
             kf, bf, kb, bb = self._cell_params(cell)
             dkf, dbf, dkb, dbb = self._cell_params(cell, grad=True)
             if need_dx and G.dx is None:

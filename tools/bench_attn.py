@@ -2,13 +2,13 @@
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 from fvta_memexqa_amd import ops
-N, K, T, JQ, w = 64, 40, 150, 30, 1024
+N, K, T, JQ, w = 64, 6, 1200, 30, 1024  # the metric shape: K = 5 text streams + photo stream, T = 40 photos x 30
 g = torch.Generator(device="cuda").manual_seed(0)
 h = torch.randn(N, K, T, w, device="cuda", generator=g) * 0.5
 q = torch.randn(N, JQ, w, device="cuda", generator=g) * 0.5
 W = torch.randn(2 * w, device="cuda", generator=g) * 0.1
 b = torch.zeros(1, device="cuda")
-hm = torch.ones(N, K, T, dtype=torch.uint8, device="cuda")
+hm = torch.ones(N, K, T, dtype=torch.uint8, device="cuda"); hm[:, 5, 40:] = 0
 qm = torch.ones(N, JQ, dtype=torch.uint8, device="cuda")
 op = ops.FocalAttention(N, K, T, JQ, w, 2, True)
 def timeit(f, n=5):
