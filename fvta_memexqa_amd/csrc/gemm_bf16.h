@@ -188,25 +188,32 @@ struct KMajorSrc {
 // Every wave issues exactly A_GLDS + B_GLDS = 6 wave-instructions per tile, so "all but the newest
 // tile have landed" is s_waitcnt vmcnt(6).  The barrier after the wait both publishes tile t to all
 // waves and retires every wave's reads of stage (t-1)%3, which the next issue overwrites.
+// `stamps` (diagnostics, normally null): shader-clock stamps per k-tile: [4t] before the wait, [4t+1] after it,
+// [4t+2] after the barrier + next issue, [4t+3] after the MFMAs were issued.
 template <bool KMAJOR, class Issue>
-__device__ __forceinline__ void glds_mainloop(MmaB& mma, Issue&& issue, int ntiles, bf16_t* smem) {
+__device__ __forceinline__ void glds_mainloop(MmaB& mma, Issue&& issue, int ntiles, bf16_t* smem,
+                                              unsigned long long* stamps = nullptr) {
   auto a_stage = [&](int t) { return smem + (t % TileCfg::STAGES) * TileCfg::STAGE_ELEMS; };
   if (ntiles <= 0) return;
   issue(0, a_stage(0), a_stage(0) + TileCfg::A_ELEMS);
   if (ntiles > 1) issue(1, a_stage(1), a_stage(1) + TileCfg::A_ELEMS);
   for (int t = 0; t < ntiles; ++t) {
+    if (stamps) stamps[4 * t] = __builtin_readcyclecounter();
     if (t + 1 < ntiles)
       wait_vmcnt<TileCfg::A_GLDS + TileCfg::B_GLDS>();
     else
       wait_vmcnt<0>();
+    if (stamps) stamps[4 * t + 1] = __builtin_readcyclecounter();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (t + 2 < ntiles) issue(t + 2, a_stage(t + 2), a_stage(t + 2) + TileCfg::A_ELEMS);
+    if (stamps) stamps[4 * t + 2] = __builtin_readcyclecounter();
     const bf16_t* As = a_stage(t);
     if (KMAJOR)
       mma.compute_kmajor(As, As + TileCfg::A_ELEMS);
     else
       mma.compute_rows(As, As + TileCfg::A_ELEMS);
+    if (stamps) stamps[4 * t + 3] = __builtin_readcyclecounter();
   }
 }
 

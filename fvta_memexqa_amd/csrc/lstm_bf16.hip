@@ -75,6 +75,8 @@ void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, in
   hipLaunchKernelGGL(cvt_x_kernel, dim3((B + 3) / 4, J, 2), dim3(256), 0, s, pv, x, xs, B, J, in, in_i);
 }
 
+__device__ unsigned long long g_lstm_stamps[512];  // diagnostics (FVTA_DEBUG_SKIP & 32768)
+
 // ------------------------------------------------------------ forward step --
 // z = [xs_t | hs_{t-1}] * wt^T over the 4 gate strips of 32 units.  grid (pad8(ceil(B/256)), d/32, 2)
 __global__ __launch_bounds__(256, 2) void lstm_step_fwd_bf16(StepArgs a) {
@@ -89,6 +91,19 @@ __global__ __launch_bounds__(256, 2) void lstm_step_fwd_bf16(StepArgs a) {
   const int d = a.d, t = a.t, in_i = a.Kp - a.d;
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
   s_oo[tid] = (m0 + tid < nact) ? a.plan.oo[trow + m0 + tid] : -1;
+  if (a.dbg & (4096 | 8192 | 16384)) {  // EXPERIMENT: put the two workgroups of a CU out of phase
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    bool late = false;
+    if (a.dbg & 4096) late = (lin >> 8) & 1;
+    if (a.dbg & 8192) late = (lin >> 3) & 1;
+    if (a.dbg & 16384) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      late = hw & 1;  // wave slot parity on its SIMD
+    }
+    if (late && lin < 512)
+      for (int i = 0; i < 5; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   MmaB mma;
   mma.init(tid);
@@ -114,9 +129,27 @@ __global__ __launch_bounds__(256, 2) void lstm_step_fwd_bf16(StepArgs a) {
       ah.issue(rh, As, mma.wave, (tile - nx) * 64);
     bw.issue(rw, Bs, mma.wave, tile * 64);
   };
-  if (!(a.dbg & 1)) glds_mainloop<false>(mma, issue, nt, smem_h);
+  // FVTA_DEBUG_SKIP & 32768: one wave of one workgroup stamps the shader clock (tools/lstm_phases.py)
+  const int lin_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  unsigned long long* st = ((a.dbg & 32768) && lin_wg == ((a.dbg >> 16) & 0xFFF) && tid == 0 && a.t == 5) ? g_lstm_stamps : nullptr;
+  if (st) st[0] = __builtin_readcyclecounter();
+  if (!(a.dbg & 1)) glds_mainloop<false>(mma, issue, nt, smem_h, st ? st + 8 : nullptr);
+  if (st) st[1] = __builtin_readcyclecounter();
   __syncthreads();  // s_oo visible (and, with the k-loop skipped, written) before the epilogue reads it
   if (!(a.dbg & 2)) lstm_gate_epilogue(mma, a, dir, m0, u0, nact, trow, s_oo);
+  if (st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[2] = __builtin_readcyclecounter();
+    st[3] = nt;
+  }
+}
+
+int lstm_read_stamp(int i, long long* v) {
+  if (i < 0 || i >= 512) return FVTA_ERR_INVALID_ARG;
+  unsigned long long x = 0;
+  if (hipMemcpyFromSymbol(&x, HIP_SYMBOL(g_lstm_stamps), 8, (size_t)i * 8, hipMemcpyDeviceToHost) != hipSuccess) return FVTA_ERR_INVALID_ARG;
+  *v = (long long)x;
+  return FVTA_OK;
 }
 
 static constexpr int FWD_LDS = TileCfg::LDS_BYTES + 256 * 8;
