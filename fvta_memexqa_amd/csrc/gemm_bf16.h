@@ -47,23 +47,33 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-struct TileCfg {
-  static constexpr int BM = 256, BN = 128, BK = 32, STAGES = 3, NT = 256;
+// WN = wave columns: 1 -> 256 x 128 block tile, 4 waves, 72 KiB (two workgroups per CU);
+//                    2 -> 256 x 256 block tile, 8 waves (4 x 2), 96 KiB (one workgroup per CU).  The wave tile is
+// 64 x 128 either way; the wider block tile re-reads the A operand half as often (the operand DMA runs at the CU's
+// address-unit rate, ~24 B/clk, which a 256 x 128 tile saturates before the matrix pipe).
+template <int WN>
+struct TileCfgT {
+  static constexpr int BM = 256, BN = 128 * WN, BK = 32, STAGES = 3, NT = 256 * WN;
   static constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;  // per stage
   static constexpr int STAGE_ELEMS = A_ELEMS + B_ELEMS;
-  static constexpr int LDS_BYTES = STAGES * STAGE_ELEMS * 2;  // 73,728
-  static constexpr int A_GLDS = A_ELEMS * 2 / 1024 / 4;       // wave-instructions per wave per tile: 4
-  static constexpr int B_GLDS = B_ELEMS * 2 / 1024 / 4;       // 2
+  static constexpr int LDS_BYTES = STAGES * STAGE_ELEMS * 2;        // 73,728 (WN = 1)
+  static constexpr int A_GLDS = A_ELEMS * 2 / 1024 / (4 * WN);      // wave-instructions per wave per tile: 4 / 2
+  static constexpr int B_GLDS = B_ELEMS * 2 / 1024 / (4 * WN);      // 2 / 2
 };
+typedef TileCfgT<1> TileCfg;
 
 // ---- accumulators + fragment reads -------------------------------------------------------------
-struct MmaB {
-  static constexpr int TM = 2, TN = 4, WAVES_M = 4, WAVES_N = 1, BM = TileCfg::BM, BN = TileCfg::BN;
+template <int WN>
+struct MmaBT {
+  typedef TileCfgT<WN> Cfg;
+  static constexpr int TM = 2, TN = 4, WAVES_M = 4, WAVES_N = 1, BM = Cfg::BM, BN = Cfg::BN;  // WAVES_N: per wave column
   f32x16 acc[TM][TN];
-  int wave, lane, l31, hf;
+  int wave_all, wave, wn, lane, l31, hf;  // wave = row of the 4 x WN wave grid (the M position), wn = its column
 
   __device__ __forceinline__ void init(int tid) {
-    wave = tid >> 6;
+    wave_all = tid >> 6;
+    wave = wave_all & 3;
+    wn = wave_all >> 2;
     lane = tid & 63;
     l31 = lane & 31;
     hf = lane >> 5;
@@ -88,7 +98,7 @@ struct MmaB {
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int r = j * 32 + l31;
+        const int r = wn * 128 + j * 32 + l31;
         b[j].f = *reinterpret_cast<const f32x4*>(Bs + r * 32 + ((c ^ ((r >> 2) & 3)) << 3));
       }
 #pragma unroll
@@ -127,7 +137,7 @@ struct MmaB {
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = tr_frag<BM>(As, ks * 16, wave * 64 + i * 32);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = tr_frag<BN>(Bs, ks * 16, j * 32);
+      for (int j = 0; j < TN; ++j) b[j] = tr_frag<BN>(Bs, ks * 16, wn * 128 + j * 32);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -136,8 +146,9 @@ struct MmaB {
   }
 
   __device__ __forceinline__ int row_of(int i, int r) const { return wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf; }
-  __device__ __forceinline__ int col_of(int j) const { return j * 32 + l31; }
+  __device__ __forceinline__ int col_of(int j) const { return wn * 128 + j * 32 + l31; }
 };
+typedef MmaBT<1> MmaB;
 
 // ---- per-lane DMA source offsets ---------------------------------------------------------------
 // Row image of ROWS rows: wave-instruction n (0 .. ROWS/16-1) fills LDS chunks [64n, 64n+64): unit
@@ -190,9 +201,10 @@ struct KMajorSrc {
 // waves and retires every wave's reads of stage (t-1)%3, which the next issue overwrites.
 // `stamps` (diagnostics, normally null): shader-clock stamps per k-tile: [4t] before the wait, [4t+1] after it,
 // [4t+2] after the barrier + next issue, [4t+3] after the MFMAs were issued.
-template <bool KMAJOR, class Issue>
-__device__ __forceinline__ void glds_mainloop(MmaB& mma, Issue&& issue, int ntiles, bf16_t* smem,
+template <bool KMAJOR, class Mma, class Issue>
+__device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntiles, bf16_t* smem,
                                               unsigned long long* stamps = nullptr) {
+  typedef typename Mma::Cfg TileCfg;
   auto a_stage = [&](int t) { return smem + (t % TileCfg::STAGES) * TileCfg::STAGE_ELEMS; };
   if (ntiles <= 0) return;
   issue(0, a_stage(0), a_stage(0) + TileCfg::A_ELEMS);

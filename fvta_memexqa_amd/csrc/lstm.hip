@@ -582,6 +582,10 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
     f.in = in;
     f.d = dd;
     f.in_i = in_internal(d);
+    {
+      const char* e = getenv("FVTA_LSTM_STAMP_BWD");
+      f.stamp_wg = e ? atoi(e) : -1;
+    }
     for (int t = J - 1; t >= 0; --t) {
       f.t = t;
       launch_bwd_fused_bf16(f, stream);

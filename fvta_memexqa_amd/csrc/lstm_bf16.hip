@@ -17,6 +17,7 @@
 // Gates, c, h, accumulators and weight-gradient slabs stay fp32; the saved gate
 // activations are bf16 in this engine.
 #include "gemm_bf16.h"
+#include <type_traits>
 #include "lstm_common.h"
 
 namespace fvta {
@@ -78,65 +79,70 @@ void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, in
 __device__ unsigned long long g_lstm_stamps[512];  // diagnostics (FVTA_DEBUG_SKIP & 32768)
 
 // ------------------------------------------------------------ forward step --
-// z = [xs_t | hs_{t-1}] * wt^T over the 4 gate strips of 32 units.  grid (pad8(ceil(B/256)), d/32, 2)
-__global__ __launch_bounds__(256, 2) void lstm_step_fwd_bf16(StepArgs a) {
+// z = [xs_t | hs_{t-1}] * wt^T over the 4 gate strips of 32 units per wave column.
+// grid (pad8(ceil(B/256)), d/(32 WN), 2), 256 WN threads
+template <int WN>
+__global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_step_fwd_bf16(StepArgs a) {
+  typedef TileCfgT<WN> Cfg;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
-  int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + TileCfg::STAGES * TileCfg::STAGE_ELEMS);  // [256], same array
+  int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + Cfg::STAGES * Cfg::STAGE_ELEMS);  // [256], same array
   const int tid = threadIdx.x;
   const int dir = blockIdx.z;
-  const int m0 = blockIdx.x * TileCfg::BM;
+  const int m0 = blockIdx.x * Cfg::BM;
   const int nact = a.plan.nactive[a.t];
   if (m0 >= nact) return;
-  const int u0 = blockIdx.y * 32;
+  const int ub = blockIdx.y * 32 * WN;  // first unit of the block; wave column wn owns units ub + 32 wn ..
   const int d = a.d, t = a.t, in_i = a.Kp - a.d;
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
-  s_oo[tid] = (m0 + tid < nact) ? a.plan.oo[trow + m0 + tid] : -1;
-  if (a.dbg & (4096 | 8192 | 16384)) {  // EXPERIMENT: put the two workgroups of a CU out of phase
-    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    bool late = false;
-    if (a.dbg & 4096) late = (lin >> 8) & 1;
-    if (a.dbg & 8192) late = (lin >> 3) & 1;
-    if (a.dbg & 16384) {
-      unsigned hw;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      late = hw & 1;  // wave slot parity on its SIMD
-    }
-    if (late && lin < 512)
-      for (int i = 0; i < 5; ++i) __builtin_amdgcn_s_sleep(127);
-  }
+  if (tid < 256) s_oo[tid] = (m0 + tid < nact) ? a.plan.oo[trow + m0 + tid] : -1;
 
-  MmaB mma;
+  MmaBT<WN> mma;
   mma.init(tid);
-  // A rows m0.. of xs[dir][t] (nact rows) and of hs[dir][t-1]; B rows = the 4 gate strips of wt
+  const int u0 = ub + 32 * mma.wn;
+  // A rows m0.. of xs[dir][t] (nact rows) and of hs[dir][t-1]; B rows = the 4 gate strips of wt per wave column
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xs + trow * in_i, (unsigned)nact * in_i * 2);
   const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (t > 0 ? trow - a.B : trow) * d, (unsigned)nact * d * 2);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wt[dir], (unsigned)(4 * d) * a.Kp * 2);
-  RowSrc<TileCfg::A_GLDS> ax, ah;
-  RowSrc<TileCfg::B_GLDS> bw;
-  ax.setup(mma.wave, mma.lane, m0, nact, in_i * 2);
-  ah.setup(mma.wave, mma.lane, m0, nact, d * 2);
+  RowSrc<Cfg::A_GLDS> ax, ah;
+  RowSrc<Cfg::B_GLDS> bw;
+  ax.setup(mma.wave_all, mma.lane, m0, nact, in_i * 2);
+  ah.setup(mma.wave_all, mma.lane, m0, nact, d * 2);
 #pragma unroll
-  for (int j = 0; j < TileCfg::B_GLDS; ++j) {  // B row r (0..127) = gate strip r>>5, unit u0 + (r&31)
-    const int U = (mma.wave * TileCfg::B_GLDS + j) * 64 + mma.lane;
+  for (int j = 0; j < Cfg::B_GLDS; ++j) {  // B row r = wave column r>>7, gate strip (r>>5)&3, unit ub + 32 (r>>7) + (r&31)
+    const int U = (mma.wave_all * Cfg::B_GLDS + j) * 64 + mma.lane;
     const int r = U >> 2, c = (U & 3) ^ ((r >> 2) & 3);
-    bw.voff[j] = (unsigned)((r >> 5) * d + u0 + (r & 31)) * (unsigned)(a.Kp * 2) + 16u * c;
+    bw.voff[j] = (unsigned)(((r >> 5) & 3) * d + ub + 32 * (r >> 7) + (r & 31)) * (unsigned)(a.Kp * 2) + 16u * c;
   }
   const int nx = in_i / 32, nt = (t == 0) ? nx : nx + d / 32;
   auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
     if (tile < nx)
-      ax.issue(rx, As, mma.wave, tile * 64);
+      ax.issue(rx, As, mma.wave_all, tile * 64);
     else
-      ah.issue(rh, As, mma.wave, (tile - nx) * 64);
-    bw.issue(rw, Bs, mma.wave, tile * 64);
+      ah.issue(rh, As, mma.wave_all, (tile - nx) * 64);
+    bw.issue(rw, Bs, mma.wave_all, tile * 64);
   };
   // FVTA_DEBUG_SKIP & 32768: one wave of one workgroup stamps the shader clock (tools/lstm_phases.py)
   const int lin_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
   unsigned long long* st = ((a.dbg & 32768) && lin_wg == ((a.dbg >> 16) & 0xFFF) && tid == 0 && a.t == 5) ? g_lstm_stamps : nullptr;
   if (st) st[0] = __builtin_readcyclecounter();
+  // c_{t-1} of the wave's rows, row-contiguous (16 B per lane), requested before the k-loop hides their latency
+  f32x4 cprev[2][4];
+  if (t > 0) {
+    const float* src = a.cs ? a.cs + (trow - a.B) * (size_t)d : a.cstate + (size_t)dir * a.B * d;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int i = min(m0 + mma.wave * 64 + ti * 32 + it * 8 + (mma.lane >> 3), nact - 1);  // clamped: valid row
+        cprev[ti][it] = *reinterpret_cast<const f32x4*>(src + (size_t)i * d + u0 + 4 * (mma.lane & 7));
+      }
+  }
   if (!(a.dbg & 1)) glds_mainloop<false>(mma, issue, nt, smem_h, st ? st + 8 : nullptr);
   if (st) st[1] = __builtin_readcyclecounter();
-  __syncthreads();  // s_oo visible (and, with the k-loop skipped, written) before the epilogue reads it
-  if (!(a.dbg & 2)) lstm_gate_epilogue(mma, a, dir, m0, u0, nact, trow, s_oo);
+  __syncthreads();  // s_oo visible; every wave is done with the stage buffers, which become the epilogue's scratch
+  if (!(a.dbg & 2))
+    lstm_gate_epilogue_staged(mma, a, dir, m0, u0, nact, trow, s_oo, cprev,
+                              reinterpret_cast<char*>(smem_h) + mma.wave_all * 9216);
   if (st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     st[2] = __builtin_readcyclecounter();
@@ -155,9 +161,24 @@ int lstm_read_stamp(int i, long long* v) {
 static constexpr int FWD_LDS = TileCfg::LDS_BYTES + 256 * 8;
 
 void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s) {
-  allow_big_lds(lstm_step_fwd_bf16, FWD_LDS);
-  const dim3 grid(pad8((a.B + TileCfg::BM - 1) / TileCfg::BM), a.d / 32, 2);
-  hipLaunchKernelGGL(lstm_step_fwd_bf16, grid, dim3(256), FWD_LDS, s, a);
+  // the 256 x 256 tile (8 waves) halves the A-operand re-reads; it needs whole 64-unit column blocks
+  // (measured on the metric shape: no faster than two 256 x 128 workgroups per CU, whose k-loops and epilogues
+  // overlap better -- kept selectable: FVTA_LSTM_WIDE_TILE=1)
+  static const bool wide = [] {
+    const char* e = getenv("FVTA_LSTM_WIDE_TILE");
+    return e && e[0] == '1';
+  }();
+  if (a.d % 64 == 0 && wide) {
+    constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
+    allow_big_lds(lstm_step_fwd_bf16<2>, LDS);
+    const dim3 grid(pad8((a.B + 255) / 256), a.d / 64, 2);
+    hipLaunchKernelGGL(lstm_step_fwd_bf16<2>, grid, dim3(512), LDS, s, a);
+  } else {
+    constexpr int LDS = TileCfgT<1>::LDS_BYTES + 256 * 8;
+    allow_big_lds(lstm_step_fwd_bf16<1>, LDS);
+    const dim3 grid(pad8((a.B + 255) / 256), a.d / 32, 2);
+    hipLaunchKernelGGL(lstm_step_fwd_bf16<1>, grid, dim3(256), LDS, s, a);
+  }
 }
 
 // ----------------------------------------------------------- backward step --
@@ -237,6 +258,9 @@ __global__ __launch_bounds__(256, 2) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
   s_oo[tid] = a.plan.oo[trow + min(m0 + tid, nact - 1)];  // clamped: always a valid row
   MmaB mma;
   mma.init(tid);
+  // FVTA_DEBUG_SKIP & 65536-style diagnostics: env FVTA_LSTM_STAMP_BWD=<workgroup> stamps step t = 5 (tools/lstm_phases.py)
+  const int lin_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  unsigned long long* st = (a.stamp_wg >= 0 && lin_wg == a.stamp_wg && tid == 0 && t == 5) ? g_lstm_stamps : nullptr;
   if (m0 < nnext) {
     const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + (trow + a.B) * (size_t)K, (unsigned)nnext * K * 2);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir] + (size_t)a.in_i * K, (unsigned)d * K * 2);  // the h rows of wb
@@ -248,9 +272,14 @@ __global__ __launch_bounds__(256, 2) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
       az.issue(rz, As, mma.wave, tile * 64);
       bw.issue(rw, Bs, mma.wave, tile * 64);
     };
-    glds_mainloop<false>(mma, issue, K / 32, smem_h);
+    if (st) st[0] = __builtin_readcyclecounter();
+    glds_mainloop<false>(mma, issue, K / 32, smem_h, st ? st + 8 : nullptr);
+    if (st) st[1] = __builtin_readcyclecounter();
   }
   __syncthreads();
+  // (An LDS-staged, row-contiguous version of this epilogue -- as in the forward step -- was measured and is NOT
+  // faster here: the tile's epilogue moves 36 B per (row, unit), 484 MB per launch, and the kernel already runs at
+  // ~4.2 TB/s; it is bound by HBM and by the latency of these loads, not by the number of VMEM instructions.)
   const float* __restrict__ cs_t = a.cs + trow * d;
   const float* __restrict__ cs_p = a.cs + (trow - a.B) * d;  // step t-1 (unused at t == 0)
   float* __restrict__ dcs = a.dc + (size_t)dir * a.B * d;
@@ -292,6 +321,11 @@ __global__ __launch_bounds__(256, 2) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
         }
       }
     }
+  if (st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[2] = __builtin_readcyclecounter();
+    st[3] = K / 32;
+  }
 }
 
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {

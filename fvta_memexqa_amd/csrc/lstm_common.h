@@ -232,6 +232,131 @@ __device__ __forceinline__ void lstm_gate_epilogue(const Mma& mma, const StepArg
 }
 #endif
 
+#ifdef __HIPCC__
+// The same gate math with every global access staged through LDS (bf16 engine).  In the MFMA C layout a lane holds
+// ONE unit of 16 rows, so the direct epilogue above moves 4 (or 2) bytes per lane and instruction: 160 VMEM
+// instructions per wave and tile.  The CU's address unit takes ~40-50 cycles per VMEM wave-instruction whatever its
+// width, which made the epilogue as long as the k-loop.  Here a wave transposes each 32-row x 32-unit plane through
+// a private LDS scratch (scr, >= 8704 B per wave, the k-loop's stage buffers after the closing barrier) and moves
+// 16 bytes per lane: 44 VMEM instructions per wave and tile.
+//   cprev[ti][it]: c_{t-1} of rows ti*32 + it*8 + (lane>>3), units 4*(lane&7)..+3 -- loaded by the caller BEFORE the
+//   k-loop (latency hidden), ignored when t == 0.
+template <class Mma>
+__device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const StepArgs& a, int dir, int m0, int u0,
+                                                          int nact, size_t trow, const int64_t* s_oo,
+                                                          const f32x4 (&cprev)[2][4], char* scr) {
+  static_assert(Mma::TN == 4 && Mma::WAVES_N == 1 && Mma::TM == 2, "wave tile: 64 rows x the four gate strips");
+  constexpr int LDP = 36;  // floats per staged fp32 row (32 + pad, keeps 16-byte alignment)
+  const int d = a.d, t = a.t, lane = mma.lane;
+  const float* __restrict__ bias = a.bias[dir];
+  const int u = u0 + mma.l31;
+  const float bi = bias[u], bj = bias[d + u], bf = bias[2 * d + u], bo = bias[3 * d + u];
+  float* pl = reinterpret_cast<float*>(scr);
+  bf16_t* plh = reinterpret_cast<bf16_t*>(scr);
+  const int io_row = lane >> 3, io_c4 = lane & 7;  // fp32 planes: 8 lanes x 16 B per row, 8 rows per instruction
+  auto wave_sync = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    const int wrow0 = mma.wave * 64 + ti * 32;  // first tile row of this 32-row half
+    // ---- c_{t-1}: row-contiguous registers -> LDS -> MFMA layout
+    float cp[16];
+    if (t > 0) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) *reinterpret_cast<f32x4*>(&pl[(it * 8 + io_row) * LDP + 4 * io_c4]) = cprev[ti][it];
+      wave_sync();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cp[r] = pl[((r & 3) + 8 * (r >> 2) + 4 * mma.hf) * LDP + mma.l31];
+      wave_sync();
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cp[r] = 0.f;
+    }
+    float cv[16], hv[16];
+    bf16x4 gv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float ig = fvta_sigmoid(mma.acc[ti][0][r] + bi);
+      const float jg = fvta_tanh(mma.acc[ti][1][r] + bj);
+      const float fg = fvta_sigmoid(mma.acc[ti][2][r] + bf + 1.0f);  // forget_bias
+      const float og = fvta_sigmoid(mma.acc[ti][3][r] + bo);
+      cv[r] = cp[r] * fg + ig * jg;
+      hv[r] = fvta_tanh(cv[r]) * og;
+      gv[r][0] = (short)f2bf(ig);
+      gv[r][1] = (short)f2bf(jg);
+      gv[r][2] = (short)f2bf(fg);
+      gv[r][3] = (short)f2bf(og);
+    }
+    // ---- c_t -> cs (training) or the rolling cstate
+    {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pl[((r & 3) + 8 * (r >> 2) + 4 * mma.hf) * LDP + mma.l31] = cv[r];
+      wave_sync();
+      float* dst = a.cs ? a.cs + trow * d : a.cstate + (size_t)dir * a.B * d;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int lr = it * 8 + io_row, i = m0 + wrow0 + lr;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&pl[lr * LDP + 4 * io_c4]);
+        if (i < nact) *reinterpret_cast<f32x4*>(dst + (size_t)i * d + u0 + 4 * io_c4) = v;
+      }
+      wave_sync();
+    }
+    // ---- h_t -> the caller's output rows (fp32)
+    {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pl[((r & 3) + 8 * (r >> 2) + 4 * mma.hf) * LDP + mma.l31] = hv[r];
+      wave_sync();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int lr = it * 8 + io_row;
+        const int64_t oo = s_oo[wrow0 + lr];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&pl[lr * LDP + 4 * io_c4]);
+        if (oo >= 0) {
+          float* o = a.out + oo + u0 + 4 * io_c4;
+          if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+            *reinterpret_cast<f32x4*>(o) = v;
+          } else {  // an output row that is not 16-byte aligned
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+          }
+        }
+      }
+      wave_sync();
+    }
+    // ---- bf16 shadow of h_t (next step's MFMA operand): 4 lanes x 16 B per row, 16 rows per instruction
+    if (a.hs) {
+      constexpr int LDH = 40;  // bf16 per staged row (32 + pad)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) plh[((r & 3) + 8 * (r >> 2) + 4 * mma.hf) * LDH + mma.l31] = f2bf(hv[r]);
+      wave_sync();
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int lr = it * 16 + (lane >> 2), c8 = lane & 3, i = m0 + wrow0 + lr;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&plh[lr * LDH + 8 * c8]);
+        if (i < nact) *reinterpret_cast<f32x4*>(a.hs + (trow + i) * d + u0 + 8 * c8) = v;
+      }
+      wave_sync();
+    }
+    // ---- gates, unit-major [row][u][i,j,f,o] bf16: 16 lanes x 16 B per row, 4 rows per instruction
+    if (a.gatesb) {
+      constexpr int LDG = 136;  // bf16 per staged row (128 + pad)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        *reinterpret_cast<bf16x4*>(&plh[((r & 3) + 8 * (r >> 2) + 4 * mma.hf) * LDG + 4 * mma.l31]) = gv[r];
+      wave_sync();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int lr = it * 4 + (lane >> 4), c8 = lane & 15, i = m0 + wrow0 + lr;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&plh[lr * LDG + 8 * c8]);
+        if (i < nact) *reinterpret_cast<f32x4*>(a.gatesb + (trow + i) * (size_t)(4 * d) + 4 * u0 + 8 * c8) = v;
+      }
+      wave_sync();
+    }
+  }
+}
+#endif
+
 // bf16 engine launchers (lstm_bf16.hip)
 void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int in, int in_i, int d, hipStream_t s);
 void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, int J, int in, int in_i, hipStream_t s);
@@ -247,6 +372,7 @@ struct FusedBwdArgs {
   float* dc;  // [2][B][d]
   float* dx;  // lstm_dx only
   int t, B, J, in, d, in_i;
+  int stamp_wg;  // diagnostics: workgroup that stamps the shader clock (-1: none)
 };
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s);
 void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s);

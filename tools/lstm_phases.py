@@ -2,7 +2,11 @@
 import os, sys, ctypes, torch
 sys.path.insert(0, os.getcwd())
 wg = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-os.environ["FVTA_DEBUG_SKIP"] = str(32768 | (wg << 16))
+bwd = len(sys.argv) > 2 and sys.argv[2] == "bwd"
+if bwd:
+    os.environ["FVTA_LSTM_STAMP_BWD"] = str(wg)
+else:
+    os.environ["FVTA_DEBUG_SKIP"] = str(32768 | (wg << 16))
 from fvta_memexqa_amd import ops, _lib
 B, J, din, d = 12864, 30, 200, 512
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -17,6 +21,10 @@ op.make_plan(lens)
 out = torch.empty(B, J, 2 * d, device="cuda")
 for _ in range(2):
     op.forward(x, out, k, b)
+if bwd:
+    dout = torch.randn(B, J, 2 * d, device="cuda", generator=g)
+    dx = torch.zeros_like(x); dk = torch.zeros_like(k); db = torch.zeros_like(b)
+    op.backward(x, out, dout, k, None, dx, dk, db)
 torch.cuda.synchronize()
 lib = _lib.load()
 def rd(i):
@@ -31,5 +39,7 @@ for t in range(nt):
     nxt = rd(8 + 4 * (t + 1)) if t + 1 < nt else t1
     rows.append((s[1] - s[0], s[2] - s[1], s[3] - s[2], nxt - s[3]))
 print("tile   wait_vmcnt  barrier+issue  mfma_issue  tail")
-for t, r in enumerate(rows):
+for t, r in enumerate(rows[:24]):
     print("%4d %10d %12d %11d %6d" % ((t,) + r))
+import statistics
+print("mean per k-tile:", [round(statistics.mean(r[i] for r in rows)) for i in range(4)], "sum", round(sum(sum(r) for r in rows) / len(rows)))
