@@ -245,7 +245,10 @@ void launch_step_bwd_bf16(const StepBwdArgs& a, hipStream_t s) {
 // the epilogue adds the upstream d_out, runs the gate gradient and writes dz_t (packed, unit-major) and
 // the running dc.  No dh round trip through HBM, no separate elementwise launch.
 // grid (pad8(ceil(B/256)), d/128 (ceil), 2)
-__global__ __launch_bounds__(256, 2) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
+template <int WN>
+__global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
+  typedef TileCfgT<WN> TileCfg;
+  typedef MmaBT<WN> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + TileCfg::STAGES * TileCfg::STAGE_ELEMS);
   const int tid = threadIdx.x, dir = blockIdx.z;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
   if (m0 >= nact) return;
   const int nnext = (t + 1 < a.J) ? a.plan.nactive[t + 1] : 0;
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
-  s_oo[tid] = a.plan.oo[trow + min(m0 + tid, nact - 1)];  // clamped: always a valid row
+  if (tid < 256) s_oo[tid] = a.plan.oo[trow + min(m0 + tid, nact - 1)];  // clamped: always a valid row
   MmaB mma;
   mma.init(tid);
   // FVTA_DEBUG_SKIP & 65536-style diagnostics: env FVTA_LSTM_STAMP_BWD=<workgroup> stamps step t = 5 (tools/lstm_phases.py)
@@ -266,11 +269,11 @@ __global__ __launch_bounds__(256, 2) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir] + (size_t)a.in_i * K, (unsigned)d * K * 2);  // the h rows of wb
     RowSrc<TileCfg::A_GLDS> az;
     RowSrc<TileCfg::B_GLDS> bw;
-    az.setup(mma.wave, mma.lane, m0, nnext, K * 2);
-    bw.setup(mma.wave, mma.lane, u0, d, K * 2);
+    az.setup(mma.wave_all, mma.lane, m0, nnext, K * 2);
+    bw.setup(mma.wave_all, mma.lane, u0, d, K * 2);
     auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
-      az.issue(rz, As, mma.wave, tile * 64);
-      bw.issue(rw, Bs, mma.wave, tile * 64);
+      az.issue(rz, As, mma.wave_all, tile * 64);
+      bw.issue(rw, Bs, mma.wave_all, tile * 64);
     };
     if (st) st[0] = __builtin_readcyclecounter();
     glds_mainloop<false>(mma, issue, K / 32, smem_h, st ? st + 8 : nullptr);
@@ -329,13 +332,27 @@ __global__ __launch_bounds__(256, 2) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
 }
 
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
-  allow_big_lds(lstm_bwd_fused_bf16, FWD_LDS);
-  const dim3 grid(pad8((a.B + TileCfg::BM - 1) / TileCfg::BM), (a.d + TileCfg::BN - 1) / TileCfg::BN, 2);
-  hipLaunchKernelGGL(lstm_bwd_fused_bf16, grid, dim3(256), FWD_LDS, s, a);
+  static const bool narrow = [] {
+    const char* e = getenv("FVTA_LSTM_BWD_NARROW_TILE");
+    return e && e[0] == '1';
+  }();
+  if (a.d % 256 == 0 && !narrow) {  // 256 x 256 tile: dz (the A operand, K = 4d wide) is re-read d/256 instead of d/128 times
+    constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
+    allow_big_lds(lstm_bwd_fused_bf16<2>, LDS);
+    const dim3 grid(pad8((a.B + 255) / 256), a.d / 256, 2);
+    hipLaunchKernelGGL(lstm_bwd_fused_bf16<2>, grid, dim3(512), LDS, s, a);
+  } else {
+    allow_big_lds(lstm_bwd_fused_bf16<1>, FWD_LDS);
+    const dim3 grid(pad8((a.B + 255) / 256), (a.d + 127) / 128, 2);
+    hipLaunchKernelGGL(lstm_bwd_fused_bf16<1>, grid, dim3(256), FWD_LDS, s, a);
+  }
 }
 
 // dx = dz * wb_x^T for every (direction, step) at once.  grid (pad8(ceil(B/256)), ceil(in/128), 2*J)
-__global__ __launch_bounds__(256, 2) void lstm_dx_bf16(FusedBwdArgs a) {
+template <int WN>
+__global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_dx_bf16(FusedBwdArgs a) {
+  typedef TileCfgT<WN> TileCfg;
+  typedef MmaBT<WN> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   const int tid = threadIdx.x;
   const int t = blockIdx.z % a.J, dir = blockIdx.z / a.J;
@@ -350,11 +367,11 @@ __global__ __launch_bounds__(256, 2) void lstm_dx_bf16(FusedBwdArgs a) {
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir], (unsigned)in * K * 2);  // the x rows of wb
   RowSrc<TileCfg::A_GLDS> az;
   RowSrc<TileCfg::B_GLDS> bw;
-  az.setup(mma.wave, mma.lane, m0, nact, K * 2);
-  bw.setup(mma.wave, mma.lane, n0, in, K * 2);
+  az.setup(mma.wave_all, mma.lane, m0, nact, K * 2);
+  bw.setup(mma.wave_all, mma.lane, n0, in, K * 2);
   auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
-    az.issue(rz, As, mma.wave, tile * 64);
-    bw.issue(rw, Bs, mma.wave, tile * 64);
+    az.issue(rz, As, mma.wave_all, tile * 64);
+    bw.issue(rw, Bs, mma.wave_all, tile * 64);
   };
   glds_mainloop<false>(mma, issue, K / 32, smem_h);
 #pragma unroll
@@ -376,16 +393,31 @@ __global__ __launch_bounds__(256, 2) void lstm_dx_bf16(FusedBwdArgs a) {
 }
 
 void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
-  allow_big_lds(lstm_dx_bf16, TileCfg::LDS_BYTES);
-  const dim3 grid(pad8((a.B + TileCfg::BM - 1) / TileCfg::BM), (a.in + TileCfg::BN - 1) / TileCfg::BN, 2 * a.J);
-  hipLaunchKernelGGL(lstm_dx_bf16, grid, dim3(256), TileCfg::LDS_BYTES, s, a);
+  static const bool wide = [] {  // (one 256-wide column tile instead of two 128-wide ones: measured slower at in = 200)
+    const char* e = getenv("FVTA_LSTM_DX_WIDE_TILE");
+    return e && e[0] == '1';
+  }();
+  if (a.in > 128 && wide) {
+    allow_big_lds(lstm_dx_bf16<2>, TileCfgT<2>::LDS_BYTES);
+    const dim3 grid(pad8((a.B + 255) / 256), (a.in + 255) / 256, 2 * a.J);
+    hipLaunchKernelGGL(lstm_dx_bf16<2>, grid, dim3(512), TileCfgT<2>::LDS_BYTES, s, a);
+  } else {
+    allow_big_lds(lstm_dx_bf16<1>, TileCfgT<1>::LDS_BYTES);
+    const dim3 grid(pad8((a.B + 255) / 256), (a.in + 127) / 128, 2 * a.J);
+    hipLaunchKernelGGL(lstm_dx_bf16<1>, grid, dim3(256), TileCfgT<1>::LDS_BYTES, s, a);
+  }
 }
 
 // -------------------------------------------------------- weight gradient --
 // slab(dir, split) [in_i+d][4d] = sum over the split's steps of [xs_t | hs_{t-1}]^T * dz_t.  Both operands
 // are k-major in memory: staged as they lie, read through the transposing LDS read.
 // grid (xtiles + htiles, 4d/128, 2*nsplit): m-tiles never mix x and h columns.
-__global__ __launch_bounds__(256, 2) void lstm_dw_bf16(DwArgs a) {
+// WN = 2: 256 x 256 output tile, 8 waves -- the operands are re-read 8 + 3 instead of 16 + 3 times (this kernel runs
+// at the rate the address unit feeds the LDS).
+template <int WN>
+__global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_dw_bf16(DwArgs a) {
+  typedef TileCfgT<WN> TileCfg;
+  typedef MmaBT<WN> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   const int tid = threadIdx.x;
   const int d = a.d, in_i = a.in_i, N4 = 4 * d;
@@ -399,8 +431,8 @@ __global__ __launch_bounds__(256, 2) void lstm_dw_bf16(DwArgs a) {
   mma.init(tid);
   KMajorSrc<TileCfg::BM, TileCfg::A_GLDS> sa;
   KMajorSrc<TileCfg::BN, TileCfg::B_GLDS> sb;
-  sa.setup(mma.wave, mma.lane, col0, ncols, (unsigned)ncols * 2);
-  sb.setup(mma.wave, mma.lane, n0, N4, (unsigned)N4 * 2);
+  sa.setup(mma.wave_all, mma.lane, col0, ncols, (unsigned)ncols * 2);
+  sb.setup(mma.wave_all, mma.lane, n0, N4, (unsigned)N4 * 2);
   const int t_begin = split * a.tgroup, t_end = min(a.J, t_begin + a.tgroup);
   for (int t = t_begin; t < t_end; ++t) {
     const int nact = a.plan.nactive[t];
@@ -411,8 +443,8 @@ __global__ __launch_bounds__(256, 2) void lstm_dw_bf16(DwArgs a) {
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(A, (unsigned)nact * ncols * 2);
     const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + trow * (size_t)N4, (unsigned)nact * N4 * 2);
     auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
-      sa.issue(ra, As, mma.wave, (unsigned)tile * 32u * ncols * 2u);
-      sb.issue(rz, Bs, mma.wave, (unsigned)tile * 32u * N4 * 2u);
+      sa.issue(ra, As, mma.wave_all, (unsigned)tile * 32u * ncols * 2u);
+      sb.issue(rz, Bs, mma.wave_all, (unsigned)tile * 32u * N4 * 2u);
     };
     glds_mainloop<true>(mma, issue, (nact + 31) / 32, smem_h);
     __builtin_amdgcn_s_barrier();  // every wave is done with the ring before the next step refills it
@@ -431,10 +463,20 @@ __global__ __launch_bounds__(256, 2) void lstm_dw_bf16(DwArgs a) {
 }
 
 void launch_dw_bf16(const DwArgs& a, hipStream_t s) {
-  allow_big_lds(lstm_dw_bf16, TileCfg::LDS_BYTES);
-  const int xtiles = (a.in_i + TileCfg::BM - 1) / TileCfg::BM, htiles = (a.d + TileCfg::BM - 1) / TileCfg::BM;
-  const dim3 grid(xtiles + htiles, 4 * a.d / TileCfg::BN, 2 * a.nsplit);
-  hipLaunchKernelGGL(lstm_dw_bf16, grid, dim3(256), TileCfg::LDS_BYTES, s, a);
+  const int xtiles = (a.in_i + 255) / 256, htiles = (a.d + 255) / 256;
+  static const bool narrow = [] {
+    const char* e = getenv("FVTA_LSTM_DW_NARROW_TILE");
+    return e && e[0] == '1';
+  }();
+  if ((4 * a.d) % 256 == 0 && !narrow) {
+    allow_big_lds(lstm_dw_bf16<2>, TileCfgT<2>::LDS_BYTES);
+    const dim3 grid(xtiles + htiles, 4 * a.d / 256, 2 * a.nsplit);
+    hipLaunchKernelGGL(lstm_dw_bf16<2>, grid, dim3(512), TileCfgT<2>::LDS_BYTES, s, a);
+  } else {
+    allow_big_lds(lstm_dw_bf16<1>, TileCfgT<1>::LDS_BYTES);
+    const dim3 grid(xtiles + htiles, 4 * a.d / 128, 2 * a.nsplit);
+    hipLaunchKernelGGL(lstm_dw_bf16<1>, grid, dim3(256), TileCfgT<1>::LDS_BYTES, s, a);
+  }
 }
 
 // slabs (internal row order) -> dkernel [in+d][4d] and dbias [4d], accumulated, fixed summation order
