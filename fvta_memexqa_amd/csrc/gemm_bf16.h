@@ -203,7 +203,7 @@ struct KMajorSrc {
 // [4t+2] after the barrier + next issue, [4t+3] after the MFMAs were issued.
 template <bool KMAJOR, class Mma, class Issue>
 __device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntiles, bf16_t* smem,
-                                              unsigned long long* stamps = nullptr) {
+                                              unsigned long long* stamps = nullptr, int xdbg = 0) {
   typedef typename Mma::Cfg TileCfg;
   auto a_stage = [&](int t) { return smem + (t % TileCfg::STAGES) * TileCfg::STAGE_ELEMS; };
   if (ntiles <= 0) return;
@@ -218,9 +218,10 @@ __device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntile
     if (stamps) stamps[4 * t + 1] = __builtin_readcyclecounter();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 2 < ntiles) issue(t + 2, a_stage(t + 2), a_stage(t + 2) + TileCfg::A_ELEMS);
+    if (t + 2 < ntiles && !(xdbg & 1)) issue(t + 2, a_stage(t + 2), a_stage(t + 2) + TileCfg::A_ELEMS);  // xdbg: experiments
     if (stamps) stamps[4 * t + 2] = __builtin_readcyclecounter();
     const bf16_t* As = a_stage(t);
+    if (xdbg & 2) continue;
     if (KMAJOR)
       mma.compute_kmajor(As, As + TileCfg::A_ELEMS);
     else

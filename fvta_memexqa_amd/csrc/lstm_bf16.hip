@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_step_fwd_bf16(
         cprev[ti][it] = *reinterpret_cast<const f32x4*>(src + (size_t)i * d + u0 + 4 * (mma.lane & 7));
       }
   }
-  if (!(a.dbg & 1)) glds_mainloop<false>(mma, issue, nt, smem_h, st ? st + 8 : nullptr);
+  if (!(a.dbg & 1)) glds_mainloop<false>(mma, issue, nt, smem_h, st ? st + 8 : nullptr, (a.dbg >> 17) & 3);
   if (st) st[1] = __builtin_readcyclecounter();
   __syncthreads();  // s_oo visible; every wave is done with the stage buffers, which become the epilogue's scratch
   if (!(a.dbg & 2))

@@ -111,21 +111,29 @@ __global__ __launch_bounds__(256) void scorer_bwd_inputs_kernel(fvta_scorer_desc
   }
 }
 
-// dW [F] += sum_n sum_c dl * feat ; db += sum dl.   grid ceil(w/256): one thread per channel, loops n
+// dW [F] += sum_n sum_c dl * feat ; db += sum dl.   grid ceil(w/64); 256 threads = 64 channels x 4 groups of n.
+// Fixed summation order (bitwise reproducible); dl is computed once per block into LDS.
+constexpr int SCORER_DL_MAX = 4096;
 __global__ __launch_bounds__(256) void scorer_bwd_params_kernel(fvta_scorer_desc d, const float* __restrict__ gq,
                                                                 const float* __restrict__ g1,
                                                                 const float* __restrict__ gch, const uint8_t* y,
                                                                 const float* logits, const float* yp, float scale,
                                                                 float* __restrict__ dW, float* __restrict__ db) {
-  const int ch = blockIdx.x * 256 + threadIdx.x, w = d.w;
+  __shared__ float s_dl[SCORER_DL_MAX];
+  __shared__ float s_p[4][7][64];
+  const int tid = threadIdx.x, w = d.w, NC = d.N * d.C;
+  const bool cached = NC <= SCORER_DL_MAX;
+  if (cached)
+    for (int i = tid; i < NC; i += 256) s_dl[i] = dlogit_of(d, i / d.C, i % d.C, logits, yp, y, scale);
+  __syncthreads();
+  const int cl = tid & 63, grp = tid >> 6, ch = blockIdx.x * 64 + cl;
   float s[7] = {0, 0, 0, 0, 0, 0, 0};
-  float sb = 0.f;
-  for (int n = 0; n < d.N; ++n)
-    for (int c = 0; c < d.C; ++c) {
-      const float dl = dlogit_of(d, n, c, logits, yp, y, scale);
-      sb += dl;
-      if (ch < w) {
-        const float q = gq[(size_t)n * w + ch], a = g1[(size_t)n * w + ch], g = gch[((size_t)n * d.C + c) * w + ch];
+  if (ch < w)
+    for (int n = grp; n < d.N; n += 4) {
+      const float q = gq[(size_t)n * w + ch], a = g1[(size_t)n * w + ch];
+      for (int c = 0; c < d.C; ++c) {
+        const float dl = cached ? s_dl[n * d.C + c] : dlogit_of(d, n, c, logits, yp, y, scale);
+        const float g = gch[((size_t)n * d.C + c) * w + ch];
         s[0] += dl * q;
         s[1] += dl * a;
         s[2] += dl * g;
@@ -135,11 +143,18 @@ __global__ __launch_bounds__(256) void scorer_bwd_params_kernel(fvta_scorer_desc
         s[6] += dl * (q - g) * (q - g);
       }
     }
-  if (ch < w) {
+#pragma unroll
+  for (int f = 0; f < 7; ++f) s_p[grp][f][cl] = s[f];
+  __syncthreads();
+  if (grp == 0 && ch < w) {
     const int nf = d.use_eu_output ? 7 : 5;
-    for (int f = 0; f < nf; ++f) dW[f * w + ch] += s[f];
+    for (int f = 0; f < nf; ++f) dW[f * w + ch] += (s_p[0][f][cl] + s_p[1][f][cl]) + (s_p[2][f][cl] + s_p[3][f][cl]);
   }
-  if (ch == 0) db[0] += sb;
+  if (blockIdx.x == 0 && tid == 0) {
+    float sb = 0.f;
+    for (int i = 0; i < NC; ++i) sb += cached ? s_dl[i] : dlogit_of(d, i / d.C, i % d.C, logits, yp, y, scale);
+    db[0] += sb;
+  }
 }
 
 }  // namespace fvta
@@ -173,7 +188,7 @@ extern "C" int fvta_scorer_ce_bwd(const fvta_scorer_desc* d, const float* gq, co
   const float scale = loss_scale / (float)d->N;
   hipLaunchKernelGGL(scorer_bwd_inputs_kernel, dim3(d->N), dim3(256), 0, stream, *d, gq, g1, gch, W, y, logits, yp,
                      scale, dgq, dg1, dgch);
-  hipLaunchKernelGGL(scorer_bwd_params_kernel, dim3((d->w + 255) / 256), dim3(256), 0, stream, *d, gq, g1, gch, y,
+  hipLaunchKernelGGL(scorer_bwd_params_kernel, dim3((d->w + 63) / 64), dim3(256), 0, stream, *d, gq, g1, gch, y,
                      logits, yp, scale, dW, db);
   FVTA_CHECK_LAUNCH("scorer_bwd");
   return FVTA_OK;
