@@ -544,7 +544,8 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
   a.d_hinfo = d_hinfo;
   a.accumulate = accumulate;
   const dim3 grid(s.bsplit, s.N * s.ng);
-  fvta_prof_begin(FVTA_PROF_ATTN_BWD_MAIN, stream);
+  const bool prof_it = (size_t)s.N * s.K * s.T >= 65536;  // the context attention, see attn_fwd.hip
+  if (prof_it) fvta_prof_begin(FVTA_PROF_ATTN_BWD_MAIN, stream);
   switch (s.w) {
 #define FVTA_BWD_LAUNCH(TPR, G, TR)                                                                      \
   do {                                                                                                   \
@@ -562,7 +563,7 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
     case 2048: FVTA_BWD_LAUNCH(256, 2, 16); break;
 #undef FVTA_BWD_LAUNCH
   }
-  fvta_prof_end(FVTA_PROF_ATTN_BWD_MAIN, 1, stream);
+  if (prof_it) fvta_prof_end(FVTA_PROF_ATTN_BWD_MAIN, 1, stream);
   FVTA_CHECK_LAUNCH("attn_bwd_main");
   if (s.simi == 4) {
     hipLaunchKernelGGL(attn_bwd_cosine_q_kernel, dim3(s.N * s.JQ), dim3(256), 0, stream, s, wk, RH, hq, d_hq, accumulate);

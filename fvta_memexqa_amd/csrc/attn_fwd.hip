@@ -978,7 +978,9 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
     const char* e = getenv("FVTA_ATTN_DBG");
     a.dbg = e ? atoi(e) : 0;
   }
-  fvta_prof_begin(FVTA_PROF_ATTN_FWD_MAIN, stream);
+  // (the bracket files the context attention only: the K = 1 question attention is a 15 us launch of the same kernel)
+  const bool prof_it = (size_t)s.N * s.K * s.T >= 65536;
+  if (prof_it) fvta_prof_begin(FVTA_PROF_ATTN_FWD_MAIN, stream);
   const char* exact = getenv("FVTA_ATTN_EXACT");
   // (the full logit tensor is an inspection output: only the general kernel writes it)
   const bool rows16 = s.JT == 1 && s.w >= 128 && s.w <= 1024 && !a_logits && !(exact && exact[0] == '1');
@@ -1021,7 +1023,7 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
     case 1024: launch_main<16, 2, 8, 4, 1, 8>(a, stream); break;
     case 2048: launch_main<16, 2, 8, 4, 2, 8>(a, stream); break;
   }
-  fvta_prof_end(FVTA_PROF_ATTN_FWD_MAIN, 1, stream);
+  if (prof_it) fvta_prof_end(FVTA_PROF_ATTN_FWD_MAIN, 1, stream);
   FVTA_CHECK_LAUNCH("attn_fwd_main");
   hipLaunchKernelGGL(attn_merge_kernel, dim3(s.N, (s.w + 255) / 256), dim3(256), 0, stream, s, sv, a.part, h_a);
   FVTA_CHECK_LAUNCH("attn_merge");

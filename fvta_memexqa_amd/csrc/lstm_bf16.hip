@@ -422,11 +422,19 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_dw_bf16(DwArgs
   const int tid = threadIdx.x;
   const int d = a.d, in_i = a.in_i, N4 = 4 * d;
   const int xtiles = (in_i + TileCfg::BM - 1) / TileCfg::BM;
-  const bool isx = (int)blockIdx.x < xtiles;
-  const int col0 = isx ? blockIdx.x * TileCfg::BM : (blockIdx.x - xtiles) * TileCfg::BM;  // within x / h columns
+  // XCD-aware decode of the 1-D grid: workgroups are dealt round-robin over the 8 XCDs, and every tile of one
+  // (direction, step group) slice streams the SAME rows -- so a slice's tiles all go to ONE XCD, where the re-reads
+  // hit its L2 instead of crossing the fabric 8 times (measured: 18 GB of fabric reads per call before, 4.4 GB unique).
+  const int mtiles = xtiles + (d + TileCfg::BM - 1) / TileCfg::BM, ntiles = N4 / TileCfg::BN, per = mtiles * ntiles;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bz = xcd + 8 * (slot / per), tile_id = slot % per;
+  if (bz >= 2 * a.nsplit) return;
+  const int bx = tile_id % mtiles, by = tile_id / mtiles;
+  const bool isx = bx < xtiles;
+  const int col0 = isx ? bx * TileCfg::BM : (bx - xtiles) * TileCfg::BM;  // within x / h columns
   const int ncols = isx ? in_i : d;
-  const int n0 = blockIdx.y * TileCfg::BN;
-  const int split = blockIdx.z % a.nsplit, dir = blockIdx.z / a.nsplit;
+  const int n0 = by * TileCfg::BN;
+  const int split = bz % a.nsplit, dir = bz / a.nsplit;
   MmaB mma;
   mma.init(tid);
   KMajorSrc<TileCfg::BM, TileCfg::A_GLDS> sa;
@@ -449,7 +457,7 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_dw_bf16(DwArgs
     glds_mainloop<true>(mma, issue, (nact + 31) / 32, smem_h);
     __builtin_amdgcn_s_barrier();  // every wave is done with the ring before the next step refills it
   }
-  float* slab = a.slabs + (size_t)blockIdx.z * (in_i + d) * N4;
+  float* slab = a.slabs + (size_t)bz * (in_i + d) * N4;
   const int mrow0 = isx ? col0 : in_i + col0;
 #pragma unroll
   for (int ti = 0; ti < MmaB::TM; ++ti)
@@ -470,11 +478,13 @@ void launch_dw_bf16(const DwArgs& a, hipStream_t s) {
   }();
   if ((4 * a.d) % 256 == 0 && !narrow) {
     allow_big_lds(lstm_dw_bf16<2>, TileCfgT<2>::LDS_BYTES);
-    const dim3 grid(xtiles + htiles, 4 * a.d / 256, 2 * a.nsplit);
+    const int per = (xtiles + htiles) * (4 * a.d / 256);
+    const dim3 grid(8 * per * ((2 * a.nsplit + 7) / 8));
     hipLaunchKernelGGL(lstm_dw_bf16<2>, grid, dim3(512), TileCfgT<2>::LDS_BYTES, s, a);
   } else {
     allow_big_lds(lstm_dw_bf16<1>, TileCfgT<1>::LDS_BYTES);
-    const dim3 grid(xtiles + htiles, 4 * a.d / 128, 2 * a.nsplit);
+    const int per = (xtiles + htiles) * (4 * a.d / 128);
+    const dim3 grid(8 * per * ((2 * a.nsplit + 7) / 8));
     hipLaunchKernelGGL(lstm_dw_bf16<1>, grid, dim3(256), TileCfgT<1>::LDS_BYTES, s, a);
   }
 }
