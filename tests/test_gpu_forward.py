@@ -169,3 +169,39 @@ def test_optimizer_steps_match_oracle():
     _close(tv, ev, atol=1e-6)
     _close(tm, em, atol=1e-6)
     _close(tvv, evv, atol=1e-6)
+
+
+@pytest.mark.parametrize("w,JQ", [(1024, 30), (512, 17), (2048, 30), (1024, 40)])
+def test_attention_forward_is_bitwise_reproducible(w, JQ):
+    """Same inputs, 12 launches: bitwise equal outputs and saved state.  (Guards the asynchronous operand pipelines
+    of the forward kernels -- a write-after-read race there shows up as run-to-run differences, not as a crash.)"""
+    from fvta_memexqa_amd import ops
+    N, K, T = 4, 6, 333
+    h, q, W, b, hm, qm = _att_case(N, K, T, JQ, w, 2, True, True, seed=w + JQ)
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    op = ops.FocalAttention(N, K, T, JQ, w, 2, True)
+    args = (cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)), cu(W.reshape(-1)), cu(b))
+    ref = None
+    for _ in range(12):
+        ha, _ = op.forward(*args)
+        torch.cuda.synchronize()
+        cur = (ha.clone(), op.saved.clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1])
+
+
+def test_attention_fast_path_matches_exact_path(monkeypatch):
+    """JQ <= 32, 128 <= w <= 1024 runs the fp16 3-term-split kernel; FVTA_ATTN_EXACT=1 routes to the fp32-MFMA kernel.
+    The two must agree far inside the 1e-4 parity tolerance."""
+    from fvta_memexqa_amd import ops
+    N, K, T, JQ, w = 3, 5, 200, 30, 1024
+    h, q, W, b, hm, qm = _att_case(N, K, T, JQ, w, 2, True, True, seed=77)
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    op = ops.FocalAttention(N, K, T, JQ, w, 2, True)
+    args = (cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)), cu(W.reshape(-1)), cu(b))
+    fast, _ = op.forward(*args)
+    monkeypatch.setenv("FVTA_ATTN_EXACT", "1")
+    exact, _ = op.forward(*args)
+    _close(fast, exact.cpu(), rtol=2e-5, atol=2e-6, msg="fast vs exact")

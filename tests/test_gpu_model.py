@@ -172,3 +172,29 @@ def test_model_with_time_warp(warp_type):
     for k, v in p64.items():
         if v.grad is not None:
             _close(grads[k].reshape(v.grad.shape), v.grad, rtol=2e-4, atol=2e-5, msg="grad " + k)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_forward_backward_bitwise_reproducible(precision):
+    """Whole path, ragged metric-shaped batch (N = 4): the context tensor, g1, yp and the flat gradient buffer are
+    bitwise equal across repeated steps on the same inputs (no atomics on the value path, fixed reduction orders,
+    counted-wait pipelines without races)."""
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import CONFIGS, SynthSpec, make_inputs, make_params
+    spec = SynthSpec(dense=False, **dict(CONFIGS["metric"], N=4))
+    params, inputs = make_params(spec), make_inputs(spec)
+    model = Model(dict(spec.cfg(), batch_size=spec.N, precision=precision), text_in=spec.text_in, img_in=spec.img_in)
+    model.set_oracle_params(params)
+    L = model.load_inputs(inputs, training=True)
+    ref = None
+    for _ in range(4):
+        model.zero_grad()
+        yp = model.forward(L)
+        model.backward(L)
+        torch.cuda.synchronize()
+        cur = (L.arena.clone(), L.g1.clone(), yp.clone(), model.params.grad.clone())
+        if ref is None:
+            ref = cur
+        else:
+            for a, b, name in zip(cur, ref, ("arena", "g1", "yp", "grad")):
+                assert torch.equal(a, b), name
