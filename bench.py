@@ -204,6 +204,24 @@ def main():
         roof_att = dict(kernel="attn_fwd_rows16 (fvta_attn_fwd main kernel)", bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                         frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, algorithmic_bytes=att_bytes,
                         ms_per_step=round(per_step_ms, 4))
+    # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    # tools/bench_lstm.py / tools/bench_attn.py at this same shape; FETCH_SIZE doubled per the gfx950 note of
+    # MI355X_MICROARCH.md).  Not collected live: counters need their own profiler pass.
+    def pmc_traffic(fname, key):
+        try:
+            d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", fname)))
+            for k, v in d.items():
+                if key in k:
+                    return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]
+        except Exception:
+            pass
+        return None
+    if roof is not None and args.config == "metric" and args.precision == "bf16" and not args.batch:
+        roof["traffic"] = pmc_traffic("r01_final_lstm_pmc.json", "lstm_step_fwd_bf16")
+        roof["traffic_note"] = "bytes per launch, profiles/r01_final_lstm_pmc.json; algorithmic per launch = algorithmic_bytes_per_call / 30"
+    if roof_att is not None and args.config == "metric" and not args.batch:
+        roof_att["traffic"] = pmc_traffic("r01_final_attention_pmc.json", "attn_fwd_rows16")
+        roof_att["traffic_note"] = "bytes per launch, profiles/r01_final_attention_pmc.json"
     out = dict(
         metric="QA-pairs/sec (fwd+bwd) at B=64, 40 photos x 5 streams x 30 tok, h=512" if args.config == "metric" and not args.forward_only
         else "QA-pairs/sec (%s, config %s)" % ("fwd" if args.forward_only else "fwd+bwd", args.config),
