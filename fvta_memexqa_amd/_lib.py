@@ -30,6 +30,14 @@ class TimewarpDesc(Structure):
     _fields_ = [(n, c_int32) for n in ("N", "K", "T", "w", "warp_type")] + [("window_t", c_float)]
 
 
+class EmbedDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ("ntok", "W", "cdim", "cwdim", "wdim", "VW", "VT", "VC", "height")]
+
+
+class ImgTransDesc(Structure):
+    _fields_ = [(n, c_int32) for n in ("M", "idim", "tdim", "add_tanh")]
+
+
 class ScorerDesc(Structure):
     _fields_ = [(n, c_int32) for n in ("N", "C", "w", "use_eu_output", "add_tanh")]
 
@@ -57,6 +65,11 @@ _SIGS = {
     "fvta_timewarp_workspace_bytes": (c_size_t, [POINTER(TimewarpDesc)]),
     "fvta_timewarp_fwd": (c_int, [POINTER(TimewarpDesc), P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_timewarp_bwd": (c_int, [POINTER(TimewarpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_embed_workspace_bytes": (c_size_t, [POINTER(EmbedDesc)]),
+    "fvta_embed_fwd": (c_int, [POINTER(EmbedDesc), P, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_embed_bwd": (c_int, [POINTER(EmbedDesc), P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_image_trans_fwd": (c_int, [POINTER(ImgTransDesc), P, P, P, P, P, P, P]),
+    "fvta_image_trans_bwd": (c_int, [POINTER(ImgTransDesc), P, P, P, P, P, P, P, P, P]),
     "fvta_adadelta_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, P]),
     "fvta_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float, P]),
     "fvta_test_gemm": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),

@@ -1,0 +1,362 @@
+// Embedding front-end for gfx950: model_v2.py:524-645 (char lookup -> conv1d 52-70 -> concat with the word
+// lookup; photo feature lookup -> image_trans_linear).  SURVEY.md 8f rank 1: the step immediately before the
+// encoders.  Per token the char-CNN is 12 windows x 100 filters x 40 MACs -- 1.6 % of one LSTM step's work -- so
+// this is a gather/scatter problem, not a GEMM: one 128-thread workgroup walks tokens; thread f owns filter f with
+// its 40 weights in registers, the token's W x cdim character embeddings sit in LDS and are read as broadcasts,
+// and the token's row (char part | word part) is written once, straight into the encoder input arena.
+#include "fvta_common.h"
+
+namespace fvta {
+
+constexpr int EMB_NT = 128;       // threads = max cwdim
+constexpr int EMB_MAXKC = 64;     // height * cdim
+constexpr int EMB_MAXWC = 1024;   // W * cdim
+constexpr int EMB_MAXVC = 1024;   // char vocabulary (backward's per-workgroup table)
+constexpr int EMB_BWD_BLOCKS = 2048;
+
+struct EmbArgs {
+  fvta_embed_desc d;
+  const int32_t* word_ids;
+  const int32_t* char_ids;
+  const int64_t* tok_off;
+  const float* word_emb;
+  const float* fixed_emb;
+  const float* char_emb;
+  const float* filt;
+  const float* bias;
+  float* x;
+  uint8_t* argpos;
+  // backward
+  const float* dx;
+  float* d_word_emb;
+  float* slab;  // [blocks][KC*cwdim + cwdim + VC*cdim]
+};
+
+__global__ __launch_bounds__(EMB_NT) void embed_fwd_kernel(EmbArgs a) {
+  __shared__ float s_E[EMB_MAXWC];
+  const fvta_embed_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int KC = d.height * d.cdim, P = d.W - d.height + 1;
+  float wf[EMB_MAXKC];
+  float bf = 0.f;
+  if (tid < d.cwdim) {
+#pragma unroll
+    for (int i = 0; i < EMB_MAXKC; ++i) wf[i] = i < KC ? a.filt[(size_t)i * d.cwdim + tid] : 0.f;
+    bf = a.bias[tid];
+  }
+  for (int tok = blockIdx.x; tok < d.ntok; tok += gridDim.x) {
+    float* row = a.x + a.tok_off[tok];
+    if (d.cwdim > 0) {
+      __syncthreads();  // the previous token's readers of s_E are done
+      for (int i = tid; i < d.W * d.cdim; i += EMB_NT)
+        s_E[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / d.cdim] * d.cdim + i % d.cdim];
+      __syncthreads();
+      if (tid < d.cwdim) {
+        float best = -INFINITY;
+        int bp = 0;
+        for (int p = 0; p < P; ++p) {
+          const float* e = s_E + p * d.cdim;  // the window's height*cdim values are contiguous
+          float v = 0.f;
+#pragma unroll
+          for (int i = 0; i < EMB_MAXKC; ++i)
+            if (i < KC) v += e[i] * wf[i];
+          if (v > best) {  // first arg-max
+            best = v;
+            bp = p;
+          }
+        }
+        const float y = best + bf;
+        row[tid] = y > 0.f ? y : 0.f;
+        a.argpos[(size_t)tok * d.cwdim + tid] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
+      }
+    }
+    const int id = a.word_ids[tok];
+    const float* src = id < d.VW ? a.word_emb + (size_t)id * d.wdim : a.fixed_emb + (size_t)(id - d.VW) * d.wdim;
+    for (int i = tid; i < d.wdim; i += EMB_NT) row[d.cwdim + i] = src[i];
+  }
+}
+
+// gradients of the char-CNN parameters per workgroup (fixed token order), word rows by atomics
+__global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel(EmbArgs a) {
+  __shared__ float s_E[EMB_MAXWC], s_dE[EMB_MAXWC];
+  __shared__ float s_g[EMB_NT];
+  __shared__ int s_p[EMB_NT];
+  __shared__ int s_ch[64];
+  extern __shared__ float s_dyn[];  // filt [KC][cwdim], then dC [VC][cdim]
+  const fvta_embed_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int KC = d.height * d.cdim, WC = d.W * d.cdim;
+  float* s_filt = s_dyn;
+  float* s_dC = s_dyn + KC * d.cwdim;
+  float acc[EMB_MAXKC];
+#pragma unroll
+  for (int i = 0; i < EMB_MAXKC; ++i) acc[i] = 0.f;
+  float accb = 0.f;
+  if (d.cwdim > 0) {
+    for (int i = tid; i < KC * d.cwdim; i += EMB_NT) s_filt[i] = a.filt[i];
+    for (int i = tid; i < d.VC * d.cdim; i += EMB_NT) s_dC[i] = 0.f;
+  }
+  for (int tok = blockIdx.x; tok < d.ntok; tok += gridDim.x) {
+    const float* row = a.dx + a.tok_off[tok];
+    const int id = a.word_ids[tok];
+    if (id < d.VW)
+      for (int i = tid; i < d.wdim; i += EMB_NT) atomicAdd(a.d_word_emb + (size_t)id * d.wdim + i, row[d.cwdim + i]);
+    if (d.cwdim == 0) continue;
+    __syncthreads();
+    if (tid < d.W) s_ch[tid] = a.char_ids[(size_t)tok * d.W + tid];
+    for (int i = tid; i < WC; i += EMB_NT)
+      s_E[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / d.cdim] * d.cdim + i % d.cdim];
+    float g = 0.f;
+    int p = 0;
+    if (tid < d.cwdim) {
+      const int ap = a.argpos[(size_t)tok * d.cwdim + tid];
+      if (ap != 255) {
+        g = row[tid];
+        p = ap;
+      }
+    }
+    s_g[tid] = g;
+    s_p[tid] = p;
+    __syncthreads();
+    if (tid < d.cwdim) {  // d filt[:, :, f] += g * window(p); d bias[f] += g
+      const float* e = s_E + p * d.cdim;
+      accb += g;
+#pragma unroll
+      for (int i = 0; i < EMB_MAXKC; ++i)
+        if (i < KC) acc[i] += g * e[i];
+    }
+    // d E[pos][c] = sum_f g_f * filt[pos - p_f][c][f], one thread per (pos, c), f in order
+    for (int i = tid; i < WC; i += EMB_NT) {
+      const int pos = i / d.cdim, c = i % d.cdim;
+      float v = 0.f;
+      for (int f = 0; f < d.cwdim; ++f) {
+        const int k = pos - s_p[f];
+        if (k >= 0 && k < d.height) v += s_g[f] * s_filt[(k * d.cdim + c) * d.cwdim + f];
+      }
+      s_dE[i] = v;
+    }
+    __syncthreads();
+    // into the workgroup's char table: thread c walks the positions serially (two positions may hold the same char)
+    if (tid < d.cdim)
+      for (int pos = 0; pos < d.W; ++pos) s_dC[s_ch[pos] * d.cdim + tid] += s_dE[pos * d.cdim + tid];
+  }
+  if (d.cwdim == 0) return;
+  __syncthreads();
+  float* slab = a.slab + (size_t)blockIdx.x * (KC * d.cwdim + d.cwdim + d.VC * d.cdim);
+  if (tid < d.cwdim) {
+#pragma unroll
+    for (int i = 0; i < EMB_MAXKC; ++i)
+      if (i < KC) slab[(size_t)i * d.cwdim + tid] = acc[i];
+    slab[KC * d.cwdim + tid] = accb;
+  }
+  for (int i = tid; i < d.VC * d.cdim; i += EMB_NT) slab[KC * d.cwdim + d.cwdim + i] = s_dC[i];
+}
+
+// slabs -> d_filt, d_bias, d_char_emb (accumulate), fixed order over workgroups
+__global__ void embed_bwd_reduce_kernel(const float* __restrict__ slab, int nblk, int nfb, int nchar,
+                                        float* __restrict__ d_filt, float* __restrict__ d_bias, int nfilt,
+                                        float* __restrict__ d_char) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, per = nfb + nchar;
+  if (i >= per) return;
+  float v = 0.f;
+  for (int b = 0; b < nblk; ++b) v += slab[(size_t)b * per + i];
+  if (i < nfilt) d_filt[i] += v;
+  else if (i < nfb) d_bias[i - nfilt] += v;
+  else d_char[i - nfb] += v;
+}
+
+// ---- photo features ---------------------------------------------------------------------------------------
+// y[m][n] = act(sum_k feat[pidx[m]][k] W[k][n] + b[n]) -> x + row_off[m].  32 x 32 tiles, 256 threads.
+__global__ __launch_bounds__(256) void img_fwd_kernel(fvta_imgtrans_desc d, const int32_t* __restrict__ pidx,
+                                                      const int64_t* __restrict__ row_off,
+                                                      const float* __restrict__ feat, const float* __restrict__ W,
+                                                      const float* __restrict__ b, float* __restrict__ x) {
+  __shared__ float As[32][33], Bs[32][33];
+  __shared__ int64_t s_src[32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  if (threadIdx.x < 32) s_src[threadIdx.x] = m0 + threadIdx.x < d.M ? (int64_t)pidx[m0 + threadIdx.x] * d.idim : -1;
+  __syncthreads();
+  if (W == nullptr) {  // plain gather: tdim == idim
+    for (int r = ty; r < 32; r += 8)
+      if (s_src[r] >= 0 && n0 + tx < d.idim) x[row_off[m0 + r] + n0 + tx] = feat[s_src[r] + n0 + tx];
+    return;
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < d.idim; k0 += 32) {
+    for (int r = ty; r < 32; r += 8) {
+      const int k = k0 + tx;
+      As[r][tx] = (s_src[r] >= 0 && k < d.idim) ? feat[s_src[r] + k] : 0.f;
+      const int kk = k0 + r, n = n0 + tx;
+      Bs[r][tx] = (kk < d.idim && n < d.tdim) ? W[(size_t)kk * d.tdim + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const float bv = Bs[k][tx];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] += As[ty + 8 * i][k] * bv;
+    }
+    __syncthreads();
+  }
+  const int n = n0 + tx;
+  if (n >= d.tdim) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = ty + 8 * i;
+    if (s_src[r] < 0) continue;
+    const float v = acc[i] + b[n];
+    x[row_off[m0 + r] + n] = d.add_tanh ? tanhf(v) : v;
+  }
+}
+
+// dpre[m][n] = dx * (1 - y^2) (tanh) or dx
+__global__ void img_dpre_kernel(fvta_imgtrans_desc d, const int64_t* __restrict__ row_off, const float* __restrict__ x,
+                                const float* __restrict__ dx, float* __restrict__ dpre) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)d.M * d.tdim) return;
+  const int m = (int)(i / d.tdim), n = (int)(i % d.tdim);
+  const float g = dx[row_off[m] + n];
+  const float y = x[row_off[m] + n];
+  dpre[i] = d.add_tanh ? g * (1.f - y * y) : g;
+}
+
+// dW[k][n] += sum_m feat[pidx[m]][k] dpre[m][n] (m in order); grid (ceil(idim/32), ceil(tdim/32)); db by block row 0
+__global__ __launch_bounds__(256) void img_dw_kernel(fvta_imgtrans_desc d, const int32_t* __restrict__ pidx,
+                                                     const float* __restrict__ feat, const float* __restrict__ dpre,
+                                                     float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float As[32][33], Bs[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float colsum = 0.f;
+  for (int m0 = 0; m0 < d.M; m0 += 32) {
+    for (int r = ty; r < 32; r += 8) {
+      // As[kk = r][mm = tx] = feat[pidx[m0+tx]][k0 + r]
+      const int m = m0 + tx, k = k0 + r;
+      As[r][tx] = (m < d.M && k < d.idim) ? feat[(size_t)pidx[m] * d.idim + k] : 0.f;
+      const int mm = m0 + r, n = n0 + tx;
+      Bs[r][tx] = (mm < d.M && n < d.tdim) ? dpre[(size_t)mm * d.tdim + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mm = 0; mm < 32; ++mm) {
+      const float bv = Bs[mm][tx];
+      if (ty == 0) colsum += bv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] += As[ty + 8 * i][mm] * bv;
+    }
+    __syncthreads();
+  }
+  const int n = n0 + tx;
+  if (n >= d.tdim) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty + 8 * i;
+    if (k < d.idim) dW[(size_t)k * d.tdim + n] += acc[i];
+  }
+  if (blockIdx.x == 0 && ty == 0) db[n] += colsum;
+}
+
+}  // namespace fvta
+using namespace fvta;
+
+static int check_embed(const fvta_embed_desc* d) {
+  FVTA_CHECK_ARG(d && d->ntok > 0 && d->wdim > 0 && d->VW >= 0 && d->VT >= d->VW, "embed: bad descriptor");
+  if (d->cwdim > 0) {
+    FVTA_CHECK_ARG(d->cwdim <= EMB_NT && d->W >= d->height && d->W <= 64 && d->height > 0 && d->cdim > 0 &&
+                       d->height * d->cdim <= EMB_MAXKC && d->W * d->cdim <= EMB_MAXWC && d->VC > 0 &&
+                       d->VC <= EMB_MAXVC,
+                   "embed: unsupported char-CNN shape (cwdim<=128, W<=64, height*cdim<=64, VC<=1024)");
+  }
+  return FVTA_OK;
+}
+
+static size_t embed_slab_floats(const fvta_embed_desc* d) {
+  return (size_t)d->height * d->cdim * d->cwdim + d->cwdim + (size_t)d->VC * d->cdim;
+}
+
+extern "C" size_t fvta_embed_workspace_bytes(const fvta_embed_desc* d) {
+  if (check_embed(d)) return 0;
+  const size_t b = (size_t)EMB_BWD_BLOCKS * embed_slab_floats(d) * sizeof(float);
+  return b < 256 ? 256 : b;
+}
+
+extern "C" int fvta_embed_fwd(const fvta_embed_desc* d, const int32_t* word_ids, const int32_t* char_ids,
+                              const int64_t* tok_off, const float* word_emb, const float* fixed_emb,
+                              const float* char_emb, const float* filt, const float* bias, float* x,
+                              uint8_t* argpos, fvta_stream_t stream_) {
+  if (int e = check_embed(d)) return e;
+  FVTA_CHECK_ARG(word_ids && tok_off && x, "embed_fwd: null pointer");
+  FVTA_CHECK_ARG(d->VW == 0 || word_emb, "embed_fwd: word_emb required");
+  FVTA_CHECK_ARG(d->VT == d->VW || fixed_emb, "embed_fwd: fixed_emb required");
+  FVTA_CHECK_ARG(d->cwdim == 0 || (char_ids && char_emb && filt && bias && argpos), "embed_fwd: char-CNN pointers");
+  EmbArgs a{};
+  a.d = *d;
+  a.word_ids = word_ids; a.char_ids = char_ids; a.tok_off = tok_off;
+  a.word_emb = word_emb; a.fixed_emb = fixed_emb; a.char_emb = char_emb; a.filt = filt; a.bias = bias;
+  a.x = x; a.argpos = argpos;
+  const int blocks = d->ntok < 8192 ? d->ntok : 8192;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks), dim3(EMB_NT), 0, (hipStream_t)stream_, a);
+  FVTA_CHECK_LAUNCH("embed_fwd");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids, const int32_t* char_ids,
+                              const int64_t* tok_off, const float* char_emb, const float* filt,
+                              const uint8_t* argpos, const float* dx, float* d_word_emb, float* d_char_emb,
+                              float* d_filt, float* d_bias, void* workspace, fvta_stream_t stream_) {
+  if (int e = check_embed(d)) return e;
+  FVTA_CHECK_ARG(word_ids && tok_off && dx && workspace, "embed_bwd: null pointer");
+  FVTA_CHECK_ARG(d->VW == 0 || d_word_emb, "embed_bwd: d_word_emb required");
+  FVTA_CHECK_ARG(d->cwdim == 0 || (char_ids && char_emb && filt && argpos && d_char_emb && d_filt && d_bias),
+                 "embed_bwd: char-CNN pointers");
+  hipStream_t stream = (hipStream_t)stream_;
+  EmbArgs a{};
+  a.d = *d;
+  a.word_ids = word_ids; a.char_ids = char_ids; a.tok_off = tok_off;
+  a.char_emb = char_emb; a.filt = filt; a.argpos = const_cast<uint8_t*>(argpos);
+  a.dx = dx; a.d_word_emb = d_word_emb; a.slab = (float*)workspace;
+  const int blocks = d->ntok < EMB_BWD_BLOCKS ? d->ntok : EMB_BWD_BLOCKS;
+  const size_t dyn = ((size_t)d->height * d->cdim * d->cwdim + (size_t)d->VC * d->cdim) * sizeof(float);
+  if (dyn > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)dyn);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
+  if (d->cwdim > 0) {
+    const int nfilt = d->height * d->cdim * d->cwdim, nfb = nfilt + d->cwdim, nchar = d->VC * d->cdim;
+    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((nfb + nchar + 255) / 256), dim3(256), 0, stream,
+                       (const float*)workspace, blocks, nfb, nchar, d_filt, d_bias, nfilt, d_char_emb);
+  }
+  FVTA_CHECK_LAUNCH("embed_bwd");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_image_trans_fwd(const fvta_imgtrans_desc* d, const int32_t* pidx, const int64_t* row_off,
+                                    const float* image_emb_mat, const float* W, const float* b, float* x,
+                                    fvta_stream_t stream_) {
+  FVTA_CHECK_ARG(d && d->M > 0 && d->idim > 0 && d->tdim > 0 && pidx && row_off && image_emb_mat && x,
+                 "image_trans_fwd: bad argument");
+  FVTA_CHECK_ARG(W ? b != nullptr : d->tdim == d->idim, "image_trans_fwd: W without b, or tdim != idim without W");
+  const int nd = W ? d->tdim : d->idim;
+  hipLaunchKernelGGL(img_fwd_kernel, dim3((d->M + 31) / 32, (nd + 31) / 32), dim3(256), 0, (hipStream_t)stream_, *d, pidx,
+                     row_off, image_emb_mat, W, b, x);
+  FVTA_CHECK_LAUNCH("image_trans_fwd");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_image_trans_bwd(const fvta_imgtrans_desc* d, const int32_t* pidx, const int64_t* row_off,
+                                    const float* image_emb_mat, const float* x, const float* dx, float* dW,
+                                    float* db, void* workspace, fvta_stream_t stream_) {
+  FVTA_CHECK_ARG(d && d->M > 0 && d->idim > 0 && d->tdim > 0 && pidx && row_off && image_emb_mat && x && dx && dW &&
+                     db && workspace,
+                 "image_trans_bwd: bad argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  float* dpre = (float*)workspace;
+  const size_t n = (size_t)d->M * d->tdim;
+  hipLaunchKernelGGL(img_dpre_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *d, row_off, x, dx, dpre);
+  hipLaunchKernelGGL(img_dw_kernel, dim3((d->idim + 31) / 32, (d->tdim + 31) / 32), dim3(256), 0, stream, *d, pidx,
+                     image_emb_mat, dpre, dW, db);
+  FVTA_CHECK_LAUNCH("image_trans_bwd");
+  return FVTA_OK;
+}

@@ -9,7 +9,8 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, AttnDesc, LstmDesc, ScorerDesc, TimewarpDesc, check, ptr, stream_ptr
+from ._lib import (F32, BF16, AttnDesc, EmbedDesc, ImgTransDesc, LstmDesc, ScorerDesc, TimewarpDesc, check, ptr,
+                   stream_ptr)
 
 
 def require_gpu():
@@ -231,3 +232,50 @@ class TimeWarp:
                                          ptr(WC_b), ptr(self.c), ptr(_f32c(d_warp)), ptr(d_hall), ptr(d_lq), ptr(dWH_W),
                                          ptr(dWH_b), ptr(dWC_W), ptr(dWC_b), ptr(self.work), stream_ptr()),
               "fvta_timewarp_bwd")
+
+
+# ------------------------------------------------------- embedding front-end
+class TokenEmbed:
+    """model_v2.py:524-620 for all text tokens of a batch: char-CNN + word lookup, rows written at tok_off.
+
+    word_ids [ntok] i32, char_ids [ntok, W] i32 (None without the char-CNN), tok_off [ntok] i64 element offsets."""
+
+    def __init__(self, ntok, W, cdim, cwdim, wdim, VW, VT, VC, height=5):
+        self.lib = _lib.load()
+        self.dev = require_gpu()
+        self.desc = EmbedDesc(ntok, W, cdim, cwdim, wdim, VW, VT, VC, height)
+        nb = self.lib.fvta_embed_workspace_bytes(ctypes.byref(self.desc))
+        if nb == 0:
+            raise _lib.FvtaError("embed: " + self.lib.fvta_last_error().decode())
+        self.work = _bytes(nb, self.dev)
+        self.argpos = torch.empty(max(ntok * cwdim, 1), dtype=torch.uint8, device=self.dev)
+        self.cwdim = cwdim
+
+    def forward(self, word_ids, char_ids, tok_off, word_emb, fixed_emb, char_emb, filt, bias, x):
+        check(self.lib.fvta_embed_fwd(ctypes.byref(self.desc), ptr(word_ids), ptr(char_ids), ptr(tok_off), ptr(word_emb),
+                                      ptr(fixed_emb), ptr(char_emb), ptr(filt), ptr(bias), ptr(x), ptr(self.argpos),
+                                      stream_ptr()), "fvta_embed_fwd")
+
+    def backward(self, word_ids, char_ids, tok_off, char_emb, filt, dx, d_word_emb, d_char_emb, d_filt, d_bias):
+        check(self.lib.fvta_embed_bwd(ctypes.byref(self.desc), ptr(word_ids), ptr(char_ids), ptr(tok_off), ptr(char_emb),
+                                      ptr(filt), ptr(self.argpos), ptr(dx), ptr(d_word_emb), ptr(d_char_emb),
+                                      ptr(d_filt), ptr(d_bias), ptr(self.work), stream_ptr()), "fvta_embed_bwd")
+
+
+class ImageTrans:
+    """model_v2.py:634-645: photo feature lookup (+ image_trans_linear); rows written at row_off."""
+
+    def __init__(self, M, idim, tdim, add_tanh):
+        self.lib = _lib.load()
+        self.dev = require_gpu()
+        self.desc = ImgTransDesc(M, idim, tdim, int(add_tanh))
+        self.work = torch.empty(M * tdim, dtype=torch.float32, device=self.dev)
+
+    def forward(self, pidx, row_off, image_emb_mat, W, b, x):
+        check(self.lib.fvta_image_trans_fwd(ctypes.byref(self.desc), ptr(pidx), ptr(row_off), ptr(_f32c(image_emb_mat)),
+                                            ptr(W), ptr(b), ptr(x), stream_ptr()), "fvta_image_trans_fwd")
+
+    def backward(self, pidx, row_off, image_emb_mat, x, dx, dW, db):
+        check(self.lib.fvta_image_trans_bwd(ctypes.byref(self.desc), ptr(pidx), ptr(row_off), ptr(image_emb_mat), ptr(x),
+                                            ptr(dx), ptr(dW), ptr(db), ptr(self.work), stream_ptr()),
+              "fvta_image_trans_bwd")

@@ -202,6 +202,67 @@ int fvta_timewarp_bwd(const fvta_timewarp_desc* d, const float* hall, const floa
                       float* dWC_b, void* workspace, fvta_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * Embedding front-end (model_v2.py:524-645): what turns the
+ * reference's token-id feed into the encoder inputs.
+ *
+ * fvta_embed_fwd replaces, for ALL text inputs of a batch at once (at, ad, when,
+ * where, pts, q, choices: model_v2.py:531-620),
+ *   tf.nn.embedding_lookup(char_emb, *_c) -> conv1d (52-70: conv2d VALID, +bias,
+ *   relu, reduce_max over the width) -> concat([char part, word part]) with the
+ *   word table concat([word_emb_mat (trainable, VW rows), existing_emb_mat
+ *   (frozen GloVe, VT - VW rows)]) (590).
+ * Token t: word_ids[t] in [0, VT), char_ids[t*W .. +W) in [0, VC); its row of
+ * cwdim + wdim floats is written at x + tok_off[t] (element offset: the caller
+ * lays tokens out as the encoder input arena wants them).  cwdim = 0: use_char
+ * off (char_ids / char_emb / filt / bias ignored).  keep_prob is 1.
+ *   filt [height, cdim, cwdim] (= TF's [1, height, cdim, cwdim]), bias [cwdim].
+ *   argpos [ntok, cwdim] u8 (saved for backward): arg-max window, 255 where the
+ *   relu is inactive.  Limits: cwdim <= 128, W <= 64, height*cdim <= 64, VC <= 1024.
+ * fvta_embed_bwd: dx rows (same offsets) -> gradients ACCUMULATED into
+ *   d_word_emb [VW, wdim] (rows >= VW are frozen; float atomics: the one
+ *   order-dependent sum of the library, as TF's own IndexedSlices sum),
+ *   d_char_emb [VC, cdim], d_filt, d_bias (fixed-order reductions).
+ *   max ties go to the first window (TF splits them), as in the attention.
+ * ------------------------------------------------------------------------- */
+typedef struct fvta_embed_desc {
+  int32_t ntok;
+  int32_t W;      /* chars per word (config.max_word_size) */
+  int32_t cdim;   /* char_emb_size */
+  int32_t cwdim;  /* char_out_size; 0 = no char-CNN */
+  int32_t wdim;   /* word_emb_size */
+  int32_t VW;     /* trainable word rows */
+  int32_t VT;     /* all word rows (trainable + frozen) */
+  int32_t VC;     /* char vocabulary */
+  int32_t height; /* conv window (5) */
+} fvta_embed_desc;
+
+size_t fvta_embed_workspace_bytes(const fvta_embed_desc* d);
+int fvta_embed_fwd(const fvta_embed_desc* d, const int32_t* word_ids, const int32_t* char_ids,
+                   const int64_t* tok_off, const float* word_emb, const float* fixed_emb, const float* char_emb,
+                   const float* filt, const float* bias, float* x, uint8_t* argpos, fvta_stream_t stream);
+int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids, const int32_t* char_ids,
+                   const int64_t* tok_off, const float* char_emb, const float* filt, const uint8_t* argpos,
+                   const float* dx, float* d_word_emb, float* d_char_emb, float* d_filt, float* d_bias,
+                   void* workspace, fvta_stream_t stream);
+
+/* Photo features (model_v2.py:634-645): row m of the output, at x + row_off[m]
+ * (element offset), = embedding_lookup(image_emb_mat [*, idim], pidx[m]), passed
+ * through image_trans_linear W [idim, tdim], b [tdim] (+tanh if add_tanh) when W
+ * is not NULL (use_image_trans); with W NULL it is the gathered row itself
+ * (tdim = idim).  image_emb_mat is a placeholder in the reference: no gradient.
+ * Backward (use_image_trans only): dW, db accumulated; workspace M*tdim floats. */
+typedef struct fvta_imgtrans_desc {
+  int32_t M, idim, tdim, add_tanh;
+} fvta_imgtrans_desc;
+
+int fvta_image_trans_fwd(const fvta_imgtrans_desc* d, const int32_t* pidx, const int64_t* row_off,
+                         const float* image_emb_mat, const float* W, const float* b, float* x,
+                         fvta_stream_t stream);
+int fvta_image_trans_bwd(const fvta_imgtrans_desc* d, const int32_t* pidx, const int64_t* row_off,
+                         const float* image_emb_mat, const float* x, const float* dx, float* dW, float* db,
+                         void* workspace, fvta_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Parameter update over the flat fp32 parameter buffer: trainer.py:16
  * AdadeltaOptimizer(init_lr) (rho 0.95, eps 1e-8) and the commented-out
  * AdamOptimizer of trainer.py:17.  grad_scale multiplies the gradient first

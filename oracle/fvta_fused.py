@@ -184,6 +184,35 @@ def time_warp_closed(hall, lq, WH_W, WH_b, WC_W, WC_b, warp_type=1, window_t=3.0
     return (h * scale[:, None, :, None]).reshape(hall.shape), c
 
 
+# ------------------------------------------------- embedding front-end ---
+def conv1d(x, filt, bias):
+    """model_v2.py:52-70 (keep_prob = 1) as an unfold + matmul: x [B, JX, W, cdim], filt [1, height, cdim, cwdim]."""
+    height = filt.shape[1]
+    win = x.unfold(2, height, 1)                                  # [B, JX, P, cdim, height]
+    win = win.permute(0, 1, 2, 4, 3).reshape(*x.shape[:2], win.shape[2], -1)
+    xc = torch.relu(win @ filt[0].reshape(-1, filt.shape[3]) + bias)
+    return xc.max(dim=2).values
+
+
+def embed_tokens(word_ids, char_ids, word_emb_mat, existing_emb_mat, char_emb, filt, bias):
+    """model_v2.py:524-620 for one text input; see oracle/fvta_literal.py:embed_tokens."""
+    table = torch.cat([word_emb_mat, existing_emb_mat], 0)
+    A = table[word_ids.long()]
+    if char_emb is None:
+        return A
+    Ac = char_emb[char_ids.long()]
+    lead = tuple(char_ids.shape[:-2])
+    J, W = char_ids.shape[-2:]
+    xc = conv1d(Ac.reshape(-1, J, W, char_emb.shape[1]), filt, bias).reshape(lead + (J, filt.shape[3]))
+    return torch.cat([xc, A], -1)
+
+
+def image_features(pis, image_emb_mat, W=None, b=None, add_tanh=False):
+    """model_v2.py:634-645."""
+    x = image_emb_mat[pis.long()]
+    return x if W is None else linear(x, W, b, add_tanh)
+
+
 def scorer(gq, g1, gch, W, b, use_eu_output=False, add_tanh=False):
     """model_v2.py:1061-1079."""
     g1t = g1[:, None, :].expand_as(gch)

@@ -306,6 +306,42 @@ def time_warp_literal(hall, lq, WH_W, WH_b, WC_W, WC_b, warp_type=1, window_t=3.
 # ----------------------------------------------------------------------------
 # Scorer + loss: model_v2.py:1053-1096
 # ----------------------------------------------------------------------------
+# ------------------------------------------------- embedding front-end ---
+def conv1d(x, filt, bias):
+    """model_v2.py:52-70 with keep_prob = 1: x [B, JX, W, cdim], filt [1, height, cdim, cwdim] ->
+    relu(conv2d(x, filt, VALID) + bias) [B, JX, W-height+1, cwdim] -> reduce_max over axis 2."""
+    B, JX, W, cdim = x.shape
+    _, height, _, cw = filt.shape
+    P = W - height + 1
+    out = np.zeros((B, JX, P, cw), x.dtype)
+    for p in range(P):                      # the literal sliding window of conv2d, stride 1
+        win = x[:, :, p:p + height, :]      # [B, JX, height, cdim]
+        out[:, :, p, :] = np.tensordot(win, filt[0], axes=([2, 3], [0, 1]))
+    xc = np.maximum(out + bias, 0.0)
+    return xc.max(axis=2)
+
+
+def embed_tokens(word_ids, char_ids, word_emb_mat, existing_emb_mat, char_emb, filt, bias):
+    """model_v2.py:524-620 for ONE text input (at / ad / when / where / pts / q / choices):
+    char lookup -> conv1d -> concat([char part, word part]) with word table = concat([trainable, frozen]).
+    word_ids [..., J], char_ids [..., J, W]; returns [..., J, cwdim + wdim].  char_emb None: use_char = False."""
+    table = np.concatenate([word_emb_mat, existing_emb_mat], 0)      # :590
+    A = table[word_ids]                                              # embedding_lookup
+    if char_emb is None:
+        return A
+    Ac = char_emb[char_ids]                                          # [..., J, W, cdim]
+    lead = char_ids.shape[:-2]
+    J, W = char_ids.shape[-2:]
+    xc = conv1d(Ac.reshape(-1, J, W, char_emb.shape[1]), filt, bias).reshape(lead + (J, filt.shape[3]))
+    return np.concatenate([xc, A], -1)                               # :611 (char part FIRST)
+
+
+def image_features(pis, image_emb_mat, W=None, b=None, add_tanh=False):
+    """model_v2.py:634-645: embedding_lookup(image_emb_mat, pis) then optionally image_trans_linear."""
+    x = image_emb_mat[pis]
+    return x if W is None else linear(x, W, b, add_tanh)
+
+
 def scorer(gq, g1, gch, W, b, use_eu_output=False, add_tanh=False):
     """model_v2.py:1061-1079.  gq[N,w], g1[N,w], gch[N,C,w] -> logits[N,C], yp."""
     C = gch.shape[1]

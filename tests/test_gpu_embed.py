@@ -1,0 +1,101 @@
+"""Embedding front-end (model_v2.py:52-70, 524-645) on the GPU vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def _close(a, b, rtol=RTOL, atol=1e-5, msg=""):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=msg)
+
+
+def _case(seed, B, J, W, cd, cw, wd, VW, VF, VC):
+    g = torch.Generator().manual_seed(seed)
+    p = dict(word_emb=torch.randn(VW, wd, generator=g), fixed=torch.randn(VF, wd, generator=g),
+             char_emb=torch.randn(VC, cd, generator=g), filt=torch.randn(1, 5, cd, cw, generator=g) * 0.3,
+             bias=torch.randn(cw, generator=g) * 0.2)
+    ids = torch.randint(0, VW + VF, (B, J), generator=g, dtype=torch.int32)
+    ch = torch.randint(0, VC, (B, J, W), generator=g, dtype=torch.int32)
+    return p, ids, ch
+
+
+@pytest.mark.parametrize("B,J,W,cd,cw,wd,VW,VF,VC", [(3, 7, 16, 8, 100, 100, 50, 30, 40), (5, 4, 9, 4, 24, 300, 7, 5, 11),
+                                                      (64, 30, 16, 8, 100, 100, 500, 2000, 97)])
+def test_token_embed_forward_backward(B, J, W, cd, cw, wd, VW, VF, VC):
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    p, ids, ch = _case(B + J + W, B, J, W, cd, cw, wd, VW, VF, VC)
+    p64 = {k: v.double().requires_grad_() for k, v in p.items()}
+    ref = F.embed_tokens(ids, ch, p64["word_emb"], p64["fixed"], p64["char_emb"], p64["filt"], p64["bias"])
+    g = torch.Generator().manual_seed(5)
+    gout = torch.randn(B, J, cw + wd, generator=g)
+    (ref * gout.double()).sum().backward()
+    # rows land in an arena with a stride wider than the row (as the padded encoder input has)
+    stride = cw + wd + 8
+    ntok = B * J
+    op = ops.TokenEmbed(ntok, W, cd, cw, wd, VW, VW + VF, VC)
+    cu = lambda t: t.cuda().contiguous()
+    tok_off = cu(torch.arange(ntok, dtype=torch.int64) * stride + 4)
+    x = torch.zeros(ntok * stride + 4, device="cuda")
+    filt = cu(p["filt"].reshape(5, cd, cw))
+    args = (cu(ids.reshape(-1)), cu(ch.reshape(-1, W)), tok_off)
+    op.forward(*args, cu(p["word_emb"]), cu(p["fixed"]), cu(p["char_emb"]), filt, cu(p["bias"]), x)
+    got = x[4:].view(ntok, stride)[:, :cw + wd]
+    _close(got, ref.reshape(ntok, -1), msg="x")
+    dx = torch.zeros_like(x)
+    dx[4:].view(ntok, stride)[:, :cw + wd] = cu(gout.reshape(ntok, -1))
+    dwe, dce = torch.zeros(VW, wd, device="cuda"), torch.zeros(VC, cd, device="cuda")
+    dfl, dbi = torch.zeros(5, cd, cw, device="cuda"), torch.zeros(cw, device="cuda")
+    op.backward(*args, cu(p["char_emb"]), filt, dx, dwe, dce, dfl, dbi)
+    _close(dwe, p64["word_emb"].grad, atol=1e-4, msg="d word_emb")
+    _close(dce, p64["char_emb"].grad, atol=1e-4, msg="d char_emb")
+    _close(dfl, p64["filt"].grad.reshape(5, cd, cw), atol=1e-4, msg="d filt")
+    _close(dbi, p64["bias"].grad, atol=1e-4, msg="d bias")
+    assert p64["fixed"].grad is not None  # the oracle differentiates it; the library treats it as frozen (model_v2.py:590)
+
+
+def test_token_embed_without_char_cnn():
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    p, ids, ch = _case(3, 4, 6, 16, 8, 100, 50, 20, 10, 30)
+    ref = F.embed_tokens(ids, ch, p["word_emb"], p["fixed"], None, None, None)
+    ntok = 24
+    op = ops.TokenEmbed(ntok, 16, 8, 0, 50, 20, 30, 30)
+    cu = lambda t: t.cuda().contiguous()
+    x = torch.zeros(ntok * 50, device="cuda")
+    op.forward(cu(ids.reshape(-1)), None, cu(torch.arange(ntok, dtype=torch.int64) * 50), cu(p["word_emb"]), cu(p["fixed"]),
+               None, None, None, x)
+    _close(x.view(ntok, 50), ref.reshape(ntok, 50))
+
+
+@pytest.mark.parametrize("trans,tanh", [(True, True), (True, False), (False, False)])
+def test_image_features(trans, tanh):
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    g = torch.Generator().manual_seed(11)
+    VI, idim, tdim, M = 37, 157, 100 if trans else 157, 45
+    feat = torch.randn(VI, idim, generator=g)
+    W = (torch.randn(idim, tdim, generator=g) * 0.1).double().requires_grad_() if trans else None
+    b = (torch.randn(tdim, generator=g) * 0.1).double().requires_grad_() if trans else None
+    pis = torch.randint(0, VI, (M,), generator=g, dtype=torch.int32)
+    ref = F.image_features(pis, feat.double(), W, b, tanh)
+    stride = tdim + 4
+    cu = lambda t: None if t is None else t.detach().float().cuda().contiguous()
+    row_off = cu(torch.arange(M, dtype=torch.int64) * stride).long()
+    x = torch.zeros(M * stride, device="cuda")
+    op = ops.ImageTrans(M, idim, tdim, tanh)
+    op.forward(cu(pis).int(), row_off, cu(feat), cu(W), cu(b), x)
+    _close(x.view(M, stride)[:, :tdim], ref, msg="x")
+    if trans:
+        gout = torch.randn(M, tdim, generator=g)
+        (ref * gout.double()).sum().backward()
+        dx = torch.zeros_like(x)
+        dx.view(M, stride)[:, :tdim] = cu(gout)
+        dW, db = torch.zeros(idim, tdim, device="cuda"), torch.zeros(tdim, device="cuda")
+        op.backward(cu(pis).int(), row_off, cu(feat), x, dx, dW, db)
+        _close(dW, W.grad, atol=1e-4, msg="dW")
+        _close(db, b.grad, atol=1e-4, msg="db")
