@@ -69,6 +69,9 @@ def parse():
                     help="torch-CPU threads of the baseline; 16 is the fastest setting measured on the 2x EPYC 9575F host "
                          "(64 threads: 3.5x slower, 128: 9.5x slower for this op mix; DESIGN.md section 5)")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE.json configs[1] (inference) instead of the train step")
+    ap.add_argument("--front-end", action="store_true",
+                    help="enter with the reference's token-id feed (SURVEY 8f rank 1): the char-CNN / word / photo embedding "
+                         "front-end and its gradients are inside the timed step (the headline enters at the encoder inputs)")
     return ap.parse_args()
 
 
@@ -126,11 +129,20 @@ def main():
     spec = SynthSpec(**kw)
     cfg = dict(spec.cfg(), batch_size=spec.N, precision=args.precision, optimizer=args.optimizer,
                init_lr=0.001 if args.optimizer == "adam" else 0.5)
+    if args.front_end:   # README.MD:144-147 sizes: 100-d GloVe + 100-d char-CNN, 2537-d photo features -> 100
+        from fvta_memexqa_amd.synth import make_token_inputs
+        cfg.update(word_vocab_size=400, word_emb_size=100, use_char=True, char_vocab_size=100, max_word_size=16,
+                   char_emb_size=8, char_out_size=100, image_feat_dim=2537, use_image_trans=True, image_trans_dim=100)
     model = Model(cfg, text_in=spec.text_in, img_in=spec.img_in, device=dev)
     trainer = Trainer(model, cfg)
     trainer.need_dx = True   # the real model trains its embeddings: gradients flow into the encoder inputs
     log('model built; generating synthetic inputs')
-    inputs = make_inputs(spec, rank=rank)                      # synthetic, seed 1234+rank
+    if args.front_end:
+        model.set_existing_emb(torch.randn(20000, 100, generator=torch.Generator().manual_seed(5)) * 0.5)
+        inputs = make_token_inputs(spec, VW=400, VF=20000, VC=100, W=16, rank=rank)
+        inputs["image_emb_mat"] = torch.randn(inputs["n_image_rows"], 2537, generator=torch.Generator().manual_seed(6))
+    else:
+        inputs = make_inputs(spec, rank=rank)                  # synthetic, seed 1234+rank
     L = model.load_inputs(inputs, training=not args.forward_only)   # resident in HBM from here on
     del inputs
     log('inputs resident in HBM; warm-up')
@@ -229,7 +241,8 @@ def main():
         ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
         dtype=args.precision, data="synthetic",
         config=dict(workload=("BASELINE.json configs[2] train step (fwd+bwd+%s)" % args.optimizer if not args.forward_only
-                              else "BASELINE.json configs[1] forward only") + ", shape '%s', %s lengths" % (args.config, args.variant),
+                              else "BASELINE.json configs[1] forward only") + ", shape '%s', %s lengths" % (args.config, args.variant)
+                    + (", token-id entry (embedding front-end inside the step)" if args.front_end else ""),
                     qa_pairs_per_gpu=spec.N, albums=spec.A, photos=spec.P, text_streams=spec.S, tokens=spec.L, hidden=spec.d,
                     K=L.K, T=L.T, JQ=L.JQ, parallelism="dp%d (QA pairs sharded, flat-gradient all-reduce)" % ws),
         roofline=roof, roofline_attention=roof_att,

@@ -76,6 +76,65 @@ __global__ __launch_bounds__(EMB_NT) void embed_fwd_kernel(EmbArgs a) {
   }
 }
 
+// The reference's shape (height 5, char_emb_size 8, max_word_size <= 16) with everything static: a value of the
+// token's character block is read ONCE (LDS broadcast, 16 B at a time) and pushed into the <= 5 windows it belongs
+// to, 12 window accumulators in registers -- exactly P*40 FMAs per filter, no predicated slots.
+__global__ __launch_bounds__(EMB_NT) void embed_fwd_kernel_5x8(EmbArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_E[16 * 8];
+  const fvta_embed_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int W = d.W, P = W - 4;
+  float wf[5][8];
+  float bf = 0.f;
+  if (tid < d.cwdim) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) wf[k][c] = a.filt[(size_t)(k * 8 + c) * d.cwdim + tid];
+    bf = a.bias[tid];
+  }
+  for (int tok = blockIdx.x; tok < d.ntok; tok += gridDim.x) {
+    float* row = a.x + a.tok_off[tok];
+    __syncthreads();  // the previous token's readers of s_E are done
+    if (tid < W * 8) s_E[tid] = a.char_emb[(size_t)a.char_ids[(size_t)tok * W + (tid >> 3)] * 8 + (tid & 7)];
+    __syncthreads();
+    if (tid < d.cwdim) {
+      float acc[12];
+#pragma unroll
+      for (int p = 0; p < 12; ++p) acc[p] = 0.f;
+#pragma unroll
+      for (int pos = 0; pos < 16; ++pos) {
+        if (pos < W) {  // workgroup-uniform
+          const f32x4 e0 = *reinterpret_cast<const f32x4*>(&s_E[pos * 8]);
+          const f32x4 e1 = *reinterpret_cast<const f32x4*>(&s_E[pos * 8 + 4]);
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            const int p = pos - k;  // static after unrolling
+            if (p >= 0 && p < 12) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[p] += e0[c] * wf[k][c] + e1[c] * wf[k][c + 4];
+            }
+          }
+        }
+      }
+      float best = acc[0];
+      int bp = 0;
+#pragma unroll
+      for (int p = 1; p < 12; ++p)
+        if (p < P && acc[p] > best) {  // first arg-max
+          best = acc[p];
+          bp = p;
+        }
+      const float y = best + bf;
+      row[tid] = y > 0.f ? y : 0.f;
+      a.argpos[(size_t)tok * d.cwdim + tid] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
+    }
+    const int id = a.word_ids[tok];
+    const float* src = id < d.VW ? a.word_emb + (size_t)id * d.wdim : a.fixed_emb + (size_t)(id - d.VW) * d.wdim;
+    for (int i = tid; i < d.wdim; i += EMB_NT) row[d.cwdim + i] = src[i];
+  }
+}
+
 // gradients of the char-CNN parameters per workgroup (fixed token order), word rows by atomics
 __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel(EmbArgs a) {
   __shared__ float s_E[EMB_MAXWC], s_dE[EMB_MAXWC];
@@ -125,13 +184,15 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel(EmbArgs a) {
       for (int i = 0; i < EMB_MAXKC; ++i)
         if (i < KC) acc[i] += g * e[i];
     }
-    // d E[pos][c] = sum_f g_f * filt[pos - p_f][c][f], one thread per (pos, c), f in order
+    // d E[pos][c] = sum_f g_f * filt[pos - p_f][c][f], one thread per (pos, c), f in order (inactive filters carry
+    // g = 0 and p = 0: they only cost the compare)
     for (int i = tid; i < WC; i += EMB_NT) {
       const int pos = i / d.cdim, c = i % d.cdim;
       float v = 0.f;
       for (int f = 0; f < d.cwdim; ++f) {
         const int k = pos - s_p[f];
-        if (k >= 0 && k < d.height) v += s_g[f] * s_filt[(k * d.cdim + c) * d.cwdim + f];
+        const float g = s_g[f];
+        if (g != 0.f && k >= 0 && k < d.height) v += g * s_filt[(k * d.cdim + c) * d.cwdim + f];
       }
       s_dE[i] = v;
     }
@@ -152,14 +213,106 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel(EmbArgs a) {
   for (int i = tid; i < d.VC * d.cdim; i += EMB_NT) slab[KC * d.cwdim + d.cwdim + i] = s_dC[i];
 }
 
+// backward for the reference's shape (height 5, cdim 8, W <= 16): see embed_fwd_kernel_5x8.  The gradient w.r.t. the
+// token's character block is a scatter of each active filter's 5 x 8 weights to its arg-max window; it is made
+// conflict-free and order-fixed by letting thread (group, k*8+c) walk the filters f = group, group+3, ... and
+// accumulate S[group][p_f][k*8+c] in ITS OWN LDS cell, then dE[pos][c] = sum_group sum_k S[group][pos-k][k*8+c].
+__global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_5x8(EmbArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_E[16 * 8 + 32], s_dE[16 * 8];
+  __shared__ float s_g[EMB_NT];
+  __shared__ int s_p[EMB_NT];
+  __shared__ int s_ch[16];
+  __shared__ float s_S[3][12][40];
+  extern __shared__ float s_dyn[];  // filt [40][cwdim], then dC [VC][8]
+  const fvta_embed_desc& d = a.d;
+  const int tid = threadIdx.x, W = d.W, cw = d.cwdim;
+  float* s_filt = s_dyn;
+  float* s_dC = s_dyn + 40 * cw;
+  float acc[40];
+#pragma unroll
+  for (int i = 0; i < 40; ++i) acc[i] = 0.f;
+  float accb = 0.f;
+  for (int i = tid; i < 40 * cw; i += EMB_NT) s_filt[i] = a.filt[i];
+  for (int i = tid; i < d.VC * 8; i += EMB_NT) s_dC[i] = 0.f;
+  if (tid < 32) s_E[128 + tid] = 0.f;  // slack behind the block: a window read may run 4 positions past W - 5 + 4
+  const int grp = tid / 40, kc = tid % 40;  // tid < 120: the S builders
+  for (int tok = blockIdx.x; tok < d.ntok; tok += gridDim.x) {
+    const float* row = a.dx + a.tok_off[tok];
+    const int id = a.word_ids[tok];
+    if (id < d.VW)
+      for (int i = tid; i < d.wdim; i += EMB_NT) atomicAdd(a.d_word_emb + (size_t)id * d.wdim + i, row[cw + i]);
+    __syncthreads();
+    if (tid < W) s_ch[tid] = a.char_ids[(size_t)tok * W + tid];
+    if (tid < W * 8) s_E[tid] = a.char_emb[(size_t)a.char_ids[(size_t)tok * W + (tid >> 3)] * 8 + (tid & 7)];
+    float g = 0.f;
+    int p = 0;
+    if (tid < cw) {
+      const int ap = a.argpos[(size_t)tok * cw + tid];
+      if (ap != 255) {
+        g = row[tid];
+        p = ap;
+      }
+    }
+    s_g[tid] = g;
+    s_p[tid] = p;
+    for (int i = tid; i < 3 * 12 * 40; i += EMB_NT) (&s_S[0][0][0])[i] = 0.f;
+    __syncthreads();
+    if (tid < cw && g != 0.f) {  // d filt[:, :, f] += g * window(p) (40 contiguous values); d bias[f] += g
+      accb += g;
+      const float* e = s_E + p * 8;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(e + 4 * i);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[4 * i + c] += g * v[c];
+      }
+    }
+    if (tid < 120)
+      for (int f = grp; f < cw; f += 3) {
+        const float gf = s_g[f];
+        if (gf != 0.f) s_S[grp][s_p[f]][kc] += gf * s_filt[kc * cw + f];
+      }
+    __syncthreads();
+    if (tid < W * 8) {
+      const int pos = tid >> 3, c = tid & 7;
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int pp = pos - k;
+        if (pp >= 0 && pp < 12) v += (s_S[0][pp][k * 8 + c] + s_S[1][pp][k * 8 + c]) + s_S[2][pp][k * 8 + c];
+      }
+      s_dE[tid] = v;
+    }
+    __syncthreads();
+    // into the workgroup's char table: thread c walks the positions serially (two positions may hold the same char)
+    if (tid < 8)
+      for (int pos = 0; pos < W; ++pos) s_dC[s_ch[pos] * 8 + tid] += s_dE[pos * 8 + tid];
+  }
+  __syncthreads();
+  float* slab = a.slab + (size_t)blockIdx.x * (40 * cw + cw + d.VC * 8);
+  if (tid < cw) {
+#pragma unroll
+    for (int i = 0; i < 40; ++i) slab[(size_t)i * cw + tid] = acc[i];
+    slab[40 * cw + tid] = accb;
+  }
+  for (int i = tid; i < d.VC * 8; i += EMB_NT) slab[40 * cw + cw + i] = s_dC[i];
+}
+
 // slabs -> d_filt, d_bias, d_char_emb (accumulate), fixed order over workgroups
-__global__ void embed_bwd_reduce_kernel(const float* __restrict__ slab, int nblk, int nfb, int nchar,
-                                        float* __restrict__ d_filt, float* __restrict__ d_bias, int nfilt,
-                                        float* __restrict__ d_char) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x, per = nfb + nchar;
-  if (i >= per) return;
-  float v = 0.f;
-  for (int b = 0; b < nblk; ++b) v += slab[(size_t)b * per + i];
+// 256 threads = 64 elements x 4 slab groups (group g sums slabs g, g+4, ...; the four partials combine in order)
+__global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float* __restrict__ slab, int nblk, int nfb, int nchar,
+                                                               float* __restrict__ d_filt, float* __restrict__ d_bias,
+                                                               int nfilt, float* __restrict__ d_char) {
+  __shared__ float s_part[4][64];
+  const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + el, per = nfb + nchar;
+  float part = 0.f;
+  if (i < per)
+    for (int b = grp; b < nblk; b += 4) part += slab[(size_t)b * per + i];
+  s_part[grp][el] = part;
+  __syncthreads();
+  if (grp != 0 || i >= per) return;
+  const float v = (s_part[0][el] + s_part[1][el]) + (s_part[2][el] + s_part[3][el]);
   if (i < nfilt) d_filt[i] += v;
   else if (i < nfb) d_bias[i - nfilt] += v;
   else d_char[i - nfb] += v;
@@ -297,7 +450,10 @@ extern "C" int fvta_embed_fwd(const fvta_embed_desc* d, const int32_t* word_ids,
   a.word_emb = word_emb; a.fixed_emb = fixed_emb; a.char_emb = char_emb; a.filt = filt; a.bias = bias;
   a.x = x; a.argpos = argpos;
   const int blocks = d->ntok < 8192 ? d->ntok : 8192;
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks), dim3(EMB_NT), 0, (hipStream_t)stream_, a);
+  if (d->cwdim > 0 && d->height == 5 && d->cdim == 8 && d->W <= 16)
+    hipLaunchKernelGGL(embed_fwd_kernel_5x8, dim3(blocks), dim3(EMB_NT), 0, (hipStream_t)stream_, a);
+  else
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks), dim3(EMB_NT), 0, (hipStream_t)stream_, a);
   FVTA_CHECK_LAUNCH("embed_fwd");
   return FVTA_OK;
 }
@@ -319,13 +475,19 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
   a.dx = dx; a.d_word_emb = d_word_emb; a.slab = (float*)workspace;
   const int blocks = d->ntok < EMB_BWD_BLOCKS ? d->ntok : EMB_BWD_BLOCKS;
   const size_t dyn = ((size_t)d->height * d->cdim * d->cwdim + (size_t)d->VC * d->cdim) * sizeof(float);
-  if (dyn > 48 * 1024)
+  if (dyn > 32 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)dyn);
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel_5x8),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+  }
+  if (d->cwdim > 0 && d->height == 5 && d->cdim == 8 && d->W <= 16)
+    hipLaunchKernelGGL(embed_bwd_kernel_5x8, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
+  else
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
   if (d->cwdim > 0) {
     const int nfilt = d->height * d->cdim * d->cwdim, nfb = nfilt + d->cwdim, nchar = d->VC * d->cdim;
-    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((nfb + nchar + 255) / 256), dim3(256), 0, stream,
+    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((nfb + nchar + 63) / 64), dim3(256), 0, stream,
                        (const float*)workspace, blocks, nfb, nchar, d_filt, d_bias, nfilt, d_char_emb);
   }
   FVTA_CHECK_LAUNCH("embed_bwd");

@@ -85,6 +85,12 @@ class Model:
     N_OUT_W, N_OUT_B = "output/choicelogits/W", "output/choicelogits/b"
     N_TW_WH_W, N_TW_WH_B = "time_warp/WH/W", "time_warp/WH/b"
     N_TW_WC_W, N_TW_WC_B = "time_warp/WC/W", "time_warp/WC/b"
+    # embedding front-end (model_v2.py:524-645), present when the config carries the vocabulary sizes
+    N_CHAR_EMB = "emb/var/char_emb"
+    N_CONV_F, N_CONV_B = "emb/conv/conv1d/filter", "emb/conv/conv1d/bias"
+    N_WORD_EMB = "emb/word/var/word_emb_mat"
+    N_IMGT_W = "emb/image/image_transform/image_trans_linear/W"
+    N_IMGT_B = "emb/image/image_transform/image_trans_linear/b"
 
     def __init__(self, config, scope="model", text_in=None, img_in=None, device=None):
         self.scope = scope
@@ -118,6 +124,22 @@ class Model:
             raise ValueError("similarity matrix not implemented")    # model_v2.py:255-257 (sys.exit there)
         self.text_in = int(text_in if text_in is not None else _cfg(config, "text_in", 200))
         self.img_in = int(img_in if img_in is not None else _cfg(config, "img_in", 100))
+        # token-id entry (the reference's own feed: word / char ids + photo indices, model_v2.py:524-645): enabled by
+        # the vocabulary sizes in the config; the encoder input widths then follow from the embedding sizes
+        self.token_mode = _cfg(config, "word_vocab_size", None) is not None
+        if self.token_mode:
+            self.VW = int(_cfg(config, "word_vocab_size", 0))
+            self.wdim = int(_cfg(config, "word_emb_size", 100))
+            self.use_char = bool(_cfg(config, "use_char", False))
+            self.VC = int(_cfg(config, "char_vocab_size", 0))
+            self.Wc = int(_cfg(config, "max_word_size", 16))
+            self.cdim = int(_cfg(config, "char_emb_size", 8))
+            self.cwdim = int(_cfg(config, "char_out_size", 100)) if self.use_char else 0
+            self.idim = int(_cfg(config, "image_feat_dim", 2537))
+            self.use_image_trans = bool(_cfg(config, "use_image_trans", False))
+            self.tdim = int(_cfg(config, "image_trans_dim", 100)) if self.use_image_trans else self.idim
+            self.text_in, self.img_in = self.wdim + self.cwdim, self.tdim
+            self.existing_emb_mat = torch.zeros(0, self.wdim, dtype=torch.float32, device=self.dev)
         # encoder input widths are zero padded to a multiple of 8 (16-byte bf16 operand pieces); exact, like
         # the hidden padding: padded input columns are 0 and their kernel rows stay 0
         self.text_in_p = (self.text_in + 7) // 8 * 8
@@ -147,6 +169,16 @@ class Model:
             specs[self.N_TW_WC_W], specs[self.N_TW_WC_B] = (wp,), (1,)
         specs[self.N_OUT_W] = ((7 if self.use_eu_output else 5) * wp,)
         specs[self.N_OUT_B] = (1,)
+        self._plain = set()     # parameters stored exactly in the reference's shape (no hidden-size padding)
+        if self.token_mode:
+            specs[self.N_WORD_EMB] = (max(self.VW, 1), self.wdim)
+            if self.cwdim:
+                specs[self.N_CHAR_EMB] = (self.VC, self.cdim)
+                specs[self.N_CONV_F] = (5, self.cdim, self.cwdim)      # the reference's [1, 5, cdim, cwdim]
+                specs[self.N_CONV_B] = (self.cwdim,)
+            if self.use_image_trans:
+                specs[self.N_IMGT_W], specs[self.N_IMGT_B] = (self.idim, self.tdim), (self.tdim,)
+            self._plain = {self.N_WORD_EMB, self.N_CHAR_EMB, self.N_CONV_F, self.N_CONV_B, self.N_IMGT_W, self.N_IMGT_B}
         self.params = ParamStore(specs, self.dev)
         self.init_parameters(int(_cfg(config, "weight_seed", 42)))
 
@@ -210,7 +242,9 @@ class Model:
             if name not in self.params.specs:
                 continue
             t = torch.as_tensor(np.asarray(val), dtype=torch.float32)
-            if name.endswith("basic_lstm_cell/kernel"):
+            if name in self._plain:
+                pass
+            elif name.endswith("basic_lstm_cell/kernel"):
                 t = self._pad_kernel(t, *self._din(name))
             elif name.endswith("basic_lstm_cell/bias"):
                 t = self._pad_blocks(t, 4, self.d, self.dp)
@@ -225,7 +259,9 @@ class Model:
         out = {}
         for name in self.params.specs:
             t = self.params.view(name, grad=grad).detach().cpu()
-            if name.endswith("basic_lstm_cell/kernel"):
+            if name in self._plain:
+                t = t.reshape((1,) + tuple(t.shape)) if name == self.N_CONV_F else t
+            elif name.endswith("basic_lstm_cell/kernel"):
                 t = self._unpad_kernel(t, *self._din(name))
             elif name.endswith("basic_lstm_cell/bias"):
                 t = torch.cat([t[g * self.dp:g * self.dp + self.d] for g in range(4)])
@@ -245,7 +281,18 @@ class Model:
         g = torch.Generator().manual_seed(seed)
         wts = {}
         for name, shape in self.params.specs.items():
-            if name.endswith("basic_lstm_cell/kernel"):
+            if name in self._plain:
+                if name == self.N_WORD_EMB:         # main.py:308: N(0, I) rows for the non-GloVe words
+                    wts[name] = torch.randn(shape, generator=g)
+                elif name == self.N_IMGT_W:          # linear: truncated_normal(0.1), b = 0
+                    wts[name] = _trunc_normal(g, shape)
+                elif name == self.N_IMGT_B:
+                    wts[name] = torch.zeros(shape)
+                else:                               # tf.get_variable default: Glorot uniform
+                    fan = (shape[0] * shape[1], shape[2]) if len(shape) == 3 else (shape[0], shape[-1])
+                    lim = (6.0 / (fan[0] + fan[1])) ** 0.5
+                    wts[name] = (torch.rand(shape, generator=g) * 2 - 1) * lim
+            elif name.endswith("basic_lstm_cell/kernel"):
                 din = self.text_in if "utext" in name else self.img_in
                 wts[name] = _glorot(g, din + self.d, 4 * self.d)
             elif name == self.N_TW_WH_W:
@@ -262,7 +309,10 @@ class Model:
              "image_kernel_bw": self.N_IMG_K % "bw", "image_bias_bw": self.N_IMG_B % "bw",
              "att_W": self.N_ATT_W, "att_b": self.N_ATT_B, "qatt_W": self.N_QATT_W, "qatt_b": self.N_QATT_B,
              "out_W": self.N_OUT_W, "out_b": self.N_OUT_B, "WH_W": self.N_TW_WH_W, "WH_b": self.N_TW_WH_B,
-             "WC_W": self.N_TW_WC_W, "WC_b": self.N_TW_WC_B}
+             "WC_W": self.N_TW_WC_W, "WC_b": self.N_TW_WC_B, "word_emb": self.N_WORD_EMB, "char_emb": self.N_CHAR_EMB,
+             "conv_filter": self.N_CONV_F, "conv_bias": self.N_CONV_B, "img_W": self.N_IMGT_W, "img_b": self.N_IMGT_B}
+        if "existing_emb_mat" in p:
+            self.set_existing_emb(p["existing_emb_mat"])
         if "window_t" in p:
             self.window_t = float(p["window_t"])
         self.set_weights({m[k]: v for k, v in p.items() if k in m})
@@ -275,12 +325,19 @@ class Model:
              self.N_IMG_K % "bw": "image_kernel_bw", self.N_IMG_B % "bw": "image_bias_bw",
              self.N_ATT_W: "att_W", self.N_ATT_B: "att_b", self.N_QATT_W: "qatt_W", self.N_QATT_B: "qatt_b",
              self.N_OUT_W: "out_W", self.N_OUT_B: "out_b", self.N_TW_WH_W: "WH_W", self.N_TW_WH_B: "WH_b",
-             self.N_TW_WC_W: "WC_W", self.N_TW_WC_B: "WC_b"}
+             self.N_TW_WC_W: "WC_W", self.N_TW_WC_B: "WC_b", self.N_WORD_EMB: "word_emb", self.N_CHAR_EMB: "char_emb",
+             self.N_CONV_F: "conv_filter", self.N_CONV_B: "conv_bias", self.N_IMGT_W: "img_W", self.N_IMGT_B: "img_b"}
         return {m[k]: v for k, v in g.items()}
+
+    def set_existing_emb(self, mat):
+        """the frozen pre-trained word vectors the reference feeds as `existing_emb_mat` (model_v2.py:470, 590):
+        word ids >= word_vocab_size index into it."""
+        self.existing_emb_mat = torch.as_tensor(np.asarray(mat), dtype=torch.float32).to(self.dev).contiguous()
 
     # ---------------------------------------------------------------- layout
     def _layout(self, shapes, training):
-        key = (tuple(shapes["ctx"]), shapes["q"], shapes["choices"], bool(training))
+        key = (tuple(shapes["ctx"]), shapes["q"], shapes["choices"], bool(training), int(self.existing_emb_mat.shape[0])
+               if self.token_mode else -1)
         if key in self._layouts:
             return self._layouts[key]
         L = _Layout()
@@ -348,6 +405,25 @@ class Model:
             G.B, G.J = B, Jmax
             G.x = torch.zeros(pos, dtype=torch.float32, device=dev)
             G.dx = None
+            if self.token_mode:
+                # one row per sequence position (padding positions included, as the reference embeds them too)
+                t0 = 0
+                offs = []
+                for s in segs:
+                    s["tok0"] = t0
+                    n = s["count"] * s["J"]
+                    offs.append(s["x_elem0"] + torch.arange(n, dtype=torch.int64) * din)
+                    t0 += n
+                G.ntok = t0
+                G.tok_off = torch.cat(offs).to(dev)
+                if cell == "text":
+                    G.word_ids = torch.zeros(t0, dtype=torch.int32, device=dev)
+                    G.char_ids = torch.zeros(t0, self.Wc, dtype=torch.int32, device=dev) if self.cwdim else None
+                    G.embed = ops.TokenEmbed(t0, self.Wc, self.cdim, self.cwdim, self.wdim, self.VW,
+                                             self.VW + int(self.existing_emb_mat.shape[0]), max(self.VC, 1))
+                else:
+                    G.pidx = torch.zeros(t0, dtype=torch.int32, device=dev)
+                    G.embed = ops.ImageTrans(t0, self.idim, self.tdim, self.add_tanh)
             G.lens = torch.zeros(B, dtype=torch.int32, device=dev)
             G.op = ops.BiLstm(B, Jmax, din, dp, torch.cat(x_off), torch.cat(out_off), torch.cat(seq_J), wp,
                               share_fw_bw=self.share_fw_bw, precision=self.precision, training=training,
@@ -376,16 +452,24 @@ class Model:
         return G.x[s["x_elem0"]:s["x_elem0"] + n].view(s["count"], s["J"], G.din)
 
     @staticmethod
-    def shapes_of(inputs):
-        return dict(ctx=tuple((st.get("cell", "text"), tuple(st["x"].shape[:-1])) for st in inputs["ctx"]),
-                    q=tuple(inputs["q"]["x"].shape[:-1]), choices=tuple(inputs["choices"]["x"].shape[:-1]))
+    def _lead(st):
+        """leading (sequence) shape of a stream in either entry form: encoder inputs `x`, word ids, photo indices"""
+        if "x" in st:
+            return tuple(st["x"].shape[:-1])
+        return tuple(st["ids"].shape) if "ids" in st else tuple(st["pis"].shape)
+
+    @classmethod
+    def shapes_of(cls, inputs):
+        return dict(ctx=tuple((st.get("cell", "text"), cls._lead(st)) for st in inputs["ctx"]),
+                    q=cls._lead(inputs["q"]), choices=cls._lead(inputs["choices"]))
 
     def get_feed_dict(self, batch, is_train=False):
         """model_v2.py:1099: here a batch already holds ENCODER inputs (the oracle
         `inputs` dict, optionally with 'num_examples'); the token-id form of the
         reference's feed dict needs the embedding front-end."""
         if not (isinstance(batch, dict) and "ctx" in batch):
-            raise NotImplementedError("token-id batches need the embedding front-end (SURVEY.md 8f rank 1-2)")
+            raise NotImplementedError("raw Dataset batches need the host batch assembly (SURVEY.md 8f rank 2); pass "
+                                      "the index arrays of the reference's feed (ids / chars / pis) or encoder inputs")
         return batch
 
     def load_inputs(self, inputs, training=False):
@@ -395,19 +479,37 @@ class Model:
         L = self._layout(self.shapes_of(inputs), training)
         dev = self.dev
 
-        def put(cell, si, x, mask):
-            self.seg_x(L, cell, si)[:, :, :x.shape[-1]].copy_(x.reshape(-1, x.shape[-2], x.shape[-1]).to(dev, torch.float32))
+        L.token = "x" not in inputs["q"]
+        if L.token and not self.token_mode:
+            raise ValueError("token-id inputs need a model built with word_vocab_size & co. in its config")
+        if L.token:
+            L.image_emb_mat = torch.as_tensor(np.asarray(inputs["image_emb_mat"]) if not torch.is_tensor(
+                inputs["image_emb_mat"]) else inputs["image_emb_mat"]).to(dev, torch.float32).contiguous()
+
+        def put(cell, si, st):
             G = L.groups[cell]
             s = G.segs[si]
+            mask = st["mask"]
+            if "x" in st:
+                x = st["x"]
+                self.seg_x(L, cell, si)[:, :, :x.shape[-1]].copy_(x.reshape(-1, x.shape[-2], x.shape[-1]).to(dev, torch.float32))
+            else:
+                n = s["count"] * s["J"]
+                if cell == "text":
+                    G.word_ids[s["tok0"]:s["tok0"] + n] = st["ids"].reshape(-1).to(dev, torch.int32)
+                    if G.char_ids is not None:
+                        G.char_ids[s["tok0"]:s["tok0"] + n] = st["chars"].reshape(n, -1).to(dev, torch.int32)
+                else:
+                    G.pidx[s["tok0"]:s["tok0"] + n] = st["pis"].reshape(-1).to(dev, torch.int32)
             G.lens[s["s0"]:s["s0"] + s["count"]] = mask.reshape(-1, mask.shape[-1]).to(dev).sum(1).to(torch.int32)
 
-        put("text", 0, inputs["q"]["x"], inputs["q"]["mask"])
-        put("text", 1, inputs["choices"]["x"], inputs["choices"]["mask"])
+        put("text", 0, inputs["q"])
+        put("text", 1, inputs["choices"])
         L.q_mask.copy_(inputs["q"]["mask"].to(dev, torch.uint8))
         L.hall_mask.zero_()
         for k, st in enumerate(inputs["ctx"]):
             cell, si, dims = L.ctx_slots[k]
-            put(cell, si, st["x"], st["mask"])
+            put(cell, si, st)
             m = st["mask"].to(dev, torch.uint8).reshape(L.N, L.M, -1)
             L.hall_mask[:, k, :, :m.shape[2]] = m
         if inputs.get("y") is not None:
@@ -429,6 +531,16 @@ class Model:
         """model_v2.py:649-1096 on the loaded batch.  Returns yp (device tensor)."""
         P = self.params
         main = torch.cuda.current_stream()
+        if getattr(L, "token", False):                                      # model_v2.py:524-645
+            T_, I_ = L.groups["text"], L.groups.get("image")
+            cw = self.cwdim
+            T_.embed.forward(T_.word_ids, T_.char_ids, T_.tok_off, P.view(self.N_WORD_EMB), self.existing_emb_mat,
+                             P.view(self.N_CHAR_EMB) if cw else None, P.view(self.N_CONV_F) if cw else None,
+                             P.view(self.N_CONV_B) if cw else None, T_.x)
+            if I_ is not None:
+                it = self.use_image_trans
+                I_.embed.forward(I_.pidx, I_.tok_off, L.image_emb_mat, P.view(self.N_IMGT_W) if it else None,
+                                 P.view(self.N_IMGT_B) if it else None, I_.x)
         # the photo cell (few rows, one short latency-bound launch per photo) runs beside the text cell on a side
         # HIP stream: the two write disjoint rows of the arena and meet again before the attention.  It is
         # enqueued FIRST -- a side stream that waits for main after the text launches are queued runs after them.
@@ -509,6 +621,8 @@ class Model:
             L.att.backward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, d_hall, d_hq, daW, dab,
                            accumulate=2)
         main = torch.cuda.current_stream()
+        token = getattr(L, "token", False)
+        need_dx = need_dx or token          # the embedding parameters are trained through the encoder inputs
         for cell, G in sorted(L.groups.items(), key=lambda kv: kv[0] != "image"):   # side-stream cell first, see forward
             kf, bf, kb, bb = self._cell_params(cell)
             dkf, dbf, dkb, dbb = self._cell_params(cell, grad=True)
@@ -522,6 +636,16 @@ class Model:
                     G.dx.zero_()
                 G.op.backward(G.x, L.arena, L.d_arena, kf, kb, G.dx if need_dx else None, dkf, dbf, dkb, dbb)
         main.wait_stream(self._side)            # both cells' gradients are in params.grad
+        if token:
+            T_, I_ = L.groups["text"], L.groups.get("image")
+            cw = self.cwdim
+            g = lambda n: P.view(n, True)
+            T_.embed.backward(T_.word_ids, T_.char_ids, T_.tok_off, P.view(self.N_CHAR_EMB) if cw else None,
+                              P.view(self.N_CONV_F) if cw else None, T_.dx, g(self.N_WORD_EMB),
+                              g(self.N_CHAR_EMB) if cw else None, g(self.N_CONV_F) if cw else None,
+                              g(self.N_CONV_B) if cw else None)
+            if I_ is not None and self.use_image_trans:
+                I_.embed.backward(I_.pidx, I_.tok_off, L.image_emb_mat, I_.x, I_.dx, g(self.N_IMGT_W), g(self.N_IMGT_B))
 
     def zero_grad(self):
         self.params.grad.zero_()

@@ -163,6 +163,43 @@ def make_inputs(spec: SynthSpec, rank: int = 0, dtype=torch.float32):
     )
 
 
+def make_token_inputs(spec: SynthSpec, VW=300, VF=2000, VC=60, W=16, VI=None, rank: int = 0):
+    """The same batch as make_inputs but in the reference's own feed form (model_v2.py:415-470): word ids in
+    [0, VW + VF) (ids >= VW index the frozen `existing_emb_mat`), char ids [.., W], photo indices into a per-batch
+    `image_emb_mat` [VI, img feature dim].  Masks / lengths / y are those of make_inputs (same seed)."""
+    base = make_inputs(spec, rank)
+    g = torch.Generator().manual_seed(spec.seed + 7919 + rank)
+
+    def text(st):
+        lead = tuple(st["x"].shape[:-1])
+        return dict(ids=torch.randint(0, VW + VF, lead, generator=g, dtype=torch.int32),
+                    chars=torch.randint(0, VC, lead + (W,), generator=g, dtype=torch.int32), mask=st["mask"])
+
+    ctx = []
+    for st in base["ctx"]:
+        if st["cell"] == "image":
+            lead = tuple(st["x"].shape[:-1])
+            nvi = VI or int(lead[0] * lead[1] * lead[2])
+            ctx.append(dict(pis=torch.randint(0, nvi, lead, generator=g, dtype=torch.int32), mask=st["mask"], cell="image"))
+            vi = nvi
+        else:
+            ctx.append(dict(text(st), cell="text"))
+    return dict(ctx=ctx, q=text(base["q"]), choices=text(base["choices"]), y=base["y"], n_image_rows=vi)
+
+
+def make_embed_params(spec: SynthSpec, VW=300, VF=2000, VC=60, cdim=8, cwdim=100, wdim=100, idim=2537, tdim=100,
+                      use_image_trans=True, dtype=torch.float32):
+    """Embedding front-end parameters in the oracle's short-key format (+ the frozen tables)."""
+    g = torch.Generator().manual_seed(spec.seed + 104729)
+    p = dict(word_emb=torch.randn(VW, wdim, generator=g) * 0.5, existing_emb_mat=torch.randn(VF, wdim, generator=g) * 0.5)
+    if cwdim:
+        p.update(char_emb=torch.randn(VC, cdim, generator=g) * 0.5,
+                 conv_filter=torch.randn(1, 5, cdim, cwdim, generator=g) * 0.3, conv_bias=torch.randn(cwdim, generator=g) * 0.1)
+    if use_image_trans:
+        p.update(img_W=_trunc_normal(g, (idim, tdim)) * 0.3, img_b=torch.zeros(tdim))
+    return {k: v.to(dtype) for k, v in p.items()}
+
+
 def to_numpy(tree, dtype=None):
     """torch tree -> numpy tree (for the literal oracle)."""
     import numpy as np

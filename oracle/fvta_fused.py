@@ -237,6 +237,28 @@ def attention_gru_cell(inputs, state, Wg, bg, Wc, Wi, bi):
     return (1 - g) * state + g * torch.tanh(r + x @ Wi + bi)
 
 
+def embed_inputs(params, tok, cfg):
+    """model_v2.py:524-645 over a whole token-id batch: `tok` has the layout of the encoder-input dict but text
+    streams carry ids [..., J] (+ chars [..., J, W]) and the photo stream pis [N, M, JI]; returns the encoder-input
+    dict fvta_forward takes.  params: word_emb, existing_emb_mat, (char_emb, conv_filter, conv_bias), (img_W, img_b)."""
+    use_char = "char_emb" in params and params.get("char_emb") is not None
+
+    def text(st):
+        return embed_tokens(st["ids"], st.get("chars"), params["word_emb"], params["existing_emb_mat"],
+                            params["char_emb"] if use_char else None, params.get("conv_filter"), params.get("conv_bias"))
+
+    ctx = []
+    for st in tok["ctx"]:
+        if st.get("cell", "text") == "image":
+            x = image_features(st["pis"], tok["image_emb_mat"].to(params["word_emb"].dtype), params.get("img_W"),
+                               params.get("img_b"), bool(cfg.get("add_tanh", False)))
+        else:
+            x = text(st)
+        ctx.append(dict(x=x, mask=st["mask"], cell=st.get("cell", "text")))
+    return dict(ctx=ctx, q=dict(x=text(tok["q"]), mask=tok["q"]["mask"]),
+                choices=dict(x=text(tok["choices"]), mask=tok["choices"]["mask"]), y=tok.get("y"))
+
+
 # ------------------------------------------------------------- whole path ---
 def fvta_forward(params, inputs, cfg):
     """Same contract as oracle.fvta_literal.fvta_forward, on torch tensors."""

@@ -198,3 +198,38 @@ def test_forward_backward_bitwise_reproducible(precision):
         else:
             for a, b, name in zip(cur, ref, ("arena", "g1", "yp", "grad")):
                 assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("use_char,use_image_trans", [(True, True), (False, False)])
+def test_token_id_entry_matches_oracle(use_char, use_image_trans):
+    """the model entered with the reference's own feed (word / char ids, photo indices):
+    yp, loss and the gradients of the embedding parameters vs the oracle (embed_inputs -> fvta_forward)."""
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import SynthSpec, make_embed_params, make_params, make_token_inputs
+    from oracle import fvta_fused as F
+    VW, VF, VC, W, cd, cw, wd, idim, tdim = 40, 60, 30, 12, 8, 24 if use_char else 0, 20, 57, 16 if use_image_trans else 57
+    spec = SynthSpec(N=3, A=2, P=3, S=2, L=5, d=32, SA=1, dense=False, text_in=wd + cw, img_in=tdim)
+    params = dict(make_params(spec), **make_embed_params(spec, VW, VF, VC, cd, cw, wd, idim, tdim, use_image_trans))
+    tok = make_token_inputs(spec, VW, VF, VC, W)
+    g = torch.Generator().manual_seed(3)
+    tok["image_emb_mat"] = torch.randn(tok["n_image_rows"], idim, generator=g) * 0.5
+    cfg = dict(spec.cfg(), batch_size=spec.N, word_vocab_size=VW, word_emb_size=wd, use_char=use_char, char_vocab_size=VC,
+               max_word_size=W, char_emb_size=cd, char_out_size=cw, image_feat_dim=idim, use_image_trans=use_image_trans,
+               image_trans_dim=tdim)
+    p64 = {k: (v.double().requires_grad_() if k != "existing_emb_mat" else v.double()) for k, v in params.items()}
+    ref = F.fvta_forward(p64, F.embed_inputs(p64, tok, cfg), cfg)
+    ref["loss"].backward()
+    model = Model(cfg)
+    model.set_oracle_params(params)
+    L = model.load_inputs(tok, training=True)
+    model.zero_grad()
+    yp = model.forward(L)
+    _close(yp, ref["yp"], msg="yp")
+    _close(model.loss, ref["loss"].reshape(1), msg="loss")
+    model.backward(L)
+    grads = model.get_oracle_grads()
+    keys = ["word_emb", "text_kernel", "out_W"] + (["char_emb", "conv_filter", "conv_bias"] if use_char else []) \
+        + (["img_W", "img_b"] if use_image_trans else [])
+    for k in keys:
+        exp = p64[k].grad.numpy()
+        _close(np.asarray(grads[k]).reshape(exp.shape), exp, rtol=2e-4, atol=2e-6, msg="grad " + k)

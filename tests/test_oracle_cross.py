@@ -98,3 +98,39 @@ def test_attention_gru_cell_agree():
     a = F.attention_gru_cell(*args).numpy()
     b = L.attention_gru_cell(*[x.numpy() for x in args])
     np.testing.assert_allclose(a, b, rtol=1e-12)
+
+
+@pytest.mark.parametrize("W,cd,cw,wd", [(16, 8, 100, 100), (7, 3, 5, 11)])
+def test_embedding_front_end_agree(W, cd, cw, wd):
+    """model_v2.py:52-70, 524-645: literal sliding-window conv1d vs the unfold+matmul restatement, fp64."""
+    g = np.random.default_rng(W + cw)
+    VW, VF, VC = 9, 6, 13
+    we, fe, ce = g.normal(size=(VW, wd)), g.normal(size=(VF, wd)), g.normal(size=(VC, cd))
+    fl, b = g.normal(size=(1, 5, cd, cw)) * 0.3, g.normal(size=cw) * 0.1
+    ids = g.integers(0, VW + VF, size=(2, 3, 4))
+    ch = g.integers(0, VC, size=(2, 3, 4, W))
+    lit = L.embed_tokens(ids, ch, we, fe, ce, fl, b)
+    t = torch.tensor
+    fus = F.embed_tokens(t(ids), t(ch), t(we), t(fe), t(ce), t(fl), t(b)).numpy()
+    assert lit.shape == (2, 3, 4, cw + wd)
+    np.testing.assert_allclose(fus, lit, rtol=1e-12, atol=1e-12)
+    # char part first, word part second (model_v2.py:611), frozen rows index past the trainable ones (:590)
+    np.testing.assert_array_equal(lit[..., cw:], np.concatenate([we, fe], 0)[ids])
+    np.testing.assert_allclose(F.embed_tokens(t(ids), None, t(we), t(fe), None, None, None).numpy(),
+                               L.embed_tokens(ids, None, we, fe, None, None, None))
+    feat, Wm, bm = g.normal(size=(5, 17)), g.normal(size=(17, 6)), g.normal(size=6)
+    pis = g.integers(0, 5, size=(2, 2, 3))
+    np.testing.assert_allclose(F.image_features(t(pis), t(feat), t(Wm), t(bm), True).numpy(),
+                               L.image_features(pis, feat, Wm, bm, True), rtol=1e-12)
+    np.testing.assert_array_equal(L.image_features(pis, feat), feat[pis])
+
+
+def test_conv1d_known_answer():
+    """one filter that picks char-embedding channel 0 of the window's first position: output = relu(max over the
+    W-4 window starts of that value + bias)."""
+    x = np.zeros((1, 1, 8, 2))
+    x[0, 0, :, 0] = [3, -1, 7, 2, 9, 100, 100, 100]          # only starts 0..3 exist for height 5
+    filt = np.zeros((1, 5, 2, 1))
+    filt[0, 0, 0, 0] = 1.0
+    assert L.conv1d(x, filt, np.array([-1.0]))[0, 0, 0] == 6.0      # max(3,-1,7,2) - 1
+    assert L.conv1d(x, filt, np.array([-10.0]))[0, 0, 0] == 0.0     # relu
