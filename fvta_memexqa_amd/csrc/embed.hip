@@ -9,8 +9,9 @@
 namespace fvta {
 
 constexpr int EMB_NT = 128;       // threads = max cwdim
-constexpr int EMB_MAXKC = 64;     // height * cdim
-constexpr int EMB_MAXWC = 1024;   // W * cdim
+constexpr int EMB_MAXKC = 64;     // height * cdim of the register-resident kernels
+constexpr int EMB_MAXWC = 1024;   // W * cdim of the register-resident kernels
+constexpr int EMB_BIG_WC = 8192;  // W * cdim of the general kernels (the published flag set: char_emb_size 100)
 constexpr int EMB_MAXVC = 1024;   // char vocabulary (backward's per-workgroup table)
 constexpr int EMB_BWD_BLOCKS = 2048;
 
@@ -298,6 +299,100 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_5x8(EmbArgs a) {
   for (int i = tid; i < d.VC * 8; i += EMB_NT) slab[40 * cw + cw + i] = s_dC[i];
 }
 
+// ---- general shape (any height * cdim, e.g. README.MD:144's --char_emb_size 100: a 500-deep window) ------------
+// Correct and order-fixed, not fast: the filter does not fit registers or LDS, so it is streamed from L2
+// (coalesced over the filter index) and the workgroup's filter-gradient slab is accumulated in global memory by
+// its owner threads.  The reference's default shape never gets here (embed_*_kernel_5x8).
+__global__ __launch_bounds__(EMB_NT) void embed_fwd_kernel_big(EmbArgs a) {
+  extern __shared__ float s_dyn[];  // E [W * cdim]
+  const fvta_embed_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int KC = d.height * d.cdim, P = d.W - d.height + 1, WC = d.W * d.cdim;
+  const float bf = tid < d.cwdim ? a.bias[tid] : 0.f;
+  for (int tok = blockIdx.x; tok < d.ntok; tok += gridDim.x) {
+    float* row = a.x + a.tok_off[tok];
+    __syncthreads();
+    for (int i = tid; i < WC; i += EMB_NT)
+      s_dyn[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / d.cdim] * d.cdim + i % d.cdim];
+    __syncthreads();
+    if (tid < d.cwdim) {
+      float best = -INFINITY;
+      int bp = 0;
+      for (int p = 0; p < P; ++p) {
+        const float* e = s_dyn + p * d.cdim;
+        float v = 0.f;
+        for (int i = 0; i < KC; ++i) v += e[i] * a.filt[(size_t)i * d.cwdim + tid];
+        if (v > best) {
+          best = v;
+          bp = p;
+        }
+      }
+      const float y = best + bf;
+      row[tid] = y > 0.f ? y : 0.f;
+      a.argpos[(size_t)tok * d.cwdim + tid] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
+    }
+    const int id = a.word_ids[tok];
+    const float* src = id < d.VW ? a.word_emb + (size_t)id * d.wdim : a.fixed_emb + (size_t)(id - d.VW) * d.wdim;
+    for (int i = tid; i < d.wdim; i += EMB_NT) row[d.cwdim + i] = src[i];
+  }
+}
+
+// the slab [KC*cwdim | cwdim | VC*cdim] of this workgroup is zeroed by the launcher and accumulated in place
+__global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_big(EmbArgs a) {
+  extern __shared__ float s_dyn[];  // E [W*cdim], dE [W*cdim]
+  __shared__ float s_g[EMB_NT];
+  __shared__ int s_p[EMB_NT];
+  __shared__ int s_ch[64];
+  const fvta_embed_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int KC = d.height * d.cdim, WC = d.W * d.cdim;
+  float* s_E = s_dyn;
+  float* s_dE = s_dyn + WC;
+  float* slab = a.slab + (size_t)blockIdx.x * ((size_t)KC * d.cwdim + d.cwdim + (size_t)d.VC * d.cdim);
+  float* slab_b = slab + (size_t)KC * d.cwdim;
+  float* slab_c = slab_b + d.cwdim;
+  for (int tok = blockIdx.x; tok < d.ntok; tok += gridDim.x) {
+    const float* row = a.dx + a.tok_off[tok];
+    const int id = a.word_ids[tok];
+    if (id < d.VW)
+      for (int i = tid; i < d.wdim; i += EMB_NT) atomicAdd(a.d_word_emb + (size_t)id * d.wdim + i, row[d.cwdim + i]);
+    __syncthreads();
+    if (tid < d.W) s_ch[tid] = a.char_ids[(size_t)tok * d.W + tid];
+    for (int i = tid; i < WC; i += EMB_NT)
+      s_E[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / d.cdim] * d.cdim + i % d.cdim];
+    float g = 0.f;
+    int p = 0;
+    if (tid < d.cwdim) {
+      const int ap = a.argpos[(size_t)tok * d.cwdim + tid];
+      if (ap != 255) {
+        g = row[tid];
+        p = ap;
+      }
+    }
+    s_g[tid] = g;
+    s_p[tid] = p;
+    __syncthreads();
+    if (tid < d.cwdim && g != 0.f) {  // the owner of filter column f accumulates its slab column
+      slab_b[tid] += g;
+      const float* e = s_E + p * d.cdim;
+      for (int i = 0; i < KC; ++i) slab[(size_t)i * d.cwdim + tid] += g * e[i];
+    }
+    for (int i = tid; i < WC; i += EMB_NT) {
+      const int pos = i / d.cdim, c = i % d.cdim;
+      float v = 0.f;
+      for (int f = 0; f < d.cwdim; ++f) {
+        const int k = pos - s_p[f];
+        const float gf = s_g[f];
+        if (gf != 0.f && k >= 0 && k < d.height) v += gf * a.filt[(size_t)(k * d.cdim + c) * d.cwdim + f];
+      }
+      s_dE[i] = v;
+    }
+    __syncthreads();
+    if (tid < d.cdim)
+      for (int pos = 0; pos < d.W; ++pos) slab_c[(size_t)s_ch[pos] * d.cdim + tid] += s_dE[pos * d.cdim + tid];
+  }
+}
+
 // slabs -> d_filt, d_bias, d_char_emb (accumulate), fixed order over workgroups
 // 256 threads = 64 elements x 4 slab groups (group g sums slabs g, g+4, ...; the four partials combine in order)
 __global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float* __restrict__ slab, int nblk, int nfb, int nchar,
@@ -418,12 +513,16 @@ static int check_embed(const fvta_embed_desc* d) {
   FVTA_CHECK_ARG(d && d->ntok > 0 && d->wdim > 0 && d->VW >= 0 && d->VT >= d->VW, "embed: bad descriptor");
   if (d->cwdim > 0) {
     FVTA_CHECK_ARG(d->cwdim <= EMB_NT && d->W >= d->height && d->W <= 64 && d->height > 0 && d->cdim > 0 &&
-                       d->height * d->cdim <= EMB_MAXKC && d->W * d->cdim <= EMB_MAXWC && d->VC > 0 &&
-                       d->VC <= EMB_MAXVC,
-                   "embed: unsupported char-CNN shape (cwdim<=128, W<=64, height*cdim<=64, VC<=1024)");
+                       d->cdim <= EMB_NT && d->W * d->cdim <= EMB_BIG_WC && d->VC > 0 && d->VC <= EMB_MAXVC,
+                   "embed: unsupported char-CNN shape (cwdim<=128, cdim<=128, height<=W<=64, W*cdim<=8192, VC<=1024)");
   }
   return FVTA_OK;
 }
+
+static bool embed_is_big(const fvta_embed_desc* d) {
+  return d->cwdim > 0 && (d->height * d->cdim > EMB_MAXKC || d->W * d->cdim > EMB_MAXWC);
+}
+constexpr int EMB_BIG_BLOCKS = 256;
 
 static size_t embed_slab_floats(const fvta_embed_desc* d) {
   return (size_t)d->height * d->cdim * d->cwdim + d->cwdim + (size_t)d->VC * d->cdim;
@@ -431,7 +530,7 @@ static size_t embed_slab_floats(const fvta_embed_desc* d) {
 
 extern "C" size_t fvta_embed_workspace_bytes(const fvta_embed_desc* d) {
   if (check_embed(d)) return 0;
-  const size_t b = (size_t)EMB_BWD_BLOCKS * embed_slab_floats(d) * sizeof(float);
+  const size_t b = (size_t)(embed_is_big(d) ? EMB_BIG_BLOCKS : EMB_BWD_BLOCKS) * embed_slab_floats(d) * sizeof(float);
   return b < 256 ? 256 : b;
 }
 
@@ -450,7 +549,10 @@ extern "C" int fvta_embed_fwd(const fvta_embed_desc* d, const int32_t* word_ids,
   a.word_emb = word_emb; a.fixed_emb = fixed_emb; a.char_emb = char_emb; a.filt = filt; a.bias = bias;
   a.x = x; a.argpos = argpos;
   const int blocks = d->ntok < 8192 ? d->ntok : 8192;
-  if (d->cwdim > 0 && d->height == 5 && d->cdim == 8 && d->W <= 16)
+  if (embed_is_big(d)) {
+    const size_t dyn = (size_t)d->W * d->cdim * sizeof(float);
+    hipLaunchKernelGGL(embed_fwd_kernel_big, dim3(blocks), dim3(EMB_NT), dyn, (hipStream_t)stream_, a);
+  } else if (d->cwdim > 0 && d->height == 5 && d->cdim == 8 && d->W <= 16)
     hipLaunchKernelGGL(embed_fwd_kernel_5x8, dim3(blocks), dim3(EMB_NT), 0, (hipStream_t)stream_, a);
   else
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks), dim3(EMB_NT), 0, (hipStream_t)stream_, a);
@@ -473,18 +575,29 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
   a.word_ids = word_ids; a.char_ids = char_ids; a.tok_off = tok_off;
   a.char_emb = char_emb; a.filt = filt; a.argpos = const_cast<uint8_t*>(argpos);
   a.dx = dx; a.d_word_emb = d_word_emb; a.slab = (float*)workspace;
-  const int blocks = d->ntok < EMB_BWD_BLOCKS ? d->ntok : EMB_BWD_BLOCKS;
-  const size_t dyn = ((size_t)d->height * d->cdim * d->cwdim + (size_t)d->VC * d->cdim) * sizeof(float);
-  if (dyn > 32 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)dyn);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel_5x8),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+  int blocks;
+  if (embed_is_big(d)) {
+    blocks = d->ntok < EMB_BIG_BLOCKS ? d->ntok : EMB_BIG_BLOCKS;
+    FVTA_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)blocks * embed_slab_floats(d) * sizeof(float), stream));
+    const size_t dyn = (size_t)2 * d->W * d->cdim * sizeof(float);
+    if (dyn > 32 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel_big),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    hipLaunchKernelGGL(embed_bwd_kernel_big, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
+  } else {
+    blocks = d->ntok < EMB_BWD_BLOCKS ? d->ntok : EMB_BWD_BLOCKS;
+    const size_t dyn = ((size_t)d->height * d->cdim * d->cwdim + (size_t)d->VC * d->cdim) * sizeof(float);
+    if (dyn > 32 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)dyn);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel_5x8),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    }
+    if (d->cwdim > 0 && d->height == 5 && d->cdim == 8 && d->W <= 16)
+      hipLaunchKernelGGL(embed_bwd_kernel_5x8, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
+    else
+      hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
   }
-  if (d->cwdim > 0 && d->height == 5 && d->cdim == 8 && d->W <= 16)
-    hipLaunchKernelGGL(embed_bwd_kernel_5x8, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
-  else
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
   if (d->cwdim > 0) {
     const int nfilt = d->height * d->cdim * d->cwdim, nfb = nfilt + d->cwdim, nchar = d->VC * d->cdim;
     hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((nfb + nchar + 63) / 64), dim3(256), 0, stream,

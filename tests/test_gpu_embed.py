@@ -24,7 +24,9 @@ def _case(seed, B, J, W, cd, cw, wd, VW, VF, VC):
 
 
 @pytest.mark.parametrize("B,J,W,cd,cw,wd,VW,VF,VC", [(3, 7, 16, 8, 100, 100, 50, 30, 40), (5, 4, 9, 4, 24, 300, 7, 5, 11),
-                                                      (64, 30, 16, 8, 100, 100, 500, 2000, 97)])
+                                                      (64, 30, 16, 8, 100, 100, 500, 2000, 97),
+                                                      (4, 6, 16, 100, 100, 100, 20, 30, 60),   # README.MD:144 flags
+                                                      (3, 5, 21, 8, 64, 50, 9, 9, 20)])         # W > 16: general kernels
 def test_token_embed_forward_backward(B, J, W, cd, cw, wd, VW, VF, VC):
     from fvta_memexqa_amd import ops
     from oracle import fvta_fused as F
