@@ -11,9 +11,12 @@ Surface kept from the reference:
   Model.att_logits / .q_att_logits / .hall        model_v2.py:914, 1022, 1045 (vis)
   parameter names of the TF checkpoint / weights.npz (main.py:578-588)
 
-Entry level: the ENCODER INPUTS (embedded token / photo features + masks), i.e.
-the tensors x* of model_v2.py:680-688.  The embedding front-end
-(model_v2.py:524-645) and get_feed_dict (1099-1565) are SURVEY 8f "next" rows.
+Three entry levels, all through load_inputs():
+  * the reference's own feed (Dataset mini-batch -> get_feed_dict -> id / char / photo-index arrays,
+    model_v2.py:1099-1565), with the embedding front-end (524-645) inside the step -- needs the vocabulary sizes in
+    the config;
+  * the same index arrays as an `inputs` tree (synth.make_token_inputs);
+  * the ENCODER INPUTS x* of model_v2.py:680-688 (embedded tokens / photo features + masks) -- the bench headline.
 """
 import math
 from types import SimpleNamespace
@@ -148,6 +151,7 @@ class Model:
         self.loss = self.yp = self.logits = None
         self.att_logits = self.q_att_logits = self.hall = None
         self._layouts = {}
+        self.max_layouts = int(_cfg(config, "max_cached_layouts", 4))
         self._side = torch.cuda.Stream(device=self.dev)
 
         dp, wp = self.dp, self.wp
@@ -317,17 +321,27 @@ class Model:
             self.window_t = float(p["window_t"])
         self.set_weights({m[k]: v for k, v in p.items() if k in m})
 
+    def _oracle_names(self):
+        return {self.N_TEXT_K % "fw": "text_kernel", self.N_TEXT_B % "fw": "text_bias",
+                self.N_TEXT_K % "bw": "text_kernel_bw", self.N_TEXT_B % "bw": "text_bias_bw",
+                self.N_IMG_K % "fw": "image_kernel", self.N_IMG_B % "fw": "image_bias",
+                self.N_IMG_K % "bw": "image_kernel_bw", self.N_IMG_B % "bw": "image_bias_bw",
+                self.N_ATT_W: "att_W", self.N_ATT_B: "att_b", self.N_QATT_W: "qatt_W", self.N_QATT_B: "qatt_b",
+                self.N_OUT_W: "out_W", self.N_OUT_B: "out_b", self.N_TW_WH_W: "WH_W", self.N_TW_WH_B: "WH_b",
+                self.N_TW_WC_W: "WC_W", self.N_TW_WC_B: "WC_b", self.N_WORD_EMB: "word_emb", self.N_CHAR_EMB: "char_emb",
+                self.N_CONV_F: "conv_filter", self.N_CONV_B: "conv_bias", self.N_IMGT_W: "img_W", self.N_IMGT_B: "img_b"}
+
     def get_oracle_grads(self):
-        g = self.get_weights(grad=True)
-        m = {self.N_TEXT_K % "fw": "text_kernel", self.N_TEXT_B % "fw": "text_bias",
-             self.N_TEXT_K % "bw": "text_kernel_bw", self.N_TEXT_B % "bw": "text_bias_bw",
-             self.N_IMG_K % "fw": "image_kernel", self.N_IMG_B % "fw": "image_bias",
-             self.N_IMG_K % "bw": "image_kernel_bw", self.N_IMG_B % "bw": "image_bias_bw",
-             self.N_ATT_W: "att_W", self.N_ATT_B: "att_b", self.N_QATT_W: "qatt_W", self.N_QATT_B: "qatt_b",
-             self.N_OUT_W: "out_W", self.N_OUT_B: "out_b", self.N_TW_WH_W: "WH_W", self.N_TW_WH_B: "WH_b",
-             self.N_TW_WC_W: "WC_W", self.N_TW_WC_B: "WC_b", self.N_WORD_EMB: "word_emb", self.N_CHAR_EMB: "char_emb",
-             self.N_CONV_F: "conv_filter", self.N_CONV_B: "conv_bias", self.N_IMGT_W: "img_W", self.N_IMGT_B: "img_b"}
-        return {m[k]: v for k, v in g.items()}
+        m = self._oracle_names()
+        return {m[k]: v for k, v in self.get_weights(grad=True).items()}
+
+    def get_oracle_params(self):
+        """current parameters in the oracle's short-key format (torch fp32, CPU), incl. the frozen word table"""
+        m = self._oracle_names()
+        out = {m[k]: torch.from_numpy(np.ascontiguousarray(v)) for k, v in self.get_weights().items()}
+        if self.token_mode:
+            out["existing_emb_mat"] = self.existing_emb_mat.cpu()
+        return out
 
     def set_existing_emb(self, mat):
         """the frozen pre-trained word vectors the reference feeds as `existing_emb_mat` (model_v2.py:470, 590):
@@ -339,7 +353,10 @@ class Model:
         key = (tuple(shapes["ctx"]), shapes["q"], shapes["choices"], bool(training), int(self.existing_emb_mat.shape[0])
                if self.token_mode else -1)
         if key in self._layouts:
+            self._layouts[key] = self._layouts.pop(key)      # most recently used last
             return self._layouts[key]
+        while len(self._layouts) >= self.max_layouts:         # real batches change shape (per-batch maxima): bounded cache
+            self._layouts.pop(next(iter(self._layouts)))
         L = _Layout()
         dev, wp, dp = self.dev, self.wp, self.dp
         N, JQ = shapes["q"]
@@ -464,18 +481,43 @@ class Model:
                     q=cls._lead(inputs["q"]), choices=cls._lead(inputs["choices"]))
 
     def get_feed_dict(self, batch, is_train=False):
-        """model_v2.py:1099: here a batch already holds ENCODER inputs (the oracle
-        `inputs` dict, optionally with 'num_examples'); the token-id form of the
-        reference's feed dict needs the embedding front-end."""
-        if not (isinstance(batch, dict) and "ctx" in batch):
-            raise NotImplementedError("raw Dataset batches need the host batch assembly (SURVEY.md 8f rank 2); pass "
-                                      "the index arrays of the reference's feed (ids / chars / pis) or encoder inputs")
-        return batch
+        """model_v2.py:1099-1565.  `batch` is a utils.Dataset mini-batch (what Dataset.get_batches yields): returns the
+        reference's feed arrays keyed by placeholder name (`at`, `at_c`, `at_mask`, ..., `y`, `image_emb_mat`,
+        `existing_emb_mat`), built by feed.build_feed_dict.  A dict that already holds encoder inputs or index arrays
+        (the oracle `inputs` format) passes through."""
+        if isinstance(batch, dict) and ("ctx" in batch or "at" in batch):
+            return batch
+        if not (hasattr(batch, "data") and hasattr(batch, "shared")):
+            raise TypeError("get_feed_dict wants a utils.Dataset mini-batch or an inputs / feed dict")
+        from .feed import build_feed_dict
+        feed, self._vocab_memo = build_feed_dict(self.config, batch, is_train, self.num_choice,
+                                                 getattr(self, "_vocab_memo", None))
+        return feed
+
+    def inputs_from_feed(self, feed):
+        """feed dict (placeholder names) -> the `inputs` tree load_inputs takes; context streams in the reference's
+        stacking order at, ad, when, where, pts, pis (model_v2.py:905-912; `no_photo` drops pis)."""
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+        def text(n):
+            return dict(ids=t(feed[n]), chars=t(feed[n + "_c"]), mask=t(feed[n + "_mask"]), cell="text")
+
+        ctx = [text(n) for n in ("at", "ad", "when", "where", "pts")]
+        if not _cfg(self.config, "no_photo", False):
+            ctx.append(dict(pis=t(feed["pis"]), mask=t(feed["pis_mask"]), cell="image"))
+        emb = feed.get("existing_emb_mat")
+        if emb is not None and emb is not getattr(self, "_fed_emb", None):     # fed every step, uploaded when it changes
+            self.set_existing_emb(emb)
+            self._fed_emb = emb
+        return dict(ctx=ctx, q=text("q"), choices=text("choices"), y=t(feed["y"]) if feed.get("y") is not None else None,
+                    image_emb_mat=feed["image_emb_mat"])
 
     def load_inputs(self, inputs, training=False):
         """Copy encoder inputs (oracle `inputs` format, any device) into the arenas.
         Host-side plumbing: masks -> lengths (model_v2.py:667-678) and the mask
         pad/stack of model_v2.py:890-912."""
+        if "at" in inputs:
+            inputs = self.inputs_from_feed(inputs)
         L = self._layout(self.shapes_of(inputs), training)
         dev = self.dev
 

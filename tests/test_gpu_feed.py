@@ -1,0 +1,92 @@
+"""The reference's own entry, end to end on the GPU: Dataset.get_batches -> Trainer.step / Tester.step
+(trainer.py:30-40, tester.py:16-25) on the golden synthetic dataset, checked against the oracle run on the SAME feed
+arrays (embed_inputs -> fvta_forward).  Streams have different lengths here (album title / description / when / where
+/ photo titles / photos), so the context tensor's per-stream padding to JMAX (model_v2.py:863-914) is exercised with
+real shapes, and the last batch is short (num_examples < batch_size)."""
+import json
+import os
+from copy import deepcopy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Config:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _setup(name, is_train, **over):
+    from test_feed_golden import MAXMETA, load_case
+    from fvta_memexqa_amd import utils as U
+    js, z, shared, case, config = load_case(os.path.join(HERE, "golden", name + ".json"))
+    config.is_train = is_train
+    U.update_config(config, [U.Dataset(deepcopy(js["data"]), "x", shared=shared)])
+    config.__dict__.update(hidden_size=32, simiMatrix=2, add_tanh=True, use_question_att=True, num_choice=4,
+                           word_vocab_size=len(shared["word2idx"]) + 2, char_vocab_size=len(shared["char2idx"]) + 2,
+                           word_emb_size=shared["existing_emb_mat"].shape[1], use_char=True, char_emb_size=8, char_out_size=12,
+                           image_feat_dim=z["pid2feat"].shape[1], use_image_trans=True, image_trans_dim=8, init_lr=0.5,
+                           precision="f32", **over)
+    ds = U.Dataset(deepcopy(js["data"]), "train" if is_train else "val", shared=shared)
+    return config, ds, case
+
+
+def _oracle(model, feed, cfg):
+    from oracle import fvta_fused as F
+    tok = model.inputs_from_feed(feed)                 # (uploads the fed existing_emb_mat on first sight)
+    p = {k: v.double() for k, v in model.get_oracle_params().items()}
+    tok["image_emb_mat"] = torch.from_numpy(np.asarray(tok["image_emb_mat"])).double()
+    ocfg = dict(hidden_size=cfg.hidden_size, simiMatrix=cfg.simiMatrix, add_tanh=cfg.add_tanh,
+                use_question_att=cfg.use_question_att, num_choice=4)
+    return F.fvta_forward(p, F.embed_inputs(p, tok, ocfg), ocfg)
+
+
+def test_tester_step_on_dataset_batches():
+    from fvta_memexqa_amd.model_v2 import get_model
+    from fvta_memexqa_amd.tester import Tester
+    config, ds, case = _setup("feed_test_nocaps", False)
+    model = get_model(config)
+    tester = Tester(model, config)
+    seen = 0
+    for batch in ds.get_batches(case["batch_size"], case["steps"], shuffle=False):
+        yp = tester.step(None, batch)
+        assert yp.shape == (batch[1].num_examples, 4)
+        ref = _oracle(model, model.get_feed_dict(batch[1], is_train=False), config)["yp"].numpy()[:batch[1].num_examples]
+        np.testing.assert_allclose(yp, ref, rtol=1e-4, atol=1e-6)
+        assert (yp.argmax(1) == ref.argmax(1)).all()
+        seen += len(yp)
+    assert seen == ds.num_examples                       # 10 QA pairs in batches of 3: the last batch holds one
+
+
+def test_trainer_step_on_dataset_batches():
+    from fvta_memexqa_amd.model_v2 import get_model
+    from fvta_memexqa_amd.trainer import Trainer
+    config, ds, case = _setup("feed_train_shuffle", True)
+    model = get_model(config)
+    trainer = Trainer(model, config)
+    import random
+    random.seed(5)
+    for b, batch in enumerate(ds.get_batches(case["batch_size"], 3, shuffle=True)):
+        np.random.seed(100 + b)                           # the slot of the correct answer is drawn inside get_feed_dict
+        feed = model.get_feed_dict(batch[1], is_train=True)
+        ref = _oracle(model, feed, config)                # with the parameters BEFORE the update
+        np.random.seed(100 + b)
+        loss, summary, train_op = trainer.step(None, batch)
+        assert summary is None
+        np.testing.assert_allclose(loss, float(ref["loss"]), rtol=1e-4)
+    assert model.global_step == 3
+
+
+def test_no_photo_drops_the_photo_stream():
+    from fvta_memexqa_amd.model_v2 import get_model
+    config, ds, case = _setup("feed_test_nocaps", False, no_photo=True)
+    model = get_model(config)
+    batch = next(ds.get_batches(case["batch_size"], 1, shuffle=False))
+    L = model.load_inputs(model.get_feed_dict(batch[1]), training=False)
+    assert L.K == 5 and "image" not in L.groups          # model_v2.py:864-865
+    model.forward(L)
+    assert torch.isfinite(model.yp).all()
