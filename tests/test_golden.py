@@ -10,7 +10,7 @@ import torch
 from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params, to_dtype, to_numpy
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
+FILES = sorted(glob.glob(os.path.join(HERE, "golden", "fvta_*.npz")))
 
 
 def _spec(z):
