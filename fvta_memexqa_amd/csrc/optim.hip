@@ -27,7 +27,35 @@ __global__ void adam_kernel(float* __restrict__ var, const float* __restrict__ g
   v[i] = vi;
   var[i] -= lr_t * mi / (sqrtf(vi) + eps);
 }
+// add_wd (model_v2.py:347-354): one term wd * l2_loss(var) = wd/2 * sum(var^2) per trainable of the scope.
+// One workgroup per call so that the sum has ONE fixed order (bitwise reproducible); the slices are small (<= ~3M).
+__global__ __launch_bounds__(1024) void weight_decay_kernel(const float* __restrict__ p, float* __restrict__ g, int64_t n,
+                                                            float coef, float* __restrict__ loss) {
+  __shared__ float s_red[1024];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float v = p[i];
+    if (g) g[i] += coef * v;
+    acc += v * v;
+  }
+  if (!loss) return;
+  s_red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) s_red[threadIdx.x] += s_red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] += 0.5f * coef * s_red[0];
+}
 }  // namespace fvta
+
+extern "C" int fvta_weight_decay(const float* var, float* grad, int64_t n, float coef, float* loss,
+                                 fvta_stream_t stream) {
+  FVTA_CHECK_ARG(var && n > 0 && (grad || loss), "weight_decay: bad arguments");
+  hipLaunchKernelGGL(fvta::weight_decay_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, var, grad, n, coef, loss);
+  FVTA_CHECK_LAUNCH("weight_decay");
+  return FVTA_OK;
+}
 
 extern "C" int fvta_adadelta_step(float* var, const float* grad, float* accum, float* accum_update, int64_t n,
                                   float lr, float rho, float eps, float grad_scale, fvta_stream_t stream) {

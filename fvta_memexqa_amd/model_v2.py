@@ -110,8 +110,7 @@ class Model:
         self.use_eu_output = bool(_cfg(config, "use_eu_output", False))
         self.share_fw_bw = bool(_cfg(config, "share_fw_bw", True))
         self.precision = {"f32": F32, "bf16": BF16}[_cfg(config, "precision", "f32")]
-        if _cfg(config, "wd", None) not in (None, 0.0):
-            raise NotImplementedError("weight decay (--wd) is not built yet")
+        self.wd = float(_cfg(config, "wd", None) or 0.0)                # --wd (main.py:105); None / 0.0: no l2 terms
         if float(_cfg(config, "keep_prob", 1.0)) != 1.0:
             raise NotImplementedError("LSTM input dropout (--keep_prob < 1) is not built yet")
         self.use_time_warp = bool(_cfg(config, "use_time_warp", False))
@@ -185,6 +184,28 @@ class Model:
             self._plain = {self.N_WORD_EMB, self.N_CHAR_EMB, self.N_CONV_F, self.N_CONV_B, self.N_IMGT_W, self.N_IMGT_B}
         self.params = ParamStore(specs, self.dev)
         self.init_parameters(int(_cfg(config, "weight_seed", 42)))
+        self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self.dev)
+
+    def wd_multipliers(self):
+        """How many add_wd calls cover each variable (model_v2.py:347-354 adds one l2 term per trainable of the
+        CURRENT scope per call): the reader scope once (:835-836: both LSTM cells), attention/all and
+        question_emb/question_att once each (:295-296, :198-199), image_trans_linear once (:96-97 via :645), and the
+        shared char-CNN filter/bias once per conv1d call -- seven (:564-571).  Embedding tables, the scorer and the time
+        warp carry no wd argument."""
+        out = {}
+        for name in self.params.specs:
+            if name.startswith("reader/") or name.startswith("attention/all/") or name.startswith("question_emb/question_att/") \
+                    or name.startswith("emb/image/image_transform/image_trans_linear/"):
+                out[name] = 1
+            elif name.startswith("emb/conv/conv1d/"):
+                out[name] = 7
+        return out
+
+    def _apply_wd(self, grads, loss):
+        """l2 terms of the "losses" collection: into params.grad (grads=True) and/or added to the loss scalar"""
+        for name, mult in self.wd_multipliers().items():
+            ops.weight_decay(self.params.view(name).reshape(-1), self.params.view(name, True).reshape(-1) if grads else None,
+                             self.wd * mult, loss)
 
     # ------------------------------------------------------------ parameters
     def _pad_kernel(self, k, din, dinp):
@@ -617,6 +638,8 @@ class Model:
             L.gq, qatt = L.lq, None
         L.logits, L.yp, L.loss_t = ops.scorer_ce_fwd(L.gq, L.g1, L.lch, P.view(self.N_OUT_W), P.view(self.N_OUT_B),
                                                      L.y if L.has_y else None, self.use_eu_output, self.add_tanh)
+        if self.wd and L.has_y:                                              # :1094-1095: loss = add_n("losses")
+            self._apply_wd(False, L.loss_t)
         self.logits, self.yp, self.loss = L.logits, L.yp, L.loss_t
         self.hall = L.hall
         if want_logits:
@@ -678,6 +701,8 @@ class Model:
                     G.dx.zero_()
                 G.op.backward(G.x, L.arena, L.d_arena, kf, kb, G.dx if need_dx else None, dkf, dbf, dkb, dbb)
         main.wait_stream(self._side)            # both cells' gradients are in params.grad
+        if self.wd:
+            self._apply_wd(True, None)
         if token:
             T_, I_ = L.groups["text"], L.groups.get("image")
             cw = self.cwdim

@@ -182,6 +182,12 @@ def adam_step(var, grad, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_sca
                                      grad_scale, stream_ptr()), "fvta_adam_step")
 
 
+def weight_decay(var, grad, coef, loss):
+    """add_wd (model_v2.py:347-354) for one variable: loss += coef/2 * sum(var^2), grad += coef * var (either may be None)."""
+    check(_lib.load().fvta_weight_decay(ptr(var), ptr(grad) if grad is not None else None, var.numel(), float(coef),
+                                        ptr(loss) if loss is not None else None, stream_ptr()), "fvta_weight_decay")
+
+
 # ------------------------------------------------------------ AttentionGRUCell
 def attgru_fwd(inputs, state, Wg, bg, Wc, Wi, bi):
     """attention_gru_cell.py:50-70, one step.  inputs [B,d+1] (last column = gate), state [B,d]."""

@@ -272,6 +272,11 @@ int fvta_adadelta_step(float* var, const float* grad, float* accum, float* accum
                        float lr, float rho, float eps, float grad_scale, fvta_stream_t stream);
 int fvta_adam_step(float* var, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                    float beta2, float eps, int32_t t, float grad_scale, fvta_stream_t stream);
+/* add_wd (model_v2.py:347-354; --wd, main.py:105): one l2 term of the "losses" collection for one variable:
+ * loss[0] += coef/2 * sum(var^2) (if loss != NULL) and grad += coef * var (if grad != NULL); coef = wd x the number
+ * of add_wd calls that cover the variable (the shared char-CNN filter is covered once per conv1d call,
+ * model_v2.py:564-571).  Fixed summation order. */
+int fvta_weight_decay(const float* var, float* grad, int64_t n, float coef, float* loss, fvta_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Test hooks (not part of the reference surface): the MFMA tile engines the

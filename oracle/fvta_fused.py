@@ -302,5 +302,29 @@ def fvta_forward(params, inputs, cfg):
                         cfg.get("use_eu_output", False), cfg.get("add_tanh", False))
     out["logits"], out["yp"] = logits, yp
     if inputs.get("y") is not None:
-        out["loss"] = softmax_cross_entropy_mean(logits, inputs["y"])
+        out["loss"] = softmax_cross_entropy_mean(logits, inputs["y"]) + weight_decay_terms(params, cfg)
     return out
+
+
+# add_wd call sites of model_v2.py and the variables (oracle short keys) each call covers (model_v2.py:347-354: one
+# wd * l2_loss(var) per trainable of the CURRENT variable scope, added to the "losses" collection per call)
+WD_COVER = {
+    "text_kernel": 1, "text_bias": 1, "text_kernel_bw": 1, "text_bias_bw": 1,          # reader scope, :835-836
+    "image_kernel": 1, "image_bias": 1, "image_kernel_bw": 1, "image_bias_bw": 1,
+    "att_W": 1, "att_b": 1,                                                              # attention/all, :295-296
+    "qatt_W": 1, "qatt_b": 1,                                                            # question_att, :198-199
+    "img_W": 1, "img_b": 1,                                                              # image_trans_linear, :96-97
+    "conv_filter": 7, "conv_bias": 7,                                                    # conv1d x 7 calls, :564-571
+}
+
+
+def weight_decay_terms(params, cfg):
+    """sum of the l2 entries of the "losses" collection (model_v2.py:1094-1095); 0 when --wd is unset"""
+    wd = cfg.get("wd", None)
+    if not wd:
+        return 0.0
+    total = 0.0
+    for k, mult in WD_COVER.items():
+        if params.get(k) is not None and (k != "qatt_W" and k != "qatt_b" or cfg.get("use_question_att", False)):
+            total = total + mult * wd * 0.5 * (params[k] ** 2).sum()      # tf.nn.l2_loss = sum(t^2) / 2
+    return total

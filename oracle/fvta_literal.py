@@ -461,4 +461,9 @@ def fvta_forward(params, inputs, cfg):
     out["logits"], out["yp"] = logits, yp
     if inputs.get("y") is not None:
         out["loss"] = softmax_cross_entropy_mean(logits, inputs["y"])                # :1085-1096
+        if cfg.get("wd"):                                                            # add_wd, :347-354 (see fvta_fused.WD_COVER)
+            from .fvta_fused import WD_COVER
+            for k, mult in WD_COVER.items():
+                if params.get(k) is not None and (k not in ("qatt_W", "qatt_b") or cfg.get("use_question_att", False)):
+                    out["loss"] = out["loss"] + mult * cfg["wd"] * 0.5 * np.sum(np.asarray(params[k], np.float64) ** 2)
     return out

@@ -233,3 +233,49 @@ def test_token_id_entry_matches_oracle(use_char, use_image_trans):
     for k in keys:
         exp = p64[k].grad.numpy()
         _close(np.asarray(grads[k]).reshape(exp.shape), exp, rtol=2e-4, atol=2e-6, msg="grad " + k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("token", [False, True])
+def test_weight_decay_matches_oracle(token):
+    """--wd (model_v2.py:347-354): the l2 terms in the loss and their gradients, incl. the 7x cover of the shared char-CNN
+    filter; yp is unaffected."""
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import SynthSpec, make_embed_params, make_inputs, make_params, make_token_inputs
+    from oracle import fvta_fused as F
+    wd = 0.002
+    if token:
+        VW, VF, VC, W, cd, cw, wdim, idim, tdim = 40, 60, 30, 12, 8, 24, 20, 57, 16
+        spec = SynthSpec(N=3, A=2, P=3, S=2, L=5, d=32, SA=1, dense=False, text_in=wdim + cw, img_in=tdim)
+        params = dict(make_params(spec), **make_embed_params(spec, VW, VF, VC, cd, cw, wdim, idim, tdim, True))
+        inputs = make_token_inputs(spec, VW, VF, VC, W)
+        inputs["image_emb_mat"] = torch.randn(inputs["n_image_rows"], idim, generator=torch.Generator().manual_seed(3)) * 0.5
+        cfg = dict(spec.cfg(), batch_size=spec.N, word_vocab_size=VW, word_emb_size=wdim, use_char=True, char_vocab_size=VC,
+                   max_word_size=W, char_emb_size=cd, char_out_size=cw, image_feat_dim=idim, use_image_trans=True,
+                   image_trans_dim=tdim, wd=wd)
+    else:
+        spec = SynthSpec(N=3, A=2, P=3, S=2, L=5, d=32, SA=1, dense=False, text_in=12, img_in=8)
+        params, inputs = make_params(spec), make_inputs(spec)
+        cfg = dict(spec.cfg(), batch_size=spec.N, wd=wd)
+    p64 = {k: (v.double().requires_grad_() if k != "existing_emb_mat" else v.double()) for k, v in params.items()}
+    from fvta_memexqa_amd.synth import to_dtype
+    oin = F.embed_inputs(p64, inputs, cfg) if token else to_dtype(inputs, torch.float64)
+    ref = F.fvta_forward(p64, oin, cfg)
+    ref0 = F.fvta_forward(p64, oin, dict(cfg, wd=None))
+    assert float(ref["loss"].detach()) > float(ref0["loss"].detach()) + 1e-3          # the terms are not negligible in this test
+    ref["loss"].backward()
+    model = Model(cfg) if token else Model(cfg, text_in=spec.text_in, img_in=spec.img_in)
+    model.set_oracle_params(params)
+    L = model.load_inputs(inputs, training=True)
+    model.zero_grad()
+    yp = model.forward(L)
+    _close(yp, ref0["yp"], msg="yp")
+    _close(model.loss, ref["loss"].reshape(1), msg="loss")
+    model.backward(L)
+    grads = model.get_oracle_grads()
+    for k in ["text_kernel", "text_bias", "image_kernel", "att_W", "att_b", "qatt_W", "out_W"] + \
+            (["conv_filter", "conv_bias", "img_W", "img_b", "word_emb", "char_emb"] if token else []):
+        if p64.get(k) is None or p64[k].grad is None:
+            continue
+        exp = p64[k].grad.numpy()
+        _close(np.asarray(grads[k]).reshape(exp.shape), exp, rtol=2e-4, atol=2e-6, msg="grad " + k)
