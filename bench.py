@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--optimizer", default="adam", choices=["adam", "adadelta"])
     ap.add_argument("--batch", type=int, default=None, help="QA pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2, help="QA pairs in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="QA pairs in the CPU-baseline sample (4: ~10-15 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch-CPU threads of the baseline; 16 is the fastest setting measured on the 2x EPYC 9575F host "
                          "(64 threads: 3.5x slower, 128: 9.5x slower for this op mix; DESIGN.md section 5)")
@@ -175,6 +175,27 @@ def main():
         lib.fvta_profile_collect(pid, ctypes.byref(ms), ctypes.byref(n))
         return ms.value, n.value
 
+    # achievable HBM read rate on THIS device: one coalesced read-only pass over 1.5 GiB, median of 5
+    probe_gbs = None
+    if rank == 0:
+        try:
+            pbuf = torch.empty(3 << 28, dtype=torch.float32, device=dev).zero_()       # 1.5 GiB, about the context tensor
+            sink = torch.zeros(16, dtype=torch.float32, device=dev)
+            strm = torch.cuda.current_stream().cuda_stream
+            ts = []
+            for i in range(6):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                lib.fvta_probe_hbm_read(pbuf.data_ptr(), pbuf.numel() * 4, sink.data_ptr(), strm)
+                e1.record()
+                e1.synchronize()
+                if i:
+                    ts.append(e0.elapsed_time(e1))
+            probe_gbs = round(pbuf.numel() * 4 / (statistics.median(ts) * 1e-3) / 1e9, 1)
+            del pbuf
+        except Exception as exc:                                                        # measurement aid only
+            log("hbm probe failed: %r" % (exc,))
+
     prof = {name: collect(pid) for name, pid in [("lstm_step_fwd", 1), ("lstm_step_bwd", 2), ("lstm_dw", 3),
                                                  ("attn_fwd_main", 4), ("attn_bwd_main", 5)]}
     if rank != 0:
@@ -228,10 +249,15 @@ def main():
         except Exception:
             pass
         return None
-    if roof is not None and args.config == "metric" and args.precision == "bf16" and not args.batch:
+    for r_ in (roof, roof_att):
+        if r_ is not None and probe_gbs:
+            r_["achievable_peak"] = probe_gbs
+            r_["frac_of_achievable"] = round(r_["achieved"] / probe_gbs, 4)
+    dense_metric = args.config == "metric" and args.variant == "dense" and not args.batch
+    if roof is not None and dense_metric and args.precision == "bf16":
         roof["traffic"] = pmc_traffic("r01_final_lstm_pmc.json", "lstm_step_fwd_bf16")
         roof["traffic_note"] = "bytes per launch, profiles/r01_final_lstm_pmc.json; algorithmic per launch = algorithmic_bytes_per_call / 30"
-    if roof_att is not None and args.config == "metric" and not args.batch:
+    if roof_att is not None and dense_metric:
         roof_att["traffic"] = pmc_traffic("r01_final_attention_pmc.json", "attn_fwd_rows16")
         roof_att["traffic_note"] = "bytes per launch, profiles/r01_final_attention_pmc.json"
     out = dict(

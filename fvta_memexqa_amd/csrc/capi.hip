@@ -89,3 +89,31 @@ extern "C" int fvta_profile_collect(int32_t id, double* total_ms, int64_t* launc
   *launches = n;
   return FVTA_OK;
 }
+
+// ---- achievable-HBM probe (bench.py): a read-only stream over `bytes` of device memory, 16 B per lane, fully
+// coalesced, non-temporal -- the rate the roofline fractions can be held against next to the nominal 8 TB/s.
+namespace fvta {
+typedef float probe_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void hbm_read_probe_kernel(const probe_f32x4* __restrict__ p, size_t n16, float* sink) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  probe_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    probe_f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(p + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; i < n16; i += stride) acc += p[i];
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345678e30f) sink[0] = acc[0];  // never true: keeps the loads alive
+}
+}  // namespace fvta
+
+extern "C" int fvta_probe_hbm_read(const void* buf, size_t bytes, float* sink, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(buf && sink && bytes >= 16, "probe_hbm_read: bad arguments");
+  hipLaunchKernelGGL(fvta::hbm_read_probe_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream,
+                     (const fvta::probe_f32x4*)buf, bytes / 16, sink);
+  FVTA_CHECK_LAUNCH("hbm_read_probe");
+  return FVTA_OK;
+}

@@ -301,6 +301,9 @@ int fvta_test_gemm(int32_t precision, int32_t layout, int32_t M, int32_t N, int3
 #define FVTA_PROF_ATTN_BWD_MAIN 5 /* attn_bwd_main */
 int fvta_profile_enable(int32_t on);
 int fvta_profile_collect(int32_t id, double* total_ms, int64_t* launches);
+/* Measurement hook (bench.py, SURVEY 8d "achievable peak"): one read-only, fully coalesced, non-temporal pass over
+ * `bytes` of device memory; the caller times it.  Not part of the reference surface. */
+int fvta_probe_hbm_read(const void* buf, size_t bytes, float* sink, fvta_stream_t stream);
 
 #ifdef __cplusplus
 }
