@@ -90,3 +90,28 @@ def test_no_photo_drops_the_photo_stream():
     assert L.K == 5 and "image" not in L.groups          # model_v2.py:864-865
     model.forward(L)
     assert torch.isfinite(model.yp).all()
+
+
+def test_published_fvta_flag_set_on_dataset_batches():
+    """README.MD:141-147 / 219-226 flag set at its own sizes where they matter for the code paths: hidden_size 50 (padded to
+    64 by the kernels), char_emb_size 100 (the general char-CNN kernels), time warp type 5, question attention,
+    image_trans 100 -- Tester.step on Dataset batches vs the oracle on the same feed."""
+    from fvta_memexqa_amd.model_v2 import get_model
+    from fvta_memexqa_amd.tester import Tester
+    from oracle import fvta_fused as F
+    config, ds, case = _setup("feed_test_nocaps", False, use_time_warp=True, warp_type=5)
+    config.__dict__.update(hidden_size=50, char_emb_size=100, char_out_size=100, image_trans_dim=100)
+    model = get_model(config)
+    tester = Tester(model, config)
+    for batch in ds.get_batches(case["batch_size"], 2, shuffle=False):
+        yp = tester.step(None, batch)
+        feed = model.get_feed_dict(batch[1], is_train=False)
+        tok = model.inputs_from_feed(feed)
+        p = {k: (v.double() if torch.is_tensor(v) else v) for k, v in model.get_oracle_params().items()}
+        p["window_t"] = model.window_t
+        tok["image_emb_mat"] = torch.from_numpy(np.asarray(tok["image_emb_mat"])).double()
+        ocfg = dict(hidden_size=50, simiMatrix=2, add_tanh=True, use_question_att=True, num_choice=4, use_time_warp=True,
+                    warp_type=5)
+        ref = F.fvta_forward(p, F.embed_inputs(p, tok, ocfg), ocfg)["yp"].numpy()[:batch[1].num_examples]
+        np.testing.assert_allclose(yp, ref, rtol=1e-4, atol=1e-6)
+        assert (yp.argmax(1) == ref.argmax(1)).all()
