@@ -74,6 +74,10 @@ _SIGS = {
     "fvta_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float, P]),
     "fvta_weight_decay": (c_int, [P, P, c_int64, c_float, P, P]),
     "fvta_probe_hbm_read": (c_int, [P, ctypes.c_size_t, P, P]),
+    "fvta_softmax_fwd": (c_int, [P, P, c_int64, c_int32, P]),
+    "fvta_softsel_fwd": (c_int, [P, P, P, c_int64, c_int32, c_int32, P]),
+    "fvta_exp_mask": (c_int, [P, P, P, c_int64, P]),
+    "fvta_linear_fwd": (c_int, [P, P, P, P, c_int64, c_int32, c_int32, c_int32, P]),
     "fvta_test_gemm": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),
     "fvta_profile_enable": (c_int, [c_int32]),
     "fvta_profile_collect": (c_int, [c_int32, POINTER(ctypes.c_double), POINTER(c_int64)]),

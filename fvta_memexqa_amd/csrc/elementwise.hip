@@ -1,0 +1,159 @@
+// Stand-alone forms of the small graph helpers the reference exposes next to attention / attention_3d:
+// softmax (model_v2.py:23-28), softsel (39-48), linear (75-100), exp_mask (utils.py:210-213).  Inside the model
+// these are folded into the attention / scorer / embedding kernels; the stand-alone entry points exist so that code
+// written against the reference's functional surface has something to call.  Forward only.
+#include "fvta_common.h"
+
+namespace fvta {
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// softmax over the last axis: one wave per row.  grid ceil(rows/4), 256 threads
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t rows,
+                                                          int J) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float* xr = x + r * J;
+  float m = -INFINITY;
+  for (int j = lane; j < J; j += 64) m = fmaxf(m, xr[j]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int j = lane; j < J; j += 64) s += expf(xr[j] - m);
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+  for (int j = lane; j < J; j += 64) y[r * J + j] = expf(xr[j] - m) * inv;
+}
+
+// softsel: out[r, :] = sum_j softmax(logits[r, :])[j] * target[r, j, :].  One workgroup per row: the weights go to
+// LDS once, then thread c walks j for its channels (coalesced over c).  grid rows, 256 threads, dyn LDS J floats
+__global__ __launch_bounds__(256) void softsel_kernel(const float* __restrict__ target, const float* __restrict__ logits,
+                                                     float* __restrict__ out, int J, int d) {
+  extern __shared__ float s_p[];
+  __shared__ float s_red[4];
+  const int64_t r = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* lr = logits + r * J;
+  float m = -INFINITY;
+  for (int j = tid; j < J; j += 256) m = fmaxf(m, lr[j]);
+  m = wave_max(m);
+  if (lane == 0) s_red[wv] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int j = tid; j < J; j += 256) {
+    const float e = expf(lr[j] - m);
+    s_p[j] = e;
+    s += e;
+  }
+  s = wave_sum(s);
+  if (lane == 0) s_red[wv] = s;
+  __syncthreads();
+  const float inv = 1.f / ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+  const float* tr = target + r * (int64_t)J * d;
+  for (int c = tid; c < d; c += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < J; ++j) acc += s_p[j] * tr[(int64_t)j * d + c];
+    out[r * d + c] = acc * inv;
+  }
+}
+
+__global__ void exp_mask_kernel(const float* __restrict__ val, const uint8_t* __restrict__ mask, float* __restrict__ out,
+                                int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = val[i] + (1.f - (mask[i] ? 1.f : 0.f)) * FVTA_NEG;  // utils.py:213, literally
+}
+
+// linear: y[M, out] = x[M, in] * W[in, out] + b (+ tanh).  64 x 64 output tile, 16-deep k slices through LDS,
+// fp32 FMA in k order (bit-stable).  Not a hot kernel: every linear of the model is fused into its consumer.
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                     const float* __restrict__ b, float* __restrict__ y, int64_t M, int in,
+                                                     int out, int add_tanh) {
+  __shared__ float sx[64][17], sw[16][65];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 x 4 outputs each
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int n0 = blockIdx.y * 64;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < in; k0 += 16) {
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+      const int r = i >> 4, c = i & 15;
+      sx[r][c] = (m0 + r < M && k0 + c < in) ? x[(m0 + r) * in + k0 + c] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      sw[r][c] = (k0 + r < in && n0 + c < out) ? W[(int64_t)(k0 + r) * out + n0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = sx[ty * 4 + i][k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = sw[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * bb[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t m = m0 + ty * 4 + i;
+      const int n = n0 + tx * 4 + j;
+      if (m < M && n < out) {
+        const float v = acc[i][j] + (b ? b[n] : 0.f);
+        y[m * out + n] = add_tanh ? tanhf(v) : v;
+      }
+    }
+}
+
+}  // namespace fvta
+
+extern "C" int fvta_softmax_fwd(const float* logits, float* out, int64_t rows, int32_t J, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(logits && out && rows > 0 && J > 0, "softmax_fwd: bad arguments");
+  hipLaunchKernelGGL(fvta::softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits,
+                     out, rows, J);
+  FVTA_CHECK_LAUNCH("softmax_rows");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_softsel_fwd(const float* target, const float* logits, float* out, int64_t rows, int32_t J, int32_t d,
+                                fvta_stream_t stream) {
+  FVTA_CHECK_ARG(target && logits && out && rows > 0 && J > 0 && d > 0, "softsel_fwd: bad arguments");
+  FVTA_CHECK_ARG(J <= 16000 && rows < (1ll << 31), "softsel_fwd: J=%d > 16000 or too many rows", J);
+  hipLaunchKernelGGL(fvta::softsel_kernel, dim3((unsigned)rows), dim3(256), (size_t)J * sizeof(float), (hipStream_t)stream,
+                     target, logits, out, J, d);
+  FVTA_CHECK_LAUNCH("softsel");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_exp_mask(const float* val, const uint8_t* mask, float* out, int64_t n, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(val && mask && out && n > 0, "exp_mask: bad arguments");
+  hipLaunchKernelGGL(fvta::exp_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, val, mask,
+                     out, n);
+  FVTA_CHECK_LAUNCH("exp_mask");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_linear_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int32_t in,
+                               int32_t out, int32_t add_tanh, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(x && W && y && M > 0 && in > 0 && out > 0, "linear_fwd: bad arguments");
+  hipLaunchKernelGGL(fvta::linear_kernel, dim3((unsigned)((M + 63) / 64), (unsigned)((out + 63) / 64)), dim3(256), 0,
+                     (hipStream_t)stream, x, W, b, y, M, in, out, add_tanh);
+  FVTA_CHECK_LAUNCH("linear");
+  return FVTA_OK;
+}

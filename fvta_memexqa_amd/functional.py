@@ -1,0 +1,184 @@
+"""The reference's functional graph helpers with their own keyword signatures (SURVEY 8b "functional ops"):
+
+    softmax(logits, scope=None)                                                     model_v2.py:23-28
+    softsel(target, logits, hard=False, hardK=None, scope=None)                      model_v2.py:39-48
+    linear(x, output_size, scope, add_tanh=False, wd=None)                           model_v2.py:75-100
+    exp_mask(val, mask)                                                              utils.py:210-213
+    attention(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, wd=None,
+              add_tanh=False, bidirect=False, scope=None) -> (h_a, a_logits)         model_v2.py:125-201
+    attention_3d(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, wd=None, add_tanh=False,
+                 time_warp_att=False, C=None, bidirect=False, scope=None)            model_v2.py:210-298
+
+Tensors are torch CUDA tensors; every op is one call into libfvta_hip.so (forward only -- training goes through
+`Model`, whose backward kernels own the gradients).  Where the reference creates TF variables (`linear`'s W / b, the
+`att_logits` linear inside the attentions) the variable lives in a module-level store under the same scoped name
+(`variable_scope("attention")` + `scope="all"` -> "attention/all/att_logits/W"), initialised like the reference
+(truncated normal 0.1 / zeros) and reused on the next call, which is what `tf.get_variable` under reuse does.
+`wd` appends the l2 terms to `losses` like `add_wd` (model_v2.py:347-354).
+"""
+import contextlib
+import zlib
+
+import torch
+
+from . import _lib, ops
+from ._lib import check, ptr, stream_ptr
+from .model_v2 import SUPPORTED_W
+
+variables = {}      # scoped name -> torch tensor (fp32, CUDA)
+losses = []         # the "losses" collection: scalar tensors appended by `wd`
+_scope = []
+
+
+@contextlib.contextmanager
+def variable_scope(name):
+    _scope.append(name)
+    try:
+        yield
+    finally:
+        _scope.pop()
+
+
+def reset_default_graph():
+    variables.clear()
+    del losses[:]
+
+
+def _name(*parts):
+    return "/".join(list(_scope) + [p for p in parts if p])
+
+
+def get_variable(name, shape, init="trunc_normal", seed=None):
+    """tf.get_variable under reuse: create on first use, return the same tensor afterwards."""
+    if name in variables:
+        if tuple(variables[name].shape) != tuple(shape):
+            raise ValueError("variable %s exists with shape %s, asked for %s" % (name, tuple(variables[name].shape), tuple(shape)))
+        return variables[name]
+    dev = ops.require_gpu()
+    if init == "zeros":
+        v = torch.zeros(*shape, dtype=torch.float32, device=dev)
+    else:
+        from .synth import _trunc_normal
+        g = torch.Generator().manual_seed(zlib.crc32(name.encode()) if seed is None else seed)
+        v = _trunc_normal(g, tuple(shape)).to(dev)                  # truncated_normal(stddev=0.1), model_v2.py:88
+    variables[name] = v
+    return v
+
+
+def _add_wd(names, wd):
+    """add_wd (model_v2.py:347-354) for the variables of the current call's scope"""
+    if wd is None or wd == 0.0:
+        return
+    for n in names:
+        t = torch.zeros(1, dtype=torch.float32, device=variables[n].device)
+        ops.weight_decay(variables[n].reshape(-1), None, wd, t)
+        losses.append(t)
+
+
+def _f32(t):
+    return t.to(torch.float32).contiguous()
+
+
+def softmax(logits, scope=None):
+    logits = _f32(logits)
+    out = torch.empty_like(logits)
+    J = logits.shape[-1]
+    check(_lib.load().fvta_softmax_fwd(ptr(logits), ptr(out), logits.numel() // J, J, stream_ptr()), "fvta_softmax_fwd")
+    return out
+
+
+def softsel(target, logits, hard=False, hardK=None, scope=None):
+    """target [..., J, d], logits [..., J] -> [..., d]  (`hard` / `hardK` are accepted and unused, as in the reference)"""
+    target, logits = _f32(target), _f32(logits)
+    J, d = target.shape[-2], target.shape[-1]
+    if tuple(logits.shape) != tuple(target.shape[:-1]):
+        raise ValueError("softsel: logits %s do not match target %s" % (tuple(logits.shape), tuple(target.shape)))
+    out = torch.empty(*target.shape[:-2], d, dtype=torch.float32, device=target.device)
+    check(_lib.load().fvta_softsel_fwd(ptr(target), ptr(logits), ptr(out), logits.numel() // J, J, d, stream_ptr()),
+          "fvta_softsel_fwd")
+    return out
+
+
+def exp_mask(val, mask):
+    val = _f32(val)
+    m = ops.as_mask_u8(mask.expand_as(val) if tuple(mask.shape) != tuple(val.shape) else mask)
+    out = torch.empty_like(val)
+    check(_lib.load().fvta_exp_mask(ptr(val), ptr(m), ptr(out), val.numel(), stream_ptr()), "fvta_exp_mask")
+    return out
+
+
+def linear(x, output_size, scope, add_tanh=False, wd=None):
+    x = _f32(x)
+    din = x.shape[-1]
+    with variable_scope(scope):
+        wn, bn = _name("W"), _name("b")
+        W = get_variable(wn, (din, int(output_size)))
+        b = get_variable(bn, (int(output_size),), init="zeros")
+        _add_wd([wn, bn], wd)
+    y = torch.empty(*x.shape[:-1], int(output_size), dtype=torch.float32, device=x.device)
+    check(_lib.load().fvta_linear_fwd(ptr(x), ptr(W), ptr(b), ptr(y), x.numel() // din, din, int(output_size), int(add_tanh),
+                                      stream_ptr()), "fvta_linear_fwd")
+    return y
+
+
+def _pad_channels(t, wp):
+    w = t.shape[-1]
+    if w == wp:
+        return t.contiguous()
+    out = torch.zeros(*t.shape[:-1], wp, dtype=torch.float32, device=t.device)
+    out[..., :w] = t
+    return out
+
+
+def _attention(hinfo, hq, hinfo_mask, hq_mask, simiMatrix, wd, add_tanh, scope, feat_order):
+    """hinfo [N,K,T,w] -> (h_a [N,w], a_logits [N,K,T,JQ]) through fvta_attn_fwd; w is zero padded to a kernel width
+    (exact: a zero channel adds nothing to any feature of any similarity), W block-wise with it."""
+    if simiMatrix not in (1, 2, 3, 4):
+        raise ValueError("similarity matrix not implemented")              # model_v2.py:255-257 (sys.exit there)
+    hinfo, hq = _f32(hinfo), _f32(hq)
+    N, K, T, w = hinfo.shape
+    JQ = hq.shape[1]
+    wp = next((c for c in SUPPORTED_W if w <= c), None)
+    if wp is None:
+        raise ValueError("attention: feature width %d too large (max %d)" % (w, SUPPORTED_W[-1]))
+    F = {1: 3, 2: 2, 3: 4, 4: 0}[simiMatrix]
+    W = b = None
+    with variable_scope(scope):
+        if F:
+            wn, bn = _name("att_logits", "W"), _name("att_logits", "b")
+            Wv = get_variable(wn, (F * w, 1))                              # linear(..., output_size=1, scope="att_logits")
+            b = get_variable(bn, (1,), init="zeros")
+            W = Wv.reshape(F, w)
+            if wp != w:
+                W = _pad_channels(W, wp)
+            W = W.reshape(-1).contiguous()
+            _add_wd([wn, bn], wd)
+    op = ops.FocalAttention(N, K, T, JQ, wp, simiMatrix, add_tanh, feat_order=feat_order)
+    both = hinfo_mask is not None and hq_mask is not None                  # model_v2.py:146 / 233: only when BOTH are given
+    hm = ops.as_mask_u8(hinfo_mask.reshape(N, K, T)) if both else None
+    qm = ops.as_mask_u8(hq_mask) if both else None
+    h_a, a = op.forward(_pad_channels(hinfo, wp), _pad_channels(hq, wp), hm, qm, W, b, want_logits=True)
+    return h_a[:, :w].contiguous(), a
+
+
+def attention_3d(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, wd=None, add_tanh=False, time_warp_att=False,
+                 C=None, bidirect=False, scope=None):
+    """hinfo [N,K,M,JX,w] (or [N,K,T,w]), hq [N,JQ,w], masks [N,K,M,JX] / [N,JQ] -> (h_a [N,w], a_logits [N,K,T,JQ])."""
+    if time_warp_att:
+        raise NotImplementedError("time_warp_att (model_v2.py:269-275) is not built")
+    if bidirect:
+        raise NotImplementedError("bidirect: the 3-D branch cannot run in the reference either (SURVEY 3.5)")
+    N, K, w = hinfo.shape[0], hinfo.shape[1], hinfo.shape[-1]
+    return _attention(hinfo.reshape(N, K, -1, w), hq, hinfo_mask, hq_mask, simiMatrix, wd, add_tanh,
+                      scope or "attention_2vector", 0)
+
+
+def attention(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, wd=None, add_tanh=False, bidirect=False, scope=None):
+    """hinfo [N,...,w] flattened to [N,V,w] (model_v2.py:133) -> (h_a [N,w], a_logits [N,V,JQ])."""
+    if bidirect:
+        raise NotImplementedError("bidirect (model_v2.py:176-190) is not built")
+    N, w = hinfo.shape[0], hinfo.shape[-1]
+    h = hinfo.reshape(N, 1, -1, w)
+    hm = hinfo_mask.reshape(N, 1, -1) if hinfo_mask is not None else None
+    h_a, a = _attention(h, hq, hm, hq_mask, simiMatrix, wd, add_tanh, scope or "attention_2vector", 0)
+    return h_a, a.reshape(N, h.shape[2], hq.shape[1])

@@ -279,6 +279,21 @@ int fvta_adam_step(float* var, const float* grad, float* m, float* v, int64_t n,
 int fvta_weight_decay(const float* var, float* grad, int64_t n, float coef, float* loss, fvta_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ * Stand-alone forms of the reference's small graph helpers (SURVEY 8b "functional ops"), forward only.  Inside the
+ * model they are folded into the attention / scorer / embedding kernels.
+ *   fvta_softmax_fwd : softmax(logits) over the last axis, model_v2.py:23-28 (logits viewed as [rows, J])
+ *   fvta_softsel_fwd : softsel(target [rows,J,d], logits [rows,J]) -> [rows,d], model_v2.py:39-48
+ *   fvta_exp_mask    : val + (1 - mask) * -1e30, utils.py:210-213
+ *   fvta_linear_fwd  : flatten(x,1) * W[in,out] + b (+ tanh), model_v2.py:75-100 (b may be NULL)
+ * ------------------------------------------------------------------------- */
+int fvta_softmax_fwd(const float* logits, float* out, int64_t rows, int32_t J, fvta_stream_t stream);
+int fvta_softsel_fwd(const float* target, const float* logits, float* out, int64_t rows, int32_t J, int32_t d,
+                     fvta_stream_t stream);
+int fvta_exp_mask(const float* val, const uint8_t* mask, float* out, int64_t n, fvta_stream_t stream);
+int fvta_linear_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int32_t in, int32_t out,
+                    int32_t add_tanh, fvta_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  * Test hooks (not part of the reference surface): the MFMA tile engines the
  * LSTM kernels are built from, exposed as plain GEMMs so tests can check the
  * fragment layouts in isolation.  layout 0: C=A[M,K]*B[K,N];

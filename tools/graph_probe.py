@@ -1,0 +1,32 @@
+"""Experiment: does replaying the train step as one HIP graph (torch.cuda.CUDAGraph) shorten it?"""
+import os, sys, time, torch
+sys.path.insert(0, os.getcwd())
+from fvta_memexqa_amd import _lib
+from fvta_memexqa_amd.model_v2 import Model
+from fvta_memexqa_amd.synth import CONFIGS, SynthSpec, make_inputs
+from fvta_memexqa_amd.trainer import Trainer
+spec = SynthSpec(**dict(CONFIGS["metric"], dense=True))
+cfg = dict(spec.cfg(), batch_size=spec.N, precision="bf16", optimizer="adam", init_lr=0.001)
+model = Model(cfg, text_in=spec.text_in, img_in=spec.img_in)
+tr = Trainer(model, cfg); tr.need_dx = True
+L = model.load_inputs(make_inputs(spec), training=True)
+def fb():
+    model.zero_grad(); model.forward(L); model.backward(L, need_dx=True)
+def timeit(f, n=20):
+    for _ in range(3): f()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+print("eager fwd+bwd ms", round(timeit(fb), 3))
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    for _ in range(3): fb()
+torch.cuda.current_stream().wait_stream(s)
+g = torch.cuda.CUDAGraph()
+try:
+    with torch.cuda.graph(g):
+        fb()
+    print("graph fwd+bwd ms", round(timeit(g.replay), 3))
+except Exception as e:
+    print("capture failed:", repr(e)[:400])
