@@ -364,6 +364,12 @@ class Model:
             out["existing_emb_mat"] = self.existing_emb_mat.cpu()
         return out
 
+    def unpad_w(self, t):
+        """[..., 2*d_pad] kernel layout (fw half | bw half, each zero padded) -> the reference's [..., 2d]"""
+        if self.dp == self.d:
+            return t
+        return torch.cat([t[..., :self.d], t[..., self.dp:self.dp + self.d]], -1)
+
     def set_existing_emb(self, mat):
         """the frozen pre-trained word vectors the reference feeds as `existing_emb_mat` (model_v2.py:470, 590):
         word ids >= word_vocab_size index into it."""

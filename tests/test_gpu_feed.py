@@ -115,3 +115,32 @@ def test_published_fvta_flag_set_on_dataset_batches():
         ref = F.fvta_forward(p, F.embed_inputs(p, tok, ocfg), ocfg)["yp"].numpy()[:batch[1].num_examples]
         np.testing.assert_allclose(yp, ref, rtol=1e-4, atol=1e-6)
         assert (yp.argmax(1) == ref.argmax(1)).all()
+
+
+def test_step_vis_returns_the_reference_tuple():
+    """tester.py:30-43: 28 values in the reference's order, trimmed like there."""
+    from fvta_memexqa_amd.model_v2 import get_model
+    from fvta_memexqa_amd.tester import Tester
+    config, ds, case = _setup("feed_test_nocaps", False, use_time_warp=True, warp_type=5)
+    config.hidden_size = 50                                     # padded to 64 inside: the vis tensors come back as [.., 100]
+    model = get_model(config)
+    batches = list(ds.get_batches(case["batch_size"], 4, shuffle=False))
+    batch = batches[-1]                                         # the short last batch: one example in a batch of 3
+    out = Tester(model, config).step_vis(None, batch)
+    assert len(out) == 28
+    (yp, C, C_win, att, qatt, at_mask, ad_mask, when_mask, where_mask, pts_mask, pis_mask, q_mask, hat_len, had_len, hwhen_len,
+     hwhere_len, hpts_len, hpis_len, JXP, warp_h, h, at, ad, when, where, pts, pis, q) = out
+    n, N = batch[1].num_examples, config.batch_size
+    assert n == 1 and yp.shape == (n, 4)
+    feed = model.get_feed_dict(batch[1])
+    K, M, T = 6, feed["at"].shape[1], h.shape[2] * h.shape[3]
+    assert h.shape[:3] == (N, K, M) and h.shape[-1] == 100 and warp_h.shape == h.shape
+    assert C.shape == (n, T, T)
+    assert C_win == -1            # a scalar is not an ndarray: tester.py:28's `trim` turns it into -1, there and here
+    assert att.shape == (n, K, T, feed["q"].shape[1]) and qatt.shape[0] == n
+    assert at_mask.shape[0] == n and pts_mask.shape[0] == n and ad_mask.shape[0] == N      # only some are trimmed (:42)
+    assert np.array_equal(hat_len, feed["at_mask"].sum(2)) and np.array_equal(hpts_len, feed["pts_mask"].sum(3))
+    assert JXP == feed["pts"].shape[3] and np.array_equal(pts, feed["pts"]) and np.array_equal(q, feed["q"])
+    # the context tensor rows past each stream's own length are zero (model_v2.py:871-888 pads with zeros)
+    JXA = feed["at"].shape[2]
+    assert np.abs(h[:, 0, :, JXA:, :]).max() == 0
