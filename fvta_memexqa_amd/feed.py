@@ -10,7 +10,7 @@ index vectors; word ids come from a memo over the vocabulary (`word -> id` with 
 written, lower, capitalised, upper; trainable vocabulary before the frozen one; model_v2.py:1325-1336) and char rows
 from a memo `tuple(chars) -> int32[max_word_size]`; the arrays are filled by one fancy-index assignment per field.
 """
-from copy import deepcopy
+from itertools import chain
 
 import numpy as np
 
@@ -41,21 +41,26 @@ class VocabMemo:
             return v
 
     class _Chars(dict):
+        """tuple of characters -> row of `table` (int32 [rows, W], grown by doubling)"""
+
         def __init__(self, c2i, W):
             super().__init__()
             self.c2i, self.W = c2i, W
+            self.table = np.zeros((256, W), np.int32)
+            self.n = 0
 
-        def __missing__(self, chars):                                       # chars: tuple of characters
-            row = np.zeros(self.W, np.int32)
+        def __missing__(self, chars):
+            if self.n == len(self.table):
+                self.table = np.concatenate([self.table, np.zeros_like(self.table)])
             get = self.c2i.get
             n = min(len(chars), self.W)
-            row[:n] = [get(c, 1) for c in chars[:n]]
-            self[chars] = row
-            return row
+            self.table[self.n, :n] = [get(c, 1) for c in chars[:n]]
+            self[chars] = self.n
+            self.n += 1
+            return self.n - 1
 
     def __init__(self, shared, W):
-        self.key = (id(shared["word2idx"]), len(shared["word2idx"]), id(shared["existing_word2idx"]),
-                    len(shared["existing_word2idx"]), id(shared["char2idx"]), len(shared["char2idx"]), W)
+        self.key = self.key_of(shared, W)
         self.words = self._Words(shared["word2idx"], shared["existing_word2idx"])
         self.chars = self._Chars(shared["char2idx"], W)
 
@@ -68,9 +73,8 @@ class VocabMemo:
         return np.fromiter(map(self.words.__getitem__, words), np.int32, len(words))
 
     def char_rows(self, words_c):
-        if not words_c:
-            return np.zeros((0, self.chars.W), np.int32)
-        return np.stack(list(map(self.chars.__getitem__, map(tuple, words_c))))
+        rows = np.fromiter(map(self.chars.__getitem__, map(tuple, words_c)), np.int64, len(words_c))
+        return self.chars.table[rows]
 
 
 def _longest(seqs):
@@ -90,31 +94,145 @@ def _fill_text(ids, mask, chars, words, words_c, caps, sent_cap, memo):
     """One text field.  words / words_c: nested lists (sentence = list of words / list of char lists).  The reference
     fills ids+mask from `words` and the char array from `words_c` in separate loops (e.g. model_v2.py:1344-1374), so the
     two sources stay separate here too."""
+    nd = len(caps)
     for source, is_char in ((words, False), (words_c, True)):
-        index_cols, flat = [], []
         sents = _sentences(source, caps)
-        lens = [min(len(s), sent_cap) if sent_cap is not None else len(s) for _, s in sents]
-        total = sum(lens)
+        if not sents:
+            continue
+        lens = np.fromiter((len(s) for _, s in sents), np.int64, len(sents))
+        if sent_cap is not None:
+            np.minimum(lens, sent_cap, out=lens)
+        total = int(lens.sum())
         if total == 0:
             continue
-        nd = len(caps)
-        prefix = np.empty((total, nd + 1), np.int64)
-        pos = 0
-        for (ix, s), n in zip(sents, lens):
-            if n:
-                prefix[pos:pos + n, :nd] = ix
-                prefix[pos:pos + n, nd] = np.arange(n)
-                flat.extend(s[:n])
-                pos += n
-        index_cols = tuple(prefix[:, c] for c in range(nd + 1))
+        lead = np.asarray([ix for ix, _ in sents], np.int64).reshape(len(sents), nd)
+        start = np.cumsum(lens) - lens
+        cols = tuple(np.repeat(lead[:, c], lens) for c in range(nd)) + (np.arange(total) - np.repeat(start, lens),)
+        flat = list(chain.from_iterable(s[:n] for (_, s), n in zip(sents, lens.tolist())))
         if is_char:
-            chars[index_cols] = memo.char_rows(flat)
+            chars[cols] = memo.char_rows(flat)
         else:
-            ids[index_cols] = memo.word_ids(flat)
-            mask[index_cols] = True
+            ids[cols] = memo.word_ids(flat)
+            mask[cols] = True
 
 
-def build_feed_dict(config, batch, is_train=False, num_choice=4, memo=None):
+class AlbumTables:
+    """Every album of `shared['albums']` converted ONCE (lazily, on first sight) into fixed-size id / char / length
+    arrays cut at the configured caps; a batch then gathers rows by album index instead of walking words.  Valid because
+    an album's texts are the same objects in every batch (utils.Dataset._mini_batch hands out shared['albums'][aid][...])
+    and because truncating at the cap commutes with truncating at the smaller per-batch size."""
+
+    FIELDS = (("at", "title", "max_sent_album_title_size"), ("ad", "description", "max_sent_des_size"),
+              ("when", "when", "max_when_size"), ("where", "where", "max_where_size"))
+
+    def __init__(self, g, memo):
+        self.memo = memo
+        self.W = g("max_word_size")
+        self.caps = {name: g(cap) for name, _, cap in self.FIELDS}
+        self.cap_JI, self.cap_JXP = g("max_num_photos"), g("max_sent_photo_title_size")
+        self.key = (memo.key, tuple(sorted(self.caps.items())), self.cap_JI, self.cap_JXP)
+        self.row = {}                  # album id -> row
+        self.n = 0
+        self.cap = 0
+        self.t = {}
+
+    def _grow(self, need):
+        if need <= self.cap:
+            return
+        cap = max(64, 2 * self.cap, need)
+        W, JI, JXP = self.W, self.cap_JI, self.cap_JXP
+        shapes = {}
+        for name, _, _ in self.FIELDS:
+            c = self.caps[name]
+            shapes[name] = ((c,), np.int32)
+            shapes[name + "_c"] = ((c, W), np.int32)
+            shapes[name + "_len"] = ((), np.int32)        # min(len, cap): mask length
+            shapes[name + "_raw"] = ((), np.int32)        # uncapped: feeds the per-batch maxima
+        shapes.update(pts=((JI, JXP), np.int32), pts_c=((JI, JXP, W), np.int32), pts_len=((JI,), np.int32),
+                      pts_raw=((), np.int32), nph_raw=((), np.int32))
+        for k, (shp, dt) in shapes.items():
+            new = np.zeros((cap + 1,) + shp, dt)       # row `cap` stays all-zero: the "no album" row
+            if k in self.t:
+                new[:self.n] = self.t[k][:self.n]
+            self.t[k] = new
+        self.cap = cap
+
+    def rows_of(self, albums, aids):
+        """album ids -> rows, converting the albums seen for the first time"""
+        out = []
+        for aid in aids:
+            r = self.row.get(aid)
+            if r is None:
+                self._grow(self.n + 1)
+                r = self.row[aid] = self.n
+                self.n += 1
+                self._convert(albums[aid], r)
+            out.append(r)
+        return out
+
+    def _convert(self, alb, r):
+        t, memo = self.t, self.memo
+        for name, key, _ in self.FIELDS:
+            words, chars, cap = alb[key], alb[key + "_c"], self.caps[name]
+            n = min(len(words), cap)
+            if n:
+                t[name][r, :n] = memo.word_ids(words[:n])
+            nc = min(len(chars), cap)
+            if nc:
+                t[name + "_c"][r, :nc] = memo.char_rows(chars[:nc])
+            t[name + "_len"][r], t[name + "_raw"][r] = n, len(words)
+        titles, titles_c = alb["photo_titles"], alb["photo_titles_c"]
+        t["nph_raw"][r] = len(alb["photo_ids"])
+        t["pts_raw"][r] = max(map(len, titles), default=0)
+        for k, title in enumerate(titles[:self.cap_JI]):
+            n = min(len(title), self.cap_JXP)
+            if n:
+                t["pts"][r, k, :n] = memo.word_ids(title[:n])
+            t["pts_len"][r, k] = n
+        for k, title_c in enumerate(titles_c[:self.cap_JI]):
+            n = min(len(title_c), self.cap_JXP)
+            if n:
+                t["pts_c"][r, k, :n] = memo.char_rows(title_c[:n])
+
+
+def _album_fields_from_tables(f, batch, g, N, tables):
+    """at / ad / when / where / pts (+ _c, _mask) of the feed by gathering album rows; returns False when the batch does
+    not carry album ids (a hand-made batch): the caller then walks the nested lists instead."""
+    d, sh = batch.data, batch.shared
+    aids = d.get("aid")
+    if aids is None or "albums" not in sh or any(a not in sh["albums"] for s_ in aids for a in s_):
+        return False
+    cap_M = g("max_num_albums")
+    flat = tables.rows_of(sh["albums"], [a for s_ in aids for a in s_])
+    t = tables.t
+    zero = tables.cap                                               # the all-zero row
+    counts = [len(s_) for s_ in aids]
+    allrows = np.asarray(flat, np.int64)
+    one = lambda v: int(v) if v else 1
+    M = min(cap_M, one(max(counts, default=0)))
+    idx = np.full((N, M), zero, np.int64)
+    pos = 0
+    for i, c in enumerate(counts):
+        m = min(c, M)
+        idx[i, :m] = flat[pos:pos + m]
+        pos += c
+    raw_max = lambda k: int(t[k][allrows].max()) if len(allrows) else 0
+    for name, _, cap in AlbumTables.FIELDS:
+        J = min(tables.caps[name], one(raw_max(name + "_raw")))
+        f[name] = t[name][idx][:, :, :J]
+        f[name + "_c"] = t[name + "_c"][idx][:, :, :J]
+        f[name + "_mask"] = np.arange(J) < t[name + "_len"][idx][..., None]
+    JI = min(tables.cap_JI, one(raw_max("nph_raw")))
+    JXP = min(tables.cap_JXP, one(raw_max("pts_raw")))
+    f["pts"] = np.ascontiguousarray(t["pts"][idx][:, :, :JI, :JXP])
+    f["pts_c"] = np.ascontiguousarray(t["pts_c"][idx][:, :, :JI, :JXP])
+    f["pts_mask"] = np.arange(JXP) < t["pts_len"][idx][:, :, :JI, None]
+    for name, _, _ in AlbumTables.FIELDS:
+        f[name], f[name + "_c"] = np.ascontiguousarray(f[name]), np.ascontiguousarray(f[name + "_c"])
+    return True
+
+
+def build_feed_dict(config, batch, is_train=False, num_choice=4, memo=None, use_tables=True):
     """-> (feed dict keyed by placeholder name, memo).  `config` needs batch_size and the max_* sizes
     (utils.update_config); `batch` is a utils.Dataset mini-batch (data + shared)."""
     d, sh = batch.data, batch.shared
@@ -137,9 +255,19 @@ def build_feed_dict(config, batch, is_train=False, num_choice=4, memo=None):
         memo = VocabMemo(sh, W)
 
     f = {}
+    tables = None
+    if use_tables:
+        tables = getattr(memo, "tables", None)
+        if tables is None or tables.key[1:] != AlbumTables(g, memo).key[1:]:
+            tables = memo.tables = AlbumTables(g, memo)
+        if not _album_fields_from_tables(f, batch, g, N, tables):
+            tables = None
     shapes = dict(at=(N, M, JXA), ad=(N, M, JD), when=(N, M, JT), where=(N, M, JG), pts=(N, M, JI, JXP), q=(N, JQ),
                   choices=(N, num_choice, JA))
     for name in TEXT_FIELDS:
+        if tables is not None and name in ("at", "ad", "when", "where", "pts"):
+            assert f[name].shape == shapes[name], (name, f[name].shape, shapes[name])
+            continue
         f[name] = np.zeros(shapes[name], np.int32)
         f[name + "_c"] = np.zeros(shapes[name] + (W,), np.int32)
         f[name + "_mask"] = np.zeros(shapes[name], bool)
@@ -148,7 +276,9 @@ def build_feed_dict(config, batch, is_train=False, num_choice=4, memo=None):
     f["image_emb_mat"], f["existing_emb_mat"] = d["pidx2feat"], sh["existing_emb_mat"]
 
     # choices: the correct answer goes to a random slot when training (y marks it), to `yidx` when evaluating
-    C, Cc = deepcopy(d["cs"]), deepcopy(d["ccs"])
+    C, Cc = [list(ci) for ci in d["cs"]], [list(ci) for ci in d["ccs"]]    # per-QA lists are copied (the answer is inserted into
+    #                                                                        them), their sentences are shared: same effect
+    #                                                                        as the reference's deepcopy (:1249-1250)
     if is_train:                                                            # model_v2.py:1270-1288
         f["y"] = np.zeros((N, num_choice), bool)
         slot = np.random.choice(num_choice, N)                              # same draw as the reference (global NumPy RNG)
@@ -181,11 +311,12 @@ def build_feed_dict(config, batch, is_train=False, num_choice=4, memo=None):
     def text(name, words, words_c, caps, sent_cap):
         _fill_text(f[name], f[name + "_mask"], f[name + "_c"], words, words_c, caps, sent_cap, memo)
 
-    text("at", d["album_title"], d["album_title_c"], (None, cap_M), g("max_sent_album_title_size"))
-    text("ad", d["album_description"], d["album_description_c"], (None, cap_M), g("max_sent_des_size"))
-    text("when", d["when"], d["when_c"], (None, cap_M), g("max_when_size"))
-    text("where", d["where"], d["where_c"], (None, cap_M), g("max_where_size"))
-    text("pts", d["photo_titles"], d["photo_titles_c"], (None, cap_M, cap_JI), g("max_sent_photo_title_size"))
+    if tables is None:
+        text("at", d["album_title"], d["album_title_c"], (None, cap_M), g("max_sent_album_title_size"))
+        text("ad", d["album_description"], d["album_description_c"], (None, cap_M), g("max_sent_des_size"))
+        text("when", d["when"], d["when_c"], (None, cap_M), g("max_when_size"))
+        text("where", d["where"], d["where_c"], (None, cap_M), g("max_where_size"))
+        text("pts", d["photo_titles"], d["photo_titles_c"], (None, cap_M, cap_JI), g("max_sent_photo_title_size"))
     text("choices", C, Cc, (None, None), JA)
     text("q", d["q"], d["cq"], (None,), None)                               # the question is never clipped (:1525)
     return f, memo

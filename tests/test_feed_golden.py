@@ -50,14 +50,14 @@ def check_feed(feed, z, b, is_train):
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-5] for p in CASES])
-@pytest.mark.parametrize("impl", ["product", "literal"])
+@pytest.mark.parametrize("impl", ["product", "product_walk", "literal"])
 def test_batches_and_feed_match_reference(path, impl):
     js, z, shared, case, config = load_case(path)
     from fvta_memexqa_amd import utils as U
-    if impl == "product":
+    if impl.startswith("product"):         # "product": album tables gathered by album index; "product_walk": nested lists walked
         from fvta_memexqa_amd.feed import build_feed_dict
         DS = U.Dataset
-        feed_of = lambda batch, memo: build_feed_dict(config, batch, case["is_train"], 4, memo)
+        feed_of = lambda batch, memo: build_feed_dict(config, batch, case["is_train"], 4, memo, use_tables=impl == "product")
     else:
         from oracle import feed_literal as FL
         DS = FL.Dataset
