@@ -218,42 +218,76 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel(EmbArgs a) {
 // token's character block is a scatter of each active filter's 5 x 8 weights to its arg-max window; it is made
 // conflict-free and order-fixed by letting thread (group, k*8+c) walk the filters f = group, group+3, ... and
 // accumulate S[group][p_f][k*8+c] in ITS OWN LDS cell, then dE[pos][c] = sum_group sum_k S[group][pos-k][k*8+c].
+// Like the forward kernel: char table in LDS, token stream software-pipelined two deep (ids / offsets of token i+2,
+// then arg-max positions and the dx row of token i+1, in flight while token i is processed).  The scatter into the
+// workgroup's char-gradient table is done by the first position of each distinct character, which sums its later
+// duplicates in position order -- parallel over (position, channel), same fixed order as a serial walk.
 __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_5x8(EmbArgs a) {
   __shared__ __attribute__((aligned(16))) float s_E[16 * 8 + 32], s_dE[16 * 8];
   __shared__ float s_g[EMB_NT];
   __shared__ int s_p[EMB_NT];
   __shared__ int s_ch[16];
   __shared__ float s_S[3][12][40];
-  extern __shared__ float s_dyn[];  // filt [40][cwdim], then dC [VC][8]
+  extern __shared__ float s_dyn[];  // filt [40][cwdim], dC [VC][8], char_emb [VC][8]
   const fvta_embed_desc& d = a.d;
   const int tid = threadIdx.x, W = d.W, cw = d.cwdim;
   float* s_filt = s_dyn;
   float* s_dC = s_dyn + 40 * cw;
+  float* s_cemb = s_dC + d.VC * 8;
   float acc[40];
 #pragma unroll
   for (int i = 0; i < 40; ++i) acc[i] = 0.f;
   float accb = 0.f;
   for (int i = tid; i < 40 * cw; i += EMB_NT) s_filt[i] = a.filt[i];
-  for (int i = tid; i < d.VC * 8; i += EMB_NT) s_dC[i] = 0.f;
+  for (int i = tid; i < d.VC * 8; i += EMB_NT) {
+    s_dC[i] = 0.f;
+    s_cemb[i] = a.char_emb[i];
+  }
   if (tid < 32) s_E[128 + tid] = 0.f;  // slack behind the block: a window read may run 4 positions past W - 5 + 4
   const int grp = tid / 40, kc = tid % 40;  // tid < 120: the S builders
-  for (int tok = blockIdx.x; tok < d.ntok; tok += gridDim.x) {
-    const float* row = a.dx + a.tok_off[tok];
-    const int id = a.word_ids[tok];
-    if (id < d.VW)
-      for (int i = tid; i < d.wdim; i += EMB_NT) atomicAdd(a.d_word_emb + (size_t)id * d.wdim + i, row[cw + i]);
-    __syncthreads();
-    if (tid < W) s_ch[tid] = a.char_ids[(size_t)tok * W + tid];
-    if (tid < W * 8) s_E[tid] = a.char_emb[(size_t)a.char_ids[(size_t)tok * W + (tid >> 3)] * 8 + (tid & 7)];
-    float g = 0.f;
-    int p = 0;
+  const int step = gridDim.x;
+  auto load_ids = [&](int tok, int& ch, int& wid, int64_t& off) {
+    const bool ok = tok < d.ntok;
+    ch = (ok && tid < W * 8) ? a.char_ids[(size_t)tok * W + (tid >> 3)] : 0;
+    wid = ok ? a.word_ids[tok] : 0;
+    off = ok ? a.tok_off[tok] : 0;
+  };
+  // stage B: this thread's arg-max position + upstream gradient of the char part, and its element(s) of the word part
+  auto load_grad = [&](int tok, int64_t off, int& ap, float& g, float& w0, float& w1) {
+    ap = 255;
+    g = w0 = w1 = 0.f;
+    if (tok >= d.ntok) return;
+    const float* row = a.dx + off;
     if (tid < cw) {
-      const int ap = a.argpos[(size_t)tok * cw + tid];
-      if (ap != 255) {
-        g = row[tid];
-        p = ap;
-      }
+      ap = a.argpos[(size_t)tok * cw + tid];
+      g = row[tid];
     }
+    if (tid < d.wdim) w0 = row[cw + tid];
+    if (tid + EMB_NT < d.wdim) w1 = row[cw + tid + EMB_NT];
+  };
+  int tok = blockIdx.x;
+  int ch0, wid0, ch1, wid1, ch2, wid2, ap0, ap1;
+  int64_t off0, off1, off2;
+  float g0, g1, w0a, w0b, w1a, w1b;
+  load_ids(tok, ch0, wid0, off0);
+  load_ids(tok + step, ch1, wid1, off1);
+  load_grad(tok, off0, ap0, g0, w0a, w0b);
+  for (; tok < d.ntok; tok += step) {
+    load_ids(tok + 2 * step, ch2, wid2, off2);
+    load_grad(tok + step, off1, ap1, g1, w1a, w1b);
+    if (wid0 < d.VW) {
+      float* dst = a.d_word_emb + (size_t)wid0 * d.wdim;
+      if (tid < d.wdim) atomicAdd(dst + tid, w0a);
+      if (tid + EMB_NT < d.wdim) atomicAdd(dst + tid + EMB_NT, w0b);
+      for (int i = tid + 2 * EMB_NT; i < d.wdim; i += EMB_NT) atomicAdd(dst + i, a.dx[off0 + cw + i]);
+    }
+    __syncthreads();
+    if (tid < W * 8) {
+      if ((tid & 7) == 0) s_ch[tid >> 3] = ch0;
+      s_E[tid] = s_cemb[ch0 * 8 + (tid & 7)];
+    }
+    const float g = ap0 != 255 ? g0 : 0.f;
+    const int p = ap0 != 255 ? ap0 : 0;
     s_g[tid] = g;
     s_p[tid] = p;
     for (int i = tid; i < 3 * 12 * 40; i += EMB_NT) (&s_S[0][0][0])[i] = 0.f;
@@ -285,9 +319,21 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_5x8(EmbArgs a) {
       s_dE[tid] = v;
     }
     __syncthreads();
-    // into the workgroup's char table: thread c walks the positions serially (two positions may hold the same char)
-    if (tid < 8)
-      for (int pos = 0; pos < W; ++pos) s_dC[s_ch[pos] * 8 + tid] += s_dE[pos * 8 + tid];
+    // into the workgroup's char table.  Two positions may hold the same character: the FIRST position of a character
+    // adds its own value and then those of its later duplicates, in position order (what a serial walk would do).
+    if (tid < W * 8) {
+      const int pos = tid >> 3, c = tid & 7, me = s_ch[pos];
+      bool first = true;
+      for (int q = 0; q < pos; ++q) first = first && (s_ch[q] != me);
+      if (first) {
+        float v = s_dC[me * 8 + c];
+        for (int q = pos; q < W; ++q)
+          if (s_ch[q] == me) v += s_dE[q * 8 + c];
+        s_dC[me * 8 + c] = v;
+      }
+    }
+    ch0 = ch1; wid0 = wid1; off0 = off1; ap0 = ap1; g0 = g1; w0a = w1a; w0b = w1b;
+    ch1 = ch2; wid1 = wid2; off1 = off2;
   }
   __syncthreads();
   float* slab = a.slab + (size_t)blockIdx.x * (40 * cw + cw + d.VC * 8);
@@ -585,8 +631,16 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     hipLaunchKernelGGL(embed_bwd_kernel_big, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
   } else {
-    blocks = d->ntok < EMB_BWD_BLOCKS ? d->ntok : EMB_BWD_BLOCKS;
-    const size_t dyn = ((size_t)d->height * d->cdim * d->cwdim + (size_t)d->VC * d->cdim) * sizeof(float);
+    const bool k5x8 = d->cwdim > 0 && d->height == 5 && d->cdim == 8 && d->W <= 16;
+    const size_t dyn = ((size_t)d->height * d->cdim * d->cwdim + (size_t)(k5x8 ? 2 : 1) * d->VC * d->cdim) * sizeof(float);
+    // one dispatch round: as many workgroups as fit the 256 CUs at once (LDS bound; ~9 KB static), never more than the
+    // slab workspace holds -- a second, partly filled round would run at the speed of the first
+    int per_cu = (int)((160 * 1024) / (dyn + 9 * 1024));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    blocks = 256 * per_cu;
+    if (blocks > EMB_BWD_BLOCKS) blocks = EMB_BWD_BLOCKS;
+    if (blocks > d->ntok) blocks = d->ntok;
     if (dyn > 32 * 1024) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)dyn);
