@@ -225,6 +225,9 @@ def main():
                     unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, algorithmic_bytes_per_call=by_text,
                     mfma_tflops=round(tf, 1), mfma_frac=round(tf / peak_tf, 4), launches=n_f,
                     avg_launch_ms=round(ms_f / n_f, 4))
+        if args.precision == "f32":   # exact-fp32 MFMA: 64 flop/clk/SIMD -- the matrix pipe bounds this engine, not HBM
+            roof.update(bound="mfma", achieved=round(tf, 1), peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=round(tf / peak_tf, 4),
+                        hbm_gbs=round(gbs, 1))
     # ---- attention kernel against HBM: algorithmic bytes = valid rows * w * 4 + question + output
     valid_rows = int(L.hall_mask.sum().item())
     att_bytes = (valid_rows * model.wp + spec.N * L.JQ * model.wp + spec.N * model.wp) * 4.0
@@ -250,7 +253,7 @@ def main():
             pass
         return None
     for r_ in (roof, roof_att):
-        if r_ is not None and probe_gbs:
+        if r_ is not None and probe_gbs and r_["bound"] == "hbm":
             r_["achievable_peak"] = probe_gbs
             r_["frac_of_achievable"] = round(r_["achieved"] / probe_gbs, 4)
     dense_metric = args.config == "metric" and args.variant == "dense" and not args.batch
