@@ -520,6 +520,97 @@ constexpr int R16_CAP = 1600;            // rows of one workgroup's items (LDS r
 constexpr int R16_MAXT = R16_CAP / 16;   // tiles
 constexpr int R16_MAXI = 32;             // items
 
+// Row loads the compiler does NOT track.  Its waitcnt pass merges the rarely taken "new n" path (whose loads are
+// issued after the prefetch) into the common one and guards every later use of anything loaded there -- and, at the
+// loop header, the prefetched rows themselves -- with `s_waitcnt vmcnt(0)`: the prefetch of tile g+2 then has to LAND
+// inside tile g, i.e. memory and compute take turns instead of overlapping (measured: the phases add up).  Issued
+// through inline asm the loads are invisible to that pass; the kernel waits for exactly the tile it is about to use
+// (loads return in order) with counted waits.  Two things the compiler no longer does for us:
+//  * it must not MOVE a register that has a load in flight (it happily inserted phi copies of the three buffers at the
+//    loop latch): each buffer is pinned to fixed physical registers (A: v160.., B: v192.., C: v224..) both where it is
+//    loaded and where it is first used, so there is nothing to shuffle;
+//  * its hazard recogniser does not look into inline asm: a VMEM instruction may read an SGPR 5 wait states after a
+//    SALU instruction wrote it at the earliest -- and the compiler is free to copy the base pointer into the asm's
+//    SGPR operand right in front of it -- so every load carries its own `s_nop 4`.
+template <int BUF, int NB, int FROM = 0, int TO = 8>
+__device__ __forceinline__ void rows_issue(const float* base, unsigned voff, f32x4 (&d)[NB]) {
+  static_assert(NB == 2 || NB == 4 || NB == 8, "pinned register tables below");
+  if constexpr (BUF == 0) {
+    if (NB > 0 && 0 >= FROM && 0 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:0" : "={v[160:163]}"(d[0 % NB]) : "v"(voff), "s"(base));
+    if (NB > 1 && 1 >= FROM && 1 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:64" : "={v[164:167]}"(d[1 % NB]) : "v"(voff), "s"(base));
+    if (NB > 2 && 2 >= FROM && 2 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:128" : "={v[168:171]}"(d[2 % NB]) : "v"(voff), "s"(base));
+    if (NB > 3 && 3 >= FROM && 3 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:192" : "={v[172:175]}"(d[3 % NB]) : "v"(voff), "s"(base));
+    if (NB > 4 && 4 >= FROM && 4 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:256" : "={v[176:179]}"(d[4 % NB]) : "v"(voff), "s"(base));
+    if (NB > 5 && 5 >= FROM && 5 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:320" : "={v[180:183]}"(d[5 % NB]) : "v"(voff), "s"(base));
+    if (NB > 6 && 6 >= FROM && 6 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:384" : "={v[184:187]}"(d[6 % NB]) : "v"(voff), "s"(base));
+    if (NB > 7 && 7 >= FROM && 7 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:448" : "={v[188:191]}"(d[7 % NB]) : "v"(voff), "s"(base));
+  } else if constexpr (BUF == 1) {
+    if (NB > 0 && 0 >= FROM && 0 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:0" : "={v[192:195]}"(d[0 % NB]) : "v"(voff), "s"(base));
+    if (NB > 1 && 1 >= FROM && 1 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:64" : "={v[196:199]}"(d[1 % NB]) : "v"(voff), "s"(base));
+    if (NB > 2 && 2 >= FROM && 2 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:128" : "={v[200:203]}"(d[2 % NB]) : "v"(voff), "s"(base));
+    if (NB > 3 && 3 >= FROM && 3 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:192" : "={v[204:207]}"(d[3 % NB]) : "v"(voff), "s"(base));
+    if (NB > 4 && 4 >= FROM && 4 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:256" : "={v[208:211]}"(d[4 % NB]) : "v"(voff), "s"(base));
+    if (NB > 5 && 5 >= FROM && 5 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:320" : "={v[212:215]}"(d[5 % NB]) : "v"(voff), "s"(base));
+    if (NB > 6 && 6 >= FROM && 6 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:384" : "={v[216:219]}"(d[6 % NB]) : "v"(voff), "s"(base));
+    if (NB > 7 && 7 >= FROM && 7 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:448" : "={v[220:223]}"(d[7 % NB]) : "v"(voff), "s"(base));
+  } else {
+    if (NB > 0 && 0 >= FROM && 0 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:0" : "={v[224:227]}"(d[0 % NB]) : "v"(voff), "s"(base));
+    if (NB > 1 && 1 >= FROM && 1 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:64" : "={v[228:231]}"(d[1 % NB]) : "v"(voff), "s"(base));
+    if (NB > 2 && 2 >= FROM && 2 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:128" : "={v[232:235]}"(d[2 % NB]) : "v"(voff), "s"(base));
+    if (NB > 3 && 3 >= FROM && 3 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:192" : "={v[236:239]}"(d[3 % NB]) : "v"(voff), "s"(base));
+    if (NB > 4 && 4 >= FROM && 4 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:256" : "={v[240:243]}"(d[4 % NB]) : "v"(voff), "s"(base));
+    if (NB > 5 && 5 >= FROM && 5 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:320" : "={v[244:247]}"(d[5 % NB]) : "v"(voff), "s"(base));
+    if (NB > 6 && 6 >= FROM && 6 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:384" : "={v[248:251]}"(d[6 % NB]) : "v"(voff), "s"(base));
+    if (NB > 7 && 7 >= FROM && 7 < TO) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:448" : "={v[252:255]}"(d[7 % NB]) : "v"(voff), "s"(base));
+  }
+}
+// Wait until at most `tiles_younger` * NB loads issued after buffer b's tile are still in flight; every later use of
+// b depends on the pinning statement that follows the wait, so nothing can be scheduled above it.
+template <int BUF, int NB>
+__device__ __forceinline__ void rows_wait(int tiles_younger, f32x4 (&b)[NB]) {
+  if (tiles_younger >= 2)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
+  else if (tiles_younger == 1)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB) : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (BUF == 0) {
+    if constexpr (NB == 8) {
+      asm volatile("" : "+{v[160:163]}"(b[0]), "+{v[164:167]}"(b[1]), "+{v[168:171]}"(b[2]), "+{v[172:175]}"(b[3]), "+{v[176:179]}"(b[4]), "+{v[180:183]}"(b[5]), "+{v[184:187]}"(b[6]), "+{v[188:191]}"(b[7]));
+    }
+    else if constexpr (NB == 4) {
+      asm volatile("" : "+{v[160:163]}"(b[0]), "+{v[164:167]}"(b[1]), "+{v[168:171]}"(b[2]), "+{v[172:175]}"(b[3]));
+    }
+    else if constexpr (NB == 2) {
+      asm volatile("" : "+{v[160:163]}"(b[0]), "+{v[164:167]}"(b[1]));
+    }
+  } else if constexpr (BUF == 1) {
+    if constexpr (NB == 8) {
+      asm volatile("" : "+{v[192:195]}"(b[0]), "+{v[196:199]}"(b[1]), "+{v[200:203]}"(b[2]), "+{v[204:207]}"(b[3]), "+{v[208:211]}"(b[4]), "+{v[212:215]}"(b[5]), "+{v[216:219]}"(b[6]), "+{v[220:223]}"(b[7]));
+    }
+    else if constexpr (NB == 4) {
+      asm volatile("" : "+{v[192:195]}"(b[0]), "+{v[196:199]}"(b[1]), "+{v[200:203]}"(b[2]), "+{v[204:207]}"(b[3]));
+    }
+    else if constexpr (NB == 2) {
+      asm volatile("" : "+{v[192:195]}"(b[0]), "+{v[196:199]}"(b[1]));
+    }
+  } else {
+    if constexpr (NB == 8) {
+      asm volatile("" : "+{v[224:227]}"(b[0]), "+{v[228:231]}"(b[1]), "+{v[232:235]}"(b[2]), "+{v[236:239]}"(b[3]), "+{v[240:243]}"(b[4]), "+{v[244:247]}"(b[5]), "+{v[248:251]}"(b[6]), "+{v[252:255]}"(b[7]));
+    }
+    else if constexpr (NB == 4) {
+      asm volatile("" : "+{v[224:227]}"(b[0]), "+{v[228:231]}"(b[1]), "+{v[232:235]}"(b[2]), "+{v[236:239]}"(b[3]));
+    }
+    else if constexpr (NB == 2) {
+      asm volatile("" : "+{v[224:227]}"(b[0]), "+{v[228:231]}"(b[1]));
+    }
+  }
+}
+template <int I>
+struct BufTag {
+  static constexpr int value = I;
+};
+
 // Workgroup barrier for LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which on gfx9 is
 // s_waitcnt vmcnt(0): it would drain the row loads in flight at each barrier and serialise the prefetch.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -618,18 +709,17 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(Attn
   int cur_n = -1;
 
   // lane (row l15, k quarter kq) loads 4 consecutive channels of its row per 16-channel block
-  auto tile_rsrc = [&](int g2) {
+  auto tile_base = [&](int g2) {
     const int nk2 = __builtin_amdgcn_readfirstlane(s_tnk[g2]);
-    const float* hb = a.hinfo + (size_t)nk2 * T * w;
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(hb), 0, (unsigned)((size_t)T * w * 4), 0x00020000);
+    return a.hinfo + (size_t)nk2 * T * w;
   };
   auto tile_voff = [&](int g2) {
     const int t = s_idx[g2 * 16 + l15];
     // (invalid rows of the last tile read row 0: finite data, weight 0)
-    return (t == 0xFFFF ? 0 : t) * (w * 4) + (16 * NB * wave + 4 * kq) * 4;
+    return (unsigned)((t == 0xFFFF ? 0 : t) * (w * 4) + (16 * NB * wave + 4 * kq) * 4);
   };
-  auto load_block = [&](const __amdgpu_buffer_rsrc_t rh, int voff, int i) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rh, voff + i * 64, 0, 0));
+  auto load_tile = [&](int g2, f32x4(&dst)[NB], auto buf) {
+    rows_issue<decltype(buf)::value, NB>(tile_base(g2), tile_voff(g2), dst);
   };
 
   // FVTA_ATTN_DBG & 16: wave `dbg >> 8` of workgroup 0 stamps the shader clock at each phase boundary of its first
@@ -638,19 +728,15 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(Attn
   const bool stamp = (a.dbg & 16) && wg == 0 && wave == ((a.dbg >> 8) & 7) && lane == 0;
 #define FVTA_STAMP(k) do { if (stamp && g < 64) stamps[g * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 
-  auto tile = [&](const int g, f32x4 (&frag)[NB], f32x4 (&next)[NB]) {
+  auto tile = [&](const int g, f32x4 (&frag)[NB], f32x4 (&next)[NB], auto fbuf, auto nbuf) {
     FVTA_STAMP(0);
     const int it = s_titem[g];
     const int nk = s_tnk[g], n = nk / s.K;
     const bool first = g == s_ifirst[it], last = g + 1 == s_ifirst[it + 1];
     // prefetch distance TWO tiles (three register buffers): with one tile in flight the CU holds 64 KB of
     // outstanding reads at best and ~32 KB on average -- half of what HBM latency x the CU's bandwidth share needs
-    if (g + 2 < G) {
-      const __amdgpu_buffer_rsrc_t rnext = tile_rsrc(g + 2);
-      const int vnext = tile_voff(g + 2);
-#pragma unroll
-      for (int i = 0; i < NB; ++i) next[i] = load_block(rnext, vnext, i);
-    }
+    if (g + 2 < G) load_tile(g + 2, next, nbuf);
+    rows_wait<decltype(fbuf)::value, NB>(g + 2 < G ? 2 : (g + 1 < G ? 1 : 0), frag);  // tile g has landed; g+1, g+2 in flight
     FVTA_STAMP(1);
     if (first) {
       m_run = -INFINITY;
@@ -681,7 +767,8 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(Attn
               if (pc == 0) s_bhi[wave][m * 2 + jt][lane] = v;
               else s_blo[wave][m * 2 + jt][lane] = v;  // wave-private: written and read by this wave only
             }
-        qvalid = a.sv.qvalid[(size_t)n * 2];
+        // (a SCALAR load: it waits on lgkmcnt, not on the vmcnt the row prefetch is counted with)
+        qvalid = a.sv.qvalid[(size_t)__builtin_amdgcn_readfirstlane(n) * 2];
         if (tid < 32) s_ct[tid] = a.sv.ct[(size_t)n * JP + tid];  // read after the next barrier
       }
     }
@@ -816,22 +903,13 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(Attn
     stamps[15] = t_entry;
     stamps[14] = __builtin_readcyclecounter();
   }
-  {
-    const __amdgpu_buffer_rsrc_t r0 = tile_rsrc(0);
-    const int v0 = tile_voff(0);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) fragA[i] = load_block(r0, v0, i);
-    if (G > 1) {
-      const __amdgpu_buffer_rsrc_t r1 = tile_rsrc(1);
-      const int v1 = tile_voff(1);
-#pragma unroll
-      for (int i = 0; i < NB; ++i) fragB[i] = load_block(r1, v1, i);
-    }
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the prologue is in flight when the counting starts
+  load_tile(0, fragA, BufTag<0>{});
+  if (G > 1) load_tile(1, fragB, BufTag<1>{});
   for (int g = 0; g < G; g += 3) {  // (tile, buffer of tile g, buffer that takes tile g + 2)
-    tile(g, fragA, fragC);
-    if (g + 1 < G) tile(g + 1, fragB, fragA);
-    if (g + 2 < G) tile(g + 2, fragC, fragB);
+    tile(g, fragA, fragC, BufTag<0>{}, BufTag<2>{});
+    if (g + 1 < G) tile(g + 1, fragB, fragA, BufTag<1>{}, BufTag<0>{});
+    if (g + 2 < G) tile(g + 2, fragC, fragB, BufTag<2>{}, BufTag<1>{});
   }
 #undef FVTA_STAMP
 }

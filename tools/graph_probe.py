@@ -5,8 +5,11 @@ from fvta_memexqa_amd import _lib
 from fvta_memexqa_amd.model_v2 import Model
 from fvta_memexqa_amd.synth import CONFIGS, SynthSpec, make_inputs
 from fvta_memexqa_amd.trainer import Trainer
-spec = SynthSpec(**dict(CONFIGS["metric"], dense=True))
-cfg = dict(spec.cfg(), batch_size=spec.N, precision="bf16", optimizer="adam", init_lr=0.001)
+kw = dict(CONFIGS["metric"], dense=True)
+if len(sys.argv) > 1 and sys.argv[1] == "readme":     # README.MD:219-226 training sizes: batch 6, 4 albums x 8 photos, 8-word texts, hidden 50
+    kw = dict(N=6, A=4, P=8, S=5, L=8, d=50, dense=False)
+spec = SynthSpec(**kw)
+cfg = dict(spec.cfg(), batch_size=spec.N, precision="bf16" if kw["d"] >= 512 else "f32", optimizer="adam", init_lr=0.001)
 model = Model(cfg, text_in=spec.text_in, img_in=spec.img_in)
 tr = Trainer(model, cfg); tr.need_dx = True
 L = model.load_inputs(make_inputs(spec), training=True)
