@@ -705,6 +705,9 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(Attn
   const bool cosine = s.simi == 4;
   f32x4 fragA[NB], fragB[NB], fragC[NB], uacc[NB];
   float m_run = -INFINITY, l_run = 0.f;
+  half8 bhi[NM * 2];
+#pragma unroll
+  for (int i = 0; i < NM * 2; ++i) bhi[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t qvalid = 0;
   int cur_n = -1;
 
@@ -768,6 +771,10 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(Attn
               else s_blo[wave][m * 2 + jt][lane] = v;  // wave-private: written and read by this wave only
             }
         // (a SCALAR load: it waits on lgkmcnt, not on the vmcnt the row prefetch is counted with)
+        // the hi pieces feed two of the three MFMAs of a group: they go on into registers (through LDS, so that the
+        // registers never have a VMEM load pending -- see rows_issue); the lo pieces are read from LDS per tile
+#pragma unroll
+        for (int i = 0; i < NM * 2; ++i) bhi[i] = s_bhi[wave][i][lane];
         qvalid = a.sv.qvalid[(size_t)__builtin_amdgcn_readfirstlane(n) * 2];
         if (tid < 32) s_ct[tid] = a.sv.ct[(size_t)n * JP + tid];  // read after the next barrier
       }
@@ -796,7 +803,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(Attn
         split_f16x8(frag[2 * m], frag[2 * m + 1], hi, lo);
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
-          const half8 bh = s_bhi[wave][m * 2 + jt][lane];
+          const half8 bh = bhi[m * 2 + jt];
           ahh[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, bh, ahh[jt], 0, 0, 0);
           axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, s_blo[wave][m * 2 + jt][lane], axx[jt], 0, 0, 0);
           axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, bh, axx[jt], 0, 0, 0);
