@@ -54,7 +54,7 @@ def load_reference():
             if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in names:
                 exec(compile(ast.Module(body=[node], type_ignores=[]), fname, "exec"), ns)
 
-    pull("utils.py", {"grouper", "Dataset", "update_config"})
+    pull("utils.py", {"grouper", "Dataset", "update_config", "getAnswers", "getAnswers_yp", "getEvalScore", "sec2time"})
     pull("model_v2.py", {"get_feed_dict"}, inside_class="Model")
     return ns
 
@@ -186,7 +186,26 @@ def run_case(ref, name, case):
     print(name, nb, "batches;", {k: arrays["b0_" + k].shape for k in ("at", "pts_c", "q", "choices")}, js["config_max"])
 
 
+def run_eval_case(ref):
+    """getAnswers / getAnswers_yp / getEvalScore / grouper / sec2time (utils.py:12-29, 247-292) on a fixed yp"""
+    rng = np.random.RandomState(5)
+    yp = rng.rand(7, 4).astype("float32")
+    yp[2] = [0.25, 0.25, 0.25, 0.25]                                # a tie: argmax takes the first
+    qid, yidx = [101, 102, 103, 104, 105, 106, 107], [0, 3, 0, 2, 1, 1, 3]
+    batch = (tuple(range(7)), ref["Dataset"](dict(qid=qid, yidx=yidx), "val"))
+    pred, real = ref["getAnswers"](yp, batch)
+    pred2, real2, id2yp = ref["getAnswers_yp"](yp, batch)
+    out = dict(yp=yp.tolist(), qid=qid, yidx=yidx, pred={str(k): int(v) for k, v in pred.items()},
+               real={str(k): int(v) for k, v in real.items()}, score=ref["getEvalScore"](pred, real),
+               grouper=[list(g) for g in ref["grouper"](list(range(7)), 3)],
+               sec2time={str(t): ref["sec2time"](t) for t in (0.5, 9.999, 75.25, 3671.0)})
+    assert pred == pred2 and real == real2 and len(id2yp) == 7
+    json.dump(out, open(os.path.join(HERE, "feed_eval.json"), "w"), sort_keys=True)
+    print("feed_eval", out["pred"], out["score"], out["sec2time"])
+
+
 if __name__ == "__main__":
     ref = load_reference()
     for n, c in CASES.items():
         run_case(ref, n, c)
+    run_eval_case(ref)

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = sorted(glob.glob(os.path.join(HERE, "golden", "feed_*.json")))
+CASES = sorted(p for p in glob.glob(os.path.join(HERE, "golden", "feed_*.json")) if not p.endswith("feed_eval.json"))
 ARRAY_KEYS = ["at", "at_c", "at_mask", "ad", "ad_c", "ad_mask", "when", "when_c", "when_mask", "where", "where_c",
               "where_mask", "pts", "pts_c", "pts_mask", "pis", "pis_mask", "q", "q_c", "q_mask", "choices", "choices_c",
               "choices_mask", "image_emb_mat", "existing_emb_mat"]
@@ -124,3 +124,20 @@ def test_get_answers_and_score():
     assert pred == {7: 0, 8: 3, 9: 0} and real == {7: 0, 8: 3, 9: 1}
     assert abs(U.getEvalScore(pred, real) - 2 / 3) < 1e-12
     assert U.grouper([1, 2, 3, 4, 5], 2) == [(1, 2), (3, 4), (5, None)]
+
+
+def test_eval_helpers_match_reference():
+    """getAnswers / getAnswers_yp / getEvalScore / grouper / sec2time vs the values the reference's own functions
+    produced (tests/golden/feed_eval.json, made by make_feed_golden.run_eval_case)."""
+    from fvta_memexqa_amd import utils as U
+    z = json.load(open(os.path.join(HERE, "golden", "feed_eval.json")))
+    yp = np.asarray(z["yp"], "float32")
+    batch = (tuple(range(len(z["qid"]))), U.Dataset(dict(qid=z["qid"], yidx=z["yidx"]), "val"))
+    pred, real = U.getAnswers(yp, batch)
+    assert {str(k): v for k, v in pred.items()} == z["pred"] and {str(k): v for k, v in real.items()} == z["real"]
+    p2, r2, id2yp = U.getAnswers_yp(yp, batch)
+    assert p2 == pred and r2 == real and all(np.array_equal(id2yp[q], yp[i]) for i, q in enumerate(z["qid"]))
+    assert U.getEvalScore(pred, real) == z["score"]
+    assert [list(g) for g in U.grouper(list(range(7)), 3)] == z["grouper"]
+    for t, want in z["sec2time"].items():
+        assert U.sec2time(float(t)) == want
