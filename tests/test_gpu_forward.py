@@ -205,3 +205,38 @@ def test_attention_fast_path_matches_exact_path(monkeypatch):
     monkeypatch.setenv("FVTA_ATTN_EXACT", "1")
     exact, _ = op.forward(*args)
     _close(fast, exact.cpu(), rtol=2e-5, atol=2e-6, msg="fast vs exact")
+
+
+def test_attention_fast_path_randomised_differential(monkeypatch):
+    """The 16-row kernel loads its rows through inline asm into pinned registers with hand-counted waits (a misplaced
+    wait or a moved register shows as garbage in SOME stream position): 24 random shapes / maskings / stream lengths
+    (1 to many tiles per workgroup, several items per workgroup, fully masked and single-row modalities, n changing inside
+    a workgroup's stream), each against the exact-fp32 kernel, values and arg-max positions."""
+    from fvta_memexqa_amd import ops
+    rng = np.random.RandomState(2024)
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    for case in range(24):
+        w = int(rng.choice([128, 256, 512, 1024]))
+        N, K = int(rng.randint(1, 9)), int(rng.randint(1, 8))
+        T = int(rng.choice([5, 16, 17, 48, 150, 333, 700, 1300]))
+        JQ = int(rng.randint(1, 33))
+        simi = int(rng.choice([1, 2, 3, 4]))
+        masked = bool(rng.rand() < 0.8)
+        h, q, W, b, hm, qm = _att_case(N, K, T, JQ, w, simi, True, masked, seed=1000 + case, p_valid=float(rng.choice([0.1, 0.6, 0.95])))
+        op = ops.FocalAttention(N, K, T, JQ, w, simi, True)
+        args = (cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)), cu(W.reshape(-1)) if W is not None else None, cu(b))
+        monkeypatch.delenv("FVTA_ATTN_EXACT", raising=False)
+        fast, _ = op.forward(*args)
+        fast, saved_fast = fast.cpu(), op.saved.clone()
+        again, _ = op.forward(*args)
+        assert torch.equal(again.cpu(), fast), "case %d: not reproducible" % case
+        monkeypatch.setenv("FVTA_ATTN_EXACT", "1")
+        exact, _ = op.forward(*args)
+        tag = "case %d (N %d K %d T %d JQ %d w %d simi %d masked %s)" % (case, N, K, T, JQ, w, simi, masked)
+        assert torch.isfinite(fast).all(), tag
+        _close(fast, exact.cpu(), rtol=5e-5, atol=5e-6, msg=tag)
+        nkt = N * K * T
+        amax_f = saved_fast[:4 * nkt].view(torch.float32).cpu()
+        amax_e = op.saved[:4 * nkt].view(torch.float32).cpu()
+        ok = torch.isfinite(amax_e) & (amax_e > -1e29)
+        np.testing.assert_allclose(amax_f[ok].numpy(), amax_e[ok].numpy(), rtol=5e-5, atol=5e-6, err_msg=tag + " amax")
