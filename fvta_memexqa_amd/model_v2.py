@@ -18,7 +18,6 @@ Three entry levels, all through load_inputs():
   * the same index arrays as an `inputs` tree (synth.make_token_inputs);
   * the ENCODER INPUTS x* of model_v2.py:680-688 (embedded tokens / photo features + masks) -- the bench headline.
 """
-import math
 from types import SimpleNamespace
 
 import numpy as np
