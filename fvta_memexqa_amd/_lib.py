@@ -78,6 +78,8 @@ _SIGS = {
     "fvta_softsel_fwd": (c_int, [P, P, P, c_int64, c_int32, c_int32, P]),
     "fvta_exp_mask": (c_int, [P, P, P, c_int64, P]),
     "fvta_linear_fwd": (c_int, [P, P, P, P, c_int64, c_int32, c_int32, c_int32, P]),
+    "fvta_wsum_fwd": (c_int, [P, P, P, c_int64, c_int32, c_int32, P]),
+    "fvta_attn_read_u": (c_int, [POINTER(AttnDesc), P, P, P]),
     "fvta_test_gemm": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),
     "fvta_profile_enable": (c_int, [c_int32]),
     "fvta_profile_collect": (c_int, [c_int32, POINTER(ctypes.c_double), POINTER(c_int64)]),

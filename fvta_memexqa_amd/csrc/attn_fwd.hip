@@ -1114,3 +1114,15 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
   FVTA_CHECK_LAUNCH("attn_merge");
   return FVTA_OK;
 }
+
+// The inner softsel result u[n,k,:] (saved by fvta_attn_fwd for the backward) IS attention_keeprank1's output
+// (model.py:247-314: softsel over the rows of each (n, m), no softmax over m): copy it out.
+extern "C" int fvta_attn_read_u(const fvta_attn_desc* d, const void* saved, float* u_out, fvta_stream_t stream) {
+  if (int e = fvta_attn_check_desc(d)) return e;
+  FVTA_CHECK_ARG(saved && u_out, "attn_read_u: null pointer");
+  const AttnShape s = attn_shape(d, true);
+  const AttnSaved sv = attn_saved_view(s, const_cast<void*>(saved));
+  FVTA_CHECK_HIP(hipMemcpyAsync(u_out, sv.u, (size_t)s.N * s.K * s.w * sizeof(float), hipMemcpyDeviceToDevice,
+                                (hipStream_t)stream));
+  return FVTA_OK;
+}

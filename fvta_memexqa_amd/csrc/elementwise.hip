@@ -121,7 +121,28 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     }
 }
 
+// weighted sum without a softmax: out[r, :] = sum_j weights[r, j] * target[r, j, :]  (attention_tgif, model.py:236-238:
+// the weights there are softmax(score) with exp_mask applied AFTERWARDS).  grid rows, 256 threads
+__global__ __launch_bounds__(256) void wsum_kernel(const float* __restrict__ target, const float* __restrict__ weights,
+                                                   float* __restrict__ out, int J, int d) {
+  const int64_t r = blockIdx.x;
+  const float* tr = target + r * (int64_t)J * d;
+  const float* wr = weights + r * J;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < J; ++j) acc += wr[j] * tr[(int64_t)j * d + c];
+    out[r * d + c] = acc;
+  }
+}
 }  // namespace fvta
+
+extern "C" int fvta_wsum_fwd(const float* target, const float* weights, float* out, int64_t rows, int32_t J, int32_t d,
+                             fvta_stream_t stream) {
+  FVTA_CHECK_ARG(target && weights && out && rows > 0 && rows < (1ll << 31) && J > 0 && d > 0, "wsum_fwd: bad arguments");
+  hipLaunchKernelGGL(fvta::wsum_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, target, weights, out, J, d);
+  FVTA_CHECK_LAUNCH("wsum");
+  return FVTA_OK;
+}
 
 extern "C" int fvta_softmax_fwd(const float* logits, float* out, int64_t rows, int32_t J, fvta_stream_t stream) {
   FVTA_CHECK_ARG(logits && out && rows > 0 && J > 0, "softmax_fwd: bad arguments");

@@ -8,6 +8,9 @@
               add_tanh=False, bidirect=False, scope=None) -> (h_a, a_logits)         model_v2.py:125-201
     attention_3d(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, wd=None, add_tanh=False,
                  time_warp_att=False, C=None, bidirect=False, scope=None)            model_v2.py:210-298
+    attention_keeprank1(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, wd=None,
+                        bidirect=False, scope=None) -> h_a [N,M,w]                   model.py:247-314
+    attention_tgif(hinfo, lq, hinfo_mask=None, wd=None, mlp_dim=512, scope=None)     model.py:210-244
 
 Tensors are torch CUDA tensors; every op is one call into libfvta_hip.so (forward only -- training goes through
 `Model`, whose backward kernels own the gradients).  Where the reference creates TF variables (`linear`'s W / b, the
@@ -17,6 +20,7 @@ Tensors are torch CUDA tensors; every op is one call into libfvta_hip.so (forwar
 `wd` appends the l2 terms to `losses` like `add_wd` (model_v2.py:347-354).
 """
 import contextlib
+import ctypes
 import zlib
 
 import torch
@@ -182,3 +186,61 @@ def attention(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, wd=None, a
     hm = hinfo_mask.reshape(N, 1, -1) if hinfo_mask is not None else None
     h_a, a = _attention(h, hq, hm, hq_mask, simiMatrix, wd, add_tanh, scope or "attention_2vector", 0)
     return h_a, a.reshape(N, h.shape[2], hq.shape[1])
+
+
+def attention_keeprank1(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, wd=None, bidirect=False, scope=None):
+    """model.py:247-314: hinfo [N,M,...,w] -> h_a [N,M,w], each album attended on its own (softsel over the rows of
+    (n, m) with the max-over-question logits; no softmax over m).  That is the inner stage of attention_3d with K = M:
+    one fvta_attn_fwd, then the per-(n,k) result is read back out of the saved state.  model.py's feature order for
+    simiMatrix 2 is [(h-q)^2, h*q] (feat_order 1); no tanh on the logits."""
+    if bidirect:
+        raise NotImplementedError("bidirect (model.py:297-307) is not built")
+    if simiMatrix not in (1, 2, 3):
+        raise ValueError("similarity matrix not implemented")              # model.py:283-285 (sys.exit there)
+    hinfo, hq = _f32(hinfo), _f32(hq)
+    N, M, w = hinfo.shape[0], hinfo.shape[1], hinfo.shape[-1]
+    h = hinfo.reshape(N, M, -1, w)
+    V, JQ = h.shape[2], hq.shape[1]
+    wp = next((c for c in SUPPORTED_W if w <= c), None)
+    if wp is None:
+        raise ValueError("attention: feature width %d too large (max %d)" % (w, SUPPORTED_W[-1]))
+    F = {1: 3, 2: 2, 3: 4}[simiMatrix]
+    with variable_scope(scope or "attention_2vector"):
+        wn, bn = _name("att_logits", "W"), _name("att_logits", "b")
+        Wv = get_variable(wn, (F * w, 1))
+        b = get_variable(bn, (1,), init="zeros")
+        W = _pad_channels(Wv.reshape(F, w), wp).reshape(-1).contiguous()
+        _add_wd([wn, bn], wd)
+    op = ops.FocalAttention(N, M, V, JQ, wp, simiMatrix, False, feat_order=1)
+    both = hinfo_mask is not None and hq_mask is not None
+    hm = ops.as_mask_u8(hinfo_mask.reshape(N, M, V)) if both else None
+    qm = ops.as_mask_u8(hq_mask) if both else None
+    op.forward(_pad_channels(h, wp), _pad_channels(hq, wp), hm, qm, W, b)
+    u = torch.empty(N, M, wp, dtype=torch.float32, device=h.device)
+    check(op.lib.fvta_attn_read_u(ctypes.byref(op.desc), ptr(op.saved), ptr(u), stream_ptr()), "fvta_attn_read_u")
+    return u[..., :w].contiguous()
+
+
+def attention_tgif(hinfo, lq, hinfo_mask=None, wd=None, mlp_dim=512, scope=None):
+    """model.py:210-244 (the TGIF-QA attention baseline): score = linear(linear(lq)[:,None] + linear(hinfo)) ->
+    softmax over the rows -> exp_mask applied to the PROBABILITIES (as the reference does: masked rows get weight
+    -1e30, harmless only because their h is 0) -> weighted sum -> tanh(linear) + lq.  Returns (logits [N,2*mlp_dim],
+    att [N,V]); needs lq.shape[-1] == 2 * mlp_dim like the reference's tf.add."""
+    hinfo, lq = _f32(hinfo), _f32(lq)
+    N, w = hinfo.shape[0], hinfo.shape[-1]
+    h = hinfo.reshape(N, -1, w)
+    V = h.shape[1]
+    with variable_scope(scope or "attention_2vector"):
+        q_in = linear(lq, mlp_dim, scope="mlp_q", wd=None)
+        h_in = linear(h, mlp_dim, scope="mlp_h", wd=None)
+        preatt = (h_in + q_in[:, None, :]).contiguous()                      # tf.tile + tf.add (plumbing)
+        score = linear(preatt, 1, scope="preatt").reshape(N, V)
+        att = softmax(score)
+        if hinfo_mask is not None:
+            att = exp_mask(att, hinfo_mask.reshape(N, V))
+        attended = torch.empty(N, w, dtype=torch.float32, device=h.device)
+        check(_lib.load().fvta_wsum_fwd(ptr(h), ptr(att), ptr(attended), N, V, w, stream_ptr()), "fvta_wsum_fwd")
+        final = linear(attended, 2 * mlp_dim, scope="final", add_tanh=True)
+        if wd is not None:                                                    # add_wd over the whole scope (:241-242)
+            _add_wd([n for n in variables if n.startswith(_name("") )], wd)
+    return final + lq, att

@@ -292,6 +292,12 @@ int fvta_softsel_fwd(const float* target, const float* logits, float* out, int64
 int fvta_exp_mask(const float* val, const uint8_t* mask, float* out, int64_t n, fvta_stream_t stream);
 int fvta_linear_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int32_t in, int32_t out,
                     int32_t add_tanh, fvta_stream_t stream);
+/* sum_j weights[r,j] * target[r,j,:] -> out[r,:] (no softmax): the attended vector of attention_tgif, model.py:236-238 */
+int fvta_wsum_fwd(const float* target, const float* weights, float* out, int64_t rows, int32_t J, int32_t d,
+                  fvta_stream_t stream);
+/* attention_keeprank1 (model.py:247-314) = the per-(n,k) inner softsel of attention_3d without the softmax over k:
+ * after fvta_attn_fwd(desc with K = M) this copies that result, u[N,K,w], out of the saved state. */
+int fvta_attn_read_u(const fvta_attn_desc* d, const void* saved, float* u_out, fvta_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Test hooks (not part of the reference surface): the MFMA tile engines the

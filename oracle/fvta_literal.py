@@ -174,6 +174,43 @@ def attention_3d(hinfo, hq, W=None, b=None, hinfo_mask=None, hq_mask=None,
 # ----------------------------------------------------------------------------
 # Encoders: model_v2.py:649-833   [TF-internal cell / rnn semantics, SURVEY 3.6]
 # ----------------------------------------------------------------------------
+def attention_keeprank1(hinfo, hq, W, b, hinfo_mask=None, hq_mask=None, simiMatrix=1):
+    """model.py:247-314 (bidirect=False): h_a[N,M,w], one softsel per album, max over the question inside."""
+    N, M, w = hinfo.shape[0], hinfo.shape[1], hinfo.shape[-1]
+    JQ = hq.shape[1]
+    hinfo = hinfo.reshape(N, M, -1, w)
+    V = hinfo.shape[2]
+    h_aug = np.broadcast_to(hinfo[:, :, :, None, :], (N, M, V, JQ, w))
+    q_aug = np.broadcast_to(hq[:, None, None, :, :], (N, M, V, JQ, w))
+    if simiMatrix == 1:
+        feat = np.concatenate([h_aug, q_aug, h_aug * q_aug], 4)
+    elif simiMatrix == 2:
+        feat = np.concatenate([(h_aug - q_aug) * (h_aug - q_aug), h_aug * q_aug], 4)     # model.py:280 order
+    elif simiMatrix == 3:
+        feat = np.concatenate([h_aug, q_aug, (h_aug - q_aug) * (h_aug - q_aug), h_aug * q_aug], 4)
+    else:
+        raise ValueError("similarity matrix not implemented")
+    a_logits = linear(feat, W, b)[..., 0]
+    if hinfo_mask is not None and hq_mask is not None:
+        mask = hinfo_mask.reshape(N, M, V)[..., None] & hq_mask[:, None, None, :]
+        a_logits = exp_mask(a_logits, mask)
+    return softsel(hinfo, a_logits.max(3))
+
+
+def attention_tgif(hinfo, lq, Wq, bq, Wh, bh, Wp, bp, Wf, bf, hinfo_mask=None):
+    """model.py:210-244, literally (incl. exp_mask on the softmax OUTPUT)."""
+    N, w = hinfo.shape[0], hinfo.shape[-1]
+    hinfo = hinfo.reshape(N, -1, w)
+    q_in = linear(lq, Wq, bq)
+    h_in = linear(hinfo, Wh, bh)
+    score = linear(q_in[:, None, :] + h_in, Wp, bp)[..., 0]
+    att = softmax(score)
+    if hinfo_mask is not None:
+        att = exp_mask(att, hinfo_mask.reshape(N, -1))
+    attended = (hinfo * att[..., None]).sum(1)
+    return np.tanh(linear(attended, Wf, bf)) + lq, att
+
+
 def sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
