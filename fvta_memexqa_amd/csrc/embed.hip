@@ -5,6 +5,7 @@
 // its 40 weights in registers, the token's W x cdim character embeddings sit in LDS and are read as broadcasts,
 // and the token's row (char part | word part) is written once, straight into the encoder input arena.
 #include "fvta_common.h"
+#include "gemm_f32.h"
 
 namespace fvta {
 
@@ -383,6 +384,220 @@ __global__ __launch_bounds__(EMB_NT) void embed_fwd_kernel_big(EmbArgs a) {
   }
 }
 
+// ---- wide char embeddings on the matrix pipe (README.MD:144's --char_emb_size 100) ----------------------------------
+// With a 500-deep window the convolution IS a GEMM: rows (token, window position p), k = (kh, c) -- the window of
+// position p is the CONTIGUOUS slice E[tok][p*cdim .. p*cdim + height*cdim) of the token's character block -- columns
+// the filters.  Exact-fp32 MFMA tile engine of the LSTM's parity path (gemm_f32.h): 128 x 128 tile = 8 tokens x 16
+// positions (positions >= P are zero rows) x 128 filters; the A operand is gathered straight from the character table
+// (a few KB, L1 / L2 resident) through the char ids staged in LDS; the epilogue takes max / first arg-max over the
+// positions of a token (its 16 rows sit in one 32 x 32 accumulator tile: 8 rows per lane, the other 8 in lane ^ 32).
+// Needs W <= 16, cdim % 4 == 0, cwdim % 4 == 0, cwdim <= 128.
+typedef MmaF32<2, 2, 2, 2> MmaEmb;  // 128 x 128, four waves
+__global__ __launch_bounds__(256) void embed_fwd_kernel_mfma(EmbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_gemm[];
+  __shared__ int s_chid[8 * 16];
+  const fvta_embed_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int tok0 = blockIdx.x * 8;
+  const int KC = d.height * d.cdim, P = d.W - d.height + 1, cd = d.cdim, cw = d.cwdim;
+  if (tid < 128) {
+    const int tk = tok0 + (tid >> 4), pos = tid & 15;
+    s_chid[tid] = (tk < d.ntok && pos < d.W) ? a.char_ids[(size_t)tk * d.W + pos] : -1;
+  }
+  __syncthreads();
+  MmaEmb mma;
+  mma.init(tid);
+  StageKContig<128, 16, 256, MmaEmb::LDA> sa;
+  StageMNContig<128, 16, 256, MmaEmb::LDB> sb;
+  auto fa = [&](int r, int k, bool& ok) -> const float* {  // row r = 16 * local token + p, k = kh * cdim + c (c % 4 == 0)
+    const int tl = r >> 4, pp = r & 15;
+    const int kh = k / cd, c = k - kh * cd;
+    const int pos = pp + kh;
+    const int ch = (k < KC && pp < P) ? s_chid[tl * 16 + (pos & 15)] : -1;   // pp < P => pos < W <= 16
+    ok = ch >= 0;
+    return a.char_emb + (size_t)(ok ? ch : 0) * cd + (ok ? c : 0);
+  };
+  auto fb = [&](int k, int c, bool& ok) -> const float* {  // filt [KC][cwdim]
+    ok = k < KC && c < cw;
+    return a.filt + (ok ? (size_t)k * cw + c : 0);
+  };
+  gemm_mainloop(mma, sa, sb, fa, fb, 0, (KC + 15) / 16 * 16, s_gemm, tid);
+#pragma unroll
+  for (int i = 0; i < MmaEmb::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < MmaEmb::TN; ++j) {
+      const int f = mma.col_of(j);
+      const float bf = f < cw ? a.bias[f] : 0.f;
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {  // the tile's two tokens: accumulator registers 0..7 and 8..15
+        float best = -INFINITY;
+        int bp = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = hs * 8 + q;
+          const int pp = (r & 3) + 8 * ((r >> 2) & 1) + 4 * mma.hf;  // position inside the token, increasing with q
+          const float v = mma.acc[i][j][r];
+          if (pp < P && v > best) {
+            best = v;
+            bp = pp;
+          }
+        }
+        const float ob = __shfl_xor(best, 32, 64);
+        const int op = __shfl_xor(bp, 32, 64);
+        if (ob > best || (ob == best && op < bp)) {  // first arg-max over all positions
+          best = ob;
+          bp = op;
+        }
+        const int tok = tok0 + mma.wm * 4 + i * 2 + hs;
+        if (mma.hf == 0 && tok < d.ntok && f < cw) {
+          const float y = best + bf;
+          a.x[a.tok_off[tok] + f] = y > 0.f ? y : 0.f;
+          a.argpos[(size_t)tok * cw + f] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
+        }
+      }
+    }
+  // the word part of the 8 rows
+  for (int tl = 0; tl < 8; ++tl) {
+    const int tok = tok0 + tl;
+    if (tok >= d.ntok) break;
+    const int id = a.word_ids[tok];
+    const float* src = id < d.VW ? a.word_emb + (size_t)id * d.wdim : a.fixed_emb + (size_t)(id - d.VW) * d.wdim;
+    float* row = a.x + a.tok_off[tok];
+    for (int c = tid; c < d.wdim; c += 256) row[cw + c] = src[c];
+  }
+}
+
+// Backward of the wide shape, in the SPARSE form (one window per token and filter carries gradient: 12x fewer MACs than
+// the GEMM form), split so that every accumulator lives in registers / LDS instead of a global slab:
+//  * embed_bwdw_filt: d filter / d bias.  grid (k chunks of 128, blocks); thread f keeps its 128 filter-gradient
+//    values of the chunk in registers and adds g_f * E[tok][argpos_f * cdim + k] from the token's character block in
+//    LDS (positions of different filters hit different banks: 100 * p mod 64 is injective for p < 12);
+//  * embed_bwdw_char: d E -> d char_emb.  grid (channel slices of 32, blocks); the filter slice of 32 channels
+//    ([height][32][cwdim], 64 KB) sits in LDS, thread (position group, channel) sums g_f * filt[pos - argpos_f][c][f]
+//    over the filters in fixed order, then the first position of every distinct character folds its duplicates and
+//    adds into the workgroup's char table slice.
+// Both write the SAME slab layout as the other kernels ([KC*cwdim | cwdim | VC*cdim] per block), so
+// embed_bwd_reduce_kernel finishes the job in a fixed order.
+constexpr int EMBW_KCH = 128;   // k values per chunk (registers)
+constexpr int EMBW_CS = 32;     // channels per slice
+__global__ __launch_bounds__(EMB_NT) void embed_bwdw_filt(EmbArgs a) {
+  extern __shared__ float s_E[];  // [W * cdim]
+  const fvta_embed_desc& d = a.d;
+  const int tid = threadIdx.x, cw = d.cwdim, cd = d.cdim;
+  const int KC = d.height * cd, WC = d.W * cd;
+  const int k0 = blockIdx.x * EMBW_KCH;
+  float acc[EMBW_KCH];
+#pragma unroll
+  for (int i = 0; i < EMBW_KCH; ++i) acc[i] = 0.f;
+  float accb = 0.f;
+  for (int tok = blockIdx.y; tok < d.ntok; tok += gridDim.y) {
+    const float* row = a.dx + a.tok_off[tok];
+    if (blockIdx.x == 0) {  // the word rows ride along with the first chunk
+      const int id = a.word_ids[tok];
+      if (id < d.VW)
+        for (int i = tid; i < d.wdim; i += EMB_NT) atomicAdd(a.d_word_emb + (size_t)id * d.wdim + i, row[cw + i]);
+    }
+    float g = 0.f;
+    int p = 0;
+    if (tid < cw) {
+      const int ap = a.argpos[(size_t)tok * cw + tid];
+      if (ap != 255) {
+        g = row[tid];
+        p = ap;
+      }
+    }
+    __syncthreads();  // the previous token's readers of s_E are done
+    for (int i = tid; i < WC; i += EMB_NT) s_E[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / cd] * cd + i % cd];
+    __syncthreads();
+    if (g != 0.f) {
+      accb += g;
+      const float* e = s_E + p * cd + k0;
+#pragma unroll
+      for (int i = 0; i < EMBW_KCH; ++i)
+        if (k0 + i < KC) acc[i] += g * e[i];
+    }
+  }
+  float* slab = a.slab + (size_t)blockIdx.y * ((size_t)KC * cw + cw + (size_t)d.VC * cd);
+  if (tid < cw) {
+#pragma unroll
+    for (int i = 0; i < EMBW_KCH; ++i)
+      if (k0 + i < KC) slab[(size_t)(k0 + i) * cw + tid] = acc[i];
+    if (blockIdx.x == 0) slab[(size_t)KC * cw + tid] = accb;
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_bwdw_char(EmbArgs a) {
+  extern __shared__ float s_dyn[];  // filter slice [height][CS][cwdim], then dC [VC][CS], then dE [16][CS]
+  __shared__ float s_g[128];
+  __shared__ int s_p[128];
+  __shared__ int s_ch[16];
+  const fvta_embed_desc& d = a.d;
+  const int tid = threadIdx.x, cw = d.cwdim, cd = d.cdim, H = d.height, W = d.W;
+  const int c0 = blockIdx.x * EMBW_CS, nc = min(EMBW_CS, cd - c0);
+  float* s_f = s_dyn;                       // [H][CS][cw]
+  float* s_dC = s_f + H * EMBW_CS * cw;     // [VC][CS]
+  float* s_dE = s_dC + d.VC * EMBW_CS;      // [16][CS]
+  for (int i = tid; i < H * EMBW_CS * cw; i += 256) {
+    const int f = i % cw, cl = (i / cw) % EMBW_CS, kh = i / (cw * EMBW_CS);
+    s_f[i] = cl < nc ? a.filt[(size_t)(kh * cd + c0 + cl) * cw + f] : 0.f;
+  }
+  for (int i = tid; i < d.VC * EMBW_CS; i += 256) s_dC[i] = 0.f;
+  const int cl = tid & (EMBW_CS - 1), pg = tid >> 5;  // 8 position groups: positions pg and pg + 8
+  for (int tok = blockIdx.y; tok < d.ntok; tok += gridDim.y) {
+    const float* row = a.dx + a.tok_off[tok];
+    __syncthreads();
+    if (tid < 128) {
+      float g = 0.f;
+      int p = 0;
+      if (tid < cw) {
+        const int ap = a.argpos[(size_t)tok * cw + tid];
+        if (ap != 255) {
+          g = row[tid];
+          p = ap;
+        }
+      }
+      s_g[tid] = g;
+      s_p[tid] = p;
+    }
+    if (tid < 16) s_ch[tid] = tid < W ? a.char_ids[(size_t)tok * W + tid] : -1;
+    __syncthreads();
+    float v0 = 0.f, v1 = 0.f;  // d E[pg][c], d E[pg + 8][c]
+    for (int f = 0; f < cw; ++f) {
+      const float g = s_g[f];
+      if (g == 0.f) continue;  // (uniform: s_g[f] is a broadcast read)
+      const int p = s_p[f];
+      const int ka = pg - p, kb = pg + 8 - p;
+      if (ka >= 0 && ka < H) v0 += g * s_f[(ka * EMBW_CS + cl) * cw + f];
+      if (kb >= 0 && kb < H) v1 += g * s_f[(kb * EMBW_CS + cl) * cw + f];
+    }
+    s_dE[pg * EMBW_CS + cl] = v0;
+    s_dE[(pg + 8) * EMBW_CS + cl] = v1;
+    __syncthreads();
+    // the first position of a character adds itself and its later duplicates (position order) to the table slice
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pos = pg + 8 * h;
+      const int me = pos < W ? s_ch[pos] : -1;
+      if (me < 0) continue;
+      bool first = true;
+      for (int q = 0; q < pos; ++q) first = first && (s_ch[q] != me);
+      if (first) {
+        float v = s_dC[me * EMBW_CS + cl];
+        for (int q = pos; q < W; ++q)
+          if (s_ch[q] == me) v += s_dE[q * EMBW_CS + cl];
+        s_dC[me * EMBW_CS + cl] = v;
+      }
+    }
+  }
+  __syncthreads();
+  const int KC = H * cd;
+  float* slab_c = a.slab + (size_t)blockIdx.y * ((size_t)KC * cw + cw + (size_t)d.VC * cd) + (size_t)KC * cw + cw;
+  for (int i = tid; i < d.VC * EMBW_CS; i += 256) {
+    const int v = i / EMBW_CS, c = i % EMBW_CS;
+    if (c < nc) slab_c[(size_t)v * cd + c0 + c] = s_dC[i];
+  }
+}
+
 // the slab [KC*cwdim | cwdim | VC*cdim] of this workgroup is zeroed by the launcher and accumulated in place
 __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_big(EmbArgs a) {
   extern __shared__ float s_dyn[];  // E [W*cdim], dE [W*cdim]
@@ -569,6 +784,13 @@ static bool embed_is_big(const fvta_embed_desc* d) {
   return d->cwdim > 0 && (d->height * d->cdim > EMB_MAXKC || d->W * d->cdim > EMB_MAXWC);
 }
 constexpr int EMB_BIG_BLOCKS = 256;
+static bool embed_mfma_ok(const fvta_embed_desc* d) {  // shapes the matrix-pipe char-CNN kernels take
+  static const bool off = [] {
+    const char* e = getenv("FVTA_EMBED_MFMA");
+    return e && e[0] == '0';
+  }();
+  return !off && d->W <= 16 && d->cdim % 4 == 0 && d->cwdim % 4 == 0 && d->cwdim <= 128;
+}
 
 static size_t embed_slab_floats(const fvta_embed_desc* d) {
   return (size_t)d->height * d->cdim * d->cwdim + d->cwdim + (size_t)d->VC * d->cdim;
@@ -595,7 +817,10 @@ extern "C" int fvta_embed_fwd(const fvta_embed_desc* d, const int32_t* word_ids,
   a.word_emb = word_emb; a.fixed_emb = fixed_emb; a.char_emb = char_emb; a.filt = filt; a.bias = bias;
   a.x = x; a.argpos = argpos;
   const int blocks = d->ntok < 8192 ? d->ntok : 8192;
-  if (embed_is_big(d)) {
+  if (embed_is_big(d) && embed_mfma_ok(d)) {
+    hipLaunchKernelGGL(embed_fwd_kernel_mfma, dim3((d->ntok + 7) / 8), dim3(256), MmaEmb::LDS_FLOATS * sizeof(float),
+                       (hipStream_t)stream_, a);
+  } else if (embed_is_big(d)) {
     const size_t dyn = (size_t)d->W * d->cdim * sizeof(float);
     hipLaunchKernelGGL(embed_fwd_kernel_big, dim3(blocks), dim3(EMB_NT), dyn, (hipStream_t)stream_, a);
   } else if (d->cwdim > 0 && d->height == 5 && d->cdim == 8 && d->W <= 16)
@@ -622,7 +847,16 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
   a.char_emb = char_emb; a.filt = filt; a.argpos = const_cast<uint8_t*>(argpos);
   a.dx = dx; a.d_word_emb = d_word_emb; a.slab = (float*)workspace;
   int blocks;
-  if (embed_is_big(d)) {
+  const size_t charw_lds = ((size_t)d->height * EMBW_CS * d->cwdim + (size_t)d->VC * EMBW_CS + 16 * EMBW_CS) * sizeof(float);
+  if (embed_is_big(d) && embed_mfma_ok(d) && charw_lds <= 150 * 1024) {
+    blocks = d->ntok < EMB_BIG_BLOCKS ? d->ntok : EMB_BIG_BLOCKS;
+    const int KC = d->height * d->cdim;
+    hipLaunchKernelGGL(embed_bwdw_filt, dim3((KC + EMBW_KCH - 1) / EMBW_KCH, blocks), dim3(EMB_NT),
+                       (size_t)d->W * d->cdim * sizeof(float), stream, a);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)charw_lds);
+    hipLaunchKernelGGL(embed_bwdw_char, dim3((d->cdim + EMBW_CS - 1) / EMBW_CS, blocks), dim3(256), charw_lds, stream, a);
+  } else if (embed_is_big(d)) {
     blocks = d->ntok < EMB_BIG_BLOCKS ? d->ntok : EMB_BIG_BLOCKS;
     FVTA_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)blocks * embed_slab_floats(d) * sizeof(float), stream));
     const size_t dyn = (size_t)2 * d->W * d->cdim * sizeof(float);
