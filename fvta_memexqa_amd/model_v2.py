@@ -554,34 +554,78 @@ class Model:
             L.image_emb_mat = torch.as_tensor(np.asarray(inputs["image_emb_mat"]) if not torch.is_tensor(
                 inputs["image_emb_mat"]) else inputs["image_emb_mat"]).to(dev, torch.float32).contiguous()
 
-        def put(cell, si, st):
-            G = L.groups[cell]
-            s = G.segs[si]
-            mask = st["mask"]
-            if "x" in st:
-                x = st["x"]
-                self.seg_x(L, cell, si)[:, :, :x.shape[-1]].copy_(x.reshape(-1, x.shape[-2], x.shape[-1]).to(dev, torch.float32))
-            else:
-                n = s["count"] * s["J"]
-                if cell == "text":
-                    G.word_ids[s["tok0"]:s["tok0"] + n] = st["ids"].reshape(-1).to(dev, torch.int32)
-                    if G.char_ids is not None:
-                        G.char_ids[s["tok0"]:s["tok0"] + n] = st["chars"].reshape(n, -1).to(dev, torch.int32)
-                else:
-                    G.pidx[s["tok0"]:s["tok0"] + n] = st["pis"].reshape(-1).to(dev, torch.int32)
-            G.lens[s["s0"]:s["s0"] + s["count"]] = mask.reshape(-1, mask.shape[-1]).to(dev).sum(1).to(torch.int32)
+        # Host-resident index inputs (the feed path: NumPy arrays / CPU tensors) are packed on the host and go up as ONE
+        # copy per device buffer -- word ids, char ids, photo indices, lengths, context mask -- instead of one small copy
+        # per stream and field (~45 per step, which at README batch sizes cost as much host time as the device step).
+        host = L.token and all(not (torch.is_tensor(v) and v.is_cuda)
+                               for st in [inputs["q"], inputs["choices"]] + list(inputs["ctx"]) for v in st.values()
+                               if torch.is_tensor(v))
+        if host:
+            npy = lambda v: v.numpy() if torch.is_tensor(v) else np.asarray(v)
+            parts = {c: dict(ids=[None] * len(G.segs), chars=[None] * len(G.segs), lens=[None] * len(G.segs))
+                     for c, G in L.groups.items()}
+            hall_mask = np.zeros((L.N, L.K, L.M, L.JMAX), np.uint8)
 
-        put("text", 0, inputs["q"])
-        put("text", 1, inputs["choices"])
-        L.q_mask.copy_(inputs["q"]["mask"].to(dev, torch.uint8))
-        L.hall_mask.zero_()
-        for k, st in enumerate(inputs["ctx"]):
-            cell, si, dims = L.ctx_slots[k]
-            put(cell, si, st)
-            m = st["mask"].to(dev, torch.uint8).reshape(L.N, L.M, -1)
-            L.hall_mask[:, k, :, :m.shape[2]] = m
+            def stage(cell, si, st):
+                mask = npy(st["mask"])
+                pp = parts[cell]
+                pp["lens"][si] = mask.reshape(-1, mask.shape[-1]).sum(1).astype(np.int32)
+                if cell == "text":
+                    pp["ids"][si] = npy(st["ids"]).reshape(-1).astype(np.int32, copy=False)
+                    if L.groups[cell].char_ids is not None:
+                        pp["chars"][si] = npy(st["chars"]).reshape(-1, self.Wc).astype(np.int32, copy=False)
+                else:
+                    pp["ids"][si] = npy(st["pis"]).reshape(-1).astype(np.int32, copy=False)
+                return mask
+
+            stage("text", 0, inputs["q"])
+            stage("text", 1, inputs["choices"])
+            for k, st in enumerate(inputs["ctx"]):
+                cell, si, dims = L.ctx_slots[k]
+                m = stage(cell, si, st).reshape(L.N, L.M, -1)
+                hall_mask[:, k, :, :m.shape[2]] = m
+            up = lambda dst, arr: dst.copy_(torch.from_numpy(np.ascontiguousarray(arr)))
+            for cell, G in L.groups.items():
+                pp = parts[cell]
+                up(G.lens, np.concatenate(pp["lens"]))
+                if cell == "text":
+                    up(G.word_ids, np.concatenate(pp["ids"]))
+                    if G.char_ids is not None:
+                        up(G.char_ids, np.concatenate(pp["chars"]))
+                else:
+                    up(G.pidx, np.concatenate(pp["ids"]))
+            up(L.hall_mask, hall_mask)
+            up(L.q_mask, npy(inputs["q"]["mask"]).astype(np.uint8))
+        else:
+            def put(cell, si, st):
+                G = L.groups[cell]
+                s = G.segs[si]
+                mask = st["mask"]
+                if "x" in st:
+                    x = st["x"]
+                    self.seg_x(L, cell, si)[:, :, :x.shape[-1]].copy_(x.reshape(-1, x.shape[-2], x.shape[-1]).to(dev, torch.float32))
+                else:
+                    n = s["count"] * s["J"]
+                    if cell == "text":
+                        G.word_ids[s["tok0"]:s["tok0"] + n] = st["ids"].reshape(-1).to(dev, torch.int32)
+                        if G.char_ids is not None:
+                            G.char_ids[s["tok0"]:s["tok0"] + n] = st["chars"].reshape(n, -1).to(dev, torch.int32)
+                    else:
+                        G.pidx[s["tok0"]:s["tok0"] + n] = st["pis"].reshape(-1).to(dev, torch.int32)
+                G.lens[s["s0"]:s["s0"] + s["count"]] = mask.reshape(-1, mask.shape[-1]).to(dev).sum(1).to(torch.int32)
+
+            put("text", 0, inputs["q"])
+            put("text", 1, inputs["choices"])
+            L.q_mask.copy_(inputs["q"]["mask"].to(dev, torch.uint8))
+            L.hall_mask.zero_()
+            for k, st in enumerate(inputs["ctx"]):
+                cell, si, dims = L.ctx_slots[k]
+                put(cell, si, st)
+                m = st["mask"].to(dev, torch.uint8).reshape(L.N, L.M, -1)
+                L.hall_mask[:, k, :, :m.shape[2]] = m
         if inputs.get("y") is not None:
-            L.y.copy_(inputs["y"].to(dev, torch.uint8))
+            y = inputs["y"]
+            L.y.copy_((y if torch.is_tensor(y) else torch.from_numpy(np.ascontiguousarray(y))).to(torch.uint8))
             L.has_y = True
         else:
             L.has_y = False
