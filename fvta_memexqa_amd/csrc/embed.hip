@@ -543,23 +543,36 @@ __global__ __launch_bounds__(256) void embed_bwdw_char(EmbArgs a) {
   }
   for (int i = tid; i < d.VC * EMBW_CS; i += 256) s_dC[i] = 0.f;
   const int cl = tid & (EMBW_CS - 1), pg = tid >> 5;  // 8 position groups: positions pg and pg + 8
+  // this thread's share of a token's staging data (tid < 128: filter tid; tid < 16: char position tid), requested one
+  // token ahead: the dependent global loads (tok_off -> dx row, argpos, char ids) otherwise cost ~2 us per token
+  auto fetch = [&](int tok, float& g, int& p, int& ch) {
+    g = 0.f;
+    p = 0;
+    ch = -1;
+    if (tok >= d.ntok) return;
+    if (tid < cw) {
+      const int ap = a.argpos[(size_t)tok * cw + tid];
+      const float r = a.dx[a.tok_off[tok] + tid];
+      if (ap != 255) {
+        g = r;
+        p = ap;
+      }
+    }
+    if (tid < W) ch = a.char_ids[(size_t)tok * W + tid];
+  };
+  float g_n;
+  int p_n, ch_n;
+  fetch(blockIdx.y, g_n, p_n, ch_n);
   for (int tok = blockIdx.y; tok < d.ntok; tok += gridDim.y) {
-    const float* row = a.dx + a.tok_off[tok];
+    const float g_c = g_n;
+    const int p_c = p_n, ch_c = ch_n;
+    fetch(tok + gridDim.y, g_n, p_n, ch_n);
     __syncthreads();
     if (tid < 128) {
-      float g = 0.f;
-      int p = 0;
-      if (tid < cw) {
-        const int ap = a.argpos[(size_t)tok * cw + tid];
-        if (ap != 255) {
-          g = row[tid];
-          p = ap;
-        }
-      }
-      s_g[tid] = g;
-      s_p[tid] = p;
+      s_g[tid] = g_c;
+      s_p[tid] = p_c;
     }
-    if (tid < 16) s_ch[tid] = tid < W ? a.char_ids[(size_t)tok * W + tid] : -1;
+    if (tid < 16) s_ch[tid] = ch_c;
     __syncthreads();
     float v0 = 0.f, v1 = 0.f;  // d E[pg][c], d E[pg + 8][c]
     for (int f = 0; f < cw; ++f) {
