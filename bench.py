@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--front-end", action="store_true",
                     help="enter with the reference's token-id feed (SURVEY 8f rank 1): the char-CNN / word / photo embedding "
                          "front-end and its gradients are inside the timed step (the headline enters at the encoder inputs)")
+    ap.add_argument("--char-emb-size", type=int, default=8,
+                    help="--front-end only: char embedding width (8: the reference's default; 100: the published flag set, "
+                         "README.MD:144 -- a 500-deep char-CNN window, run on the fp32 MFMA engine)")
     return ap.parse_args()
 
 
@@ -132,7 +135,7 @@ def main():
     if args.front_end:   # README.MD:144-147 sizes: 100-d GloVe + 100-d char-CNN, 2537-d photo features -> 100
         from fvta_memexqa_amd.synth import make_token_inputs
         cfg.update(word_vocab_size=400, word_emb_size=100, use_char=True, char_vocab_size=100, max_word_size=16,
-                   char_emb_size=8, char_out_size=100, image_feat_dim=2537, use_image_trans=True, image_trans_dim=100)
+                   char_emb_size=args.char_emb_size, char_out_size=100, image_feat_dim=2537, use_image_trans=True, image_trans_dim=100)
     model = Model(cfg, text_in=spec.text_in, img_in=spec.img_in, device=dev)
     trainer = Trainer(model, cfg)
     trainer.need_dx = True   # the real model trains its embeddings: gradients flow into the encoder inputs
@@ -271,7 +274,8 @@ def main():
         dtype=args.precision, data="synthetic",
         config=dict(workload=("BASELINE.json configs[2] train step (fwd+bwd+%s)" % args.optimizer if not args.forward_only
                               else "BASELINE.json configs[1] forward only") + ", shape '%s', %s lengths" % (args.config, args.variant)
-                    + (", token-id entry (embedding front-end inside the step)" if args.front_end else ""),
+                    + (", token-id entry (embedding front-end inside the step, char_emb_size %d)" % args.char_emb_size
+                       if args.front_end else ""),
                     qa_pairs_per_gpu=spec.N, albums=spec.A, photos=spec.P, text_streams=spec.S, tokens=spec.L, hidden=spec.d,
                     K=L.K, T=L.T, JQ=L.JQ, parallelism="dp%d (QA pairs sharded, flat-gradient all-reduce)" % ws),
         roofline=roof, roofline_attention=roof_att,

@@ -534,12 +534,13 @@ __global__ __launch_bounds__(256) void embed_bwdw_char(EmbArgs a) {
   const fvta_embed_desc& d = a.d;
   const int tid = threadIdx.x, cw = d.cwdim, cd = d.cdim, H = d.height, W = d.W;
   const int c0 = blockIdx.x * EMBW_CS, nc = min(EMBW_CS, cd - c0);
-  float* s_f = s_dyn;                       // [H][CS][cw]
-  float* s_dC = s_f + H * EMBW_CS * cw;     // [VC][CS]
+  const int ldf = cw + 1;                   // odd row length: the 32 channels of a wave read 32 different banks
+  float* s_f = s_dyn;                       // [H][CS][ldf]
+  float* s_dC = s_f + H * EMBW_CS * ldf;    // [VC][CS]
   float* s_dE = s_dC + d.VC * EMBW_CS;      // [16][CS]
   for (int i = tid; i < H * EMBW_CS * cw; i += 256) {
     const int f = i % cw, cl = (i / cw) % EMBW_CS, kh = i / (cw * EMBW_CS);
-    s_f[i] = cl < nc ? a.filt[(size_t)(kh * cd + c0 + cl) * cw + f] : 0.f;
+    s_f[(kh * EMBW_CS + cl) * ldf + f] = cl < nc ? a.filt[(size_t)(kh * cd + c0 + cl) * cw + f] : 0.f;
   }
   for (int i = tid; i < d.VC * EMBW_CS; i += 256) s_dC[i] = 0.f;
   const int cl = tid & (EMBW_CS - 1), pg = tid >> 5;  // 8 position groups: positions pg and pg + 8
@@ -575,13 +576,17 @@ __global__ __launch_bounds__(256) void embed_bwdw_char(EmbArgs a) {
     if (tid < 16) s_ch[tid] = ch_c;
     __syncthreads();
     float v0 = 0.f, v1 = 0.f;  // d E[pg][c], d E[pg + 8][c]
-    for (int f = 0; f < cw; ++f) {
+    // branch-free (clamped row, zero weight) so that the loop unrolls and its LDS reads pipeline: with the test on g
+    // and on the window offsets as branches every iteration exposed ~4 dependent LDS latencies (400 cycles)
+    const float* fa = s_f + cl * ldf;
+#pragma unroll 4
+    for (int f = 0; f < cw; ++f) {  // filters in index order: d E has ONE summation order
       const float g = s_g[f];
-      if (g == 0.f) continue;  // (uniform: s_g[f] is a broadcast read)
       const int p = s_p[f];
-      const int ka = pg - p, kb = pg + 8 - p;
-      if (ka >= 0 && ka < H) v0 += g * s_f[(ka * EMBW_CS + cl) * cw + f];
-      if (kb >= 0 && kb < H) v1 += g * s_f[(kb * EMBW_CS + cl) * cw + f];
+      const int ka = pg - p, kb = ka + 8;
+      const bool oa = (unsigned)ka < (unsigned)H, ob = (unsigned)kb < (unsigned)H;
+      v0 += (oa ? g : 0.f) * fa[(oa ? ka : 0) * (EMBW_CS * ldf) + f];
+      v1 += (ob ? g : 0.f) * fa[(ob ? kb : 0) * (EMBW_CS * ldf) + f];
     }
     s_dE[pg * EMBW_CS + cl] = v0;
     s_dE[(pg + 8) * EMBW_CS + cl] = v1;
@@ -860,7 +865,7 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
   a.char_emb = char_emb; a.filt = filt; a.argpos = const_cast<uint8_t*>(argpos);
   a.dx = dx; a.d_word_emb = d_word_emb; a.slab = (float*)workspace;
   int blocks;
-  const size_t charw_lds = ((size_t)d->height * EMBW_CS * d->cwdim + (size_t)d->VC * EMBW_CS + 16 * EMBW_CS) * sizeof(float);
+  const size_t charw_lds = ((size_t)d->height * EMBW_CS * (d->cwdim + 1) + (size_t)d->VC * EMBW_CS + 16 * EMBW_CS) * sizeof(float);
   if (embed_is_big(d) && embed_mfma_ok(d) && charw_lds <= 150 * 1024) {
     blocks = d->ntok < EMB_BIG_BLOCKS ? d->ntok : EMB_BIG_BLOCKS;
     const int KC = d->height * d->cdim;
