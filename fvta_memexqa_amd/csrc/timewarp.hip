@@ -157,18 +157,27 @@ __global__ __launch_bounds__(256) void tw_apply_bwd_kernel(fvta_timewarp_desc d,
   }
 }
 
-// dv[c] = sum over workgroups; dsq[n] = K sum_t dz ; ds0 = K sum dz.   grid ceil((w + N)/256)
-__global__ void tw_reduce_kernel(fvta_timewarp_desc d, TwWork wk) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+// dv[c] = sum over workgroups; dsq[n] = K sum_t dz.  grid w + N, 256 threads: one output per block, strided partial
+// sums folded by a fixed tree (a single thread walking all partials was a ~1000-deep chain of L2 latencies)
+__global__ __launch_bounds__(256) void tw_reduce_kernel(fvta_timewarp_desc d, TwWork wk) {
+  __shared__ float s_red[256];
+  const int o = blockIdx.x, tid = threadIdx.x;
+  float acc = 0.f;
   if (o < d.w) {
-    float acc = 0.f;
-    for (int g = 0; g < wk.nwg; ++g) acc += wk.dvp[(size_t)g * d.w + o];
-    wk.dv[o] = acc;
-  } else if (o < d.w + d.N) {
+    for (int g = tid; g < wk.nwg; g += 256) acc += wk.dvp[(size_t)g * d.w + o];
+  } else {
     const int n = o - d.w;
-    float acc = 0.f;
-    for (int t = 0; t < d.T; ++t) acc += wk.dz[(size_t)n * d.T + t];
-    wk.dsq[n] = acc * (float)d.K;
+    for (int t = tid; t < d.T; t += 256) acc += wk.dz[(size_t)n * d.T + t];
+  }
+  s_red[tid] = acc;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) s_red[tid] += s_red[tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (o < d.w) wk.dv[o] = s_red[0];
+    else wk.dsq[o - d.w] = s_red[0] * (float)d.K;
   }
 }
 
@@ -253,7 +262,7 @@ extern "C" int fvta_timewarp_bwd(const fvta_timewarp_desc* d, const float* hall,
   hipLaunchKernelGGL(tw_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *d, hall, d_warp, wk.dsk);
   hipLaunchKernelGGL(tw_dz_kernel, dim3((d->N * d->T + 255) / 256), dim3(256), 0, s, *d, win, c_saved, wk);
   hipLaunchKernelGGL(tw_apply_bwd_kernel, dim3(wk.nwg), dim3(256), 0, s, *d, win, hall, d_warp, c_saved, wk, d_hall);
-  hipLaunchKernelGGL(tw_reduce_kernel, dim3((d->w + d->N + 255) / 256), dim3(256), 0, s, *d, wk);
+  hipLaunchKernelGGL(tw_reduce_kernel, dim3(d->w + d->N), dim3(256), 0, s, *d, wk);
   hipLaunchKernelGGL(tw_param_bwd_kernel, dim3(d->w), dim3(256), 0, s, *d, WH_W, WH_b, WC_W, lq, wk, d_lq, dWH_W, dWH_b,
                      dWC_W, dWC_b);
   FVTA_CHECK_LAUNCH("timewarp_bwd");
