@@ -21,6 +21,8 @@ __device__ __forceinline__ f32x4 ld4b(const float* p) { return *reinterpret_cast
 
 constexpr int BWD_CHMAX = 1024;  // rows per backward workgroup chunk (LDS sort capacity)
 
+static inline __host__ __device__ int attn_bwd_jz(const AttnShape& s) { return (s.JQ + 7) / 8; }
+
 struct AttnBwdWork {
   float* coef;   // [N,K]  r / L
   float* gu;     // [N,K]  g . u[k]
@@ -28,7 +30,7 @@ struct AttnBwdWork {
   float* slabs;  // [N*ng][bsplit][RH][JP][w]   dQs partials (ng = groups of gk consecutive k per n)
   float* dctp;   // [N*ng][bsplit][RH][JP]      d ct partials
   float* rowp;   // [N*ng][bsplit][RH][2][w]    d Rh, d R2 partials
-  float* pvec;   // [N][5][w]                  per-n parameter-vector partials
+  float* pvec;   // [N * JZ][5][w]             parameter-vector partials per n and group of 8 question positions
   float* dctn;   // [N][JP]
   size_t bytes;
   size_t slab_bytes;
@@ -45,7 +47,7 @@ static AttnBwdWork bwd_work_view(const AttnShape& s, void* p) {
   v.coef = c.take<float>(nk);
   v.gu = c.take<float>(nk);
   v.dss = c.take<float>(nk);
-  v.pvec = c.take<float>((size_t)s.N * VEC_COUNT * s.w);
+  v.pvec = c.take<float>((size_t)s.N * attn_bwd_jz(s) * VEC_COUNT * s.w);
   v.dctn = c.take<float>((size_t)s.N * s.JP);
   const size_t before = c.off;
   const size_t ngr = (size_t)s.N * s.ng;
@@ -382,7 +384,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   }
 }
 
-// ---- fold slabs per n: d_hq and per-n parameter partials.  grid (N, ceil(w/256))
+// ---- fold slabs per n: d_hq and per-n parameter partials.  grid (N, ceil(w/256), ceil(JQ/8)): a block takes 8 question
+// positions (one thread per channel walking all JQ x nslot slab rows was a 500-deep chain of loads on 256 blocks)
 __global__ __launch_bounds__(256) void attn_bwd_reduce_q_kernel(AttnShape s, AttnSaved sv, AttnBwdWork wk, int RH,
                                                                 const float* __restrict__ hq,
                                                                 float* __restrict__ d_hq, int accumulate) {
@@ -395,13 +398,14 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_q_kernel(AttnShape s, Att
     float acc = 0.f;
     for (int sl = 0; sl < nslot; ++sl) acc += wk.dctp[(slot0 + sl) * JP + threadIdx.x];
     s_dct[threadIdx.x] = acc;
-    if (blockIdx.y == 0) wk.dctn[(size_t)n * JP + threadIdx.x] = acc;
+    if (blockIdx.y == 0 && blockIdx.z == 0) wk.dctn[(size_t)n * JP + threadIdx.x] = acc;
   }
   __syncthreads();
   if (c >= w) return;
   const float U = sv.vecs[VEC_U * w + c], Cq = sv.vecs[VEC_CQ * w + c], C2 = sv.vecs[VEC_C2 * w + c];
   float pU = 0.f, pCq = 0.f, pC2 = 0.f;
-  for (int j = 0; j < JQ; ++j) {
+  const int jz = blockIdx.z, j_lo = jz * 8, j_hi = min(JQ, j_lo + 8);
+  for (int j = j_lo; j < j_hi; ++j) {
     float dQ = 0.f;
     for (int sl = 0; sl < nslot; ++sl) dQ += wk.slabs[((slot0 + sl) * JP + j) * w + c];
     const float qv = hq[((size_t)n * JQ + j) * w + c];
@@ -414,11 +418,12 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_q_kernel(AttnShape s, Att
     pC2 += dct * qv * qv;
   }
   float pRh = 0.f, pR2 = 0.f;
-  for (int sl = 0; sl < nslot; ++sl) {
-    pRh += wk.rowp[(slot0 + sl) * 2 * w + c];
-    pR2 += wk.rowp[(slot0 + sl) * 2 * w + w + c];
-  }
-  float* pv = wk.pvec + (size_t)n * VEC_COUNT * w;
+  if (jz == 0)
+    for (int sl = 0; sl < nslot; ++sl) {
+      pRh += wk.rowp[(slot0 + sl) * 2 * w + c];
+      pR2 += wk.rowp[(slot0 + sl) * 2 * w + w + c];
+    }
+  float* pv = wk.pvec + ((size_t)n * gridDim.z + jz) * VEC_COUNT * w;
   pv[VEC_U * w + c] = pU;
   pv[VEC_RH * w + c] = pRh;
   pv[VEC_R2 * w + c] = pR2;
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(256) void attn_bwd_params_kernel(AttnShape s, AttnB
   const int cl = tid & 63, grp = tid >> 6, c = blockIdx.x * 64 + cl;
   float v[VEC_COUNT] = {0, 0, 0, 0, 0};
   if (c < w)
-    for (int n = grp; n < s.N; n += 4)
+    for (int n = grp; n < s.N * attn_bwd_jz(s); n += 4)   // rows = (n, group of question positions)
 #pragma unroll
       for (int k = 0; k < VEC_COUNT; ++k) v[k] += wk.pvec[((size_t)n * VEC_COUNT + k) * w + c];
 #pragma unroll
@@ -568,7 +573,7 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
   if (s.simi == 4) {
     hipLaunchKernelGGL(attn_bwd_cosine_q_kernel, dim3(s.N * s.JQ), dim3(256), 0, stream, s, wk, RH, hq, d_hq, accumulate);
   } else {
-    hipLaunchKernelGGL(attn_bwd_reduce_q_kernel, dim3(s.N, (s.w + 255) / 256), dim3(256), 0, stream, s, sv, wk, RH, hq,
+    hipLaunchKernelGGL(attn_bwd_reduce_q_kernel, dim3(s.N, (s.w + 255) / 256, attn_bwd_jz(s)), dim3(256), 0, stream, s, sv, wk, RH, hq,
                        d_hq, accumulate);
     hipLaunchKernelGGL(attn_bwd_params_kernel, dim3((s.w + 63) / 64 + 1), dim3(256), 0, stream, s, wk, dW, db);
   }
