@@ -52,15 +52,18 @@ void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int in, int
   hipLaunchKernelGGL(cvt_weights_kernel, dim3(4 * d / 32, (in_i + d) / 32), dim3(256), 0, s, W, wt, wb, in, in_i, d);
 }
 
-// ---- input shadow: xs[dir][t][i][:] for every active (dir, t, i).  grid (ceil(B/4), J, 2) -------
+// ---- input shadow: xs[dir][t][i][:] for every active (dir, t, i).  grid (ceil(B/4), J) ----------
+// One wave per (sorted row i, position pos): the row is read ONCE and written to both places it is needed -- step pos
+// of the forward direction and step len - 1 - pos of the backward direction (reverse_sequence).
 __global__ void cvt_x_kernel(PlanView pv, const float* __restrict__ x, bf16_t* __restrict__ xs, int B, int J, int in,
                              int in_i) {
-  const int t = blockIdx.y, dir = blockIdx.z;
+  const int pos = blockIdx.y;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= pv.nactive[t]) return;
-  const size_t idx = ((size_t)dir * J + t) * B + i;
-  const float* src = x + pv.xo[idx];
-  bf16_t* dst = xs + idx * in_i;
+  if (i >= pv.nactive[pos]) return;  // len_i <= pos
+  const int len = pv.len[pv.order[i]];
+  const float* src = x + pv.xo[(size_t)pos * B + i];  // forward direction, step pos = position pos
+  bf16_t* dst_fw = xs + ((size_t)pos * B + i) * in_i;
+  bf16_t* dst_bw = xs + (((size_t)J + (len - 1 - pos)) * B + i) * in_i;
   for (int c = lane * 4; c < in_i; c += 256) {
     bf16x4 o;
 #pragma unroll
@@ -68,12 +71,13 @@ __global__ void cvt_x_kernel(PlanView pv, const float* __restrict__ x, bf16_t* _
       const int k = c + e;
       o[e] = k < in ? (short)f2bf(src[k]) : (k == in ? (short)0x3f80 : (short)0);  // ones column at `in`
     }
-    *reinterpret_cast<bf16x4*>(dst + c) = o;
+    *reinterpret_cast<bf16x4*>(dst_fw + c) = o;
+    *reinterpret_cast<bf16x4*>(dst_bw + c) = o;
   }
 }
 
 void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, int J, int in, int in_i, hipStream_t s) {
-  hipLaunchKernelGGL(cvt_x_kernel, dim3((B + 3) / 4, J, 2), dim3(256), 0, s, pv, x, xs, B, J, in, in_i);
+  hipLaunchKernelGGL(cvt_x_kernel, dim3((B + 3) / 4, J), dim3(256), 0, s, pv, x, xs, B, J, in, in_i);
 }
 
 __device__ unsigned long long g_lstm_stamps[512];  // diagnostics (FVTA_DEBUG_SKIP & 32768)
