@@ -74,6 +74,7 @@ _SIGS = {
     "fvta_adam_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_int32, c_float, P]),
     "fvta_weight_decay": (c_int, [P, P, c_int64, c_float, P, P]),
     "fvta_probe_hbm_read": (c_int, [P, ctypes.c_size_t, P, P]),
+    "fvta_probe_spin": (c_int, [c_int64, P]),
     "fvta_softmax_fwd": (c_int, [P, P, c_int64, c_int32, P]),
     "fvta_softsel_fwd": (c_int, [P, P, P, c_int64, c_int32, c_int32, P]),
     "fvta_exp_mask": (c_int, [P, P, P, c_int64, P]),

@@ -108,7 +108,20 @@ __global__ __launch_bounds__(256) void hbm_read_probe_kernel(const probe_f32x4* 
   for (; i < n16; i += stride) acc += p[i];
   if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345678e30f) sink[0] = acc[0];  // never true: keeps the loads alive
 }
+// one wave that waits `ticks` of the 100 MHz wall clock: two of these on two streams finish in one wait when the
+// streams own different hardware queues and in two when they share one (fvta_probe_spin)
+__global__ void spin_probe_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 }  // namespace fvta
+
+extern "C" int fvta_probe_spin(int64_t microseconds, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(microseconds > 0 && microseconds <= 100000, "probe_spin: 1..100000 us");
+  hipLaunchKernelGGL(fvta::spin_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
+  FVTA_CHECK_LAUNCH("spin_probe");
+  return FVTA_OK;
+}
 
 extern "C" int fvta_probe_hbm_read(const void* buf, size_t bytes, float* sink, fvta_stream_t stream) {
   FVTA_CHECK_ARG(buf && sink && bytes >= 16, "probe_hbm_read: bad arguments");

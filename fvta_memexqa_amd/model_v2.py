@@ -150,7 +150,9 @@ class Model:
         self.att_logits = self.q_att_logits = self.hall = None
         self._layouts = {}
         self.max_layouts = int(_cfg(config, "max_cached_layouts", 4))
-        self._side = torch.cuda.Stream(device=self.dev)
+        # the side stream (photo cell, small launches that run beside the text cell) must own a hardware queue of
+        # its own; which torch stream does is measured once here against the current stream (ops.pick_side_stream)
+        self._side, self.side_stream_ratio = ops.pick_side_stream(self.dev)
 
         dp, wp = self.dp, self.wp
         F = {1: 3 * wp, 2: 2 * wp, 3: 4 * wp, 4: 0}[self.simi]

@@ -28,6 +28,51 @@ def _bytes(n, dev):
     return torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
 
 
+# ------------------------------------------------------------------ side stream
+def concurrency_ratio(main, cand, spin_us=400, repeats=3):
+    """time(one spin wave on each of two streams) / time(one spin wave on `main`): about 1 when the streams run
+    concurrently, about 2 when HIP mapped both onto the same hardware queue."""
+    import time
+    lib = _lib.load()
+
+    def run(streams):
+        best = float("inf")
+        for _ in range(repeats):
+            for s in streams:
+                s.synchronize()
+            t0 = time.perf_counter()
+            for s in streams:
+                check(lib.fvta_probe_spin(spin_us, ctypes.c_void_p(s.cuda_stream)), "fvta_probe_spin")
+            for s in streams:
+                s.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    run([main, cand])                       # first use creates the hardware queues
+    return run([main, cand]) / run([main])
+
+
+def pick_side_stream(dev, main=None, candidates=8):
+    """A HIP stream that really runs beside `main`.  HIP maps streams onto a small pool of hardware queues
+    (GPU_MAX_HW_QUEUES, 4 by default) and two streams on one queue serialise; which streams collide depends on how
+    many were created before -- an RCCL communicator created ahead of the model moved the side stream onto the main
+    stream's queue and the training step lost the photo-cell overlap (21.9 ms instead of 15.7 ms,
+    tools/dist_probe3.py).  So the choice is measured: candidates are tried in turn with fvta_probe_spin and the
+    first one that overlaps with `main` wins.  Rejected candidates stay referenced until the search ends so that the
+    next one is mapped to another queue."""
+    main = main if main is not None else torch.cuda.current_stream(dev)
+    tried, best = [], None
+    for _ in range(candidates):
+        cand = torch.cuda.Stream(device=dev)
+        r = concurrency_ratio(main, cand)
+        tried.append(cand)
+        if best is None or r < best[0]:
+            best = (r, cand)
+        if r < 1.4:
+            break
+    return best[1], best[0]
+
+
 # ------------------------------------------------------------------ test hook
 def test_gemm(A, B, layout, precision=F32):
     lib = _lib.load()

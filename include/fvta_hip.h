@@ -325,6 +325,10 @@ int fvta_profile_collect(int32_t id, double* total_ms, int64_t* launches);
 /* Measurement hook (bench.py, SURVEY 8d "achievable peak"): one read-only, fully coalesced, non-temporal pass over
  * `bytes` of device memory; the caller times it.  Not part of the reference surface. */
 int fvta_probe_hbm_read(const void* buf, size_t bytes, float* sink, fvta_stream_t stream);
+/* Measurement hook (Model side-stream selection): one wave that occupies `stream` for `microseconds` of the 100 MHz
+ * wall clock.  Two of them on two streams take one wait if the streams run concurrently (separate hardware queues)
+ * and two if HIP mapped both streams onto one queue.  Not part of the reference surface. */
+int fvta_probe_spin(int64_t microseconds, fvta_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -279,3 +279,17 @@ def test_weight_decay_matches_oracle(token):
             continue
         exp = p64[k].grad.numpy()
         _close(np.asarray(grads[k]).reshape(exp.shape), exp, rtol=2e-4, atol=2e-6, msg="grad " + k)
+
+
+@pytest.mark.gpu
+def test_side_stream_runs_beside_the_main_stream():
+    """The photo cell's side stream is chosen by measurement (ops.pick_side_stream): two spin waves, one per
+    stream, must take about one wait, and a stream paired with itself about two."""
+    import torch
+    from fvta_memexqa_amd import ops
+    dev = ops.require_gpu()
+    main = torch.cuda.current_stream(dev)
+    side, ratio = ops.pick_side_stream(dev)
+    assert side.cuda_stream != main.cuda_stream
+    assert ratio < 1.4, ratio
+    assert ops.concurrency_ratio(main, main) > 1.6          # the same queue serialises: the probe can tell
