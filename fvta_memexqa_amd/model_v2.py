@@ -300,6 +300,48 @@ class Model:
             out[name] = t.numpy()
         return out
 
+    N_TW_WINDOW = "time_warp/time_warp_C/time_warp_window_t"            # model_v2.py:334
+
+    def save_weights(self, weights_path):
+        """main.py:578-588 (`--is_save_weights`): every trainable variable under its TF name ("<scope>/<name>:0",
+        scope = "model_<modelname>", model_v2.py:15) in `weights.npz`, plus the `all.txt` name/shape listing."""
+        import os
+        os.makedirs(weights_path, exist_ok=True)
+        out = {"%s/%s:0" % (self.scope, k): v for k, v in self.get_weights().items()}
+        if self.use_time_warp and self.warp_type == 5:
+            out["%s/%s:0" % (self.scope, self.N_TW_WINDOW)] = np.float32(self.window_t)
+        with open(os.path.join(weights_path, "all.txt"), "w") as f:
+            for k, v in out.items():
+                f.writelines("%s %s\n" % (k, str(tuple(int(x) for x in np.shape(v)))))
+        np.savez(os.path.join(weights_path, "weights.npz"), **out)
+        return os.path.join(weights_path, "weights.npz")
+
+    def load_weights(self, path):
+        """Inverse of save_weights: `path` is the weights directory or the .npz itself.  Keys may carry any
+        "<scope>/" prefix and the ":0" suffix; a variable of this model that the file lacks is an error, like the
+        reference's restore by variable name (main.py:640-665)."""
+        import os
+        if os.path.isdir(path):
+            path = os.path.join(path, "weights.npz")
+        if not os.path.exists(path):
+            raise Exception("Model not exists")                         # main.py:665
+        known = list(self.params.specs) + [self.N_TW_WINDOW]
+        got = {}
+        with np.load(path) as z:
+            for key in z.files:
+                k = key[:-2] if key.endswith(":0") else key
+                for name in known:
+                    if k == name or k.endswith("/" + name):
+                        got[name] = z[key]
+                        break
+        missing = [n for n in self.params.specs if n not in got]
+        if missing:
+            raise KeyError("weights file %s lacks %s" % (path, ", ".join(missing)))
+        if self.N_TW_WINDOW in got:
+            self.window_t = float(got.pop(self.N_TW_WINDOW))
+            self._layouts.clear()                                       # the window is baked into the warp descriptors
+        self.set_weights(got)
+
     def init_parameters(self, seed=42):
         """Reference initialisers: linear W ~ truncated_normal(0.1), b = 0
         (model_v2.py:88-89); LSTM kernels Glorot-uniform, zero bias [TF default]."""

@@ -293,3 +293,31 @@ def test_side_stream_runs_beside_the_main_stream():
     assert side.cuda_stream != main.cuda_stream
     assert ratio < 1.4, ratio
     assert ops.concurrency_ratio(main, main) > 1.6          # the same queue serialises: the probe can tell
+
+
+@pytest.mark.gpu
+def test_weights_npz_round_trip(tmp_path):
+    """main.py:578-588 layout: TF variable names as keys, reference shapes; load restores them bit for bit."""
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import SynthSpec
+    spec = SynthSpec(N=2, A=1, P=3, S=2, L=4, d=20, dense=False, simiMatrix=2, add_tanh=True, use_question_att=True,
+                     text_in=12, img_in=8)
+    cfg = dict(spec.cfg(), use_time_warp=True, warp_type=5, window_t=2.3)
+    a = Model(cfg, scope="model_fvta", text_in=12, img_in=8)
+    a.init_parameters(seed=3)
+    f = a.save_weights(str(tmp_path / "w"))
+    z = np.load(f)
+    assert "model_fvta/attention/all/att_logits/W:0" in z.files
+    assert z["model_fvta/reader/text/utext/fw/basic_lstm_cell/kernel:0"].shape == (12 + 20, 80)
+    assert z["model_fvta/attention/all/att_logits/W:0"].shape == (80, 1)          # simiMatrix 2: [h*q, (h-q)^2], w = 40
+    assert abs(float(z["model_fvta/time_warp/time_warp_C/time_warp_window_t:0"]) - 2.3) < 1e-6
+    lines = open(tmp_path / "w" / "all.txt").read().splitlines()
+    assert "model_fvta/output/choicelogits/b:0 (1,)" in lines and "model_fvta/attention/all/att_logits/W:0 (80, 1)" in lines
+    b = Model(dict(cfg, window_t=3.0), scope="other", text_in=12, img_in=8)
+    b.init_parameters(seed=9)
+    b.load_weights(str(tmp_path / "w"))
+    wa, wb = a.get_weights(), b.get_weights()
+    assert set(wa) == set(wb) and all(np.array_equal(wa[k], wb[k]) for k in wa)
+    assert abs(b.window_t - 2.3) < 1e-6
+    with pytest.raises(Exception, match="Model not exists"):
+        b.load_weights(str(tmp_path / "nope"))
