@@ -200,7 +200,8 @@ def main():
             log("hbm probe failed: %r" % (exc,))
 
     prof = {name: collect(pid) for name, pid in [("lstm_step_fwd", 1), ("lstm_step_bwd", 2), ("lstm_dw", 3),
-                                                 ("attn_fwd_main", 4), ("attn_bwd_main", 5)]}
+                                                 ("attn_fwd_main", 4), ("attn_bwd_main", 5),
+                                                 ("lstm_step_fwd_photo_cell", 17)]}
     if rank != 0:
         dist.shutdown()
         return
@@ -228,6 +229,13 @@ def main():
                     unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, algorithmic_bytes_per_call=by_text,
                     mfma_tflops=round(tf, 1), mfma_frac=round(tf / peak_tf, 4), launches=n_f,
                     avg_launch_ms=round(ms_f / n_f, 4))
+        # rocprofv3 --stats averages per kernel SYMBOL: the photo cell (side stream, small launches) runs the same
+        # lstm_step_fwd symbol, so its launches are reported too -- the all-launch mean is the figure to hold against
+        # the profiler's AverageNs (profiles/README.md)
+        ms_p, n_p = prof["lstm_step_fwd_photo_cell"]
+        if n_p:
+            roof.update(launches_photo_cell=n_p, avg_launch_ms_photo_cell=round(ms_p / n_p, 4),
+                        avg_launch_ms_all_launches=round((ms_f + ms_p) / (n_f + n_p), 4))
         if args.precision == "f32":   # exact-fp32 MFMA: 64 flop/clk/SIMD -- the matrix pipe bounds this engine, not HBM
             roof.update(bound="mfma", achieved=round(tf, 1), peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=round(tf / peak_tf, 4),
                         hbm_gbs=round(gbs, 1))
