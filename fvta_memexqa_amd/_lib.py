@@ -39,7 +39,7 @@ class ImgTransDesc(Structure):
 
 
 class ScorerDesc(Structure):
-    _fields_ = [(n, c_int32) for n in ("N", "C", "w", "use_eu_output", "add_tanh")]
+    _fields_ = [(n, c_int32) for n in ("N", "C", "w", "use_eu_output", "add_tanh", "xent_grad")]
 
 
 P = c_void_p

@@ -67,8 +67,15 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(int N, int C, const float*
 
 __device__ __forceinline__ float dlogit_of(const fvta_scorer_desc& d, int n, int c, const float* logits,
                                            const float* yp, const uint8_t* y, float scale) {
-  float ysum = 0.f;
-  for (int k = 0; k < d.C; ++k) ysum += y[n * d.C + k] ? 1.f : 0.f;
+  // TF-1's SoftmaxCrossEntropyWithLogits kernel hands back `softmax - labels` as its backprop output whatever the
+  // labels sum to [TF-internal]; the gradient of -sum(y log softmax) proper is `softmax * sum(y) - y`.  They differ
+  // on rows whose labels are all False: the padded rows of a short last batch (model_v2.py:1270) -- the reference
+  // pushes softmax/N into the scorer from those rows.  xent_grad 0 (default) = the reference's behaviour.
+  float ysum = 1.f;
+  if (d.xent_grad == 1) {
+    ysum = 0.f;
+    for (int k = 0; k < d.C; ++k) ysum += y[n * d.C + k] ? 1.f : 0.f;
+  }
   float dl = scale * (yp[n * d.C + c] * ysum - (y[n * d.C + c] ? 1.f : 0.f));
   if (d.use_eu_output && d.add_tanh) {
     const float l = logits[n * d.C + c];
@@ -162,6 +169,7 @@ using namespace fvta;
 
 static int check_scorer(const fvta_scorer_desc* d) {
   FVTA_CHECK_ARG(d && d->N > 0 && d->C > 0 && d->C <= 64 && d->w > 0, "scorer: bad descriptor");
+  FVTA_CHECK_ARG(d->xent_grad == 0 || d->xent_grad == 1, "scorer: xent_grad must be 0 (TF kernel) or 1 (mathematical)");
   return FVTA_OK;
 }
 

@@ -110,6 +110,9 @@ class Model:
         self.share_fw_bw = bool(_cfg(config, "share_fw_bw", True))
         self.precision = {"f32": F32, "bf16": BF16}[_cfg(config, "precision", "f32")]
         self.wd = float(_cfg(config, "wd", None) or 0.0)                # --wd (main.py:105); None / 0.0: no l2 terms
+        # d logits of softmax_cross_entropy_with_logits (model_v2.py:1088): True = what TF-1's kernel returns,
+        # softmax - labels on every row, all-False label rows (padded rows of a short batch, :1270) included
+        self.tf_xent_grad = bool(_cfg(config, "tf_xent_grad", True))
         if float(_cfg(config, "keep_prob", 1.0)) != 1.0:
             raise NotImplementedError("LSTM input dropout (--keep_prob < 1) is not built yet")
         self.use_time_warp = bool(_cfg(config, "use_time_warp", False))
@@ -752,7 +755,7 @@ class Model:
             qW = qb = dqW = dqb = None
         dgq, dg1, dgch = ops.scorer_ce_bwd(L.gq, L.g1, L.lch, P.view(self.N_OUT_W), P.view(self.N_OUT_B), L.y, L.logits,
                                            L.yp, loss_scale, P.view(self.N_OUT_W, True), P.view(self.N_OUT_B, True),
-                                           self.use_eu_output, self.add_tanh)
+                                           self.use_eu_output, self.add_tanh, self.tf_xent_grad)
         L.d_arena[L.row_hq:].zero_()   # hq / hchoices gradient rows; the hall rows are written by the attention backward
         d_hall = L.d_arena[:L.row_hq].view(L.N, L.K, L.T, self.wp)
         d_hq = L.d_arena[L.row_hq:L.row_hch].view(L.N, L.JQ, self.wp)

@@ -57,7 +57,7 @@ def pick_side_stream(dev, main=None, candidates=8):
     (GPU_MAX_HW_QUEUES, 4 by default) and two streams on one queue serialise; which streams collide depends on how
     many were created before -- an RCCL communicator created ahead of the model moved the side stream onto the main
     stream's queue and the training step lost the photo-cell overlap (21.9 ms instead of 15.7 ms,
-    tools/dist_probe3.py).  So the choice is measured: candidates are tried in turn with fvta_probe_spin and the
+    tools/dist_probe.py).  So the choice is measured: candidates are tried in turn with fvta_probe_spin and the
     first one that overlaps with `main` wins.  Rejected candidates stay referenced until the search ends so that the
     next one is mapped to another queue."""
     main = main if main is not None else torch.cuda.current_stream(dev)
@@ -196,7 +196,7 @@ def as_mask_u8(m):
 def scorer_ce_fwd(gq, g1, gch, W, b, y=None, use_eu_output=False, add_tanh=False):
     lib = _lib.load()
     N, C, w = gch.shape
-    desc = ScorerDesc(N, C, w, int(use_eu_output), int(add_tanh))
+    desc = ScorerDesc(N, C, w, int(use_eu_output), int(add_tanh), 0)
     logits = torch.empty(N, C, device=gq.device, dtype=torch.float32)
     yp = torch.empty_like(logits)
     loss = torch.zeros(1, device=gq.device, dtype=torch.float32) if y is not None else None
@@ -205,10 +205,13 @@ def scorer_ce_fwd(gq, g1, gch, W, b, y=None, use_eu_output=False, add_tanh=False
     return logits, yp, loss
 
 
-def scorer_ce_bwd(gq, g1, gch, W, b, y, logits, yp, loss_scale, dW, db, use_eu_output=False, add_tanh=False):
+def scorer_ce_bwd(gq, g1, gch, W, b, y, logits, yp, loss_scale, dW, db, use_eu_output=False, add_tanh=False,
+                  tf_xent_grad=True):
+    """tf_xent_grad: d logits = softmax - labels on every row (TF-1's kernel; all-False label rows still carry
+    gradient); False: the gradient of -sum(y log softmax) proper."""
     lib = _lib.load()
     N, C, w = gch.shape
-    desc = ScorerDesc(N, C, w, int(use_eu_output), int(add_tanh))
+    desc = ScorerDesc(N, C, w, int(use_eu_output), int(add_tanh), 0 if tf_xent_grad else 1)
     dgq, dg1, dgch = torch.empty_like(gq), torch.empty_like(g1), torch.empty_like(gch)
     check(lib.fvta_scorer_ce_bwd(ctypes.byref(desc), ptr(gq), ptr(g1), ptr(gch), ptr(W), ptr(b), ptr(y), ptr(logits),
                                  ptr(yp), float(loss_scale), ptr(dgq), ptr(dg1), ptr(dgch), ptr(dW), ptr(db),

@@ -150,6 +150,10 @@ typedef struct fvta_scorer_desc {
   int32_t N, C, w;
   int32_t use_eu_output; /* model_v2.py:1071-1073 */
   int32_t add_tanh;      /* only with use_eu_output */
+  int32_t xent_grad;     /* backward only.  0: d logits = softmax - labels on EVERY row, what TF-1's
+                          * SoftmaxCrossEntropyWithLogits kernel returns (model_v2.py:1088) -- rows whose labels are all
+                          * False (the padded rows of a short batch, model_v2.py:1270) still push softmax/N into the
+                          * scorer; 1: the gradient of -sum(y log softmax) proper, softmax * sum(y) - y */
 } fvta_scorer_desc;
 
 int fvta_scorer_ce_fwd(const fvta_scorer_desc* d, const float* gq, const float* g1, const float* gch,

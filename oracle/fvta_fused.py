@@ -224,8 +224,30 @@ def scorer(gq, g1, gch, W, b, use_eu_output=False, add_tanh=False):
     return logits, torch.softmax(logits, -1)
 
 
-def softmax_cross_entropy_mean(logits, y):
-    """model_v2.py:1088-1090."""
+class _TfSoftmaxXent(torch.autograd.Function):
+    """[TF-internal] tf.nn.softmax_cross_entropy_with_logits (model_v2.py:1088).  The TF-1 kernel
+    (SoftmaxCrossEntropyWithLogits) emits the per-row loss AND a `backprop` tensor = softmax(logits) - labels; its
+    registered gradient is grad_loss[:, None] * backprop -- labels are not assumed to sum to 1.  For a row whose labels
+    are all False (the padded rows of a short last batch, model_v2.py:1270) the loss is 0 but d logits is softmax, where
+    autograd of -sum(y log softmax) gives 0."""
+
+    @staticmethod
+    def forward(ctx, logits, y):
+        yf = y.to(logits.dtype)
+        ctx.save_for_backward(torch.softmax(logits, -1) - yf)
+        return -(yf * torch.log_softmax(logits, -1)).sum(-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (backprop,) = ctx.saved_tensors
+        return g.unsqueeze(-1) * backprop, None
+
+
+def softmax_cross_entropy_mean(logits, y, tf_grad=True):
+    """model_v2.py:1088-1090: mean over ALL N rows.  tf_grad: gradient of TF-1's kernel (see _TfSoftmaxXent);
+    False: plain autograd of the same value."""
+    if tf_grad:
+        return _TfSoftmaxXent.apply(logits, y).mean()
     return -(y.to(logits.dtype) * torch.log_softmax(logits, -1)).sum(1).mean()
 
 
@@ -302,7 +324,8 @@ def fvta_forward(params, inputs, cfg):
                         cfg.get("use_eu_output", False), cfg.get("add_tanh", False))
     out["logits"], out["yp"] = logits, yp
     if inputs.get("y") is not None:
-        out["loss"] = softmax_cross_entropy_mean(logits, inputs["y"]) + weight_decay_terms(params, cfg)
+        out["loss"] = softmax_cross_entropy_mean(logits, inputs["y"], bool(cfg.get("tf_xent_grad", True))) \
+            + weight_decay_terms(params, cfg)
     return out
 
 

@@ -403,6 +403,16 @@ def softmax_cross_entropy_mean(logits, y):
     return losses.mean()
 
 
+def softmax_cross_entropy_mean_grad(logits, y):
+    """[TF-internal] d(mean loss)/d logits as TF-1 computes it for model_v2.py:1088-1090: the
+    SoftmaxCrossEntropyWithLogits kernel returns backprop = softmax(logits) - labels next to the loss and the op's
+    gradient is grad_loss[:, None] * backprop (no assumption that a row of labels sums to 1); the mean over all N rows
+    contributes 1/N.  A row of all-False labels (padded batch row, model_v2.py:1270) has loss 0 and gradient
+    softmax/N."""
+    y = np.asarray(y).astype(logits.dtype)
+    return (softmax(logits) - y) / logits.shape[0]
+
+
 # ----------------------------------------------------------------------------
 # AttentionGRUCell: attention_gru_cell.py:50-70
 # ----------------------------------------------------------------------------

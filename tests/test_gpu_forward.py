@@ -116,8 +116,10 @@ def test_attention_1d_question_form():
     _close(a.reshape(N, JQ, 1), ref_a, atol=2e-5)
 
 
-@pytest.mark.parametrize("eu,tanh", [(False, False), (True, True)])
-def test_scorer_ce_forward_and_backward(eu, tanh):
+@pytest.mark.parametrize("eu,tanh,tf_grad", [(False, False, True), (True, True, True), (False, False, False)])
+def test_scorer_ce_forward_and_backward(eu, tanh, tf_grad):
+    """tf_grad: TF-1's kernel gradient softmax - labels (the padded last row, labels all False, still carries
+    gradient; the default) vs the mathematical one."""
     from fvta_memexqa_amd import ops
     from oracle import fvta_fused as F
     g = torch.Generator().manual_seed(5)
@@ -130,7 +132,7 @@ def test_scorer_ce_forward_and_backward(eu, tanh):
     y = torch.zeros(N, C, dtype=torch.bool)
     y[torch.arange(N - 1), torch.randint(0, C, (N - 1,), generator=g)] = True   # last row = padded (all False)
     logits, yp = F.scorer(gq, g1, gch, W, b, eu, tanh)
-    loss = F.softmax_cross_entropy_mean(logits, y)
+    loss = F.softmax_cross_entropy_mean(logits, y, tf_grad=tf_grad)
     loss.backward()
     f = lambda t: t.detach().float().cuda().contiguous()
     yd = ops.as_mask_u8(y).cuda()
@@ -141,7 +143,10 @@ def test_scorer_ce_forward_and_backward(eu, tanh):
     assert (yp2.argmax(1).cpu() == yp.argmax(1)).all()
     dW = torch.zeros(W.numel(), device="cuda")
     db = torch.zeros(1, device="cuda")
-    dgq, dg1, dgch = ops.scorer_ce_bwd(f(gq), f(g1), f(gch), f(W).reshape(-1), f(b), yd, l2, yp2, 1.0, dW, db, eu, tanh)
+    dgq, dg1, dgch = ops.scorer_ce_bwd(f(gq), f(g1), f(gch), f(W).reshape(-1), f(b), yd, l2, yp2, 1.0, dW, db, eu, tanh,
+                                       tf_xent_grad=tf_grad)
+    # the padded row: softmax/N through the scorer with TF's gradient, nothing with the mathematical one
+    assert (dgch[N - 1].abs().max().item() > 0) == tf_grad
     _close(dgq, gq.grad, atol=1e-6)
     _close(dg1, g1.grad, atol=1e-6)
     _close(dgch, gch.grad, atol=1e-6)

@@ -137,3 +137,23 @@ def test_optimizer_known_steps():
     np.testing.assert_allclose(au, 0.05 * upd * upd, rtol=1e-12)
     v, m, s = L.adam_step(np.array([1.0]), np.array([2.0]), np.zeros(1), np.zeros(1), 1, lr=0.1)
     np.testing.assert_allclose(v, 1.0 - 0.1 * math.sqrt(0.001) / 0.1 * 0.2 / (math.sqrt(0.004) + 1e-8), rtol=1e-9)
+
+
+def test_tf_softmax_xent_gradient_on_all_false_label_rows():
+    """TF-1's softmax_cross_entropy_with_logits backprop is softmax - labels on every row (model_v2.py:1088):
+    a padded row (labels all False, model_v2.py:1270) has loss 0 but still sends softmax/N into the scorer.  Pins the
+    fused oracle's custom gradient against the literal restatement and against the hand value."""
+    logits = torch.tensor([[0.3, -1.2, 0.8, 0.1], [2.0, 0.0, -1.0, 0.5], [0.0, 0.0, 0.0, 0.0]], dtype=torch.float64)
+    y = torch.tensor([[0, 0, 1, 0], [1, 0, 0, 0], [0, 0, 0, 0]], dtype=torch.bool)   # last row: padded
+    lt = logits.clone().requires_grad_()
+    loss = F.softmax_cross_entropy_mean(lt, y)            # default: TF gradient
+    loss.backward()
+    np.testing.assert_allclose(float(loss), L.softmax_cross_entropy_mean(logits.numpy(), y.numpy()), rtol=1e-12)
+    np.testing.assert_allclose(lt.grad.numpy(), L.softmax_cross_entropy_mean_grad(logits.numpy(), y.numpy()), rtol=1e-12)
+    np.testing.assert_allclose(lt.grad[2].numpy(), np.full(4, 0.25 / 3), rtol=1e-12)    # uniform softmax / N
+    lm = logits.clone().requires_grad_()
+    loss_m = F.softmax_cross_entropy_mean(lm, y, tf_grad=False)
+    loss_m.backward()
+    assert float(loss_m) == float(loss)
+    np.testing.assert_allclose(lm.grad[:2].numpy(), lt.grad[:2].numpy(), rtol=1e-12)   # rows with one label agree
+    assert (lm.grad[2] == 0).all()                                                      # the mathematical form: nothing
