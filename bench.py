@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--optimizer", default="adam", choices=["adam", "adadelta"])
     ap.add_argument("--batch", type=int, default=None, help="QA pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="serial LSTM backward: dx and the weight gradient after the recurrence instead of beside it on a side stream")
     ap.add_argument("--cpu-sample", type=int, default=4, help="QA pairs in the CPU-baseline sample (4: ~10-15 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch-CPU threads of the baseline; 16 is the fastest setting measured on the 2x EPYC 9575F host "
@@ -131,7 +133,7 @@ def main():
         kw["N"] = args.batch
     spec = SynthSpec(**kw)
     cfg = dict(spec.cfg(), batch_size=spec.N, precision=args.precision, optimizer=args.optimizer,
-               init_lr=0.001 if args.optimizer == "adam" else 0.5)
+               init_lr=0.001 if args.optimizer == "adam" else 0.5, overlap_bwd_tails=not args.no_overlap)
     if args.front_end:   # README.MD:144-147 sizes: 100-d GloVe + 100-d char-CNN, 2537-d photo features -> 100
         from fvta_memexqa_amd.synth import make_token_inputs
         cfg.update(word_vocab_size=400, word_emb_size=100, use_char=True, char_vocab_size=100, max_word_size=16,

@@ -51,32 +51,62 @@ __device__ __forceinline__ void wait_vmcnt() {
 //                    2 -> 256 x 256 block tile, 8 waves (4 x 2), 96 KiB (one workgroup per CU).  The wave tile is
 // 64 x 128 either way; the wider block tile re-reads the A operand half as often (the operand DMA runs at the CU's
 // address-unit rate, ~24 B/clk, which a 256 x 128 tile saturates before the matrix pipe).
-template <int WN>
+// TM = MFMA row tiles per wave: 2 -> four wave rows of 64 (the wave tile is 64 x 128, 6 LDS fragments per 8 MFMAs);
+//                             4 -> two wave rows of 128 (wave tile 128 x 128, 8 fragments per 16 MFMAs: a third less
+// LDS read traffic per flop; 256 accumulator registers, so one wave per SIMD with the accumulators in AGPRs).  With
+// WN = 2, TM = 4 the 256 x 256 block tile runs on FOUR waves.
+template <int WN, int TM_ = 2>
 struct TileCfgT {
-  static constexpr int BM = 256, BN = 128 * WN, BK = 32, STAGES = 3, NT = 256 * WN;
+  static constexpr int TM = TM_, WAVES_M = 8 / TM_, NWAVES = WAVES_M * WN;
+  static constexpr int BM = 256, BN = 128 * WN, BK = 32, STAGES = 3, NT = 64 * NWAVES;
   static constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;  // per stage
   static constexpr int STAGE_ELEMS = A_ELEMS + B_ELEMS;
   static constexpr int LDS_BYTES = STAGES * STAGE_ELEMS * 2;        // 73,728 (WN = 1)
-  static constexpr int A_GLDS = A_ELEMS * 2 / 1024 / (4 * WN);      // wave-instructions per wave per tile: 4 / 2
-  static constexpr int B_GLDS = B_ELEMS * 2 / 1024 / (4 * WN);      // 2 / 2
+  static constexpr int A_GLDS = A_ELEMS * 2 / 1024 / NWAVES;        // wave-instructions per wave per tile
+  static constexpr int B_GLDS = B_ELEMS * 2 / 1024 / NWAVES;
 };
 typedef TileCfgT<1> TileCfg;
 
 // ---- accumulators + fragment reads -------------------------------------------------------------
-template <int WN>
+template <int WN, int TM_ = 2>
 struct MmaBT {
-  typedef TileCfgT<WN> Cfg;
-  static constexpr int TM = 2, TN = 4, WAVES_M = 4, WAVES_N = 1, BM = Cfg::BM, BN = Cfg::BN;  // WAVES_N: per wave column
+  typedef TileCfgT<WN, TM_> Cfg;
+  static constexpr int TM = TM_, TN = 4, WAVES_M = Cfg::WAVES_M, WAVES_N = 1, BM = Cfg::BM, BN = Cfg::BN;  // WAVES_N: per wave column
+  static constexpr int WROWS = 32 * TM;  // rows of a wave tile
   f32x16 acc[TM][TN];
-  int wave_all, wave, wn, lane, l31, hf;  // wave = row of the 4 x WN wave grid (the M position), wn = its column
+  int wave_all, wave, wn, lane, l31, hf;  // wave = row of the WAVES_M x WN wave grid (the M position), wn = its column
+
+  // TM = 4: 256 accumulator registers.  Left to itself the compiler keeps them in VGPRs across the loop and shuttles
+  // them through AGPRs around every MFMA (~440 v_accvgpr moves per k-tile); the asm form pins the accumulators to
+  // AGPRs ("+a"), where the matrix pipe reads and writes them directly.  A/B fragments stay compiler-scheduled VGPRs.
+  static __device__ __forceinline__ void mfma(f32x16& c, bf16x8_t a, bf16x8_t b) {
+#ifdef FVTA_MFMA_ASM
+    if constexpr (TM == 4)
+      asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else
+#endif
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  // the asm MFMAs are opaque to the hazard recogniser: before the accumulators are read by VALU code the last
+  // MFMA's passes must have retired (XDL write -> VALU read, up to 18 wait states for a 16-pass MFMA)
+  static __device__ __forceinline__ void drain() {
+#ifdef FVTA_MFMA_ASM
+    if constexpr (TM == 4) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+  }
 
   __device__ __forceinline__ void init(int tid) {
     wave_all = tid >> 6;
-    wave = wave_all & 3;
-    wn = wave_all >> 2;
+    wave = wave_all % WAVES_M;
+    wn = wave_all / WAVES_M;
     lane = tid & 63;
     l31 = lane & 31;
     hf = lane >> 5;
+#ifndef FVTA_MFMA_ASM
+    // an explicit AGPR operand keeps the compiler from marking the kernel "amdgpu-no-agpr", under which it selects
+    // the VGPR-destination MFMA forms and uses the AGPRs as spill space only
+    if constexpr (TM == 4) asm volatile("; accumulators live in AGPRs %0" ::"a"(0));
+#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -93,7 +123,7 @@ struct MmaBT {
       const int c = 2 * ks + hf;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int r = wave * 64 + i * 32 + l31;
+        const int r = wave * WROWS + i * 32 + l31;
         a[i].f = *reinterpret_cast<const f32x4*>(As + r * 32 + ((c ^ ((r >> 2) & 3)) << 3));
       }
 #pragma unroll
@@ -105,7 +135,7 @@ struct MmaBT {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i].b, b[j].b, acc[i][j], 0, 0, 0);
+          mfma(acc[i][j], a[i].b, b[j].b);
     }
   }
 
@@ -135,17 +165,17 @@ struct MmaBT {
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8_t a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = tr_frag<BM>(As, ks * 16, wave * 64 + i * 32);
+      for (int i = 0; i < TM; ++i) a[i] = tr_frag<BM>(As, ks * 16, wave * WROWS + i * 32);
 #pragma unroll
       for (int j = 0; j < TN; ++j) b[j] = tr_frag<BN>(Bs, ks * 16, wn * 128 + j * 32);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) mfma(acc[i][j], a[i], b[j]);
     }
   }
 
-  __device__ __forceinline__ int row_of(int i, int r) const { return wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf; }
+  __device__ __forceinline__ int row_of(int i, int r) const { return wave * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf; }
   __device__ __forceinline__ int col_of(int j) const { return wn * 128 + j * 32 + l31; }
 };
 typedef MmaBT<1> MmaB;
@@ -207,6 +237,40 @@ __device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntile
   typedef typename Mma::Cfg TileCfg;
   auto a_stage = [&](int t) { return smem + (t % TileCfg::STAGES) * TileCfg::STAGE_ELEMS; };
   if (ntiles <= 0) return;
+  if constexpr (Mma::TM == 4) {
+    // the same pipeline with a single-block steady-state loop and the last two tiles peeled: with 256 accumulator
+    // registers the loop-carried values must stay in AGPRs, which the compiler manages only for a plain loop body
+    auto compute = [&](int t) {
+      const bf16_t* As = a_stage(t);
+      if (KMAJOR)
+        mma.compute_kmajor(As, As + TileCfg::A_ELEMS);
+      else
+        mma.compute_rows(As, As + TileCfg::A_ELEMS);
+    };
+    issue(0, a_stage(0), a_stage(0) + TileCfg::A_ELEMS);
+    if (ntiles > 1) issue(1, a_stage(1), a_stage(1) + TileCfg::A_ELEMS);
+    int t = 0;
+    for (; t + 2 < ntiles; ++t) {
+      wait_vmcnt<TileCfg::A_GLDS + TileCfg::B_GLDS>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue(t + 2, a_stage(t + 2), a_stage(t + 2) + TileCfg::A_ELEMS);
+      compute(t);
+    }
+    if (t + 1 < ntiles) {
+      wait_vmcnt<TileCfg::A_GLDS + TileCfg::B_GLDS>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      compute(t);
+      ++t;
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    compute(t);
+    Mma::drain();
+    return;
+  }
   issue(0, a_stage(0), a_stage(0) + TileCfg::A_ELEMS);
   if (ntiles > 1) issue(1, a_stage(1), a_stage(1) + TileCfg::A_ELEMS);
   for (int t = 0; t < ntiles; ++t) {
@@ -228,6 +292,7 @@ __device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntile
       mma.compute_rows(As, As + TileCfg::A_ELEMS);
     if (stamps) stamps[4 * t + 3] = __builtin_readcyclecounter();
   }
+  Mma::drain();
 }
 
 }  // namespace fvta

@@ -14,6 +14,12 @@
 // reverse_sequence(x, len) and its outputs are reversed back.
 #include "gemm_f32.h"
 #include "fvta_prof.h"
+#include <vector>
+
+#ifndef FVTA_LSTM_OVERLAP_DEFAULT
+#define FVTA_LSTM_OVERLAP_DEFAULT 0
+#endif
+
 #include "lstm_common.h"
 
 namespace fvta {
@@ -515,6 +521,15 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
                                const float* d_out, const float* kernel_fw, const float* kernel_bw, void* saved,
                                float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw,
                                float* dbias_bw, void* workspace, fvta_stream_t stream_) {
+  return fvta_bilstm_bwd_overlap(d, plan, x, out, d_out, kernel_fw, kernel_bw, saved, dx, dkernel_fw, dbias_fw, dkernel_bw,
+                                 dbias_bw, workspace, stream_, nullptr);
+}
+
+extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan, const float* x, const float* out,
+                                       const float* d_out, const float* kernel_fw, const float* kernel_bw, void* saved,
+                                       float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw,
+                                       float* dbias_bw, void* workspace, fvta_stream_t stream_,
+                                       fvta_stream_t side_stream_) {
   if (int e = check_lstm_desc(d)) return e;
   FVTA_CHECK_ARG(d->training, "bilstm_bwd: forward was not run with training=1");
   FVTA_CHECK_ARG(plan && x && out && d_out && kernel_fw && saved && dkernel_fw && dbias_fw && workspace,
@@ -563,10 +578,50 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
   const dim3 ggrid((unsigned)(((size_t)B * dd + 255) / 256), 1, 2);
   const dim3 sgrid((B + MmaSq::BM - 1) / MmaSq::BM, (in + dd + MmaSq::BN - 1) / MmaSq::BN, 2);
   const size_t sh = MmaSq::LDS_FLOATS * sizeof(float);
+  // the weight-gradient launch arguments (both engines)
+  DwArgs w;
+  w.plan = pv;
+  w.x = x;
+  w.out = out;
+  w.dz = sv.gates;
+  w.slabs = wv.slabs;
+  w.B = B;
+  w.J = J;
+  w.in = in;
+  w.d = dd;
+  w.tgroup = dw_tgroup(d);
+  w.nsplit = dw_nsplit(d);
+  w.dzb = wv.dzb;
+  w.in_i = in_internal(d);
+  w.xs = sv.xs;
+  w.hs = sv.hs;
+  w.split0 = 0;
+  w.nsl = w.nsplit;
+  w.xcd_aware = 1;
+  // Overlap mode (bf16 engine, side stream given): dx and the weight gradient of a step group do not depend on the
+  // rest of the recurrence -- they are launched on `side` as soon as the group's dz is final and run on the CUs the
+  // single-round step kernel leaves idle (one 8-wave workgroup per CU on 204 of 256 CUs at the metric shape), reading
+  // dz while it is still in the memory-side cache, instead of as a serial tail after step 0.
+  hipStream_t side = (hipStream_t)side_stream_;
+  // what goes to the side stream: bit 0 dx, bit 1 the weight gradient (FVTA_LSTM_OVERLAP overrides: measurement switch)
+  static const int ov_mask = [] {
+    const char* e = getenv("FVTA_LSTM_OVERLAP");
+    return e ? atoi(e) : FVTA_LSTM_OVERLAP_DEFAULT;
+  }();
+  const bool overlap = bf && !(dbg & 2048) && side != nullptr && side != stream && (ov_mask & 3);
+  const bool ov_dx = overlap && (ov_mask & 1), ov_dw = overlap && (ov_mask & 2);
+  std::vector<hipEvent_t> events;
+  auto new_event = [&]() -> hipEvent_t {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    events.push_back(e);
+    return e;
+  };
+  bool ev_ok = true;
   fvta_prof_begin(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, stream);
   if (bf && !(dbg & 2048)) {
     // bf16 engine: ONE launch per step -- dh_{t} = dz_{t+1} * wb_h^T in the k-loop, the gate gradient
-    // (dz_t, dc) as its epilogue -- and a single batched dx = dz * wb_x^T over all steps afterwards
+    // (dz_t, dc) as its epilogue -- and dx = dz * wb_x^T batched over steps
     FusedBwdArgs f;
     f.plan = pv;
     f.Wb[0] = wv.wb[0];
@@ -582,6 +637,8 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
     f.in = in;
     f.d = dd;
     f.in_i = in_internal(d);
+    f.t0 = 0;
+    f.nt = J;
     {
       const char* e = getenv("FVTA_LSTM_STAMP_BWD");
       f.stamp_wg = e ? atoi(e) : -1;
@@ -589,8 +646,28 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
     for (int t = J - 1; t >= 0; --t) {
       f.t = t;
       launch_bwd_fused_bf16(f, stream);
+      if (overlap && t % w.tgroup == 0) {  // every dz of step group t / tgroup is final once this launch is done
+        hipEvent_t e = new_event();
+        if (!e || hipEventRecord(e, stream) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) {
+          ev_ok = false;
+          break;
+        }
+        FusedBwdArgs fx = f;
+        fx.t0 = t;
+        fx.nt = (t + w.tgroup <= J ? w.tgroup : J - t);
+        if (dx && ov_dx) launch_dx_bf16(fx, side);
+        if (!(dbg & 1024) && ov_dw) {
+          DwArgs wg = w;
+          wg.split0 = t / w.tgroup;
+          wg.nsl = 1;
+          wg.xcd_aware = 0;
+          fvta_prof_begin(FVTA_PROF_LSTM_DW + 16 * d->reserved, side);
+          launch_dw_bf16(wg, side);
+          fvta_prof_end(FVTA_PROF_LSTM_DW + 16 * d->reserved, 1, side);
+        }
+      }
     }
-    if (dx) launch_dx_bf16(f, stream);
+    if (dx && !ov_dx) launch_dx_bf16(f, stream);
   } else
   for (int t = J - 1; t >= 0; --t) {
     g.t = t;
@@ -604,27 +681,21 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
     }
   }
   fvta_prof_end(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, 2 * J, stream);
+  if (overlap && ev_ok) {  // the main stream takes the side stream's work back before the slab reduce
+    hipEvent_t e = new_event();
+    ev_ok = e && hipEventRecord(e, side) == hipSuccess && hipStreamWaitEvent(stream, e, 0) == hipSuccess;
+  }
+  for (hipEvent_t e : events) (void)hipEventDestroy(e);  // released by the runtime once the recorded work completes
+  if (!ev_ok) {
+    fvta_set_error("bilstm_bwd: event plumbing between the main and the side stream failed: %s",
+                   hipGetErrorString(hipGetLastError()));
+    return FVTA_ERR_LAUNCH;
+  }
   FVTA_CHECK_LAUNCH("lstm_step_bwd");
-  DwArgs w;
-  w.plan = pv;
-  w.x = x;
-  w.out = out;
-  w.dz = sv.gates;
-  w.slabs = wv.slabs;
-  w.B = B;
-  w.J = J;
-  w.in = in;
-  w.d = dd;
-  w.tgroup = dw_tgroup(d);
-  w.nsplit = dw_nsplit(d);
   const int MM = in + dd + 1, N4 = 4 * dd;
   const dim3 wgrid((MM + MmaSq::BM - 1) / MmaSq::BM, N4 / MmaSq::BN, 2 * w.nsplit);
-  fvta_prof_begin(FVTA_PROF_LSTM_DW + 16 * d->reserved, stream);
-  w.dzb = wv.dzb;
-  w.in_i = in_internal(d);
-  w.xs = sv.xs;
-  w.hs = sv.hs;
-  if (dbg & 1024) {
+  if (!ov_dw) fvta_prof_begin(FVTA_PROF_LSTM_DW + 16 * d->reserved, stream);
+  if ((dbg & 1024) || ov_dw) {
   } else if (bf)
     launch_dw_bf16(w, stream);
   else
@@ -647,7 +718,7 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
     hipLaunchKernelGGL(lstm_dw_reduce, dim3(rgrid), dim3(256), 0, stream, wv.slabs + (size_t)w.nsplit * slab_elems,
                        w.nsplit, slab_elems, in + dd, N4, dkernel_bw, dbias_bw);
   }
-  fvta_prof_end(FVTA_PROF_LSTM_DW + 16 * d->reserved, 1, stream);
+  if (!ov_dw) fvta_prof_end(FVTA_PROF_LSTM_DW + 16 * d->reserved, 1, stream);
   FVTA_CHECK_LAUNCH("lstm_dw_reduce");
   return FVTA_OK;
 }

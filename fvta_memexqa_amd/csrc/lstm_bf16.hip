@@ -20,9 +20,23 @@
 #include <type_traits>
 #include "lstm_common.h"
 
+#ifndef FVTA_TILE128_DEFAULT
+#define FVTA_TILE128_DEFAULT 0
+#endif
+
 namespace fvta {
 
 static inline int pad8(int v) { return (v + 7) / 8 * 8; }
+
+// Which kernels take the 256 x 256 / four-wave (128 x 128 wave tile) configuration: bit 0 forward step, 1 fused
+// backward step, 2 dx, 3 weight gradient.  FVTA_LSTM_TILE128 overrides the built-in choice (measurement switch).
+static int tile128_mask() {
+  static const int m = [] {
+    const char* e = getenv("FVTA_LSTM_TILE128");
+    return e ? atoi(e) : FVTA_TILE128_DEFAULT;
+  }();
+  return m;
+}
 
 template <class K>
 static void allow_big_lds(K kernel, int bytes) {  // > 64 KB of dynamic LDS must be opted into, per kernel symbol
@@ -85,9 +99,9 @@ __device__ unsigned long long g_lstm_stamps[512];  // diagnostics (FVTA_DEBUG_SK
 // ------------------------------------------------------------ forward step --
 // z = [xs_t | hs_{t-1}] * wt^T over the 4 gate strips of 32 units per wave column.
 // grid (pad8(ceil(B/256)), d/(32 WN), 2), 256 WN threads
-template <int WN>
-__global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_step_fwd_bf16(StepArgs a) {
-  typedef TileCfgT<WN> Cfg;
+template <int WN, int TM>
+__global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lstm_step_fwd_bf16(StepArgs a) {
+  typedef TileCfgT<WN, TM> Cfg;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + Cfg::STAGES * Cfg::STAGE_ELEMS);  // [256], same array
   const int tid = threadIdx.x;
@@ -98,9 +112,9 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_step_fwd_bf16(
   const int ub = blockIdx.y * 32 * WN;  // first unit of the block; wave column wn owns units ub + 32 wn ..
   const int d = a.d, t = a.t, in_i = a.Kp - a.d;
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
-  if (tid < 256) s_oo[tid] = (m0 + tid < nact) ? a.plan.oo[trow + m0 + tid] : -1;
+  for (int r = tid; r < 256; r += Cfg::NT) s_oo[r] = (m0 + r < nact) ? a.plan.oo[trow + m0 + r] : -1;
 
-  MmaBT<WN> mma;
+  MmaBT<WN, TM> mma;
   mma.init(tid);
   const int u0 = ub + 32 * mma.wn;
   // A rows m0.. of xs[dir][t] (nact rows) and of hs[dir][t-1]; B rows = the 4 gate strips of wt per wave column
@@ -130,19 +144,24 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_step_fwd_bf16(
   unsigned long long* st = ((a.dbg & 32768) && lin_wg == ((a.dbg >> 16) & 0xFFF) && tid == 0 && a.t == 5) ? g_lstm_stamps : nullptr;
   if (st) st[0] = __builtin_readcyclecounter();
   // c_{t-1} of the wave's rows, row-contiguous (16 B per lane), requested before the k-loop hides their latency
-  f32x4 cprev[2][4];
-  if (t > 0) {
-    const float* src = a.cs ? a.cs + (trow - a.B) * (size_t)d : a.cstate + (size_t)dir * a.B * d;
+  // (TM = 4: after it -- 64 more live registers across the k-loop spill next to the 256 accumulators)
+  f32x4 cprev[TM][4];
+  auto load_cprev = [&] {
+    if (t > 0) {
+      const float* src = a.cs ? a.cs + (trow - a.B) * (size_t)d : a.cstate + (size_t)dir * a.B * d;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
+      for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int i = min(m0 + mma.wave * 64 + ti * 32 + it * 8 + (mma.lane >> 3), nact - 1);  // clamped: valid row
-        cprev[ti][it] = *reinterpret_cast<const f32x4*>(src + (size_t)i * d + u0 + 4 * (mma.lane & 7));
-      }
-  }
+        for (int it = 0; it < 4; ++it) {
+          const int i = min(m0 + mma.wave * (32 * TM) + ti * 32 + it * 8 + (mma.lane >> 3), nact - 1);  // clamped: valid row
+          cprev[ti][it] = *reinterpret_cast<const f32x4*>(src + (size_t)i * d + u0 + 4 * (mma.lane & 7));
+        }
+    }
+  };
+  if (TM == 2) load_cprev();
   if (!(a.dbg & 1)) glds_mainloop<false>(mma, issue, nt, smem_h, st ? st + 8 : nullptr, (a.dbg >> 17) & 3);
   if (st) st[1] = __builtin_readcyclecounter();
+  if (TM != 2) load_cprev();
   __syncthreads();  // s_oo visible; every wave is done with the stage buffers, which become the epilogue's scratch
   if (!(a.dbg & 2))
     lstm_gate_epilogue_staged(mma, a, dir, m0, u0, nact, trow, s_oo, cprev,
@@ -172,16 +191,21 @@ void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s) {
     const char* e = getenv("FVTA_LSTM_WIDE_TILE");
     return e && e[0] == '1';
   }();
-  if (a.d % 64 == 0 && wide) {
-    constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
-    allow_big_lds(lstm_step_fwd_bf16<2>, LDS);
+  if (a.d % 64 == 0 && (tile128_mask() & 1)) {  // 256 x 256 block tile on four waves of 128 x 128
+    constexpr int LDS = TileCfgT<2, 4>::LDS_BYTES + 256 * 8;
+    allow_big_lds(lstm_step_fwd_bf16<2, 4>, LDS);
     const dim3 grid(pad8((a.B + 255) / 256), a.d / 64, 2);
-    hipLaunchKernelGGL(lstm_step_fwd_bf16<2>, grid, dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((lstm_step_fwd_bf16<2, 4>), grid, dim3(256), LDS, s, a);
+  } else if (a.d % 64 == 0 && wide) {
+    constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
+    allow_big_lds(lstm_step_fwd_bf16<2, 2>, LDS);
+    const dim3 grid(pad8((a.B + 255) / 256), a.d / 64, 2);
+    hipLaunchKernelGGL((lstm_step_fwd_bf16<2, 2>), grid, dim3(512), LDS, s, a);
   } else {
     constexpr int LDS = TileCfgT<1>::LDS_BYTES + 256 * 8;
-    allow_big_lds(lstm_step_fwd_bf16<1>, LDS);
+    allow_big_lds(lstm_step_fwd_bf16<1, 2>, LDS);
     const dim3 grid(pad8((a.B + 255) / 256), a.d / 32, 2);
-    hipLaunchKernelGGL(lstm_step_fwd_bf16<1>, grid, dim3(256), LDS, s, a);
+    hipLaunchKernelGGL((lstm_step_fwd_bf16<1, 2>), grid, dim3(256), LDS, s, a);
   }
 }
 
@@ -249,10 +273,10 @@ void launch_step_bwd_bf16(const StepBwdArgs& a, hipStream_t s) {
 // the epilogue adds the upstream d_out, runs the gate gradient and writes dz_t (packed, unit-major) and
 // the running dc.  No dh round trip through HBM, no separate elementwise launch.
 // grid (pad8(ceil(B/256)), d/128 (ceil), 2)
-template <int WN>
-__global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
-  typedef TileCfgT<WN> TileCfg;
-  typedef MmaBT<WN> MmaB;
+template <int WN, int TM>
+__global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
+  typedef TileCfgT<WN, TM> TileCfg;
+  typedef MmaBT<WN, TM> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + TileCfg::STAGES * TileCfg::STAGE_ELEMS);
   const int tid = threadIdx.x, dir = blockIdx.z;
@@ -262,7 +286,7 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_bwd_fused_bf16
   if (m0 >= nact) return;
   const int nnext = (t + 1 < a.J) ? a.plan.nactive[t + 1] : 0;
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
-  if (tid < 256) s_oo[tid] = a.plan.oo[trow + min(m0 + tid, nact - 1)];  // clamped: always a valid row
+  for (int r = tid; r < 256; r += TileCfg::NT) s_oo[r] = a.plan.oo[trow + min(m0 + r, nact - 1)];  // clamped: always a valid row
   MmaB mma;
   mma.init(tid);
   // FVTA_DEBUG_SKIP & 65536-style diagnostics: env FVTA_LSTM_STAMP_BWD=<workgroup> stamps step t = 5 (tools/lstm_phases.py)
@@ -340,26 +364,31 @@ void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
     const char* e = getenv("FVTA_LSTM_BWD_NARROW_TILE");
     return e && e[0] == '1';
   }();
-  if (a.d % 256 == 0 && !narrow) {  // 256 x 256 tile: dz (the A operand, K = 4d wide) is re-read d/256 instead of d/128 times
-    constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
-    allow_big_lds(lstm_bwd_fused_bf16<2>, LDS);
+  if (a.d % 256 == 0 && (tile128_mask() & 2)) {
+    constexpr int LDS = TileCfgT<2, 4>::LDS_BYTES + 256 * 8;
+    allow_big_lds(lstm_bwd_fused_bf16<2, 4>, LDS);
     const dim3 grid(pad8((a.B + 255) / 256), a.d / 256, 2);
-    hipLaunchKernelGGL(lstm_bwd_fused_bf16<2>, grid, dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4>), grid, dim3(256), LDS, s, a);
+  } else if (a.d % 256 == 0 && !narrow) {  // 256 x 256 tile: dz (the A operand, K = 4d wide) is re-read d/256 instead of d/128 times
+    constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
+    allow_big_lds(lstm_bwd_fused_bf16<2, 2>, LDS);
+    const dim3 grid(pad8((a.B + 255) / 256), a.d / 256, 2);
+    hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 2>), grid, dim3(512), LDS, s, a);
   } else {
-    allow_big_lds(lstm_bwd_fused_bf16<1>, FWD_LDS);
+    allow_big_lds(lstm_bwd_fused_bf16<1, 2>, FWD_LDS);
     const dim3 grid(pad8((a.B + 255) / 256), (a.d + 127) / 128, 2);
-    hipLaunchKernelGGL(lstm_bwd_fused_bf16<1>, grid, dim3(256), FWD_LDS, s, a);
+    hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 2>), grid, dim3(256), FWD_LDS, s, a);
   }
 }
 
-// dx = dz * wb_x^T for every (direction, step) at once.  grid (pad8(ceil(B/256)), ceil(in/128), 2*J)
-template <int WN>
-__global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_dx_bf16(FusedBwdArgs a) {
-  typedef TileCfgT<WN> TileCfg;
-  typedef MmaBT<WN> MmaB;
+// dx = dz * wb_x^T for the steps [t0, t0 + nt) of both directions.  grid (pad8(ceil(B/256)), ceil(in/128), 2*nt)
+template <int WN, int TM>
+__global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lstm_dx_bf16(FusedBwdArgs a) {
+  typedef TileCfgT<WN, TM> TileCfg;
+  typedef MmaBT<WN, TM> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   const int tid = threadIdx.x;
-  const int t = blockIdx.z % a.J, dir = blockIdx.z / a.J;
+  const int t = a.t0 + blockIdx.z % a.nt, dir = blockIdx.z / a.nt;
   const int m0 = blockIdx.x * TileCfg::BM, n0 = blockIdx.y * TileCfg::BN;
   const int nact = a.plan.nactive[t];
   if (m0 >= nact) return;
@@ -401,14 +430,19 @@ void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
     const char* e = getenv("FVTA_LSTM_DX_WIDE_TILE");
     return e && e[0] == '1';
   }();
-  if (a.in > 128 && wide) {
-    allow_big_lds(lstm_dx_bf16<2>, TileCfgT<2>::LDS_BYTES);
-    const dim3 grid(pad8((a.B + 255) / 256), (a.in + 255) / 256, 2 * a.J);
-    hipLaunchKernelGGL(lstm_dx_bf16<2>, grid, dim3(512), TileCfgT<2>::LDS_BYTES, s, a);
+  if (a.in > 128 && (tile128_mask() & 4)) {
+    constexpr int LDS = TileCfgT<2, 4>::LDS_BYTES;
+    allow_big_lds(lstm_dx_bf16<2, 4>, LDS);
+    const dim3 grid(pad8((a.B + 255) / 256), (a.in + 255) / 256, 2 * a.nt);
+    hipLaunchKernelGGL((lstm_dx_bf16<2, 4>), grid, dim3(256), LDS, s, a);
+  } else if (a.in > 128 && wide) {
+    allow_big_lds(lstm_dx_bf16<2, 2>, TileCfgT<2>::LDS_BYTES);
+    const dim3 grid(pad8((a.B + 255) / 256), (a.in + 255) / 256, 2 * a.nt);
+    hipLaunchKernelGGL((lstm_dx_bf16<2, 2>), grid, dim3(512), TileCfgT<2>::LDS_BYTES, s, a);
   } else {
-    allow_big_lds(lstm_dx_bf16<1>, TileCfgT<1>::LDS_BYTES);
-    const dim3 grid(pad8((a.B + 255) / 256), (a.in + 127) / 128, 2 * a.J);
-    hipLaunchKernelGGL(lstm_dx_bf16<1>, grid, dim3(256), TileCfgT<1>::LDS_BYTES, s, a);
+    allow_big_lds(lstm_dx_bf16<1, 2>, TileCfgT<1>::LDS_BYTES);
+    const dim3 grid(pad8((a.B + 255) / 256), (a.in + 127) / 128, 2 * a.nt);
+    hipLaunchKernelGGL((lstm_dx_bf16<1, 2>), grid, dim3(256), TileCfgT<1>::LDS_BYTES, s, a);
   }
 }
 
@@ -418,10 +452,10 @@ void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
 // grid (xtiles + htiles, 4d/128, 2*nsplit): m-tiles never mix x and h columns.
 // WN = 2: 256 x 256 output tile, 8 waves -- the operands are re-read 8 + 3 instead of 16 + 3 times (this kernel runs
 // at the rate the address unit feeds the LDS).
-template <int WN>
-__global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_dw_bf16(DwArgs a) {
-  typedef TileCfgT<WN> TileCfg;
-  typedef MmaBT<WN> MmaB;
+template <int WN, int TM>
+__global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lstm_dw_bf16(DwArgs a) {
+  typedef TileCfgT<WN, TM> TileCfg;
+  typedef MmaBT<WN, TM> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   const int tid = threadIdx.x;
   const int d = a.d, in_i = a.in_i, N4 = 4 * d;
@@ -430,9 +464,17 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void lstm_dw_bf16(DwArgs
   // (direction, step group) slice streams the SAME rows -- so a slice's tiles all go to ONE XCD, where the re-reads
   // hit its L2 instead of crossing the fabric 8 times (measured: 18 GB of fabric reads per call before, 4.4 GB unique).
   const int mtiles = xtiles + (d + TileCfg::BM - 1) / TileCfg::BM, ntiles = N4 / TileCfg::BN, per = mtiles * ntiles;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int bz = xcd + 8 * (slot / per), tile_id = slot % per;
-  if (bz >= 2 * a.nsplit) return;
+  int bzl, tile_id;  // slice (direction, group) within this launch, tile within the slice
+  if (a.xcd_aware) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    bzl = xcd + 8 * (slot / per);
+    tile_id = slot % per;
+  } else {
+    bzl = blockIdx.x / per;
+    tile_id = blockIdx.x % per;
+  }
+  if (bzl >= 2 * a.nsl) return;
+  const int bz = (bzl / a.nsl) * a.nsplit + a.split0 + bzl % a.nsl;  // slab index: dir * nsplit + split
   const int bx = tile_id % mtiles, by = tile_id / mtiles;
   const bool isx = bx < xtiles;
   const int col0 = isx ? bx * TileCfg::BM : (bx - xtiles) * TileCfg::BM;  // within x / h columns
@@ -480,16 +522,22 @@ void launch_dw_bf16(const DwArgs& a, hipStream_t s) {
     const char* e = getenv("FVTA_LSTM_DW_NARROW_TILE");
     return e && e[0] == '1';
   }();
-  if ((4 * a.d) % 256 == 0 && !narrow) {
-    allow_big_lds(lstm_dw_bf16<2>, TileCfgT<2>::LDS_BYTES);
+  if ((4 * a.d) % 256 == 0 && (tile128_mask() & 8)) {
+    constexpr int LDS = TileCfgT<2, 4>::LDS_BYTES;
+    allow_big_lds(lstm_dw_bf16<2, 4>, LDS);
     const int per = (xtiles + htiles) * (4 * a.d / 256);
-    const dim3 grid(8 * per * ((2 * a.nsplit + 7) / 8));
-    hipLaunchKernelGGL(lstm_dw_bf16<2>, grid, dim3(512), TileCfgT<2>::LDS_BYTES, s, a);
+    const dim3 grid(a.xcd_aware ? 8 * per * ((2 * a.nsl + 7) / 8) : per * 2 * a.nsl);
+    hipLaunchKernelGGL((lstm_dw_bf16<2, 4>), grid, dim3(256), LDS, s, a);
+  } else if ((4 * a.d) % 256 == 0 && !narrow) {
+    allow_big_lds(lstm_dw_bf16<2, 2>, TileCfgT<2>::LDS_BYTES);
+    const int per = (xtiles + htiles) * (4 * a.d / 256);
+    const dim3 grid(a.xcd_aware ? 8 * per * ((2 * a.nsl + 7) / 8) : per * 2 * a.nsl);
+    hipLaunchKernelGGL((lstm_dw_bf16<2, 2>), grid, dim3(512), TileCfgT<2>::LDS_BYTES, s, a);
   } else {
-    allow_big_lds(lstm_dw_bf16<1>, TileCfgT<1>::LDS_BYTES);
+    allow_big_lds(lstm_dw_bf16<1, 2>, TileCfgT<1>::LDS_BYTES);
     const int per = (xtiles + htiles) * (4 * a.d / 128);
-    const dim3 grid(8 * per * ((2 * a.nsplit + 7) / 8));
-    hipLaunchKernelGGL(lstm_dw_bf16<1>, grid, dim3(256), TileCfgT<1>::LDS_BYTES, s, a);
+    const dim3 grid(a.xcd_aware ? 8 * per * ((2 * a.nsl + 7) / 8) : per * 2 * a.nsl);
+    hipLaunchKernelGGL((lstm_dw_bf16<1, 2>), grid, dim3(256), TileCfgT<1>::LDS_BYTES, s, a);
   }
 }
 

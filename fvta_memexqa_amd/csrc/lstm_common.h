@@ -166,6 +166,10 @@ struct DwArgs {
   const bf16_t* hs;
   float* slabs;
   int B, J, in, d, tgroup, nsplit, in_i;
+  // the launch covers step groups [split0, split0 + nsl) of both directions (whole call: 0, nsplit)
+  int split0, nsl;
+  int xcd_aware;  // 1: a (direction, group) slice's tiles share one XCD (whole-call launch); 0: tiles dealt round-robin
+                  // over the XCDs (per-group launches that fill the CUs the recurrence leaves idle on EVERY XCD)
 };
 
 #ifdef __HIPCC__
@@ -244,8 +248,8 @@ __device__ __forceinline__ void lstm_gate_epilogue(const Mma& mma, const StepArg
 template <class Mma>
 __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const StepArgs& a, int dir, int m0, int u0,
                                                           int nact, size_t trow, const int64_t* s_oo,
-                                                          const f32x4 (&cprev)[2][4], char* scr) {
-  static_assert(Mma::TN == 4 && Mma::WAVES_N == 1 && Mma::TM == 2, "wave tile: 64 rows x the four gate strips");
+                                                          const f32x4 (&cprev)[Mma::TM][4], char* scr) {
+  static_assert(Mma::TN == 4 && Mma::WAVES_N == 1, "wave tile: 32 TM rows x the four gate strips");
   constexpr int LDP = 36;  // floats per staged fp32 row (32 + pad, keeps 16-byte alignment)
   const int d = a.d, t = a.t, lane = mma.lane;
   const float* __restrict__ bias = a.bias[dir];
@@ -259,8 +263,8 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
     __builtin_amdgcn_wave_barrier();
   };
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti) {
-    const int wrow0 = mma.wave * 64 + ti * 32;  // first tile row of this 32-row half
+  for (int ti = 0; ti < Mma::TM; ++ti) {
+    const int wrow0 = mma.wave * Mma::WROWS + ti * 32;  // first tile row of this 32-row slice of the wave tile
     // ---- c_{t-1}: row-contiguous registers -> LDS -> MFMA layout
     float cp[16];
     if (t > 0) {
@@ -371,6 +375,7 @@ struct FusedBwdArgs {
   bf16_t* dzb;
   float* dc;  // [2][B][d]
   float* dx;  // lstm_dx only
+  int t0, nt; // lstm_dx only: the launch covers steps [t0, t0 + nt) of both directions
   int t, B, J, in, d, in_i;
   int stamp_wg;  // diagnostics: workgroup that stamps the shader clock (-1: none)
 };

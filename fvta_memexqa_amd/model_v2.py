@@ -156,6 +156,15 @@ class Model:
         # the side stream (photo cell, small launches that run beside the text cell) must own a hardware queue of
         # its own; which torch stream does is measured once here against the current stream (ops.pick_side_stream)
         self._side, self.side_stream_ratio = ops.pick_side_stream(self.dev)
+        # a second one, lowest priority, for the text cell's backward tails (dx, weight gradient per step group:
+        # fvta_bilstm_bwd_overlap); it has to run beside the main stream AND the photo cell's stream
+        self._side2 = None
+        if self.precision == BF16 and bool(_cfg(config, "overlap_bwd_tails", True)):
+            try:
+                lo = torch.cuda.Stream.priority_range()[0]
+            except Exception:
+                lo = 0
+            self._side2, self.side2_stream_ratio = ops.pick_side_stream(self.dev, others=(self._side,), priority=lo)
 
         dp, wp = self.dp, self.wp
         F = {1: 3 * wp, 2: 2 * wp, 3: 4 * wp, 4: 0}[self.simi]
@@ -795,7 +804,8 @@ class Model:
             with torch.cuda.stream(side if side is not None else main):
                 if need_dx:
                     G.dx.zero_()
-                G.op.backward(G.x, L.arena, L.d_arena, kf, kb, G.dx if need_dx else None, dkf, dbf, dkb, dbb)
+                G.op.backward(G.x, L.arena, L.d_arena, kf, kb, G.dx if need_dx else None, dkf, dbf, dkb, dbb,
+                              side_stream=self._side2 if side is None else None)
         main.wait_stream(self._side)            # both cells' gradients are in params.grad
         if self.wd:
             self._apply_wd(True, None)

@@ -29,9 +29,9 @@ def _bytes(n, dev):
 
 
 # ------------------------------------------------------------------ side stream
-def concurrency_ratio(main, cand, spin_us=400, repeats=3):
-    """time(one spin wave on each of two streams) / time(one spin wave on `main`): about 1 when the streams run
-    concurrently, about 2 when HIP mapped both onto the same hardware queue."""
+def concurrency_ratio(main, cand, spin_us=400, repeats=3, others=()):
+    """time(one spin wave on each of the streams main, others..., cand) / time(one spin wave on `main`): about 1 when
+    they all run concurrently, 2 or more when HIP mapped some of them onto the same hardware queue."""
     import time
     lib = _lib.load()
 
@@ -48,12 +48,13 @@ def concurrency_ratio(main, cand, spin_us=400, repeats=3):
             best = min(best, time.perf_counter() - t0)
         return best
 
-    run([main, cand])                       # first use creates the hardware queues
-    return run([main, cand]) / run([main])
+    group = [main] + list(others) + [cand]
+    run(group)                              # first use creates the hardware queues
+    return run(group) / run([main])
 
 
-def pick_side_stream(dev, main=None, candidates=8):
-    """A HIP stream that really runs beside `main`.  HIP maps streams onto a small pool of hardware queues
+def pick_side_stream(dev, main=None, candidates=8, others=(), priority=0):
+    """A HIP stream that really runs beside `main` (and beside every stream in `others`).  HIP maps streams onto a small pool of hardware queues
     (GPU_MAX_HW_QUEUES, 4 by default) and two streams on one queue serialise; which streams collide depends on how
     many were created before -- an RCCL communicator created ahead of the model moved the side stream onto the main
     stream's queue and the training step lost the photo-cell overlap (21.9 ms instead of 15.7 ms,
@@ -63,8 +64,8 @@ def pick_side_stream(dev, main=None, candidates=8):
     main = main if main is not None else torch.cuda.current_stream(dev)
     tried, best = [], None
     for _ in range(candidates):
-        cand = torch.cuda.Stream(device=dev)
-        r = concurrency_ratio(main, cand)
+        cand = torch.cuda.Stream(device=dev, priority=priority)
+        r = concurrency_ratio(main, cand, others=others)
         tried.append(cand)
         if best is None or r < best[0]:
             best = (r, cand)
@@ -126,11 +127,14 @@ class BiLstm:
                                        ptr(_f32c(kernel_fw)), ptr(_f32c(bias_fw)), ptr(kernel_bw), ptr(bias_bw),
                                        ptr(self.saved), ptr(self.work), stream_ptr()), "fvta_bilstm_fwd")
 
-    def backward(self, x, out, d_out, kernel_fw, kernel_bw, dx, dk_fw, db_fw, dk_bw=None, db_bw=None):
-        check(self.lib.fvta_bilstm_bwd(ctypes.byref(self.desc), ptr(self.plan), ptr(x), ptr(out), ptr(_f32c(d_out)),
-                                       ptr(kernel_fw), ptr(kernel_bw), ptr(self.saved), ptr(dx), ptr(dk_fw),
-                                       ptr(db_fw), ptr(dk_bw), ptr(db_bw), ptr(self.work), stream_ptr()),
-              "fvta_bilstm_bwd")
+    def backward(self, x, out, d_out, kernel_fw, kernel_bw, dx, dk_fw, db_fw, dk_bw=None, db_bw=None, side_stream=None):
+        """side_stream (a torch stream, bf16 engine): dx and the per-step-group weight gradients run there, beside the
+        recurrence (fvta_bilstm_bwd_overlap); the current stream has joined it again when this returns."""
+        side = ctypes.c_void_p(side_stream.cuda_stream) if side_stream is not None else None
+        check(self.lib.fvta_bilstm_bwd_overlap(ctypes.byref(self.desc), ptr(self.plan), ptr(x), ptr(out), ptr(_f32c(d_out)),
+                                               ptr(kernel_fw), ptr(kernel_bw), ptr(self.saved), ptr(dx), ptr(dk_fw),
+                                               ptr(db_fw), ptr(dk_bw), ptr(db_bw), ptr(self.work), stream_ptr(), side),
+              "fvta_bilstm_bwd_overlap")
 
     def last_state(self, out, s0, count, dst):
         check(self.lib.fvta_lstm_last_state(ctypes.byref(self.desc), ptr(self.plan), ptr(out), s0, count, ptr(dst),

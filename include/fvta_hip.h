@@ -132,6 +132,18 @@ int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const float* x, c
                     float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
                     void* workspace, fvta_stream_t stream);
 
+/* The same with a second stream the caller lends for the call (bf16 engine; ignored otherwise, NULL = fvta_bilstm_bwd):
+ * the work that does not sit on the recurrence's critical path -- dx and the weight gradient of a step group, final as
+ * soon as that group's gate gradients are -- is launched on `side_stream` behind an event and joins `stream` again
+ * before the call's last kernel, so the caller sees the same stream-ordered semantics on `stream`.  It runs on the CUs
+ * the one-round step kernel leaves idle.  `side_stream` should not carry other work of the caller's during the call
+ * and is best created with the lowest priority.  Results are bitwise those of fvta_bilstm_bwd, except dx where its two
+ * directions meet (float atomics, two addends: order-free). */
+int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan, const float* x, const float* out,
+                            const float* d_out, const float* kernel_fw, const float* kernel_bw, void* saved,
+                            float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
+                            void* workspace, fvta_stream_t stream, fvta_stream_t side_stream);
+
 /* Final states = concat(fw .h at t=len-1, bw .h at t=0) of sequences
  * [s0, s0+count): lq model_v2.py:697, lchoices 807-812.  dst [count, 2d]. */
 int fvta_lstm_last_state(const fvta_lstm_desc* d, const void* plan, const float* out, int32_t s0,

@@ -99,3 +99,35 @@ def test_model_bf16_matches_oracle_loosely_and_fp32_engine_closely():
     _close(outs["bf16"], ref["yp"], rtol=0, atol=2e-2, msg="bf16 engine")
     err = (outs["bf16_g"] - outs["f32_g"]).norm() / outs["f32_g"].norm()
     assert err < 5e-2, "bf16 text_kernel gradient off by %.4f (relative L2)" % err
+
+
+@pytest.mark.parametrize("B,J,din,d,dense", [(300, 9, 16, 64, False), (1100, 30, 200, 256, True), (700, 33, 40, 128, False)])
+def test_bilstm_bf16_backward_overlapped_equals_serial(B, J, din, d, dense):
+    """fvta_bilstm_bwd_overlap (dx and the per-step-group weight gradients on a lent side stream, beside the
+    recurrence) against the serial fvta_bilstm_bwd: weight and bias gradients bitwise, dx to the order of its two
+    float-atomic addends.  Repeated, so that a missing event dependency between the two streams would show."""
+    from fvta_memexqa_amd import ops
+    g = torch.Generator().manual_seed(B + J)
+    x = torch.randn(B, J, din, generator=g).cuda()
+    lens = torch.full((B,), J) if dense else torch.randint(0, J + 1, (B,), generator=g)
+    lim = (6.0 / (din + 5 * d)) ** 0.5
+    kf = ((torch.rand(din + d, 4 * d, generator=g) * 2 - 1) * lim).cuda()
+    bf = (torch.randn(4 * d, generator=g) * 0.1).cuda()
+    mask = torch.arange(J)[None, :] < lens[:, None]
+    g_out = (torch.randn(B, J, 2 * d, generator=g) * mask[:, :, None]).cuda()
+    out, last, op = ops.bilstm_simple(x, lens, kf, bf, training=True, precision=BF16)
+    side = torch.cuda.Stream()
+
+    def run(side_stream):
+        dx, dk, db = torch.zeros_like(x), torch.zeros_like(kf), torch.zeros_like(bf)
+        op.backward(x, out, g_out, kf, None, dx, dk, db, side_stream=side_stream)
+        torch.cuda.synchronize()
+        return dx, dk, db
+
+    ref = run(None)
+    assert float(ref[1].abs().max()) > 0
+    for _ in range(3):
+        cur = run(side)
+        assert torch.equal(cur[1], ref[1]), "dkernel"
+        assert torch.equal(cur[2], ref[2]), "dbias"
+        _close(cur[0], ref[0], rtol=1e-5, atol=1e-6, msg="dx")

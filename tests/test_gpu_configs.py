@@ -60,7 +60,8 @@ def test_metric_shape_bf16_train_step_gradients_vs_oracle(dense):
     grads = model.get_oracle_grads()
     worst = {}
     for k, v in p64.items():
-        if v.grad is None or float(v.grad.norm()) == 0.0:
+        if v.grad is None or float(v.grad.norm()) < 1e-9:     # out_b: sum_c (softmax - y) = 0 when every row has a label
+            assert v.grad is None or float(np.abs(grads[k]).max()) < 1e-5, k
             continue
         worst[k] = _rel_l2(grads[k].reshape(v.grad.shape), v.grad)
     assert worst and max(worst.values()) < 4e-2, "relative L2 gradient error per parameter: %r" % worst
