@@ -71,6 +71,10 @@ def parse():
                     help="torch-CPU threads of the baseline; 16 is the fastest setting measured on the 2x EPYC 9575F host "
                          "(64 threads: 3.5x slower, 128: 9.5x slower for this op mix; DESIGN.md section 5)")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE.json configs[1] (inference) instead of the train step")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank gets the config's batch (64 QA pairs per GPU; the driver's default run). "
+                         "strong: --global-batch QA pairs in total, global/N per rank (north_star's strong-scaling target)")
+    ap.add_argument("--global-batch", type=int, default=512, help="--scaling strong: total QA pairs (BASELINE.json configs[3]: 512)")
     ap.add_argument("--front-end", action="store_true",
                     help="enter with the reference's token-id feed (SURVEY 8f rank 1): the char-CNN / word / photo embedding "
                          "front-end and its gradients are inside the timed step (the headline enters at the encoder inputs)")
@@ -85,33 +89,72 @@ def lstm_flops(spec, B, J, din, d):
     return 2 * (J * 2.0 * B * (din + d) * 4 * d - 2.0 * B * d * 4 * d)
 
 
-def cpu_baseline(spec_kw, sample_n, forward_only, threads):
-    """The CPU oracle (oracle/fvta_fused.py, torch-CPU fp32, all host cores) on `sample_n` QA pairs of
-    the same workload: 1 warm-up + 3 timed passes, median."""
-    from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params
+def _median_time(fn, passes):
+    """1 warm-up + `passes` timed calls, median seconds"""
+    times = []
+    for it in range(passes + 1):
+        t0 = time.perf_counter()
+        fn()
+        if it:
+            times.append(time.perf_counter() - t0)
+    return statistics.median(times)
+
+
+def cpu_baseline(spec_kw, sample_n, forward_only, threads, literal_n=1):
+    """The reference's CPU path cannot run (Python-2 / TF-1); what is timed beside the GPU is the CPU oracle, on a
+    bounded sample of the same workload on this box's host cores:
+      fused   oracle/fvta_fused.py, torch-CPU fp32: forward+backward (the metric's unit) and forward only;
+      literal oracle/fvta_literal.py, NumPy fp32, the op-for-op mirror of the TF graph (tile/concat/linear attention
+              materialised per (n,k), per-stream LSTM loops with concat([x,h]) . kernel, pad+stack): forward only --
+              it has no autograd.
+    `value` is the fused forward+backward rate (forward-only runs: the faster of the two forward rates)."""
+    import numpy as np
+    from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params, to_numpy
     from oracle import fvta_fused as F
+    from oracle import fvta_literal as Lit
     torch.set_num_threads(max(1, min(threads, host_cores())))
     spec = SynthSpec(**dict(spec_kw, N=sample_n))
-    params = {k: v.requires_grad_(not forward_only) for k, v in make_params(spec).items()}
+    params = {k: v.requires_grad_(True) for k, v in make_params(spec).items()}
     inputs = make_inputs(spec)
-    times = []
-    for it in range(4):
-        t0 = time.perf_counter()
-        if forward_only:
-            with torch.no_grad():
-                F.fvta_forward(params, inputs, spec.cfg())
-        else:
-            for p in params.values():
-                p.grad = None
-            out = F.fvta_forward(params, inputs, spec.cfg())
-            out["loss"].backward()
-        dt = time.perf_counter() - t0
-        if it > 0:
-            times.append(dt)
-    med = statistics.median(times)
-    return dict(value=sample_n / med, unit="QA-pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d QA pairs of the same shape, %s, torch-CPU fp32 oracle, median of 3 (%.2f s each)"
-                       % (sample_n, "forward only" if forward_only else "forward+backward", med))
+
+    def fwd_bwd():
+        for p in params.values():
+            p.grad = None
+        F.fvta_forward(params, inputs, spec.cfg())["loss"].backward()
+
+    def fwd():
+        with torch.no_grad():
+            F.fvta_forward(params, inputs, spec.cfg())
+
+    t_fb = None if forward_only else _median_time(fwd_bwd, 3)
+    t_f = _median_time(fwd, 2 if not forward_only else 3)
+    out = dict(unit="QA-pairs/s", cores=torch.get_num_threads(), kind="port",
+               fused=dict(fwd_only=round(sample_n / t_f, 3), sample_qa_pairs=sample_n,
+                          note="oracle/fvta_fused.py, torch-CPU fp32, %d threads, median (1 warm-up)" % torch.get_num_threads()))
+    if t_fb is not None:
+        out["fused"]["fwd_bwd"] = round(sample_n / t_fb, 3)
+    # the literal mirror: one pass per timing (a pass is ~10 s per QA pair at the metric shape)
+    lspec = SynthSpec(**dict(spec_kw, N=literal_n))
+    lp = to_numpy(make_params(lspec), np.float32)
+    li = to_numpy(make_inputs(lspec), np.float32)
+    t_l = _median_time(lambda: Lit.fvta_forward(lp, li, lspec.cfg()), 1)
+    out["literal"] = dict(fwd_only=round(literal_n / t_l, 3), sample_qa_pairs=literal_n,
+                          note="oracle/fvta_literal.py, NumPy fp32 op-for-op mirror, forward only (no autograd), 1 warm-up + 1 timed pass")
+    out["faster_forward"] = "fused" if out["fused"]["fwd_only"] >= out["literal"]["fwd_only"] else "literal"
+    if forward_only:
+        out["value"] = max(out["fused"]["fwd_only"], out["literal"]["fwd_only"])
+    else:
+        out["value"] = out["fused"]["fwd_bwd"]
+    out["sample"] = ("%d QA pairs of the same shape through the fused torch-CPU oracle (%s, median of 3, %.2f s each); "
+                     "%d QA pair through the NumPy literal mirror (forward only, %.1f s)"
+                     % (sample_n, "forward only" if forward_only else "forward+backward", t_f if forward_only else t_fb,
+                        literal_n, t_l))
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
+        out["cpu_model"], out["host_logical_cpus"] = (model[0] if model else "?"), host_cores()
+    except Exception:
+        pass
+    return out
 
 
 def main():
@@ -131,6 +174,9 @@ def main():
     kw = dict(CONFIGS[args.config], dense=(args.variant == "dense"))
     if args.batch:
         kw["N"] = args.batch
+    if args.scaling == "strong":      # fixed total work: global/ws QA pairs per rank
+        lo, hi = dist.shard_range(args.global_batch, ws, rank)
+        kw["N"] = hi - lo
     spec = SynthSpec(**kw)
     cfg = dict(spec.cfg(), batch_size=spec.N, precision=args.precision, optimizer=args.optimizer,
                init_lr=0.001 if args.optimizer == "adam" else 0.5, overlap_bwd_tails=not args.no_overlap)
@@ -162,18 +208,32 @@ def main():
         step()
         torch.cuda.synchronize()
         log('warm-up step %d done' % i)
-    lib.fvta_profile_enable(1)
+    # ---- the timed region: exactly `steps` steps between barrier + synchronize pairs, no profiling brackets inside;
+    # one HIP event per step on the main stream (every side stream has joined it when a step ends) gives the
+    # per-step device times whose median is reported beside the wall-clock mean
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
-    lib.fvta_profile_enable(0)
     elapsed = dist.max_over_ranks(elapsed, dev)
-    log('timed region done: %.3f s for %d steps' % (elapsed, args.steps))
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    log('timed region done: %.3f s for %d steps (per-step HIP events: median %.3f ms)'
+        % (elapsed, args.steps, statistics.median(step_ms)))
+    # ---- a second pass of the same steps with the library's HIP-event brackets around the kernels the rooflines
+    # are quoted for (events on the launch streams); kept out of the headline
+    lib.fvta_profile_enable(1)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    lib.fvta_profile_enable(0)
+    dist.barrier()
 
     def collect(pid):
         ms, n = ctypes.c_double(0), ctypes.c_int64(0)
@@ -280,16 +340,20 @@ def main():
         metric="QA-pairs/sec (fwd+bwd) at B=64, 40 photos x 5 streams x 30 tok, h=512" if args.config == "metric" and not args.forward_only
         else "QA-pairs/sec (%s, config %s)" % ("fwd" if args.forward_only else "fwd+bwd", args.config),
         value=round(value, 2), unit="QA-pairs/s", n_gpus=ws, steps=args.steps, warmup=args.warmup,
-        ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+        ms_per_step=round(elapsed / args.steps * 1e3, 3), ms_per_step_event_median=round(statistics.median(step_ms), 3),
+        higher_is_better=True, scaling=args.scaling, vs_baseline=None,
         dtype=args.precision, data="synthetic",
         config=dict(workload=("BASELINE.json configs[2] train step (fwd+bwd+%s)" % args.optimizer if not args.forward_only
                               else "BASELINE.json configs[1] forward only") + ", shape '%s', %s lengths" % (args.config, args.variant)
                     + (", token-id entry (embedding front-end inside the step, char_emb_size %d)" % args.char_emb_size
                        if args.front_end else ""),
                     qa_pairs_per_gpu=spec.N, albums=spec.A, photos=spec.P, text_streams=spec.S, tokens=spec.L, hidden=spec.d,
-                    K=L.K, T=L.T, JQ=L.JQ, parallelism="dp%d (QA pairs sharded, flat-gradient all-reduce)" % ws),
+                    global_batch=spec.N * ws, K=L.K, T=L.T, JQ=L.JQ,
+                    parallelism="dp%d (QA pairs sharded, flat-gradient all-reduce)" % ws),
         roofline=roof, roofline_attention=roof_att,
         kernel_ms_per_step={k: round(v[0] / args.steps, 4) for k, v in prof.items()},
+        kernel_ms_note="HIP-event brackets on the launch streams, over a second pass of the same %d steps right after the "
+                       "timed region (the timed region itself carries no brackets)" % args.steps,
     )
     if ws == 1 and not args.no_cpu_baseline:
         log('timing the CPU oracle (%d threads of %d host CPUs)' % (args.cpu_threads, host_cores()))

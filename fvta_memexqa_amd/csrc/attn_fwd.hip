@@ -1059,10 +1059,7 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
   a.a_logits = a_logits;
   a.part = (float*)workspace;
   a.ipw = 1;
-  {
-    const char* e = getenv("FVTA_ATTN_DBG");
-    a.dbg = e ? atoi(e) : 0;
-  }
+  a.dbg = fvta_diag_env("FVTA_ATTN_DBG", 0);  // -DFVTA_DIAG builds only
   // (the bracket files the context attention only: the K = 1 question attention is a 15 us launch of the same kernel)
   const bool prof_it = (size_t)s.N * s.K * s.T >= 65536;
   if (prof_it) fvta_prof_begin(FVTA_PROF_ATTN_FWD_MAIN, stream);

@@ -44,6 +44,20 @@ void fvta_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// Diagnostic switches (kernel-skipping ablations, shader-clock stamps, phase masks) exist only in a -DFVTA_DIAG build
+// (`make DIAG=1`): a production library must not change its results, or write stamp areas the workspace query did not
+// reserve, because of an environment variable.  Switches that choose between equally correct kernels stay plain getenv.
+#include <stdlib.h>
+static inline int fvta_diag_env(const char* name, int dflt) {
+#ifdef FVTA_DIAG
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
+
 static inline size_t fvta_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Carve a caller-provided workspace into 256-byte aligned pieces.

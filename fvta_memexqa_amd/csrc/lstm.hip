@@ -492,10 +492,7 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   fvta_prof_begin(FVTA_PROF_LSTM_STEP_FWD + 16 * d->reserved, stream);
   const bool bf = d->precision == FVTA_BF16;
   a.Kp = kpad8(d);
-  {
-    const char* e = getenv("FVTA_DEBUG_SKIP");
-    a.dbg = e ? atoi(e) : 0;
-  }
+  a.dbg = fvta_diag_env("FVTA_DEBUG_SKIP", 0);  // -DFVTA_DIAG builds only
   a.Wt[0] = a.Wt[1] = nullptr;
   if (bf) {  // refresh the bf16 weight shadows (the optimiser has just changed the fp32 masters)
     const int ndir = d->share_fw_bw ? 1 : 2;
@@ -563,11 +560,7 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
   s.dh_rec = wv.dh_rec;
   s.dzb = wv.dzb;
   s.in_i = in_internal(d);
-  int dbg = 0;
-  {
-    const char* e = getenv("FVTA_DEBUG_SKIP");
-    dbg = e ? atoi(e) : 0;
-  }
+  const int dbg = fvta_diag_env("FVTA_DEBUG_SKIP", 0);  // -DFVTA_DIAG builds only
   s.dbg = dbg;
   s.Wb[0] = wv.wb[0];
   s.Wb[1] = d->share_fw_bw ? wv.wb[0] : wv.wb[1];
@@ -639,10 +632,7 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
     f.in_i = in_internal(d);
     f.t0 = 0;
     f.nt = J;
-    {
-      const char* e = getenv("FVTA_LSTM_STAMP_BWD");
-      f.stamp_wg = e ? atoi(e) : -1;
-    }
+    f.stamp_wg = fvta_diag_env("FVTA_LSTM_STAMP_BWD", -1);  // -DFVTA_DIAG builds only
     for (int t = J - 1; t >= 0; --t) {
       f.t = t;
       launch_bwd_fused_bf16(f, stream);

@@ -41,13 +41,42 @@ def shard_range(global_batch, ws, rank):
     return rank * per, (rank + 1) * per
 
 
-def allreduce_grads(flat_grad):
-    """Sum the single flat gradient bucket across ranks; returns the 1/world factor the optimiser
-    must apply so that the update equals the reference's global-batch mean (model_v2.py:1090)."""
+def allreduce_async(flat_slice):
+    """Start the sum all-reduce of a slice of the flat gradient buffer whose producers are already enqueued on the
+    CURRENT stream (torch orders the collective's stream behind it); returns the work handle, or None when there is one
+    rank.  Used for the "early" bucket -- scorer / attention / photo-cell gradients, final while the text cell's
+    backward recurrence still runs -- so that its wire time hides behind that recurrence."""
+    if not is_dist():
+        return None
+    return dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def allreduce_grads(flat_grad, early_numel=0, early_work=None):
+    """Sum the flat gradient bucket across ranks; returns the 1/world factor the optimiser must apply so that the
+    update equals the reference's global-batch mean (model_v2.py:1090).  If the first `early_numel` elements are
+    already being reduced (`early_work` from allreduce_async) only the rest is reduced here, then the early work is
+    waited for (the current stream waits, not the host)."""
     if not is_dist():
         return 1.0
-    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    if early_work is not None and 0 < early_numel < flat_grad.numel():
+        dist.all_reduce(flat_grad[early_numel:], op=dist.ReduceOp.SUM)
+        early_work.wait()
+    else:
+        if early_work is not None:
+            early_work.wait()
+            if early_numel >= flat_grad.numel():
+                return 1.0 / dist.get_world_size()
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return 1.0 / dist.get_world_size()
+
+
+def mean_over_ranks(t):
+    """mean of a (device or CPU) tensor over ranks, in place: the loss a data-parallel step reports is the global-batch
+    mean (equal shards), as the single-process reference's is"""
+    if is_dist():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t /= dist.get_world_size()
+    return t
 
 
 def barrier():

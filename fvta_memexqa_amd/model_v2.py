@@ -54,13 +54,20 @@ class ParamStore:
     """All trainables in ONE flat fp32 device buffer (+ one flat gradient buffer):
     a single RCCL all-reduce bucket and a single optimiser launch per step."""
 
-    def __init__(self, specs, device):
-        self.specs = specs  # name -> shape (padded)
+    def __init__(self, specs, device, late=()):
+        """`late`: names whose gradients are final only at the very end of the backward pass (the text cell and what
+        hangs off its dx); they are laid out LAST, so that [0, early_numel) -- scorer, attention, photo cell -- is one
+        contiguous bucket whose all-reduce can start while the text cell's recurrence still runs."""
+        order = [n for n in specs if n not in late] + [n for n in specs if n in late]
+        self.specs = {n: specs[n] for n in order}  # name -> shape (padded)
         self.offsets = {}
         off = 0
-        for name, shape in specs.items():
+        self.early_numel = 0
+        for name, shape in self.specs.items():
             self.offsets[name] = off
             off += (int(np.prod(shape)) + 63) // 64 * 64  # 256-byte aligned slices
+            if name not in late:
+                self.early_numel = off
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
@@ -195,7 +202,9 @@ class Model:
             if self.use_image_trans:
                 specs[self.N_IMGT_W], specs[self.N_IMGT_B] = (self.idim, self.tdim), (self.tdim,)
             self._plain = {self.N_WORD_EMB, self.N_CHAR_EMB, self.N_CONV_F, self.N_CONV_B, self.N_IMGT_W, self.N_IMGT_B}
-        self.params = ParamStore(specs, self.dev)
+        late = {n for n in specs if "/utext/" in n} | self._plain      # text cell; embeddings and photo transform (off dx)
+        self.params = ParamStore(specs, self.dev, late=late)
+        self.early_work = None      # pending all-reduce of the early gradient bucket (data parallelism), see backward()
         self.init_parameters(int(_cfg(config, "weight_seed", 42)))
         self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self.dev)
 
@@ -322,6 +331,7 @@ class Model:
         out = {"%s/%s:0" % (self.scope, k): v for k, v in self.get_weights().items()}
         if self.use_time_warp and self.warp_type == 5:
             out["%s/%s:0" % (self.scope, self.N_TW_WINDOW)] = np.float32(self.window_t)
+        out["%s/global_step:0" % self.scope] = np.int64(self.global_step)           # model_v2.py:366; not a trainable
         with open(os.path.join(weights_path, "all.txt"), "w") as f:
             for k, v in out.items():
                 f.writelines("%s %s\n" % (k, str(tuple(int(x) for x in np.shape(v)))))
@@ -337,8 +347,8 @@ class Model:
             path = os.path.join(path, "weights.npz")
         if not os.path.exists(path):
             raise Exception("Model not exists")                         # main.py:665
-        known = list(self.params.specs) + [self.N_TW_WINDOW]
-        got = {}
+        known = list(self.params.specs) + [self.N_TW_WINDOW, "global_step"]
+        got, unmatched = {}, []
         with np.load(path) as z:
             for key in z.files:
                 k = key[:-2] if key.endswith(":0") else key
@@ -346,9 +356,20 @@ class Model:
                     if k == name or k.endswith("/" + name):
                         got[name] = z[key]
                         break
+                else:
+                    unmatched.append(key)
         missing = [n for n in self.params.specs if n not in got]
         if missing:
             raise KeyError("weights file %s lacks %s" % (path, ", ".join(missing)))
+        # a variable of the FILE that this model has no place for is an error too: silently dropping e.g. the
+        # .../bw/basic_lstm_cell/{kernel,bias} of a TF-1.0-style checkpoint into a share_fw_bw=True model would load a
+        # different network (switches that legitimately remove variables: share_fw_bw, use_question_att, use_time_warp, ...)
+        if unmatched:
+            hint = " (the file has separate backward-direction cells: build the model with share_fw_bw=False)" \
+                if any("/bw/basic_lstm_cell/" in k for k in unmatched) and self.share_fw_bw else ""
+            raise KeyError("weights file %s holds variables this model does not have: %s%s" % (path, ", ".join(unmatched), hint))
+        if "global_step" in got:
+            self.global_step = int(got.pop("global_step"))
         if self.N_TW_WINDOW in got:
             self.window_t = float(got.pop(self.N_TW_WINDOW))
             self._layouts.clear()                                       # the window is baked into the warp descriptors
@@ -806,6 +827,12 @@ class Model:
                     G.dx.zero_()
                 G.op.backward(G.x, L.arena, L.d_arena, kf, kb, G.dx if need_dx else None, dkf, dbf, dkb, dbb,
                               side_stream=self._side2 if side is None else None)
+                if side is not None and not self.wd:
+                    # data parallelism: everything in [0, early_numel) of the flat gradient -- scorer, attention(s),
+                    # time warp, photo cell -- is final in THIS stream's order now; start its all-reduce on RCCL's
+                    # stream while the text cell's recurrence (enqueued next, on the main stream) runs
+                    from . import dist
+                    self.early_work = dist.allreduce_async(P.grad[:P.early_numel])
         main.wait_stream(self._side)            # both cells' gradients are in params.grad
         if self.wd:
             self._apply_wd(True, None)

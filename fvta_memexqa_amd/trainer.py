@@ -48,7 +48,9 @@ class Trainer:
         m.zero_grad()
         m.forward(layout)
         m.backward(layout, loss_scale=1.0, need_dx=self.need_dx)
-        scale = dist.allreduce_grads(m.params.grad)
+        # one flat gradient bucket; its early part (scorer / attention / photo cell) may already be on the wire
+        early, m.early_work = getattr(m, "early_work", None), None
+        scale = dist.allreduce_grads(m.params.grad, getattr(m.params, "early_numel", 0), early)
         self.opt.apply(m.params, scale)
         m.global_step += 1
         return m.loss
@@ -59,4 +61,6 @@ class Trainer:
         feed_dict = self.model.get_feed_dict(batch_data, is_train=True)
         layout = self.model.load_inputs(feed_dict, training=True)
         loss = self.step_device(layout)
+        if dist.is_dist():          # report the global-batch mean, like the single-process reference's loss
+            loss = dist.mean_over_ranks(loss.clone())
         return float(loss.item()), None, None

@@ -67,17 +67,27 @@ class Dataset:
         bd["photo_idxs"] = [[[pid2idx[pid] for pid in alb["photo_ids"]] for alb in qa] for qa in per_qa]
         return Dataset(bd, self.datatype, shared=self.shared)
 
-    def get_batches(self, batch_size, num_steps, shuffle=True, cap=False):
+    def get_batches(self, batch_size, num_steps, shuffle=True, cap=False, rank=0, world=1, seed=None):
         """yields (batch_idxs, Dataset) num_steps times; every epoch walks the same (shuffled once) order; `cap` limits
-        the run to one epoch (utils.py:89-198)."""
-        per_epoch = int(math.ceil(self.num_examples / float(batch_size)))
+        the run to one epoch (utils.py:89-198).
+
+        Data parallelism (no counterpart in the reference): with world > 1 every rank must pass the same
+        `seed`; all ranks then walk ONE shuffled order in global batches of batch_size * world and rank r takes the r-th
+        contiguous batch_size slice of each, so an epoch covers every example exactly once across ranks.  The
+        single-process call (world = 1, seed None) is the reference's: one draw from the global `random`."""
+        if world > 1 and shuffle and seed is None:
+            raise ValueError("get_batches: data-parallel ranks need a common shuffle seed")
+        gbs = batch_size * world
+        per_epoch = int(math.ceil(self.num_examples / float(gbs)))
         if cap and num_steps > per_epoch:
             num_steps = per_epoch
         num_epochs = int(math.ceil(num_steps / float(per_epoch)))
-        order = random.sample(list(self.valid_idxs), len(self.valid_idxs)) if shuffle else list(self.valid_idxs)
-        groups = chain.from_iterable(grouper(order, batch_size) for _ in range(num_epochs))
+        rng = random if seed is None else random.Random(seed)
+        order = rng.sample(list(self.valid_idxs), len(self.valid_idxs)) if shuffle else list(self.valid_idxs)
+        groups = chain.from_iterable(grouper(order, gbs) for _ in range(num_epochs))
         for _ in range(num_steps):
-            batch_idxs = tuple(i for i in next(groups) if i is not None)
+            group = next(groups)[rank * batch_size:(rank + 1) * batch_size]
+            batch_idxs = tuple(i for i in group if i is not None)
             yield batch_idxs, self._mini_batch(batch_idxs)
 
 

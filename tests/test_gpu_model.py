@@ -321,3 +321,13 @@ def test_weights_npz_round_trip(tmp_path):
     assert abs(b.window_t - 2.3) < 1e-6
     with pytest.raises(Exception, match="Model not exists"):
         b.load_weights(str(tmp_path / "nope"))
+    # a file holding variables the model has no place for is refused (it would load a different network):
+    # separate fw / bw cells into a share_fw_bw=True model, and the global step travels with the weights
+    c = Model(dict(cfg, share_fw_bw=False), scope="model_fvta", text_in=12, img_in=8)
+    c.global_step = 7
+    c.save_weights(str(tmp_path / "w2"))
+    with pytest.raises(KeyError, match="share_fw_bw=False"):
+        b.load_weights(str(tmp_path / "w2"))
+    d2 = Model(dict(cfg, share_fw_bw=False), scope="x", text_in=12, img_in=8)
+    d2.load_weights(str(tmp_path / "w2"))
+    assert d2.global_step == 7
