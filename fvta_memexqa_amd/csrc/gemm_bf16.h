@@ -55,10 +55,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 //                             4 -> two wave rows of 128 (wave tile 128 x 128, 8 fragments per 16 MFMAs: a third less
 // LDS read traffic per flop; 256 accumulator registers, so one wave per SIMD with the accumulators in AGPRs).  With
 // WN = 2, TM = 4 the 256 x 256 block tile runs on FOUR waves.
-template <int WN, int TM_ = 2>
+//  TM = 1 with WM = 4 wave rows: a 128 x 128 block tile (wave tile 32 x 128), the half-size unit the forward step uses for
+//  the rows that do not fill a whole round of 256-row tiles (launch_step_fwd_bf16).
+template <int WN, int TM_ = 2, int WM_ = 8 / TM_>
 struct TileCfgT {
-  static constexpr int TM = TM_, WAVES_M = 8 / TM_, NWAVES = WAVES_M * WN;
-  static constexpr int BM = 256, BN = 128 * WN, BK = 32, STAGES = 3, NT = 64 * NWAVES;
+  static constexpr int TM = TM_, WAVES_M = WM_, NWAVES = WAVES_M * WN;
+  static constexpr int BM = 32 * TM_ * WM_, BN = 128 * WN, BK = 32, STAGES = 3, NT = 64 * NWAVES;
   static constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;  // per stage
   static constexpr int STAGE_ELEMS = A_ELEMS + B_ELEMS;
   static constexpr int LDS_BYTES = STAGES * STAGE_ELEMS * 2;        // 73,728 (WN = 1)
@@ -68,9 +70,9 @@ struct TileCfgT {
 typedef TileCfgT<1> TileCfg;
 
 // ---- accumulators + fragment reads -------------------------------------------------------------
-template <int WN, int TM_ = 2>
+template <int WN, int TM_ = 2, int WM_ = 8 / TM_>
 struct MmaBT {
-  typedef TileCfgT<WN, TM_> Cfg;
+  typedef TileCfgT<WN, TM_, WM_> Cfg;
   static constexpr int TM = TM_, TN = 4, WAVES_M = Cfg::WAVES_M, WAVES_N = 1, BM = Cfg::BM, BN = Cfg::BN;  // WAVES_N: per wave column
   static constexpr int WROWS = 32 * TM;  // rows of a wave tile
   f32x16 acc[TM][TN];

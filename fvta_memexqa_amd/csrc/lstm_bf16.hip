@@ -98,23 +98,17 @@ __device__ unsigned long long g_lstm_stamps[512];  // diagnostics (FVTA_DEBUG_SK
 
 // ------------------------------------------------------------ forward step --
 // z = [xs_t | hs_{t-1}] * wt^T over the 4 gate strips of 32 units per wave column.
-// grid (pad8(ceil(B/256)), d/(32 WN), 2), 256 WN threads
-template <int WN, int TM>
-__global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lstm_step_fwd_bf16(StepArgs a) {
-  typedef TileCfgT<WN, TM> Cfg;
-  extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
-  int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + Cfg::STAGES * Cfg::STAGE_ELEMS);  // [256], same array
+// One block tile of rows [m0, m0 + Cfg::BM) x the 32 WN units from ub.
+template <int WN, int TM, int WM>
+__device__ __forceinline__ void lstm_step_fwd_tile(const StepArgs& a, bf16_t* smem_h, int64_t* s_oo, int m0, int ub,
+                                                   int dir, int nact) {
+  typedef TileCfgT<WN, TM, WM> Cfg;
   const int tid = threadIdx.x;
-  const int dir = blockIdx.z;
-  const int m0 = blockIdx.x * Cfg::BM;
-  const int nact = a.plan.nactive[a.t];
-  if (m0 >= nact) return;
-  const int ub = blockIdx.y * 32 * WN;  // first unit of the block; wave column wn owns units ub + 32 wn ..
   const int d = a.d, t = a.t, in_i = a.Kp - a.d;
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
-  for (int r = tid; r < 256; r += Cfg::NT) s_oo[r] = (m0 + r < nact) ? a.plan.oo[trow + m0 + r] : -1;
+  for (int r = tid; r < Cfg::BM; r += Cfg::NT) s_oo[r] = (m0 + r < nact) ? a.plan.oo[trow + m0 + r] : -1;
 
-  MmaBT<WN, TM> mma;
+  MmaBT<WN, TM, WM> mma;
   mma.init(tid);
   const int u0 = ub + 32 * mma.wn;
   // A rows m0.. of xs[dir][t] (nact rows) and of hs[dir][t-1]; B rows = the 4 gate strips of wt per wave column
@@ -158,10 +152,10 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
         }
     }
   };
-  if (TM == 2) load_cprev();
+  if (TM != 4) load_cprev();
   if (!(a.dbg & 1)) glds_mainloop<false>(mma, issue, nt, smem_h, st ? st + 8 : nullptr, (a.dbg >> 17) & 3);
   if (st) st[1] = __builtin_readcyclecounter();
-  if (TM != 2) load_cprev();
+  if (TM == 4) load_cprev();
   __syncthreads();  // s_oo visible; every wave is done with the stage buffers, which become the epilogue's scratch
   if (!(a.dbg & 2))
     lstm_gate_epilogue_staged(mma, a, dir, m0, u0, nact, trow, s_oo, cprev,
@@ -173,6 +167,32 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
   }
 }
 
+// grid (pad8(row tiles), d/(32 WN), 2), 64 * 8/TM * WN threads.  Row tiles [0, nbig) are 256 rows; with TM = 2, WN = 1
+// the tiles from nbig on are HALF tiles (128 rows, wave tile 32 x 128): the 256 x 128 tiles of a step do not divide
+// into whole rounds of the chip's workgroup slots (metric shape: 1632 tiles on 512 slots = 3.19 rounds, and the partial
+// round costs a full tile time), so the launcher gives whole rounds to full tiles and covers the remaining rows with
+// units of half the duration.
+template <int WN, int TM>
+__global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lstm_step_fwd_bf16(StepArgs a, int nbig) {
+  typedef TileCfgT<WN, TM> Cfg;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
+  int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + Cfg::STAGES * Cfg::STAGE_ELEMS);  // [256], same array
+  const int dir = blockIdx.z;
+  const int nact = a.plan.nactive[a.t];
+  const int ub = blockIdx.y * 32 * WN;  // first unit of the block; wave column wn owns units ub + 32 wn ..
+  if constexpr (WN == 1 && TM == 2) {
+    if ((int)blockIdx.x >= nbig) {
+      const int m0 = nbig * 256 + ((int)blockIdx.x - nbig) * 128;
+      if (m0 >= nact) return;
+      lstm_step_fwd_tile<1, 1, 4>(a, smem_h, s_oo, m0, ub, dir, nact);
+      return;
+    }
+  }
+  const int m0 = blockIdx.x * Cfg::BM;
+  if (m0 >= nact) return;
+  lstm_step_fwd_tile<WN, TM, 8 / TM>(a, smem_h, s_oo, m0, ub, dir, nact);
+}
+
 int lstm_read_stamp(int i, long long* v) {
   if (i < 0 || i >= 512) return FVTA_ERR_INVALID_ARG;
   unsigned long long x = 0;
@@ -181,7 +201,31 @@ int lstm_read_stamp(int i, long long* v) {
   return FVTA_OK;
 }
 
-static constexpr int FWD_LDS = TileCfg::LDS_BYTES + 256 * 8;
+// Row tiles that get the full 256-row shape: as many as fill WHOLE rounds of the device's workgroup slots (2 per CU for
+// the 256 x 128 kernel); the rest of the rows go to half tiles.  B is the call's sequence count (the active prefix of a
+// ragged batch shrinks with t on the device; the split is a host-side choice made for the full prefix).
+static int fwd_big_row_tiles(int B, int d) {
+  static const int slots = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return 2 * (cus > 0 ? cus : 256);
+  }();
+  // FVTA_LSTM_FWD_TAIL: 0 (default) every row tile full size; 1 whole rounds of full tiles + half tiles for the rest;
+  // 2 force half tiles on the upper half of the rows (tests).  Measured at the metric shape: 5.29 ms per 30 steps
+  // either way -- the partial fourth round already runs faster than a full one, the kernel is bound by the aggregate
+  // L2 -> LDS / HBM traffic, not by the number of rounds.
+  static const int mode = [] {
+    const char* e = getenv("FVTA_LSTM_FWD_TAIL");
+    return e ? atoi(e) : 0;
+  }();
+  const int rt = (B + 255) / 256, per_rt = (d / 32) * 2;  // workgroups per row tile: column blocks x directions
+  if (!mode) return rt;
+  if (mode == 2) return rt / 2;  // tests: force half tiles on small shapes
+  const long long total = (long long)rt * per_rt;
+  if (total % slots == 0 || total < slots) return rt;     // whole rounds already / less than one round
+  const int nbig = (int)((total / slots) * slots / per_rt);
+  return nbig < rt ? nbig : rt;
+}
 
 void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s) {
   // the 256 x 256 tile (8 waves) halves the A-operand re-reads; it needs whole 64-unit column blocks
@@ -191,23 +235,28 @@ void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s) {
     const char* e = getenv("FVTA_LSTM_WIDE_TILE");
     return e && e[0] == '1';
   }();
+  const int rt = (a.B + 255) / 256;
   if (a.d % 64 == 0 && (tile128_mask() & 1)) {  // 256 x 256 block tile on four waves of 128 x 128
     constexpr int LDS = TileCfgT<2, 4>::LDS_BYTES + 256 * 8;
     allow_big_lds(lstm_step_fwd_bf16<2, 4>, LDS);
-    const dim3 grid(pad8((a.B + 255) / 256), a.d / 64, 2);
-    hipLaunchKernelGGL((lstm_step_fwd_bf16<2, 4>), grid, dim3(256), LDS, s, a);
+    const dim3 grid(pad8(rt), a.d / 64, 2);
+    hipLaunchKernelGGL((lstm_step_fwd_bf16<2, 4>), grid, dim3(256), LDS, s, a, rt);
   } else if (a.d % 64 == 0 && wide) {
     constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
     allow_big_lds(lstm_step_fwd_bf16<2, 2>, LDS);
-    const dim3 grid(pad8((a.B + 255) / 256), a.d / 64, 2);
-    hipLaunchKernelGGL((lstm_step_fwd_bf16<2, 2>), grid, dim3(512), LDS, s, a);
+    const dim3 grid(pad8(rt), a.d / 64, 2);
+    hipLaunchKernelGGL((lstm_step_fwd_bf16<2, 2>), grid, dim3(512), LDS, s, a, rt);
   } else {
     constexpr int LDS = TileCfgT<1>::LDS_BYTES + 256 * 8;
     allow_big_lds(lstm_step_fwd_bf16<1, 2>, LDS);
-    const dim3 grid(pad8((a.B + 255) / 256), a.d / 32, 2);
-    hipLaunchKernelGGL((lstm_step_fwd_bf16<1, 2>), grid, dim3(256), LDS, s, a);
+    const int nbig = fwd_big_row_tiles(a.B, a.d);
+    const int nsmall = (a.B - nbig * 256 + 127) / 128;
+    const dim3 grid(pad8(nbig + (nsmall > 0 ? nsmall : 0)), a.d / 32, 2);
+    hipLaunchKernelGGL((lstm_step_fwd_bf16<1, 2>), grid, dim3(256), LDS, s, a, nbig);
   }
 }
+
+static constexpr int FWD_LDS = TileCfg::LDS_BYTES + 256 * 8;
 
 // ----------------------------------------------------------- backward step --
 // [dx_t | . | dh_{t-1}] = dz_t * wb^T : rows x (in_i + d), K = 4d.  grid (pad8(ceil(B/256)), (in_i+d)/128, 2)
