@@ -50,6 +50,9 @@ _SIGS = {
     "fvta_attn_saved_bytes": (c_size_t, [POINTER(AttnDesc)]),
     "fvta_attn_fwd": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_attn_bwd": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P]),
+    "fvta_attn_fwd_tw": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_attn_bwd_tw": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P]),
+    "fvta_timewarp_bwd_att": (c_int, [POINTER(TimewarpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_lstm_plan_bytes": (c_size_t, [POINTER(LstmDesc)]),
     "fvta_lstm_saved_bytes": (c_size_t, [POINTER(LstmDesc)]),
     "fvta_lstm_workspace_bytes": (c_size_t, [POINTER(LstmDesc)]),

@@ -32,6 +32,7 @@ struct AttnBwdWork {
   float* rowp;   // [N*ng][bsplit][RH][2][w]    d Rh, d R2 partials
   float* pvec;   // [N * JZ][5][w]             parameter-vector partials per n and group of 8 question positions
   float* dctn;   // [N][JP]
+  float* dscr;   // [N,K,T] time_warp_att: per-row terms of d tscale[n,t] (summed over k in a fixed order afterwards)
   size_t bytes;
   size_t slab_bytes;
 };
@@ -49,6 +50,7 @@ static AttnBwdWork bwd_work_view(const AttnShape& s, void* p) {
   v.dss = c.take<float>(nk);
   v.pvec = c.take<float>((size_t)s.N * attn_bwd_jz(s) * VEC_COUNT * s.w);
   v.dctn = c.take<float>((size_t)s.N * s.JP);
+  v.dscr = c.take<float>(nk * s.T);
   const size_t before = c.off;
   const size_t ngr = (size_t)s.N * s.ng;
   v.slabs = c.take<float>(ngr * s.bsplit * RH * s.JP * s.w);
@@ -105,6 +107,7 @@ struct AttnBwdArgs {
   const float* d_h_a;
   float* d_hinfo;
   int accumulate;
+  const float* tscale;  // [N,T] or null (time_warp_att): the inner softmax ran on z = amax * tscale
 };
 
 // TPR threads cover one row (16 B each, G float4 per thread when w > 1024);
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   __shared__ int s_tt[TR], s_jj[TR];
   // the workgroup's group of consecutive k: per-k scalars, and the start of each k's rows in the concatenated list
   __shared__ int s_kbase[17];
-  __shared__ float s_kM[16], s_kcoef[16], s_kgu[16], s_kdss[16];
+  __shared__ float s_kM[16], s_kMz[16], s_kcoef[16], s_kgu[16], s_kdss[16];
   __shared__ uint8_t s_kallm[16];
 
   const AttnShape& s = a.s;
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   }
   if (tid < nkl) {
     s_kM[tid] = a.sv.M[nk + tid];
+    s_kMz[tid] = a.sv.Mz[nk + tid];
     s_kcoef[tid] = a.wk.coef[nk + tid];
     s_kgu[tid] = a.wk.gu[nk + tid];
     s_kdss[tid] = a.wk.dss[nk + tid];
@@ -331,9 +335,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
         const int kl = t / T;
         const float M = s_kM[kl];
         const float am = amax[t];
-        pr = expf(am - M) * s_kcoef[kl];
+        // z = am * tscale[n,t] under time_warp_att (model_v2.py:269-275); p = softmax_t(z), d z = p (g.h - g.u)
+        const float sc = a.tscale ? a.tscale[(size_t)n * T + (t - kl * T)] : 1.f;
+        pr = expf(tw_logit(am, sc) - s_kMz[kl]) * s_kcoef[kl];
+        const float dz = pr * (gh - s_kgu[kl]);
+        if (a.tscale) a.wk.dscr[(size_t)nk * T + t] = dz * am;  // d tscale[n,t] += d z * amax (also for -1e30 rows, as TF)
         if (!s_kallm[kl]) {  // fully masked rows: am = -1e30, no gradient into the masked logits
-          const float damax = pr * (gh - s_kgu[kl]) + (am == M ? s_kdss[kl] : 0.f);
+          const float damax = dz * sc + (am == M ? s_kdss[kl] : 0.f);
           dx = s.add_tanh ? damax * (1.f - am * am) : damax;
           if (cosine) {  // x = (h.qn) * rh with rh = rsqrt(max(|h|^2, eps)) (model_v2.py:250-254): am IS x
             const float rhn = rsqrtf(fmaxf(hh, 1e-12f));
@@ -516,6 +524,87 @@ __global__ __launch_bounds__(256) void attn_bwd_params_kernel(AttnShape s, AttnB
   }
 }
 
+// ---- time_warp_att: the masked rows that carry softmax weight (see attn_pad_terms_kernel in attn_fwd.hip): their
+// direct term p r g into d_hinfo and their share of d tscale (d z * -1e30, as TF computes it).  No gradient into the
+// masked logits themselves (deviation (b)).  grid N*K, 256 threads.
+__global__ __launch_bounds__(256) void attn_bwd_pad_kernel(AttnBwdArgs a, const uint8_t* __restrict__ hmask) {
+  __shared__ float s_red[4];
+  __shared__ int s_list[256];
+  __shared__ int s_n;
+  const AttnShape& s = a.s;
+  const int nk = blockIdx.x, n = nk / s.K, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int T = s.T, w = s.w;
+  if (a.sv.allmasked[nk]) return;
+  const uint8_t* hm = hmask + (size_t)nk * T;
+  const float* sc = a.tscale + (size_t)n * T;
+  const float Mz = a.sv.Mz[nk], L = a.sv.L[nk], coef = a.wk.coef[nk];
+  const float* g = a.d_h_a + (size_t)n * w;
+  // Two passes over the masked rows that carry weight.  Pass 0 sums their weights and weighted g.h; when they hold
+  // ALL of the softmax's weight (the usual case: exp() of every valid row's logit underflows against +1e30) the mean
+  // g.u the softmax gradient subtracts is taken from these very sums, so that a single winner gets d z = 0 EXACTLY, as
+  // TF's p (g - sum p g) does -- it is multiplied by -1e30 on its way into d tscale.
+  float wsum = 0.f, gsum = 0.f, gbar = a.wk.gu[nk];
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int t0 = 0; t0 < T; t0 += 256) {
+      __syncthreads();
+      if (tid == 0) s_n = 0;
+      __syncthreads();
+      const int t = t0 + tid;
+      const bool on = t < T && !hm[t] && tw_logit(FVTA_NEG, sc[t]) >= Mz - 104.f;
+      // ascending t within the chunk (ballot ranks), chunks in order: the sums below run in a fixed order
+      const unsigned long long bal = __ballot(on);
+      if (lane == 0) s_red[wave] = (float)__popcll(bal);
+      __syncthreads();
+      int base = 0;
+      for (int v = 0; v < wave; ++v) base += (int)s_red[v];
+      if (on) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = t;
+      if (tid == 0) s_n = (int)(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+      __syncthreads();
+      const int cnt = s_n;
+      for (int i = 0; i < cnt; ++i) {
+        const int tt = s_list[i];
+        const float wt = expf(tw_logit(FVTA_NEG, sc[tt]) - Mz);
+        const float pr = wt * coef;
+        const float* row = a.hinfo + ((size_t)nk * T + tt) * w;
+        float* drow = a.d_hinfo + ((size_t)nk * T + tt) * w;
+        float dot = 0.f;
+        for (int c = 4 * tid; c < w; c += 1024) {
+          const f32x4 hv = ld4b(row + c), gv = ld4b(g + c);
+          const f32x4 pdt = hv * gv;
+          dot += (pdt[0] + pdt[1]) + (pdt[2] + pdt[3]);
+          if (pass == 1) {
+            f32x4 dh = gv * pr;
+            if (a.accumulate != 2) dh += ld4b(drow + c);  // modes 0/3 zeroed the row first, mode 1 accumulates; 2: plain store
+            *reinterpret_cast<f32x4*>(drow + c) = dh;
+          }
+        }
+        dot = wave_sum(dot);
+        __syncthreads();
+        if (lane == 0) s_red[wave] = dot;
+        __syncthreads();
+        dot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        if (pass == 0) {
+          wsum += wt;
+          gsum += wt * dot;
+        } else if (tid == 0) {
+          a.wk.dscr[(size_t)nk * T + tt] = pr * (dot - gbar) * FVTA_NEG;
+        }
+      }
+    }
+    if (pass == 0 && wsum == L) gbar = gsum / L;  // the masked rows hold all the weight
+  }
+}
+
+// d_tscale[n,t] += sum_k dscr[n,k,t], fixed order
+__global__ void attn_bwd_dscale_kernel(AttnShape s, const float* __restrict__ dscr, float* __restrict__ d_tscale) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= s.N * s.T) return;
+  const int n = pos / s.T, t = pos % s.T;
+  float acc = 0.f;
+  for (int k = 0; k < s.K; ++k) acc += dscr[((size_t)n * s.K + k) * s.T + t];
+  d_tscale[pos] += acc;
+}
+
 }  // namespace fvta
 
 using namespace fvta;
@@ -527,7 +616,16 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
                              const uint8_t* qmask, const float* W, const float* b, const float* d_h_a,
                              const void* saved, float* d_hinfo, float* d_hq, float* dW, float* db, int accumulate,
                              void* workspace, fvta_stream_t stream_) {
+  return fvta_attn_bwd_tw(d, hinfo, hq, hmask, qmask, W, b, nullptr, d_h_a, saved, d_hinfo, d_hq, dW, db, nullptr,
+                          accumulate, workspace, stream_);
+}
+
+extern "C" int fvta_attn_bwd_tw(const fvta_attn_desc* d, const float* hinfo, const float* hq, const uint8_t* hmask,
+                                const uint8_t* qmask, const float* W, const float* b, const float* tscale,
+                                const float* d_h_a, const void* saved, float* d_hinfo, float* d_hq, float* dW, float* db,
+                                float* d_tscale, int accumulate, void* workspace, fvta_stream_t stream_) {
   if (int e = fvta_attn_check_desc(d)) return e;
+  FVTA_CHECK_ARG((tscale == nullptr) == (d_tscale == nullptr), "attn_bwd: tscale and d_tscale go together");
   FVTA_CHECK_ARG(hinfo && hq && d_h_a && saved && d_hinfo && d_hq && workspace, "attn_bwd: null pointer");
   FVTA_CHECK_ARG(d->simi == 4 || (dW && db), "attn_bwd: dW/db required");
   hipStream_t stream = (hipStream_t)stream_;
@@ -537,6 +635,7 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
   AttnBwdWork wk = bwd_work_view(s, workspace);
   const int RH = bwd_rh(s.W4);
   FVTA_CHECK_HIP(hipMemsetAsync(wk.slabs, 0, wk.slab_bytes, stream));
+  if (tscale) FVTA_CHECK_HIP(hipMemsetAsync(wk.dscr, 0, (size_t)s.N * s.K * s.T * sizeof(float), stream));
   if (accumulate == 0 || accumulate == 3)
     FVTA_CHECK_HIP(hipMemsetAsync(d_hinfo, 0, (size_t)s.N * s.K * s.T * s.w * sizeof(float), stream));
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(s.N), dim3(256), 0, stream, s, sv, wk, d_h_a);
@@ -548,6 +647,7 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
   a.d_h_a = d_h_a;
   a.d_hinfo = d_hinfo;
   a.accumulate = accumulate;
+  a.tscale = tscale;
   const dim3 grid(s.bsplit, s.N * s.ng);
   const bool prof_it = (size_t)s.N * s.K * s.T >= 65536;  // the context attention, see attn_fwd.hip
   if (prof_it) fvta_prof_begin(FVTA_PROF_ATTN_BWD_MAIN, stream);
@@ -570,6 +670,11 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
   }
   if (prof_it) fvta_prof_end(FVTA_PROF_ATTN_BWD_MAIN, 1, stream);
   FVTA_CHECK_LAUNCH("attn_bwd_main");
+  if (tscale) {
+    if (use_mask) hipLaunchKernelGGL(attn_bwd_pad_kernel, dim3(s.N * s.K), dim3(256), 0, stream, a, hmask);
+    hipLaunchKernelGGL(attn_bwd_dscale_kernel, dim3((s.N * s.T + 255) / 256), dim3(256), 0, stream, s, wk.dscr, d_tscale);
+    FVTA_CHECK_LAUNCH("attn_bwd_tw");
+  }
   if (s.simi == 4) {
     hipLaunchKernelGGL(attn_bwd_cosine_q_kernel, dim3(s.N * s.JQ), dim3(256), 0, stream, s, wk, RH, hq, d_hq, accumulate);
   } else {

@@ -59,6 +59,18 @@ inline AttnShape attn_shape(const fvta_attn_desc* d, bool use_mask) {
   return s;
 }
 
+#ifdef __HIPCC__
+// The softmax logit of a row under time_warp_att: amax * tscale as a ROUNDED fp32 product.  Written as a plain `a * b - m`
+// the compiler contracts it into fma(a, b, -m); for masked rows a = -1e30 and m is the (rounded) maximum of the same
+// products, so the unrounded product differs from m by ~1e30 * 2^-24 = 6e22 and exp() of that is inf.
+// (an opaque v_mul_f32: HIP's __fmul_rn is a plain `x * y` and contracts just the same)
+__device__ __forceinline__ float tw_logit(float amax, float tscale) {
+  float r;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(amax), "v"(tscale));
+  return r;
+}
+#endif
+
 // per-channel vectors of the bilinear form, float [5][w]: U, Rh, R2, Cq, C2
 enum { VEC_U = 0, VEC_RH = 1, VEC_R2 = 2, VEC_CQ = 3, VEC_C2 = 4, VEC_COUNT = 5 };
 
@@ -70,7 +82,8 @@ struct AttnSaved {
   int32_t* cnt;    // [N,K] rows in the list
   int32_t* allmasked;  // [N,K] 1: no valid (t,j) pair -> softmax goes uniform over all T
   float* M;        // [N,K] max_t amax  (= reduce_max [3,2], model_v2.py:278)
-  float* L;        // [N,K] sum_t exp(amax - M)
+  float* Mz;       // [N,K] max_t of the inner softmax's logits z = amax * tscale (time_warp_att, model_v2.py:269-275); = M without it
+  float* L;        // [N,K] sum_t exp(z - Mz)
   float* r;        // [N,K] softmax_k(M)
   float* u;        // [N,K,w] inner softsel result
   float* Qs;       // [N][W4][JP][4] pre-scaled question, MFMA-B friendly
@@ -91,6 +104,7 @@ inline AttnSaved attn_saved_view(const AttnShape& s, void* p) {
   v.cnt = c.take<int32_t>(nk);
   v.allmasked = c.take<int32_t>(nk);
   v.M = c.take<float>(nk);
+  v.Mz = c.take<float>(nk);
   v.L = c.take<float>(nk);
   v.r = c.take<float>(nk);
   v.u = c.take<float>(nk * s.w);

@@ -197,7 +197,8 @@ struct AttnFwdArgs {
   AttnSaved sv;
   const float* hinfo;
   float* a_logits;  // may be null
-  float* part;      // [N*K][nsplit][w+4] : m, l, -, -, u[w]
+  float* part;      // [N*K][nsplit][w+4] : m, l, mu, -, u[w]   (m: max of the softmax logits z, mu: max of amax)
+  const float* tscale;  // [N,T] or null: z[n,k,t] = amax[n,k,t] * tscale[n,t] (time_warp_att)
   int ipw;          // 16-row kernel: items per workgroup
   int dbg;          // FVTA_ATTN_DBG experiment bits (diagnostics only)
 };
@@ -207,7 +208,9 @@ struct AttnFwdArgs {
 // rg = lane / SCW) holds rows rg + RGN*p.  The 32 x (w / NSLAB) row slab lives in
 // registers (NSC * P float4 per lane) between the score pass and the weighted
 // sum, so NSC * P is kept <= 16: wide rows use 8 waves, not more sub-chunks.
-template <int SCW, int NSC, int NSLAB, int JT, int NW>
+// TW: time_warp_att (the softmax over t runs on amax * tscale[n,t]) -- a compile-time flag: the widest shapes sit at
+// the 256-VGPR limit and must not pay for it when it is off.
+template <int SCW, int NSC, int NSLAB, int JT, int NW, bool TW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_main(AttnFwdArgs a) {
   constexpr int NT = NW * 64;
   constexpr int RGN = 64 / SCW;
@@ -226,7 +229,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_main(AttnFw
   __shared__ __attribute__((aligned(16))) float s_vec[2][4 * SLAB4 * NSLAB];
   __shared__ float s_rt[NW][32];
   __shared__ int s_t[32];
-  __shared__ float s_amax[32];
+  __shared__ float s_amax[32];  // the inner softmax's logits z of the tile's rows
+  __shared__ float s_amu[32];   // amax itself (differs from z under time_warp_att)
+  __shared__ float s_mu_run;    // running max of amax over the workgroup's rows
   __shared__ float s_p[32];
 
   const AttnShape& s = a.s;
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_main(AttnFw
     if (tid == 0) {
       part[0] = -INFINITY;
       part[1] = 0.f;
+      part[2] = -INFINITY;
     }
     return;
   }
@@ -272,6 +278,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_main(AttnFw
 #pragma unroll
     for (int sc = 0; sc < NSC; ++sc) uacc[sl][sc] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
+  if (TW && tid == 0) s_mu_run = -INFINITY;  // (thread 0 alone keeps it: no register per lane)
   float* stage = s_stage[wave];
   float* bq = s_bq[wave];
   const __amdgpu_buffer_rsrc_t rq =
@@ -429,16 +436,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_main(AttnFw
         if (jg == 0) {
           if (t >= 0) {
             const float av = s.add_tanh ? tanhf(best) : best;
-            s_amax[row] = av;
+            s_amax[row] = TW ? tw_logit(av, a.tscale[(size_t)n * T + t]) : av;
+            if (TW) s_amu[row] = av;
             a.sv.amax[(size_t)nk * T + t] = av;
             a.sv.jmax[(size_t)nk * T + t] = (uint8_t)bestj;
           } else {
             s_amax[row] = -INFINITY;
+            if (TW) s_amu[row] = -INFINITY;
           }
         }
       }
     } else {
-      if (tid < 32) s_amax[tid] = s_t[tid] >= 0 ? FVTA_NEG : -INFINITY;
+      if (tid < 32) {
+        const int t = s_t[tid];
+        s_amax[tid] = t >= 0 ? (TW ? tw_logit(FVTA_NEG, a.tscale[(size_t)n * T + t]) : FVTA_NEG) : -INFINITY;
+        if (TW) s_amu[tid] = t >= 0 ? FVTA_NEG : -INFINITY;
+      }
       load_slab(NSLAB - 1);
     }
     __syncthreads();
@@ -446,6 +459,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_main(AttnFw
     float mt = s_amax[0];
 #pragma unroll
     for (int r = 1; r < 32; ++r) mt = fmaxf(mt, s_amax[r]);
+    if (TW && tid == 0) {
+      float mut = s_mu_run;
+      for (int r = 0; r < 32; ++r) mut = fmaxf(mut, s_amu[r]);
+      s_mu_run = mut;
+    }
     const float m_new = fmaxf(m_run, mt);
     const float scale = expf(m_run - m_new);
     if (tid < 32) s_p[tid] = expf(s_amax[tid] - m_new);
@@ -492,6 +510,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_main(AttnFw
   if (tid == 0) {
     part[0] = m_run;
     part[1] = l_run;
+    part[2] = TW ? s_mu_run : m_run;
   }
 }
 
@@ -668,6 +687,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(Attn
       float* part = a.part + (size_t)item * (w + 4);
       part[0] = -INFINITY;
       part[1] = 0.f;
+      part[2] = -INFINITY;
     }
   }
   for (int c = tid; c < w; c += NT) {
@@ -902,6 +922,7 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(Attn
       if (tid == 0) {
         part[0] = m_run;
         part[1] = l_run;
+        part[2] = m_run;  // no time_warp_att in this kernel: the softmax logits are amax itself
       }
     }
   };
@@ -921,33 +942,130 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(Attn
 #undef FVTA_STAMP
 }
 
+// ---- time_warp_att only: the MASKED rows of a (n,k) that has valid rows.  The reference scales the max-pooled logit
+// AFTER exp_mask (model_v2.py:263-275), so a masked row's softmax logit is -1e30 * tscale[n,t]: hugely negative for
+// tscale > 0 (weight exactly 0, as exp underflows), but +huge for tscale < 0 -- then the masked rows take the whole
+// softmax (one-hot on the smallest tscale, uniform over exact ties; rows that are padding for every modality share one
+// c[n,t] and tie).  The main kernels read valid rows only; this kernel adds the masked rows' share as one more partial
+// (m, l, u) per (n,k), gathering the few rows that carry weight.  grid N*K, 256 threads.
+constexpr float EXP_CUT = 104.f;  // expf(x) == 0 in fp32 below about -103.97
+__global__ __launch_bounds__(256) void attn_pad_terms_kernel(AttnShape s, AttnSaved sv, const float* __restrict__ hinfo,
+                                                             const uint8_t* __restrict__ hmask,
+                                                             const float* __restrict__ tscale,
+                                                             const float* __restrict__ part, float* __restrict__ padpart) {
+  __shared__ float s_red[4];
+  __shared__ int s_list[256];
+  __shared__ float s_wt[256];
+  __shared__ int s_n;
+  const int nk = blockIdx.x, n = nk / s.K, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int T = s.T, w = s.w;
+  float* pd = padpart + (size_t)nk * (w + 4);
+  const uint8_t* hm = hmask + (size_t)nk * T;
+  const float* sc = tscale + (size_t)n * T;
+  float Mv = -INFINITY;
+  for (int sp = 0; sp < s.nsplit; ++sp) Mv = fmaxf(Mv, part[((size_t)nk * s.nsplit + sp) * (w + 4)]);
+  float zp = -INFINITY;
+  if (!sv.allmasked[nk])  // (a fully masked (n,k) runs all its T rows through the main kernel already)
+    for (int t = tid; t < T; t += 256)
+      if (!hm[t]) zp = fmaxf(zp, tw_logit(FVTA_NEG, sc[t]));
+  zp = wave_max(zp);
+  if (lane == 0) s_red[wave] = zp;
+  __syncthreads();
+  zp = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  if (!(zp >= Mv - EXP_CUT)) {  // no masked rows, or every one of them underflows to weight 0
+    if (tid == 0) {
+      pd[0] = -INFINITY;
+      pd[1] = 0.f;
+      pd[2] = -INFINITY;
+    }
+    return;
+  }
+  float lsum = 0.f;
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // channels 4 tid .. (w <= 2048)
+  for (int t0 = 0; t0 < T; t0 += 256) {
+    __syncthreads();
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int t = t0 + tid;
+    if (t < T && !hm[t]) {
+      const float z = tw_logit(FVTA_NEG, sc[t]);
+      if (z >= zp - EXP_CUT) {
+        const int slot = atomicAdd(&s_n, 1);  // (order within the chunk is irrelevant only for the list; the sums
+        s_list[slot] = t;                     //  below run over the sorted list: fixed order)
+        s_wt[slot] = expf(z - zp);
+      }
+    }
+    __syncthreads();
+    const int cnt = s_n;
+    if (tid == 0) {  // insertion sort by t: a handful of rows in practice
+      for (int i = 1; i < cnt; ++i) {
+        const int tv = s_list[i];
+        const float wv = s_wt[i];
+        int j = i - 1;
+        while (j >= 0 && s_list[j] > tv) {
+          s_list[j + 1] = s_list[j];
+          s_wt[j + 1] = s_wt[j];
+          --j;
+        }
+        s_list[j + 1] = tv;
+        s_wt[j + 1] = wv;
+      }
+    }
+    __syncthreads();
+    for (int i = 0; i < cnt; ++i) {
+      const float wt = s_wt[i];
+      lsum += wt;
+      const float* row = hinfo + ((size_t)nk * T + s_list[i]) * w;
+      if (4 * tid < w) acc[0] += ld4g(row + 4 * tid) * wt;
+      if (4 * tid + 1024 < w) acc[1] += ld4g(row + 4 * tid + 1024) * wt;
+    }
+  }
+  if (4 * tid < w) *reinterpret_cast<f32x4*>(pd + 4 + 4 * tid) = acc[0];
+  if (4 * tid + 1024 < w) *reinterpret_cast<f32x4*>(pd + 4 + 4 * tid + 1024) = acc[1];
+  if (tid == 0) {
+    pd[0] = zp;
+    pd[1] = lsum;
+    pd[2] = -INFINITY;
+  }
+}
+
 // ---- merge: splits -> u[n,k], M, L; softmax over K; h_a.  grid (N, w/256), 256 threads: one channel per thread
 constexpr int MERGE_MAXP = 2048;  // K * nsplit partials of one n whose weights are cached in LDS
 __global__ __launch_bounds__(256) void attn_merge_kernel(AttnShape s, AttnSaved sv, const float* __restrict__ part,
-                                                         float* __restrict__ h_a) {
-  __shared__ float s_M[64], s_L[64], s_r[64];
-  __shared__ float s_wt[MERGE_MAXP];  // exp(m_split - M_k) / L_k, 0 for empty splits
+                                                         const float* __restrict__ padpart, float* __restrict__ h_a) {
+  __shared__ float s_M[64], s_Mz[64], s_L[64], s_r[64], s_pw[64];
+  __shared__ float s_wt[MERGE_MAXP];  // exp(m_split - Mz_k), 0 for empty splits
   const int n = blockIdx.x, tid = threadIdx.x;
   const int w = s.w, K = s.K, ns = s.nsplit;
   const size_t pstride = (size_t)(w + 4);
   for (int k = tid; k < K; k += 256) {
     const float* pp = part + ((size_t)(n * K + k) * ns) * pstride;
-    float M = -INFINITY;
-    for (int sp = 0; sp < ns; ++sp) M = fmaxf(M, pp[(size_t)sp * pstride]);
+    const float* pd = padpart ? padpart + (size_t)(n * K + k) * pstride : nullptr;
+    const bool pad = pd && pd[1] > 0.f;
+    float Mz = pad ? pd[0] : -INFINITY, Mu = -INFINITY;
+    for (int sp = 0; sp < ns; ++sp) {
+      Mz = fmaxf(Mz, pp[(size_t)sp * pstride]);
+      Mu = fmaxf(Mu, pp[(size_t)sp * pstride + 2]);
+    }
     float L = 0.f;
     for (int sp = 0; sp < ns; ++sp) {
       const float l = pp[(size_t)sp * pstride + 1];
-      if (l > 0.f) L += l * expf(pp[(size_t)sp * pstride] - M);
+      if (l > 0.f) L += l * expf(pp[(size_t)sp * pstride] - Mz);
     }
-    s_M[k] = M;
+    const float pw = pad ? expf(pd[0] - Mz) : 0.f;
+    if (pad) L += pd[1] * pw;
+    s_M[k] = Mu;
+    s_Mz[k] = Mz;
     s_L[k] = L;
+    s_pw[k] = pw;
     if (blockIdx.y == 0) {
-      sv.M[n * K + k] = M;
+      sv.M[n * K + k] = Mu;
+      sv.Mz[n * K + k] = Mz;
       sv.L[n * K + k] = L;
     }
   }
   __syncthreads();
-  if (tid == 0) {  // outer softsel over K (model_v2.py:278)
+  if (tid == 0) {  // outer softsel over K (model_v2.py:278): logits = max over (t, j) of the masked logits, unscaled
     float mx = -INFINITY;
     for (int k = 0; k < K; ++k) mx = fmaxf(mx, s_M[k]);
     float sum = 0.f;
@@ -965,7 +1083,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnShape s, AttnSaved 
     for (int i = tid; i < K * ns; i += 256) {
       const int k = i / ns;
       const float* pp = part + ((size_t)n * K * ns + i) * pstride;
-      s_wt[i] = pp[1] > 0.f ? expf(pp[0] - s_M[k]) : 0.f;
+      s_wt[i] = pp[1] > 0.f ? expf(pp[0] - s_Mz[k]) : 0.f;
     }
   __syncthreads();
   const int c = blockIdx.y * 256 + tid;
@@ -979,10 +1097,11 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnShape s, AttnSaved 
       if (cached) {
         wt = s_wt[k * ns + sp];
       } else {
-        wt = pp[(size_t)sp * pstride + 1] > 0.f ? expf(pp[(size_t)sp * pstride] - s_M[k]) : 0.f;
+        wt = pp[(size_t)sp * pstride + 1] > 0.f ? expf(pp[(size_t)sp * pstride] - s_Mz[k]) : 0.f;
       }
       if (wt != 0.f) u += pp[(size_t)sp * pstride + 4 + c] * wt;  // (empty splits hold no vector)
     }
+    if (s_pw[k] != 0.f) u += padpart[(size_t)(n * K + k) * pstride + 4 + c] * s_pw[k];
     u /= s_L[k];
     sv.u[((size_t)n * K + k) * w + c] = u;
     ha += s_r[k] * u;
@@ -995,10 +1114,15 @@ template <int SCW1, int NSC1, int SCW2, int NSC2, int NSLAB, int NW>
 static int launch_main(const AttnFwdArgs& a, hipStream_t stream) {
   const int nitems = a.s.nsplit * a.s.N * a.s.K;
   const dim3 grid(((nitems + 7) / 8) * 8);
-  if (a.s.JT == 1)
-    hipLaunchKernelGGL((attn_fwd_main<SCW1, NSC1, NSLAB, 1, NW>), grid, dim3(NW * 64), 0, stream, a);
+  if (a.tscale) {
+    if (a.s.JT == 1)
+      hipLaunchKernelGGL((attn_fwd_main<SCW1, NSC1, NSLAB, 1, NW, true>), grid, dim3(NW * 64), 0, stream, a);
+    else
+      hipLaunchKernelGGL((attn_fwd_main<SCW2, NSC2, NSLAB, 2, NW, true>), grid, dim3(NW * 64), 0, stream, a);
+  } else if (a.s.JT == 1)
+    hipLaunchKernelGGL((attn_fwd_main<SCW1, NSC1, NSLAB, 1, NW, false>), grid, dim3(NW * 64), 0, stream, a);
   else
-    hipLaunchKernelGGL((attn_fwd_main<SCW2, NSC2, NSLAB, 2, NW>), grid, dim3(NW * 64), 0, stream, a);
+    hipLaunchKernelGGL((attn_fwd_main<SCW2, NSC2, NSLAB, 2, NW, false>), grid, dim3(NW * 64), 0, stream, a);
   return 0;
 }
 
@@ -1028,7 +1152,8 @@ size_t fvta_attn_bwd_workspace_bytes(const AttnShape& s);  // attn_bwd.hip
 extern "C" size_t fvta_attn_workspace_bytes(const fvta_attn_desc* d) {
   if (fvta_attn_check_desc(d)) return 0;
   const AttnShape s = attn_shape(d, true);
-  const size_t fwd = fvta_align_up((size_t)s.N * s.K * s.nsplit * (s.w + 4) * sizeof(float), 256);
+  // forward: the split partials, then one more partial per (n,k) for the masked rows' share under time_warp_att
+  const size_t fwd = fvta_align_up((size_t)s.N * s.K * (s.nsplit + 1) * (s.w + 4) * sizeof(float), 256);
   const size_t bwd = fvta_attn_bwd_workspace_bytes(s);
   return fwd > bwd ? fwd : bwd;
 }
@@ -1036,6 +1161,12 @@ extern "C" size_t fvta_attn_workspace_bytes(const fvta_attn_desc* d) {
 extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const float* hq, const uint8_t* hmask,
                              const uint8_t* qmask, const float* W, const float* b, float* h_a, float* a_logits,
                              void* saved, void* workspace, fvta_stream_t stream_) {
+  return fvta_attn_fwd_tw(d, hinfo, hq, hmask, qmask, W, b, nullptr, h_a, a_logits, saved, workspace, stream_);
+}
+
+extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, const float* hq, const uint8_t* hmask,
+                                const uint8_t* qmask, const float* W, const float* b, const float* tscale, float* h_a,
+                                float* a_logits, void* saved, void* workspace, fvta_stream_t stream_) {
   if (int e = fvta_attn_check_desc(d)) return e;
   FVTA_CHECK_ARG(hinfo && hq && h_a && saved && workspace, "attn_fwd: null pointer");
   FVTA_CHECK_ARG(d->simi == 4 || (W && b), "attn_fwd: W and b required for simiMatrix 1-3");
@@ -1058,6 +1189,7 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
   a.hinfo = hinfo;
   a.a_logits = a_logits;
   a.part = (float*)workspace;
+  a.tscale = tscale;
   a.ipw = 1;
   a.dbg = fvta_diag_env("FVTA_ATTN_DBG", 0);  // -DFVTA_DIAG builds only
   // (the bracket files the context attention only: the K = 1 question attention is a 15 us launch of the same kernel)
@@ -1065,7 +1197,8 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
   if (prof_it) fvta_prof_begin(FVTA_PROF_ATTN_FWD_MAIN, stream);
   const char* exact = getenv("FVTA_ATTN_EXACT");
   // (the full logit tensor is an inspection output: only the general kernel writes it)
-  const bool rows16 = s.JT == 1 && s.w >= 128 && s.w <= 1024 && !a_logits && !(exact && exact[0] == '1');
+  // (time_warp_att runs on the general kernel: the 16-row kernel's softmax logits are amax itself)
+  const bool rows16 = s.JT == 1 && s.w >= 128 && s.w <= 1024 && !a_logits && !tscale && !(exact && exact[0] == '1');
   if (rows16) {
     // a workgroup streams `ipw` consecutive items: about one workgroup per CU, bounded by its LDS row list
     const int nitems = s.nsplit * s.N * s.K;
@@ -1107,7 +1240,13 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
   }
   if (prof_it) fvta_prof_end(FVTA_PROF_ATTN_FWD_MAIN, 1, stream);
   FVTA_CHECK_LAUNCH("attn_fwd_main");
-  hipLaunchKernelGGL(attn_merge_kernel, dim3(s.N, (s.w + 255) / 256), dim3(256), 0, stream, s, sv, a.part, h_a);
+  float* padpart = nullptr;
+  if (tscale && use_mask) {
+    padpart = a.part + (size_t)s.N * s.K * s.nsplit * (s.w + 4);
+    hipLaunchKernelGGL(attn_pad_terms_kernel, dim3(s.N * s.K), dim3(256), 0, stream, s, sv, hinfo, hmask, tscale, a.part,
+                       padpart);
+  }
+  hipLaunchKernelGGL(attn_merge_kernel, dim3(s.N, (s.w + 255) / 256), dim3(256), 0, stream, s, sv, a.part, padpart, h_a);
   FVTA_CHECK_LAUNCH("attn_merge");
   return FVTA_OK;
 }

@@ -123,11 +123,12 @@ __global__ void tw_rowdot_kernel(fvta_timewarp_desc d, const float* __restrict__
 }
 
 // dz[n,t] = (sum_k dsk) * cnt(t) * (1 - c^2)
-__global__ void tw_dz_kernel(fvta_timewarp_desc d, int win, const float* __restrict__ c_saved, TwWork wk) {
+__global__ void tw_dz_kernel(fvta_timewarp_desc d, int win, const float* __restrict__ c_saved, TwWork wk,
+                             const float* __restrict__ d_scale_att) {
   const int pos = blockIdx.x * blockDim.x + threadIdx.x;
   if (pos >= d.N * d.T) return;
   const int n = pos / d.T, t = pos % d.T;
-  float ds = 0.f;
+  float ds = d_scale_att ? d_scale_att[pos] : 0.f;  // time_warp_att: the attention's own gradient w.r.t. c[n,t] cnt(t)
   for (int k = 0; k < d.K; ++k) ds += wk.dsk[((size_t)n * d.K + k) * d.T + t];
   const float c = c_saved[pos];
   wk.dz[pos] = ds * tw_count(t, d.T, d.warp_type, win) * (1.f - c * c);
@@ -248,6 +249,15 @@ extern "C" int fvta_timewarp_bwd(const fvta_timewarp_desc* d, const float* hall,
                                  const float* WH_b, const float* WC_W, const float* WC_b, const float* c_saved,
                                  const float* d_warp, float* d_hall, float* d_lq, float* dWH_W, float* dWH_b,
                                  float* dWC_W, float* dWC_b, void* workspace, fvta_stream_t stream_) {
+  return fvta_timewarp_bwd_att(d, hall, lq, WH_W, WH_b, WC_W, WC_b, c_saved, d_warp, nullptr, d_hall, d_lq, dWH_W, dWH_b,
+                               dWC_W, dWC_b, workspace, stream_);
+}
+
+extern "C" int fvta_timewarp_bwd_att(const fvta_timewarp_desc* d, const float* hall, const float* lq, const float* WH_W,
+                                     const float* WH_b, const float* WC_W, const float* WC_b, const float* c_saved,
+                                     const float* d_warp, const float* d_scale_att, float* d_hall, float* d_lq,
+                                     float* dWH_W, float* dWH_b, float* dWC_W, float* dWC_b, void* workspace,
+                                     fvta_stream_t stream_) {
   if (int e = check_tw(d)) return e;
   FVTA_CHECK_ARG(hall && lq && WH_W && WH_b && WC_W && WC_b && c_saved && d_warp && d_hall && d_lq && dWH_W && dWH_b &&
                      dWC_W && dWC_b && workspace,
@@ -260,7 +270,7 @@ extern "C" int fvta_timewarp_bwd(const fvta_timewarp_desc* d, const float* hall,
                      wk);
   const size_t rows = (size_t)d->N * d->K * d->T;
   hipLaunchKernelGGL(tw_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *d, hall, d_warp, wk.dsk);
-  hipLaunchKernelGGL(tw_dz_kernel, dim3((d->N * d->T + 255) / 256), dim3(256), 0, s, *d, win, c_saved, wk);
+  hipLaunchKernelGGL(tw_dz_kernel, dim3((d->N * d->T + 255) / 256), dim3(256), 0, s, *d, win, c_saved, wk, d_scale_att);
   hipLaunchKernelGGL(tw_apply_bwd_kernel, dim3(wk.nwg), dim3(256), 0, s, *d, win, hall, d_warp, c_saved, wk, d_hall);
   hipLaunchKernelGGL(tw_reduce_kernel, dim3(d->w + d->N), dim3(256), 0, s, *d, wk);
   hipLaunchKernelGGL(tw_param_bwd_kernel, dim3(d->w), dim3(256), 0, s, *d, WH_W, WH_b, WC_W, lq, wk, d_lq, dWH_W, dWH_b,

@@ -111,6 +111,16 @@ def exp_mask(val, mask):
     return out
 
 
+def linear_raw(x, W, b, add_tanh=False):
+    """flatten(x, 1) . W [in, out] + b through fvta_linear_fwd with explicit weights (no variable scope)"""
+    x = _f32(x)
+    din, dout = x.shape[-1], W.shape[1]
+    y = torch.empty(*x.shape[:-1], dout, dtype=torch.float32, device=x.device)
+    check(_lib.load().fvta_linear_fwd(ptr(x), ptr(_f32(W)), ptr(b), ptr(y), x.numel() // din, din, dout, int(add_tanh),
+                                      stream_ptr()), "fvta_linear_fwd")
+    return y
+
+
 def linear(x, output_size, scope, add_tanh=False, wd=None):
     x = _f32(x)
     din = x.shape[-1]
@@ -134,7 +144,7 @@ def _pad_channels(t, wp):
     return out
 
 
-def _attention(hinfo, hq, hinfo_mask, hq_mask, simiMatrix, wd, add_tanh, scope, feat_order):
+def _attention(hinfo, hq, hinfo_mask, hq_mask, simiMatrix, wd, add_tanh, scope, feat_order, tscale=None):
     """hinfo [N,K,T,w] -> (h_a [N,w], a_logits [N,K,T,JQ]) through fvta_attn_fwd; w is zero padded to a kernel width
     (exact: a zero channel adds nothing to any feature of any similarity), W block-wise with it."""
     if simiMatrix not in (1, 2, 3, 4):
@@ -161,20 +171,27 @@ def _attention(hinfo, hq, hinfo_mask, hq_mask, simiMatrix, wd, add_tanh, scope, 
     both = hinfo_mask is not None and hq_mask is not None                  # model_v2.py:146 / 233: only when BOTH are given
     hm = ops.as_mask_u8(hinfo_mask.reshape(N, K, T)) if both else None
     qm = ops.as_mask_u8(hq_mask) if both else None
-    h_a, a = op.forward(_pad_channels(hinfo, wp), _pad_channels(hq, wp), hm, qm, W, b, want_logits=True)
+    h_a, a = op.forward(_pad_channels(hinfo, wp), _pad_channels(hq, wp), hm, qm, W, b, want_logits=True, tscale=tscale)
     return h_a[:, :w].contiguous(), a
 
 
 def attention_3d(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, wd=None, add_tanh=False, time_warp_att=False,
                  C=None, bidirect=False, scope=None):
     """hinfo [N,K,M,JX,w] (or [N,K,T,w]), hq [N,JQ,w], masks [N,K,M,JX] / [N,JQ] -> (h_a [N,w], a_logits [N,K,T,JQ])."""
-    if time_warp_att:
-        raise NotImplementedError("time_warp_att (model_v2.py:269-275) is not built")
     if bidirect:
         raise NotImplementedError("bidirect: the 3-D branch cannot run in the reference either (SURVEY 3.5)")
     N, K, w = hinfo.shape[0], hinfo.shape[1], hinfo.shape[-1]
+    tscale = None
+    if time_warp_att:
+        if C is None:
+            raise ValueError("time_warp_att needs C [N,T,T] (model_v2.py:269-275)")
+        # model_v2.py:269-275: a_logits_maxed[n,k,t] * sum_t' C[n,t,t'] -- the row sums of C [N,T,T] as a linear layer
+        # with an all-ones weight (fvta_linear_fwd)
+        C = _f32(C)
+        T = C.shape[-1]
+        tscale = linear_raw(C.reshape(N * T, T), torch.ones(T, 1, dtype=torch.float32, device=C.device), None).reshape(N, T)
     return _attention(hinfo.reshape(N, K, -1, w), hq, hinfo_mask, hq_mask, simiMatrix, wd, add_tanh,
-                      scope or "attention_2vector", 0)
+                      scope or "attention_2vector", 0, tscale=tscale)
 
 
 def attention(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, wd=None, add_tanh=False, bidirect=False, scope=None):

@@ -127,8 +127,11 @@ class Model:
         self.window_t = float(_cfg(config, "window_t", 3.0))     # time_warp_window_t, init 3.0 (model_v2.py:333); no gradient
         if self.use_time_warp and self.warp_type not in (1, 2, 3, 4, 5):
             raise Exception("time warping type not implemented")    # model_v2.py:341
-        if _cfg(config, "use_time_warp_att", False):
-            raise NotImplementedError("use_time_warp_att is not built yet")
+        # model_v2.py:1020 passes C (defined only inside the use_time_warp block, :995) to attention_3d: without the
+        # time warp the reference's graph construction fails on the undefined name
+        self.use_time_warp_att = bool(_cfg(config, "use_time_warp_att", False))
+        if self.use_time_warp_att and not self.use_time_warp:
+            raise NameError("name 'C' is not defined (use_time_warp_att needs use_time_warp, model_v2.py:995, 1020)")
         if _cfg(config, "use_bidirection", False):
             raise NotImplementedError("use_bidirection: the 3-D branch cannot run in the reference either (SURVEY 3.5)")
         if self.simi not in (1, 2, 3, 4):
@@ -560,6 +563,7 @@ class Model:
             L.warp_h = torch.zeros(N, K, T, wp, dtype=torch.float32, device=dev)
             L.d_warp = torch.zeros(N, K, T, wp, dtype=torch.float32, device=dev) if training else None
             L.d_lq = torch.zeros(N, wp, dtype=torch.float32, device=dev) if training else None
+            L.d_tscale = torch.zeros(N, T, dtype=torch.float32, device=dev) if (training and self.use_time_warp_att) else None
         L.y = torch.zeros(N, C, dtype=torch.uint8, device=dev)
         self._layouts[key] = L
         return L
@@ -754,7 +758,9 @@ class Model:
             ctx = self.warp_h = L.warp_h
             self.C = L.tw.c                                                 # c[n,t]; the reference's C[n,t,t'] = c[n,t]
         L.ctx = ctx
-        L.g1, att = L.att.forward(ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, W, b, want_logits)  # :1020
+        # :1020; time_warp_att: the softmax over t runs on amax * sum_t' C[n,t,t'] = amax * c[n,t] cnt(t) (:269-275)
+        L.tscale = L.tw.scale if self.use_time_warp_att else None
+        L.g1, att = L.att.forward(ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, W, b, want_logits, tscale=L.tscale)
         if self.use_question_att:                                           # :1044
             Wq = P.view(self.N_QATT_W) if self.simi != 4 else None
             bq = P.view(self.N_QATT_B) if self.simi != 4 else None
@@ -801,12 +807,15 @@ class Model:
         if self.use_time_warp:
             # attention gradient w.r.t. the warped tensor (masked rows zeroed: the warp backward walks every row),
             # then through the warp into the hall rows of the arena and into lq -> the question encoder's last state
+            if L.d_tscale is not None:
+                L.d_tscale.zero_()
             L.att.backward(L.ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, L.d_warp, d_hq, daW, dab,
-                           accumulate=3)
+                           accumulate=3, tscale=L.tscale, d_tscale=L.d_tscale)
             L.d_lq.zero_()
             L.tw.backward(L.hall, L.lq, P.view(self.N_TW_WH_W), P.view(self.N_TW_WH_B), P.view(self.N_TW_WC_W),
                           P.view(self.N_TW_WC_B), L.d_warp, d_hall, L.d_lq, P.view(self.N_TW_WH_W, True),
-                          P.view(self.N_TW_WH_B, True), P.view(self.N_TW_WC_W, True), P.view(self.N_TW_WC_B, True))
+                          P.view(self.N_TW_WH_B, True), P.view(self.N_TW_WC_W, True), P.view(self.N_TW_WC_B, True),
+                          d_scale_att=L.d_tscale)
             T.op.last_state_bwd(L.d_lq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
         else:
             L.att.backward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, d_hall, d_hq, daW, dab,

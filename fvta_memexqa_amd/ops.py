@@ -176,18 +176,21 @@ class FocalAttention:
         self.work = _bytes(self.lib.fvta_attn_workspace_bytes(r), self.dev)
         self.N, self.K, self.T, self.JQ, self.w = N, K, T, JQ, w
 
-    def forward(self, hinfo, hq, hmask, qmask, W, b, want_logits=False):
+    def forward(self, hinfo, hq, hmask, qmask, W, b, want_logits=False, tscale=None):
+        """tscale [N,T] (time_warp_att, model_v2.py:269-275): the softmax over t runs on amax * tscale."""
         h_a = torch.empty(self.N, self.w, device=self.dev, dtype=torch.float32)
         a_logits = torch.empty(self.N, self.K, self.T, self.JQ, device=self.dev, dtype=torch.float32) if want_logits else None
-        check(self.lib.fvta_attn_fwd(ctypes.byref(self.desc), ptr(_f32c(hinfo)), ptr(_f32c(hq)), ptr(hmask), ptr(qmask),
-                                     ptr(W), ptr(b), ptr(h_a), ptr(a_logits), ptr(self.saved), ptr(self.work),
-                                     stream_ptr()), "fvta_attn_fwd")
+        check(self.lib.fvta_attn_fwd_tw(ctypes.byref(self.desc), ptr(_f32c(hinfo)), ptr(_f32c(hq)), ptr(hmask), ptr(qmask),
+                                        ptr(W), ptr(b), ptr(tscale), ptr(h_a), ptr(a_logits), ptr(self.saved),
+                                        ptr(self.work), stream_ptr()), "fvta_attn_fwd")
         return h_a, a_logits
 
-    def backward(self, hinfo, hq, hmask, qmask, W, b, d_h_a, d_hinfo, d_hq, dW, db, accumulate):
-        check(self.lib.fvta_attn_bwd(ctypes.byref(self.desc), ptr(hinfo), ptr(hq), ptr(hmask), ptr(qmask), ptr(W),
-                                     ptr(b), ptr(_f32c(d_h_a)), ptr(self.saved), ptr(d_hinfo), ptr(d_hq), ptr(dW),
-                                     ptr(db), int(accumulate), ptr(self.work), stream_ptr()), "fvta_attn_bwd")
+    def backward(self, hinfo, hq, hmask, qmask, W, b, d_h_a, d_hinfo, d_hq, dW, db, accumulate, tscale=None,
+                 d_tscale=None):
+        check(self.lib.fvta_attn_bwd_tw(ctypes.byref(self.desc), ptr(hinfo), ptr(hq), ptr(hmask), ptr(qmask), ptr(W),
+                                        ptr(b), ptr(tscale), ptr(_f32c(d_h_a)), ptr(self.saved), ptr(d_hinfo), ptr(d_hq),
+                                        ptr(dW), ptr(db), ptr(d_tscale), int(accumulate), ptr(self.work), stream_ptr()),
+              "fvta_attn_bwd")
 
 
 def as_mask_u8(m):
@@ -285,11 +288,13 @@ class TimeWarp:
                                          ptr(WC_W), ptr(WC_b), ptr(_f32c(warp_h)), ptr(self.c), ptr(self.scale),
                                          ptr(self.work), stream_ptr()), "fvta_timewarp_fwd")
 
-    def backward(self, hall, lq, WH_W, WH_b, WC_W, WC_b, d_warp, d_hall, d_lq, dWH_W, dWH_b, dWC_W, dWC_b):
-        check(self.lib.fvta_timewarp_bwd(ctypes.byref(self.desc), ptr(hall), ptr(lq), ptr(WH_W), ptr(WH_b), ptr(WC_W),
-                                         ptr(WC_b), ptr(self.c), ptr(_f32c(d_warp)), ptr(d_hall), ptr(d_lq), ptr(dWH_W),
-                                         ptr(dWH_b), ptr(dWC_W), ptr(dWC_b), ptr(self.work), stream_ptr()),
-              "fvta_timewarp_bwd")
+    def backward(self, hall, lq, WH_W, WH_b, WC_W, WC_b, d_warp, d_hall, d_lq, dWH_W, dWH_b, dWC_W, dWC_b,
+                 d_scale_att=None):
+        """d_scale_att [N,T]: the attention's gradient w.r.t. the per-position scale (use_time_warp_att)."""
+        check(self.lib.fvta_timewarp_bwd_att(ctypes.byref(self.desc), ptr(hall), ptr(lq), ptr(WH_W), ptr(WH_b), ptr(WC_W),
+                                             ptr(WC_b), ptr(self.c), ptr(_f32c(d_warp)), ptr(d_scale_att), ptr(d_hall),
+                                             ptr(d_lq), ptr(dWH_W), ptr(dWH_b), ptr(dWC_W), ptr(dWC_b), ptr(self.work),
+                                             stream_ptr()), "fvta_timewarp_bwd")
 
 
 # ------------------------------------------------------- embedding front-end

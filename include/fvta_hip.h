@@ -84,6 +84,19 @@ int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const float* hq, 
                   const void* saved, float* d_hinfo, float* d_hq, float* dW, float* db, int accumulate,
                   void* workspace, fvta_stream_t stream);
 
+/* attention_3d(..., time_warp_att=True, C=C): model_v2.py:269-275.  The max-pooled logits are multiplied by the
+ * row sums of C before the softmax over t: tscale [N,T] = sum_t' C[n,t,t'] (with the model's time warp, c[n,t] cnt(t) =
+ * fvta_timewarp_fwd's scale_out).  The softmax over K keeps the unscaled maxima.  The reference scales AFTER exp_mask,
+ * so a masked row's logit is -1e30 * tscale: for tscale < 0 the masked rows take the softmax; the kernels
+ * reproduce that.  tscale NULL = fvta_attn_fwd / fvta_attn_bwd.  d_tscale [N,T] is accumulated into. */
+int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, const float* hq, const uint8_t* hmask,
+                     const uint8_t* qmask, const float* W, const float* b, const float* tscale, float* h_a,
+                     float* a_logits, void* saved, void* workspace, fvta_stream_t stream);
+int fvta_attn_bwd_tw(const fvta_attn_desc* d, const float* hinfo, const float* hq, const uint8_t* hmask,
+                     const uint8_t* qmask, const float* W, const float* b, const float* tscale, const float* d_h_a,
+                     const void* saved, float* d_hinfo, float* d_hq, float* dW, float* db, float* d_tscale,
+                     int accumulate, void* workspace, fvta_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * bi-LSTM modality encoders: model_v2.py:652-661 (cells), 667-678 (lengths),
  * 694/732/747/760/774/789/802/823 (the eight bidirectional_dynamic_rnn calls)
@@ -216,6 +229,13 @@ int fvta_timewarp_bwd(const fvta_timewarp_desc* d, const float* hall, const floa
                       const float* WH_b, const float* WC_W, const float* WC_b, const float* c_saved,
                       const float* d_warp, float* d_hall, float* d_lq, float* dWH_W, float* dWH_b, float* dWC_W,
                       float* dWC_b, void* workspace, fvta_stream_t stream);
+
+/* The same with the attention's gradient w.r.t. the per-position scale (fvta_attn_bwd_tw's d_tscale, [N,T]; NULL =
+ * fvta_timewarp_bwd): use_time_warp_att feeds c[n,t] cnt(t) into the attention as well (model_v2.py:1020). */
+int fvta_timewarp_bwd_att(const fvta_timewarp_desc* d, const float* hall, const float* lq, const float* WH_W,
+                          const float* WH_b, const float* WC_W, const float* WC_b, const float* c_saved,
+                          const float* d_warp, const float* d_scale_att, float* d_hall, float* d_lq, float* dWH_W,
+                          float* dWH_b, float* dWC_W, float* dWC_b, void* workspace, fvta_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Embedding front-end (model_v2.py:524-645): what turns the

@@ -184,6 +184,24 @@ def time_warp_closed(hall, lq, WH_W, WH_b, WC_W, WC_b, warp_type=1, window_t=3.0
     return (h * scale[:, None, :, None]).reshape(hall.shape), c
 
 
+def time_indication_band(T, warp_type=1, window_t=3.0, dtype=torch.float32):
+    """the 0/1 factor time_indication_func multiplies C with (model_v2.py:301-341): [T,T]"""
+    import math
+    ones = torch.ones(T, T, dtype=dtype)
+    if warp_type == 1:
+        return ones
+    if warp_type == 2:
+        return torch.eye(T, dtype=dtype)
+    if warp_type == 3:
+        return torch.tril(ones)
+    if warp_type == 4:
+        return torch.triu(ones)
+    if warp_type == 5:
+        win = int(math.ceil(window_t))
+        return torch.triu(torch.tril(ones, win), -win)
+    raise Exception("time warping type not implemented")
+
+
 # ------------------------------------------------- embedding front-end ---
 def conv1d(x, filt, bias):
     """model_v2.py:52-70 (keep_prob = 1) as an unfold + matmul: x [B, JX, W, cdim], filt [1, height, cdim, cwdim]."""
@@ -308,8 +326,14 @@ def fvta_forward(params, inputs, cfg):
         out["c_warp"] = c
     out["hall"] = hall
     qmask = inputs["q"]["mask"]
+    twa = bool(cfg.get("use_time_warp_att", False))            # model_v2.py:1020: C of the time-warp block (:995)
+    C = None
+    if twa:
+        T = out["c_warp"].shape[1]
+        C = out["c_warp"][:, :, None] * time_indication_band(T, cfg.get("warp_type", 1), float(params.get("window_t", 3.0)),
+                                                             out["c_warp"].dtype)[None]
     g1, att = attention_3d(hall, hq, params.get("att_W"), params.get("att_b"), hall_mask, qmask,
-                           simiMatrix=cfg["simiMatrix"], add_tanh=cfg.get("add_tanh", False))
+                           simiMatrix=cfg["simiMatrix"], add_tanh=cfg.get("add_tanh", False), time_warp_att=twa, C=C)
     out["g1_all"], out["att_logits"] = g1, att
     if cfg.get("use_question_att", False):
         N = hq.shape[0]

@@ -489,10 +489,13 @@ def fvta_forward(params, inputs, cfg):
         hall, Cl, C = time_warp_literal(hall, lq, params["WH_W"], params["WH_b"], params["WC_W"],
                                         params["WC_b"], cfg.get("warp_type", 1), params.get("window_t", 3.0))
         out["C"] = Cl
+        out["C_masked"] = C                                # after time_indication_func (:995): what attention_3d gets
     out["hall"] = hall
     qmask = np.asarray(inputs["q"]["mask"], bool)
+    twa = bool(cfg.get("use_time_warp_att", False))
     g1, att = attention_3d(hall, hq, params.get("att_W"), params.get("att_b"), hall_mask, qmask,
-                           simiMatrix=cfg["simiMatrix"], add_tanh=cfg.get("add_tanh", False))  # :1020
+                           simiMatrix=cfg["simiMatrix"], add_tanh=cfg.get("add_tanh", False),
+                           time_warp_att=twa, C=out["C_masked"] if twa else None)              # :1020, C of :995
     out["g1_all"], out["att_logits"] = g1, att
     if cfg.get("use_question_att", False):                # :1044
         N = hq.shape[0]

@@ -119,7 +119,33 @@ def test_unknown_similarity_and_unbuilt_switches():
     with pytest.raises(ValueError, match="similarity matrix not implemented"):
         Fn.attention_3d(h, q, simiMatrix=5)
     with pytest.raises(NotImplementedError):
-        Fn.attention_3d(h, q, time_warp_att=True)
+        Fn.attention_3d(h, q, bidirect=True)                 # shape error in the reference's 3-D branch too
+
+
+def test_attention_3d_functional_time_warp_att():
+    """attention_3d(..., time_warp_att=True, C=C) with the reference's keyword signature: C [N,T,T] arbitrary (its row
+    sums scale the max-pooled logits, model_v2.py:269-275), masks given, vs the literal oracle."""
+    from fvta_memexqa_amd import functional as Fn
+    from oracle import fvta_literal as L
+    Fn.reset_default_graph()
+    g = torch.Generator().manual_seed(21)
+    N, K, M, JX, JQ, w = 2, 3, 2, 6, 4, 64
+    T = M * JX
+    h = torch.randn(N, K, M, JX, w, generator=g) * 0.5
+    q = torch.randn(N, JQ, w, generator=g) * 0.5
+    hm = torch.rand(N, K, M, JX, generator=g) < 0.7
+    hm[:, :, 0, 0] = True
+    qm = torch.ones(N, JQ, dtype=torch.bool)
+    C = torch.randn(N, T, T, generator=g) * 0.4
+    ha, a = Fn.attention_3d(h.cuda(), q.cuda(), hm.cuda(), qm.cuda(), simiMatrix=2, add_tanh=True, time_warp_att=True,
+                            C=C.cuda(), scope="tw")
+    W = Fn.variables["tw/att_logits/W"].cpu().double().numpy()
+    b = Fn.variables["tw/att_logits/b"].cpu().double().numpy()
+    ref, ref_a = L.attention_3d(h.double().numpy(), q.double().numpy(), W, b, hm.numpy(), qm.numpy(), simiMatrix=2,
+                                add_tanh=True, time_warp_att=True, C=C.double().numpy())
+    _close(ha, torch.from_numpy(ref), rtol=2e-4, atol=2e-5)
+    with pytest.raises(ValueError, match="time_warp_att"):
+        Fn.attention_3d(h.cuda(), q.cuda(), time_warp_att=True)
 
 
 @pytest.mark.parametrize("simi,masked,w", [(1, True, 64), (2, True, 100), (3, False, 128)])

@@ -45,3 +45,106 @@ def test_unknown_warp_type_raises_like_the_reference():
     from fvta_memexqa_amd import ops
     with pytest.raises(Exception, match="time warping type not implemented"):
         ops.TimeWarp(1, 1, 4, 64, 9)
+
+
+def _close(a, b, rtol=1e-4, atol=1e-5):
+    a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, np.float64)
+    b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, np.float64)
+    scale = max(1.0, float(np.abs(b).max())) if b.size else 1.0
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol * scale)
+
+
+def _tw_att_case(seed, N, K, T, JQ, w, simi, tanh, neg_scale, ties, all_masked_k=None):
+    g = torch.Generator().manual_seed(seed)
+    h = torch.randn(N, K, T, w, generator=g) * 0.5
+    q = torch.randn(N, JQ, w, generator=g) * 0.5
+    F_ = {1: 3, 2: 2, 3: 4}[simi]
+    W = torch.randn(F_ * w, 1, generator=g) * 0.1
+    b = torch.randn(1, generator=g) * 0.1
+    lens = torch.randint(1, T + 1, (N, K), generator=g)
+    hm = torch.arange(T)[None, None, :] < lens[:, :, None]
+    if all_masked_k is not None:
+        hm[:, all_masked_k] = False
+    qm = torch.arange(JQ)[None, :] < torch.randint(1, JQ + 1, (N,), generator=g)[:, None]
+    scale = torch.rand(N, T, generator=g) * 1.5 + 0.2
+    if neg_scale:
+        scale = torch.where(torch.rand(N, T, generator=g) < 0.4, -scale, scale)
+    if ties:                       # the rows that are padding for every k share one scale (same c[n,t], same count)
+        allpad = ~hm.any(1)
+        scale = torch.where(allpad, torch.full_like(scale, -2.37), scale)
+        # ... and, as in the model, they are zero rows (LSTM outputs past the length; the warp keeps zeros zero).  With
+        # non-zero tied rows TF also pushes gradient through the MASKED logits (DESIGN.md deviation (b)), which the
+        # kernels do not; partially padded positions keep random values (their scales differ: one winner, d z = 0)
+        h = h * (~allpad)[:, None, :, None]
+    return h, q, W, b, hm, qm, scale
+
+
+@pytest.mark.parametrize("N,K,T,JQ,w,simi,tanh,neg,ties,amk", [
+    (3, 3, 40, 5, 64, 2, True, False, False, None), (3, 3, 40, 5, 64, 2, True, True, False, None),
+    (4, 2, 70, 7, 128, 1, False, True, True, None), (2, 4, 300, 30, 256, 3, True, True, True, 1),
+    (2, 6, 1200, 30, 1024, 2, True, True, True, None)])
+def test_attention_3d_time_warp_att_forward_backward(N, K, T, JQ, w, simi, tanh, neg, ties, amk):
+    """fvta_attn_fwd_tw / fvta_attn_bwd_tw against the fp64 oracle: positive scales, negative scales on masked rows
+    (they take the softmax), tied masked rows, a fully masked modality; h_a, and the gradients w.r.t. hinfo, hq, W, b
+    and the scale itself."""
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    h, q, W, b, hm, qm, scale = _tw_att_case(N * 7 + T, N, K, T, JQ, w, simi, tanh, neg, ties, amk)
+    leaves = [t.double().requires_grad_() for t in (h, q, W, b, scale)]
+    C = torch.diag_embed(leaves[4])                                       # [N,T,T] with row sums = scale
+    ref, _ = F.attention_3d(leaves[0], leaves[1], leaves[2], leaves[3], hm, qm, simiMatrix=simi, add_tanh=tanh,
+                            time_warp_att=True, C=C)
+    gout = torch.randn(N, w, generator=torch.Generator().manual_seed(5)).double()
+    (ref * gout).sum().backward()
+    op = ops.FocalAttention(N, K, T, JQ, w, simi, tanh)
+    cu = lambda t: t.float().cuda().contiguous()
+    hd, qd, Wd, bd, sd = cu(h), cu(q), cu(W).reshape(-1), cu(b), cu(scale)
+    hmd, qmd = ops.as_mask_u8(hm).cuda(), ops.as_mask_u8(qm).cuda()
+    ha, _ = op.forward(hd, qd, hmd, qmd, Wd, bd, tscale=sd)
+    _close(ha, ref.detach(), rtol=1e-4, atol=2e-5)
+    d_h, d_q = torch.empty_like(hd), torch.empty_like(qd)
+    dW, db, dsc = torch.zeros_like(Wd), torch.zeros_like(bd), torch.zeros_like(sd)
+    op.backward(hd, qd, hmd, qmd, Wd, bd, cu(gout), d_h, d_q, dW, db, accumulate=0, tscale=sd, d_tscale=dsc)
+    _close(d_h, leaves[0].grad, rtol=2e-4, atol=2e-5)
+    _close(d_q, leaves[1].grad, rtol=2e-4, atol=2e-5)
+    _close(dW, leaves[2].grad.reshape(-1), rtol=2e-4, atol=2e-5)
+    _close(db, leaves[3].grad, rtol=2e-4, atol=2e-5)
+    # d scale: rows that take the whole softmax carry 0 * 1e30-scale terms; compare where the oracle's is finite and sane
+    gs = leaves[4].grad
+    ok = gs.abs() < 1e6
+    _close(dsc.cpu().double()[ok], gs[ok], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("warp_type", [1, 5])
+def test_model_with_time_warp_att(warp_type):
+    """--use_time_warp --use_time_warp_att through the Model: forward and every parameter gradient vs the oracle."""
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params, to_dtype
+    from oracle import fvta_fused as F
+    spec = SynthSpec(N=3, A=2, P=3, S=2, L=5, d=32, SA=1, dense=False, text_in=12, img_in=8)
+    params, inputs = make_params(spec), make_inputs(spec)
+    g = torch.Generator().manual_seed(17)
+    w = spec.w
+    params.update(WH_W=torch.randn(2 * w, w, generator=g) * 0.05, WH_b=torch.randn(w, generator=g) * 0.05,
+                  WC_W=torch.randn(w, 1, generator=g) * 0.1, WC_b=torch.randn(1, generator=g) * 0.05)
+    cfg = dict(spec.cfg(), use_time_warp=True, use_time_warp_att=True, warp_type=warp_type, window_t=1.4)
+    p64 = {k: v.double().requires_grad_() for k, v in params.items()}
+    ref = F.fvta_forward(dict(p64, window_t=1.4), to_dtype(inputs, torch.float64), cfg)
+    ref["loss"].backward()
+    assert (ref["c_warp"] < 0).any()
+    model = Model(dict(cfg, batch_size=spec.N), text_in=spec.text_in, img_in=spec.img_in)
+    model.set_oracle_params(params)
+    L = model.load_inputs(inputs, training=True)
+    model.zero_grad()
+    yp = model.forward(L)
+    model.backward(L)
+    d, dp = model.d, model.dp
+    unpad = lambda t: torch.cat([t[..., :d], t[..., dp:dp + d]], -1)
+    _close(unpad(L.g1), ref["g1_all"].detach(), rtol=1e-4, atol=2e-5)
+    _close(yp, ref["yp"].detach(), rtol=1e-4, atol=1e-5)
+    grads = model.get_oracle_grads()
+    for k, v in p64.items():
+        if v.grad is not None:
+            _close(torch.from_numpy(grads[k]).reshape(v.grad.shape), v.grad, rtol=2e-4, atol=2e-5)
+    with pytest.raises(NameError):
+        Model(dict(spec.cfg(), use_time_warp_att=True, batch_size=spec.N), text_in=spec.text_in, img_in=spec.img_in)

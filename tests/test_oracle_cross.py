@@ -55,6 +55,27 @@ def test_time_warp_closed_form_matches_literal(warp_type):
     np.testing.assert_allclose(of["yp"].numpy(), ol["yp"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("warp_type", [1, 3, 5])
+def test_time_warp_att_literal_matches_fused(warp_type):
+    """use_time_warp_att (model_v2.py:269-275, 1020) through both whole-path restatements, ragged lengths (masked rows
+    whose scale is negative take the softmax over t: the scale is applied AFTER exp_mask)."""
+    spec = SynthSpec(N=3, A=1, P=3, S=2, L=3, d=4, dense=False, text_in=8, img_in=8)
+    g = torch.Generator().manual_seed(11)
+    w = spec.w
+    extra = dict(WH_W=torch.randn(2 * w, w, generator=g, dtype=torch.float64) * 0.3,
+                 WH_b=torch.randn(w, generator=g, dtype=torch.float64) * 0.3,
+                 WC_W=torch.randn(w, 1, generator=g, dtype=torch.float64) * 0.5,
+                 WC_b=torch.randn(1, generator=g, dtype=torch.float64) * 0.1,
+                 window_t=1.3)
+    of, ol = _run_both(spec, dict(use_time_warp=True, use_time_warp_att=True, warp_type=warp_type), extra)
+    assert (of["c_warp"] < 0).any() and (of["c_warp"] > 0).any()         # both signs of the scale occur
+    np.testing.assert_allclose(of["g1_all"].numpy(), ol["g1_all"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(of["yp"].numpy(), ol["yp"], rtol=1e-9)
+    # and it differs from the run without it
+    of0, _ = _run_both(spec, dict(use_time_warp=True, warp_type=warp_type), extra)
+    assert np.abs(of0["g1_all"].numpy() - of["g1_all"].numpy()).max() > 1e-6
+
+
 def test_plumbing_config_fp32_agree():
     """BASELINE.json configs[0] shape, fp32 both sides: <=1e-5."""
     from fvta_memexqa_amd.synth import CONFIGS

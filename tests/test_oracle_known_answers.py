@@ -157,3 +157,35 @@ def test_tf_softmax_xent_gradient_on_all_false_label_rows():
     assert float(loss_m) == float(loss)
     np.testing.assert_allclose(lm.grad[:2].numpy(), lt.grad[:2].numpy(), rtol=1e-12)   # rows with one label agree
     assert (lm.grad[2] == 0).all()                                                      # the mathematical form: nothing
+
+
+def test_time_warp_att_masked_rows_with_negative_scale_take_the_softmax():
+    """model_v2.py:263-275: the scale sum_t' C[n,t,t'] multiplies the max-pooled logits AFTER exp_mask, so a masked
+    row's softmax logit is -1e30 * scale.  scale > 0 everywhere: masked rows weigh 0 and u is the softmax over the
+    valid rows of amax * scale.  One masked row with scale < 0: it takes ALL the weight, u = that row's h.  Two masked
+    rows tied at the smallest scale: they share it equally."""
+    rng = np.random.default_rng(3)
+    N, K, T, JQ, w = 1, 1, 6, 2, 4
+    h = rng.standard_normal((N, K, 1, T, w))
+    q = rng.standard_normal((N, JQ, w))
+    hm = np.zeros((N, K, 1, T), bool)
+    hm[..., :3] = True                                     # rows 3, 4, 5 are masked
+    qm = np.ones((N, JQ), bool)
+    W, b = np.zeros((2 * w, 1)), np.array([0.4])           # a = tanh(0.4) on valid cells
+    am = math.tanh(0.4)
+
+    def run(scale):
+        C = np.diag(scale)[None]                           # row sums = scale
+        ha, _ = _both_att3d(h, q, W, b, hm, qm, simiMatrix=2, add_tanh=True, time_warp_att=True, C=C)
+        return ha[0]
+
+    s_pos = np.array([0.5, 1.0, 2.0, 0.3, 0.7, 0.9])
+    p = np.exp(am * s_pos[:3])
+    p /= p.sum()
+    np.testing.assert_allclose(run(s_pos), (p[:, None] * h[0, 0, 0, :3]).sum(0), rtol=1e-12)
+    s_neg = s_pos.copy()
+    s_neg[4] = -0.2                                        # masked row 4: logit +2e29
+    np.testing.assert_allclose(run(s_neg), h[0, 0, 0, 4], rtol=1e-12)
+    s_tie = s_pos.copy()
+    s_tie[3] = s_tie[5] = -0.6
+    np.testing.assert_allclose(run(s_tie), 0.5 * (h[0, 0, 0, 3] + h[0, 0, 0, 5]), rtol=1e-12)
