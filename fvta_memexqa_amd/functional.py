@@ -194,24 +194,52 @@ def attention_3d(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, wd=None
                       scope or "attention_2vector", 0, tscale=tscale)
 
 
+def _wsum(target, weights):
+    """sum_j weights[r,j] * target[r,j,:] -> [rows, d] (fvta_wsum_fwd)"""
+    target, weights = _f32(target), _f32(weights)
+    rows, J, d = target.shape
+    out = torch.empty(rows, d, dtype=torch.float32, device=target.device)
+    check(_lib.load().fvta_wsum_fwd(ptr(target), ptr(weights), ptr(out), rows, J, d, stream_ptr()), "fvta_wsum_fwd")
+    return out
+
+
+def _bidirect_q_a(a_logits, hq, lead):
+    """the reversed-direction vector of the `bidirect` branch (model_v2.py:184-188, model.py:169-174, 297-304):
+    q_a = reduce_mean over the V rows of softsel(q_aug, a_logits), i.e. every row (masked ones included: their logits are
+    all -1e30, so they attend the question uniformly) softmaxes its JQ logits and averages the question with them.
+    a_logits [*lead, V, JQ], hq [N, JQ, w] -> [*lead, w].  Three launches: softmax over JQ, the mean over V of the
+    weights (the average commutes with the weighted sum), the weighted sum of the question vectors."""
+    V, JQ = a_logits.shape[-2], a_logits.shape[-1]
+    G = int(torch.tensor(lead).prod().item()) if len(lead) else 1
+    p = softmax(a_logits)                                                   # [*lead, V, JQ]
+    ones = torch.full((G, V), 1.0 / V, dtype=torch.float32, device=p.device)
+    pbar = _wsum(p.reshape(G, V, JQ), ones)                                 # [G, JQ]
+    N = hq.shape[0]
+    per_n = G // N                                                          # (n, m) groups share n's question
+    q = _f32(hq)
+    if per_n > 1:
+        q = q[:, None].expand(N, per_n, JQ, q.shape[-1]).reshape(G, JQ, q.shape[-1])
+    return _wsum(q, pbar).reshape(*lead, q.shape[-1])
+
+
 def attention(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, wd=None, add_tanh=False, bidirect=False, scope=None):
-    """hinfo [N,...,w] flattened to [N,V,w] (model_v2.py:133) -> (h_a [N,w], a_logits [N,V,JQ])."""
-    if bidirect:
-        raise NotImplementedError("bidirect (model_v2.py:176-190) is not built")
+    """hinfo [N,...,w] flattened to [N,V,w] (model_v2.py:133) -> (h_a [N,w], a_logits [N,V,JQ]); with `bidirect`
+    h_a is [N,2w] = concat([h_a, q_a]) (model_v2.py:184-192)."""
     N, w = hinfo.shape[0], hinfo.shape[-1]
     h = hinfo.reshape(N, 1, -1, w)
     hm = hinfo_mask.reshape(N, 1, -1) if hinfo_mask is not None else None
     h_a, a = _attention(h, hq, hm, hq_mask, simiMatrix, wd, add_tanh, scope or "attention_2vector", 0)
-    return h_a, a.reshape(N, h.shape[2], hq.shape[1])
+    a = a.reshape(N, h.shape[2], hq.shape[1])
+    if bidirect:
+        h_a = torch.cat([h_a, _bidirect_q_a(a, hq, (N,))], 1)              # tf.concat: memory layout, no arithmetic
+    return h_a, a
 
 
 def attention_keeprank1(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, wd=None, bidirect=False, scope=None):
-    """model.py:247-314: hinfo [N,M,...,w] -> h_a [N,M,w], each album attended on its own (softsel over the rows of
+    """model.py:247-314: hinfo [N,M,...,w] -> h_a [N,M,w] ([N,M,2w] with `bidirect`), each album attended on its own (softsel over the rows of
     (n, m) with the max-over-question logits; no softmax over m).  That is the inner stage of attention_3d with K = M:
     one fvta_attn_fwd, then the per-(n,k) result is read back out of the saved state.  model.py's feature order for
     simiMatrix 2 is [(h-q)^2, h*q] (feat_order 1); no tanh on the logits."""
-    if bidirect:
-        raise NotImplementedError("bidirect (model.py:297-307) is not built")
     if simiMatrix not in (1, 2, 3):
         raise ValueError("similarity matrix not implemented")              # model.py:283-285 (sys.exit there)
     hinfo, hq = _f32(hinfo), _f32(hq)
@@ -232,10 +260,13 @@ def attention_keeprank1(hinfo, hq, hinfo_mask=None, hq_mask=None, simiMatrix=1, 
     both = hinfo_mask is not None and hq_mask is not None
     hm = ops.as_mask_u8(hinfo_mask.reshape(N, M, V)) if both else None
     qm = ops.as_mask_u8(hq_mask) if both else None
-    op.forward(_pad_channels(h, wp), _pad_channels(hq, wp), hm, qm, W, b)
+    _, a = op.forward(_pad_channels(h, wp), _pad_channels(hq, wp), hm, qm, W, b, want_logits=bool(bidirect))
     u = torch.empty(N, M, wp, dtype=torch.float32, device=h.device)
     check(op.lib.fvta_attn_read_u(ctypes.byref(op.desc), ptr(op.saved), ptr(u), stream_ptr()), "fvta_attn_read_u")
-    return u[..., :w].contiguous()
+    u = u[..., :w].contiguous()
+    if bidirect:                                                            # model.py:297-307 -> [N,M,2w]
+        u = torch.cat([u, _bidirect_q_a(a, hq, (N, M))], 2)
+    return u
 
 
 def attention_tgif(hinfo, lq, hinfo_mask=None, wd=None, mlp_dim=512, scope=None):

@@ -133,7 +133,11 @@ class Model:
         if self.use_time_warp_att and not self.use_time_warp:
             raise NameError("name 'C' is not defined (use_time_warp_att needs use_time_warp, model_v2.py:995, 1020)")
         if _cfg(config, "use_bidirection", False):
-            raise NotImplementedError("use_bidirection: the 3-D branch cannot run in the reference either (SURVEY 3.5)")
+            # model_v2.py:1020 hands bidirect=True to attention_3d, whose branch (:281-292) concatenates h_a [N,w] with
+            # q_a [N,T,w]: TF refuses the graph.  (The 1-D `attention(..., bidirect=True)` of model.py's baselines is in
+            # functional.py.)
+            raise ValueError("Shape must be rank 2 but is rank 3: attention_3d's bidirect branch (model_v2.py:281-292) "
+                             "cannot be built; use_bidirection only works with model.py's 1-D attentions")
         if self.simi not in (1, 2, 3, 4):
             raise ValueError("similarity matrix not implemented")    # model_v2.py:255-257 (sys.exit there)
         self.text_in = int(text_in if text_in is not None else _cfg(config, "text_in", 200))

@@ -174,8 +174,9 @@ def attention_3d(hinfo, hq, W=None, b=None, hinfo_mask=None, hq_mask=None,
 # ----------------------------------------------------------------------------
 # Encoders: model_v2.py:649-833   [TF-internal cell / rnn semantics, SURVEY 3.6]
 # ----------------------------------------------------------------------------
-def attention_keeprank1(hinfo, hq, W, b, hinfo_mask=None, hq_mask=None, simiMatrix=1):
-    """model.py:247-314 (bidirect=False): h_a[N,M,w], one softsel per album, max over the question inside."""
+def attention_keeprank1(hinfo, hq, W, b, hinfo_mask=None, hq_mask=None, simiMatrix=1, bidirect=False):
+    """model.py:247-314: h_a[N,M,w], one softsel per album, max over the question inside; `bidirect` (:297-307)
+    appends the question attended by every row and averaged over the rows -> [N,M,2w]."""
     N, M, w = hinfo.shape[0], hinfo.shape[1], hinfo.shape[-1]
     JQ = hq.shape[1]
     hinfo = hinfo.reshape(N, M, -1, w)
@@ -194,7 +195,11 @@ def attention_keeprank1(hinfo, hq, W, b, hinfo_mask=None, hq_mask=None, simiMatr
     if hinfo_mask is not None and hq_mask is not None:
         mask = hinfo_mask.reshape(N, M, V)[..., None] & hq_mask[:, None, None, :]
         a_logits = exp_mask(a_logits, mask)
-    return softsel(hinfo, a_logits.max(3))
+    h_a = softsel(hinfo, a_logits.max(3))
+    if bidirect:
+        q_a = softsel(q_aug, a_logits).mean(axis=2)            # :299-302  [N,M,w]
+        h_a = np.concatenate([h_a, q_a], 2)                    # :305
+    return h_a
 
 
 def attention_tgif(hinfo, lq, Wq, bq, Wh, bh, Wp, bp, Wf, bf, hinfo_mask=None):

@@ -148,6 +148,50 @@ def test_attention_3d_functional_time_warp_att():
         Fn.attention_3d(h.cuda(), q.cuda(), time_warp_att=True)
 
 
+@pytest.mark.parametrize("simi,masked,tanh", [(2, True, True), (1, False, False), (3, True, False)])
+def test_attention_bidirect(simi, masked, tanh):
+    """attention(..., bidirect=True) (model_v2.py:184-192, model.py:169-177): h_a [N,2w] = concat(softsel over the rows,
+    mean over the rows of the question attended by each row -- masked rows attend it uniformly)."""
+    from fvta_memexqa_amd import functional as Fn
+    from oracle import fvta_literal as L
+    Fn.reset_default_graph()
+    g = torch.Generator().manual_seed(31 + simi)
+    N, V, JQ, w = 3, 11, 6, 100
+    h = torch.randn(N, V, w, generator=g) * 0.5
+    q = torch.randn(N, JQ, w, generator=g) * 0.5
+    hm = torch.arange(V)[None, :] < torch.randint(1, V + 1, (N,), generator=g)[:, None]
+    qm = torch.arange(JQ)[None, :] < torch.randint(1, JQ + 1, (N,), generator=g)[:, None]
+    kw = dict(hinfo_mask=hm.cuda(), hq_mask=qm.cuda()) if masked else {}
+    ha, a = Fn.attention(h.cuda(), q.cuda(), simiMatrix=simi, add_tanh=tanh, bidirect=True, scope="bi", **kw)
+    W = Fn.variables["bi/att_logits/W"].cpu().double().numpy()
+    b = Fn.variables["bi/att_logits/b"].cpu().double().numpy()
+    ref, ref_a = L.attention(h.double().numpy(), q.double().numpy(), W, b, hm.numpy() if masked else None,
+                             qm.numpy() if masked else None, simiMatrix=simi, add_tanh=tanh, bidirect=True)
+    assert tuple(ha.shape) == (N, 2 * w)
+    _close(ha, ref, rtol=2e-4, atol=2e-5)
+    _close(a, ref_a, rtol=2e-4, atol=2e-5)
+
+
+def test_attention_keeprank1_bidirect():
+    from fvta_memexqa_amd import functional as Fn
+    from oracle import fvta_literal as L
+    Fn.reset_default_graph()
+    g = torch.Generator().manual_seed(77)
+    N, M, V, JQ, w = 2, 3, 7, 5, 64
+    h = torch.randn(N, M, V, w, generator=g) * 0.5
+    q = torch.randn(N, JQ, w, generator=g) * 0.5
+    hm = torch.rand(N, M, V, generator=g) < 0.7
+    hm[:, :, 0] = True
+    qm = torch.ones(N, JQ, dtype=torch.bool)
+    out = Fn.attention_keeprank1(h.cuda(), q.cuda(), hm.cuda(), qm.cuda(), simiMatrix=2, bidirect=True, scope="kb")
+    W = Fn.variables["kb/att_logits/W"].cpu().double().numpy()
+    b = Fn.variables["kb/att_logits/b"].cpu().double().numpy()
+    ref = L.attention_keeprank1(h.double().numpy(), q.double().numpy(), W, b, hm.numpy(), qm.numpy(), simiMatrix=2,
+                                bidirect=True)
+    assert tuple(out.shape) == (N, M, 2 * w)
+    _close(out, ref, rtol=2e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("simi,masked,w", [(1, True, 64), (2, True, 100), (3, False, 128)])
 def test_attention_keeprank1(simi, masked, w):
     from fvta_memexqa_amd import functional as Fn
