@@ -141,6 +141,40 @@ struct MmaBT {
     }
   }
 
+  // the same in two halves, so that a main loop can put other work between a k-step's fragment reads and its MFMAs
+  struct Frags {
+    bf16x8_t a[TM], b[TN];
+  };
+  __device__ __forceinline__ void load_rows(const bf16_t* __restrict__ As, const bf16_t* __restrict__ Bs, int ks, Frags& f) const {
+    const int c = 2 * ks + hf;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r = wave * WROWS + i * 32 + l31;
+      Pack8 p;
+      p.f = *reinterpret_cast<const f32x4*>(As + r * 32 + ((c ^ ((r >> 2) & 3)) << 3));
+      f.a[i] = p.b;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int r = wn * 128 + j * 32 + l31;
+      Pack8 p;
+      p.f = *reinterpret_cast<const f32x4*>(Bs + r * 32 + ((c ^ ((r >> 2) & 3)) << 3));
+      f.b[j] = p.b;
+    }
+  }
+  __device__ __forceinline__ void load_kmajor(const bf16_t* __restrict__ As, const bf16_t* __restrict__ Bs, int ks, Frags& f) const {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) f.a[i] = tr_frag<BM>(As, ks * 16, wave * WROWS + i * 32);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) f.b[j] = tr_frag<BN>(Bs, ks * 16, wn * 128 + j * 32);
+  }
+  __device__ __forceinline__ void mma_frags(const Frags& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) mfma(acc[i][j], f.a[i], f.b[j]);
+  }
+
   // k-major image [32][LD] (LD = 256 or 128 elements), chunk c of row k stored at c ^ ((k & 3) << 2).
   // Transposing read: group g = lane>>4 reads the 4(k) x 16(m) blocks at k0 = kbase + 8(g>>1) (+4),
   // m0 = mbase + 16(g&1); lane 4q+p of the group supplies row k0+q, columns m0+4p..+3 and receives
@@ -233,12 +267,74 @@ struct KMajorSrc {
 // waves and retires every wave's reads of stage (t-1)%3, which the next issue overwrites.
 // `stamps` (diagnostics, normally null): shader-clock stamps per k-tile: [4t] before the wait, [4t+1] after it,
 // [4t+2] after the barrier + next issue, [4t+3] after the MFMAs were issued.
+// Software-pipelined variant (FVTA_GLDS_SP, TM <= 2).  A k-tile is two k-steps of fragments; the loop keeps ONE k-step of
+// fragments in flight at all times, across the barrier:
+//     read F1 <- (tile t, step 1) | MFMA F0 | wait tile t+1, barrier | DMA tile t+3 -> stage t | read F0 <- (t+1, step 0) | MFMA F1
+// so (a) the LDS latency of a k-step's fragment reads hides behind the other k-step's eight MFMAs also at the tile
+// boundary, where the plain loop stalls on freshly issued reads after every barrier, and (b) a stage is released in the
+// MIDDLE of its tile (both k-steps are in registers by then), which puts THREE tiles in flight on the same three stages.
+template <bool KMAJOR, class Mma, class Issue>
+__device__ __forceinline__ void glds_mainloop_sp(Mma& mma, Issue&& issue, int ntiles, bf16_t* smem) {
+  typedef typename Mma::Cfg TileCfg;
+  constexpr int G = TileCfg::A_GLDS + TileCfg::B_GLDS;  // DMA wave-instructions per wave and tile
+  auto a_stage = [&](int t) { return smem + (t % TileCfg::STAGES) * TileCfg::STAGE_ELEMS; };
+  auto load = [&](int t, int ks, typename Mma::Frags& f) {
+    const bf16_t* As = a_stage(t);
+    if (KMAJOR)
+      mma.load_kmajor(As, As + TileCfg::A_ELEMS, ks, f);
+    else
+      mma.load_rows(As, As + TileCfg::A_ELEMS, ks, f);
+  };
+  if (ntiles <= 0) return;
+  issue(0, a_stage(0), a_stage(0) + TileCfg::A_ELEMS);
+  if (ntiles > 1) issue(1, a_stage(1), a_stage(1) + TileCfg::A_ELEMS);
+  if (ntiles > 2) issue(2, a_stage(2), a_stage(2) + TileCfg::A_ELEMS);
+  if (ntiles > 2)
+    wait_vmcnt<2 * G>();
+  else if (ntiles > 1)
+    wait_vmcnt<G>();
+  else
+    wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  typename Mma::Frags f0, f1;
+  load(0, 0, f0);
+  for (int t = 0; t < ntiles; ++t) {
+    load(t, 1, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma.mma_frags(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < ntiles) {
+      // tiles 0 .. t+2 are issued; tile t+1 has landed once at most tile t+2's loads are outstanding
+      if (t + 2 < ntiles)
+        wait_vmcnt<G>();
+      else
+        wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of stage t are complete
+      __builtin_amdgcn_s_barrier();                          // tile t+1 visible to all; stage t free
+      asm volatile("" ::: "memory");
+      if (t + 3 < ntiles) issue(t + 3, a_stage(t + 3), a_stage(t + 3) + TileCfg::A_ELEMS);
+      load(t + 1, 0, f0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mma.mma_frags(f1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  Mma::drain();
+}
+
 template <bool KMAJOR, class Mma, class Issue>
 __device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntiles, bf16_t* smem,
                                               unsigned long long* stamps = nullptr, int xdbg = 0) {
   typedef typename Mma::Cfg TileCfg;
   auto a_stage = [&](int t) { return smem + (t % TileCfg::STAGES) * TileCfg::STAGE_ELEMS; };
   if (ntiles <= 0) return;
+  if constexpr (Mma::TM <= 2 && !KMAJOR) {  // (the k-major loop, two transposing reads per fragment, spills with it)
+    if (xdbg & 4) {  // bit 2 of xdbg: the software-pipelined loop (runtime switch while both are measured)
+      glds_mainloop_sp<KMAJOR>(mma, issue, ntiles, smem);
+      return;
+    }
+  }
   if constexpr (Mma::TM == 4) {
     // the same pipeline with a single-block steady-state loop and the last two tiles peeled: with 256 accumulator
     // registers the loop-carried values must stay in AGPRs, which the compiler manages only for a plain loop body

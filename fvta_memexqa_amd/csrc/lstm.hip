@@ -16,6 +16,9 @@
 #include "fvta_prof.h"
 #include <vector>
 
+#ifndef FVTA_LSTM_NT_DEFAULT
+#define FVTA_LSTM_NT_DEFAULT 2
+#endif
 #ifndef FVTA_LSTM_OVERLAP_DEFAULT
 #define FVTA_LSTM_OVERLAP_DEFAULT 0
 #endif
@@ -493,6 +496,13 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   const bool bf = d->precision == FVTA_BF16;
   a.Kp = kpad8(d);
   a.dbg = fvta_diag_env("FVTA_DEBUG_SKIP", 0);  // -DFVTA_DIAG builds only
+  {
+    static const int nt = [] {
+      const char* e = getenv("FVTA_LSTM_NT");
+      return e ? atoi(e) : FVTA_LSTM_NT_DEFAULT;
+    }();
+    a.nt = nt & 1;
+  }
   a.Wt[0] = a.Wt[1] = nullptr;
   if (bf) {  // refresh the bf16 weight shadows (the optimiser has just changed the fp32 masters)
     const int ndir = d->share_fw_bw ? 1 : 2;
@@ -633,6 +643,13 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
     f.t0 = 0;
     f.nt = J;
     f.stamp_wg = fvta_diag_env("FVTA_LSTM_STAMP_BWD", -1);  // -DFVTA_DIAG builds only
+    {
+      static const int nt = [] {
+        const char* e = getenv("FVTA_LSTM_NT");
+        return e ? atoi(e) : FVTA_LSTM_NT_DEFAULT;
+      }();
+      f.ntl = (nt & 2) != 0;
+    }
     for (int t = J - 1; t >= 0; --t) {
       f.t = t;
       launch_bwd_fused_bf16(f, stream);

@@ -20,6 +20,9 @@
 #include <type_traits>
 #include "lstm_common.h"
 
+#ifndef FVTA_GLDS_SP_DEFAULT
+#define FVTA_GLDS_SP_DEFAULT 1
+#endif
 #ifndef FVTA_TILE128_DEFAULT
 #define FVTA_TILE128_DEFAULT 0
 #endif
@@ -30,6 +33,16 @@ static inline int pad8(int v) { return (v + 7) / 8 * 8; }
 
 // Which kernels take the 256 x 256 / four-wave (128 x 128 wave tile) configuration: bit 0 forward step, 1 fused
 // backward step, 2 dx, 3 weight gradient.  FVTA_LSTM_TILE128 overrides the built-in choice (measurement switch).
+// Which kernels run the software-pipelined main loop: bit 0 forward step (and the row-image test GEMM), 1 fused backward
+// step, 2 dx, 3 weight gradient (and the k-major test GEMM).  FVTA_GLDS_SP overrides the built-in choice.
+int glds_sp_mask() {
+  static const int m = [] {
+    const char* e = getenv("FVTA_GLDS_SP");
+    return e ? atoi(e) : FVTA_GLDS_SP_DEFAULT;
+  }();
+  return m;
+}
+
 static int tile128_mask() {
   static const int m = [] {
     const char* e = getenv("FVTA_LSTM_TILE128");
@@ -148,12 +161,13 @@ __device__ __forceinline__ void lstm_step_fwd_tile(const StepArgs& a, bf16_t* sm
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int i = min(m0 + mma.wave * (32 * TM) + ti * 32 + it * 8 + (mma.lane >> 3), nact - 1);  // clamped: valid row
-          cprev[ti][it] = *reinterpret_cast<const f32x4*>(src + (size_t)i * d + u0 + 4 * (mma.lane & 7));
+          const f32x4* cp = reinterpret_cast<const f32x4*>(src + (size_t)i * d + u0 + 4 * (mma.lane & 7));
+          cprev[ti][it] = a.nt ? __builtin_nontemporal_load(cp) : *cp;
         }
     }
   };
   if (TM != 4) load_cprev();
-  if (!(a.dbg & 1)) glds_mainloop<false>(mma, issue, nt, smem_h, st ? st + 8 : nullptr, (a.dbg >> 17) & 3);
+  if (!(a.dbg & 1)) glds_mainloop<false>(mma, issue, nt, smem_h, st ? st + 8 : nullptr, ((a.dbg >> 17) & 3) | (a.sp ? 4 : 0));
   if (st) st[1] = __builtin_readcyclecounter();
   if (TM == 4) load_cprev();
   __syncthreads();  // s_oo visible; every wave is done with the stage buffers, which become the epilogue's scratch
@@ -227,7 +241,9 @@ static int fwd_big_row_tiles(int B, int d) {
   return nbig < rt ? nbig : rt;
 }
 
-void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s) {
+void launch_step_fwd_bf16(const StepArgs& a_, hipStream_t s) {
+  StepArgs a = a_;
+  a.sp = glds_sp_mask() & 1;
   // the 256 x 256 tile (8 waves) halves the A-operand re-reads; it needs whole 64-unit column blocks
   // (measured on the metric shape: no faster than two 256 x 128 workgroups per CU, whose k-loops and epilogues
   // overlap better -- kept selectable: FVTA_LSTM_WIDE_TILE=1)
@@ -353,7 +369,7 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
       bw.issue(rw, Bs, mma.wave_all, tile * 64);
     };
     if (st) st[0] = __builtin_readcyclecounter();
-    glds_mainloop<false>(mma, issue, K / 32, smem_h, st ? st + 8 : nullptr);
+    glds_mainloop<false>(mma, issue, K / 32, smem_h, st ? st + 8 : nullptr, a.sp ? 4 : 0);
     if (st) st[1] = __builtin_readcyclecounter();
   }
   __syncthreads();
@@ -376,11 +392,18 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
 #pragma unroll
       for (int tj = 0; tj < MmaB::TN; ++tj) {
         const int u = min(u0 + mma.col_of(tj), d - 1);
-        gp[tj] = *reinterpret_cast<const bf16x4*>(a.gatesb + (trow + ic) * (size_t)K + 4 * u);
-        c[tj] = cs_t[(size_t)ic * d + u];
-        cp[tj] = t > 0 ? cs_p[(size_t)ic * d + u] : 0.f;
+        if (a.ntl) {
+          gp[tj] = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(a.gatesb + (trow + ic) * (size_t)K + 4 * u));
+          c[tj] = __builtin_nontemporal_load(cs_t + (size_t)ic * d + u);
+          cp[tj] = t > 0 ? __builtin_nontemporal_load(cs_p + (size_t)ic * d + u) : 0.f;
+          dout[tj] = __builtin_nontemporal_load(a.d_out + oo + u);
+        } else {
+          gp[tj] = *reinterpret_cast<const bf16x4*>(a.gatesb + (trow + ic) * (size_t)K + 4 * u);
+          c[tj] = cs_t[(size_t)ic * d + u];
+          cp[tj] = t > 0 ? cs_p[(size_t)ic * d + u] : 0.f;
+          dout[tj] = a.d_out[oo + u];
+        }
         dcv[tj] = dcs[(size_t)ic * d + u];
-        dout[tj] = a.d_out[oo + u];
       }
 #pragma unroll
       for (int tj = 0; tj < MmaB::TN; ++tj) {
@@ -408,7 +431,9 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
   }
 }
 
-void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
+void launch_bwd_fused_bf16(const FusedBwdArgs& a_, hipStream_t s) {
+  FusedBwdArgs a = a_;
+  a.sp = (glds_sp_mask() >> 1) & 1;
   static const bool narrow = [] {
     const char* e = getenv("FVTA_LSTM_BWD_NARROW_TILE");
     return e && e[0] == '1';
@@ -455,7 +480,7 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
     az.issue(rz, As, mma.wave_all, tile * 64);
     bw.issue(rw, Bs, mma.wave_all, tile * 64);
   };
-  glds_mainloop<false>(mma, issue, K / 32, smem_h);
+  glds_mainloop<false>(mma, issue, K / 32, smem_h, nullptr, a.sp ? 4 : 0);
 #pragma unroll
   for (int ti = 0; ti < MmaB::TM; ++ti) {
     int64_t xos[16];
@@ -474,7 +499,9 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
   }
 }
 
-void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
+void launch_dx_bf16(const FusedBwdArgs& a_, hipStream_t s) {
+  FusedBwdArgs a = a_;
+  a.sp = (glds_sp_mask() >> 2) & 1;
   static const bool wide = [] {  // (one 256-wide column tile instead of two 128-wide ones: measured slower at in = 200)
     const char* e = getenv("FVTA_LSTM_DX_WIDE_TILE");
     return e && e[0] == '1';
@@ -549,7 +576,7 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
       sa.issue(ra, As, mma.wave_all, (unsigned)tile * 32u * ncols * 2u);
       sb.issue(rz, Bs, mma.wave_all, (unsigned)tile * 32u * N4 * 2u);
     };
-    glds_mainloop<true>(mma, issue, (nact + 31) / 32, smem_h);
+    glds_mainloop<true>(mma, issue, (nact + 31) / 32, smem_h, nullptr, a.sp ? 4 : 0);
     __builtin_amdgcn_s_barrier();  // every wave is done with the ring before the next step refills it
   }
   float* slab = a.slabs + (size_t)bz * (in_i + d) * N4;
@@ -565,7 +592,9 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
     }
 }
 
-void launch_dw_bf16(const DwArgs& a, hipStream_t s) {
+void launch_dw_bf16(const DwArgs& a_, hipStream_t s) {
+  DwArgs a = a_;
+  a.sp = (glds_sp_mask() >> 3) & 1;
   const int xtiles = (a.in_i + 255) / 256, htiles = (a.d + 255) / 256;
   static const bool narrow = [] {
     const char* e = getenv("FVTA_LSTM_DW_NARROW_TILE");
@@ -626,7 +655,7 @@ __global__ void cvt_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __res
 
 template <int LAYOUT>
 __global__ __launch_bounds__(256, 2) void test_gemm_bf16_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
-                                                                const bf16_t* __restrict__ B, float* __restrict__ C) {
+                                                                const bf16_t* __restrict__ B, float* __restrict__ C, int sp) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   const int tid = threadIdx.x;
   const int m0 = blockIdx.x * TileCfg::BM, n0 = blockIdx.y * TileCfg::BN;
@@ -642,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void test_gemm_bf16_kernel(int M, int N, in
       sa.issue(ra, As, mma.wave, tile * 64);
       sb.issue(rb, Bs, mma.wave, tile * 64);
     };
-    glds_mainloop<false>(mma, issue, K / 32, smem_h);
+    glds_mainloop<false>(mma, issue, K / 32, smem_h, nullptr, sp ? 4 : 0);
   } else {
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(A, (unsigned)K * M * 2), rb = make_rsrc(B, (unsigned)K * N * 2);
     KMajorSrc<TileCfg::BM, TileCfg::A_GLDS> sa;
@@ -653,7 +682,7 @@ __global__ __launch_bounds__(256, 2) void test_gemm_bf16_kernel(int M, int N, in
       sa.issue(ra, As, mma.wave, (unsigned)tile * 32u * M * 2u);
       sb.issue(rb, Bs, mma.wave, (unsigned)tile * 32u * N * 2u);
     };
-    glds_mainloop<true>(mma, issue, (K + 31) / 32, smem_h);
+    glds_mainloop<true>(mma, issue, (K + 31) / 32, smem_h, nullptr, sp ? 4 : 0);
   }
 #pragma unroll
   for (int ti = 0; ti < MmaB::TM; ++ti)
@@ -682,10 +711,10 @@ int test_gemm_bf16(int layout, int M, int N, int K, const float* A, const float*
   const dim3 grid((M + TileCfg::BM - 1) / TileCfg::BM, (N + TileCfg::BN - 1) / TileCfg::BN);
   if (layout == 1) {
     allow_big_lds(test_gemm_bf16_kernel<1>, TileCfg::LDS_BYTES);
-    hipLaunchKernelGGL(test_gemm_bf16_kernel<1>, grid, dim3(256), TileCfg::LDS_BYTES, s, M, N, K, Ab, Bb, C);
+    hipLaunchKernelGGL(test_gemm_bf16_kernel<1>, grid, dim3(256), TileCfg::LDS_BYTES, s, M, N, K, Ab, Bb, C, glds_sp_mask() & 1);
   } else {
     allow_big_lds(test_gemm_bf16_kernel<2>, TileCfg::LDS_BYTES);
-    hipLaunchKernelGGL(test_gemm_bf16_kernel<2>, grid, dim3(256), TileCfg::LDS_BYTES, s, M, N, K, Ab, Bb, C);
+    hipLaunchKernelGGL(test_gemm_bf16_kernel<2>, grid, dim3(256), TileCfg::LDS_BYTES, s, M, N, K, Ab, Bb, C, (glds_sp_mask() >> 3) & 1);
   }
   (void)hipFreeAsync(Ab, s);
   (void)hipFreeAsync(Bb, s);

@@ -130,6 +130,9 @@ struct StepArgs {
   float* cstate;  // used when cs is null
   int t, B, J, in, d, Kp;
   int dbg;  // diagnostics only (FVTA_DEBUG_SKIP): 1 = skip the k-loop, 2 = skip the epilogue
+  int sp;   // bf16 engine: software-pipelined main loop (gemm_bf16.h glds_mainloop_sp)
+  int nt;   // bf16 engine: stream-once data (saved gates, cell states, fp32 h rows) with non-temporal stores / loads,
+            // so that what the NEXT step re-reads through L2 -- the h shadow and the weights -- is not evicted by it
 };
 
 struct GateBwdArgs {
@@ -167,6 +170,7 @@ struct DwArgs {
   float* slabs;
   int B, J, in, d, tgroup, nsplit, in_i;
   // the launch covers step groups [split0, split0 + nsl) of both directions (whole call: 0, nsplit)
+  int sp;  // software-pipelined main loop
   int split0, nsl;
   int xcd_aware;  // 1: a (direction, group) slice's tiles share one XCD (whole-call launch); 0: tiles dealt round-robin
                   // over the XCDs (per-group launches that fill the CUs the recurrence leaves idle on EVERY XCD)
@@ -245,6 +249,13 @@ __device__ __forceinline__ void lstm_gate_epilogue(const Mma& mma, const StepArg
 // 16 bytes per lane: 44 VMEM instructions per wave and tile.
 //   cprev[ti][it]: c_{t-1} of rows ti*32 + it*8 + (lane>>3), units 4*(lane&7)..+3 -- loaded by the caller BEFORE the
 //   k-loop (latency hidden), ignored when t == 0.
+__device__ __forceinline__ void st16(float* p, const f32x4 v, bool nt) {
+  if (nt)
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  else
+    *reinterpret_cast<f32x4*>(p) = v;
+}
+
 template <class Mma>
 __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const StepArgs& a, int dir, int m0, int u0,
                                                           int nact, size_t trow, const int64_t* s_oo,
@@ -303,7 +314,7 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
       for (int it = 0; it < 4; ++it) {
         const int lr = it * 8 + io_row, i = m0 + wrow0 + lr;
         const f32x4 v = *reinterpret_cast<const f32x4*>(&pl[lr * LDP + 4 * io_c4]);
-        if (i < nact) *reinterpret_cast<f32x4*>(dst + (size_t)i * d + u0 + 4 * io_c4) = v;
+        if (i < nact) st16(dst + (size_t)i * d + u0 + 4 * io_c4, v, a.nt != 0);
       }
       wave_sync();
     }
@@ -320,7 +331,7 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
         if (oo >= 0) {
           float* o = a.out + oo + u0 + 4 * io_c4;
           if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
-            *reinterpret_cast<f32x4*>(o) = v;
+            st16(o, v, a.nt != 0);
           } else {  // an output row that is not 16-byte aligned
             o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
           }
@@ -353,7 +364,7 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
       for (int it = 0; it < 8; ++it) {
         const int lr = it * 4 + (lane >> 4), c8 = lane & 15, i = m0 + wrow0 + lr;
         const f32x4 v = *reinterpret_cast<const f32x4*>(&plh[lr * LDG + 8 * c8]);
-        if (i < nact) *reinterpret_cast<f32x4*>(a.gatesb + (trow + i) * (size_t)(4 * d) + 4 * u0 + 8 * c8) = v;
+        if (i < nact) st16(reinterpret_cast<float*>(a.gatesb + (trow + i) * (size_t)(4 * d) + 4 * u0 + 8 * c8), v, a.nt != 0);
       }
       wave_sync();
     }
@@ -378,6 +389,8 @@ struct FusedBwdArgs {
   int t0, nt; // lstm_dx only: the launch covers steps [t0, t0 + nt) of both directions
   int t, B, J, in, d, in_i;
   int stamp_wg;  // diagnostics: workgroup that stamps the shader clock (-1: none)
+  int sp;        // software-pipelined main loop
+  int ntl;       // read-once operands of the gate gradient (saved gates, cell states, d_out) through non-temporal loads
 };
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s);
 void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s);

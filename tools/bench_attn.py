@@ -19,4 +19,7 @@ print("attn fwd ms", round(timeit(lambda: op.forward(h, q, hm, qm, W, b)), 3), "
 if len(sys.argv) > 1:
     gout = torch.randn(N, w, device="cuda", generator=g)
     dh = torch.zeros_like(h); dq = torch.zeros_like(q); dW = torch.zeros_like(W); db = torch.zeros(1, device="cuda")
-    print("attn bwd ms", round(timeit(lambda: op.backward(h, q, hm, qm, W, b, gout, dh, dq, dW, db, True)), 3))
+    # accumulate = 2: the mode the Model runs (d_hq accumulated, only the valid rows of d_hinfo written, never read);
+    # mode 1 additionally READS every d_hinfo row -- which is what doubled the fetch figure of profiles/r01d_attention_pmc.json
+    mode = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    print("attn bwd ms (accumulate=%d)" % mode, round(timeit(lambda: op.backward(h, q, hm, qm, W, b, gout, dh, dq, dW, db, mode)), 3))
