@@ -512,14 +512,19 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
     a.Wt[1] = d->share_fw_bw ? wv.wt[0] : wv.wt[1];
     launch_cvt_x_bf16(pv, x, sv.xs, d->B, d->J, d->in, in_internal(d), stream);
   }
-  for (int t = 0; t < d->J; ++t) {
-    a.t = t;
-    if (bf)
-      launch_step_fwd_bf16(a, stream);
-    else
-      hipLaunchKernelGGL(lstm_step_fwd_f32, grid, dim3(256), sh, stream, a);
+  int launches = d->J;
+  if (bf && launch_seq_fwd_bf16(a, stream)) {
+    launches = 1;  // the sequence-stationary kernel: all J steps in one launch
+  } else {
+    for (int t = 0; t < d->J; ++t) {
+      a.t = t;
+      if (bf)
+        launch_step_fwd_bf16(a, stream);
+      else
+        hipLaunchKernelGGL(lstm_step_fwd_f32, grid, dim3(256), sh, stream, a);
+    }
   }
-  fvta_prof_end(FVTA_PROF_LSTM_STEP_FWD + 16 * d->reserved, d->J, stream);
+  fvta_prof_end(FVTA_PROF_LSTM_STEP_FWD + 16 * d->reserved, launches, stream);
   FVTA_CHECK_LAUNCH("lstm_step_fwd");
   return FVTA_OK;
 }

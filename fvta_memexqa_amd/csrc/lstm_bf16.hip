@@ -20,6 +20,9 @@
 #include <type_traits>
 #include "lstm_common.h"
 
+#ifndef FVTA_LSTM_SEQ_DEFAULT
+#define FVTA_LSTM_SEQ_DEFAULT 0
+#endif
 #ifndef FVTA_GLDS_SP_DEFAULT
 #define FVTA_GLDS_SP_DEFAULT 1
 #endif
@@ -112,13 +115,16 @@ __device__ unsigned long long g_lstm_stamps[512];  // diagnostics (FVTA_DEBUG_SK
 // ------------------------------------------------------------ forward step --
 // z = [xs_t | hs_{t-1}] * wt^T over the 4 gate strips of 32 units per wave column.
 // One block tile of rows [m0, m0 + Cfg::BM) x the 32 WN units from ub.
-template <int WN, int TM, int WM>
+// LEAN: no diagnostic switches, software-pipelined main loop only (the sequence-stationary kernel: its two loops around
+// the tile leave no registers for code paths that never run)
+template <int WN, int TM, int WM, bool LATE_CPREV = (TM == 4), bool LEAN = false>
 __device__ __forceinline__ void lstm_step_fwd_tile(const StepArgs& a, bf16_t* smem_h, int64_t* s_oo, int m0, int ub,
-                                                   int dir, int nact) {
+                                                   int dir, int nact, int t) {
   typedef TileCfgT<WN, TM, WM> Cfg;
   const int tid = threadIdx.x;
-  const int d = a.d, t = a.t, in_i = a.Kp - a.d;
+  const int d = a.d, in_i = a.Kp - a.d;
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
+  __syncthreads();  // a workgroup that runs several tiles: the previous tile's epilogue is done with s_oo and the stage buffers
   for (int r = tid; r < Cfg::BM; r += Cfg::NT) s_oo[r] = (m0 + r < nact) ? a.plan.oo[trow + m0 + r] : -1;
 
   MmaBT<WN, TM, WM> mma;
@@ -148,7 +154,8 @@ __device__ __forceinline__ void lstm_step_fwd_tile(const StepArgs& a, bf16_t* sm
   };
   // FVTA_DEBUG_SKIP & 32768: one wave of one workgroup stamps the shader clock (tools/lstm_phases.py)
   const int lin_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  unsigned long long* st = ((a.dbg & 32768) && lin_wg == ((a.dbg >> 16) & 0xFFF) && tid == 0 && a.t == 5) ? g_lstm_stamps : nullptr;
+  const int dbg = LEAN ? 0 : a.dbg;
+  unsigned long long* st = (!LEAN && (dbg & 32768) && lin_wg == ((dbg >> 16) & 0xFFF) && tid == 0 && t == 5) ? g_lstm_stamps : nullptr;
   if (st) st[0] = __builtin_readcyclecounter();
   // c_{t-1} of the wave's rows, row-contiguous (16 B per lane), requested before the k-loop hides their latency
   // (TM = 4: after it -- 64 more live registers across the k-loop spill next to the 256 accumulators)
@@ -166,14 +173,17 @@ __device__ __forceinline__ void lstm_step_fwd_tile(const StepArgs& a, bf16_t* sm
         }
     }
   };
-  if (TM != 4) load_cprev();
-  if (!(a.dbg & 1)) glds_mainloop<false>(mma, issue, nt, smem_h, st ? st + 8 : nullptr, ((a.dbg >> 17) & 3) | (a.sp ? 4 : 0));
+  if (!LATE_CPREV) load_cprev();
+  if (LEAN)
+    glds_mainloop_sp<false>(mma, issue, nt, smem_h);
+  else if (!(dbg & 1))
+    glds_mainloop<false>(mma, issue, nt, smem_h, st ? st + 8 : nullptr, ((dbg >> 17) & 3) | (a.sp ? 4 : 0));
   if (st) st[1] = __builtin_readcyclecounter();
-  if (TM == 4) load_cprev();
+  if (LATE_CPREV) load_cprev();
   __syncthreads();  // s_oo visible; every wave is done with the stage buffers, which become the epilogue's scratch
-  if (!(a.dbg & 2))
+  if (!(dbg & 2))
     lstm_gate_epilogue_staged(mma, a, dir, m0, u0, nact, trow, s_oo, cprev,
-                              reinterpret_cast<char*>(smem_h) + mma.wave_all * 9216);
+                              reinterpret_cast<char*>(smem_h) + mma.wave_all * 9216, t);
   if (st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     st[2] = __builtin_readcyclecounter();
@@ -198,13 +208,13 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
     if ((int)blockIdx.x >= nbig) {
       const int m0 = nbig * 256 + ((int)blockIdx.x - nbig) * 128;
       if (m0 >= nact) return;
-      lstm_step_fwd_tile<1, 1, 4>(a, smem_h, s_oo, m0, ub, dir, nact);
+      lstm_step_fwd_tile<1, 1, 4>(a, smem_h, s_oo, m0, ub, dir, nact, a.t);
       return;
     }
   }
   const int m0 = blockIdx.x * Cfg::BM;
   if (m0 >= nact) return;
-  lstm_step_fwd_tile<WN, TM, 8 / TM>(a, smem_h, s_oo, m0, ub, dir, nact);
+  lstm_step_fwd_tile<WN, TM, 8 / TM>(a, smem_h, s_oo, m0, ub, dir, nact, a.t);
 }
 
 int lstm_read_stamp(int i, long long* v) {
@@ -213,6 +223,55 @@ int lstm_read_stamp(int i, long long* v) {
   if (hipMemcpyFromSymbol(&x, HIP_SYMBOL(g_lstm_stamps), 8, (size_t)i * 8, hipMemcpyDeviceToHost) != hipSuccess) return FVTA_ERR_INVALID_ARG;
   *v = (long long)x;
   return FVTA_OK;
+}
+
+// ------------------------------------------------ sequence-stationary forward --
+// ONE launch for all J steps: a workgroup owns 128 sorted sequences of one direction for the whole recurrence (sequences
+// are independent, so there is no cross-workgroup dependency and no grid-wide step barrier) and walks the 4d gate
+// columns in chunks of 128 units (512 columns: 8 waves as 2 x 4 wave tiles of 64 x 128, the same wave tile and gate
+// epilogue as the per-step kernel).  h_{t-1} and c_{t-1} come back through global memory, written by this very
+// workgroup one step earlier (same CU, same L1/L2: a vmcnt(0) + barrier orders them); the weights stream from L2 once
+// per step and workgroup.  What it buys over J launches of lstm_step_fwd_bf16: no launch skeletons and dispatch tails,
+// the A operand re-read 4x instead of 16x, and -- workgroups drift apart -- the chip is no longer in one phase (all
+// matrix pipe / all HBM) at a time.  grid (ceil(B/128), 2), 512 threads, one workgroup per CU.
+// MEASURED (metric shape, text cell, train step): 7.60 ms against 5.08 ms for the 30 per-step launches (forward only:
+// 6.00 vs 4.36 ms) -- it loses, and stays off (FVTA_LSTM_SEQ=1 selects it).  Why: 202 workgroups of 8 waves occupy
+// 202 of 256 CUs with ONE workgroup each, so a CU's k-loop and epilogue strictly alternate (the per-step kernel keeps
+// two 4-wave workgroups per CU and 1632 of them per step); the two loops around the tile push the kernel to 256 VGPRs
+// + 690 B of scratch even with c_{t-1} loaded after the k-loop (exposed once per chunk); every step ends in a
+// vmcnt(0) drain + barrier before h_{t-1} can be re-read.
+__global__ __launch_bounds__(512, 1) void lstm_seq_fwd_bf16(StepArgs a) {
+  typedef TileCfgT<4, 2, 2> Cfg;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
+  int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + Cfg::STAGES * Cfg::STAGE_ELEMS);
+  const int dir = blockIdx.y, m0 = blockIdx.x * Cfg::BM;
+  for (int t = 0; t < a.J; ++t) {
+    const int nact = a.plan.nactive[t];
+    if (m0 >= nact) break;  // sorted by length: once the tile's first row has ended, all of it has, for good
+    for (int ub = 0; ub < a.d; ub += 128) lstm_step_fwd_tile<4, 2, 2, true, true>(a, smem_h, s_oo, m0, ub, dir, nact, t);
+    // this step's h shadow / cell states are read back by the next one (DMA and plain loads through the same L1/L2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
+bool launch_seq_fwd_bf16(const StepArgs& a_, hipStream_t s) {
+  static const int mode = [] {
+    const char* e = getenv("FVTA_LSTM_SEQ");
+    return e ? atoi(e) : FVTA_LSTM_SEQ_DEFAULT;
+  }();
+  // (a call with few sequences would run on a handful of workgroups: the per-step kernel spreads a step over the
+  // column blocks instead -- the photo cell's 64 rows took 9.0 ms here against 2.2 ms)
+  if (!mode || a_.d % 128 != 0 || a_.B < 128 * 64) return false;
+  StepArgs a = a_;
+  a.sp = glds_sp_mask() & 1;
+  a.t = 0;
+  typedef TileCfgT<4, 2, 2> Cfg;
+  constexpr int LDS = Cfg::LDS_BYTES + 256 * 8;
+  allow_big_lds(lstm_seq_fwd_bf16, LDS);
+  const dim3 grid((a.B + Cfg::BM - 1) / Cfg::BM, 2);
+  hipLaunchKernelGGL(lstm_seq_fwd_bf16, grid, dim3(Cfg::NT), LDS, s, a);
+  return true;
 }
 
 // Row tiles that get the full 256-row shape: as many as fill WHOLE rounds of the device's workgroup slots (2 per CU for

@@ -259,10 +259,10 @@ __device__ __forceinline__ void st16(float* p, const f32x4 v, bool nt) {
 template <class Mma>
 __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const StepArgs& a, int dir, int m0, int u0,
                                                           int nact, size_t trow, const int64_t* s_oo,
-                                                          const f32x4 (&cprev)[Mma::TM][4], char* scr) {
+                                                          const f32x4 (&cprev)[Mma::TM][4], char* scr, int t) {
   static_assert(Mma::TN == 4 && Mma::WAVES_N == 1, "wave tile: 32 TM rows x the four gate strips");
   constexpr int LDP = 36;  // floats per staged fp32 row (32 + pad, keeps 16-byte alignment)
-  const int d = a.d, t = a.t, lane = mma.lane;
+  const int d = a.d, lane = mma.lane;  // t: the step (a.t for the per-step kernels; the sequence-stationary kernel loops over it)
   const float* __restrict__ bias = a.bias[dir];
   const int u = u0 + mma.l31;
   const float bi = bias[u], bj = bias[d + u], bf = bias[2 * d + u], bo = bias[3 * d + u];
@@ -376,6 +376,7 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
 void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int in, int in_i, int d, hipStream_t s);
 void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, int J, int in, int in_i, hipStream_t s);
 void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s);
+bool launch_seq_fwd_bf16(const StepArgs& a, hipStream_t s);  // all J steps in one launch; false: shape not covered / switched off
 void launch_step_bwd_bf16(const StepBwdArgs& a, hipStream_t s);
 struct FusedBwdArgs {
   PlanView plan;
