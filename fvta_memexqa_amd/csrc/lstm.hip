@@ -647,6 +647,9 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
     f.in_i = in_internal(d);
     f.t0 = 0;
     f.nt = J;
+    f.dh_tiles = 0;
+    // dx rides on the step launches (dx_{t+1} next to dh_t: same A operand) unless it goes to the side stream / is off
+    f.dx_tiles = (dx && !ov_dx) ? bwd_fused_dx_tiles(in, dd) : 0;
     f.stamp_wg = fvta_diag_env("FVTA_LSTM_STAMP_BWD", -1);  // -DFVTA_DIAG builds only
     {
       static const int nt = [] {
@@ -679,7 +682,14 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
         }
       }
     }
-    if (dx && !ov_dx) launch_dx_bf16(f, stream);
+    if (dx && !ov_dx) {
+      if (f.dx_tiles > 0) {
+        f.t = -1;  // dx_0: the dx tiles of one more launch
+        launch_bwd_fused_bf16(f, stream);
+      } else {
+        launch_dx_bf16(f, stream);
+      }
+    }
   } else
   for (int t = J - 1; t >= 0; --t) {
     g.t = t;

@@ -20,6 +20,9 @@
 #include <type_traits>
 #include "lstm_common.h"
 
+#ifndef FVTA_LSTM_DX_FUSED_DEFAULT
+#define FVTA_LSTM_DX_FUSED_DEFAULT 0
+#endif
 #ifndef FVTA_LSTM_SEQ_DEFAULT
 #define FVTA_LSTM_SEQ_DEFAULT 0
 #endif
@@ -406,6 +409,49 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
   const int tid = threadIdx.x, dir = blockIdx.z;
   const int m0 = blockIdx.x * TileCfg::BM, u0 = blockIdx.y * TileCfg::BN;
   const int t = a.t, d = a.d, K = 4 * d;
+  // ---- dx tiles riding on the step launch (a.dx_tiles > 0): the column tiles from d/BN on compute
+  // dx_{t+1} = dz_{t+1} * wb_x^T -- the SAME A operand the step's dh tiles stream, so dz is not fetched from HBM a
+  // second time by a separate pass over all steps (4.8 GB per call), and the tiles run on the CUs the single-round
+  // step leaves idle.  The launch with t = -1 holds only the dx tiles of step 0.
+  if ((int)blockIdx.y >= a.dh_tiles) {
+    const int t1 = t + 1;
+    if (t1 >= a.J) return;
+    const int nn = a.plan.nactive[t1];
+    if (m0 >= nn) return;
+    const int n0 = ((int)blockIdx.y - a.dh_tiles) * TileCfg::BN, in = a.in;
+    const size_t trow1 = ((size_t)dir * a.J + t1) * a.B;
+    MmaB mma;
+    mma.init(tid);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + trow1 * (size_t)K, (unsigned)nn * K * 2);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir], (unsigned)in * K * 2);  // the x rows of wb
+    RowSrc<TileCfg::A_GLDS> az;
+    RowSrc<TileCfg::B_GLDS> bw;
+    az.setup(mma.wave_all, mma.lane, m0, nn, K * 2);
+    bw.setup(mma.wave_all, mma.lane, n0, in, K * 2);
+    auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
+      az.issue(rz, As, mma.wave_all, tile * 64);
+      bw.issue(rw, Bs, mma.wave_all, tile * 64);
+    };
+    glds_mainloop<false>(mma, issue, K / 32, smem_h, nullptr, a.sp ? 4 : 0);
+#pragma unroll
+    for (int ti = 0; ti < MmaB::TM; ++ti) {
+      int64_t xos[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xos[r] = a.plan.xo[trow1 + min(m0 + mma.row_of(ti, r), nn - 1)];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = m0 + mma.row_of(ti, r);
+        if (i >= nn) continue;
+#pragma unroll
+        for (int tj = 0; tj < MmaB::TN; ++tj) {
+          const int n = n0 + mma.col_of(tj);
+          if (n < in) atomicAdd(a.dx + xos[r] + n, mma.acc[ti][tj][r]);  // fw and bw meet at a position: two addends
+        }
+      }
+    }
+    return;
+  }
+  if (t < 0) return;  // the extra launch carries dx tiles only
   const int nact = a.plan.nactive[t];
   if (m0 >= nact) return;
   const int nnext = (t + 1 < a.J) ? a.plan.nactive[t + 1] : 0;
@@ -490,6 +536,21 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
   }
 }
 
+// How many 256-wide dx column tiles the fused backward step should carry (0: dx stays a separate pass).
+// FVTA_LSTM_DX_FUSED=0 switches it off (measurement).
+int bwd_fused_dx_tiles(int in, int d) {
+  static const int mode = [] {
+    const char* e = getenv("FVTA_LSTM_DX_FUSED");
+    return e ? atoi(e) : FVTA_LSTM_DX_FUSED_DEFAULT;
+  }();
+  static const bool narrow = [] {
+    const char* e = getenv("FVTA_LSTM_BWD_NARROW_TILE");
+    return e && e[0] == '1';
+  }();
+  if (!mode || d % 256 != 0 || narrow) return 0;
+  return (in + 255) / 256;
+}
+
 void launch_bwd_fused_bf16(const FusedBwdArgs& a_, hipStream_t s) {
   FusedBwdArgs a = a_;
   a.sp = (glds_sp_mask() >> 1) & 1;
@@ -497,19 +558,24 @@ void launch_bwd_fused_bf16(const FusedBwdArgs& a_, hipStream_t s) {
     const char* e = getenv("FVTA_LSTM_BWD_NARROW_TILE");
     return e && e[0] == '1';
   }();
+  // (a.dx_tiles: extra column tiles of the launch that compute dx_{t+1}; set by bwd_fused_dx_tiles())
   if (a.d % 256 == 0 && (tile128_mask() & 2)) {
     constexpr int LDS = TileCfgT<2, 4>::LDS_BYTES + 256 * 8;
     allow_big_lds(lstm_bwd_fused_bf16<2, 4>, LDS);
-    const dim3 grid(pad8((a.B + 255) / 256), a.d / 256, 2);
+    a.dh_tiles = a.d / 256;
+    const dim3 grid(pad8((a.B + 255) / 256), a.dh_tiles + a.dx_tiles, 2);
     hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4>), grid, dim3(256), LDS, s, a);
   } else if (a.d % 256 == 0 && !narrow) {  // 256 x 256 tile: dz (the A operand, K = 4d wide) is re-read d/256 instead of d/128 times
     constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
     allow_big_lds(lstm_bwd_fused_bf16<2, 2>, LDS);
-    const dim3 grid(pad8((a.B + 255) / 256), a.d / 256, 2);
+    a.dh_tiles = a.d / 256;
+    const dim3 grid(pad8((a.B + 255) / 256), a.dh_tiles + a.dx_tiles, 2);
     hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 2>), grid, dim3(512), LDS, s, a);
   } else {
     allow_big_lds(lstm_bwd_fused_bf16<1, 2>, FWD_LDS);
-    const dim3 grid(pad8((a.B + 255) / 256), (a.d + 127) / 128, 2);
+    a.dh_tiles = (a.d + 127) / 128;
+    a.dx_tiles = 0;  // (bwd_fused_dx_tiles() never asks for them with the narrow tile)
+    const dim3 grid(pad8((a.B + 255) / 256), a.dh_tiles, 2);
     hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 2>), grid, dim3(256), FWD_LDS, s, a);
   }
 }

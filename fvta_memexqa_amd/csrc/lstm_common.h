@@ -391,10 +391,12 @@ struct FusedBwdArgs {
   int t, B, J, in, d, in_i;
   int stamp_wg;  // diagnostics: workgroup that stamps the shader clock (-1: none)
   int sp;        // software-pipelined main loop
+  int dh_tiles, dx_tiles;  // column tiles of the fused step launch: dh_t tiles, then dx_{t+1} tiles (0: separate dx pass)
   int ntl;       // read-once operands of the gate gradient (saved gates, cell states, d_out) through non-temporal loads
 };
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s);
 void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s);
+int bwd_fused_dx_tiles(int in, int d);
 void launch_dw_bf16(const DwArgs& a, hipStream_t s);
 void launch_dw_reduce_bf16(const float* slabs, int nslab, int in, int in_i, int d, float* dW, float* dbias, hipStream_t s);
 int test_gemm_bf16(int layout, int M, int N, int K, const float* A, const float* B, float* C, hipStream_t s);
