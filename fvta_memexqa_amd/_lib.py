@@ -79,11 +79,13 @@ _SIGS = {
     "fvta_weight_decay": (c_int, [P, P, c_int64, c_float, P, P]),
     "fvta_probe_hbm_read": (c_int, [P, ctypes.c_size_t, P, P]),
     "fvta_probe_spin": (c_int, [c_int64, P]),
+    "fvta_probe_hbm_mix": (c_int, [P, ctypes.c_size_t, c_int32, c_int32, P]),
     "fvta_softmax_fwd": (c_int, [P, P, c_int64, c_int32, P]),
     "fvta_softsel_fwd": (c_int, [P, P, P, c_int64, c_int32, c_int32, P]),
     "fvta_exp_mask": (c_int, [P, P, P, c_int64, P]),
     "fvta_linear_fwd": (c_int, [P, P, P, P, c_int64, c_int32, c_int32, c_int32, P]),
     "fvta_wsum_fwd": (c_int, [P, P, P, c_int64, c_int32, c_int32, P]),
+    "fvta_dmn_features": (c_int, [P, P, P, P, c_int32, c_int32, c_int32, P]),
     "fvta_attn_read_u": (c_int, [POINTER(AttnDesc), P, P, P]),
     "fvta_test_gemm": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),
     "fvta_profile_enable": (c_int, [c_int32]),

@@ -108,6 +108,16 @@ __global__ __launch_bounds__(256) void hbm_read_probe_kernel(const probe_f32x4* 
   for (; i < n16; i += stride) acc += p[i];
   if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345678e30f) sink[0] = acc[0];  // never true: keeps the loads alive
 }
+// read `nr` streams and write `nw` streams of n16 float4 each, all out of / into one buffer (stream k at base + k * n16):
+// the achievable rate of a MIXED read/write stream set, which is what the LSTM step epilogues are (5 reads : 2 writes)
+__global__ __launch_bounds__(256) void hbm_mix_probe_kernel(probe_f32x4* __restrict__ base, size_t n16, int nr, int nw) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+    probe_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nr; ++k) acc += __builtin_nontemporal_load(base + (size_t)k * n16 + i);
+    for (int k = 0; k < nw; ++k) __builtin_nontemporal_store(acc, base + (size_t)(nr + k) * n16 + i);
+  }
+}
 // one wave that waits `ticks` of the 100 MHz wall clock: two of these on two streams finish in one wait when the
 // streams own different hardware queues and in two when they share one (fvta_probe_spin)
 __global__ void spin_probe_kernel(long long ticks) {
@@ -120,6 +130,14 @@ extern "C" int fvta_probe_spin(int64_t microseconds, fvta_stream_t stream) {
   FVTA_CHECK_ARG(microseconds > 0 && microseconds <= 100000, "probe_spin: 1..100000 us");
   hipLaunchKernelGGL(fvta::spin_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100);
   FVTA_CHECK_LAUNCH("spin_probe");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_probe_hbm_mix(void* buf, size_t bytes_per_stream, int32_t nread, int32_t nwrite, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(buf && bytes_per_stream >= 16 && nread >= 0 && nwrite >= 0 && nread + nwrite > 0, "probe_hbm_mix: bad arguments");
+  hipLaunchKernelGGL(fvta::hbm_mix_probe_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream,
+                     (fvta::probe_f32x4*)buf, bytes_per_stream / 16, nread, nwrite);
+  FVTA_CHECK_LAUNCH("hbm_mix_probe");
   return FVTA_OK;
 }
 

@@ -134,7 +134,34 @@ __global__ __launch_bounds__(256) void wsum_kernel(const float* __restrict__ tar
     out[r * d + c] = acc;
   }
 }
+// DMN+ episode attention features (model_dmnplus.py:93-98): out[n,f,:] = [fact*q, fact*m, |fact-q|, |fact-m|].
+// grid N*F, 256 threads
+__global__ __launch_bounds__(256) void dmn_features_kernel(const float* __restrict__ facts, const float* __restrict__ q,
+                                                          const float* __restrict__ m, float* __restrict__ out, int F, int d) {
+  const int64_t row = blockIdx.x;
+  const int n = (int)(row / F);
+  const float* f = facts + row * d;
+  const float* qv = q + (size_t)n * d;
+  const float* mv = m + (size_t)n * d;
+  float* o = out + row * 4 * d;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    const float fv = f[c], a = qv[c], b = mv[c];
+    o[c] = fv * a;
+    o[d + c] = fv * b;
+    o[2 * d + c] = fabsf(fv - a);
+    o[3 * d + c] = fabsf(fv - b);
+  }
+}
 }  // namespace fvta
+
+extern "C" int fvta_dmn_features(const float* facts, const float* q, const float* m, float* out, int32_t N, int32_t F,
+                                 int32_t d, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(facts && q && m && out && N > 0 && F > 0 && d > 0, "dmn_features: bad arguments");
+  hipLaunchKernelGGL(fvta::dmn_features_kernel, dim3((unsigned)((size_t)N * F)), dim3(256), 0, (hipStream_t)stream, facts, q, m,
+                     out, F, d);
+  FVTA_CHECK_LAUNCH("dmn_features");
+  return FVTA_OK;
+}
 
 extern "C" int fvta_wsum_fwd(const float* target, const float* weights, float* out, int64_t rows, int32_t J, int32_t d,
                              fvta_stream_t stream) {

@@ -618,6 +618,10 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
   }();
   const bool overlap = bf && !(dbg & 2048) && side != nullptr && side != stream && (ov_mask & 3);
   const bool ov_dx = overlap && (ov_mask & 1), ov_dw = overlap && (ov_mask & 2);
+  // bit 2: the two directions' recurrences on two streams (main: forward direction, side: backward direction), the
+  // side one started half a step late -- the directions are independent chains, and apart in phase one direction's
+  // HBM-bound epilogue runs beside the other's k-loop instead of the whole chip alternating between the two
+  const bool split_dirs = bf && !(dbg & 2048) && side != nullptr && side != stream && (ov_mask & 4) && !overlap;
   std::vector<hipEvent_t> events;
   auto new_event = [&]() -> hipEvent_t {
     hipEvent_t e = nullptr;
@@ -648,6 +652,8 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
     f.t0 = 0;
     f.nt = J;
     f.dh_tiles = 0;
+    f.dir0 = 0;
+    f.ndir = 2;
     // dx rides on the step launches (dx_{t+1} next to dh_t: same A operand) unless it goes to the side stream / is off
     f.dx_tiles = (dx && !ov_dx) ? bwd_fused_dx_tiles(in, dd) : 0;
     f.stamp_wg = fvta_diag_env("FVTA_LSTM_STAMP_BWD", -1);  // -DFVTA_DIAG builds only
@@ -658,6 +664,26 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
       }();
       f.ntl = (nt & 2) != 0;
     }
+    if (split_dirs) {
+      hipEvent_t e = new_event();
+      ev_ok = e && hipEventRecord(e, stream) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess;
+      const int delay_us = (ov_mask >> 8) & 0xFFF;  // bits 8..19: head start of the main stream's direction, in us
+      if (ev_ok && delay_us > 0) (void)fvta_probe_spin(delay_us, side);
+      FusedBwdArgs f0 = f, f1 = f;
+      f0.ndir = f1.ndir = 1;
+      f1.dir0 = 1;
+      f0.dx_tiles = f1.dx_tiles = 0;
+      for (int t = J - 1; t >= 0 && ev_ok; --t) {
+        f0.t = f1.t = t;
+        launch_bwd_fused_bf16(f0, stream);
+        launch_bwd_fused_bf16(f1, side);
+      }
+      f.dx_tiles = 0;
+      if (ev_ok) {
+        hipEvent_t e2 = new_event();
+        ev_ok = e2 && hipEventRecord(e2, side) == hipSuccess && hipStreamWaitEvent(stream, e2, 0) == hipSuccess;
+      }
+    } else
     for (int t = J - 1; t >= 0; --t) {
       f.t = t;
       launch_bwd_fused_bf16(f, stream);

@@ -406,7 +406,7 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
   typedef MmaBT<WN, TM> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + TileCfg::STAGES * TileCfg::STAGE_ELEMS);
-  const int tid = threadIdx.x, dir = blockIdx.z;
+  const int tid = threadIdx.x, dir = blockIdx.z + a.dir0;
   const int m0 = blockIdx.x * TileCfg::BM, u0 = blockIdx.y * TileCfg::BN;
   const int t = a.t, d = a.d, K = 4 * d;
   // ---- dx tiles riding on the step launch (a.dx_tiles > 0): the column tiles from d/BN on compute
@@ -563,19 +563,19 @@ void launch_bwd_fused_bf16(const FusedBwdArgs& a_, hipStream_t s) {
     constexpr int LDS = TileCfgT<2, 4>::LDS_BYTES + 256 * 8;
     allow_big_lds(lstm_bwd_fused_bf16<2, 4>, LDS);
     a.dh_tiles = a.d / 256;
-    const dim3 grid(pad8((a.B + 255) / 256), a.dh_tiles + a.dx_tiles, 2);
+    const dim3 grid(pad8((a.B + 255) / 256), a.dh_tiles + a.dx_tiles, a.ndir);
     hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4>), grid, dim3(256), LDS, s, a);
   } else if (a.d % 256 == 0 && !narrow) {  // 256 x 256 tile: dz (the A operand, K = 4d wide) is re-read d/256 instead of d/128 times
     constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
     allow_big_lds(lstm_bwd_fused_bf16<2, 2>, LDS);
     a.dh_tiles = a.d / 256;
-    const dim3 grid(pad8((a.B + 255) / 256), a.dh_tiles + a.dx_tiles, 2);
+    const dim3 grid(pad8((a.B + 255) / 256), a.dh_tiles + a.dx_tiles, a.ndir);
     hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 2>), grid, dim3(512), LDS, s, a);
   } else {
     allow_big_lds(lstm_bwd_fused_bf16<1, 2>, FWD_LDS);
     a.dh_tiles = (a.d + 127) / 128;
     a.dx_tiles = 0;  // (bwd_fused_dx_tiles() never asks for them with the narrow tile)
-    const dim3 grid(pad8((a.B + 255) / 256), a.dh_tiles, 2);
+    const dim3 grid(pad8((a.B + 255) / 256), a.dh_tiles, a.ndir);
     hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 2>), grid, dim3(256), FWD_LDS, s, a);
   }
 }

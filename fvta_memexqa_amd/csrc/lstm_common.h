@@ -391,6 +391,7 @@ struct FusedBwdArgs {
   int t, B, J, in, d, in_i;
   int stamp_wg;  // diagnostics: workgroup that stamps the shader clock (-1: none)
   int sp;        // software-pipelined main loop
+  int dir0, ndir;          // directions this launch covers: [dir0, dir0 + ndir) (2 streams: one direction each)
   int dh_tiles, dx_tiles;  // column tiles of the fused step launch: dh_t tiles, then dx_{t+1} tiles (0: separate dx pass)
   int ntl;       // read-once operands of the gate gradient (saved gates, cell states, d_out) through non-temporal loads
 };

@@ -49,7 +49,7 @@ def reset_default_graph():
 
 
 def _name(*parts):
-    return "/".join(list(_scope) + [p for p in parts if p])
+    return "/".join([p for p in _scope if p] + [p for p in parts if p])
 
 
 def get_variable(name, shape, init="trunc_normal", seed=None):
@@ -61,6 +61,10 @@ def get_variable(name, shape, init="trunc_normal", seed=None):
     dev = ops.require_gpu()
     if init == "zeros":
         v = torch.zeros(*shape, dtype=torch.float32, device=dev)
+    elif init == "glorot":          # tf.get_variable's default / xavier_initializer: uniform(+-sqrt(6 / (fan_in + fan_out)))
+        g = torch.Generator().manual_seed(zlib.crc32(name.encode()) if seed is None else seed)
+        lim = (6.0 / (shape[0] + shape[-1])) ** 0.5
+        v = ((torch.rand(*shape, generator=g) * 2 - 1) * lim).to(dev)
     else:
         from .synth import _trunc_normal
         g = torch.Generator().manual_seed(zlib.crc32(name.encode()) if seed is None else seed)
@@ -292,3 +296,47 @@ def attention_tgif(hinfo, lq, hinfo_mask=None, wd=None, mlp_dim=512, scope=None)
         if wd is not None:                                                    # add_wd over the whole scope (:241-242)
             _add_wd([n for n in variables if n.startswith(_name("") )], wd)
     return final + lq, att
+
+
+# ------------------------------------------------------------------ DMN+ episode (model_dmnplus.py:89-136)
+def _get_attention(q_vec, prev_memory, fact_vecs, hidden_size):
+    """model_dmnplus.py:89-111 for ALL facts at once (the reference unstacks the facts and reuses the two
+    fully_connected layers): facts [N,F,d] -> attention logits [N,F].  Variables attention/fc1/{weights,biases}
+    (tanh), attention/fc2/{weights,biases} (tf.contrib.layers.fully_connected: Glorot weights, zero biases)."""
+    N, F, d = fact_vecs.shape
+    feats = torch.empty(N, F, 4 * d, dtype=torch.float32, device=fact_vecs.device)
+    check(_lib.load().fvta_dmn_features(ptr(_f32(fact_vecs)), ptr(_f32(q_vec)), ptr(_f32(prev_memory)), ptr(feats), N, F, d,
+                                        stream_ptr()), "fvta_dmn_features")
+    with variable_scope("attention"):
+        W1 = get_variable(_name("fc1", "weights"), (4 * d, hidden_size), init="glorot")
+        b1 = get_variable(_name("fc1", "biases"), (hidden_size,), init="zeros")
+        W2 = get_variable(_name("fc2", "weights"), (hidden_size, 1), init="glorot")
+        b2 = get_variable(_name("fc2", "biases"), (1,), init="zeros")
+    a1 = linear_raw(feats, W1, b1, add_tanh=True)
+    return linear_raw(a1, W2, b2).reshape(N, F)
+
+
+def generate_episode(memory, q_vec, fact_vecs, fact_vecs_length, hop_index, hidden_size, scope=None):
+    """model_dmnplus.py:113-136 `_generate_episode`: attention over the facts from (question, previous memory), softmax
+    over ALL F facts (no mask in the reference), then the AttentionGRUCell (attention_gru_cell.py:50-70) run by
+    dynamic_rnn over the facts with sequence_length: the state is carried past a row's length -- which the cell does by
+    itself when the attention gate is 0, so the gates of steps >= length are zeroed.  Returns the episode [N,d].
+    Variables live under the current scope (hop_index > 0 reuses them, as the reference's reuse flags do)."""
+    from .attention_gru_cell import AttentionGRUCell
+    fact_vecs = _f32(fact_vecs)
+    N, F, d = fact_vecs.shape
+    with variable_scope(scope):
+        att = softmax(_get_attention(q_vec, memory, fact_vecs, hidden_size))                  # [N,F]
+        live = (torch.arange(F, device=att.device)[None, :] < fact_vecs_length.to(att.device)[:, None]).to(torch.float32)
+        g = _wsum(att.reshape(N * F, 1, 1), live.reshape(N * F, 1)).reshape(N, F, 1)          # att * (t < length)
+        gru_inputs = torch.cat([fact_vecs, g], 2).contiguous()                               # [N,F,d+1] (tf.concat)
+        with variable_scope("attention_gru"):
+            cell = AttentionGRUCell(hidden_size)
+            names = ("gates/weights", "gates/biases", "candidate/weights", "input/weights", "input/biases")
+            shapes = ((2 * d, d), (d,), (d, d), (d, d), (d,))
+            params = {n_: get_variable(_name("attention_gru_cell", n_), sh, init="zeros" if n_.endswith("biases") else "glorot")
+                      for n_, sh in zip(names, shapes)}
+        state = torch.zeros(N, d, dtype=torch.float32, device=att.device)
+        for t in range(F):
+            state, _ = cell(gru_inputs[:, t].contiguous(), state, params)
+    return state

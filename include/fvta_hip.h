@@ -331,6 +331,12 @@ int fvta_linear_fwd(const float* x, const float* W, const float* b, float* y, in
 /* sum_j weights[r,j] * target[r,j,:] -> out[r,:] (no softmax): the attended vector of attention_tgif, model.py:236-238 */
 int fvta_wsum_fwd(const float* target, const float* weights, float* out, int64_t rows, int32_t J, int32_t d,
                   fvta_stream_t stream);
+/* The feature vector of the DMN+ episode attention, model_dmnplus.py:93-98 (`_get_attention`), for all facts at once:
+ * out[n,f,:] = [fact*q, fact*m, |fact-q|, |fact-m|]  (facts [N,F,d], q / m [N,d] -> out [N,F,4d]).  The two
+ * fully_connected layers on top of it are fvta_linear_fwd, the softmax over facts fvta_softmax_fwd, the gated recurrence
+ * fvta_attgru_fwd per fact (functional.generate_episode). */
+int fvta_dmn_features(const float* facts, const float* q, const float* m, float* out, int32_t N, int32_t F, int32_t d,
+                      fvta_stream_t stream);
 /* attention_keeprank1 (model.py:247-314) = the per-(n,k) inner softsel of attention_3d without the softmax over k:
  * after fvta_attn_fwd(desc with K = M) this copies that result, u[N,K,w], out of the saved state. */
 int fvta_attn_read_u(const fvta_attn_desc* d, const void* saved, float* u_out, fvta_stream_t stream);
@@ -361,6 +367,11 @@ int fvta_profile_collect(int32_t id, double* total_ms, int64_t* launches);
 /* Measurement hook (bench.py, SURVEY 8d "achievable peak"): one read-only, fully coalesced, non-temporal pass over
  * `bytes` of device memory; the caller times it.  Not part of the reference surface. */
 int fvta_probe_hbm_read(const void* buf, size_t bytes, float* sink, fvta_stream_t stream);
+/* Measurement hook: `nread` streams read and `nwrite` streams written, bytes_per_stream each, all inside `buf`
+ * (which must hold (nread + nwrite) * bytes_per_stream bytes), 16 B per lane, coalesced, non-temporal; the caller times
+ * it.  The achievable rate of a mixed read/write stream set -- what the LSTM step epilogues are.  Not part of the
+ * reference surface. */
+int fvta_probe_hbm_mix(void* buf, size_t bytes_per_stream, int32_t nread, int32_t nwrite, fvta_stream_t stream);
 /* Measurement hook (Model side-stream selection): one wave that occupies `stream` for `microseconds` of the 100 MHz
  * wall clock.  Two of them on two streams take one wait if the streams run concurrently (separate hardware queues)
  * and two if HIP mapped both streams onto one queue.  Not part of the reference surface. */

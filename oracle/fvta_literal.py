@@ -437,6 +437,27 @@ def attention_gru_cell(inputs, state, Wg, bg, Wc, Wi, bi):
 # ----------------------------------------------------------------------------
 # Optimisers: trainer.py:16-17  [TF-internal update rules]
 # ----------------------------------------------------------------------------
+def dmn_generate_episode(memory, q_vec, fact_vecs, fact_vecs_length, p):
+    """model_dmnplus.py:89-136: `_get_attention` per fact (features [f*q, f*m, |f-q|, |f-m|] -> fc1 tanh -> fc2), softmax over
+    ALL facts, then dynamic_rnn(AttentionGRUCell) over [fact, attention] with sequence_length (state carried past the
+    length; the episode is the final state).  p: fc1_W [4d,H], fc1_b, fc2_W [H,1], fc2_b, Wg, bg, Wc, Wi, bi."""
+    N, F, d = fact_vecs.shape
+    atts = []
+    for i in range(F):                                     # tf.unstack(fact_vecs, axis=1), :116-118
+        fv = fact_vecs[:, i]
+        feat = np.concatenate([fv * q_vec, fv * memory, np.abs(fv - q_vec), np.abs(fv - memory)], 1)   # :93-98
+        a = np.tanh(feat @ p["fc1_W"] + p["fc1_b"])       # :100-104
+        atts.append((a @ p["fc2_W"] + p["fc2_b"])[:, 0])   # :106-109
+    att = softmax(np.stack(atts).T)                        # :120-121
+    state = np.zeros((N, d), fact_vecs.dtype)
+    for t in range(F):                                     # dynamic_rnn, :130-134
+        inp = np.concatenate([fact_vecs[:, t], att[:, t:t + 1]], 1)
+        new = attention_gru_cell(inp, state, p["Wg"], p["bg"], p["Wc"], p["Wi"], p["bi"])
+        live = (t < np.asarray(fact_vecs_length))[:, None]
+        state = np.where(live, new, state)
+    return state
+
+
 def adadelta_step(var, grad, accum, accum_update, lr, rho=0.95, eps=1e-8):
     """[TF-internal] tf.train.AdadeltaOptimizer(lr) (trainer.py:16)."""
     accum = rho * accum + (1 - rho) * grad * grad

@@ -39,3 +39,34 @@ def test_attention_gru_cell_forward_backward(B, d):
         np.testing.assert_allclose(got.cpu().numpy(), w, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(w).max()), err_msg=name)
     with pytest.raises(ValueError):
         cell(cu(inputs)[:, :d], cu(state), params)
+
+
+def test_dmn_generate_episode_two_hops():
+    """model_dmnplus.py:113-136 `_generate_episode` (the loop the AttentionGRUCell lives in): attention MLP over the facts,
+    softmax over all facts, gated recurrence with per-row lengths; a second hop reuses the variables."""
+    from fvta_memexqa_amd import functional as Fn
+    from oracle import fvta_literal as L
+    Fn.reset_default_graph()
+    g = torch.Generator().manual_seed(9)
+    N, F, d = 5, 11, 64
+    facts = torch.randn(N, F, d, generator=g) * 0.5
+    q = torch.randn(N, d, generator=g) * 0.5
+    lens = torch.tensor([11, 7, 1, 4, 11])
+    mem = q.clone()
+    eps = []
+    for hop in range(2):
+        ep = Fn.generate_episode(mem.cuda(), q.cuda(), facts.cuda(), lens, hop, d, scope="memory")
+        eps.append(ep.cpu())
+        mem = ep.cpu()
+    v = {k: t.cpu().double().numpy() for k, t in Fn.variables.items()}
+    p = dict(fc1_W=v["memory/attention/fc1/weights"], fc1_b=v["memory/attention/fc1/biases"],
+             fc2_W=v["memory/attention/fc2/weights"], fc2_b=v["memory/attention/fc2/biases"],
+             Wg=v["memory/attention_gru/attention_gru_cell/gates/weights"], bg=v["memory/attention_gru/attention_gru_cell/gates/biases"],
+             Wc=v["memory/attention_gru/attention_gru_cell/candidate/weights"],
+             Wi=v["memory/attention_gru/attention_gru_cell/input/weights"], bi=v["memory/attention_gru/attention_gru_cell/input/biases"])
+    m64 = q.double().numpy()
+    for hop in range(2):
+        ref = L.dmn_generate_episode(m64, q.double().numpy(), facts.double().numpy(), lens.numpy(), p)
+        np.testing.assert_allclose(eps[hop].numpy(), ref, rtol=2e-4, atol=2e-5)
+        m64 = ref
+    assert len([k for k in Fn.variables if k.startswith("memory/")]) == 9          # the second hop created nothing new
