@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--optimizer", default="adam", choices=["adam", "adadelta"])
     ap.add_argument("--batch", type=int, default=None, help="QA pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--side-priority", type=int, default=None,
+                    help="priority of the photo cell's side stream (default: the highest the device offers; 0 = normal)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="serial LSTM backward: dx and the weight gradient after the recurrence instead of beside it on a side stream")
     ap.add_argument("--cpu-sample", type=int, default=4, help="QA pairs in the CPU-baseline sample (4: ~10-15 s of CPU work)")
@@ -180,6 +182,8 @@ def main():
     spec = SynthSpec(**kw)
     cfg = dict(spec.cfg(), batch_size=spec.N, precision=args.precision, optimizer=args.optimizer,
                init_lr=0.001 if args.optimizer == "adam" else 0.5, overlap_bwd_tails=not args.no_overlap)
+    if args.side_priority is not None:
+        cfg["side_stream_priority"] = args.side_priority
     if args.front_end:   # README.MD:144-147 sizes: 100-d GloVe + 100-d char-CNN, 2537-d photo features -> 100
         from fvta_memexqa_amd.synth import make_token_inputs
         cfg.update(word_vocab_size=400, word_emb_size=100, use_char=True, char_vocab_size=100, max_word_size=16,

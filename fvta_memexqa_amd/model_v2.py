@@ -169,7 +169,14 @@ class Model:
         self.max_layouts = int(_cfg(config, "max_cached_layouts", 4))
         # the side stream (photo cell, small launches that run beside the text cell) must own a hardware queue of
         # its own; which torch stream does is measured once here against the current stream (ops.pick_side_stream)
-        self._side, self.side_stream_ratio = ops.pick_side_stream(self.dev)
+        # HIGH priority: the photo cell is a chain of tiny launches (a handful of workgroups each) that must never queue
+        # behind the text cell's chip-filling kernels -- at normal priority its 40 backward launches averaged 199 us
+        # against 70 us unloaded and the photo cell, not the text cell, ended the step (profiles/README.md, r02 timeline)
+        try:
+            hi = torch.cuda.Stream.priority_range()[1]
+        except Exception:
+            hi = 0
+        self._side, self.side_stream_ratio = ops.pick_side_stream(self.dev, priority=int(_cfg(config, "side_stream_priority", hi)))
         # a second one, lowest priority, for the text cell's backward tails (dx, weight gradient per step group:
         # fvta_bilstm_bwd_overlap); it has to run beside the main stream AND the photo cell's stream
         self._side2 = None
