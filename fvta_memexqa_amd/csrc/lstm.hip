@@ -629,7 +629,7 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
     events.push_back(e);
     return e;
   };
-  bool ev_ok = true;
+  bool ev_ok = true, join_side = false;
   fvta_prof_begin(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, stream);
   if (bf && !(dbg & 2048)) {
     // bf16 engine: ONE launch per step -- dh_{t} = dz_{t+1} * wb_h^T in the k-loop, the gate gradient
@@ -708,7 +708,15 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
         }
       }
     }
-    if (dx && !ov_dx) {
+    // bit 3 of the overlap mask: after the recurrence, dx (HBM bound on re-reading dz) runs on the side stream BESIDE
+    // the weight gradient (matrix-pipe / LDS bound) instead of before it -- two kernels with different bottlenecks
+    const bool dx_beside_dw = dx && !ov_dx && side != nullptr && side != stream && (ov_mask & 8) && f.dx_tiles == 0;
+    if (dx_beside_dw) {
+      hipEvent_t e = new_event();
+      ev_ok = ev_ok && e && hipEventRecord(e, stream) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess;
+      if (ev_ok) launch_dx_bf16(f, side);
+      join_side = true;
+    } else if (dx && !ov_dx) {
       if (f.dx_tiles > 0) {
         f.t = -1;  // dx_0: the dx tiles of one more launch
         launch_bwd_fused_bf16(f, stream);
@@ -733,8 +741,8 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
     hipEvent_t e = new_event();
     ev_ok = e && hipEventRecord(e, side) == hipSuccess && hipStreamWaitEvent(stream, e, 0) == hipSuccess;
   }
-  for (hipEvent_t e : events) (void)hipEventDestroy(e);  // released by the runtime once the recorded work completes
   if (!ev_ok) {
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
     fvta_set_error("bilstm_bwd: event plumbing between the main and the side stream failed: %s",
                    hipGetErrorString(hipGetLastError()));
     return FVTA_ERR_LAUNCH;
@@ -767,6 +775,15 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
                        w.nsplit, slab_elems, in + dd, N4, dkernel_bw, dbias_bw);
   }
   if (!ov_dw) fvta_prof_end(FVTA_PROF_LSTM_DW + 16 * d->reserved, 1, stream);
+  if (join_side) {  // dx ran beside the weight gradient: the call's stream takes it back
+    hipEvent_t e = new_event();
+    ev_ok = e && hipEventRecord(e, side) == hipSuccess && hipStreamWaitEvent(stream, e, 0) == hipSuccess;
+  }
+  for (hipEvent_t e : events) (void)hipEventDestroy(e);  // released by the runtime once the recorded work completes
+  if (!ev_ok) {
+    fvta_set_error("bilstm_bwd: joining the side stream failed: %s", hipGetErrorString(hipGetLastError()));
+    return FVTA_ERR_LAUNCH;
+  }
   FVTA_CHECK_LAUNCH("lstm_dw_reduce");
   return FVTA_OK;
 }

@@ -197,10 +197,7 @@ class Model:
         for dr in dirs:
             specs[self.N_IMG_K % dr] = (self.img_in_p + dp, 4 * dp)
             specs[self.N_IMG_B % dr] = (4 * dp,)
-        if F:
-            specs[self.N_ATT_W], specs[self.N_ATT_B] = (F,), (1,)
-            if self.use_question_att:
-                specs[self.N_QATT_W], specs[self.N_QATT_B] = (F,), (1,)
+        specs.update(self._attention_param_specs(F))
         if self.use_time_warp:     # model_v2.py:986-989: WH [4d -> 2d], WC [2d -> 1]
             specs[self.N_TW_WH_W], specs[self.N_TW_WH_B] = (2 * wp, wp), (wp,)
             specs[self.N_TW_WC_W], specs[self.N_TW_WC_B] = (wp,), (1,)
@@ -221,6 +218,16 @@ class Model:
         self.early_work = None      # pending all-reduce of the early gradient bucket (data parallelism), see backward()
         self.init_parameters(int(_cfg(config, "weight_seed", 42)))
         self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self.dev)
+
+    def _attention_param_specs(self, F):
+        """name -> shape of the attention block's variables (F = features per att_logits/W; 0: cosine, none).  The
+        model.py-style subclass (fvta_memexqa_amd/model.py) has its own set."""
+        specs = {}
+        if F:
+            specs[self.N_ATT_W], specs[self.N_ATT_B] = (F,), (1,)
+            if self.use_question_att:
+                specs[self.N_QATT_W], specs[self.N_QATT_B] = (F,), (1,)
+        return specs
 
     def wd_multipliers(self):
         """How many add_wd calls cover each variable (model_v2.py:347-354 adds one l2 term per trainable of the
@@ -757,6 +764,21 @@ class Model:
                 kf, bf, kb, bb = self._cell_params(cell)
                 G.op.forward(G.x, L.arena, kf, bf, kb, bb)                 # encoders + context tensor
         main.wait_stream(self._side)
+        att, qatt = self._attend(L, want_logits)
+        L.logits, L.yp, L.loss_t = ops.scorer_ce_fwd(L.gq, L.g1, L.lch, P.view(self.N_OUT_W), P.view(self.N_OUT_B),
+                                                     L.y if L.has_y else None, self.use_eu_output, self.add_tanh)
+        if self.wd and L.has_y:                                              # :1094-1095: loss = add_n("losses")
+            self._apply_wd(False, L.loss_t)
+        self.logits, self.yp, self.loss = L.logits, L.yp, L.loss_t
+        self.hall = L.hall
+        if want_logits:
+            self.att_logits, self.q_att_logits = att, qatt
+        return L.yp
+
+    def _attend(self, L, want_logits):
+        """The block between the encoders and the scorer (model_v2.py:953-1050): time warp, attention_3d, question
+        attention.  Sets L.g1, L.gq, L.lch (= gchoices); returns the two logit tensors (None unless wanted)."""
+        P = self.params
         T = L.groups["text"]
         T.op.last_state(L.arena, T.segs[1]["s0"], T.segs[1]["count"], L.lch)   # lchoices :807-812
         W = P.view(self.N_ATT_W) if self.simi != 4 else None
@@ -779,58 +801,16 @@ class Model:
         else:
             T.op.last_state(L.arena, T.segs[0]["s0"], T.segs[0]["count"], L.lq)  # lq :697
             L.gq, qatt = L.lq, None
-        L.logits, L.yp, L.loss_t = ops.scorer_ce_fwd(L.gq, L.g1, L.lch, P.view(self.N_OUT_W), P.view(self.N_OUT_B),
-                                                     L.y if L.has_y else None, self.use_eu_output, self.add_tanh)
-        if self.wd and L.has_y:                                              # :1094-1095: loss = add_n("losses")
-            self._apply_wd(False, L.loss_t)
-        self.logits, self.yp, self.loss = L.logits, L.yp, L.loss_t
-        self.hall = L.hall
-        if want_logits:
-            self.att_logits, self.q_att_logits = att, qatt
-        return L.yp
+        return att, qatt
 
     # -------------------------------------------------------------- backward
     def backward(self, L, loss_scale=1.0, need_dx=False):
         """Gradient of the mean cross-entropy into params.grad (accumulated)."""
         P = self.params
-        cos = self.simi == 4      # cosine similarity has no att_logits/{W,b}
-        aW, ab = (None, None) if cos else (P.view(self.N_ATT_W), P.view(self.N_ATT_B))
-        daW, dab = (None, None) if cos else (P.view(self.N_ATT_W, True), P.view(self.N_ATT_B, True))
-        if self.use_question_att and not cos:
-            qW, qb, dqW, dqb = P.view(self.N_QATT_W), P.view(self.N_QATT_B), P.view(self.N_QATT_W, True), P.view(self.N_QATT_B, True)
-        else:
-            qW = qb = dqW = dqb = None
         dgq, dg1, dgch = ops.scorer_ce_bwd(L.gq, L.g1, L.lch, P.view(self.N_OUT_W), P.view(self.N_OUT_B), L.y, L.logits,
                                            L.yp, loss_scale, P.view(self.N_OUT_W, True), P.view(self.N_OUT_B, True),
                                            self.use_eu_output, self.add_tanh, self.tf_xent_grad)
-        L.d_arena[L.row_hq:].zero_()   # hq / hchoices gradient rows; the hall rows are written by the attention backward
-        d_hall = L.d_arena[:L.row_hq].view(L.N, L.K, L.T, self.wp)
-        d_hq = L.d_arena[L.row_hq:L.row_hch].view(L.N, L.JQ, self.wp)
-        T = L.groups["text"]
-        if self.use_question_att:
-            # g1 feeds both the scorer and the question attention: accumulate its second gradient in place
-            # (the hq region of d_arena is still zero here, so accumulate mode is exact for it too)
-            L.qatt.backward(L.hq, L.g1.view(L.N, 1, self.wp), L.q_mask, L.ones_mask, qW, qb, dgq,
-                            d_hq.view(L.N, 1, L.JQ, self.wp), dg1.view(L.N, 1, self.wp), dqW, dqb, accumulate=True)
-        else:
-            T.op.last_state_bwd(dgq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
-        T.op.last_state_bwd(dgch.view(-1, self.wp), T.segs[1]["s0"], T.segs[1]["count"], L.d_arena)
-        if self.use_time_warp:
-            # attention gradient w.r.t. the warped tensor (masked rows zeroed: the warp backward walks every row),
-            # then through the warp into the hall rows of the arena and into lq -> the question encoder's last state
-            if L.d_tscale is not None:
-                L.d_tscale.zero_()
-            L.att.backward(L.ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, L.d_warp, d_hq, daW, dab,
-                           accumulate=3, tscale=L.tscale, d_tscale=L.d_tscale)
-            L.d_lq.zero_()
-            L.tw.backward(L.hall, L.lq, P.view(self.N_TW_WH_W), P.view(self.N_TW_WH_B), P.view(self.N_TW_WC_W),
-                          P.view(self.N_TW_WC_B), L.d_warp, d_hall, L.d_lq, P.view(self.N_TW_WH_W, True),
-                          P.view(self.N_TW_WH_B, True), P.view(self.N_TW_WC_W, True), P.view(self.N_TW_WC_B, True),
-                          d_scale_att=L.d_tscale)
-            T.op.last_state_bwd(L.d_lq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
-        else:
-            L.att.backward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, d_hall, d_hq, daW, dab,
-                           accumulate=2)
+        self._attend_bwd(L, dgq, dg1, dgch)
         main = torch.cuda.current_stream()
         token = getattr(L, "token", False)
         need_dx = need_dx or token          # the embedding parameters are trained through the encoder inputs
@@ -866,6 +846,46 @@ class Model:
                               g(self.N_CONV_B) if cw else None)
             if I_ is not None and self.use_image_trans:
                 I_.embed.backward(I_.pidx, I_.tok_off, L.image_emb_mat, I_.x, I_.dx, g(self.N_IMGT_W), g(self.N_IMGT_B))
+
+    def _attend_bwd(self, L, dgq, dg1, dgch):
+        """Backward of _attend: the scorer's three input gradients into every row of L.d_arena and the attention
+        block's parameter gradients."""
+        P = self.params
+        cos = self.simi == 4      # cosine similarity has no att_logits/{W,b}
+        aW, ab = (None, None) if cos else (P.view(self.N_ATT_W), P.view(self.N_ATT_B))
+        daW, dab = (None, None) if cos else (P.view(self.N_ATT_W, True), P.view(self.N_ATT_B, True))
+        if self.use_question_att and not cos:
+            qW, qb, dqW, dqb = P.view(self.N_QATT_W), P.view(self.N_QATT_B), P.view(self.N_QATT_W, True), P.view(self.N_QATT_B, True)
+        else:
+            qW = qb = dqW = dqb = None
+        L.d_arena[L.row_hq:].zero_()   # hq / hchoices gradient rows; the hall rows are written by the attention backward
+        d_hall = L.d_arena[:L.row_hq].view(L.N, L.K, L.T, self.wp)
+        d_hq = L.d_arena[L.row_hq:L.row_hch].view(L.N, L.JQ, self.wp)
+        T = L.groups["text"]
+        if self.use_question_att:
+            # g1 feeds both the scorer and the question attention: accumulate its second gradient in place
+            # (the hq region of d_arena is still zero here, so accumulate mode is exact for it too)
+            L.qatt.backward(L.hq, L.g1.view(L.N, 1, self.wp), L.q_mask, L.ones_mask, qW, qb, dgq,
+                            d_hq.view(L.N, 1, L.JQ, self.wp), dg1.view(L.N, 1, self.wp), dqW, dqb, accumulate=True)
+        else:
+            T.op.last_state_bwd(dgq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
+        T.op.last_state_bwd(dgch.view(-1, self.wp), T.segs[1]["s0"], T.segs[1]["count"], L.d_arena)
+        if self.use_time_warp:
+            # attention gradient w.r.t. the warped tensor (masked rows zeroed: the warp backward walks every row),
+            # then through the warp into the hall rows of the arena and into lq -> the question encoder's last state
+            if L.d_tscale is not None:
+                L.d_tscale.zero_()
+            L.att.backward(L.ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, L.d_warp, d_hq, daW, dab,
+                           accumulate=3, tscale=L.tscale, d_tscale=L.d_tscale)
+            L.d_lq.zero_()
+            L.tw.backward(L.hall, L.lq, P.view(self.N_TW_WH_W), P.view(self.N_TW_WH_B), P.view(self.N_TW_WC_W),
+                          P.view(self.N_TW_WC_B), L.d_warp, d_hall, L.d_lq, P.view(self.N_TW_WH_W, True),
+                          P.view(self.N_TW_WH_B, True), P.view(self.N_TW_WC_W, True), P.view(self.N_TW_WC_B, True),
+                          d_scale_att=L.d_tscale)
+            T.op.last_state_bwd(L.d_lq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
+        else:
+            L.att.backward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, d_hall, d_hq, daW, dab,
+                           accumulate=2)
 
     def zero_grad(self):
         self.params.grad.zero_()
