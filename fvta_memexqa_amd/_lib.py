@@ -19,7 +19,7 @@ class FvtaError(RuntimeError):
 
 
 class AttnDesc(Structure):
-    _fields_ = [(n, c_int32) for n in ("N", "K", "T", "JQ", "w", "simi", "feat_order", "add_tanh")]
+    _fields_ = [(n, c_int32) for n in ("N", "K", "T", "JQ", "w", "simi", "feat_order", "add_tanh")] + [("hinfo_stride", c_int64)]
 
 
 class LstmDesc(Structure):
@@ -86,6 +86,8 @@ _SIGS = {
     "fvta_linear_fwd": (c_int, [P, P, P, P, c_int64, c_int32, c_int32, c_int32, P]),
     "fvta_wsum_fwd": (c_int, [P, P, P, c_int64, c_int32, c_int32, P]),
     "fvta_dmn_features": (c_int, [P, P, P, P, c_int32, c_int32, c_int32, P]),
+    "fvta_rows_reduce": (c_int, [P, P, c_int64, c_int32, c_int32, c_int64, c_float, c_int32, P]),
+    "fvta_rows_broadcast": (c_int, [P, P, c_int64, c_int32, c_int32, c_int64, c_float, c_int32, P]),
     "fvta_attn_read_u": (c_int, [POINTER(AttnDesc), P, P, P]),
     "fvta_test_gemm": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),
     "fvta_profile_enable": (c_int, [c_int32]),

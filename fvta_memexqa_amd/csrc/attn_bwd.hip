@@ -108,6 +108,7 @@ struct AttnBwdArgs {
   float* d_hinfo;
   int accumulate;
   const float* tscale;  // [N,T] or null (time_warp_att): the inner softmax ran on z = amax * tscale
+  size_t hstride;       // elements between the row blocks of consecutive (n,k) of hinfo / d_hinfo (see AttnFwdArgs)
 };
 
 // TPR threads cover one row (16 B each, G float4 per thread when w > 1024);
@@ -224,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   }
   __syncthreads();
 
-  const float* __restrict__ hbase = a.hinfo + (size_t)nk * T * w;
-  float* __restrict__ dhbase = a.d_hinfo + (size_t)nk * T * w;
+  const float* __restrict__ hbase = a.hinfo + (size_t)nk * a.hstride;
+  float* __restrict__ dhbase = a.d_hinfo + (size_t)nk * a.hstride;
   const float* __restrict__ Qs = a.sv.Qs + (size_t)n * s.W4 * JP * 4;
   constexpr bool cosine = COS;
   const size_t slot = ((size_t)grp * s.bsplit + split) * RH + rh;
@@ -628,6 +629,7 @@ extern "C" int fvta_attn_bwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   FVTA_CHECK_ARG((tscale == nullptr) == (d_tscale == nullptr), "attn_bwd: tscale and d_tscale go together");
   FVTA_CHECK_ARG(hinfo && hq && d_h_a && saved && d_hinfo && d_hq && workspace, "attn_bwd: null pointer");
   FVTA_CHECK_ARG(d->simi == 4 || (dW && db), "attn_bwd: dW/db required");
+  FVTA_CHECK_ARG(!(tscale && d->hinfo_stride), "attn_bwd: tscale with a strided hinfo is not supported");
   hipStream_t stream = (hipStream_t)stream_;
   const bool use_mask = hmask && qmask;
   const AttnShape s = attn_shape(d, use_mask);
@@ -636,8 +638,13 @@ extern "C" int fvta_attn_bwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   const int RH = bwd_rh(s.W4);
   FVTA_CHECK_HIP(hipMemsetAsync(wk.slabs, 0, wk.slab_bytes, stream));
   if (tscale) FVTA_CHECK_HIP(hipMemsetAsync(wk.dscr, 0, (size_t)s.N * s.K * s.T * sizeof(float), stream));
-  if (accumulate == 0 || accumulate == 3)
-    FVTA_CHECK_HIP(hipMemsetAsync(d_hinfo, 0, (size_t)s.N * s.K * s.T * s.w * sizeof(float), stream));
+  if (accumulate == 0 || accumulate == 3) {
+    if (d->hinfo_stride)
+      FVTA_CHECK_HIP(hipMemset2DAsync(d_hinfo, (size_t)d->hinfo_stride * sizeof(float), 0, (size_t)s.T * s.w * sizeof(float),
+                                      (size_t)s.N, stream));
+    else
+      FVTA_CHECK_HIP(hipMemsetAsync(d_hinfo, 0, (size_t)s.N * s.K * s.T * s.w * sizeof(float), stream));
+  }
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(s.N), dim3(256), 0, stream, s, sv, wk, d_h_a);
   AttnBwdArgs a;
   a.s = s;
@@ -648,6 +655,7 @@ extern "C" int fvta_attn_bwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   a.d_hinfo = d_hinfo;
   a.accumulate = accumulate;
   a.tscale = tscale;
+  a.hstride = d->hinfo_stride ? (size_t)d->hinfo_stride : (size_t)s.T * s.w;
   const dim3 grid(s.bsplit, s.N * s.ng);
   const bool prof_it = (size_t)s.N * s.K * s.T >= 65536;  // the context attention, see attn_fwd.hip
   if (prof_it) fvta_prof_begin(FVTA_PROF_ATTN_BWD_MAIN, stream);

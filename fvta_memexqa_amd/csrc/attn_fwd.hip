@@ -201,6 +201,7 @@ struct AttnFwdArgs {
   const float* tscale;  // [N,T] or null: z[n,k,t] = amax[n,k,t] * tscale[n,t] (time_warp_att)
   int ipw;          // 16-row kernel: items per workgroup
   int dbg;          // FVTA_ATTN_DBG experiment bits (diagnostics only)
+  size_t hstride;   // elements between the row blocks of consecutive (n,k): T*w, or fvta_attn_desc.hinfo_stride (K == 1)
 };
 
 // w = 4 * SCW * NSC * NW * NSLAB.  A workgroup is NW waves; a wave owns NSC
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void attn_fwd_main(AttnFw
     }
     return;
   }
-  const float* __restrict__ hbase = a.hinfo + (size_t)nk * T * w;
+  const float* __restrict__ hbase = a.hinfo + (size_t)nk * a.hstride;
   const int32_t* __restrict__ idx = a.sv.idx + (size_t)nk * T;
   const float* __restrict__ Qs = a.sv.Qs + (size_t)n * s.W4 * JP * 4;
   const float* __restrict__ ct = a.sv.ct + (size_t)n * JP;
@@ -1139,6 +1140,8 @@ int fvta_attn_check_desc(const fvta_attn_desc* d) {
   const int w = d->w;
   FVTA_CHECK_ARG(w == 64 || w == 128 || w == 256 || w == 512 || w == 1024 || w == 2048,
                  "attn: w=%d unsupported; pad the hidden size so that w is one of 64,128,256,512,1024,2048", w);
+  FVTA_CHECK_ARG(d->hinfo_stride == 0 || (d->K == 1 && d->hinfo_stride >= (int64_t)d->T * w && d->hinfo_stride % 4 == 0),
+                 "attn: hinfo_stride=%lld needs K == 1, >= T*w and a multiple of 4", (long long)d->hinfo_stride);
   return FVTA_OK;
 }
 
@@ -1170,6 +1173,7 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   if (int e = fvta_attn_check_desc(d)) return e;
   FVTA_CHECK_ARG(hinfo && hq && h_a && saved && workspace, "attn_fwd: null pointer");
   FVTA_CHECK_ARG(d->simi == 4 || (W && b), "attn_fwd: W and b required for simiMatrix 1-3");
+  FVTA_CHECK_ARG(!(tscale && d->hinfo_stride), "attn_fwd: tscale with a strided hinfo is not supported");
   hipStream_t stream = (hipStream_t)stream_;
   const bool use_mask = hmask && qmask;  // model_v2.py:146/233: only when BOTH masks are given
   const AttnShape s = attn_shape(d, use_mask);
@@ -1190,6 +1194,7 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   a.a_logits = a_logits;
   a.part = (float*)workspace;
   a.tscale = tscale;
+  a.hstride = d->hinfo_stride ? (size_t)d->hinfo_stride : (size_t)s.T * s.w;
   a.ipw = 1;
   a.dbg = fvta_diag_env("FVTA_ATTN_DBG", 0);  // -DFVTA_DIAG builds only
   // (the bracket files the context attention only: the K = 1 question attention is a 15 us launch of the same kernel)
@@ -1198,7 +1203,8 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   const char* exact = getenv("FVTA_ATTN_EXACT");
   // (the full logit tensor is an inspection output: only the general kernel writes it)
   // (time_warp_att runs on the general kernel: the 16-row kernel's softmax logits are amax itself)
-  const bool rows16 = s.JT == 1 && s.w >= 128 && s.w <= 1024 && !a_logits && !tscale && !(exact && exact[0] == '1');
+  const bool rows16 = s.JT == 1 && s.w >= 128 && s.w <= 1024 && !a_logits && !tscale && !d->hinfo_stride &&
+                      !(exact && exact[0] == '1');
   if (rows16) {
     // a workgroup streams `ipw` consecutive items: about one workgroup per CU, bounded by its LDS row list
     const int nitems = s.nsplit * s.N * s.K;

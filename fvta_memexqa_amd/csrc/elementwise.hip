@@ -152,7 +152,49 @@ __global__ __launch_bounds__(256) void dmn_features_kernel(const float* __restri
     o[3 * d + c] = fabsf(fv - b);
   }
 }
+// out[r, :] (+)= scale * sum_j x[r, j, :]  (tf.reduce_mean over an inner axis, model.py:874-885, :907; with scale 1
+// the backward of a tile).  grid (rows, ceil(d/256))
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ x, float* __restrict__ out, int J, int d,
+                                                          int64_t out_ld, float scale, int accumulate) {
+  const int64_t r = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= d) return;
+  const float* xr = x + r * (int64_t)J * d + c;
+  float acc = 0.f;
+  for (int j = 0; j < J; ++j) acc += xr[(int64_t)j * d];
+  float* o = out + r * out_ld + c;
+  *o = accumulate ? *o + scale * acc : scale * acc;
+}
+// out[r, j, :] (+)= scale * v[r, :]  (tf.tile along an inner axis; with scale 1/J the backward of reduce_mean).
+// grid (rows * J, ceil(d/256))
+__global__ __launch_bounds__(256) void rows_broadcast_kernel(const float* __restrict__ v, float* __restrict__ out, int J, int d,
+                                                             int64_t v_ld, float scale, int accumulate) {
+  const int64_t rj = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= d) return;
+  const float val = scale * v[(rj / J) * v_ld + c];
+  float* o = out + rj * d + c;
+  *o = accumulate ? *o + val : val;
+}
 }  // namespace fvta
+
+extern "C" int fvta_rows_reduce(const float* x, float* out, int64_t rows, int32_t J, int32_t d, int64_t out_ld, float scale,
+                                int32_t accumulate, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(x && out && rows > 0 && rows < (1ll << 31) && J > 0 && d > 0 && out_ld >= d, "rows_reduce: bad arguments");
+  hipLaunchKernelGGL(fvta::rows_reduce_kernel, dim3((unsigned)rows, (unsigned)((d + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, out, J, d, out_ld, scale, accumulate);
+  FVTA_CHECK_LAUNCH("rows_reduce");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_rows_broadcast(const float* v, float* out, int64_t rows, int32_t J, int32_t d, int64_t v_ld, float scale,
+                                   int32_t accumulate, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(v && out && rows > 0 && J > 0 && rows * J < (1ll << 31) && d > 0 && v_ld >= d, "rows_broadcast: bad arguments");
+  hipLaunchKernelGGL(fvta::rows_broadcast_kernel, dim3((unsigned)(rows * J), (unsigned)((d + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, v, out, J, d, v_ld, scale, accumulate);
+  FVTA_CHECK_LAUNCH("rows_broadcast");
+  return FVTA_OK;
+}
 
 extern "C" int fvta_dmn_features(const float* facts, const float* q, const float* m, float* out, int32_t N, int32_t F,
                                  int32_t d, fvta_stream_t stream) {

@@ -1,0 +1,294 @@
+"""model.py of the reference (`--modelname` without FVTA): the soft-attention baselines the paper compares against.
+
+Same encoders, scorer, loss, feed and checkpoint surface as model_v2 (the two files share model.py:460-800 /
+model_v2.py:490-836 up to whitespace); what differs is the block between the encoders and the scorer
+(model.py:831-983), built here from the SAME HIP kernels as the FVTA path:
+
+  use_ml_att        one 1-D `attention` (model.py:117-186) per context stream            :834-850
+  (default)         mean over the albums of the streams' last LSTM states                :868-885
+  use_mm_att        `attention` over the K per-stream vectors, else their mean           :901-909
+  use_direct_links  `attention` over ALL context rows, added to (or replacing) the above :916-953
+  use_choices_att   `attention_keeprank1` of every choice against the question           :966-968
+  use_question_att  `attention` of the question against the K per-stream vectors         :977-978
+
+Every 1-D attention is fvta_attn_fwd / fvta_attn_bwd with K = 1 (feat_order 1: model.py:149's simiMatrix-2 feature
+order).  The encoder output arena is laid out [N][stream 0 rows | stream 1 rows | ...] WITHOUT the JMAX padding of the
+FVTA context tensor, so the direct-links attention reads it as one dense [N, V, w] tensor and each per-stream attention
+reads its slice through fvta_attn_desc.hinfo_stride -- no concat, no copy.  attention_keeprank1 is the same kernel at
+batch N * num_choice with the question tiled per choice (fvta_rows_broadcast; its gradient comes back through
+fvta_rows_reduce).
+
+Not built (raise at construction): use_bidirection, concat, use_tgif_ml_att (their forward ops are in functional.py).
+"""
+import numpy as np
+import torch
+
+from . import model_v2, ops
+from .model_v2 import _cfg
+
+
+def get_model(config):
+    """model.py:12-16."""
+    return Model(config, "model_%s" % getattr(config, "modelname", "memexqa"))
+
+
+def _stream_masked(cell, dims):
+    """model.py:838-850: at / ad / when / where ([N,M,J] text streams) are attended under (stream mask & q_mask) with
+    config.simiMatrix; pts (:849) and pis (:850) are called without hq_mask and without simiMatrix: NO mask is applied
+    (:137 wants both) and the similarity is the default 1."""
+    return cell == "text" and len(dims) == 3
+
+
+class Model(model_v2.Model):
+    STREAMS = (("at", "text", 3), ("ad", "text", 3), ("when", "text", 3), ("where", "text", 3), ("pts", "text", 4),
+               ("pis", "image", 3))
+    N_ML_W, N_ML_B = "attention/multi_layer_attention/%s/att_logits/W", "attention/multi_layer_attention/%s/att_logits/b"
+    N_MM_W, N_MM_B = "attention/multi_modal_attention/mm_att/att_logits/W", "attention/multi_modal_attention/mm_att/att_logits/b"
+    N_FULL_W, N_FULL_B = "attention/direct_links/full_att/att_logits/W", "attention/direct_links/full_att/att_logits/b"
+    N_CATT_W, N_CATT_B = "choices_emb/choices_att/att_logits/W", "choices_emb/choices_att/att_logits/b"
+
+    def __init__(self, config, scope="model", text_in=None, img_in=None, device=None):
+        for flag, what in (("use_bidirection", "bidirect attention + the bidrection_squash linears (model.py:895-897)"),
+                           ("concat", "the concat variant (model.py:888-889, :987-991)"),
+                           ("use_tgif_ml_att", "attention_tgif per stream (model.py:851-866)")):
+            if _cfg(config, flag, False):
+                raise NotImplementedError("model.py --%s is not built: %s" % (flag, what))
+        if int(_cfg(config, "simiMatrix", 1)) not in (1, 2, 3):
+            raise ValueError("similarity matrix not implemented")            # model.py:152-154 (sys.exit there)
+        self.use_ml_att = bool(_cfg(config, "use_ml_att", False))
+        self.use_mm_att = bool(_cfg(config, "use_mm_att", False))
+        self.use_direct_links = bool(_cfg(config, "use_direct_links", False))
+        self.direct_links_only = self.use_direct_links and bool(_cfg(config, "direct_links_only", False))
+        self.use_choices_att = bool(_cfg(config, "use_choices_att", False))
+        # context streams in stacking order (model.py:892): (name, cell, rank of the mask).  The reference has these six;
+        # `ctx_streams` in the config overrides them (synthetic shapes with another K).
+        self.streams = tuple(tuple(s) for s in (_cfg(config, "ctx_streams", None) or self.STREAMS))
+        cfg = dict(config) if isinstance(config, dict) else dict(vars(config))
+        cfg.update(use_time_warp=False, use_time_warp_att=False)                # model.py has no time warp
+        super().__init__(cfg, scope, text_in, img_in, device)
+        self.config = config
+        self.scorer_tanh = False             # model.py:1011-1013: linear(...) without add_tanh
+        self.ml_att_logits = self.mm_att_logits = None
+
+    @staticmethod
+    def streams_of(inputs):
+        """`ctx_streams` config entry for an oracle-format inputs dict"""
+        return tuple(("ctx%d" % k, st.get("cell", "text"), st["mask"].dim()) for k, st in enumerate(inputs["ctx"]))
+
+    # ------------------------------------------------------------ parameters
+    def _simi_of(self, k):
+        _, cell, rank = self.streams[k]
+        return self.simi if _stream_masked(cell, (0,) * rank) else 1
+
+    def _attention_param_specs(self, F):
+        wp = self.wp
+        feat = {1: 3 * wp, 2: 2 * wp, 3: 4 * wp}
+        specs = {}
+        if self.use_ml_att:
+            for k, (name, _, _) in enumerate(self.streams):
+                specs[self.N_ML_W % name], specs[self.N_ML_B % name] = (feat[self._simi_of(k)],), (1,)
+        if self.use_mm_att:
+            specs[self.N_MM_W], specs[self.N_MM_B] = (F,), (1,)
+        if self.use_direct_links:
+            specs[self.N_FULL_W], specs[self.N_FULL_B] = (F,), (1,)
+        if self.use_choices_att:
+            specs[self.N_CATT_W], specs[self.N_CATT_B] = (F,), (1,)
+        if self.use_question_att:
+            specs[self.N_QATT_W], specs[self.N_QATT_B] = (F,), (1,)
+        return specs
+
+    def wd_multipliers(self):
+        """model.py's add_wd sites (:320-327): the reader scope (:802), every attention / attention_keeprank1 call's own
+        scope (:184, :315), image_trans_linear (:95 via :611), conv1d once per call -- seven (:534-540)."""
+        out = {}
+        for name in self.params.specs:
+            if name.startswith(("reader/", "attention/", "choices_emb/", "question_emb/",
+                                "emb/image/image_transform/image_trans_linear/")):
+                out[name] = 1
+            elif name.startswith("emb/conv/conv1d/"):
+                out[name] = 7
+        return out
+
+    def _oracle_key_map(self):
+        m = super()._oracle_key_map()
+        for k in ("att_W", "att_b", "WH_W", "WH_b", "WC_W", "WC_b"):
+            m.pop(k)
+        for k, (name, _, _) in enumerate(self.streams):
+            m["ml%d_W" % k], m["ml%d_b" % k] = self.N_ML_W % name, self.N_ML_B % name
+        m.update(mm_W=self.N_MM_W, mm_b=self.N_MM_B, full_W=self.N_FULL_W, full_b=self.N_FULL_B, catt_W=self.N_CATT_W,
+                 catt_b=self.N_CATT_B)
+        return m
+
+    # ---------------------------------------------------------------- layout
+    def _plan_arena(self, L, ctx, training):
+        """[context N * V | hq N*JQ | hchoices N*C*JA] with V = sum over the streams of M * (rows per album): row
+        (n, stream k, album m, j) = n * V + off_k + m * per_k + j  (model.py:923-936's `full`, in place)."""
+        if len(ctx) != len(self.streams) or any(c != s[1] or len(d) != s[2] for (c, d), s in zip(ctx, self.streams)):
+            raise ValueError("context streams %s do not match the model's %s" % (ctx, self.streams))
+        dev, wp = self.dev, self.wp
+        N, M, JQ, C, JA = L.N, L.M, L.JQ, L.C, L.JA
+        L.per = [int(np.prod(dims[2:])) for _, dims in ctx]
+        L.Vk = [M * p for p in L.per]
+        L.off = [int(x) for x in np.concatenate([[0], np.cumsum(L.Vk)[:-1]])]
+        L.V = int(sum(L.Vk))
+        L.row_hall, L.row_hq = 0, N * L.V
+        L.row_hch = L.row_hq + N * JQ
+        L.rows = L.row_hch + N * C * JA
+        L.arena = torch.zeros(L.rows, wp, dtype=torch.float32, device=dev)
+        L.d_arena = torch.zeros(L.rows, wp, dtype=torch.float32, device=dev) if training else None
+        L.hall = L.arena[:L.row_hq].view(N, L.V, wp)
+        L.hq = L.arena[L.row_hq:L.row_hch].view(N, JQ, wp)
+        L.hch = L.arena[L.row_hch:].view(N, C, JA, wp)
+        # context masks, stream-major: stream k's [N, V_k] block starts at N * off_k
+        L.hall_mask = torch.zeros(N * L.V, dtype=torch.uint8, device=dev)
+
+        def seq_rows(k, dims):
+            n = torch.arange(N).view(N, 1, 1)
+            m = torch.arange(M).view(1, M, 1)
+            ji = torch.zeros(1, 1, 1, dtype=torch.int64) if len(dims) == 3 else torch.arange(dims[2]).view(1, 1, -1) * dims[3]
+            return (n * L.V + L.off[k] + m * L.per[k] + ji).reshape(-1)
+        return seq_rows
+
+    def _host_ctx_mask(self, L):
+        return np.zeros(L.N * L.V, np.uint8)
+
+    def _put_ctx_mask(self, L, buf, k, m):
+        o = L.N * L.off[k]
+        buf[o:o + L.N * L.Vk[k]].reshape(L.N, L.M, L.per[k])[...] = m
+
+    def _stream_mask(self, L, k):
+        o = L.N * L.off[k]
+        return L.hall_mask[o:o + L.N * L.Vk[k]]
+
+    def _build_attention(self, L, training):
+        dev, wp = self.dev, self.wp
+        N, K, JQ, C, JA = L.N, L.K, L.JQ, L.C, L.JA
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+        att = lambda n, t, jq, simi, stride=0: ops.FocalAttention(n, 1, t, jq, wp, simi, False, feat_order=1, hinfo_stride=stride)
+        L.g1s, L.d_g1s = z(N, K, wp), (z(N, K, wp) if training else None)        # model.py:892  g1 [N,K,2d]
+        L.g1_a, L.g1, L.dg_k = z(N, wp), z(N, wp), z(N, wp)
+        L.lq, L.lch = z(N, wp), z(N, C, wp)
+        L.masked = [_stream_masked(cell, dims) for cell, _, dims in L.ctx_slots]
+        if self.use_ml_att:
+            L.ml = [att(N, L.Vk[k], JQ, self._simi_of(k), L.V * wp) for k in range(K)]
+        else:
+            L.cnt = [L.groups[cell].segs[si]["count"] // N for cell, si, _ in L.ctx_slots]    # sequences per example
+            L.last = [z(N * c, wp) for c in L.cnt]
+            L.d_last = [z(N * c, wp) for c in L.cnt] if training else None
+        L.mm = att(N, K, JQ, self.simi) if self.use_mm_att else None
+        L.full = att(N, L.V, JQ, self.simi) if self.use_direct_links else None
+        L.qatt = att(N, JQ, K, self.simi) if self.use_question_att else None
+        if self.use_choices_att:
+            L.catt = att(N * C, JA, JQ, self.simi)
+            L.hq4, L.d_hq4 = z(N * C, JQ, wp), (z(N * C, JQ, wp) if training else None)
+            L.cmask = torch.zeros(N * C, JA, dtype=torch.uint8, device=dev)
+            L.qmask4 = torch.zeros(N, C, JQ, dtype=torch.uint8, device=dev)
+
+    def load_inputs(self, inputs, training=False):
+        if "at" in inputs:
+            inputs = self.inputs_from_feed(inputs)
+        L = super().load_inputs(inputs, training)
+        if self.use_choices_att:                                               # choices_mask, q_mask tiled per choice
+            m = inputs["choices"]["mask"]
+            m = m if torch.is_tensor(m) else torch.from_numpy(np.ascontiguousarray(m))
+            L.cmask.copy_(m.reshape(L.N * L.C, L.JA).to(torch.uint8))
+            L.qmask4.copy_(L.q_mask[:, None, :].expand(L.N, L.C, L.JQ))
+        return L
+
+    # --------------------------------------------------------------- forward
+    def _pv(self, name, grad=False):
+        return self.params.view(name, grad)
+
+    def _stream_ptr(self, L, k, grad=False):
+        """the arena from stream k's first row on (the strided attention starts there)"""
+        return (L.d_arena if grad else L.arena).view(-1)[L.off[k] * self.wp:]
+
+    def _attend(self, L, want_logits):
+        """model.py:831-983.  Sets L.g1 (g1_all), L.gq, L.lch (gchoices)."""
+        N, K, JQ, C, wp = L.N, L.K, L.JQ, L.C, self.wp
+        T = L.groups["text"]
+        ml_logits = []
+        for k, (cell, si, dims) in enumerate(L.ctx_slots):
+            if self.use_ml_att:                                                 # :834-850
+                name = self.streams[k][0]
+                hm, qm = (self._stream_mask(L, k), L.q_mask) if L.masked[k] else (None, None)
+                g, lg = L.ml[k].forward(self._stream_ptr(L, k), L.hq, hm, qm, self._pv(self.N_ML_W % name),
+                                        self._pv(self.N_ML_B % name), want_logits)
+                ml_logits.append(lg)
+                ops.rows_reduce(g, L.g1s.view(-1)[k * wp:], N, 1, wp, K * wp)   # tf.stack slot k (:892)
+            else:                                                               # :868-885: reduce_mean of the last states
+                G, seg = L.groups[cell], L.groups[cell].segs[si]
+                G.op.last_state(L.arena, seg["s0"], seg["count"], L.last[k])
+                ops.rows_reduce(L.last[k], L.g1s.view(-1)[k * wp:], N, L.cnt[k], wp, K * wp, 1.0 / L.cnt[k])
+        mm_lg = att_lg = q_lg = None
+        if self.use_mm_att:                                                     # :901-904 (hinfo_mask None: no mask)
+            L.g1_a, mm_lg = L.mm.forward(L.g1s, L.hq, None, None, self._pv(self.N_MM_W), self._pv(self.N_MM_B), want_logits)
+        else:
+            ops.rows_reduce(L.g1s, L.g1_a, N, K, wp, wp, 1.0 / K)               # :909
+        if self.use_direct_links:                                               # :916-953
+            full_a, att_lg = L.full.forward(L.hall, L.hq, None, None, self._pv(self.N_FULL_W), self._pv(self.N_FULL_B),
+                                            want_logits)
+            ops.rows_broadcast(full_a, L.g1, N, 1, wp)
+            if not self.direct_links_only:
+                ops.rows_broadcast(L.g1_a, L.g1, N, 1, wp, accumulate=True)
+        else:
+            ops.rows_broadcast(L.g1_a, L.g1, N, 1, wp)
+        if self.use_choices_att:                                                # :966-968
+            ops.rows_broadcast(L.hq, L.hq4, N, C, JQ * wp)                      # the tile of hq per choice (:262)
+            gch, _ = L.catt.forward(L.hch, L.hq4, L.cmask, L.qmask4, self._pv(self.N_CATT_W), self._pv(self.N_CATT_B))
+            L.lch = gch.view(N, C, wp)
+        else:
+            T.op.last_state(L.arena, T.segs[1]["s0"], T.segs[1]["count"], L.lch)     # lchoices :971
+        if self.use_question_att:                                               # :977-978 (hq_mask None: no mask)
+            L.gq, q_lg = L.qatt.forward(L.hq, L.g1s, None, None, self._pv(self.N_QATT_W), self._pv(self.N_QATT_B), want_logits)
+        else:
+            T.op.last_state(L.arena, T.segs[0]["s0"], T.segs[0]["count"], L.lq)      # lq :982
+            L.gq = L.lq
+        if want_logits:
+            self.ml_att_logits, self.mm_att_logits = ml_logits, mm_lg
+        return att_lg, q_lg
+
+    # -------------------------------------------------------------- backward
+    def _attend_bwd(self, L, dgq, dg1, dgch):
+        N, K, JQ, C, JA, wp = L.N, L.K, L.JQ, L.C, L.JA, self.wp
+        T = L.groups["text"]
+        L.d_arena.zero_()
+        L.d_g1s.zero_()
+        d_hall = L.d_arena[:L.row_hq]
+        d_hq = L.d_arena[L.row_hq:L.row_hch]
+        d_hch = L.d_arena[L.row_hch:]
+        g = lambda n: self._pv(n, True)
+        if self.use_choices_att:
+            L.catt.backward(L.hch, L.hq4, L.cmask, L.qmask4, self._pv(self.N_CATT_W), self._pv(self.N_CATT_B),
+                            dgch.view(N * C, wp), d_hch, L.d_hq4, g(self.N_CATT_W), g(self.N_CATT_B), accumulate=0)
+            ops.rows_reduce(L.d_hq4, d_hq, N, C, JQ * wp, accumulate=True)      # gradient of the tile
+        else:
+            T.op.last_state_bwd(dgch.view(-1, wp), T.segs[1]["s0"], T.segs[1]["count"], L.d_arena)
+        if self.use_question_att:
+            L.qatt.backward(L.hq, L.g1s, None, None, self._pv(self.N_QATT_W), self._pv(self.N_QATT_B), dgq, d_hq, L.d_g1s,
+                            g(self.N_QATT_W), g(self.N_QATT_B), accumulate=1)
+        else:
+            T.op.last_state_bwd(dgq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
+        if self.use_direct_links:
+            L.full.backward(L.hall, L.hq, None, None, self._pv(self.N_FULL_W), self._pv(self.N_FULL_B), dg1, d_hall, d_hq,
+                            g(self.N_FULL_W), g(self.N_FULL_B), accumulate=1)
+        if not self.direct_links_only:
+            if self.use_mm_att:
+                L.mm.backward(L.g1s, L.hq, None, None, self._pv(self.N_MM_W), self._pv(self.N_MM_B), dg1, L.d_g1s, d_hq,
+                              g(self.N_MM_W), g(self.N_MM_B), accumulate=1)
+            else:
+                ops.rows_broadcast(dg1, L.d_g1s, N, K, wp, scale=1.0 / K, accumulate=True)
+        elif not self.use_question_att:
+            return                                                              # nothing reaches the per-stream vectors
+        for k, (cell, si, dims) in enumerate(L.ctx_slots):
+            ops.rows_broadcast(L.d_g1s.view(-1)[k * wp:], L.dg_k, N, 1, wp, K * wp)        # d g1[:, k, :], dense
+            if self.use_ml_att:
+                name = self.streams[k][0]
+                hm, qm = (self._stream_mask(L, k), L.q_mask) if L.masked[k] else (None, None)
+                L.ml[k].backward(self._stream_ptr(L, k), L.hq, hm, qm, self._pv(self.N_ML_W % name),
+                                 self._pv(self.N_ML_B % name), L.dg_k, self._stream_ptr(L, k, True), d_hq,
+                                 g(self.N_ML_W % name), g(self.N_ML_B % name), accumulate=1)
+            else:
+                G, seg = L.groups[cell], L.groups[cell].segs[si]
+                ops.rows_broadcast(L.dg_k, L.d_last[k], N, L.cnt[k], wp, scale=1.0 / L.cnt[k])
+                G.op.last_state_bwd(L.d_last[k], seg["s0"], seg["count"], L.d_arena)

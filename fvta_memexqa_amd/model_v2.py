@@ -112,6 +112,7 @@ class Model:
         self.num_choice = int(_cfg(config, "num_choice", 4))      # model_v2.py:381 reads an undefined flag; model.py:353 says 4
         self.simi = int(_cfg(config, "simiMatrix", 1))
         self.add_tanh = bool(_cfg(config, "add_tanh", False))
+        self.scorer_tanh = self.add_tanh     # model_v2.py:1073 (with use_eu_output); model.py's scorer has none
         self.use_question_att = bool(_cfg(config, "use_question_att", False))
         self.use_eu_output = bool(_cfg(config, "use_eu_output", False))
         self.share_fw_bw = bool(_cfg(config, "share_fw_bw", True))
@@ -423,16 +424,20 @@ class Model:
                 wts[name] = _trunc_normal(g, (shape[0] // self.dp * self.d, 1))
         self.set_weights(wts)
 
+    def _oracle_key_map(self):
+        """oracle short key -> reference variable name"""
+        return {"text_kernel": self.N_TEXT_K % "fw", "text_bias": self.N_TEXT_B % "fw",
+                "text_kernel_bw": self.N_TEXT_K % "bw", "text_bias_bw": self.N_TEXT_B % "bw",
+                "image_kernel": self.N_IMG_K % "fw", "image_bias": self.N_IMG_B % "fw",
+                "image_kernel_bw": self.N_IMG_K % "bw", "image_bias_bw": self.N_IMG_B % "bw",
+                "att_W": self.N_ATT_W, "att_b": self.N_ATT_B, "qatt_W": self.N_QATT_W, "qatt_b": self.N_QATT_B,
+                "out_W": self.N_OUT_W, "out_b": self.N_OUT_B, "WH_W": self.N_TW_WH_W, "WH_b": self.N_TW_WH_B,
+                "WC_W": self.N_TW_WC_W, "WC_b": self.N_TW_WC_B, "word_emb": self.N_WORD_EMB, "char_emb": self.N_CHAR_EMB,
+                "conv_filter": self.N_CONV_F, "conv_bias": self.N_CONV_B, "img_W": self.N_IMGT_W, "img_b": self.N_IMGT_B}
+
     def set_oracle_params(self, p):
         """Parameters in the oracle's short-key format (fvta_memexqa_amd.synth.make_params)."""
-        m = {"text_kernel": self.N_TEXT_K % "fw", "text_bias": self.N_TEXT_B % "fw",
-             "text_kernel_bw": self.N_TEXT_K % "bw", "text_bias_bw": self.N_TEXT_B % "bw",
-             "image_kernel": self.N_IMG_K % "fw", "image_bias": self.N_IMG_B % "fw",
-             "image_kernel_bw": self.N_IMG_K % "bw", "image_bias_bw": self.N_IMG_B % "bw",
-             "att_W": self.N_ATT_W, "att_b": self.N_ATT_B, "qatt_W": self.N_QATT_W, "qatt_b": self.N_QATT_B,
-             "out_W": self.N_OUT_W, "out_b": self.N_OUT_B, "WH_W": self.N_TW_WH_W, "WH_b": self.N_TW_WH_B,
-             "WC_W": self.N_TW_WC_W, "WC_b": self.N_TW_WC_B, "word_emb": self.N_WORD_EMB, "char_emb": self.N_CHAR_EMB,
-             "conv_filter": self.N_CONV_F, "conv_bias": self.N_CONV_B, "img_W": self.N_IMGT_W, "img_b": self.N_IMGT_B}
+        m = self._oracle_key_map()
         if "existing_emb_mat" in p:
             self.set_existing_emb(p["existing_emb_mat"])
         if "window_t" in p:
@@ -440,14 +445,7 @@ class Model:
         self.set_weights({m[k]: v for k, v in p.items() if k in m})
 
     def _oracle_names(self):
-        return {self.N_TEXT_K % "fw": "text_kernel", self.N_TEXT_B % "fw": "text_bias",
-                self.N_TEXT_K % "bw": "text_kernel_bw", self.N_TEXT_B % "bw": "text_bias_bw",
-                self.N_IMG_K % "fw": "image_kernel", self.N_IMG_B % "fw": "image_bias",
-                self.N_IMG_K % "bw": "image_kernel_bw", self.N_IMG_B % "bw": "image_bias_bw",
-                self.N_ATT_W: "att_W", self.N_ATT_B: "att_b", self.N_QATT_W: "qatt_W", self.N_QATT_B: "qatt_b",
-                self.N_OUT_W: "out_W", self.N_OUT_B: "out_b", self.N_TW_WH_W: "WH_W", self.N_TW_WH_B: "WH_b",
-                self.N_TW_WC_W: "WC_W", self.N_TW_WC_B: "WC_b", self.N_WORD_EMB: "word_emb", self.N_CHAR_EMB: "char_emb",
-                self.N_CONV_F: "conv_filter", self.N_CONV_B: "conv_bias", self.N_IMGT_W: "img_W", self.N_IMGT_B: "img_b"}
+        return {v: k for k, v in self._oracle_key_map().items()}
 
     def get_oracle_grads(self):
         m = self._oracle_names()
@@ -492,31 +490,9 @@ class Model:
         JMAX = max(per_album)                                   # model_v2.py:869
         T = M * JMAX
         L.N, L.K, L.M, L.JMAX, L.T, L.JQ, L.C, L.JA = N, K, M, JMAX, T, JQ, C, JA
-        # ---- output arena rows: [hall N*K*T | hq N*JQ | hchoices N*C*JA]
-        L.row_hall, L.row_hq = 0, N * K * T
-        L.row_hch = L.row_hq + N * JQ
-        L.rows = L.row_hch + N * C * JA
-        L.arena = torch.zeros(L.rows, wp, dtype=torch.float32, device=dev)
-        L.d_arena = torch.zeros(L.rows, wp, dtype=torch.float32, device=dev) if training else None
-        L.hall = L.arena[:L.row_hq].view(N, K, T, wp)
-        L.hq = L.arena[L.row_hq:L.row_hch].view(N, JQ, wp)
-        L.hch = L.arena[L.row_hch:].view(N, C, JA, wp)
-        L.hall_mask = torch.zeros(N, K, M, JMAX, dtype=torch.uint8, device=dev)
+        seq_rows = self._plan_arena(L, ctx, training)
         # ---- sequence groups (text cell / image cell)
         groups = {"text": [], "image": []}
-
-        def seq_rows(k, dims):
-            """first arena row of every sequence of context stream k"""
-            n = torch.arange(N).view(N, 1, 1)
-            m = torch.arange(M).view(1, M, 1)
-            if len(dims) == 3:
-                ji = torch.zeros(1, 1, 1, dtype=torch.int64)
-                step = 0
-            else:
-                ji = torch.arange(dims[2]).view(1, 1, -1)
-                step = dims[3]
-            return (((n * K + k) * M + m) * JMAX + ji * step).reshape(-1)
-
         groups["text"].append(dict(name="q", count=N, J=JQ, rows=L.row_hq + torch.arange(N) * JQ))
         groups["text"].append(dict(name="choices", count=N * C, J=JA, rows=L.row_hch + torch.arange(N * C) * JA))
         L.ctx_slots = []
@@ -571,6 +547,43 @@ class Model:
                               prof_tag=0 if cell == "text" else 1)
             L.groups[cell] = G
         L.q_mask = torch.zeros(N, JQ, dtype=torch.uint8, device=dev)
+        self._build_attention(L, training)
+        L.y = torch.zeros(N, C, dtype=torch.uint8, device=dev)
+        self._layouts[key] = L
+        return L
+
+    def _plan_arena(self, L, ctx, training):
+        """Rows of the encoder output arena: [hall N*K*T | hq N*JQ | hchoices N*C*JA], the context tensor of
+        model_v2.py:863-914 (every stream padded to JMAX rows per album, stacked on K).  Returns seq_rows(k, dims): the
+        first arena row of every sequence of context stream k."""
+        dev, wp = self.dev, self.wp
+        N, K, M, JMAX, T, JQ, C, JA = L.N, L.K, L.M, L.JMAX, L.T, L.JQ, L.C, L.JA
+        L.row_hall, L.row_hq = 0, N * K * T
+        L.row_hch = L.row_hq + N * JQ
+        L.rows = L.row_hch + N * C * JA
+        L.arena = torch.zeros(L.rows, wp, dtype=torch.float32, device=dev)
+        L.d_arena = torch.zeros(L.rows, wp, dtype=torch.float32, device=dev) if training else None
+        L.hall = L.arena[:L.row_hq].view(N, K, T, wp)
+        L.hq = L.arena[L.row_hq:L.row_hch].view(N, JQ, wp)
+        L.hch = L.arena[L.row_hch:].view(N, C, JA, wp)
+        L.hall_mask = torch.zeros(N, K, M, JMAX, dtype=torch.uint8, device=dev)
+
+        def seq_rows(k, dims):
+            n = torch.arange(N).view(N, 1, 1)
+            m = torch.arange(M).view(1, M, 1)
+            if len(dims) == 3:
+                ji = torch.zeros(1, 1, 1, dtype=torch.int64)
+                step = 0
+            else:
+                ji = torch.arange(dims[2]).view(1, 1, -1)
+                step = dims[3]
+            return (((n * K + k) * M + m) * JMAX + ji * step).reshape(-1)
+        return seq_rows
+
+    def _build_attention(self, L, training):
+        """kernel handles and buffers of the block between the encoders and the scorer"""
+        dev, wp = self.dev, self.wp
+        N, K, T, JQ, C = L.N, L.K, L.T, L.JQ, L.C
         L.ones_mask = torch.ones(N, 1, dtype=torch.uint8, device=dev)
         L.att = ops.FocalAttention(N, K, T, JQ, wp, self.simi, self.add_tanh)
         L.qatt = ops.FocalAttention(N, 1, JQ, 1, wp, self.simi, self.add_tanh) if self.use_question_att else None
@@ -582,9 +595,13 @@ class Model:
             L.d_warp = torch.zeros(N, K, T, wp, dtype=torch.float32, device=dev) if training else None
             L.d_lq = torch.zeros(N, wp, dtype=torch.float32, device=dev) if training else None
             L.d_tscale = torch.zeros(N, T, dtype=torch.float32, device=dev) if (training and self.use_time_warp_att) else None
-        L.y = torch.zeros(N, C, dtype=torch.uint8, device=dev)
-        self._layouts[key] = L
-        return L
+
+    def _host_ctx_mask(self, L):
+        return np.zeros((L.N, L.K, L.M, L.JMAX), np.uint8)
+
+    def _put_ctx_mask(self, L, buf, k, m):
+        """stream k's mask m [N,M,rows per album] into the context mask (`buf`: L.hall_mask or its host staging array)"""
+        buf[:, k, :, :m.shape[2]] = m
 
     def seg_x(self, L, cell, si):
         """arena view of a segment's encoder input, shaped [count, J, in]"""
@@ -663,7 +680,7 @@ class Model:
             npy = lambda v: v.numpy() if torch.is_tensor(v) else np.asarray(v)
             parts = {c: dict(ids=[None] * len(G.segs), chars=[None] * len(G.segs), lens=[None] * len(G.segs))
                      for c, G in L.groups.items()}
-            hall_mask = np.zeros((L.N, L.K, L.M, L.JMAX), np.uint8)
+            hall_mask = self._host_ctx_mask(L)
 
             def stage(cell, si, st):
                 mask = npy(st["mask"])
@@ -681,8 +698,7 @@ class Model:
             stage("text", 1, inputs["choices"])
             for k, st in enumerate(inputs["ctx"]):
                 cell, si, dims = L.ctx_slots[k]
-                m = stage(cell, si, st).reshape(L.N, L.M, -1)
-                hall_mask[:, k, :, :m.shape[2]] = m
+                self._put_ctx_mask(L, hall_mask, k, stage(cell, si, st).reshape(L.N, L.M, -1))
             up = lambda dst, arr: dst.copy_(torch.from_numpy(np.ascontiguousarray(arr)))
             for cell, G in L.groups.items():
                 pp = parts[cell]
@@ -720,8 +736,7 @@ class Model:
             for k, st in enumerate(inputs["ctx"]):
                 cell, si, dims = L.ctx_slots[k]
                 put(cell, si, st)
-                m = st["mask"].to(dev, torch.uint8).reshape(L.N, L.M, -1)
-                L.hall_mask[:, k, :, :m.shape[2]] = m
+                self._put_ctx_mask(L, L.hall_mask, k, st["mask"].to(dev, torch.uint8).reshape(L.N, L.M, -1))
         if inputs.get("y") is not None:
             y = inputs["y"]
             L.y.copy_((y if torch.is_tensor(y) else torch.from_numpy(np.ascontiguousarray(y))).to(torch.uint8))
@@ -766,7 +781,7 @@ class Model:
         main.wait_stream(self._side)
         att, qatt = self._attend(L, want_logits)
         L.logits, L.yp, L.loss_t = ops.scorer_ce_fwd(L.gq, L.g1, L.lch, P.view(self.N_OUT_W), P.view(self.N_OUT_B),
-                                                     L.y if L.has_y else None, self.use_eu_output, self.add_tanh)
+                                                     L.y if L.has_y else None, self.use_eu_output, self.scorer_tanh)
         if self.wd and L.has_y:                                              # :1094-1095: loss = add_n("losses")
             self._apply_wd(False, L.loss_t)
         self.logits, self.yp, self.loss = L.logits, L.yp, L.loss_t
@@ -809,7 +824,7 @@ class Model:
         P = self.params
         dgq, dg1, dgch = ops.scorer_ce_bwd(L.gq, L.g1, L.lch, P.view(self.N_OUT_W), P.view(self.N_OUT_B), L.y, L.logits,
                                            L.yp, loss_scale, P.view(self.N_OUT_W, True), P.view(self.N_OUT_B, True),
-                                           self.use_eu_output, self.add_tanh, self.tf_xent_grad)
+                                           self.use_eu_output, self.scorer_tanh, self.tf_xent_grad)
         self._attend_bwd(L, dgq, dg1, dgch)
         main = torch.cuda.current_stream()
         token = getattr(L, "token", False)

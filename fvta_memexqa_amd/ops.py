@@ -164,10 +164,12 @@ def bilstm_simple(x, lens, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None, tra
 class FocalAttention:
     """attention_3d (model_v2.py:210-298) / attention (125-201, K=1) handle."""
 
-    def __init__(self, N, K, T, JQ, w, simi, add_tanh, feat_order=0):
+    def __init__(self, N, K, T, JQ, w, simi, add_tanh, feat_order=0, hinfo_stride=0):
+        """hinfo_stride (K == 1): floats between consecutive batch rows of hinfo / d_hinfo, for a stream that lives
+        inside a wider arena; the tensors handed to forward / backward then start at the stream's first row."""
         self.lib = _lib.load()
         self.dev = require_gpu()
-        self.desc = AttnDesc(N, K, T, JQ, w, simi, feat_order, int(add_tanh))
+        self.desc = AttnDesc(N, K, T, JQ, w, simi, feat_order, int(add_tanh), int(hinfo_stride))
         r = ctypes.byref(self.desc)
         sb = self.lib.fvta_attn_saved_bytes(r)
         if sb == 0:
@@ -191,6 +193,18 @@ class FocalAttention:
                                         ptr(b), ptr(tscale), ptr(_f32c(d_h_a)), ptr(self.saved), ptr(d_hinfo), ptr(d_hq),
                                         ptr(dW), ptr(db), ptr(d_tscale), int(accumulate), ptr(self.work), stream_ptr()),
               "fvta_attn_bwd")
+
+
+def rows_reduce(x, out, rows, J, d, out_ld=None, scale=1.0, accumulate=False):
+    """out[r, :] (+)= scale * sum_j x[r, j, :]; `out` rows out_ld floats apart (fvta_rows_reduce)"""
+    check(_lib.load().fvta_rows_reduce(ptr(x), ptr(out), rows, J, d, d if out_ld is None else out_ld, float(scale),
+                                       int(accumulate), stream_ptr()), "fvta_rows_reduce")
+
+
+def rows_broadcast(v, out, rows, J, d, v_ld=None, scale=1.0, accumulate=False):
+    """out[r, j, :] (+)= scale * v[r, :]; `v` rows v_ld floats apart (fvta_rows_broadcast)"""
+    check(_lib.load().fvta_rows_broadcast(ptr(v), ptr(out), rows, J, d, d if v_ld is None else v_ld, float(scale),
+                                          int(accumulate), stream_ptr()), "fvta_rows_broadcast")
 
 
 def as_mask_u8(m):

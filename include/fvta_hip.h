@@ -61,6 +61,10 @@ typedef struct fvta_attn_desc {
   int32_t simi;       /* 1..4 */
   int32_t feat_order; /* 0: model_v2.py order, 1: model.py:149 order (simi 2 only) */
   int32_t add_tanh;   /* model_v2.py:92-93 via linear(add_tanh=) */
+  /* Elements between consecutive batch rows n of hinfo / d_hinfo; 0 = dense (K*T*w).  Non-zero needs K == 1 and no
+   * tscale: the 1-D attention of model.py:117-186 run on ONE stream of a context arena laid out [N][all streams' rows]
+   * (model.py:836-846, per-stream attention; :929-944 runs over the concatenation of the same rows). */
+  int64_t hinfo_stride;
 } fvta_attn_desc;
 
 size_t fvta_attn_workspace_bytes(const fvta_attn_desc* d);
@@ -337,6 +341,18 @@ int fvta_wsum_fwd(const float* target, const float* weights, float* out, int64_t
  * fvta_attgru_fwd per fact (functional.generate_episode). */
 int fvta_dmn_features(const float* facts, const float* q, const float* m, float* out, int32_t N, int32_t F, int32_t d,
                       fvta_stream_t stream);
+/* The two shape ops the model.py graph (soft-attention baselines) puts between its attentions, forward and backward of
+ * each other:
+ *   fvta_rows_reduce    : out[r,:] (+)= scale * sum_j x[r,j,:]   x [rows,J,d], out rows `out_ld` floats apart.
+ *                         tf.reduce_mean (model.py:874-885 means of the last states, :907 mean over the K streams) with
+ *                         scale 1/J; with scale 1 the backward of the tile below.
+ *   fvta_rows_broadcast : out[r,j,:] (+)= scale * v[r,:]         v rows `v_ld` floats apart, out [rows,J,d].
+ *                         tf.tile (model.py:262 hq per choice) with scale 1; with scale 1/J the backward of reduce_mean.
+ * accumulate != 0 adds into the destination. */
+int fvta_rows_reduce(const float* x, float* out, int64_t rows, int32_t J, int32_t d, int64_t out_ld, float scale,
+                     int32_t accumulate, fvta_stream_t stream);
+int fvta_rows_broadcast(const float* v, float* out, int64_t rows, int32_t J, int32_t d, int64_t v_ld, float scale,
+                        int32_t accumulate, fvta_stream_t stream);
 /* attention_keeprank1 (model.py:247-314) = the per-(n,k) inner softsel of attention_3d without the softmax over k:
  * after fvta_attn_fwd(desc with K = M) this copies that result, u[N,K,w], out of the saved state. */
 int fvta_attn_read_u(const fvta_attn_desc* d, const void* saved, float* u_out, fvta_stream_t stream);

@@ -375,3 +375,97 @@ def weight_decay_terms(params, cfg):
         if params.get(k) is not None and (k != "qatt_W" and k != "qatt_b" or cfg.get("use_question_att", False)):
             total = total + mult * wd * 0.5 * (params[k] ** 2).sum()      # tf.nn.l2_loss = sum(t^2) / 2
     return total
+
+
+# ---------------------------------------------------- model.py (soft-attention baselines) ---
+def attention_keeprank1(hinfo, hq, W, b, hinfo_mask=None, hq_mask=None, simiMatrix=1):
+    """model.py:248-318 (bidirect=False): one softsel per (n, m), max over the question inside -> [N,M,w]."""
+    N, M, w = hinfo.shape[0], hinfo.shape[1], hinfo.shape[-1]
+    h = hinfo.reshape(N, M, -1, w)
+    a = simi_logits(h, hq[:, None], W, b, simiMatrix, False, "v1")       # [N,M,V,JQ]
+    if hinfo_mask is not None and hq_mask is not None:
+        a = exp_mask(a, hinfo_mask.reshape(N, M, -1)[..., None] & hq_mask[:, None, None, :])
+    return softsel(h, a.amax(dim=3))
+
+
+def v1_stream_is_masked(st):
+    """model.py:838-850: the album-level text streams (at, ad, when, where: x [N,M,J,in]) are attended under
+    (stream mask & q_mask) with config.simiMatrix; photo titles and photos (pts :849, pis :850) are called WITHOUT
+    hq_mask and without simiMatrix -- no mask is applied (:137 needs both) and the similarity is the default 1."""
+    return st.get("cell", "text") == "text" and st["x"].dim() == 4
+
+
+def model_v1_forward(params, inputs, cfg):
+    """model.py:658-1037 from the encoder inputs to the loss: the soft-attention baselines (use_ml_att / use_mm_att /
+    use_direct_links / use_choices_att / use_question_att; bidirection, concat and the tgif attention are not restated).
+    Same `inputs` as fvta_forward; params as there plus ml{k}_W/b (per context stream), mm_W/b, full_W/b, catt_W/b."""
+    def cell(name):
+        return (params[name + "_kernel"], params[name + "_bias"],
+                params.get(name + "_kernel_bw"), params.get(name + "_bias_bw"))
+
+    simi = cfg["simiMatrix"]
+    qmask = inputs["q"]["mask"]
+    hq, lq = encode_stream(inputs["q"]["x"], qmask, *cell("text"))                       # :660-663
+    hch, lch = encode_stream(inputs["choices"]["x"], inputs["choices"]["mask"], *cell("text"))   # :767-778
+    N, w = hq.shape[0], hq.shape[-1]
+    hs, g1s = [], []
+    for k, st in enumerate(inputs["ctx"]):
+        h, last = encode_stream(st["x"], st["mask"], *cell(st.get("cell", "text")))      # :691-799
+        hs.append(h.reshape(N, -1, w))
+        if cfg.get("use_ml_att", False):                                                 # :834-850
+            if v1_stream_is_masked(st):
+                g, _ = attention(h, hq, params.get("ml%d_W" % k), params.get("ml%d_b" % k), st["mask"], qmask,
+                                 simiMatrix=simi, feat_order="v1")
+            else:
+                g, _ = attention(h, hq, params.get("ml%d_W" % k), params.get("ml%d_b" % k), simiMatrix=1)
+        else:                                                                            # :868-885: means of the last states
+            g = (last.mean(2) if last.dim() == 4 else last).mean(1)
+        g1s.append(g)
+    g1 = torch.stack(g1s, 1)                                                             # :892  [N,K,w]
+    out = {"hq": hq, "lq": lq, "g1": g1}
+    if cfg.get("use_mm_att", False):                                                     # :901-904 (hinfo_mask None: unmasked)
+        g1_a, out["mm_att_logits"] = attention(g1, hq, params.get("mm_W"), params.get("mm_b"), simiMatrix=simi,
+                                               feat_order="v1")
+    else:
+        g1_a = g1.mean(1)                                                                # :909
+    if cfg.get("use_direct_links", False):                                               # :916-952
+        full = torch.cat(hs, 1)
+        full_a, out["att_logits"] = attention(full, hq, params.get("full_W"), params.get("full_b"), simiMatrix=simi,
+                                              feat_order="v1")
+        g1_all = full_a if cfg.get("direct_links_only", False) else full_a + g1_a
+    else:
+        g1_all = g1_a
+    if cfg.get("use_choices_att", False):                                                # :966-968
+        gch = attention_keeprank1(hch, hq, params.get("catt_W"), params.get("catt_b"), inputs["choices"]["mask"], qmask,
+                                  simiMatrix=simi)
+    else:
+        gch = lch                                                                        # :971
+    if cfg.get("use_question_att", False):                                               # :977-978 (hq_mask None: unmasked)
+        gq, out["q_att_logits"] = attention(hq, g1, params.get("qatt_W"), params.get("qatt_b"), simiMatrix=simi,
+                                            feat_order="v1")
+    else:
+        gq = lq                                                                          # :982
+    out["g1_all"], out["gq"], out["gchoices"] = g1_all, gq, gch
+    logits, yp = scorer(gq, g1_all, gch, params["out_W"], params["out_b"], cfg.get("use_eu_output", False), False)  # :996-1013
+    out["logits"], out["yp"] = logits, yp
+    if inputs.get("y") is not None:                                                      # :1023-1033
+        out["loss"] = softmax_cross_entropy_mean(logits, inputs["y"], bool(cfg.get("tf_xent_grad", True))) \
+            + v1_weight_decay_terms(params, cfg)
+    return out
+
+
+def v1_weight_decay_terms(params, cfg):
+    """model.py's add_wd call sites (:320-327, one l2 term per trainable of the calling scope): reader (:802), every
+    attention()/attention_keeprank1() call's own scope (:184, :315), image_trans_linear (:95 via :611), conv1d x 7."""
+    wd = cfg.get("wd", None)
+    if not wd:
+        return 0.0
+    cover = {k: v for k, v in WD_COVER.items() if k not in ("att_W", "att_b")}
+    for k in params:
+        if k.startswith(("ml", "mm_", "full_", "catt_")):
+            cover[k] = 1
+    total = 0.0
+    for k, mult in cover.items():
+        if params.get(k) is not None:
+            total = total + mult * wd * 0.5 * (params[k] ** 2).sum()
+    return total

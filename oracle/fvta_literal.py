@@ -543,3 +543,65 @@ def fvta_forward(params, inputs, cfg):
                 if params.get(k) is not None and (k not in ("qatt_W", "qatt_b") or cfg.get("use_question_att", False)):
                     out["loss"] = out["loss"] + mult * cfg["wd"] * 0.5 * np.sum(np.asarray(params[k], np.float64) ** 2)
     return out
+
+
+# ----------------------------------------------------------------------------
+# model.py:658-1037 -- the soft-attention baselines, literal
+# ----------------------------------------------------------------------------
+def model_v1_forward(params, inputs, cfg):
+    """Same contract as oracle.fvta_fused.model_v1_forward (float64 NumPy, tile/concat/linear as written)."""
+    def cell(name):
+        return (params[name + "_kernel"], params[name + "_bias"],
+                params.get(name + "_kernel_bw"), params.get(name + "_bias_bw"))
+
+    simi = cfg["simiMatrix"]
+    qmask = np.asarray(inputs["q"]["mask"], bool)
+    cmask = np.asarray(inputs["choices"]["mask"], bool)
+    hq, lq = encode_stream(inputs["q"]["x"], qmask, *cell("text"))                       # :660-663
+    hchoices, lchoices = encode_stream(inputs["choices"]["x"], cmask, *cell("text"))     # :767-778
+    N, w = hq.shape[0], hq.shape[-1]
+    hs, g1s = [], []
+    for k, st in enumerate(inputs["ctx"]):
+        h, last = encode_stream(st["x"], st["mask"], *cell(st.get("cell", "text")))
+        m = np.asarray(st["mask"], bool)
+        hs.append(h.reshape(N, -1, w))                                                   # :923-928
+        if cfg.get("use_ml_att", False):
+            W, b = params.get("ml%d_W" % k), params.get("ml%d_b" % k)
+            if st.get("cell", "text") == "text" and np.asarray(st["x"]).ndim == 4:       # at/ad/when/where :838-842
+                g, _ = attention(h, hq, W, b, m, qmask, simiMatrix=simi, feat_order="v1")
+            else:                                                                        # pts / pis :849-850
+                g, _ = attention(h, hq, W, b, m, None, simiMatrix=1, feat_order="v1")
+        else:
+            g0 = last.mean(axis=2) if last.ndim == 4 else last                           # :875-880
+            g = g0.mean(axis=1)                                                          # :882-887
+        g1s.append(g)
+    g1 = np.stack(g1s, 1)                                                                # :892
+    out = {"hq": hq, "lq": lq, "g1": g1}
+    if cfg.get("use_mm_att", False):
+        g1_a, out["mm_att_logits"] = attention(g1, hq, params.get("mm_W"), params.get("mm_b"), None, qmask,
+                                               simiMatrix=simi, feat_order="v1")         # :904
+    else:
+        g1_a = g1.mean(axis=1)                                                           # :909
+    if cfg.get("use_direct_links", False):
+        full = np.concatenate(hs, 1)                                                     # :929-936
+        full_a, out["att_logits"] = attention(full, hq, params.get("full_W"), params.get("full_b"), None, None,
+                                              simiMatrix=simi, feat_order="v1")          # :947
+        g1_all = full_a if cfg.get("direct_links_only", False) else full_a + g1_a        # :950-953
+    else:
+        g1_all = g1_a
+    if cfg.get("use_choices_att", False):
+        gchoices = attention_keeprank1(hchoices, hq, params.get("catt_W"), params.get("catt_b"), cmask, qmask,
+                                       simiMatrix=simi)                                  # :967
+    else:
+        gchoices = lchoices
+    if cfg.get("use_question_att", False):
+        gq, out["q_att_logits"] = attention(hq, g1, params.get("qatt_W"), params.get("qatt_b"), qmask, None,
+                                            simiMatrix=simi, feat_order="v1")            # :978
+    else:
+        gq = lq
+    out["g1_all"], out["gq"], out["gchoices"] = g1_all, gq, gchoices
+    logits, yp = scorer(gq, g1_all, gchoices, params["out_W"], params["out_b"], cfg.get("use_eu_output", False), False)
+    out["logits"], out["yp"] = logits, yp
+    if inputs.get("y") is not None:
+        out["loss"] = softmax_cross_entropy_mean(logits, inputs["y"])
+    return out
