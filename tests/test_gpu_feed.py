@@ -144,3 +144,47 @@ def test_step_vis_returns_the_reference_tuple():
     # the context tensor rows past each stream's own length are zero (model_v2.py:871-888 pads with zeros)
     JXA = feed["at"].shape[2]
     assert np.abs(h[:, 0, :, JXA:, :]).max() == 0
+
+
+ALL_V1 = dict(use_ml_att=True, use_mm_att=True, use_direct_links=True, use_choices_att=True, use_question_att=True)
+
+
+def _oracle_v1(model, feed, cfg, flags):
+    from oracle import fvta_fused as F
+    tok = model.inputs_from_feed(feed)
+    p = {k: v.double() for k, v in model.get_oracle_params().items()}
+    tok["image_emb_mat"] = torch.from_numpy(np.asarray(tok["image_emb_mat"])).double()
+    ocfg = dict(hidden_size=cfg.hidden_size, simiMatrix=cfg.simiMatrix, add_tanh=cfg.add_tanh, num_choice=4, **flags)
+    return F.model_v1_forward(p, F.embed_inputs(p, tok, ocfg), dict(ocfg, add_tanh=False))
+
+
+@pytest.mark.parametrize("flags", [{}, ALL_V1], ids=["lstm_baseline", "all_attentions"])
+def test_model_py_graph_on_dataset_batches(flags):
+    """main.py:161-165 without --use_3d imports model.py: the soft-attention baselines on the reference's own feed
+    (six streams of different lengths at / ad / when / where / pts / pis, short last batch), Tester.step and
+    Trainer.step against the oracle on the same feed arrays.  (add_tanh stays on: in model.py it reaches only the
+    image_trans_linear layer, :611.)"""
+    from fvta_memexqa_amd.model import get_model
+    from fvta_memexqa_amd.tester import Tester
+    from fvta_memexqa_amd.trainer import Trainer
+    config, ds, case = _setup("feed_test_nocaps", False)
+    config.__dict__.update(dict(dict(use_question_att=False), **flags))
+    model = get_model(config)
+    tester = Tester(model, config)
+    for batch in ds.get_batches(case["batch_size"], case["steps"], shuffle=False):
+        yp = tester.step(None, batch)
+        ref = _oracle_v1(model, model.get_feed_dict(batch[1], is_train=False), config, flags)["yp"].numpy()[:batch[1].num_examples]
+        np.testing.assert_allclose(yp, ref, rtol=1e-4, atol=1e-6)
+        assert (yp.argmax(1) == ref.argmax(1)).all()
+    config, ds, case = _setup("feed_train_shuffle", True)
+    config.__dict__.update(dict(dict(use_question_att=False), **flags))
+    model = get_model(config)
+    trainer = Trainer(model, config)
+    import random
+    random.seed(5)
+    for b, batch in enumerate(ds.get_batches(case["batch_size"], 3, shuffle=True)):
+        np.random.seed(100 + b)
+        ref = _oracle_v1(model, model.get_feed_dict(batch[1], is_train=True), config, flags)
+        np.random.seed(100 + b)
+        loss, _, _ = trainer.step(None, batch)
+        np.testing.assert_allclose(loss, float(ref["loss"]), rtol=1e-4)
