@@ -70,9 +70,14 @@ struct TileCfgT {
 typedef TileCfgT<1> TileCfg;
 
 // ---- accumulators + fragment reads -------------------------------------------------------------
-template <int WN, int TM_ = 2, int WM_ = 8 / TM_>
+// SWAP: the two fragment operands trade places in the MFMA (the row-image fragments of A and B have the same lane layout:
+// row l & 31, k-octet l >> 5), so the accumulators hold the TRANSPOSED tile: register r of lane l is B-row (column of the
+// product) (r & 3) + 8 (r >> 2) + 4 (l >> 5) and A-row l & 31 -- four CONSECUTIVE columns of ONE row per register quad, i.e.
+// 16 contiguous bytes of a row-major fp32 output per lane without a trip through LDS (lstm_gate_epilogue_direct).
+template <int WN, int TM_ = 2, int WM_ = 8 / TM_, bool SWAP_ = false>
 struct MmaBT {
   typedef TileCfgT<WN, TM_, WM_> Cfg;
+  static constexpr bool SWAP = SWAP_;
   static constexpr int TM = TM_, TN = 4, WAVES_M = Cfg::WAVES_M, WAVES_N = 1, BM = Cfg::BM, BN = Cfg::BN;  // WAVES_N: per wave column
   static constexpr int WROWS = 32 * TM;  // rows of a wave tile
   f32x16 acc[TM][TN];
@@ -87,6 +92,9 @@ struct MmaBT {
       asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
     else
 #endif
+    if constexpr (SWAP)
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0);
+    else
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
   // the asm MFMAs are opaque to the hazard recogniser: before the accumulators are read by VALU code the last

@@ -25,6 +25,7 @@
 #endif
 #ifndef FVTA_LSTM_SEQ_DEFAULT
 #define FVTA_LSTM_SEQ_DEFAULT 0
+#define FVTA_LSTM_FWD_DIRECT_DEFAULT 0
 #endif
 #ifndef FVTA_GLDS_SP_DEFAULT
 #define FVTA_GLDS_SP_DEFAULT 1
@@ -120,7 +121,8 @@ __device__ unsigned long long g_lstm_stamps[512];  // diagnostics (FVTA_DEBUG_SK
 // One block tile of rows [m0, m0 + Cfg::BM) x the 32 WN units from ub.
 // LEAN: no diagnostic switches, software-pipelined main loop only (the sequence-stationary kernel: its two loops around
 // the tile leave no registers for code paths that never run)
-template <int WN, int TM, int WM, bool LATE_CPREV = (TM == 4), bool LEAN = false>
+// DIRECT: transposed accumulators (MmaBT SWAP) and the LDS-free epilogue (lstm_gate_epilogue_direct)
+template <int WN, int TM, int WM, bool LATE_CPREV = (TM == 4), bool LEAN = false, bool DIRECT = false>
 __device__ __forceinline__ void lstm_step_fwd_tile(const StepArgs& a, bf16_t* smem_h, int64_t* s_oo, int m0, int ub,
                                                    int dir, int nact, int t) {
   typedef TileCfgT<WN, TM, WM> Cfg;
@@ -130,9 +132,10 @@ __device__ __forceinline__ void lstm_step_fwd_tile(const StepArgs& a, bf16_t* sm
   __syncthreads();  // a workgroup that runs several tiles: the previous tile's epilogue is done with s_oo and the stage buffers
   for (int r = tid; r < Cfg::BM; r += Cfg::NT) s_oo[r] = (m0 + r < nact) ? a.plan.oo[trow + m0 + r] : -1;
 
-  MmaBT<WN, TM, WM> mma;
+  MmaBT<WN, TM, WM, DIRECT> mma;
   mma.init(tid);
   const int u0 = ub + 32 * mma.wn;
+  if constexpr (DIRECT) lstm_direct_bias_init(mma, a.bias[dir], d, u0);
   // A rows m0.. of xs[dir][t] (nact rows) and of hs[dir][t-1]; B rows = the 4 gate strips of wt per wave column
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xs + trow * in_i, (unsigned)nact * in_i * 2);
   const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (t > 0 ? trow - a.B : trow) * d, (unsigned)nact * d * 2);
@@ -170,8 +173,10 @@ __device__ __forceinline__ void lstm_step_fwd_tile(const StepArgs& a, bf16_t* sm
       for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-          const int i = min(m0 + mma.wave * (32 * TM) + ti * 32 + it * 8 + (mma.lane >> 3), nact - 1);  // clamped: valid row
-          const f32x4* cp = reinterpret_cast<const f32x4*>(src + (size_t)i * d + u0 + 4 * (mma.lane & 7));
+          // staged: rows it*8 + lane/8, units 4 (lane%8)..; direct: row lane%32, units 8 it + 4 (lane/32)..
+          const int lr = DIRECT ? mma.l31 : it * 8 + (mma.lane >> 3), lu = DIRECT ? 8 * it + 4 * mma.hf : 4 * (mma.lane & 7);
+          const int i = min(m0 + mma.wave * (32 * TM) + ti * 32 + lr, nact - 1);  // clamped: valid row
+          const f32x4* cp = reinterpret_cast<const f32x4*>(src + (size_t)i * d + u0 + lu);
           cprev[ti][it] = a.nt ? __builtin_nontemporal_load(cp) : *cp;
         }
     }
@@ -184,9 +189,13 @@ __device__ __forceinline__ void lstm_step_fwd_tile(const StepArgs& a, bf16_t* sm
   if (st) st[1] = __builtin_readcyclecounter();
   if (LATE_CPREV) load_cprev();
   __syncthreads();  // s_oo visible; every wave is done with the stage buffers, which become the epilogue's scratch
-  if (!(dbg & 2))
-    lstm_gate_epilogue_staged(mma, a, dir, m0, u0, nact, trow, s_oo, cprev,
-                              reinterpret_cast<char*>(smem_h) + mma.wave_all * 9216, t);
+  if (!(dbg & 2)) {
+    if constexpr (DIRECT)
+      lstm_gate_epilogue_direct(mma, a, dir, m0, u0, nact, trow, s_oo, cprev, t);
+    else
+      lstm_gate_epilogue_staged(mma, a, dir, m0, u0, nact, trow, s_oo, cprev,
+                                reinterpret_cast<char*>(smem_h) + mma.wave_all * 9216, t);
+  }
   if (st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     st[2] = __builtin_readcyclecounter();
@@ -199,7 +208,7 @@ __device__ __forceinline__ void lstm_step_fwd_tile(const StepArgs& a, bf16_t* sm
 // into whole rounds of the chip's workgroup slots (metric shape: 1632 tiles on 512 slots = 3.19 rounds, and the partial
 // round costs a full tile time), so the launcher gives whole rounds to full tiles and covers the remaining rows with
 // units of half the duration.
-template <int WN, int TM>
+template <int WN, int TM, int DIRECT = 0>  // DIRECT 1: LDS-free epilogue; 2: the same with c_{t-1} loaded after the k-loop
 __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lstm_step_fwd_bf16(StepArgs a, int nbig) {
   typedef TileCfgT<WN, TM> Cfg;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
@@ -211,13 +220,13 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
     if ((int)blockIdx.x >= nbig) {
       const int m0 = nbig * 256 + ((int)blockIdx.x - nbig) * 128;
       if (m0 >= nact) return;
-      lstm_step_fwd_tile<1, 1, 4>(a, smem_h, s_oo, m0, ub, dir, nact, a.t);
+      lstm_step_fwd_tile<1, 1, 4, DIRECT == 2, false, DIRECT != 0>(a, smem_h, s_oo, m0, ub, dir, nact, a.t);
       return;
     }
   }
   const int m0 = blockIdx.x * Cfg::BM;
   if (m0 >= nact) return;
-  lstm_step_fwd_tile<WN, TM, 8 / TM>(a, smem_h, s_oo, m0, ub, dir, nact, a.t);
+  lstm_step_fwd_tile<WN, TM, 8 / TM, (TM == 4) || DIRECT == 2, false, DIRECT != 0>(a, smem_h, s_oo, m0, ub, dir, nact, a.t);
 }
 
 int lstm_read_stamp(int i, long long* v) {
@@ -330,7 +339,20 @@ void launch_step_fwd_bf16(const StepArgs& a_, hipStream_t s) {
     const int nbig = fwd_big_row_tiles(a.B, a.d);
     const int nsmall = (a.B - nbig * 256 + 127) / 128;
     const dim3 grid(pad8(nbig + (nsmall > 0 ? nsmall : 0)), a.d / 32, 2);
-    hipLaunchKernelGGL((lstm_step_fwd_bf16<1, 2>), grid, dim3(256), LDS, s, a, nbig);
+    // FVTA_LSTM_FWD_DIRECT: transposed accumulators + the LDS-free epilogue (16-byte aligned cell-state / shadow / gate
+    // rows: d % 4 == 0 always holds here, d is a multiple of 32)
+    static const int direct = [] {
+      const char* e = getenv("FVTA_LSTM_FWD_DIRECT");
+      return e ? atoi(e) : FVTA_LSTM_FWD_DIRECT_DEFAULT;
+    }();
+    if (direct == 1) {
+      allow_big_lds(lstm_step_fwd_bf16<1, 2, 1>, LDS);
+      hipLaunchKernelGGL((lstm_step_fwd_bf16<1, 2, 1>), grid, dim3(256), LDS, s, a, nbig);
+    } else if (direct == 2) {
+      allow_big_lds(lstm_step_fwd_bf16<1, 2, 2>, LDS);
+      hipLaunchKernelGGL((lstm_step_fwd_bf16<1, 2, 2>), grid, dim3(256), LDS, s, a, nbig);
+    } else
+      hipLaunchKernelGGL((lstm_step_fwd_bf16<1, 2>), grid, dim3(256), LDS, s, a, nbig);
   }
 }
 

@@ -370,6 +370,93 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
     }
   }
 }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// The gate math on a TRANSPOSED accumulator tile (MmaBT<..., SWAP = true>): lane l holds sequence (A row) l & 31 of each
+// 32-row slice and, per register quad q, the four consecutive units u0 + 8 q + 4 (l >> 5) .. + 3 of every gate.  Every
+// global access is then 16 bytes of one row straight from / into registers -- c_{t-1} in (4 per slice), c_t and h_t out
+// as fp32 quads, the bf16 shadow as 8 bytes, the unit-major gate record [u][i,j,f,o] as 32 contiguous bytes -- 48 VMEM
+// instructions per wave and tile against the staged version's 44, and NO LDS traffic, no lgkmcnt waits: the k-loop of
+// the co-resident workgroup keeps the LDS port to itself.  The biases (and the forget bias) are the accumulators'
+// initial values (lstm_direct_bias_init), so the epilogue adds nothing.
+//   cprev[ti][q]: c_{t-1} of row ti*32 + (lane & 31), units 8 q + 4 (lane >> 5) .. + 3.
+template <class Mma>
+__device__ __forceinline__ void lstm_direct_bias_init(Mma& mma, const float* __restrict__ bias, int d, int u0) {
+  static_assert(Mma::SWAP && Mma::TN == 4, "transposed accumulators, four gate strips");
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 b = *reinterpret_cast<const f32x4*>(bias + g * d + u0 + 8 * q + 4 * mma.hf);
+      if (g == 2) b += 1.0f;  // forget_bias
+#pragma unroll
+      for (int ti = 0; ti < Mma::TM; ++ti)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mma.acc[ti][g][4 * q + e] = b[e];
+    }
+}
+
+template <class Mma>
+__device__ __forceinline__ void lstm_gate_epilogue_direct(const Mma& mma, const StepArgs& a, int dir, int m0, int u0, int nact,
+                                                          size_t trow, const int64_t* s_oo,
+                                                          const f32x4 (&cprev)[Mma::TM][4], int t) {
+  static_assert(Mma::SWAP && Mma::TN == 4 && Mma::WAVES_N == 1, "transposed wave tile: 32 TM rows x the four gate strips");
+  const int d = a.d;
+  float* cdst = a.cs ? a.cs + trow * d : a.cstate + (size_t)dir * a.B * d;
+#pragma unroll
+  for (int ti = 0; ti < Mma::TM; ++ti) {
+    const int lrow = mma.wave * Mma::WROWS + ti * 32 + mma.l31, i = m0 + lrow;
+    const bool live = i < nact;
+    const int64_t oo = s_oo[lrow];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int uq = u0 + 8 * q + 4 * mma.hf;
+      f32x4 cv, hv, g01, g23;
+      bf16x4 hb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * q + e;
+        const float ig = fvta_sigmoid(mma.acc[ti][0][r]);
+        const float jg = fvta_tanh(mma.acc[ti][1][r]);
+        const float fg = fvta_sigmoid(mma.acc[ti][2][r]);
+        const float og = fvta_sigmoid(mma.acc[ti][3][r]);
+        const float c = (t > 0 ? cprev[ti][q][e] * fg : 0.f) + ig * jg;
+        const float h = fvta_tanh(c) * og;
+        cv[e] = c;
+        hv[e] = h;
+        hb[e] = (short)f2bf(h);
+        bf16x4 g4;
+        g4[0] = (short)f2bf(ig);
+        g4[1] = (short)f2bf(jg);
+        g4[2] = (short)f2bf(fg);
+        g4[3] = (short)f2bf(og);
+        const f32x2 gw = __builtin_bit_cast(f32x2, g4);
+        if (e < 2) {
+          g01[2 * e] = gw[0];
+          g01[2 * e + 1] = gw[1];
+        } else {
+          g23[2 * (e - 2)] = gw[0];
+          g23[2 * (e - 2) + 1] = gw[1];
+        }
+      }
+      if (live) st16(cdst + (size_t)i * d + uq, cv, a.nt != 0);
+      if (oo >= 0) {
+        float* o = a.out + oo + uq;
+        if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+          st16(o, hv, a.nt != 0);
+        } else {  // an output row that is not 16-byte aligned
+          o[0] = hv[0]; o[1] = hv[1]; o[2] = hv[2]; o[3] = hv[3];
+        }
+      }
+      if (live && a.hs) *reinterpret_cast<bf16x4*>(a.hs + (trow + i) * d + uq) = hb;
+      if (live && a.gatesb) {
+        float* gp = reinterpret_cast<float*>(a.gatesb + (trow + i) * (size_t)(4 * d) + 4 * uq);
+        st16(gp, g01, a.nt != 0);
+        st16(gp + 4, g23, a.nt != 0);
+      }
+    }
+  }
+}
 #endif
 
 // bf16 engine launchers (lstm_bf16.hip)
