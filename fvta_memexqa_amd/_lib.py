@@ -86,6 +86,11 @@ _SIGS = {
     "fvta_linear_fwd": (c_int, [P, P, P, P, c_int64, c_int32, c_int32, c_int32, P]),
     "fvta_wsum_fwd": (c_int, [P, P, P, c_int64, c_int32, c_int32, P]),
     "fvta_dmn_features": (c_int, [P, P, P, P, c_int32, c_int32, c_int32, P]),
+    "fvta_linear_bwd": (c_int, [P, P, P, P, P, P, P, c_int64, c_int32, c_int32, c_int32, c_int32, P]),
+    "fvta_attn_qside_fwd": (c_int, [P, P, P, c_int32, c_int32, c_int32, c_int32, P]),
+    "fvta_attn_qside_bwd": (c_int, [P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, P]),
+    "fvta_attn_logits_bwd_workspace_bytes": (c_size_t, [POINTER(AttnDesc)]),
+    "fvta_attn_logits_bwd": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P]),
     "fvta_rows_reduce": (c_int, [P, P, c_int64, c_int32, c_int32, c_int64, c_float, c_int32, P]),
     "fvta_rows_broadcast": (c_int, [P, P, c_int64, c_int32, c_int32, c_int64, c_float, c_int32, P]),
     "fvta_attn_read_u": (c_int, [POINTER(AttnDesc), P, P, P]),

@@ -121,6 +121,110 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     }
 }
 
+// linear backward, input side: dx[M, in] (+)= dyt[M, out] * W[in, out]^T with dyt = dy (1 - y^2) under add_tanh.
+// Same 64 x 64 tiling as the forward (W read transposed).
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ W, const float* __restrict__ y,
+                                                            const float* __restrict__ dy, float* __restrict__ dx, int64_t M,
+                                                            int in, int out, int add_tanh, int accumulate) {
+  __shared__ float sd[64][17], sw[16][65];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int n0 = blockIdx.y * 64;  // columns of dx = inputs
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < out; k0 += 16) {
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+      const int r = i >> 4, c = i & 15;
+      float v = 0.f;
+      if (m0 + r < M && k0 + c < out) {
+        v = dy[(m0 + r) * out + k0 + c];
+        if (add_tanh) {
+          const float yy = y[(m0 + r) * out + k0 + c];
+          v *= 1.f - yy * yy;
+        }
+      }
+      sd[r][c] = v;
+    }
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+      const int c = i >> 4, r = i & 15;  // W[n0 + c][k0 + r], read along its rows
+      sw[r][c] = (k0 + r < out && n0 + c < in) ? W[(int64_t)(n0 + c) * out + k0 + r] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = sd[ty * 4 + i][k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = sw[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * bb[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t m = m0 + ty * 4 + i;
+      const int n = n0 + tx * 4 + j;
+      if (m < M && n < in) dx[m * in + n] = accumulate ? dx[m * in + n] + acc[i][j] : acc[i][j];
+    }
+}
+
+// linear backward, parameter side: dW[in, out] += x^T dyt, db[out] += sum_m dyt.  One workgroup per 64 x 64 tile of dW
+// walks all M rows in order (fixed summation order); the workgroups of the first row of tiles also fold db.
+__global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                            const float* __restrict__ dy, float* __restrict__ dW,
+                                                            float* __restrict__ db, int64_t M, int in, int out, int add_tanh) {
+  __shared__ float sx[16][65], sd[16][65];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
+  float acc[4][4] = {};
+  float bacc = 0.f;  // threads 0..63 of the blockIdx.x == 0 tiles: db[o0 + tid]
+  for (int64_t m0 = 0; m0 < M; m0 += 16) {
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      sx[r][c] = (m0 + r < M && i0 + c < in) ? x[(m0 + r) * in + i0 + c] : 0.f;
+      float v = 0.f;
+      if (m0 + r < M && o0 + c < out) {
+        v = dy[(m0 + r) * out + o0 + c];
+        if (add_tanh) {
+          const float yy = y[(m0 + r) * out + o0 + c];
+          v *= 1.f - yy * yy;
+        }
+      }
+      sd[r][c] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = sx[k][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = sd[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * bb[j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) bacc += sd[k][threadIdx.x];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = i0 + ty * 4 + i, c = o0 + tx * 4 + j;
+      if (r < in && c < out) dW[(int64_t)r * out + c] += acc[i][j];
+    }
+  if (db && blockIdx.x == 0 && threadIdx.x < 64 && o0 + (int)threadIdx.x < out) db[o0 + threadIdx.x] += bacc;
+}
+
 // weighted sum without a softmax: out[r, :] = sum_j weights[r, j] * target[r, j, :]  (attention_tgif, model.py:236-238:
 // the weights there are softmax(score) with exp_mask applied AFTERWARDS).  grid rows, 256 threads
 __global__ __launch_bounds__(256) void wsum_kernel(const float* __restrict__ target, const float* __restrict__ weights,
@@ -177,6 +281,23 @@ __global__ __launch_bounds__(256) void rows_broadcast_kernel(const float* __rest
   *o = accumulate ? *o + val : val;
 }
 }  // namespace fvta
+
+extern "C" int fvta_linear_bwd(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW,
+                               float* db, int64_t M, int32_t in, int32_t out, int32_t add_tanh, int32_t accumulate_dx,
+                               fvta_stream_t stream) {
+  FVTA_CHECK_ARG(W && dy && M > 0 && in > 0 && out > 0 && (!add_tanh || y), "linear_bwd: bad arguments");
+  FVTA_CHECK_ARG((dW == nullptr) || x, "linear_bwd: dW wants x");
+  if (dx) {
+    hipLaunchKernelGGL(fvta::linear_bwd_dx_kernel, dim3((unsigned)((M + 63) / 64), (unsigned)((in + 63) / 64)), dim3(256), 0,
+                       (hipStream_t)stream, W, y, dy, dx, M, in, out, add_tanh, accumulate_dx);
+  }
+  if (dW) {
+    hipLaunchKernelGGL(fvta::linear_bwd_dw_kernel, dim3((unsigned)((in + 63) / 64), (unsigned)((out + 63) / 64)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, dy, dW, db, M, in, out, add_tanh);
+  }
+  FVTA_CHECK_LAUNCH("linear_bwd");
+  return FVTA_OK;
+}
 
 extern "C" int fvta_rows_reduce(const float* x, float* out, int64_t rows, int32_t J, int32_t d, int64_t out_ld, float scale,
                                 int32_t accumulate, fvta_stream_t stream) {

@@ -18,8 +18,18 @@ reads its slice through fvta_attn_desc.hinfo_stride -- no concat, no copy.  atte
 batch N * num_choice with the question tiled per choice (fvta_rows_broadcast; its gradient comes back through
 fvta_rows_reduce).
 
-Not built (raise at construction): use_bidirection, concat, use_tgif_ml_att (their forward ops are in functional.py).
+use_bidirection (model.py:169-177, 297-307, 895-897, 905-906, 968-969, 979-980): every attention that takes the flag also
+returns the question attended by each of its rows, averaged over the rows; [h_a ; q_a] goes through a `bidrection_squash`
+linear.  The max-pooled half keeps the streaming backward, the reversed half is dense in (row, question position): its
+gradient runs through fvta_attn_qside_bwd + fvta_attn_logits_bwd (csrc/attn_dense.hip).  concat (:888-889, :987-991):
+the K per-stream vectors side by side instead of attended / averaged, choices and question lifted to that width by two
+linears.  Flag sets the reference's own graph construction rejects raise ValueError here (use_bidirection + use_ml_att:
+tf.stack of [N,4d] and [N,2d]; concat + use_question_att: `g1` undefined; concat + use_direct_links: [N,2d] + [N,12d]).
+
+Not built (raises at construction): use_tgif_ml_att (its forward op is functional.attention_tgif).
 """
+from types import SimpleNamespace
+
 import numpy as np
 import torch
 
@@ -46,17 +56,27 @@ class Model(model_v2.Model):
     N_MM_W, N_MM_B = "attention/multi_modal_attention/mm_att/att_logits/W", "attention/multi_modal_attention/mm_att/att_logits/b"
     N_FULL_W, N_FULL_B = "attention/direct_links/full_att/att_logits/W", "attention/direct_links/full_att/att_logits/b"
     N_CATT_W, N_CATT_B = "choices_emb/choices_att/att_logits/W", "choices_emb/choices_att/att_logits/b"
+    # bidrection_squash linears by call site (model.py:897, 906, 969, 980) and the concat linears (:990-991)
+    N_SQ = {"g1": "attention/bidrection_squash/%s", "mm": "attention/multi_modal_attention/bidrection_squash/%s",
+            "catt": "choices_emb/bidrection_squash/%s", "qatt": "question_emb/bidrection_squash/%s"}
+    N_CC = {"ch": "output/gchoice_trans_concat/%s", "q": "output/gq_trans_concat/%s"}
 
     def __init__(self, config, scope="model", text_in=None, img_in=None, device=None):
-        for flag, what in (("use_bidirection", "bidirect attention + the bidrection_squash linears (model.py:895-897)"),
-                           ("concat", "the concat variant (model.py:888-889, :987-991)"),
-                           ("use_tgif_ml_att", "attention_tgif per stream (model.py:851-866)")):
+        for flag, what in (("use_tgif_ml_att", "attention_tgif per stream (model.py:851-866)"),):
             if _cfg(config, flag, False):
                 raise NotImplementedError("model.py --%s is not built: %s" % (flag, what))
+        self.bi = bool(_cfg(config, "use_bidirection", False))
+        self.concat = bool(_cfg(config, "concat", False))
+        if self.bi and _cfg(config, "use_ml_att", False):
+            raise ValueError("use_bidirection + use_ml_att: tf.stack of [N,4d] (at .. where) with [N,2d] (pts, pis: "
+                             "model.py:849-850 pass no bidirect) cannot be built")
+        if self.concat and (_cfg(config, "use_question_att", False) or _cfg(config, "use_direct_links", False)):
+            raise ValueError("concat: `g1` is undefined for question_att (model.py:978); full_a [N,2d] cannot be added to / "
+                             "scored against the [N,12d] concat (:952, :1013)")
         if int(_cfg(config, "simiMatrix", 1)) not in (1, 2, 3):
             raise ValueError("similarity matrix not implemented")            # model.py:152-154 (sys.exit there)
         self.use_ml_att = bool(_cfg(config, "use_ml_att", False))
-        self.use_mm_att = bool(_cfg(config, "use_mm_att", False))
+        self.use_mm_att = bool(_cfg(config, "use_mm_att", False)) and not self.concat     # (:888-909: concat skips it)
         self.use_direct_links = bool(_cfg(config, "use_direct_links", False))
         self.direct_links_only = self.use_direct_links and bool(_cfg(config, "direct_links_only", False))
         self.use_choices_att = bool(_cfg(config, "use_choices_att", False))
@@ -64,7 +84,7 @@ class Model(model_v2.Model):
         # `ctx_streams` in the config overrides them (synthetic shapes with another K).
         self.streams = tuple(tuple(s) for s in (_cfg(config, "ctx_streams", None) or self.STREAMS))
         cfg = dict(config) if isinstance(config, dict) else dict(vars(config))
-        cfg.update(use_time_warp=False, use_time_warp_att=False)                # model.py has no time warp
+        cfg.update(use_time_warp=False, use_time_warp_att=False, use_bidirection=False)   # no time warp; bidirection: here
         super().__init__(cfg, scope, text_in, img_in, device)
         self.config = config
         self.scorer_tanh = False             # model.py:1011-1013: linear(...) without add_tanh
@@ -95,13 +115,35 @@ class Model(model_v2.Model):
             specs[self.N_CATT_W], specs[self.N_CATT_B] = (F,), (1,)
         if self.use_question_att:
             specs[self.N_QATT_W], specs[self.N_QATT_B] = (F,), (1,)
+        if self.bi and not self.concat:
+            specs[self.N_SQ["g1"] % "W"], specs[self.N_SQ["g1"] % "b"] = (wp, wp), (wp,)
+            for key, on in (("mm", self.use_mm_att), ("qatt", self.use_question_att)):
+                if on:
+                    specs[self.N_SQ[key] % "W"], specs[self.N_SQ[key] % "b"] = (2 * wp, wp), (wp,)
+        if self.bi and self.use_choices_att:
+            specs[self.N_SQ["catt"] % "W"], specs[self.N_SQ["catt"] % "b"] = (2 * wp, wp), (wp,)
+        if self.concat:
+            K = len(self.streams)
+            for key in ("ch", "q"):
+                specs[self.N_CC[key] % "W"], specs[self.N_CC[key] % "b"] = (wp, K * wp), (K * wp,)
         return specs
+
+    def _scorer_width(self):
+        return len(self.streams) * self.wp if self.concat else self.wp
+
+    def _is_w2d(self, name):
+        return name.endswith(("bidrection_squash/W", "_trans_concat/W"))
+
+    def _is_bfeat(self, name):
+        return name.endswith(("bidrection_squash/b", "_trans_concat/b"))
 
     def wd_multipliers(self):
         """model.py's add_wd sites (:320-327): the reader scope (:802), every attention / attention_keeprank1 call's own
         scope (:184, :315), image_trans_linear (:95 via :611), conv1d once per call -- seven (:534-540)."""
         out = {}
         for name in self.params.specs:
+            if "bidrection_squash/" in name:                # linear(...) without wd (:897, 906, 969, 980)
+                continue
             if name.startswith(("reader/", "attention/", "choices_emb/", "question_emb/",
                                 "emb/image/image_transform/image_trans_linear/")):
                 out[name] = 1
@@ -117,6 +159,10 @@ class Model(model_v2.Model):
             m["ml%d_W" % k], m["ml%d_b" % k] = self.N_ML_W % name, self.N_ML_B % name
         m.update(mm_W=self.N_MM_W, mm_b=self.N_MM_B, full_W=self.N_FULL_W, full_b=self.N_FULL_B, catt_W=self.N_CATT_W,
                  catt_b=self.N_CATT_B)
+        for key, name in self.N_SQ.items():
+            m["sq_%s_W" % key], m["sq_%s_b" % key] = name % "W", name % "b"
+        for key, name in self.N_CC.items():
+            m["cc_%s_W" % key], m["cc_%s_b" % key] = name % "W", name % "b"
         return m
 
     # ---------------------------------------------------------------- layout
@@ -183,6 +229,20 @@ class Model(model_v2.Model):
             L.hq4, L.d_hq4 = z(N * C, JQ, wp), (z(N * C, JQ, wp) if training else None)
             L.cmask = torch.zeros(N * C, JA, dtype=torch.uint8, device=dev)
             L.qmask4 = torch.zeros(N, C, JQ, dtype=torch.uint8, device=dev)
+        # use_bidirection: per call site the [h_a ; q_a] pair, its squashed output and the dense logit gradient
+        L.bi = {}
+        if self.bi:
+            for key, on, R, V, J in (("mm", self.use_mm_att, N, K, JQ), ("catt", self.use_choices_att, N * C, JA, JQ),
+                                     ("qatt", self.use_question_att, N, JQ, K)):
+                if on:
+                    L.bi[key] = SimpleNamespace(R=R, V=V, JQ=J, cat=z(R, 2 * wp), q_a=z(R, wp), out=z(R, wp), lg=None,
+                                                d_cat=z(R, 2 * wp), d_ha=z(R, wp), d_qa=z(R, wp), dA=z(R, V, J))
+            if not self.concat:
+                L.g1s_raw, L.d_g1s_raw = z(N, K, wp), z(N, K, wp)                # the stack before its squash (:897)
+        if self.concat:                                                          # :987-991
+            Kw = K * wp
+            L.gch_in, L.gq_cc, L.gch_cc = z(N, C, wp), z(N, Kw), z(N, C, Kw)
+            L.d_gch_in, L.d_gq_in = z(N, C, wp), z(N, wp)
 
     def load_inputs(self, inputs, training=False):
         if "at" in inputs:
@@ -203,11 +263,39 @@ class Model(model_v2.Model):
         """the arena from stream k's first row on (the strided attention starts there)"""
         return (L.d_arena if grad else L.arena).view(-1)[L.off[k] * self.wp:]
 
+    def _att_fwd(self, L, key, op, hinfo, hq, hm, qm, Wn, Bn, want_logits):
+        """one attention call site: (h_a, logits); under use_bidirection [h_a ; q_a] through its bidrection_squash"""
+        W, b = self._pv(Wn), self._pv(Bn)
+        if not self.bi:
+            return op.forward(hinfo, hq, hm, qm, W, b, want_logits)
+        st, wp = L.bi[key], self.wp
+        h_a, st.lg = op.forward(hinfo, hq, hm, qm, W, b, True)
+        ops.attn_qside_fwd(st.lg, hq, st.q_a, st.R, st.V, st.JQ, wp)            # model.py:169-177 / 297-307
+        ops.rows_reduce(h_a, st.cat, st.R, 1, wp, 2 * wp)                       # tf.concat([h_a, q_a])
+        ops.rows_reduce(st.q_a, st.cat.view(-1)[wp:], st.R, 1, wp, 2 * wp)
+        ops.linear_fwd(st.cat, self._pv(self.N_SQ[key] % "W"), self._pv(self.N_SQ[key] % "b"), st.out, st.R, 2 * wp, wp)
+        return st.out, st.lg
+
+    def _att_bwd(self, L, key, op, hinfo, hq, hm, qm, Wn, Bn, d_out, d_hinfo, d_hq, accumulate):
+        W, b, dW, db = self._pv(Wn), self._pv(Bn), self._pv(Wn, True), self._pv(Bn, True)
+        if not self.bi:
+            op.backward(hinfo, hq, hm, qm, W, b, d_out, d_hinfo, d_hq, dW, db, accumulate=accumulate)
+            return
+        st, wp = L.bi[key], self.wp
+        sW, sb = self.N_SQ[key] % "W", self.N_SQ[key] % "b"
+        ops.linear_bwd(st.cat, self._pv(sW), None, d_out, st.d_cat, self._pv(sW, True), self._pv(sb, True), st.R, 2 * wp, wp)
+        ops.rows_broadcast(st.d_cat, st.d_ha, st.R, 1, wp, 2 * wp)
+        ops.rows_broadcast(st.d_cat.view(-1)[wp:], st.d_qa, st.R, 1, wp, 2 * wp)
+        op.backward(hinfo, hq, hm, qm, W, b, st.d_ha, d_hinfo, d_hq, dW, db, accumulate=accumulate)   # the max-pooled half
+        ops.attn_qside_bwd(st.lg, hq, st.d_qa, st.dA, d_hq, st.R, st.V, st.JQ, wp)                    # the reversed half
+        op.logits_bwd(hinfo, hq, W, st.dA, d_hinfo, d_hq, dW, db)
+
     def _attend(self, L, want_logits):
-        """model.py:831-983.  Sets L.g1 (g1_all), L.gq, L.lch (gchoices)."""
+        """model.py:831-991.  Sets L.g1 (g1_all), L.gq, L.lch (gchoices)."""
         N, K, JQ, C, wp = L.N, L.K, L.JQ, L.C, self.wp
         T = L.groups["text"]
         ml_logits = []
+        stack = L.g1s_raw if (self.bi and not self.concat) else L.g1s
         for k, (cell, si, dims) in enumerate(L.ctx_slots):
             if self.use_ml_att:                                                 # :834-850
                 name = self.streams[k][0]
@@ -215,35 +303,48 @@ class Model(model_v2.Model):
                 g, lg = L.ml[k].forward(self._stream_ptr(L, k), L.hq, hm, qm, self._pv(self.N_ML_W % name),
                                         self._pv(self.N_ML_B % name), want_logits)
                 ml_logits.append(lg)
-                ops.rows_reduce(g, L.g1s.view(-1)[k * wp:], N, 1, wp, K * wp)   # tf.stack slot k (:892)
+                ops.rows_reduce(g, stack.view(-1)[k * wp:], N, 1, wp, K * wp)   # tf.stack slot k (:892)
             else:                                                               # :868-885: reduce_mean of the last states
                 G, seg = L.groups[cell], L.groups[cell].segs[si]
                 G.op.last_state(L.arena, seg["s0"], seg["count"], L.last[k])
-                ops.rows_reduce(L.last[k], L.g1s.view(-1)[k * wp:], N, L.cnt[k], wp, K * wp, 1.0 / L.cnt[k])
+                ops.rows_reduce(L.last[k], stack.view(-1)[k * wp:], N, L.cnt[k], wp, K * wp, 1.0 / L.cnt[k])
         mm_lg = att_lg = q_lg = None
-        if self.use_mm_att:                                                     # :901-904 (hinfo_mask None: no mask)
-            L.g1_a, mm_lg = L.mm.forward(L.g1s, L.hq, None, None, self._pv(self.N_MM_W), self._pv(self.N_MM_B), want_logits)
+        if self.concat:                                                         # :889: [N,K,w] side by side IS the concat
+            L.g1 = L.g1s.view(N, K * wp)
         else:
-            ops.rows_reduce(L.g1s, L.g1_a, N, K, wp, wp, 1.0 / K)               # :909
-        if self.use_direct_links:                                               # :916-953
-            full_a, att_lg = L.full.forward(L.hall, L.hq, None, None, self._pv(self.N_FULL_W), self._pv(self.N_FULL_B),
-                                            want_logits)
-            ops.rows_broadcast(full_a, L.g1, N, 1, wp)
-            if not self.direct_links_only:
-                ops.rows_broadcast(L.g1_a, L.g1, N, 1, wp, accumulate=True)
-        else:
-            ops.rows_broadcast(L.g1_a, L.g1, N, 1, wp)
-        if self.use_choices_att:                                                # :966-968
+            if self.bi:                                                         # :896-897
+                ops.linear_fwd(L.g1s_raw, self._pv(self.N_SQ["g1"] % "W"), self._pv(self.N_SQ["g1"] % "b"), L.g1s, N * K, wp, wp)
+            if self.use_mm_att:                                                 # :901-906 (hinfo_mask None: no mask)
+                L.g1_a, mm_lg = self._att_fwd(L, "mm", L.mm, L.g1s, L.hq, None, None, self.N_MM_W, self.N_MM_B, want_logits)
+            else:
+                ops.rows_reduce(L.g1s, L.g1_a, N, K, wp, wp, 1.0 / K)           # :909
+            if self.use_direct_links:                                           # :916-953
+                full_a, att_lg = L.full.forward(L.hall, L.hq, None, None, self._pv(self.N_FULL_W), self._pv(self.N_FULL_B),
+                                                want_logits)
+                ops.rows_broadcast(full_a, L.g1, N, 1, wp)
+                if not self.direct_links_only:
+                    ops.rows_broadcast(L.g1_a, L.g1, N, 1, wp, accumulate=True)
+            else:
+                ops.rows_broadcast(L.g1_a, L.g1, N, 1, wp)
+        if self.use_choices_att:                                                # :966-969
             ops.rows_broadcast(L.hq, L.hq4, N, C, JQ * wp)                      # the tile of hq per choice (:262)
-            gch, _ = L.catt.forward(L.hch, L.hq4, L.cmask, L.qmask4, self._pv(self.N_CATT_W), self._pv(self.N_CATT_B))
-            L.lch = gch.view(N, C, wp)
+            gch, _ = self._att_fwd(L, "catt", L.catt, L.hch, L.hq4, L.cmask, L.qmask4, self.N_CATT_W, self.N_CATT_B, False)
+            gch = gch.view(N, C, wp)
         else:
             T.op.last_state(L.arena, T.segs[1]["s0"], T.segs[1]["count"], L.lch)     # lchoices :971
-        if self.use_question_att:                                               # :977-978 (hq_mask None: no mask)
-            L.gq, q_lg = L.qatt.forward(L.hq, L.g1s, None, None, self._pv(self.N_QATT_W), self._pv(self.N_QATT_B), want_logits)
+            gch = L.lch
+        if self.use_question_att:                                               # :977-980 (hq_mask None: no mask)
+            L.gq, q_lg = self._att_fwd(L, "qatt", L.qatt, L.hq, L.g1s, None, None, self.N_QATT_W, self.N_QATT_B, want_logits)
         else:
             T.op.last_state(L.arena, T.segs[0]["s0"], T.segs[0]["count"], L.lq)      # lq :982
             L.gq = L.lq
+        if self.concat:                                                         # :987-991: lift both to the concat width
+            Kw = K * wp
+            L.gch_in, L.gq_in = gch, L.gq
+            ops.linear_fwd(gch, self._pv(self.N_CC["ch"] % "W"), self._pv(self.N_CC["ch"] % "b"), L.gch_cc, N * C, wp, Kw)
+            ops.linear_fwd(L.gq, self._pv(self.N_CC["q"] % "W"), self._pv(self.N_CC["q"] % "b"), L.gq_cc, N, wp, Kw)
+            gch, L.gq = L.gch_cc, L.gq_cc
+        L.lch = gch
         if want_logits:
             self.ml_att_logits, self.mm_att_logits = ml_logits, mm_lg
         return att_lg, q_lg
@@ -258,30 +359,42 @@ class Model(model_v2.Model):
         d_hq = L.d_arena[L.row_hq:L.row_hch]
         d_hch = L.d_arena[L.row_hch:]
         g = lambda n: self._pv(n, True)
+        if self.concat:
+            Kw = K * wp
+            cw, cb, qw, qb = self.N_CC["ch"] % "W", self.N_CC["ch"] % "b", self.N_CC["q"] % "W", self.N_CC["q"] % "b"
+            ops.linear_bwd(L.gch_in, self._pv(cw), None, dgch, L.d_gch_in, g(cw), g(cb), N * C, wp, Kw)
+            ops.linear_bwd(L.gq_in, self._pv(qw), None, dgq, L.d_gq_in, g(qw), g(qb), N, wp, Kw)
+            dgch, dgq = L.d_gch_in, L.d_gq_in
         if self.use_choices_att:
-            L.catt.backward(L.hch, L.hq4, L.cmask, L.qmask4, self._pv(self.N_CATT_W), self._pv(self.N_CATT_B),
-                            dgch.view(N * C, wp), d_hch, L.d_hq4, g(self.N_CATT_W), g(self.N_CATT_B), accumulate=0)
+            self._att_bwd(L, "catt", L.catt, L.hch, L.hq4, L.cmask, L.qmask4, self.N_CATT_W, self.N_CATT_B,
+                          dgch.view(N * C, wp), d_hch, L.d_hq4, 0)
             ops.rows_reduce(L.d_hq4, d_hq, N, C, JQ * wp, accumulate=True)      # gradient of the tile
         else:
             T.op.last_state_bwd(dgch.view(-1, wp), T.segs[1]["s0"], T.segs[1]["count"], L.d_arena)
         if self.use_question_att:
-            L.qatt.backward(L.hq, L.g1s, None, None, self._pv(self.N_QATT_W), self._pv(self.N_QATT_B), dgq, d_hq, L.d_g1s,
-                            g(self.N_QATT_W), g(self.N_QATT_B), accumulate=1)
+            self._att_bwd(L, "qatt", L.qatt, L.hq, L.g1s, None, None, self.N_QATT_W, self.N_QATT_B, dgq, d_hq, L.d_g1s, 1)
         else:
             T.op.last_state_bwd(dgq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
-        if self.use_direct_links:
-            L.full.backward(L.hall, L.hq, None, None, self._pv(self.N_FULL_W), self._pv(self.N_FULL_B), dg1, d_hall, d_hq,
-                            g(self.N_FULL_W), g(self.N_FULL_B), accumulate=1)
-        if not self.direct_links_only:
-            if self.use_mm_att:
-                L.mm.backward(L.g1s, L.hq, None, None, self._pv(self.N_MM_W), self._pv(self.N_MM_B), dg1, L.d_g1s, d_hq,
-                              g(self.N_MM_W), g(self.N_MM_B), accumulate=1)
-            else:
-                ops.rows_broadcast(dg1, L.d_g1s, N, K, wp, scale=1.0 / K, accumulate=True)
-        elif not self.use_question_att:
-            return                                                              # nothing reaches the per-stream vectors
+        if self.concat:
+            ops.rows_broadcast(dg1, L.d_g1s, N * K, 1, wp, accumulate=True)      # d g1_a [N,K*w] = d stack
+        else:
+            if self.use_direct_links:
+                L.full.backward(L.hall, L.hq, None, None, self._pv(self.N_FULL_W), self._pv(self.N_FULL_B), dg1, d_hall, d_hq,
+                                g(self.N_FULL_W), g(self.N_FULL_B), accumulate=1)
+            if not self.direct_links_only:
+                if self.use_mm_att:
+                    self._att_bwd(L, "mm", L.mm, L.g1s, L.hq, None, None, self.N_MM_W, self.N_MM_B, dg1, L.d_g1s, d_hq, 1)
+                else:
+                    ops.rows_broadcast(dg1, L.d_g1s, N, K, wp, scale=1.0 / K, accumulate=True)
+            elif not self.use_question_att:
+                return                                                          # nothing reaches the per-stream vectors
+        dstack = L.d_g1s
+        if self.bi and not self.concat:                                         # through the stack's squash (:897)
+            sW, sb = self.N_SQ["g1"] % "W", self.N_SQ["g1"] % "b"
+            ops.linear_bwd(L.g1s_raw, self._pv(sW), None, L.d_g1s, L.d_g1s_raw, g(sW), g(sb), N * K, wp, wp)
+            dstack = L.d_g1s_raw
         for k, (cell, si, dims) in enumerate(L.ctx_slots):
-            ops.rows_broadcast(L.d_g1s.view(-1)[k * wp:], L.dg_k, N, 1, wp, K * wp)        # d g1[:, k, :], dense
+            ops.rows_broadcast(dstack.view(-1)[k * wp:], L.dg_k, N, 1, wp, K * wp)          # d g1[:, k, :], dense
             if self.use_ml_att:
                 name = self.streams[k][0]
                 hm, qm = (self._stream_mask(L, k), L.q_mask) if L.masked[k] else (None, None)

@@ -202,7 +202,7 @@ class Model:
         if self.use_time_warp:     # model_v2.py:986-989: WH [4d -> 2d], WC [2d -> 1]
             specs[self.N_TW_WH_W], specs[self.N_TW_WH_B] = (2 * wp, wp), (wp,)
             specs[self.N_TW_WC_W], specs[self.N_TW_WC_B] = (wp,), (1,)
-        specs[self.N_OUT_W] = ((7 if self.use_eu_output else 5) * wp,)
+        specs[self.N_OUT_W] = ((7 if self.use_eu_output else 5) * self._scorer_width(),)
         specs[self.N_OUT_B] = (1,)
         self._plain = set()     # parameters stored exactly in the reference's shape (no hidden-size padding)
         if self.token_mode:
@@ -219,6 +219,10 @@ class Model:
         self.early_work = None      # pending all-reduce of the early gradient bucket (data parallelism), see backward()
         self.init_parameters(int(_cfg(config, "weight_seed", 42)))
         self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self.dev)
+
+    def _scorer_width(self):
+        """width of the three vectors the scorer combines (padded layout)"""
+        return self.wp
 
     def _attention_param_specs(self, F):
         """name -> shape of the attention block's variables (F = features per att_logits/W; 0: cosine, none).  The
@@ -304,6 +308,14 @@ class Model:
         R, C = m.shape[0] // dp, m.shape[1] // dp
         return torch.cat([torch.cat([m[r * dp:r * dp + d, c * dp:c * dp + d] for c in range(C)], 1) for r in range(R)], 0)
 
+    def _is_w2d(self, name):
+        """linear weights whose rows AND columns are hidden-size blocks ([R*d, C*d], stored [R*dp, C*dp])"""
+        return name == self.N_TW_WH_W
+
+    def _is_bfeat(self, name):
+        """bias vectors in the feature layout ([C*d] stored [C*dp])"""
+        return name == self.N_TW_WH_B
+
     def set_weights(self, weights):
         """weights: dict reference-name -> array in the REFERENCE's shapes
         (main.py:578-588 `weights.npz` layout)."""
@@ -317,9 +329,9 @@ class Model:
                 t = self._pad_kernel(t, *self._din(name))
             elif name.endswith("basic_lstm_cell/bias"):
                 t = self._pad_blocks(t, 4, self.d, self.dp)
-            elif name == self.N_TW_WH_W:
+            elif self._is_w2d(name):
                 t = self._pad_feat2d(t)
-            elif name.endswith("/W") or name == self.N_TW_WH_B:
+            elif name.endswith("/W") or self._is_bfeat(name):
                 t = self._pad_feat(t)
             self.params.view(name).copy_(t.reshape(self.params.specs[name]).to(self.dev))
 
@@ -334,9 +346,9 @@ class Model:
                 t = self._unpad_kernel(t, *self._din(name))
             elif name.endswith("basic_lstm_cell/bias"):
                 t = torch.cat([t[g * self.dp:g * self.dp + self.d] for g in range(4)])
-            elif name == self.N_TW_WH_W:
+            elif self._is_w2d(name):
                 t = self._unpad_feat2d(t)
-            elif name == self.N_TW_WH_B:
+            elif self._is_bfeat(name):
                 t = self._unpad_feat(t)
             elif name.endswith("/W"):
                 t = self._unpad_feat(t).reshape(-1, 1)
@@ -418,8 +430,8 @@ class Model:
             elif name.endswith("basic_lstm_cell/kernel"):
                 din = self.text_in if "utext" in name else self.img_in
                 wts[name] = _glorot(g, din + self.d, 4 * self.d)
-            elif name == self.N_TW_WH_W:
-                wts[name] = _trunc_normal(g, (4 * self.d, 2 * self.d))
+            elif self._is_w2d(name):
+                wts[name] = _trunc_normal(g, (shape[0] // self.dp * self.d, shape[1] // self.dp * self.d))
             elif name.endswith("/W"):
                 wts[name] = _trunc_normal(g, (shape[0] // self.dp * self.d, 1))
         self.set_weights(wts)

@@ -195,6 +195,29 @@ class FocalAttention:
               "fvta_attn_bwd")
 
 
+def linear_fwd(x, W, b, y, M, din, dout, add_tanh=False):
+    """y [M,dout] = x [M,din] W [din,dout] + b (+ tanh)  (fvta_linear_fwd)"""
+    check(_lib.load().fvta_linear_fwd(ptr(x), ptr(W), ptr(b), ptr(y), M, din, dout, int(add_tanh), stream_ptr()),
+          "fvta_linear_fwd")
+
+
+def linear_bwd(x, W, y, dy, dx, dW, db, M, din, dout, add_tanh=False, accumulate_dx=False):
+    """dx = dyt W^T (overwritten / added to), dW += x^T dyt, db += sum dyt; dyt = dy (1 - y^2) under add_tanh"""
+    check(_lib.load().fvta_linear_bwd(ptr(x), ptr(W), ptr(y), ptr(dy), ptr(dx), ptr(dW), ptr(db), M, din, dout,
+                                      int(add_tanh), int(accumulate_dx), stream_ptr()), "fvta_linear_bwd")
+
+
+def attn_qside_fwd(a_logits, hq, q_a, R, V, JQ, w):
+    """q_a [R,w] = mean_v softsel(hq [R,JQ,w], a_logits [R,V,JQ])  (the bidirect branch, model.py:169-177)"""
+    check(_lib.load().fvta_attn_qside_fwd(ptr(a_logits), ptr(hq), ptr(q_a), R, V, JQ, w, stream_ptr()), "fvta_attn_qside_fwd")
+
+
+def attn_qside_bwd(a_logits, hq, d_q_a, dA, d_hq, R, V, JQ, w):
+    """dA [R,V,JQ] overwritten, d_hq accumulated"""
+    check(_lib.load().fvta_attn_qside_bwd(ptr(a_logits), ptr(hq), ptr(d_q_a), ptr(dA), ptr(d_hq), R, V, JQ, w, stream_ptr()),
+          "fvta_attn_qside_bwd")
+
+
 def rows_reduce(x, out, rows, J, d, out_ld=None, scale=1.0, accumulate=False):
     """out[r, :] (+)= scale * sum_j x[r, j, :]; `out` rows out_ld floats apart (fvta_rows_reduce)"""
     check(_lib.load().fvta_rows_reduce(ptr(x), ptr(out), rows, J, d, d if out_ld is None else out_ld, float(scale),
@@ -205,6 +228,17 @@ def rows_broadcast(v, out, rows, J, d, v_ld=None, scale=1.0, accumulate=False):
     """out[r, j, :] (+)= scale * v[r, :]; `v` rows v_ld floats apart (fvta_rows_broadcast)"""
     check(_lib.load().fvta_rows_broadcast(ptr(v), ptr(out), rows, J, d, d if v_ld is None else v_ld, float(scale),
                                           int(accumulate), stream_ptr()), "fvta_rows_broadcast")
+
+
+def _focal_logits_bwd(self, hinfo, hq, W, dA, d_hinfo, d_hq, dW, db):
+    """dense logit gradient dA [N,T,JQ] of this K = 1 attention -> d_hinfo, d_hq (accumulated), dW, db (accumulated)"""
+    if getattr(self, "dense_work", None) is None:
+        self.dense_work = _bytes(self.lib.fvta_attn_logits_bwd_workspace_bytes(ctypes.byref(self.desc)), self.dev)
+    check(self.lib.fvta_attn_logits_bwd(ctypes.byref(self.desc), ptr(hinfo), ptr(hq), ptr(W), ptr(dA), ptr(d_hinfo), ptr(d_hq),
+                                        ptr(dW), ptr(db), ptr(self.dense_work), stream_ptr()), "fvta_attn_logits_bwd")
+
+
+FocalAttention.logits_bwd = _focal_logits_bwd
 
 
 def as_mask_u8(m):

@@ -129,15 +129,18 @@ def make_params(spec: SynthSpec, dtype=torch.float32):
     return {k: v.to(dtype) for k, v in p.items()}
 
 
-def make_params_v1(spec: SynthSpec, inputs, dtype=torch.float32, use_eu_output=False):
+def make_params_v1(spec: SynthSpec, inputs, dtype=torch.float32, use_eu_output=False, concat=False):
     """Parameters of the model.py graph (soft-attention baselines, fvta_memexqa_amd/model.py) for `inputs`' context
     streams, oracle short keys: make_params' encoders / scorer plus one att_logits pair per 1-D attention
     (ml{k}: per stream, model.py:838-850 -- the photo-title and photo streams always use similarity 1; mm, full, catt,
-    qatt)."""
+    qatt), the per-stream TGIF attention (tg{k}_{q,h,p,f}_{W,b}: mlp_q, mlp_h, preatt, final; mlp_dim = d, :853), the
+    four bidrection_squash linears (sq_*) and the two concat linears (cc_*)."""
     p = {k: v for k, v in make_params(spec).items() if k not in ("att_W", "att_b")}
     g = torch.Generator().manual_seed(spec.weight_seed + 1)
-    w = spec.w
+    d, w = spec.d, spec.w
+    K = len(inputs["ctx"])
     F = att_feat_dim(spec.simiMatrix, w)
+    lin = lambda i, o: (_trunc_normal(g, (i, o)), torch.zeros(o))
     for k, st in enumerate(inputs["ctx"]):
         masked = st.get("cell", "text") == "text" and st["mask"].dim() == 3
         p["ml%d_W" % k] = _trunc_normal(g, (F if masked else 3 * w, 1))
@@ -145,8 +148,17 @@ def make_params_v1(spec: SynthSpec, inputs, dtype=torch.float32, use_eu_output=F
     for name in ("mm", "full", "catt"):
         p[name + "_W"] = _trunc_normal(g, (F, 1))
         p[name + "_b"] = torch.zeros(1)
-    if use_eu_output:                                                  # model.py:1011: seven feature blocks
-        p["out_W"] = _trunc_normal(g, (7 * w, 1))
+    for k in range(K):
+        for n, (i, o) in (("q", (w, d)), ("h", (w, d)), ("p", (d, 1)), ("f", (w, w))):
+            p["tg%d_%s_W" % (k, n)], p["tg%d_%s_b" % (k, n)] = lin(i, o)
+    p["sq_g1_W"], p["sq_g1_b"] = lin(w, w)                               # model.py:897 (g1 is already [N,K,2d])
+    for name in ("mm", "catt", "qatt"):
+        p["sq_%s_W" % name], p["sq_%s_b" % name] = lin(2 * w, w)         # :906, :969, :980  [4d -> 2d]
+    for name in ("ch", "q"):
+        p["cc_%s_W" % name], p["cc_%s_b" % name] = lin(w, K * w)         # :990-991
+    wo = K * w if concat else w
+    if use_eu_output or concat:                                          # model.py:1011 / :1013 feature blocks
+        p["out_W"] = _trunc_normal(g, ((7 if use_eu_output else 5) * wo, 1))
     return {k: v.to(dtype) for k, v in p.items()}
 
 

@@ -332,6 +332,11 @@ int fvta_softsel_fwd(const float* target, const float* logits, float* out, int64
 int fvta_exp_mask(const float* val, const uint8_t* mask, float* out, int64_t n, fvta_stream_t stream);
 int fvta_linear_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int32_t in, int32_t out,
                     int32_t add_tanh, fvta_stream_t stream);
+/* Backward of fvta_linear_fwd (the `bidrection_squash` / concat linears of model.py:895-991): with dyt = dy, or
+ * dy (1 - y^2) under add_tanh (y = the forward output): dx [M,in] = dyt W^T (overwritten, or added to when accumulate_dx),
+ * dW [in,out] += x^T dyt, db [out] += sum_m dyt.  dx, dW (with db) may each be NULL. */
+int fvta_linear_bwd(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW, float* db,
+                    int64_t M, int32_t in, int32_t out, int32_t add_tanh, int32_t accumulate_dx, fvta_stream_t stream);
 /* sum_j weights[r,j] * target[r,j,:] -> out[r,:] (no softmax): the attended vector of attention_tgif, model.py:236-238 */
 int fvta_wsum_fwd(const float* target, const float* weights, float* out, int64_t rows, int32_t J, int32_t d,
                   fvta_stream_t stream);
@@ -353,6 +358,20 @@ int fvta_rows_reduce(const float* x, float* out, int64_t rows, int32_t J, int32_
                      int32_t accumulate, fvta_stream_t stream);
 int fvta_rows_broadcast(const float* v, float* out, int64_t rows, int32_t J, int32_t d, int64_t v_ld, float scale,
                         int32_t accumulate, fvta_stream_t stream);
+/* The reversed direction of attention(..., bidirect=True) / attention_keeprank1(..., bidirect=True) (model_v2.py:184-192,
+ * model.py:169-177, 297-307): q_a[r,:] = mean_v softsel(hq[r], a_logits[r,v,:]) over the MASKED logits fvta_attn_fwd
+ * returns (a_logits [R,V,JQ], hq [R,JQ,w]; JQ <= 64, V*JQ <= 8192: the reference only runs this branch on short row
+ * lists).  Backward: d_q_a [R,w] -> dA [R,V,JQ] (overwritten; the additive mask passes it to the raw logits unchanged)
+ * and d_hq (accumulated).  fvta_attn_logits_bwd turns a DENSE logit gradient dA [N,T,JQ] of a K = 1 attention (no tanh,
+ * simiMatrix 1-3; hinfo_stride honoured) into d_hinfo, d_hq (accumulated), dW, db (accumulated) -- the max-pooled h_a
+ * path stays with fvta_attn_bwd. */
+int fvta_attn_qside_fwd(const float* a_logits, const float* hq, float* q_a, int32_t R, int32_t V, int32_t JQ, int32_t w,
+                        fvta_stream_t stream);
+int fvta_attn_qside_bwd(const float* a_logits, const float* hq, const float* d_q_a, float* dA, float* d_hq, int32_t R,
+                        int32_t V, int32_t JQ, int32_t w, fvta_stream_t stream);
+size_t fvta_attn_logits_bwd_workspace_bytes(const fvta_attn_desc* d);
+int fvta_attn_logits_bwd(const fvta_attn_desc* d, const float* hinfo, const float* hq, const float* W, const float* dA,
+                         float* d_hinfo, float* d_hq, float* dW, float* db, void* workspace, fvta_stream_t stream);
 /* attention_keeprank1 (model.py:247-314) = the per-(n,k) inner softsel of attention_3d without the softmax over k:
  * after fvta_attn_fwd(desc with K = M) this copies that result, u[N,K,w], out of the saved state. */
 int fvta_attn_read_u(const fvta_attn_desc* d, const void* saved, float* u_out, fvta_stream_t stream);

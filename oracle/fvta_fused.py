@@ -378,14 +378,34 @@ def weight_decay_terms(params, cfg):
 
 
 # ---------------------------------------------------- model.py (soft-attention baselines) ---
-def attention_keeprank1(hinfo, hq, W, b, hinfo_mask=None, hq_mask=None, simiMatrix=1):
-    """model.py:248-318 (bidirect=False): one softsel per (n, m), max over the question inside -> [N,M,w]."""
+def attention_keeprank1(hinfo, hq, W, b, hinfo_mask=None, hq_mask=None, simiMatrix=1, bidirect=False):
+    """model.py:248-318: one softsel per (n, m), max over the question inside -> [N,M,w]; bidirect (:297-308) appends
+    the question attended by every row, averaged over the rows -> [N,M,2w]."""
     N, M, w = hinfo.shape[0], hinfo.shape[1], hinfo.shape[-1]
     h = hinfo.reshape(N, M, -1, w)
     a = simi_logits(h, hq[:, None], W, b, simiMatrix, False, "v1")       # [N,M,V,JQ]
     if hinfo_mask is not None and hq_mask is not None:
         a = exp_mask(a, hinfo_mask.reshape(N, M, -1)[..., None] & hq_mask[:, None, None, :])
-    return softsel(h, a.amax(dim=3))
+    h_a = softsel(h, a.amax(dim=3))
+    if bidirect:
+        q_a = (softmax(a).unsqueeze(-1) * hq[:, None, None, :, :]).sum(-2).mean(2)
+        h_a = torch.cat([h_a, q_a], 2)
+    return h_a
+
+
+def attention_tgif(hinfo, lq, p, hinfo_mask=None):
+    """model.py:210-245 (the TGIF-QA attention): p = dict(q_W, q_b, h_W, h_b, p_W, p_b, f_W, f_b) for the scopes mlp_q,
+    mlp_h, preatt, final.  exp_mask is applied to the PROBABILITIES (:234), as written."""
+    N, w = hinfo.shape[0], hinfo.shape[-1]
+    h = hinfo.reshape(N, -1, w)
+    q_in = linear(lq, p["q_W"], p["q_b"])
+    h_in = linear(h, p["h_W"], p["h_b"])
+    score = linear(q_in[:, None, :] + h_in, p["p_W"], p["p_b"])[..., 0]
+    att = softmax(score)
+    if hinfo_mask is not None:
+        att = exp_mask(att, hinfo_mask.reshape(N, -1))
+    attended = (h * att.unsqueeze(-1)).sum(1)
+    return torch.tanh(linear(attended, p["f_W"], p["f_b"])) + lq, att
 
 
 def v1_stream_is_masked(st):
@@ -396,14 +416,24 @@ def v1_stream_is_masked(st):
 
 
 def model_v1_forward(params, inputs, cfg):
-    """model.py:658-1037 from the encoder inputs to the loss: the soft-attention baselines (use_ml_att / use_mm_att /
-    use_direct_links / use_choices_att / use_question_att; bidirection, concat and the tgif attention are not restated).
-    Same `inputs` as fvta_forward; params as there plus ml{k}_W/b (per context stream), mm_W/b, full_W/b, catt_W/b."""
+    """model.py:658-1037 from the encoder inputs to the loss: the soft-attention baselines (use_ml_att / use_tgif_ml_att /
+    use_mm_att / use_direct_links / use_choices_att / use_question_att / use_bidirection / concat).  Same `inputs` as
+    fvta_forward; params as there plus ml{k}_W/b or tg{k}_{q,h,p,f}_{W,b} (per context stream), mm_W/b, full_W/b,
+    catt_W/b, the bidrection_squash linears sq_{g1,mm,catt,qatt}_{W,b} and the concat linears cc_{ch,q}_{W,b}.
+    Flag combinations the reference's own graph construction rejects are rejected here too (ValueError)."""
     def cell(name):
         return (params[name + "_kernel"], params[name + "_bias"],
                 params.get(name + "_kernel_bw"), params.get(name + "_bias_bw"))
 
     simi = cfg["simiMatrix"]
+    bi = bool(cfg.get("use_bidirection", False))
+    concat = bool(cfg.get("concat", False))
+    if bi and cfg.get("use_ml_att", False):
+        raise ValueError("use_bidirection + use_ml_att: tf.stack of [N,4d] (at..where) with [N,2d] (pts, pis: model.py:849-850 "
+                         "pass no bidirect) fails")
+    if concat and (cfg.get("use_question_att", False) or cfg.get("use_direct_links", False)):
+        raise ValueError("concat: g1 is undefined for question_att (model.py:978) and full_a [N,2d] cannot be added to / "
+                         "scored against the [N,12d] concat (:952, :1013)")
     qmask = inputs["q"]["mask"]
     hq, lq = encode_stream(inputs["q"]["x"], qmask, *cell("text"))                       # :660-663
     hch, lch = encode_stream(inputs["choices"]["x"], inputs["choices"]["mask"], *cell("text"))   # :767-778
@@ -418,16 +448,28 @@ def model_v1_forward(params, inputs, cfg):
                                  simiMatrix=simi, feat_order="v1")
             else:
                 g, _ = attention(h, hq, params.get("ml%d_W" % k), params.get("ml%d_b" % k), simiMatrix=1)
+        elif cfg.get("use_tgif_ml_att", False):                                          # :851-866, mlp_dim = d
+            g, _ = attention_tgif(h, lq, {n: params["tg%d_%s" % (k, n)] for n in
+                                          ("q_W", "q_b", "h_W", "h_b", "p_W", "p_b", "f_W", "f_b")}, st["mask"])
         else:                                                                            # :868-885: means of the last states
             g = (last.mean(2) if last.dim() == 4 else last).mean(1)
         g1s.append(g)
-    g1 = torch.stack(g1s, 1)                                                             # :892  [N,K,w]
-    out = {"hq": hq, "lq": lq, "g1": g1}
-    if cfg.get("use_mm_att", False):                                                     # :901-904 (hinfo_mask None: unmasked)
-        g1_a, out["mm_att_logits"] = attention(g1, hq, params.get("mm_W"), params.get("mm_b"), simiMatrix=simi,
-                                               feat_order="v1")
+    out = {"hq": hq, "lq": lq}
+    if concat:
+        g1_a = torch.cat(g1s, 1)                                                         # :889  [N,K*w]
+        out["g1"] = torch.stack(g1s, 1)
     else:
-        g1_a = g1.mean(1)                                                                # :909
+        g1 = torch.stack(g1s, 1)                                                         # :892  [N,K,w]
+        if bi:
+            g1 = linear(g1, params["sq_g1_W"], params["sq_g1_b"])                        # :896-897
+        out["g1"] = g1
+        if cfg.get("use_mm_att", False):                                                 # :901-906 (hinfo_mask None: unmasked)
+            g1_a, out["mm_att_logits"] = attention(g1, hq, params.get("mm_W"), params.get("mm_b"), simiMatrix=simi,
+                                                   feat_order="v1", bidirect=bi)
+            if bi:
+                g1_a = linear(g1_a, params["sq_mm_W"], params["sq_mm_b"])
+        else:
+            g1_a = g1.mean(1)                                                            # :909
     if cfg.get("use_direct_links", False):                                               # :916-952
         full = torch.cat(hs, 1)
         full_a, out["att_logits"] = attention(full, hq, params.get("full_W"), params.get("full_b"), simiMatrix=simi,
@@ -435,16 +477,23 @@ def model_v1_forward(params, inputs, cfg):
         g1_all = full_a if cfg.get("direct_links_only", False) else full_a + g1_a
     else:
         g1_all = g1_a
-    if cfg.get("use_choices_att", False):                                                # :966-968
+    if cfg.get("use_choices_att", False):                                                # :966-969
         gch = attention_keeprank1(hch, hq, params.get("catt_W"), params.get("catt_b"), inputs["choices"]["mask"], qmask,
-                                  simiMatrix=simi)
+                                  simiMatrix=simi, bidirect=bi)
+        if bi:
+            gch = linear(gch, params["sq_catt_W"], params["sq_catt_b"])
     else:
         gch = lch                                                                        # :971
-    if cfg.get("use_question_att", False):                                               # :977-978 (hq_mask None: unmasked)
+    if cfg.get("use_question_att", False):                                               # :977-980 (hq_mask None: unmasked)
         gq, out["q_att_logits"] = attention(hq, g1, params.get("qatt_W"), params.get("qatt_b"), simiMatrix=simi,
-                                            feat_order="v1")
+                                            feat_order="v1", bidirect=bi)
+        if bi:
+            gq = linear(gq, params["sq_qatt_W"], params["sq_qatt_b"])
     else:
         gq = lq                                                                          # :982
+    if concat:                                                                           # :987-991
+        gch = linear(gch, params["cc_ch_W"], params["cc_ch_b"])
+        gq = linear(gq, params["cc_q_W"], params["cc_q_b"])
     out["g1_all"], out["gq"], out["gchoices"] = g1_all, gq, gch
     logits, yp = scorer(gq, g1_all, gch, params["out_W"], params["out_b"], cfg.get("use_eu_output", False), False)  # :996-1013
     out["logits"], out["yp"] = logits, yp
@@ -460,9 +509,12 @@ def v1_weight_decay_terms(params, cfg):
     wd = cfg.get("wd", None)
     if not wd:
         return 0.0
-    cover = {k: v for k, v in WD_COVER.items() if k not in ("att_W", "att_b")}
-    for k in params:
-        if k.startswith(("ml", "mm_", "full_", "catt_")):
+    cover = {k: v for k, v in WD_COVER.items() if k not in ("att_W", "att_b", "qatt_W", "qatt_b")}
+    on = {"ml": cfg.get("use_ml_att", False), "tg": cfg.get("use_tgif_ml_att", False) and not cfg.get("use_ml_att", False),
+          "mm_": cfg.get("use_mm_att", False) and not cfg.get("concat", False), "full_": cfg.get("use_direct_links", False),
+          "catt_": cfg.get("use_choices_att", False), "qatt_": cfg.get("use_question_att", False)}
+    for k in params:                                                   # (the squash / concat linears pass no wd)
+        if any(k.startswith(pre) and flag for pre, flag in on.items()):
             cover[k] = 1
     total = 0.0
     for k, mult in cover.items():

@@ -555,6 +555,8 @@ def model_v1_forward(params, inputs, cfg):
                 params.get(name + "_kernel_bw"), params.get(name + "_bias_bw"))
 
     simi = cfg["simiMatrix"]
+    bi = bool(cfg.get("use_bidirection", False))
+    concat = bool(cfg.get("concat", False))
     qmask = np.asarray(inputs["q"]["mask"], bool)
     cmask = np.asarray(inputs["choices"]["mask"], bool)
     hq, lq = encode_stream(inputs["q"]["x"], qmask, *cell("text"))                       # :660-663
@@ -568,20 +570,32 @@ def model_v1_forward(params, inputs, cfg):
         if cfg.get("use_ml_att", False):
             W, b = params.get("ml%d_W" % k), params.get("ml%d_b" % k)
             if st.get("cell", "text") == "text" and np.asarray(st["x"]).ndim == 4:       # at/ad/when/where :838-842
-                g, _ = attention(h, hq, W, b, m, qmask, simiMatrix=simi, feat_order="v1")
+                g, _ = attention(h, hq, W, b, m, qmask, simiMatrix=simi, feat_order="v1", bidirect=bi)
             else:                                                                        # pts / pis :849-850
                 g, _ = attention(h, hq, W, b, m, None, simiMatrix=1, feat_order="v1")
+        elif cfg.get("use_tgif_ml_att", False):                                          # :853-866
+            g, _ = attention_tgif(h, lq, *[params["tg%d_%s" % (k, n)] for n in
+                                           ("q_W", "q_b", "h_W", "h_b", "p_W", "p_b", "f_W", "f_b")], hinfo_mask=m)
         else:
             g0 = last.mean(axis=2) if last.ndim == 4 else last                           # :875-880
             g = g0.mean(axis=1)                                                          # :882-887
         g1s.append(g)
-    g1 = np.stack(g1s, 1)                                                                # :892
-    out = {"hq": hq, "lq": lq, "g1": g1}
-    if cfg.get("use_mm_att", False):
-        g1_a, out["mm_att_logits"] = attention(g1, hq, params.get("mm_W"), params.get("mm_b"), None, qmask,
-                                               simiMatrix=simi, feat_order="v1")         # :904
+    out = {"hq": hq, "lq": lq}
+    if concat:
+        g1_a = np.concatenate(g1s, 1)                                                    # :889
+        out["g1"] = np.stack(g1s, 1)
     else:
-        g1_a = g1.mean(axis=1)                                                           # :909
+        g1 = np.stack(g1s, 1)                                                            # :892 (fails on mixed widths, as tf.stack)
+        if bi:
+            g1 = linear(g1, params["sq_g1_W"], params["sq_g1_b"])                        # :896-897
+        out["g1"] = g1
+        if cfg.get("use_mm_att", False):
+            g1_a, out["mm_att_logits"] = attention(g1, hq, params.get("mm_W"), params.get("mm_b"), None, qmask,
+                                                   simiMatrix=simi, feat_order="v1", bidirect=bi)   # :904
+            if bi:
+                g1_a = linear(g1_a, params["sq_mm_W"], params["sq_mm_b"])                # :906
+        else:
+            g1_a = g1.mean(axis=1)                                                       # :909
     if cfg.get("use_direct_links", False):
         full = np.concatenate(hs, 1)                                                     # :929-936
         full_a, out["att_logits"] = attention(full, hq, params.get("full_W"), params.get("full_b"), None, None,
@@ -591,14 +605,21 @@ def model_v1_forward(params, inputs, cfg):
         g1_all = g1_a
     if cfg.get("use_choices_att", False):
         gchoices = attention_keeprank1(hchoices, hq, params.get("catt_W"), params.get("catt_b"), cmask, qmask,
-                                       simiMatrix=simi)                                  # :967
+                                       simiMatrix=simi, bidirect=bi)                     # :967
+        if bi:
+            gchoices = linear(gchoices, params["sq_catt_W"], params["sq_catt_b"])        # :969
     else:
         gchoices = lchoices
     if cfg.get("use_question_att", False):
         gq, out["q_att_logits"] = attention(hq, g1, params.get("qatt_W"), params.get("qatt_b"), qmask, None,
-                                            simiMatrix=simi, feat_order="v1")            # :978
+                                            simiMatrix=simi, feat_order="v1", bidirect=bi)  # :978 (g1 undefined under concat)
+        if bi:
+            gq = linear(gq, params["sq_qatt_W"], params["sq_qatt_b"])                    # :980
     else:
         gq = lq
+    if concat:                                                                           # :987-991
+        gchoices = linear(gchoices, params["cc_ch_W"], params["cc_ch_b"])
+        gq = linear(gq, params["cc_q_W"], params["cc_q_b"])
     out["g1_all"], out["gq"], out["gchoices"] = g1_all, gq, gchoices
     logits, yp = scorer(gq, g1_all, gchoices, params["out_W"], params["out_b"], cfg.get("use_eu_output", False), False)
     out["logits"], out["yp"] = logits, yp

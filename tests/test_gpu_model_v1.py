@@ -20,8 +20,8 @@ def _run(spec, flags, precision="f32", tol=1.0):
     from fvta_memexqa_amd.synth import make_inputs, make_params_v1, to_dtype
     from oracle import fvta_fused as F
     inputs = make_inputs(spec)
-    params = make_params_v1(spec, inputs, use_eu_output=bool(flags.get("use_eu_output")))
-    cfg = dict(spec.cfg(), add_tanh=False, **flags)
+    params = make_params_v1(spec, inputs, use_eu_output=bool(flags.get("use_eu_output")), concat=bool(flags.get("concat")))
+    cfg = {**spec.cfg(), "use_question_att": False, "add_tanh": False, **flags}
     p64 = {k: v.double().requires_grad_() for k, v in params.items()}
     ref = F.model_v1_forward(p64, to_dtype(inputs, torch.float64), cfg)
     ref["loss"].backward()
@@ -33,11 +33,13 @@ def _run(spec, flags, precision="f32", tol=1.0):
     yp = model.forward(L, want_logits=True)
     d, dp = model.d, model.dp
     unpad = lambda t: torch.cat([t[..., :d], t[..., dp:dp + d]], -1)
+    def unpadk(t):                        # [..., k*2dp] feature vectors of k hidden-size pairs (the concat variant)
+        return unpad(t.reshape(*t.shape[:-1], -1, 2 * dp)).reshape(*t.shape[:-1], -1)
     _close(unpad(L.hq), ref["hq"], rtol=1e-4 * tol, atol=1e-5 * tol, msg="hq")
     _close(unpad(L.g1s), ref["g1"], rtol=1e-4 * tol, atol=1e-5 * tol, msg="g1 (per-stream vectors)")
-    _close(unpad(L.g1), ref["g1_all"], rtol=1e-4 * tol, atol=1e-5 * tol, msg="g1_all")
-    _close(unpad(L.gq), ref["gq"], rtol=1e-4 * tol, atol=1e-5 * tol, msg="gq")
-    _close(unpad(L.lch), ref["gchoices"], rtol=1e-4 * tol, atol=1e-5 * tol, msg="gchoices")
+    _close(unpadk(L.g1), ref["g1_all"], rtol=1e-4 * tol, atol=1e-5 * tol, msg="g1_all")
+    _close(unpadk(L.gq), ref["gq"], rtol=1e-4 * tol, atol=1e-5 * tol, msg="gq")
+    _close(unpadk(L.lch), ref["gchoices"], rtol=1e-4 * tol, atol=1e-5 * tol, msg="gchoices")
     if flags.get("use_direct_links"):
         _close(model.att_logits.reshape(ref["att_logits"].shape), ref["att_logits"], atol=2e-5 * tol, msg="att_logits")
     if flags.get("use_mm_att"):
@@ -77,6 +79,14 @@ ALL = dict(use_ml_att=True, use_mm_att=True, use_direct_links=True, use_choices_
     dict(use_question_att=True),
     ALL,
     dict(ALL, use_eu_output=True),
+    dict(use_bidirection=True),                                     # only the stack's squash linear (model.py:897)
+    dict(use_bidirection=True, use_mm_att=True),
+    dict(use_bidirection=True, use_choices_att=True),
+    dict(use_bidirection=True, use_question_att=True),
+    dict(use_bidirection=True, use_mm_att=True, use_direct_links=True, use_choices_att=True, use_question_att=True),
+    dict(concat=True),
+    dict(concat=True, use_ml_att=True, use_choices_att=True, use_eu_output=True),
+    dict(concat=True, use_bidirection=True, use_choices_att=True),
 ], ids=lambda f: "+".join(k[4:] if k.startswith("use_") else k for k in f) or "baseline")
 @pytest.mark.parametrize("dense", [False, True])
 def test_v1_model_forward_backward(flags, dense):
@@ -102,7 +112,7 @@ def test_v1_model_six_streams_padded_hidden_and_wd():
     spec = SynthSpec(N=2, A=2, P=2, S=1, L=4, d=20, SA=4, dense=False, simiMatrix=2, text_in=12, img_in=8)
     inputs = make_inputs(spec)
     params = make_params_v1(spec, inputs)
-    cfg = dict(spec.cfg(), add_tanh=False, wd=1e-3, **ALL)
+    cfg = {**spec.cfg(), "add_tanh": False, "wd": 1e-3, **ALL}
     p64 = {k: v.double().requires_grad_() for k, v in params.items()}
     ref = F.model_v1_forward(p64, to_dtype(inputs, torch.float64), cfg)
     ref["loss"].backward()
@@ -118,14 +128,20 @@ def test_v1_model_six_streams_padded_hidden_and_wd():
     model.backward(L)
     grads = model.get_oracle_grads()
     for k, v in p64.items():
+        if v.grad is None:              # parameters of blocks that are switched off (tgif, squash, concat linears)
+            continue
         _close(grads[k].reshape(v.grad.shape), v.grad, rtol=2e-4, atol=2e-5, msg="grad " + k)
 
 
 def test_v1_model_unbuilt_switches_raise():
     from fvta_memexqa_amd.model import Model
-    for flag in ("use_bidirection", "concat", "use_tgif_ml_att"):
-        with pytest.raises(NotImplementedError):
-            Model({flag: True, "hidden_size": 32})
+    with pytest.raises(NotImplementedError):
+        Model({"use_tgif_ml_att": True, "hidden_size": 32})
+    # flag sets the reference's own graph construction rejects (shape mismatches / an undefined name)
+    for flags in (dict(use_bidirection=True, use_ml_att=True), dict(concat=True, use_question_att=True),
+                  dict(concat=True, use_direct_links=True)):
+        with pytest.raises(ValueError):
+            Model(dict(flags, hidden_size=32))
     with pytest.raises(ValueError):
         Model({"simiMatrix": 4, "hidden_size": 32})
 
@@ -138,7 +154,7 @@ def test_v1_model_bf16_encoders():
     spec = SynthSpec(N=4, A=2, P=3, S=1, L=6, d=64, SA=2, dense=False, simiMatrix=1, text_in=16, img_in=8)
     inputs = make_inputs(spec)
     params = make_params_v1(spec, inputs)
-    cfg = dict(spec.cfg(), add_tanh=False, **ALL)
+    cfg = {**spec.cfg(), "add_tanh": False, **ALL}
     p64 = {k: v.double().requires_grad_() for k, v in params.items()}
     ref = F.model_v1_forward(p64, to_dtype(inputs, torch.float64), cfg)
     ref["loss"].backward()
@@ -154,7 +170,7 @@ def test_v1_model_bf16_encoders():
     model.backward(L)
     grads = model.get_oracle_grads()
     for k, v in p64.items():
-        if float(v.grad.abs().max()) < 1e-9:
+        if v.grad is None or float(v.grad.abs().max()) < 1e-9:
             continue
         # (gradients that are differences of nearly cancelling terms -- norms of 1e-5 -- carry the bf16 rounding of the
         # encoder outputs at full size)
@@ -167,7 +183,7 @@ def test_v1_trainer_step():
     from fvta_memexqa_amd.trainer import Trainer
     spec = SynthSpec(N=4, A=1, P=3, S=1, L=5, d=32, SA=2, dense=False, text_in=12, img_in=8)
     inputs = make_inputs(spec)
-    model = Model(dict(spec.cfg(), add_tanh=False, batch_size=spec.N, ctx_streams=Model.streams_of(inputs), **ALL),
+    model = Model({**spec.cfg(), "add_tanh": False, "batch_size": spec.N, "ctx_streams": Model.streams_of(inputs), **ALL},
                   text_in=spec.text_in, img_in=spec.img_in)
     model.set_oracle_params(make_params_v1(spec, inputs))
     tr = Trainer(model, dict(init_lr=0.5))

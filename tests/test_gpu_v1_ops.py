@@ -79,3 +79,76 @@ def test_rows_reduce_and_broadcast():
     assert torch.equal(y, wanty.contiguous())
     ops.rows_broadcast(v.view(-1)[2 * d:], y, R, J, d, K * d, 1.0, accumulate=True)
     torch.testing.assert_close(y, wanty + v[:, 2][:, None, :], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("tanh", [False, True])
+def test_linear_bwd_against_autograd(tanh):
+    from fvta_memexqa_amd import ops
+    dev = ops.require_gpu()
+    g = torch.Generator().manual_seed(2)
+    M, din, dout = 77, 130, 70
+    x = torch.randn(M, din, generator=g).to(dev)
+    W = (torch.randn(din, dout, generator=g) * 0.1).to(dev)
+    b = torch.randn(dout, generator=g).to(dev)
+    dy = torch.randn(M, dout, generator=g).to(dev)
+    y = torch.empty(M, dout, device=dev)
+    ops.linear_fwd(x, W, b, y, M, din, dout, tanh)
+    xr, Wr, br = (t.double().cpu().requires_grad_() for t in (x, W, b))
+    yr = xr @ Wr + br
+    yr = torch.tanh(yr) if tanh else yr
+    torch.testing.assert_close(y.cpu().double(), yr.detach(), rtol=1e-5, atol=1e-5)
+    yr.backward(dy.double().cpu())
+    dx = torch.full((M, din), 0.5, device=dev)
+    dW, db = torch.ones(din, dout, device=dev), torch.ones(dout, device=dev)
+    ops.linear_bwd(x, W, y, dy, dx, dW, db, M, din, dout, tanh, accumulate_dx=True)
+    torch.testing.assert_close(dx.cpu().double(), xr.grad + 0.5, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dW.cpu().double(), Wr.grad + 1.0, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu().double(), br.grad + 1.0, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("simi", [1, 2, 3])
+@pytest.mark.parametrize("masked", [False, True])
+def test_bidirect_attention_forward_backward(simi, masked):
+    """attention(..., bidirect=True) -> [h_a ; q_a] (model.py:169-177) through fvta_attn_fwd + fvta_attn_qside_fwd, and its
+    gradient through fvta_attn_bwd (max-pooled half) + fvta_attn_qside_bwd + fvta_attn_logits_bwd (dense half), against
+    autograd of the fp64 oracle"""
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    dev = ops.require_gpu()
+    g = torch.Generator().manual_seed(11)
+    N, V, JQ, w = 4, 9, 7, 64
+    nf = {1: 3, 2: 2, 3: 4}[simi]
+    h = torch.randn(N, V, w, generator=g)
+    q = torch.randn(N, JQ, w, generator=g)
+    W = torch.randn(nf * w, 1, generator=g) * 0.1
+    b = torch.randn(1, generator=g) * 0.1
+    hm = (torch.rand(N, V, generator=g) > 0.3) if masked else None
+    qm = (torch.rand(N, JQ, generator=g) > 0.3) if masked else None
+    if masked:
+        hm[:, 0] = True
+        qm[:, 0] = True
+        # (no batch row without ANY valid context row: fvta_attn_bwd passes no gradient into the logits of a fully masked
+        # (n, k), DESIGN.md section 2 deviation (b); masked context rows -- uniform over the question -- are covered)
+    hr, qr, Wr, br = (t.double().requires_grad_() for t in (h, q, W, b))
+    ref, _ = F.attention(hr, qr, Wr, br, hm, qm, simiMatrix=simi, feat_order="v1", bidirect=True)
+    go = torch.randn(N, 2 * w, generator=g)
+    ref.backward(go.double())
+    hd, qd, Wd, bd = (t.to(dev).contiguous() for t in (h, q, W.reshape(-1), b))
+    hmd = hm.to(torch.uint8).to(dev) if masked else None
+    qmd = qm.to(torch.uint8).to(dev) if masked else None
+    op = ops.FocalAttention(N, 1, V, JQ, w, simi, False, feat_order=1)
+    h_a, lg = op.forward(hd, qd, hmd, qmd, Wd, bd, True)
+    q_a = torch.empty(N, w, device=dev)
+    ops.attn_qside_fwd(lg, qd, q_a, N, V, JQ, w)
+    torch.testing.assert_close(torch.cat([h_a, q_a], 1).cpu().double(), ref.detach(), rtol=1e-4, atol=1e-5)
+    god = go.to(dev)
+    d_h, d_q = torch.zeros(N, V, w, device=dev), torch.zeros(N, JQ, w, device=dev)
+    dW, db = torch.zeros(nf * w, device=dev), torch.zeros(1, device=dev)
+    op.backward(hd, qd, hmd, qmd, Wd, bd, god[:, :w].contiguous(), d_h, d_q, dW, db, accumulate=0)
+    dA = torch.empty(N, V, JQ, device=dev)
+    ops.attn_qside_bwd(lg, qd, god[:, w:].contiguous(), dA, d_q, N, V, JQ, w)
+    op.logits_bwd(hd, qd, Wd, dA, d_h, d_q, dW, db)
+    torch.testing.assert_close(d_h.cpu().double(), hr.grad, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(d_q.cpu().double(), qr.grad, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(dW.cpu().double(), Wr.grad.reshape(-1), rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(db.cpu().double(), br.grad, rtol=2e-4, atol=2e-5)

@@ -163,17 +163,35 @@ def test_conv1d_known_answer():
     dict(use_direct_links=True, use_choices_att=True, use_question_att=True),
     dict(use_ml_att=True, use_mm_att=True, use_direct_links=True, use_choices_att=True, use_question_att=True,
          use_eu_output=True),
+    dict(use_bidirection=True, use_mm_att=True, use_choices_att=True, use_question_att=True, use_direct_links=True),
+    dict(use_bidirection=True),
+    dict(use_tgif_ml_att=True, use_mm_att=True),
+    dict(concat=True, use_ml_att=True, use_choices_att=True),
+    dict(concat=True, use_eu_output=True),
 ])
 @pytest.mark.parametrize("simi", [1, 2, 3])
 def test_model_v1_literal_vs_fused(flags, simi):
-    """model.py's soft-attention baselines (model.py:831-983): the literal restatement (tile / concat / linear as written,
+    """model.py's soft-attention baselines (model.py:831-1013): the literal restatement (tile / concat / linear as written,
     NumPy fp64) against the fused one (bilinear logits, torch fp64) on ragged inputs"""
     from fvta_memexqa_amd.synth import make_params_v1
     spec = SynthSpec(N=3, A=2, P=2, S=1, L=4, d=6, SA=2, dense=False, simiMatrix=simi, text_in=5, img_in=4)
     inputs = to_dtype(make_inputs(spec), torch.float64)
-    params = to_dtype(make_params_v1(spec, inputs, use_eu_output=bool(flags.get("use_eu_output"))), torch.float64)
-    cfg = dict(spec.cfg(), add_tanh=False, **flags)
+    params = to_dtype(make_params_v1(spec, inputs, use_eu_output=bool(flags.get("use_eu_output")),
+                                     concat=bool(flags.get("concat"))), torch.float64)
+    cfg = {**spec.cfg(), "use_question_att": False, "add_tanh": False, **flags}
     a = F.model_v1_forward(params, inputs, cfg)
     b = L.model_v1_forward(to_numpy(params), to_numpy(inputs), cfg)
     for k in ("g1", "g1_all", "gq", "gchoices", "logits", "yp", "loss"):
         np.testing.assert_allclose(a[k].detach().numpy(), b[k], rtol=1e-9, atol=1e-11, err_msg=k)
+
+
+def test_model_v1_rejected_flag_sets():
+    """combinations the reference's graph construction cannot build (shape mismatches / an undefined name)"""
+    from fvta_memexqa_amd.synth import make_params_v1
+    spec = SynthSpec(N=2, A=1, P=2, S=1, L=3, d=4, SA=1, dense=False, text_in=5, img_in=4)
+    inputs = to_dtype(make_inputs(spec), torch.float64)
+    params = to_dtype(make_params_v1(spec, inputs), torch.float64)
+    for flags in (dict(use_bidirection=True, use_ml_att=True), dict(concat=True, use_question_att=True),
+                  dict(concat=True, use_direct_links=True)):
+        with pytest.raises(ValueError):
+            F.model_v1_forward(params, inputs, {**spec.cfg(), "use_question_att": False, "add_tanh": False, **flags})
