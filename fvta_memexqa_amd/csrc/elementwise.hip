@@ -76,9 +76,14 @@ __global__ void exp_mask_kernel(const float* __restrict__ val, const uint8_t* __
 
 // linear: y[M, out] = x[M, in] * W[in, out] + b (+ tanh).  64 x 64 output tile, 16-deep k slices through LDS,
 // fp32 FMA in k order (bit-stable).  Not a hot kernel: every linear of the model is fused into its consumer.
+// x rows may live in blocks: row m starts at (m / rpb) * bstride + (m % rpb) * in  (rpb = M, bstride = 0: dense) -- one
+// stream's rows inside the model.py graph's [N][all streams] arena.
+__device__ __forceinline__ int64_t blk_row(int64_t m, int64_t rpb, int64_t bstride, int ld) {
+  return (m / rpb) * bstride + (m % rpb) * ld;
+}
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                      const float* __restrict__ b, float* __restrict__ y, int64_t M, int in,
-                                                     int out, int add_tanh) {
+                                                     int out, int add_tanh, int64_t rpb, int64_t bstride) {
   __shared__ float sx[64][17], sw[16][65];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 x 4 outputs each
   const int64_t m0 = (int64_t)blockIdx.x * 64;
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
   for (int k0 = 0; k0 < in; k0 += 16) {
     for (int i = threadIdx.x; i < 64 * 16; i += 256) {
       const int r = i >> 4, c = i & 15;
-      sx[r][c] = (m0 + r < M && k0 + c < in) ? x[(m0 + r) * in + k0 + c] : 0.f;
+      sx[r][c] = (m0 + r < M && k0 + c < in) ? x[blk_row(m0 + r, rpb, bstride, in) + k0 + c] : 0.f;
     }
     for (int i = threadIdx.x; i < 16 * 64; i += 256) {
       const int r = i >> 6, c = i & 63;
@@ -125,7 +130,8 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 // Same 64 x 64 tiling as the forward (W read transposed).
 __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ W, const float* __restrict__ y,
                                                             const float* __restrict__ dy, float* __restrict__ dx, int64_t M,
-                                                            int in, int out, int add_tanh, int accumulate) {
+                                                            int in, int out, int add_tanh, int accumulate, int64_t rpb,
+                                                            int64_t bstride) {
   __shared__ float sd[64][17], sw[16][65];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int64_t m0 = (int64_t)blockIdx.x * 64;
@@ -169,7 +175,10 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restr
     for (int j = 0; j < 4; ++j) {
       const int64_t m = m0 + ty * 4 + i;
       const int n = n0 + tx * 4 + j;
-      if (m < M && n < in) dx[m * in + n] = accumulate ? dx[m * in + n] + acc[i][j] : acc[i][j];
+      if (m < M && n < in) {
+        float* o = dx + blk_row(m, rpb, bstride, in) + n;
+        *o = accumulate ? *o + acc[i][j] : acc[i][j];
+      }
     }
 }
 
@@ -177,7 +186,8 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restr
 // walks all M rows in order (fixed summation order); the workgroups of the first row of tiles also fold db.
 __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                             const float* __restrict__ dy, float* __restrict__ dW,
-                                                            float* __restrict__ db, int64_t M, int in, int out, int add_tanh) {
+                                                            float* __restrict__ db, int64_t M, int in, int out, int add_tanh,
+                                                            int64_t rpb, int64_t bstride) {
   __shared__ float sx[16][65], sd[16][65];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int i0 = blockIdx.x * 64, o0 = blockIdx.y * 64;
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restr
   for (int64_t m0 = 0; m0 < M; m0 += 16) {
     for (int i = threadIdx.x; i < 16 * 64; i += 256) {
       const int r = i >> 6, c = i & 63;
-      sx[r][c] = (m0 + r < M && i0 + c < in) ? x[(m0 + r) * in + i0 + c] : 0.f;
+      sx[r][c] = (m0 + r < M && i0 + c < in) ? x[blk_row(m0 + r, rpb, bstride, in) + i0 + c] : 0.f;
       float v = 0.f;
       if (m0 + r < M && o0 + c < out) {
         v = dy[(m0 + r) * out + o0 + c];
@@ -228,15 +238,47 @@ __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restr
 // weighted sum without a softmax: out[r, :] = sum_j weights[r, j] * target[r, j, :]  (attention_tgif, model.py:236-238:
 // the weights there are softmax(score) with exp_mask applied AFTERWARDS).  grid rows, 256 threads
 __global__ __launch_bounds__(256) void wsum_kernel(const float* __restrict__ target, const float* __restrict__ weights,
-                                                   float* __restrict__ out, int J, int d) {
+                                                   float* __restrict__ out, int J, int d, int64_t t_ld) {
   const int64_t r = blockIdx.x;
-  const float* tr = target + r * (int64_t)J * d;
+  const float* tr = target + r * t_ld;
   const float* wr = weights + r * J;
   for (int c = threadIdx.x; c < d; c += 256) {
     float acc = 0.f;
     for (int j = 0; j < J; ++j) acc += wr[j] * tr[(int64_t)j * d + c];
     out[r * d + c] = acc;
   }
+}
+// backward of wsum: d_weights[r, j] = target[r, j, :] . d_out[r, :] (overwritten), d_target[r, j, :] += weights[r, j] d_out[r, :].
+// grid (rows, ceil(J / 4)): a wave per j
+__global__ __launch_bounds__(256) void wsum_bwd_kernel(const float* __restrict__ target, const float* __restrict__ weights,
+                                                       const float* __restrict__ d_out, float* __restrict__ d_weights,
+                                                       float* __restrict__ d_target, int J, int d, int64_t t_ld) {
+  const int64_t r = blockIdx.x;
+  const int j = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= J) return;
+  const float* tr = target + r * t_ld + (int64_t)j * d;
+  float* dt = d_target ? d_target + r * t_ld + (int64_t)j * d : nullptr;
+  const float* g = d_out + r * d;
+  const float wv = weights[r * J + j];
+  float acc = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float gc = g[c];
+    acc += tr[c] * gc;
+    if (dt) dt[c] += wv * gc;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0 && d_weights) d_weights[r * J + j] = acc;
+}
+// backward of softmax over the last axis: dx = p (dp - sum_j p dp).  One wave per row.  grid ceil(rows/4)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                          float* __restrict__ dx, int64_t rows, int J) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  float dot = 0.f;
+  for (int j = lane; j < J; j += 64) dot += p[r * J + j] * dp[r * J + j];
+  dot = wave_sum(dot);
+  for (int j = lane; j < J; j += 64) dx[r * J + j] = p[r * J + j] * (dp[r * J + j] - dot);
 }
 // DMN+ episode attention features (model_dmnplus.py:93-98): out[n,f,:] = [fact*q, fact*m, |fact-q|, |fact-m|].
 // grid N*F, 256 threads
@@ -282,21 +324,28 @@ __global__ __launch_bounds__(256) void rows_broadcast_kernel(const float* __rest
 }
 }  // namespace fvta
 
-extern "C" int fvta_linear_bwd(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW,
-                               float* db, int64_t M, int32_t in, int32_t out, int32_t add_tanh, int32_t accumulate_dx,
-                               fvta_stream_t stream) {
+extern "C" int fvta_linear_bwd_blk(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW,
+                                   float* db, int64_t M, int32_t in, int32_t out, int32_t add_tanh, int32_t accumulate_dx,
+                                   int64_t rows_per_blk, int64_t blk_stride, fvta_stream_t stream) {
   FVTA_CHECK_ARG(W && dy && M > 0 && in > 0 && out > 0 && (!add_tanh || y), "linear_bwd: bad arguments");
   FVTA_CHECK_ARG((dW == nullptr) || x, "linear_bwd: dW wants x");
+  FVTA_CHECK_ARG(rows_per_blk > 0 && (rows_per_blk >= M || blk_stride >= rows_per_blk * in), "linear_bwd: bad row blocks");
   if (dx) {
     hipLaunchKernelGGL(fvta::linear_bwd_dx_kernel, dim3((unsigned)((M + 63) / 64), (unsigned)((in + 63) / 64)), dim3(256), 0,
-                       (hipStream_t)stream, W, y, dy, dx, M, in, out, add_tanh, accumulate_dx);
+                       (hipStream_t)stream, W, y, dy, dx, M, in, out, add_tanh, accumulate_dx, rows_per_blk, blk_stride);
   }
   if (dW) {
     hipLaunchKernelGGL(fvta::linear_bwd_dw_kernel, dim3((unsigned)((in + 63) / 64), (unsigned)((out + 63) / 64)), dim3(256), 0,
-                       (hipStream_t)stream, x, y, dy, dW, db, M, in, out, add_tanh);
+                       (hipStream_t)stream, x, y, dy, dW, db, M, in, out, add_tanh, rows_per_blk, blk_stride);
   }
   FVTA_CHECK_LAUNCH("linear_bwd");
   return FVTA_OK;
+}
+
+extern "C" int fvta_linear_bwd(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW,
+                               float* db, int64_t M, int32_t in, int32_t out, int32_t add_tanh, int32_t accumulate_dx,
+                               fvta_stream_t stream) {
+  return fvta_linear_bwd_blk(x, W, y, dy, dx, dW, db, M, in, out, add_tanh, accumulate_dx, M, 0, stream);
 }
 
 extern "C" int fvta_rows_reduce(const float* x, float* out, int64_t rows, int32_t J, int32_t d, int64_t out_ld, float scale,
@@ -326,11 +375,36 @@ extern "C" int fvta_dmn_features(const float* facts, const float* q, const float
   return FVTA_OK;
 }
 
+extern "C" int fvta_wsum_fwd_ld(const float* target, const float* weights, float* out, int64_t rows, int32_t J, int32_t d,
+                                int64_t target_ld, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(target && weights && out && rows > 0 && rows < (1ll << 31) && J > 0 && d > 0 && target_ld >= (int64_t)J * d,
+                 "wsum_fwd: bad arguments");
+  hipLaunchKernelGGL(fvta::wsum_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, target, weights, out, J, d,
+                     target_ld);
+  FVTA_CHECK_LAUNCH("wsum");
+  return FVTA_OK;
+}
+
 extern "C" int fvta_wsum_fwd(const float* target, const float* weights, float* out, int64_t rows, int32_t J, int32_t d,
                              fvta_stream_t stream) {
-  FVTA_CHECK_ARG(target && weights && out && rows > 0 && rows < (1ll << 31) && J > 0 && d > 0, "wsum_fwd: bad arguments");
-  hipLaunchKernelGGL(fvta::wsum_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, target, weights, out, J, d);
-  FVTA_CHECK_LAUNCH("wsum");
+  return fvta_wsum_fwd_ld(target, weights, out, rows, J, d, (int64_t)J * d, stream);
+}
+
+extern "C" int fvta_wsum_bwd(const float* target, const float* weights, const float* d_out, float* d_weights, float* d_target,
+                             int64_t rows, int32_t J, int32_t d, int64_t target_ld, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(target && weights && d_out && rows > 0 && rows < (1ll << 31) && J > 0 && d > 0 && target_ld >= (int64_t)J * d,
+                 "wsum_bwd: bad arguments");
+  hipLaunchKernelGGL(fvta::wsum_bwd_kernel, dim3((unsigned)rows, (unsigned)((J + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     target, weights, d_out, d_weights, d_target, J, d, target_ld);
+  FVTA_CHECK_LAUNCH("wsum_bwd");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_softmax_bwd(const float* p, const float* dp, float* dx, int64_t rows, int32_t J, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(p && dp && dx && rows > 0 && J > 0, "softmax_bwd: bad arguments");
+  hipLaunchKernelGGL(fvta::softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, dp, dx,
+                     rows, J);
+  FVTA_CHECK_LAUNCH("softmax_bwd");
   return FVTA_OK;
 }
 
@@ -360,11 +434,18 @@ extern "C" int fvta_exp_mask(const float* val, const uint8_t* mask, float* out, 
   return FVTA_OK;
 }
 
-extern "C" int fvta_linear_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int32_t in,
-                               int32_t out, int32_t add_tanh, fvta_stream_t stream) {
+extern "C" int fvta_linear_fwd_blk(const float* x, const float* W, const float* b, float* y, int64_t M, int32_t in,
+                                   int32_t out, int32_t add_tanh, int64_t rows_per_blk, int64_t blk_stride,
+                                   fvta_stream_t stream) {
   FVTA_CHECK_ARG(x && W && y && M > 0 && in > 0 && out > 0, "linear_fwd: bad arguments");
+  FVTA_CHECK_ARG(rows_per_blk > 0 && (rows_per_blk >= M || blk_stride >= rows_per_blk * in), "linear_fwd: bad row blocks");
   hipLaunchKernelGGL(fvta::linear_kernel, dim3((unsigned)((M + 63) / 64), (unsigned)((out + 63) / 64)), dim3(256), 0,
-                     (hipStream_t)stream, x, W, b, y, M, in, out, add_tanh);
+                     (hipStream_t)stream, x, W, b, y, M, in, out, add_tanh, rows_per_blk, blk_stride);
   FVTA_CHECK_LAUNCH("linear");
   return FVTA_OK;
+}
+
+extern "C" int fvta_linear_fwd(const float* x, const float* W, const float* b, float* y, int64_t M, int32_t in,
+                               int32_t out, int32_t add_tanh, fvta_stream_t stream) {
+  return fvta_linear_fwd_blk(x, W, b, y, M, in, out, add_tanh, M, 0, stream);
 }

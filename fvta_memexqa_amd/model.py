@@ -26,7 +26,10 @@ the K per-stream vectors side by side instead of attended / averaged, choices an
 linears.  Flag sets the reference's own graph construction rejects raise ValueError here (use_bidirection + use_ml_att:
 tf.stack of [N,4d] and [N,2d]; concat + use_question_att: `g1` undefined; concat + use_direct_links: [N,2d] + [N,12d]).
 
-Not built (raises at construction): use_tgif_ml_att (its forward op is functional.attention_tgif).
+use_tgif_ml_att (:851-866, attention_tgif :210-245 per stream): two linears into an mlp_dim = d space, a third down to a
+score, softmax over the stream's rows, exp_mask applied to the PROBABILITIES (as written, :234), weighted sum,
+tanh(linear) + lq -- composed from fvta_linear_fwd/bwd (over the stream's rows in place: the _blk forms), fvta_softmax_fwd/bwd,
+fvta_exp_mask, fvta_wsum_fwd/bwd.
 """
 from types import SimpleNamespace
 
@@ -60,11 +63,9 @@ class Model(model_v2.Model):
     N_SQ = {"g1": "attention/bidrection_squash/%s", "mm": "attention/multi_modal_attention/bidrection_squash/%s",
             "catt": "choices_emb/bidrection_squash/%s", "qatt": "question_emb/bidrection_squash/%s"}
     N_CC = {"ch": "output/gchoice_trans_concat/%s", "q": "output/gq_trans_concat/%s"}
+    N_TG = "attention/multi_layer_attention/%s/%s/%s"          # stream, one of mlp_q / mlp_h / preatt / final, W / b
 
     def __init__(self, config, scope="model", text_in=None, img_in=None, device=None):
-        for flag, what in (("use_tgif_ml_att", "attention_tgif per stream (model.py:851-866)"),):
-            if _cfg(config, flag, False):
-                raise NotImplementedError("model.py --%s is not built: %s" % (flag, what))
         self.bi = bool(_cfg(config, "use_bidirection", False))
         self.concat = bool(_cfg(config, "concat", False))
         if self.bi and _cfg(config, "use_ml_att", False):
@@ -76,6 +77,7 @@ class Model(model_v2.Model):
         if int(_cfg(config, "simiMatrix", 1)) not in (1, 2, 3):
             raise ValueError("similarity matrix not implemented")            # model.py:152-154 (sys.exit there)
         self.use_ml_att = bool(_cfg(config, "use_ml_att", False))
+        self.use_tgif = bool(_cfg(config, "use_tgif_ml_att", False)) and not self.use_ml_att     # :834 / :851 if / elif
         self.use_mm_att = bool(_cfg(config, "use_mm_att", False)) and not self.concat     # (:888-909: concat skips it)
         self.use_direct_links = bool(_cfg(config, "use_direct_links", False))
         self.direct_links_only = self.use_direct_links and bool(_cfg(config, "direct_links_only", False))
@@ -107,6 +109,12 @@ class Model(model_v2.Model):
         if self.use_ml_att:
             for k, (name, _, _) in enumerate(self.streams):
                 specs[self.N_ML_W % name], specs[self.N_ML_B % name] = (feat[self._simi_of(k)],), (1,)
+        if self.use_tgif:
+            dp = self.dp
+            for name, _, _ in self.streams:
+                for lin, shp in (("mlp_q", (wp, dp)), ("mlp_h", (wp, dp)), ("preatt", (dp,)), ("final", (wp, wp))):
+                    specs[self.N_TG % (name, lin, "W")] = shp
+                    specs[self.N_TG % (name, lin, "b")] = (shp[1],) if len(shp) == 2 else (1,)
         if self.use_mm_att:
             specs[self.N_MM_W], specs[self.N_MM_B] = (F,), (1,)
         if self.use_direct_links:
@@ -132,10 +140,10 @@ class Model(model_v2.Model):
         return len(self.streams) * self.wp if self.concat else self.wp
 
     def _is_w2d(self, name):
-        return name.endswith(("bidrection_squash/W", "_trans_concat/W"))
+        return name.endswith(("bidrection_squash/W", "_trans_concat/W", "/mlp_q/W", "/mlp_h/W", "/final/W"))
 
     def _is_bfeat(self, name):
-        return name.endswith(("bidrection_squash/b", "_trans_concat/b"))
+        return name.endswith(("bidrection_squash/b", "_trans_concat/b", "/mlp_q/b", "/mlp_h/b", "/final/b"))
 
     def wd_multipliers(self):
         """model.py's add_wd sites (:320-327): the reader scope (:802), every attention / attention_keeprank1 call's own
@@ -159,6 +167,9 @@ class Model(model_v2.Model):
             m["ml%d_W" % k], m["ml%d_b" % k] = self.N_ML_W % name, self.N_ML_B % name
         m.update(mm_W=self.N_MM_W, mm_b=self.N_MM_B, full_W=self.N_FULL_W, full_b=self.N_FULL_B, catt_W=self.N_CATT_W,
                  catt_b=self.N_CATT_B)
+        for k, (name, _, _) in enumerate(self.streams):
+            for key, lin in (("q", "mlp_q"), ("h", "mlp_h"), ("p", "preatt"), ("f", "final")):
+                m["tg%d_%s_W" % (k, key)], m["tg%d_%s_b" % (k, key)] = self.N_TG % (name, lin, "W"), self.N_TG % (name, lin, "b")
         for key, name in self.N_SQ.items():
             m["sq_%s_W" % key], m["sq_%s_b" % key] = name % "W", name % "b"
         for key, name in self.N_CC.items():
@@ -217,6 +228,13 @@ class Model(model_v2.Model):
         L.masked = [_stream_masked(cell, dims) for cell, _, dims in L.ctx_slots]
         if self.use_ml_att:
             L.ml = [att(N, L.Vk[k], JQ, self._simi_of(k), L.V * wp) for k in range(K)]
+        elif self.use_tgif:
+            dp = self.dp
+            L.d_lq = z(N, wp)
+            L.tg = [SimpleNamespace(q_in=z(N, dp), pre=z(N, L.Vk[k], dp), score=z(N, L.Vk[k]), p=z(N, L.Vk[k]), att=z(N, L.Vk[k]),
+                                    attended=z(N, wp), fin=z(N, wp), d_attended=z(N, wp), d_att=z(N, L.Vk[k]),
+                                    d_score=z(N, L.Vk[k]), d_pre=z(N, L.Vk[k], dp) if training else None, d_q_in=z(N, dp))
+                    for k in range(K)]
         else:
             L.cnt = [L.groups[cell].segs[si]["count"] // N for cell, si, _ in L.ctx_slots]    # sequences per example
             L.last = [z(N * c, wp) for c in L.cnt]
@@ -296,8 +314,12 @@ class Model(model_v2.Model):
         T = L.groups["text"]
         ml_logits = []
         stack = L.g1s_raw if (self.bi and not self.concat) else L.g1s
+        if self.use_tgif or not self.use_question_att:
+            T.op.last_state(L.arena, T.segs[0]["s0"], T.segs[0]["count"], L.lq)      # lq :663
         for k, (cell, si, dims) in enumerate(L.ctx_slots):
-            if self.use_ml_att:                                                 # :834-850
+            if self.use_tgif:                                                   # :851-866, attention_tgif :210-245
+                self._tgif_fwd(L, k, stack)
+            elif self.use_ml_att:                                               # :834-850
                 name = self.streams[k][0]
                 hm, qm = (self._stream_mask(L, k), L.q_mask) if L.masked[k] else (None, None)
                 g, lg = L.ml[k].forward(self._stream_ptr(L, k), L.hq, hm, qm, self._pv(self.N_ML_W % name),
@@ -336,8 +358,7 @@ class Model(model_v2.Model):
         if self.use_question_att:                                               # :977-980 (hq_mask None: no mask)
             L.gq, q_lg = self._att_fwd(L, "qatt", L.qatt, L.hq, L.g1s, None, None, self.N_QATT_W, self.N_QATT_B, want_logits)
         else:
-            T.op.last_state(L.arena, T.segs[0]["s0"], T.segs[0]["count"], L.lq)      # lq :982
-            L.gq = L.lq
+            L.gq = L.lq                                                         # :982
         if self.concat:                                                         # :987-991: lift both to the concat width
             Kw = K * wp
             L.gch_in, L.gq_in = gch, L.gq
@@ -393,9 +414,13 @@ class Model(model_v2.Model):
             sW, sb = self.N_SQ["g1"] % "W", self.N_SQ["g1"] % "b"
             ops.linear_bwd(L.g1s_raw, self._pv(sW), None, L.d_g1s, L.d_g1s_raw, g(sW), g(sb), N * K, wp, wp)
             dstack = L.d_g1s_raw
+        if self.use_tgif:
+            L.d_lq.zero_()
         for k, (cell, si, dims) in enumerate(L.ctx_slots):
             ops.rows_broadcast(dstack.view(-1)[k * wp:], L.dg_k, N, 1, wp, K * wp)          # d g1[:, k, :], dense
-            if self.use_ml_att:
+            if self.use_tgif:
+                self._tgif_bwd(L, k)
+            elif self.use_ml_att:
                 name = self.streams[k][0]
                 hm, qm = (self._stream_mask(L, k), L.q_mask) if L.masked[k] else (None, None)
                 L.ml[k].backward(self._stream_ptr(L, k), L.hq, hm, qm, self._pv(self.N_ML_W % name),
@@ -405,3 +430,40 @@ class Model(model_v2.Model):
                 G, seg = L.groups[cell], L.groups[cell].segs[si]
                 ops.rows_broadcast(L.dg_k, L.d_last[k], N, L.cnt[k], wp, scale=1.0 / L.cnt[k])
                 G.op.last_state_bwd(L.d_last[k], seg["s0"], seg["count"], L.d_arena)
+        if self.use_tgif:                                                       # lq of every stream's mlp_q and "+ lq"
+            T.op.last_state_bwd(L.d_lq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
+
+    # ---------------------------------------------------- attention_tgif (model.py:210-245)
+    def _tg(self, k, lin, which, grad=False):
+        return self._pv(self.N_TG % (self.streams[k][0], lin, which), grad)
+
+    def _tgif_fwd(self, L, k, stack):
+        N, K, wp, dp, Vk = L.N, L.K, self.wp, self.dp, L.Vk[k]
+        st, hk, blk = L.tg[k], self._stream_ptr(L, k), (Vk, L.V * wp)
+        ops.linear_fwd(L.lq, self._tg(k, "mlp_q", "W"), self._tg(k, "mlp_q", "b"), st.q_in, N, wp, dp)                # :225
+        ops.linear_fwd(hk, self._tg(k, "mlp_h", "W"), self._tg(k, "mlp_h", "b"), st.pre, N * Vk, wp, dp, blk=blk)     # :226
+        ops.rows_broadcast(st.q_in, st.pre, N, Vk, dp, accumulate=True)                                               # :227-228
+        ops.linear_fwd(st.pre, self._tg(k, "preatt", "W"), self._tg(k, "preatt", "b"), st.score, N * Vk, dp, 1)        # :229
+        ops.softmax_fwd(st.score, st.p, N, Vk)                                                                        # :231
+        ops.exp_mask(st.p, self._stream_mask(L, k), st.att, N * Vk)                                                   # :233 (on the probabilities)
+        ops.wsum_fwd(hk, st.att, st.attended, N, Vk, wp, target_ld=L.V * wp)                                          # :234-235
+        ops.linear_fwd(st.attended, self._tg(k, "final", "W"), self._tg(k, "final", "b"), st.fin, N, wp, wp, add_tanh=True)
+        ops.rows_reduce(st.fin, stack.view(-1)[k * wp:], N, 1, wp, K * wp)                                            # :236  tanh(.) + lq
+        ops.rows_reduce(L.lq, stack.view(-1)[k * wp:], N, 1, wp, K * wp, accumulate=True)
+
+    def _tgif_bwd(self, L, k):
+        N, wp, dp, Vk = L.N, self.wp, self.dp, L.Vk[k]
+        st, hk, dhk, blk = L.tg[k], self._stream_ptr(L, k), self._stream_ptr(L, k, True), (Vk, L.V * wp)
+        g = lambda lin, which: self._tg(k, lin, which, True)
+        ops.rows_broadcast(L.dg_k, L.d_lq, N, 1, wp, accumulate=True)                                                 # "+ lq"
+        ops.linear_bwd(st.attended, self._tg(k, "final", "W"), st.fin, L.dg_k, st.d_attended, g("final", "W"), g("final", "b"),
+                       N, wp, wp, add_tanh=True)
+        ops.wsum_bwd(hk, st.att, st.d_attended, st.d_att, dhk, N, Vk, wp, target_ld=L.V * wp)
+        ops.softmax_bwd(st.p, st.d_att, st.d_score, N, Vk)                      # (exp_mask adds a constant: d p = d att)
+        ops.linear_bwd(st.pre, self._tg(k, "preatt", "W"), None, st.d_score, st.d_pre, g("preatt", "W"), g("preatt", "b"),
+                       N * Vk, dp, 1)
+        ops.rows_reduce(st.d_pre, st.d_q_in, N, Vk, dp)                         # gradient of the tile of q_in
+        ops.linear_bwd(hk, self._tg(k, "mlp_h", "W"), None, st.d_pre, dhk, g("mlp_h", "W"), g("mlp_h", "b"), N * Vk, wp, dp,
+                       accumulate_dx=True, blk=blk)
+        ops.linear_bwd(L.lq, self._tg(k, "mlp_q", "W"), None, st.d_q_in, L.d_lq, g("mlp_q", "W"), g("mlp_q", "b"), N, wp, dp,
+                       accumulate_dx=True)

@@ -195,16 +195,40 @@ class FocalAttention:
               "fvta_attn_bwd")
 
 
-def linear_fwd(x, W, b, y, M, din, dout, add_tanh=False):
-    """y [M,dout] = x [M,din] W [din,dout] + b (+ tanh)  (fvta_linear_fwd)"""
-    check(_lib.load().fvta_linear_fwd(ptr(x), ptr(W), ptr(b), ptr(y), M, din, dout, int(add_tanh), stream_ptr()),
+def linear_fwd(x, W, b, y, M, din, dout, add_tanh=False, blk=None):
+    """y [M,dout] = x [M,din] W [din,dout] + b (+ tanh); blk = (rows_per_blk, blk_stride): x rows in blocks"""
+    rpb, bs = blk if blk else (M, 0)
+    check(_lib.load().fvta_linear_fwd_blk(ptr(x), ptr(W), ptr(b), ptr(y), M, din, dout, int(add_tanh), rpb, bs, stream_ptr()),
           "fvta_linear_fwd")
 
 
-def linear_bwd(x, W, y, dy, dx, dW, db, M, din, dout, add_tanh=False, accumulate_dx=False):
+def linear_bwd(x, W, y, dy, dx, dW, db, M, din, dout, add_tanh=False, accumulate_dx=False, blk=None):
     """dx = dyt W^T (overwritten / added to), dW += x^T dyt, db += sum dyt; dyt = dy (1 - y^2) under add_tanh"""
-    check(_lib.load().fvta_linear_bwd(ptr(x), ptr(W), ptr(y), ptr(dy), ptr(dx), ptr(dW), ptr(db), M, din, dout,
-                                      int(add_tanh), int(accumulate_dx), stream_ptr()), "fvta_linear_bwd")
+    rpb, bs = blk if blk else (M, 0)
+    check(_lib.load().fvta_linear_bwd_blk(ptr(x), ptr(W), ptr(y), ptr(dy), ptr(dx), ptr(dW), ptr(db), M, din, dout,
+                                          int(add_tanh), int(accumulate_dx), rpb, bs, stream_ptr()), "fvta_linear_bwd")
+
+
+def softmax_fwd(x, p, rows, J):
+    check(_lib.load().fvta_softmax_fwd(ptr(x), ptr(p), rows, J, stream_ptr()), "fvta_softmax_fwd")
+
+
+def softmax_bwd(p, dp, dx, rows, J):
+    check(_lib.load().fvta_softmax_bwd(ptr(p), ptr(dp), ptr(dx), rows, J, stream_ptr()), "fvta_softmax_bwd")
+
+
+def exp_mask(val, mask, out, n):
+    check(_lib.load().fvta_exp_mask(ptr(val), ptr(mask), ptr(out), n, stream_ptr()), "fvta_exp_mask")
+
+
+def wsum_fwd(target, weights, out, rows, J, d, target_ld=None):
+    check(_lib.load().fvta_wsum_fwd_ld(ptr(target), ptr(weights), ptr(out), rows, J, d, J * d if target_ld is None else target_ld,
+                                       stream_ptr()), "fvta_wsum_fwd")
+
+
+def wsum_bwd(target, weights, d_out, d_weights, d_target, rows, J, d, target_ld=None):
+    check(_lib.load().fvta_wsum_bwd(ptr(target), ptr(weights), ptr(d_out), ptr(d_weights), ptr(d_target), rows, J, d,
+                                    J * d if target_ld is None else target_ld, stream_ptr()), "fvta_wsum_bwd")
 
 
 def attn_qside_fwd(a_logits, hq, q_a, R, V, JQ, w):

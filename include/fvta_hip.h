@@ -337,9 +337,25 @@ int fvta_linear_fwd(const float* x, const float* W, const float* b, float* y, in
  * dW [in,out] += x^T dyt, db [out] += sum_m dyt.  dx, dW (with db) may each be NULL. */
 int fvta_linear_bwd(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW, float* db,
                     int64_t M, int32_t in, int32_t out, int32_t add_tanh, int32_t accumulate_dx, fvta_stream_t stream);
+/* The same two with x (and dx) rows in blocks: row m starts at (m / rows_per_blk) * blk_stride + (m % rows_per_blk) * in
+ * floats -- one context stream's rows inside the model.py graph's [N][all streams] arena (attention_tgif's mlp_h over a
+ * stream, model.py:226).  y / dy stay dense [M,out]. */
+int fvta_linear_fwd_blk(const float* x, const float* W, const float* b, float* y, int64_t M, int32_t in, int32_t out,
+                        int32_t add_tanh, int64_t rows_per_blk, int64_t blk_stride, fvta_stream_t stream);
+int fvta_linear_bwd_blk(const float* x, const float* W, const float* y, const float* dy, float* dx, float* dW, float* db,
+                        int64_t M, int32_t in, int32_t out, int32_t add_tanh, int32_t accumulate_dx, int64_t rows_per_blk,
+                        int64_t blk_stride, fvta_stream_t stream);
+/* Backward of fvta_softmax_fwd: dx = p (dp - sum_j p dp), p = the forward output. */
+int fvta_softmax_bwd(const float* p, const float* dp, float* dx, int64_t rows, int32_t J, fvta_stream_t stream);
 /* sum_j weights[r,j] * target[r,j,:] -> out[r,:] (no softmax): the attended vector of attention_tgif, model.py:236-238 */
 int fvta_wsum_fwd(const float* target, const float* weights, float* out, int64_t rows, int32_t J, int32_t d,
                   fvta_stream_t stream);
+/* ... with the rows' [J,d] blocks target_ld floats apart, and its backward: d_weights [rows,J] = target . d_out
+ * (overwritten; may be NULL), d_target += weights (x) d_out (same layout as target; may be NULL). */
+int fvta_wsum_fwd_ld(const float* target, const float* weights, float* out, int64_t rows, int32_t J, int32_t d,
+                     int64_t target_ld, fvta_stream_t stream);
+int fvta_wsum_bwd(const float* target, const float* weights, const float* d_out, float* d_weights, float* d_target,
+                  int64_t rows, int32_t J, int32_t d, int64_t target_ld, fvta_stream_t stream);
 /* The feature vector of the DMN+ episode attention, model_dmnplus.py:93-98 (`_get_attention`), for all facts at once:
  * out[n,f,:] = [fact*q, fact*m, |fact-q|, |fact-m|]  (facts [N,F,d], q / m [N,d] -> out [N,F,4d]).  The two
  * fully_connected layers on top of it are fvta_linear_fwd, the softmax over facts fvta_softmax_fwd, the gated recurrence

@@ -84,6 +84,10 @@ ALL = dict(use_ml_att=True, use_mm_att=True, use_direct_links=True, use_choices_
     dict(use_bidirection=True, use_choices_att=True),
     dict(use_bidirection=True, use_question_att=True),
     dict(use_bidirection=True, use_mm_att=True, use_direct_links=True, use_choices_att=True, use_question_att=True),
+    dict(use_tgif_ml_att=True),
+    dict(use_tgif_ml_att=True, use_mm_att=True, use_direct_links=True, use_question_att=True),
+    dict(use_tgif_ml_att=True, use_bidirection=True, use_mm_att=True),
+    dict(use_tgif_ml_att=True, concat=True),
     dict(concat=True),
     dict(concat=True, use_ml_att=True, use_choices_att=True, use_eu_output=True),
     dict(concat=True, use_bidirection=True, use_choices_att=True),
@@ -135,8 +139,6 @@ def test_v1_model_six_streams_padded_hidden_and_wd():
 
 def test_v1_model_unbuilt_switches_raise():
     from fvta_memexqa_amd.model import Model
-    with pytest.raises(NotImplementedError):
-        Model({"use_tgif_ml_att": True, "hidden_size": 32})
     # flag sets the reference's own graph construction rejects (shape mismatches / an undefined name)
     for flags in (dict(use_bidirection=True, use_ml_att=True), dict(concat=True, use_question_att=True),
                   dict(concat=True, use_direct_links=True)):

@@ -152,3 +152,50 @@ def test_bidirect_attention_forward_backward(simi, masked):
     torch.testing.assert_close(d_q.cpu().double(), qr.grad, rtol=2e-4, atol=2e-5)
     torch.testing.assert_close(dW.cpu().double(), Wr.grad.reshape(-1), rtol=2e-4, atol=2e-5)
     torch.testing.assert_close(db.cpu().double(), br.grad, rtol=2e-4, atol=2e-5)
+
+
+def test_blocked_linear_wsum_softmax_backward():
+    """the _blk / _ld forms on one stream of an [N][all streams] arena, and fvta_softmax_bwd / fvta_wsum_bwd, vs autograd"""
+    from fvta_memexqa_amd import ops
+    dev = ops.require_gpu()
+    g = torch.Generator().manual_seed(4)
+    N, V, off, Vtot, w, dout = 3, 11, 5, 23, 48, 20
+    arena = torch.randn(N, Vtot, w, generator=g).to(dev)
+    W = (torch.randn(w, dout, generator=g) * 0.2).to(dev)
+    b = torch.randn(dout, generator=g).to(dev)
+    xs = arena[:, off:off + V]
+    y = torch.empty(N * V, dout, device=dev)
+    ops.linear_fwd(arena.view(-1)[off * w:], W, b, y, N * V, w, dout, blk=(V, Vtot * w))
+    torch.testing.assert_close(y.view(N, V, dout), xs @ W + b, rtol=1e-5, atol=1e-5)
+    dy = torch.randn(N * V, dout, generator=g).to(dev)
+    d_arena = torch.ones(N, Vtot, w, device=dev)
+    dW, db = torch.zeros(w, dout, device=dev), torch.zeros(dout, device=dev)
+    ops.linear_bwd(arena.view(-1)[off * w:], W, None, dy, d_arena.view(-1)[off * w:], dW, db, N * V, w, dout, accumulate_dx=True,
+                   blk=(V, Vtot * w))
+    want = torch.ones(N, Vtot, w, device=dev)
+    want[:, off:off + V] += (dy @ W.t()).view(N, V, w)
+    torch.testing.assert_close(d_arena, want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dW, xs.reshape(-1, w).t() @ dy, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db, dy.sum(0), rtol=1e-5, atol=1e-5)
+    # softmax backward
+    x = torch.randn(N, V, generator=g).to(dev)
+    p = torch.empty_like(x)
+    ops.softmax_fwd(x, p, N, V)
+    dp = torch.randn(N, V, generator=g).to(dev)
+    dx = torch.empty_like(x)
+    ops.softmax_bwd(p, dp, dx, N, V)
+    xr = x.double().cpu().requires_grad_()
+    torch.softmax(xr, -1).backward(dp.double().cpu())
+    torch.testing.assert_close(dx.cpu().double(), xr.grad, rtol=1e-5, atol=1e-6)
+    # weighted sum over the stream's rows and its backward
+    out = torch.empty(N, w, device=dev)
+    ops.wsum_fwd(arena.view(-1)[off * w:], p, out, N, V, w, target_ld=Vtot * w)
+    torch.testing.assert_close(out, (xs * p[..., None]).sum(1), rtol=1e-5, atol=1e-5)
+    go = torch.randn(N, w, generator=g).to(dev)
+    dwt = torch.empty(N, V, device=dev)
+    d_arena = torch.zeros(N, Vtot, w, device=dev)
+    ops.wsum_bwd(arena.view(-1)[off * w:], p, go, dwt, d_arena.view(-1)[off * w:], N, V, w, target_ld=Vtot * w)
+    torch.testing.assert_close(dwt, (xs * go[:, None, :]).sum(-1), rtol=1e-5, atol=1e-5)
+    want = torch.zeros(N, Vtot, w, device=dev)
+    want[:, off:off + V] = p[..., None] * go[:, None, :]
+    torch.testing.assert_close(d_arena, want, rtol=1e-5, atol=1e-6)
