@@ -77,6 +77,10 @@ def parse():
                     help="weak: every rank gets the config's batch (64 QA pairs per GPU; the driver's default run). "
                          "strong: --global-batch QA pairs in total, global/N per rank (north_star's strong-scaling target)")
     ap.add_argument("--global-batch", type=int, default=512, help="--scaling strong: total QA pairs (BASELINE.json configs[3]: 512)")
+    ap.add_argument("--graph", default="fvta", choices=["fvta", "model_py"],
+                    help="fvta: model_v2.py, the FVTA model (BASELINE.json's metric); model_py: model.py's soft-attention "
+                         "baselines with every attention on (use_ml_att, use_mm_att, use_direct_links, use_choices_att, "
+                         "use_question_att) -- a side measurement, same shape and encoders")
     ap.add_argument("--front-end", action="store_true",
                     help="enter with the reference's token-id feed (SURVEY 8f rank 1): the char-CNN / word / photo embedding "
                          "front-end and its gradients are inside the timed step (the headline enters at the encoder inputs)")
@@ -188,7 +192,14 @@ def main():
         from fvta_memexqa_amd.synth import make_token_inputs
         cfg.update(word_vocab_size=400, word_emb_size=100, use_char=True, char_vocab_size=100, max_word_size=16,
                    char_emb_size=args.char_emb_size, char_out_size=100, image_feat_dim=2537, use_image_trans=True, image_trans_dim=100)
-    model = Model(cfg, text_in=spec.text_in, img_in=spec.img_in, device=dev)
+    if args.graph == "model_py":
+        from fvta_memexqa_amd.model import Model as ModelPy
+        probe = make_inputs(SynthSpec(**dict(kw, N=1, P=1, L=2)))
+        cfg.update(add_tanh=False, use_ml_att=True, use_mm_att=True, use_direct_links=True, use_choices_att=True,
+                   use_question_att=True, simiMatrix=1, ctx_streams=ModelPy.streams_of(probe))
+        model = ModelPy(cfg, text_in=spec.text_in, img_in=spec.img_in, device=dev)
+    else:
+        model = Model(cfg, text_in=spec.text_in, img_in=spec.img_in, device=dev)
     trainer = Trainer(model, cfg)
     trainer.need_dx = True   # the real model trains its embeddings: gradients flow into the encoder inputs
     log('model built; generating synthetic inputs')
@@ -310,7 +321,7 @@ def main():
     att_bytes = (valid_rows * model.wp + spec.N * L.JQ * model.wp + spec.N * model.wp) * 4.0
     ms_a, n_a = prof["attn_fwd_main"]
     roof_att = None
-    if n_a:
+    if n_a and args.graph == "fvta":   # (model.py's graph runs seven large 1-D attentions under the same bracket)
         # (the library's profile bracket covers the context attention only, not the K = 1 question attention)
         per_step_ms = ms_a / args.steps
         gbs = att_bytes / (per_step_ms * 1e-3) / 1e9
@@ -333,7 +344,7 @@ def main():
         if r_ is not None and probe_gbs and r_["bound"] == "hbm":
             r_["achievable_peak"] = probe_gbs
             r_["frac_of_achievable"] = round(r_["achieved"] / probe_gbs, 4)
-    dense_metric = args.config == "metric" and args.variant == "dense" and not args.batch
+    dense_metric = args.config == "metric" and args.variant == "dense" and not args.batch and args.graph == "fvta"
     if roof is not None and dense_metric and args.precision == "bf16":
         roof["traffic"] = pmc_traffic("r02_lstm_pmc.json", "lstm_step_fwd_bf16")
         roof["traffic_note"] = "bytes per launch, profiles/r02_lstm_pmc.json; algorithmic per launch = algorithmic_bytes_per_call / 30"
@@ -342,7 +353,8 @@ def main():
         roof_att["traffic_note"] = "bytes per launch, profiles/r02_attention_pmc.json"
     out = dict(
         metric="QA-pairs/sec (fwd+bwd) at B=64, 40 photos x 5 streams x 30 tok, h=512" if args.config == "metric" and not args.forward_only
-        else "QA-pairs/sec (%s, config %s)" % ("fwd" if args.forward_only else "fwd+bwd", args.config),
+        and args.graph == "fvta" else "QA-pairs/sec (model.py graph, %s, config %s)" % ("fwd" if args.forward_only else "fwd+bwd", args.config)
+        if args.graph == "model_py" else "QA-pairs/sec (%s, config %s)" % ("fwd" if args.forward_only else "fwd+bwd", args.config),
         value=round(value, 2), unit="QA-pairs/s", n_gpus=ws, steps=args.steps, warmup=args.warmup,
         ms_per_step=round(elapsed / args.steps * 1e3, 3), ms_per_step_event_median=round(statistics.median(step_ms), 3),
         higher_is_better=True, scaling=args.scaling, vs_baseline=None,
@@ -350,7 +362,9 @@ def main():
         config=dict(workload=("BASELINE.json configs[2] train step (fwd+bwd+%s)" % args.optimizer if not args.forward_only
                               else "BASELINE.json configs[1] forward only") + ", shape '%s', %s lengths" % (args.config, args.variant)
                     + (", token-id entry (embedding front-end inside the step, char_emb_size %d)" % args.char_emb_size
-                       if args.front_end else ""),
+                       if args.front_end else "")
+                    + (" -- model.py's soft-attention baseline graph (multi-layer + multi-modal + direct-link + choices + "
+                       "question attention) instead of the FVTA model" if args.graph == "model_py" else ""),
                     qa_pairs_per_gpu=spec.N, albums=spec.A, photos=spec.P, text_streams=spec.S, tokens=spec.L, hidden=spec.d,
                     global_batch=spec.N * ws, K=L.K, T=L.T, JQ=L.JQ,
                     parallelism="dp%d (QA pairs sharded, flat-gradient all-reduce)" % ws),
@@ -359,7 +373,7 @@ def main():
         kernel_ms_note="HIP-event brackets on the launch streams, over a second pass of the same %d steps right after the "
                        "timed region (the timed region itself carries no brackets)" % args.steps,
     )
-    if ws == 1 and not args.no_cpu_baseline:
+    if ws == 1 and not args.no_cpu_baseline and args.graph == "fvta":
         log('timing the CPU oracle (%d threads of %d host CPUs)' % (args.cpu_threads, host_cores()))
         out["cpu_baseline"] = cpu_baseline(kw, args.cpu_sample, args.forward_only, args.cpu_threads)
     else:
