@@ -72,9 +72,10 @@ class ParamStore:
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=device)
 
-    def view(self, name, grad=False):
+    def view(self, name, grad=False, flat=None):
+        """`flat`: another buffer with this store's layout (an optimiser slot)"""
         off, shape = self.offsets[name], self.specs[name]
-        buf = self.grad if grad else self.flat
+        buf = flat if flat is not None else (self.grad if grad else self.flat)
         return buf[off:off + int(np.prod(shape))].view(*shape)
 
 
@@ -316,9 +317,10 @@ class Model:
         """bias vectors in the feature layout ([C*d] stored [C*dp])"""
         return name == self.N_TW_WH_B
 
-    def set_weights(self, weights):
+    def set_weights(self, weights, flat=None):
         """weights: dict reference-name -> array in the REFERENCE's shapes
-        (main.py:578-588 `weights.npz` layout)."""
+        (main.py:578-588 `weights.npz` layout).  `flat`: write into that buffer (an optimiser slot with the parameter
+        store's layout) instead of the parameters."""
         for name, val in weights.items():
             if name not in self.params.specs:
                 continue
@@ -333,13 +335,13 @@ class Model:
                 t = self._pad_feat2d(t)
             elif name.endswith("/W") or self._is_bfeat(name):
                 t = self._pad_feat(t)
-            self.params.view(name).copy_(t.reshape(self.params.specs[name]).to(self.dev))
+            self.params.view(name, flat=flat).copy_(t.reshape(self.params.specs[name]).to(self.dev))
 
-    def get_weights(self, grad=False):
-        """-> dict reference-name -> numpy array in the reference's shapes."""
+    def get_weights(self, grad=False, flat=None):
+        """-> dict reference-name -> numpy array in the reference's shapes (`flat`: read that buffer instead)."""
         out = {}
         for name in self.params.specs:
-            t = self.params.view(name, grad=grad).detach().cpu()
+            t = self.params.view(name, grad=grad, flat=flat).detach().cpu()
             if name in self._plain:
                 t = t.reshape((1,) + tuple(t.shape)) if name == self.N_CONV_F else t
             elif name.endswith("basic_lstm_cell/kernel"):

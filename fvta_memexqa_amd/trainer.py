@@ -1,4 +1,7 @@
 """Counterpart of the reference's trainer.py (Trainer.__init__ 10-27, step 30-40)."""
+import os
+
+import numpy as np
 import torch
 
 from . import dist, ops
@@ -10,6 +13,8 @@ class AdadeltaOptimizer:
     def __init__(self, learning_rate, rho=0.95, epsilon=1e-8):
         self.lr, self.rho, self.eps = float(learning_rate), rho, epsilon
         self.state = None
+
+    SLOTS = ("Adadelta", "Adadelta_1")      # TF's slot variable names: <var>/Adadelta (accum), <var>/Adadelta_1 (accum_update)
 
     def apply(self, params, grad_scale):
         if self.state is None:
@@ -23,6 +28,8 @@ class AdamOptimizer:
     def __init__(self, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8):
         self.lr, self.b1, self.b2, self.eps = float(learning_rate), beta1, beta2, epsilon
         self.state, self.t = None, 0
+
+    SLOTS = ("Adam", "Adam_1")              # <var>/Adam (m), <var>/Adam_1 (v); beta powers follow from the step count
 
     def apply(self, params, grad_scale):
         if self.state is None:
@@ -64,3 +71,53 @@ class Trainer:
         if dist.is_dist():          # report the global-batch mean, like the single-process reference's loss
             loss = dist.mean_over_ranks(loss.clone())
         return float(loss.item()), None, None
+
+    # ---- checkpoint / resume.  The reference's tf.train.Saver (main.py:296, 430-440) writes every global variable: the
+    # trainables, global_step AND the optimiser's slot variables, so a restored run continues the Adadelta averages.
+    # Here: model.save_weights' weights.npz (main.py:578-588 layout) plus `optimizer.npz` beside it, slots keyed
+    # "<scope>/<variable>/<slot>:0" in the reference's shapes.
+    def save(self, path):
+        m = self.model
+        m.save_weights(path)
+        out = {"optimizer": np.array(type(self.opt).__name__)}
+        if self.opt.state is not None:
+            for slot, flat in zip(self.opt.SLOTS, self.opt.state):
+                for k, v in m.get_weights(flat=flat).items():
+                    out["%s/%s/%s:0" % (m.scope, k, slot)] = v
+        if hasattr(self.opt, "t"):
+            out["step_count"] = np.int64(self.opt.t)
+        np.savez(os.path.join(path, "optimizer.npz"), **out)
+        return path
+
+    def restore(self, path):
+        """weights + global_step (model.load_weights) and, when `optimizer.npz` is there, the optimiser slots"""
+        m = self.model
+        m.load_weights(path)
+        f = os.path.join(path if os.path.isdir(path) else os.path.dirname(path), "optimizer.npz")
+        if not os.path.exists(f):
+            return False
+        with np.load(f) as z:
+            if str(z["optimizer"]) != type(self.opt).__name__:
+                raise ValueError("checkpoint holds %s slots, the trainer runs %s" % (z["optimizer"], type(self.opt).__name__))
+            state = (torch.zeros_like(m.params.flat), torch.zeros_like(m.params.flat))
+            have = False
+            for slot, flat in zip(self.opt.SLOTS, state):
+                got = {}
+                for key in z.files:
+                    if key.endswith("/%s:0" % slot):
+                        name = key[:-len("/%s:0" % slot)]
+                        for known in m.params.specs:
+                            if name == known or name.endswith("/" + known):
+                                got[known] = z[key]
+                                break
+                if got:
+                    missing = [n for n in m.params.specs if n not in got]
+                    if missing:
+                        raise KeyError("optimizer.npz lacks the %s slot of %s" % (slot, ", ".join(missing)))
+                    m.set_weights(got, flat=flat)
+                    have = True
+            if have:
+                self.opt.state = state
+            if "step_count" in z.files and hasattr(self.opt, "t"):
+                self.opt.t = int(z["step_count"])
+        return True

@@ -331,3 +331,34 @@ def test_weights_npz_round_trip(tmp_path):
     d2 = Model(dict(cfg, share_fw_bw=False), scope="x", text_in=12, img_in=8)
     d2.load_weights(str(tmp_path / "w2"))
     assert d2.global_step == 7
+
+
+@pytest.mark.parametrize("optimizer", ["adadelta", "adam"])
+def test_trainer_checkpoint_resume_continues_bitwise(tmp_path, optimizer):
+    """Trainer.save / restore (the reference's Saver writes the optimiser slots too, main.py:296, 430-440): three steps,
+    checkpoint, two more == five uninterrupted steps, bit for bit, hidden size 20 (padded layout <-> reference shapes)"""
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params
+    from fvta_memexqa_amd.trainer import Trainer
+    spec = SynthSpec(N=4, A=1, P=3, S=2, L=5, d=20, dense=False, text_in=12, img_in=8)
+    params, inputs = make_params(spec), make_inputs(spec)
+    cfg = dict(spec.cfg(), batch_size=spec.N, init_lr=0.5 if optimizer == "adadelta" else 1e-3, optimizer=optimizer)
+
+    def fresh():
+        m = Model(cfg, text_in=spec.text_in, img_in=spec.img_in)
+        m.set_oracle_params(params)
+        return m, Trainer(m, cfg)
+    batch = (None, dict(inputs, num_examples=4))
+    m1, t1 = fresh()
+    ref_losses = [t1.step(None, batch)[0] for _ in range(5)]
+    m2, t2 = fresh()
+    losses = [t2.step(None, batch)[0] for _ in range(3)]
+    t2.save(str(tmp_path))
+    m3, t3 = fresh()
+    assert t3.restore(str(tmp_path)) and m3.global_step == 3
+    losses += [t3.step(None, batch)[0] for _ in range(2)]
+    assert losses == ref_losses
+    assert torch.equal(m3.params.flat, m1.params.flat)
+    with pytest.raises(ValueError):
+        other = Trainer(m3, dict(cfg, optimizer="adam" if optimizer == "adadelta" else "adadelta"))
+        other.restore(str(tmp_path))
