@@ -383,27 +383,55 @@ class Model:
             path = os.path.join(path, "weights.npz")
         if not os.path.exists(path):
             raise Exception("Model not exists")                         # main.py:665
+        with np.load(path) as z:
+            arrays = {key: z[key] for key in z.files}
+        self._assign_named(arrays, "weights file %s" % path)
+
+    OPTIMIZER_SLOTS = ("Adadelta", "Adadelta_1", "Adam", "Adam_1")       # tf.train.*Optimizer slot variable suffixes
+
+    def load_tf_checkpoint(self, path):
+        """main.py:640-665 (`saver.restore(sess, ckpt.model_checkpoint_path)`): `path` is the reference's save directory
+        (its `checkpoint` state file names the latest prefix), a checkpoint prefix or its .index file.  Restores every
+        variable of this model by name plus global_step; returns the optimiser's slot variables found in the file,
+        {slot suffix: {variable name: array}} (Trainer.restore_tf_checkpoint puts them back).  The file format is
+        restated in tf_checkpoint.py (unpinned: no TensorFlow here to write a reference file)."""
+        from .tf_checkpoint import read_checkpoint
+        arrays = read_checkpoint(path)
+        slots, model_vars = {}, {}
+        for key, val in arrays.items():
+            base, _, last = key.rpartition("/")
+            if last in self.OPTIMIZER_SLOTS and base:
+                slots.setdefault(last, {})[base] = val
+            elif last in ("beta1_power", "beta2_power"):
+                slots.setdefault(last, {})[""] = val
+            else:
+                model_vars[key] = val
+        self._assign_named(model_vars, "checkpoint %s" % path)
+        return slots
+
+    def _assign_named(self, arrays, what):
+        """{variable name (any "<scope>/" prefix, optional ":0"): array} -> parameters, global_step, the warp window.
+        Strict both ways: a variable this model lacks in `arrays`, or one of `arrays` it has no place for, is an error."""
         known = list(self.params.specs) + [self.N_TW_WINDOW, "global_step"]
         got, unmatched = {}, []
-        with np.load(path) as z:
-            for key in z.files:
-                k = key[:-2] if key.endswith(":0") else key
-                for name in known:
-                    if k == name or k.endswith("/" + name):
-                        got[name] = z[key]
-                        break
-                else:
-                    unmatched.append(key)
+        for key, val in arrays.items():
+            k = key[:-2] if key.endswith(":0") else key
+            for name in known:
+                if k == name or k.endswith("/" + name):
+                    got[name] = val
+                    break
+            else:
+                unmatched.append(key)
         missing = [n for n in self.params.specs if n not in got]
         if missing:
-            raise KeyError("weights file %s lacks %s" % (path, ", ".join(missing)))
+            raise KeyError("%s lacks %s" % (what, ", ".join(missing)))
         # a variable of the FILE that this model has no place for is an error too: silently dropping e.g. the
         # .../bw/basic_lstm_cell/{kernel,bias} of a TF-1.0-style checkpoint into a share_fw_bw=True model would load a
         # different network (switches that legitimately remove variables: share_fw_bw, use_question_att, use_time_warp, ...)
         if unmatched:
             hint = " (the file has separate backward-direction cells: build the model with share_fw_bw=False)" \
                 if any("/bw/basic_lstm_cell/" in k for k in unmatched) and self.share_fw_bw else ""
-            raise KeyError("weights file %s holds variables this model does not have: %s%s" % (path, ", ".join(unmatched), hint))
+            raise KeyError("%s holds variables this model does not have: %s%s" % (what, ", ".join(unmatched), hint))
         if "global_step" in got:
             self.global_step = int(got.pop("global_step"))
         if self.N_TW_WINDOW in got:

@@ -121,3 +121,26 @@ class Trainer:
             if "step_count" in z.files and hasattr(self.opt, "t"):
                 self.opt.t = int(z["step_count"])
         return True
+
+    def restore_tf_checkpoint(self, path):
+        """main.py:640-665: restore a checkpoint the reference's `saver.save` wrote -- the model's variables by name,
+        global_step and, when present, this optimiser's slot variables (the Saver stores them with the trainables)."""
+        m = self.model
+        slots = m.load_tf_checkpoint(path)
+        state = (torch.zeros_like(m.params.flat), torch.zeros_like(m.params.flat))
+        found = 0
+        for slot, flat in zip(self.opt.SLOTS, state):
+            named = {}
+            for key, val in slots.get(slot, {}).items():
+                for known in m.params.specs:
+                    if key == known or key.endswith("/" + known):
+                        named[known] = val
+                        break
+            if len(named) == len(m.params.specs):
+                m.set_weights(named, flat=flat)
+                found += 1
+        if found == len(self.opt.SLOTS):
+            self.opt.state = state
+            if hasattr(self.opt, "t"):
+                self.opt.t = m.global_step           # beta powers = beta ** global_step (one apply per step)
+        return found == len(self.opt.SLOTS)

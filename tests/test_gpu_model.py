@@ -362,3 +362,37 @@ def test_trainer_checkpoint_resume_continues_bitwise(tmp_path, optimizer):
     with pytest.raises(ValueError):
         other = Trainer(m3, dict(cfg, optimizer="adam" if optimizer == "adadelta" else "adadelta"))
         other.restore(str(tmp_path))
+
+
+def test_restore_from_tf_checkpoint_files(tmp_path):
+    """main.py:640-665: a V2 checkpoint under the reference's variable names (model + Adadelta slots + global_step, as its
+    Saver writes them) restores into Model / Trainer and continues like the run that wrote it.  The files come from
+    tf_checkpoint.write_checkpoint (no TensorFlow here: the reader is pinned against our own writer only)."""
+    from fvta_memexqa_amd import tf_checkpoint as tc
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params
+    from fvta_memexqa_amd.trainer import Trainer
+    spec = SynthSpec(N=4, A=1, P=3, S=2, L=5, d=20, dense=False, text_in=12, img_in=8)
+    params, inputs = make_params(spec), make_inputs(spec)
+    cfg = dict(spec.cfg(), batch_size=spec.N, init_lr=0.5)
+    batch = (None, dict(inputs, num_examples=4))
+    m1 = Model(cfg, scope="model_memoryqa", text_in=spec.text_in, img_in=spec.img_in)
+    m1.set_oracle_params(params)
+    t1 = Trainer(m1, cfg)
+    for _ in range(3):
+        t1.step(None, batch)
+    tensors = {"%s/%s" % (m1.scope, k): v for k, v in m1.get_weights().items()}
+    for slot, flat in zip(t1.opt.SLOTS, t1.opt.state):
+        tensors.update({"%s/%s/%s" % (m1.scope, k, slot): v for k, v in m1.get_weights(flat=flat).items()})
+    tensors["%s/global_step" % m1.scope] = np.int64(m1.global_step)
+    tc.write_checkpoint(str(tmp_path / "save" / "model-3"), tensors)
+    m2 = Model(cfg, scope="model_memoryqa", text_in=spec.text_in, img_in=spec.img_in)
+    t2 = Trainer(m2, cfg)
+    assert t2.restore_tf_checkpoint(str(tmp_path / "save")) and m2.global_step == 3
+    assert torch.equal(m2.params.flat, m1.params.flat)
+    assert t1.step(None, batch)[0] == t2.step(None, batch)[0] and torch.equal(m2.params.flat, m1.params.flat)
+    # a model with a variable the checkpoint lacks / without one it holds refuses, like restore-by-name does
+    with pytest.raises(KeyError):
+        Model(dict(cfg, use_time_warp=True), text_in=spec.text_in, img_in=spec.img_in).load_tf_checkpoint(str(tmp_path / "save"))
+    with pytest.raises(KeyError):
+        Model(dict(cfg, use_question_att=False), text_in=spec.text_in, img_in=spec.img_in).load_tf_checkpoint(str(tmp_path / "save"))

@@ -74,3 +74,32 @@ def test_no_reference_sources_in_repo():
             if f.endswith(".py") and f != os.path.basename(__file__):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*import tensorflow", src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_tf_checkpoint_reader_round_trip(tmp_path):
+    """tf_checkpoint.py: the V2 checkpoint layout (LevelDB-style index table + raw data shard) written and read back --
+    many variables (several index blocks, shared key prefixes), scalars, int64; the `checkpoint` state file resolves the
+    prefix like tf.train.get_checkpoint_state (main.py:641-645).  Format restated from TensorFlow's sources: unpinned."""
+    from fvta_memexqa_amd import tf_checkpoint as tc
+    assert tc.crc32c(b"123456789") == 0xE3069283                     # the CRC-32C check value
+    rng = np.random.RandomState(0)
+    tensors = {"model_x/global_step": np.int64(1234)}
+    for i in range(70):
+        tensors["model_x/reader/text/utext/fw/cell_%02d/kernel" % i] = rng.randn(3 + i % 5, 4).astype(np.float32)
+        tensors["model_x/reader/text/utext/fw/cell_%02d/kernel/Adadelta" % i] = rng.randn(3 + i % 5, 4).astype(np.float32)
+    tensors["model_x/output/choicelogits/b"] = np.zeros(1, np.float32)
+    prefix = tc.write_checkpoint(str(tmp_path / "model-1234"), tensors, block_bytes=512)
+    header, entries = tc.read_index(prefix + ".index")
+    assert header[1] == 1 and len(entries) == len(tensors)
+    for src in (str(tmp_path), prefix, prefix + ".index"):
+        got = tc.read_checkpoint(src)
+        assert set(got) == set(tensors)
+        for k, v in tensors.items():
+            assert got[k].dtype == np.asarray(v).dtype and np.array_equal(got[k], v), k
+    assert int(got["model_x/global_step"]) == 1234
+    only = tc.read_checkpoint(prefix, names={"model_x/output/choicelogits/b"})
+    assert list(only) == ["model_x/output/choicelogits/b"]
+    os.makedirs(str(tmp_path / "empty"))
+    for missing in (str(tmp_path / "empty"), str(tmp_path / "model-999")):
+        with pytest.raises(Exception, match="Model not exists"):
+            tc.read_checkpoint(missing)
