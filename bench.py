@@ -173,6 +173,7 @@ def main():
     ws, rank, local = dist.init()
     if ws != args.gpus and ws > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, ws))
+    local %= max(1, torch.cuda.device_count())      # (more ranks than GPUs only under FVTA_DIST_BACKEND=gloo, a test set-up)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _lib.load()

@@ -17,8 +17,8 @@ def init(backend=None):
     ws, rank, local = world()
     if ws == 1 and os.environ.get("FVTA_DIST_FORCE", "0") != "1":   # FVTA_DIST_FORCE=1: exercise the collective path with one rank
         return ws, rank, local
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:   # FVTA_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses that) -- a test affordance
+        backend = os.environ.get("FVTA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
     if not dist.is_initialized():

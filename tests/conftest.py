@@ -15,3 +15,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+def pytest_collection_modifyitems(config, items):
+    """tests/test_gpu_dist.py starts child processes (one per rank).  A child is a fresh interpreter, i.e. fork + exec --
+    which must not happen from a process that has already initialised the GPU on this pool.  The pytest process itself
+    never touches the GPU in those tests, so they only have to run BEFORE every other GPU test: move them to the front."""
+    first = [it for it in items if "test_gpu_dist" in it.nodeid]
+    rest = [it for it in items if "test_gpu_dist" not in it.nodeid]
+    items[:] = first + rest

@@ -56,23 +56,13 @@ def _worker(rank, ws, port, precision, q):
     dist.shutdown()
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
-def test_two_ranks_equal_one_process_on_the_whole_batch(precision):
+def _reference_worker(precision, q):
+    """one process, the whole batch"""
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
     from fvta_memexqa_amd.model_v2 import Model
     from fvta_memexqa_amd.synth import make_inputs, make_params
     from fvta_memexqa_amd.trainer import Trainer
-    ws, port = 2, _free_port()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, ws, port, precision, q)) for r in range(ws)]
-    for p in ps:
-        p.start()
-    res = sorted([q.get(timeout=300) for _ in ps], key=lambda x: x[0])
-    for p in ps:
-        p.join(120)
-        assert p.exitcode == 0
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
-        os.environ.pop(k, None)
     spec = _spec(8)
     cfg = dict(spec.cfg(), batch_size=spec.N, init_lr=0.5, precision=precision)
     model = Model(cfg, text_in=spec.text_in, img_in=spec.img_in)
@@ -80,10 +70,31 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(precision):
     tr = Trainer(model, cfg)
     tr.need_dx = True
     L = model.load_inputs(make_inputs(spec), training=True)
-    ref_losses = [float(tr.step_device(L).item()) for _ in range(2)]
-    ref = model.params.flat.cpu().numpy()
-    assert 0 < res[0][3] < ref.size                                   # an early bucket AND a late one were reduced
+    losses = [float(tr.step_device(L).item()) for _ in range(2)]
+    q.put((-1, model.params.flat.cpu().numpy(), losses, model.params.early_numel))
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_two_ranks_equal_one_process_on_the_whole_batch(precision):
+    # every GPU user of this test is a CHILD process; the pytest process must not have initialised the GPU before it
+    # starts them (conftest.py runs this file first)
+    if torch.cuda.is_initialized():
+        pytest.skip("the GPU is already initialised in this process: child processes may not be exec'd from it here; "
+                    "run tests/test_gpu_dist.py first or alone")
+    ws, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, ws, port, precision, q)) for r in range(ws)]
+    ps.append(ctx.Process(target=_reference_worker, args=(precision, q)))
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in ps], key=lambda x: x[0])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, ref, ref_losses, _), r0, r1 = res
+    assert 0 < r0[3] < ref.size                                       # an early bucket AND a late one were reduced
     tol = dict(rtol=2e-4, atol=2e-6) if precision == "f32" else dict(rtol=5e-2, atol=2e-3)
-    assert np.array_equal(res[0][1], res[1][1]), "ranks must hold identical parameters"
-    np.testing.assert_allclose(res[0][1], ref, **tol)
-    np.testing.assert_allclose(res[0][2], ref_losses, rtol=1e-4 if precision == "f32" else 2e-2)
+    assert np.array_equal(r0[1], r1[1]), "ranks must hold identical parameters"
+    np.testing.assert_allclose(r0[1], ref, **tol)
+    np.testing.assert_allclose(r0[2], ref_losses, rtol=1e-4 if precision == "f32" else 2e-2)
