@@ -92,6 +92,9 @@ class Model(model_v2.Model):
         self.scorer_tanh = False             # model.py:1011-1013: linear(...) without add_tanh
         self.ml_att_logits = self.mm_att_logits = None
 
+    def _no_photo(self):
+        return False                         # model.py never reads --no_photo: its graph always has the six streams
+
     @staticmethod
     def streams_of(inputs):
         """`ctx_streams` config entry for an oracle-format inputs dict"""

@@ -678,6 +678,10 @@ class Model:
                                                  getattr(self, "_vocab_memo", None))
         return feed
 
+    def _no_photo(self):
+        """--no_photo (main.py:42): model_v2.py:864, 904 leave the photo stream out of the context tensor"""
+        return bool(_cfg(self.config, "no_photo", False))
+
     def inputs_from_feed(self, feed):
         """feed dict (placeholder names) -> the `inputs` tree load_inputs takes; context streams in the reference's
         stacking order at, ad, when, where, pts, pis (model_v2.py:905-912; `no_photo` drops pis)."""
@@ -687,7 +691,7 @@ class Model:
             return dict(ids=t(feed[n]), chars=t(feed[n + "_c"]), mask=t(feed[n + "_mask"]), cell="text")
 
         ctx = [text(n) for n in ("at", "ad", "when", "where", "pts")]
-        if not _cfg(self.config, "no_photo", False):
+        if not self._no_photo():
             ctx.append(dict(pis=t(feed["pis"]), mask=t(feed["pis_mask"]), cell="image"))
         emb = feed.get("existing_emb_mat")
         if emb is not None and emb is not getattr(self, "_fed_emb", None):     # fed every step, uploaded when it changes
