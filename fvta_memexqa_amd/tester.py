@@ -34,6 +34,9 @@ class Tester:
         dict (no id arrays): the subset the hot path owns, (yp, att_logits, q_att_logits, hall)."""
         batchIdxs, batch_data = batch
         m = self.model
+        if not getattr(m, "HAS_VIS_TENSORS", True):
+            # tester.py:37 fetches self.model.C, C_win, warp_h, hall: only model_v2.py's Model defines them
+            raise AttributeError("Model instance has no attribute 'C' (step_vis needs the FVTA model's tensors)")
         feed = m.get_feed_dict(batch_data, is_train=False)
         L = m.load_inputs(feed, training=False)
         yp = m.forward(L, want_logits=True).cpu().numpy()

@@ -176,6 +176,8 @@ def test_model_py_graph_on_dataset_batches(flags):
         ref = _oracle_v1(model, model.get_feed_dict(batch[1], is_train=False), config, flags)["yp"].numpy()[:batch[1].num_examples]
         np.testing.assert_allclose(yp, ref, rtol=1e-4, atol=1e-6)
         assert (yp.argmax(1) == ref.argmax(1)).all()
+    with pytest.raises(AttributeError):                  # tester.py:37 asks the model for C / warp_h / hall
+        tester.step_vis(None, next(iter(ds.get_batches(case["batch_size"], 1, shuffle=False))))
     config, ds, case = _setup("feed_train_shuffle", True)
     config.__dict__.update(dict(dict(use_question_att=False), **flags))
     model = get_model(config)
