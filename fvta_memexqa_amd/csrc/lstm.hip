@@ -16,6 +16,9 @@
 #include "fvta_prof.h"
 #include <vector>
 
+#ifndef FVTA_LSTM_BWD_RC_DEFAULT
+#define FVTA_LSTM_BWD_RC_DEFAULT 1
+#endif
 #ifndef FVTA_LSTM_NT_DEFAULT
 #define FVTA_LSTM_NT_DEFAULT 2
 #endif
@@ -663,6 +666,12 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
         return e ? atoi(e) : FVTA_LSTM_NT_DEFAULT;
       }();
       f.ntl = (nt & 2) != 0;
+      // FVTA_LSTM_BWD_RC: rebuild c_t from the saved gates instead of reading it back (see FusedBwdArgs.rc)
+      static const int rc = [] {
+        const char* e = getenv("FVTA_LSTM_BWD_RC");
+        return e ? atoi(e) : FVTA_LSTM_BWD_RC_DEFAULT;
+      }();
+      f.rc = rc;
     }
     if (split_dirs) {
       hipEvent_t e = new_event();

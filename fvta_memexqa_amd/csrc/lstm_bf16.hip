@@ -26,6 +26,7 @@
 #ifndef FVTA_LSTM_SEQ_DEFAULT
 #define FVTA_LSTM_SEQ_DEFAULT 0
 #define FVTA_LSTM_FWD_DIRECT_DEFAULT 0
+#define FVTA_LSTM_SMALL_ROWS_DEFAULT 1
 #endif
 #ifndef FVTA_GLDS_SP_DEFAULT
 #define FVTA_GLDS_SP_DEFAULT 1
@@ -48,6 +49,15 @@ int glds_sp_mask() {
     return e ? atoi(e) : FVTA_GLDS_SP_DEFAULT;
   }();
   return m;
+}
+
+// FVTA_LSTM_SMALL_ROWS: calls with <= 128 sequences (the photo cell) run their backward step on 64- / 128-row block tiles
+static bool small_rows() {
+  static const bool on = [] {
+    const char* e = getenv("FVTA_LSTM_SMALL_ROWS");
+    return e ? e[0] == '1' : (FVTA_LSTM_SMALL_ROWS_DEFAULT != 0);
+  }();
+  return on;
 }
 
 static int tile128_mask() {
@@ -422,10 +432,13 @@ void launch_step_bwd_bf16(const StepBwdArgs& a, hipStream_t s) {
 // the epilogue adds the upstream d_out, runs the gate gradient and writes dz_t (packed, unit-major) and
 // the running dc.  No dh round trip through HBM, no separate elementwise launch.
 // grid (pad8(ceil(B/256)), d/128 (ceil), 2)
-template <int WN, int TM>
-__global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
-  typedef TileCfgT<WN, TM> TileCfg;
-  typedef MmaBT<WN, TM> MmaB;
+// WM < 8 / TM: block tiles of fewer rows (64 x 128 on ONE wave, 128 x 128 on two) for calls with few sequences -- the
+// photo cell's 64 rows: a step is then a chain of K/32 k-tiles whose length is the DMA wave-instructions per k-tile
+// (A rows + B rows, at ~40 clocks each whether or not the rows exist), 12 instead of 32.
+template <int WN, int TM, int WM = 8 / TM>
+__global__ __launch_bounds__((TileCfgT<WN, TM, WM>::NT), (WN == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
+  typedef TileCfgT<WN, TM, WM> TileCfg;
+  typedef MmaBT<WN, TM, WM> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + TileCfg::STAGES * TileCfg::STAGE_ELEMS);
   const int tid = threadIdx.x, dir = blockIdx.z + a.dir0;
@@ -478,7 +491,7 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
   if (m0 >= nact) return;
   const int nnext = (t + 1 < a.J) ? a.plan.nactive[t + 1] : 0;
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
-  for (int r = tid; r < 256; r += TileCfg::NT) s_oo[r] = a.plan.oo[trow + min(m0 + r, nact - 1)];  // clamped: always a valid row
+  for (int r = tid; r < TileCfg::BM; r += TileCfg::NT) s_oo[r] = a.plan.oo[trow + min(m0 + r, nact - 1)];  // clamped: always a valid row
   MmaB mma;
   mma.init(tid);
   // FVTA_DEBUG_SKIP & 65536-style diagnostics: env FVTA_LSTM_STAMP_BWD=<workgroup> stamps step t = 5 (tools/lstm_phases.py)
@@ -521,12 +534,12 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
         const int u = min(u0 + mma.col_of(tj), d - 1);
         if (a.ntl) {
           gp[tj] = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(a.gatesb + (trow + ic) * (size_t)K + 4 * u));
-          c[tj] = __builtin_nontemporal_load(cs_t + (size_t)ic * d + u);
+          c[tj] = a.rc ? 0.f : __builtin_nontemporal_load(cs_t + (size_t)ic * d + u);
           cp[tj] = t > 0 ? __builtin_nontemporal_load(cs_p + (size_t)ic * d + u) : 0.f;
           dout[tj] = __builtin_nontemporal_load(a.d_out + oo + u);
         } else {
           gp[tj] = *reinterpret_cast<const bf16x4*>(a.gatesb + (trow + ic) * (size_t)K + 4 * u);
-          c[tj] = cs_t[(size_t)ic * d + u];
+          c[tj] = a.rc ? 0.f : cs_t[(size_t)ic * d + u];
           cp[tj] = t > 0 ? cs_p[(size_t)ic * d + u] : 0.f;
           dout[tj] = a.d_out[oo + u];
         }
@@ -538,7 +551,7 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
         const float ig = bf2f((bf16_t)gp[tj][0]), jg = bf2f((bf16_t)gp[tj][1]), fg = bf2f((bf16_t)gp[tj][2]),
                     og = bf2f((bf16_t)gp[tj][3]);
         const float dh = dout[tj] + mma.acc[ti][tj][r];
-        const float tc = fvta_tanh(c[tj]);
+        const float tc = fvta_tanh(a.rc ? cp[tj] * fg + ig * jg : c[tj]);
         const float dc = dcv[tj] + dh * og * (1.f - tc * tc);
         bf16x4 pk;
         pk[0] = (short)f2bf(dc * jg * ig * (1.f - ig));
@@ -587,6 +600,17 @@ void launch_bwd_fused_bf16(const FusedBwdArgs& a_, hipStream_t s) {
     a.dh_tiles = a.d / 256;
     const dim3 grid(pad8((a.B + 255) / 256), a.dh_tiles + a.dx_tiles, a.ndir);
     hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4>), grid, dim3(256), LDS, s, a);
+  } else if (a.B <= 128 && small_rows() && a.dx_tiles == 0) {  // few sequences (the photo cell): row tiles of 64 / 128
+    a.dh_tiles = (a.d + 127) / 128;
+    if (a.B <= 64) {
+      constexpr int LDS = TileCfgT<1, 2, 1>::LDS_BYTES + 64 * 8;
+      allow_big_lds(lstm_bwd_fused_bf16<1, 2, 1>, LDS);
+      hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 2, 1>), dim3((a.B + 63) / 64, a.dh_tiles, a.ndir), dim3(64), LDS, s, a);
+    } else {
+      constexpr int LDS = TileCfgT<1, 2, 2>::LDS_BYTES + 128 * 8;
+      allow_big_lds(lstm_bwd_fused_bf16<1, 2, 2>, LDS);
+      hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 2, 2>), dim3((a.B + 127) / 128, a.dh_tiles, a.ndir), dim3(128), LDS, s, a);
+    }
   } else if (a.d % 256 == 0 && !narrow) {  // 256 x 256 tile: dz (the A operand, K = 4d wide) is re-read d/256 instead of d/128 times
     constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
     allow_big_lds(lstm_bwd_fused_bf16<2, 2>, LDS);
