@@ -657,6 +657,7 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
     f.dh_tiles = 0;
     f.dir0 = 0;
     f.ndir = 2;
+    f.dxmode = 0;
     // dx rides on the step launches (dx_{t+1} next to dh_t: same A operand) unless it goes to the side stream / is off
     f.dx_tiles = (dx && !ov_dx) ? bwd_fused_dx_tiles(in, dd) : 0;
     f.stamp_wg = fvta_diag_env("FVTA_LSTM_STAMP_BWD", -1);  // -DFVTA_DIAG builds only

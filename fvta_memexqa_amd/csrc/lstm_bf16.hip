@@ -27,6 +27,7 @@
 #define FVTA_LSTM_SEQ_DEFAULT 0
 #define FVTA_LSTM_FWD_DIRECT_DEFAULT 0
 #define FVTA_LSTM_SMALL_ROWS_DEFAULT 1
+#define FVTA_LSTM_DX_2PASS_DEFAULT 0
 #endif
 #ifndef FVTA_GLDS_SP_DEFAULT
 #define FVTA_GLDS_SP_DEFAULT 1
@@ -633,7 +634,7 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
   typedef MmaBT<WN, TM> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   const int tid = threadIdx.x;
-  const int t = a.t0 + blockIdx.z % a.nt, dir = blockIdx.z / a.nt;
+  const int t = a.t0 + blockIdx.z % a.nt, dir = a.dir0 + blockIdx.z / a.nt;
   const int m0 = blockIdx.x * TileCfg::BM, n0 = blockIdx.y * TileCfg::BN;
   const int nact = a.plan.nactive[t];
   if (m0 >= nact) return;
@@ -664,7 +665,17 @@ __global__ __launch_bounds__((TileCfgT<WN, TM>::NT), (WN == 1 ? 2 : 1)) void lst
 #pragma unroll
       for (int tj = 0; tj < MmaB::TN; ++tj) {
         const int n = n0 + mma.col_of(tj);
-        if (n < in) atomicAdd(a.dx + xos[r] + n, mma.acc[ti][tj][r]);  // fw and bw meet at a position: two addends
+        if (n < in) {
+          // fw and bw meet at a position: two addends.  One launch: atomics.  One launch per direction: within a direction
+          // every (sequence, position) is written once, so the first stores and the second adds, without atomics.
+          float* o = a.dx + xos[r] + n;
+          if (a.dxmode == 0)
+            atomicAdd(o, mma.acc[ti][tj][r]);
+          else if (a.dxmode == 1)
+            *o = mma.acc[ti][tj][r];
+          else
+            *o += mma.acc[ti][tj][r];
+        }
       }
     }
   }
@@ -677,18 +688,31 @@ void launch_dx_bf16(const FusedBwdArgs& a_, hipStream_t s) {
     const char* e = getenv("FVTA_LSTM_DX_WIDE_TILE");
     return e && e[0] == '1';
   }();
+  static const int two_pass = [] {  // FVTA_LSTM_DX_2PASS: one launch per direction (store, then add) instead of atomics
+    const char* e = getenv("FVTA_LSTM_DX_2PASS");
+    return e ? atoi(e) : FVTA_LSTM_DX_2PASS_DEFAULT;
+  }();
+  if (two_pass && a.dxmode == 0 && a.ndir == 2 && a.dir0 == 0) {
+    FusedBwdArgs p = a_;
+    p.dir0 = 0; p.ndir = 1; p.dxmode = 1;
+    launch_dx_bf16(p, s);
+    p.dir0 = 1; p.dxmode = 2;
+    launch_dx_bf16(p, s);
+    return;
+  }
+  const int zdirs = a.dxmode == 0 ? 2 : 1;
   if (a.in > 128 && (tile128_mask() & 4)) {
     constexpr int LDS = TileCfgT<2, 4>::LDS_BYTES;
     allow_big_lds(lstm_dx_bf16<2, 4>, LDS);
-    const dim3 grid(pad8((a.B + 255) / 256), (a.in + 255) / 256, 2 * a.nt);
+    const dim3 grid(pad8((a.B + 255) / 256), (a.in + 255) / 256, zdirs * a.nt);
     hipLaunchKernelGGL((lstm_dx_bf16<2, 4>), grid, dim3(256), LDS, s, a);
   } else if (a.in > 128 && wide) {
     allow_big_lds(lstm_dx_bf16<2, 2>, TileCfgT<2>::LDS_BYTES);
-    const dim3 grid(pad8((a.B + 255) / 256), (a.in + 255) / 256, 2 * a.nt);
+    const dim3 grid(pad8((a.B + 255) / 256), (a.in + 255) / 256, zdirs * a.nt);
     hipLaunchKernelGGL((lstm_dx_bf16<2, 2>), grid, dim3(512), TileCfgT<2>::LDS_BYTES, s, a);
   } else {
     allow_big_lds(lstm_dx_bf16<1, 2>, TileCfgT<1>::LDS_BYTES);
-    const dim3 grid(pad8((a.B + 255) / 256), (a.in + 127) / 128, 2 * a.nt);
+    const dim3 grid(pad8((a.B + 255) / 256), (a.in + 127) / 128, zdirs * a.nt);
     hipLaunchKernelGGL((lstm_dx_bf16<1, 2>), grid, dim3(256), TileCfgT<1>::LDS_BYTES, s, a);
   }
 }
