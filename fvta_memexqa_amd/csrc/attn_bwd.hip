@@ -15,6 +15,10 @@
 #include "attn_common.h"
 #include "fvta_prof.h"
 
+#ifndef FVTA_ATTN_BWD_NT_DEFAULT
+#define FVTA_ATTN_BWD_NT_DEFAULT 0
+#endif
+
 namespace fvta {
 
 __device__ __forceinline__ f32x4 ld4b(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -109,6 +113,7 @@ struct AttnBwdArgs {
   int accumulate;
   const float* tscale;  // [N,T] or null (time_warp_att): the inner softmax ran on z = amax * tscale
   size_t hstride;       // elements between the row blocks of consecutive (n,k) of hinfo / d_hinfo (see AttnFwdArgs)
+  int nt;               // bit 0: non-temporal stores of the d_hinfo rows (written once, read much later); bit 1: the h rows too
 };
 
 // TPR threads cover one row (16 B each, G float4 per thread when w > 1024);
@@ -273,7 +278,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
       float dsum = 0.f, nsum = 0.f;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const f32x4 hv = ld4b(hbase + (size_t)max(t, 0) * w + 4 * (cq + g * TPR));  // unconditional, then zeroed
+        const f32x4* hp = reinterpret_cast<const f32x4*>(hbase + (size_t)max(t, 0) * w + 4 * (cq + g * TPR));
+        const f32x4 hv = (a.nt & 2) ? __builtin_nontemporal_load(hp) : *hp;  // unconditional, then zeroed
         hreg[i][g] = t >= 0 ? hv : f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 pdt = hreg[i][g] * gv[g];
         dsum += (pdt[0] + pdt[1]) + (pdt[2] + pdt[3]);
@@ -376,7 +382,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
         f32x4 dh = cosine ? gv[g] * pr + qs * dx + h * self : gv[g] * pr + (qs + rh4[g] + r24[g] * h * 2.f) * dx;
         float* dst = dhbase + (size_t)t * w + 4 * c4;
         if (a.accumulate == 1) dh += ld4b(dst);
-        *reinterpret_cast<f32x4*>(dst) = dh;
+        if ((a.nt & 1) && a.accumulate != 1)
+          __builtin_nontemporal_store(dh, reinterpret_cast<f32x4*>(dst));
+        else
+          *reinterpret_cast<f32x4*>(dst) = dh;
         accq[g] += h * dx;
         if (!cosine) {
           accRh[g] += h * dx;
@@ -656,6 +665,13 @@ extern "C" int fvta_attn_bwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   a.accumulate = accumulate;
   a.tscale = tscale;
   a.hstride = d->hinfo_stride ? (size_t)d->hinfo_stride : (size_t)s.T * s.w;
+  {
+    static const int nt = [] {
+      const char* e = getenv("FVTA_ATTN_BWD_NT");
+      return e ? atoi(e) : FVTA_ATTN_BWD_NT_DEFAULT;
+    }();
+    a.nt = nt;
+  }
   const dim3 grid(s.bsplit, s.N * s.ng);
   const bool prof_it = (size_t)s.N * s.K * s.T >= 65536;  // the context attention, see attn_fwd.hip
   if (prof_it) fvta_prof_begin(FVTA_PROF_ATTN_BWD_MAIN, stream);
