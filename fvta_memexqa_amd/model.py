@@ -378,7 +378,15 @@ class Model(model_v2.Model):
     def _attend_bwd(self, L, dgq, dg1, dgch):
         N, K, JQ, C, JA, wp = L.N, L.K, L.JQ, L.C, L.JA, self.wp
         T = L.groups["text"]
-        L.d_arena.zero_()
+        # the context rows of the gradient arena are cleared only when their first writer ADDS (last-state scatter, the
+        # TGIF weighted sum); an attention over every row of a stream / of the arena writes them with plain stores
+        # (accumulate mode 2: valid rows only, the encoders never read the others) and later writers accumulate
+        hall_written = self.use_direct_links or self.use_ml_att
+        if hall_written and not (self.use_tgif and not self.use_direct_links):
+            L.d_arena[L.row_hq:].zero_()
+        else:
+            L.d_arena.zero_()
+        hall_written = self.use_direct_links
         L.d_g1s.zero_()
         d_hall = L.d_arena[:L.row_hq]
         d_hq = L.d_arena[L.row_hq:L.row_hch]
@@ -405,7 +413,7 @@ class Model(model_v2.Model):
         else:
             if self.use_direct_links:
                 L.full.backward(L.hall, L.hq, None, None, self._pv(self.N_FULL_W), self._pv(self.N_FULL_B), dg1, d_hall, d_hq,
-                                g(self.N_FULL_W), g(self.N_FULL_B), accumulate=1)
+                                g(self.N_FULL_W), g(self.N_FULL_B), accumulate=2)      # first writer of every context row
             if not self.direct_links_only:
                 if self.use_mm_att:
                     self._att_bwd(L, "mm", L.mm, L.g1s, L.hq, None, None, self.N_MM_W, self.N_MM_B, dg1, L.d_g1s, d_hq, 1)
@@ -429,7 +437,7 @@ class Model(model_v2.Model):
                 hm, qm = (self._stream_mask(L, k), L.q_mask) if L.masked[k] else (None, None)
                 L.ml[k].backward(self._stream_ptr(L, k), L.hq, hm, qm, self._pv(self.N_ML_W % name),
                                  self._pv(self.N_ML_B % name), L.dg_k, self._stream_ptr(L, k, True), d_hq,
-                                 g(self.N_ML_W % name), g(self.N_ML_B % name), accumulate=1)
+                                 g(self.N_ML_W % name), g(self.N_ML_B % name), accumulate=1 if hall_written else 2)
             else:
                 G, seg = L.groups[cell], L.groups[cell].segs[si]
                 ops.rows_broadcast(L.dg_k, L.d_last[k], N, L.cnt[k], wp, scale=1.0 / L.cnt[k])
