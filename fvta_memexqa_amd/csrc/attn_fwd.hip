@@ -14,6 +14,9 @@
 namespace fvta {
 
 __device__ __forceinline__ f32x4 ld4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+#ifndef FVTA_ATTN_WAVE16_DEFAULT
+#define FVTA_ATTN_WAVE16_DEFAULT 0
+#endif
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 // x[0..7] = (a0, a1) -> hi, lo fp16 pieces (see above); register pairs are concatenated, never re-packed
@@ -943,6 +946,228 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(Attn
 #undef FVTA_STAMP
 }
 
+// ---- one wave per 16-row tile (JQ <= 32, 256 <= w <= 1024, simi 1-3) -----------------------------------------------
+// The kernel above shares a tile among eight waves (each owns w/8 channels), so every tile pays two workgroup barriers and
+// a cross-wave reduction of the partial scores: a ~7000-cycle dependent chain per 64 KB.  Here a tile belongs to ONE wave:
+// the 16 rows (w/16 float4 registers per lane, lane = row l15, k quarter kq -- up to 256 registers, the kernel runs at one
+// wave per SIMD with the AGPRs as the second half of the register file) are scored over all channels on the fp16-split
+// pipe with the question operand read from LDS (hi and lo pieces, 2 x w x 32 x 2 B = 128 KB at w = 1024, filled once per
+// workgroup: its four waves work on items of ONE n), max / arg-max / online softmax run inside the wave, and the weighted
+// sum uses the same registers, folded over the 16 row lanes with DPP row sums -- lane (row r, quarter kq) keeps the
+// channel blocks b = r (mod 16), so the accumulator is w/256 float4 registers.  No barrier after the prologue, no
+// cross-wave traffic, rows read once; a (n, k, split) item is a wave's own tile stream and ends in the same (m, l, u)
+// partial as the kernels above.  grid: G workgroups per n, XCD-contiguous in n.
+template <int NBLK, int RMODE>
+__global__ __launch_bounds__(256, 1) void attn_fwd_wave16(AttnFwdArgs a, int G) {
+  constexpr int NKS = NBLK / 2;  // K = 32 MFMA steps over the channels
+  constexpr int NU = NBLK / 16;  // accumulator registers (float4) per lane
+  static_assert(NBLK % 16 == 0, "channel blocks are dealt round-robin to the 16 row lanes");
+  extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+  half8(*s_qhi)[2][64] = reinterpret_cast<half8(*)[2][64]>(s_dyn);                                   // [NKS][2][64]
+  half8(*s_qlo)[2][64] = reinterpret_cast<half8(*)[2][64]>(s_dyn + (size_t)NKS * 2 * 64 * sizeof(half8));
+  float* s_vec = reinterpret_cast<float*>(s_dyn + (size_t)2 * NKS * 2 * 64 * sizeof(half8));         // [2][w]
+  __shared__ float s_ct[32];
+
+  const AttnShape& s = a.s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int T = s.T, w = s.w, JP = s.JP;
+  const int nwg = s.N * G, per = (nwg + 7) / 8;
+  const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (wg >= nwg || (int)(blockIdx.x >> 3) >= per) return;
+  const int n = wg / G, g0 = wg % G;
+
+  // ---- the question operand of n, in MFMA B lane order: step ks, j tile jt, lane (col l15, k group kq) holds channels
+  // 32 ks + 4 kq + (0..3) and 32 ks + 16 + 4 kq + (0..3)
+  {
+    const int W4c = w / 4;
+    const uint16_t* qh = a.sv.Qh + (size_t)n * 2 * W4c * 32 * 4;
+    for (int e = tid; e < 2 * NKS * 2 * 64; e += 256) {
+      const int ln = e & 63, jt = (e >> 6) & 1, ks = (e >> 7) % NKS, pc = (e >> 7) / NKS;
+      const int j = (ln & 15) + 16 * jt, q4 = ln >> 4;
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x2 x0 = *reinterpret_cast<const u32x2*>(qh + (((size_t)pc * W4c + 8 * ks + q4) * 32 + j) * 4);
+      const u32x2 x1 = *reinterpret_cast<const u32x2*>(qh + (((size_t)pc * W4c + 8 * ks + 4 + q4) * 32 + j) * 4);
+      const u32x4 xx = __builtin_shufflevector(x0, x1, 0, 1, 2, 3);
+      (pc == 0 ? s_qhi : s_qlo)[ks][jt][ln] = __builtin_bit_cast(half8, xx);
+    }
+    for (int c = tid; c < w; c += 256) {
+      s_vec[c] = a.sv.vecs[VEC_RH * w + c];
+      s_vec[w + c] = a.sv.vecs[VEC_R2 * w + c];
+    }
+    if (tid < 32) s_ct[tid] = a.sv.ct[(size_t)n * JP + tid];
+  }
+  const uint64_t qvalid = a.sv.qvalid[(size_t)n * 2];
+  __syncthreads();
+
+  const int nitems_n = s.K * s.nsplit;
+  for (int il = g0 + G * wave; il < nitems_n; il += 4 * G) {
+    const int k = il / s.nsplit, split = il % s.nsplit;
+    const int nk = n * s.K + k;
+    const int cnt = a.sv.cnt[nk];
+    const bool allm = a.sv.allmasked[nk] != 0;
+    const int tiles_total = (cnt + 15) >> 4;
+    const int tiles_per = (tiles_total + s.nsplit - 1) / s.nsplit;
+    const int t0 = split * tiles_per, t1 = min(tiles_total, t0 + tiles_per);
+    float* part = a.part + ((size_t)nk * s.nsplit + split) * (w + 4);
+    if (t1 <= t0) {  // empty split
+      if (lane == 0) {
+        part[0] = -INFINITY;
+        part[1] = 0.f;
+        part[2] = -INFINITY;
+      }
+      continue;
+    }
+    const float* hbase = a.hinfo + (size_t)nk * a.hstride;
+    const int32_t* idx = a.sv.idx + (size_t)nk * T;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 u[NU];   // lane (row l15, quarter kq): channels 16 (16 i + l15) + 4 kq + (0..3) of the weighted sum
+#pragma unroll
+    for (int i = 0; i < NU; ++i) u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // the tile lives in h[] across the loop: the weighted sum hands every block's registers to the NEXT tile's load as
+    // soon as it has consumed them, so the next tile streams in under this tile's tail and the following score pass
+    f32x4 h[NBLK];
+    int t_cur;
+    bool v_cur;
+    {
+      const int lr = t0 * 16 + l15;
+      v_cur = lr < cnt;
+      t_cur = v_cur ? idx[lr] : 0;  // (invalid rows of the last tile read row 0: finite data, weight 0)
+      const float* rowp = hbase + (size_t)t_cur * w + 4 * kq;
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) h[b] = *reinterpret_cast<const f32x4*>(rowp + 16 * b);
+    }
+    for (int tl = t0; tl < t1; ++tl) {
+      const bool rvalid = v_cur;
+      const int t = t_cur;
+      const bool has_next = tl + 1 < t1;
+      const int lrn = (tl + 1) * 16 + l15;
+      const bool v_next = has_next && lrn < cnt;
+      const int t_next = v_next ? idx[lrn] : 0;
+      const float* rowp_next = hbase + (size_t)t_next * w + 4 * kq;
+      float am = rvalid ? FVTA_NEG : -INFINITY;  // (a fully masked (n,k): every row of the identity list at -1e30)
+      if (!allm) {
+        f32x4 ahh[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 axx[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        f32x4 rt4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int c0 = 16 * (2 * ks + q) + 4 * kq;
+            const f32x4 hv = h[2 * ks + q];
+            if (RMODE == 1)
+              rt4 += hv * *reinterpret_cast<const f32x4*>(&s_vec[c0]);
+            else if (RMODE == 2)
+              rt4 += (hv * hv) * *reinterpret_cast<const f32x4*>(&s_vec[w + c0]);
+            else
+              rt4 += hv * (*reinterpret_cast<const f32x4*>(&s_vec[c0]) + *reinterpret_cast<const f32x4*>(&s_vec[w + c0]) * hv);
+          }
+          half8 hi, lo;
+          split_f16x8(h[2 * ks], h[2 * ks + 1], hi, lo);
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            const half8 bh = s_qhi[ks][jt][lane];
+            ahh[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, bh, ahh[jt], 0, 0, 0);
+            axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, s_qlo[ks][jt][lane], axx[jt], 0, 0, 0);
+            axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, bh, axx[jt], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the unrolled steps apart (hoisted LDS reads / splits cost registers)
+        }
+        // the row term of row l15: fold its four k quarters (lanes l15, l15 + 16, + 32, + 48)
+        float rtp = (rt4[0] + rt4[1]) + (rt4[2] + rt4[3]);
+        rtp += __shfl_xor(rtp, 16, 64);
+        rtp += __shfl_xor(rtp, 32, 64);
+        // D layout of 16x16xK: lane -> column j = l15 (+ 16 jt), rows 4 kq + i.  Per row: max / first arg-max over j.
+        float amr[4];
+        int jmr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float rti = __shfl(rtp, 4 * kq + i, 64);
+          float best = -INFINITY;
+          int bestj = 0;
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            const int j = l15 + 16 * jt;
+            const float x = ahh[jt][i] + axx[jt][i] * (1.f / 2048.f) + rti + s_ct[j];
+            if (((qvalid >> j) & 1ull) && x > best) {
+              best = x;
+              bestj = j;
+            }
+          }
+          row16_argmax(best, bestj);
+          amr[i] = best;
+          jmr[i] = bestj;
+        }
+        // row l15's result sits in the lane group l15 >> 2 as its entry l15 & 3
+        const int src = ((l15 >> 2) << 4) | l15;
+        float bestv = 0.f;
+        int bestj = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = __shfl(amr[i], src, 64);
+          const int jj = __shfl(jmr[i], src, 64);
+          if ((l15 & 3) == i) {
+            bestv = v;
+            bestj = jj;
+          }
+        }
+        am = rvalid ? (s.add_tanh ? fvta_tanh(bestv) : bestv) : -INFINITY;
+        if (kq == 0 && rvalid) {
+          a.sv.amax[(size_t)nk * T + t] = am;
+          a.sv.jmax[(size_t)nk * T + t] = (uint8_t)bestj;
+        }
+      }
+      // online softmax over t (softsel inner, model_v2.py:278); every lane of a DPP row holds its own row l15
+      const float m_new = fmaxf(m_run, row16_max(am));
+      const float scale = expf(m_run - m_new);
+      const float pr = expf(am - m_new);
+      l_run = l_run * scale + row16_sum(pr);
+      m_run = m_new;
+      // weighted sum u[c] = u[c] * scale + sum_r p_r h[r, c]: every block summed over the 16 row lanes by DPP row sums
+      // (an all-reduce), kept by lane b & 15.  Measured alternatives, all slower with one wave per SIMD: a reduce-scatter
+      // over the row lanes (60 instead of 256 values per 16 blocks, but two selects per value and one long dependent
+      // chain: 0.48 vs 0.45 ms); a transposition through a wave-private LDS scratch (a sixth of the VALU work, but two
+      // exposed LDS round trips per 64 channels: 0.49); two blocks per butterfly step to cover the DPP read hazard
+      // (fewer s_nop, but the compiler spills: 0.50).
+      if (scale != 1.f) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] *= scale;
+      }
+      if (has_next) {
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+          f32x4 v = h[b] * pr;
+          h[b] = *reinterpret_cast<const f32x4*>(rowp_next + 16 * b);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = row16_sum(v[e]);
+          if ((b & 15) == l15) u[b >> 4] += v;
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+          f32x4 v = h[b] * pr;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = row16_sum(v[e]);
+          if ((b & 15) == l15) u[b >> 4] += v;
+        }
+      }
+      t_cur = t_next;
+      v_cur = v_next;
+    }
+    // the item's partial (m, l, u): lane (l15, kq) holds channels 16 (16 i + l15) + 4 kq + (0..3)
+#pragma unroll
+    for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(part + 4 + 16 * (16 * i + l15) + 4 * kq) = u[i];
+    if (lane == 0) {
+      part[0] = m_run;
+      part[1] = l_run;
+      part[2] = m_run;
+    }
+  }
+}
+
 // ---- time_warp_att only: the MASKED rows of a (n,k) that has valid rows.  The reference scales the max-pooled logit
 // AFTER exp_mask (model_v2.py:263-275), so a masked row's softmax logit is -1e30 * tscale[n,t]: hugely negative for
 // tscale > 0 (weight exactly 0, as exp underflows), but +huge for tscale < 0 -- then the masked rows take the whole
@@ -1205,7 +1430,38 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   // (time_warp_att runs on the general kernel: the 16-row kernel's softmax logits are amax itself)
   const bool rows16 = s.JT == 1 && s.w >= 128 && s.w <= 1024 && !a_logits && !tscale && !d->hinfo_stride &&
                       !(exact && exact[0] == '1');
-  if (rows16) {
+  // FVTA_ATTN_WAVE16: the one-wave-per-tile kernel for the shapes it covers (measurement switch)
+  const char* w16 = getenv("FVTA_ATTN_WAVE16");  // (read per call, like FVTA_ATTN_EXACT: the tests flip it)
+  const int wave16_mode = w16 ? atoi(w16) : FVTA_ATTN_WAVE16_DEFAULT;
+  if (rows16 && wave16_mode && s.simi != 4 && s.w >= 256) {
+    int G = (256 + s.N - 1) / s.N;
+    const int maxg = (s.K * s.nsplit + 3) / 4;
+    if (G > maxg) G = maxg;
+    if (G < 1) G = 1;
+    const int nwg = s.N * G;
+    const dim3 grid(((nwg + 7) / 8) * 8);
+    const int rmode = s.simi == 1 ? 1 : (s.simi == 3 ? 3 : 2);
+#define FVTA_W16(NBLK)                                                                                                   \
+  do {                                                                                                                   \
+    const size_t lds = (size_t)2 * (NBLK / 2) * 2 * 64 * 16 + (size_t)2 * s.w * sizeof(float);                           \
+    if (rmode == 1) {                                                                                                    \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_wave16<NBLK, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((attn_fwd_wave16<NBLK, 1>), grid, dim3(256), lds, stream, a, G);                               \
+    } else if (rmode == 2) {                                                                                             \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_wave16<NBLK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((attn_fwd_wave16<NBLK, 2>), grid, dim3(256), lds, stream, a, G);                               \
+    } else {                                                                                                             \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_wave16<NBLK, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((attn_fwd_wave16<NBLK, 3>), grid, dim3(256), lds, stream, a, G);                               \
+    }                                                                                                                    \
+  } while (0)
+    switch (s.w) {
+      case 256: FVTA_W16(16); break;
+      case 512: FVTA_W16(32); break;
+      case 1024: FVTA_W16(64); break;
+    }
+#undef FVTA_W16
+  } else if (rows16) {
     // a workgroup streams `ipw` consecutive items: about one workgroup per CU, bounded by its LDS row list
     const int nitems = s.nsplit * s.N * s.K;
     const int tiles_per_max = (((s.T + 15) / 16) + s.nsplit - 1) / s.nsplit;

@@ -245,3 +245,49 @@ def test_attention_fast_path_randomised_differential(monkeypatch):
         amax_e = op.saved[:4 * nkt].view(torch.float32).cpu()
         ok = torch.isfinite(amax_e) & (amax_e > -1e29)
         np.testing.assert_allclose(amax_f[ok].numpy(), amax_e[ok].numpy(), rtol=5e-5, atol=5e-6, err_msg=tag + " amax")
+
+
+def test_attention_wave16_kernel_randomised_differential(monkeypatch):
+    """FVTA_ATTN_WAVE16=1: the one-wave-per-tile forward kernel (attn_fwd_wave16) on random shapes / maskings / stream
+    lengths against the exact-fp32 kernel -- values, saved max-pooled logits and arg-max positions -- and against itself
+    (bitwise reproducible); then the backward pass on ITS saved state against the backward on the exact kernel's."""
+    from fvta_memexqa_amd import ops
+    rng = np.random.RandomState(4242)
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    for case in range(20):
+        w = int(rng.choice([256, 512, 1024]))
+        N, K = int(rng.randint(1, 9)), int(rng.randint(1, 8))
+        T = int(rng.choice([5, 16, 17, 48, 150, 333, 700, 1300]))
+        JQ = int(rng.randint(1, 33))
+        simi = int(rng.choice([1, 2, 3]))
+        tanh = bool(rng.rand() < 0.5)
+        masked = bool(rng.rand() < 0.8)
+        h, q, W, b, hm, qm = _att_case(N, K, T, JQ, w, simi, tanh, masked, seed=3000 + case, p_valid=float(rng.choice([0.1, 0.6, 0.95])))
+        op = ops.FocalAttention(N, K, T, JQ, w, simi, tanh)
+        args = (cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)), cu(W.reshape(-1)), cu(b))
+        monkeypatch.delenv("FVTA_ATTN_EXACT", raising=False)
+        monkeypatch.setenv("FVTA_ATTN_WAVE16", "1")
+        fast, _ = op.forward(*args)
+        fast, saved_fast = fast.cpu(), op.saved.clone()
+        again, _ = op.forward(*args)
+        tag = "case %d (N %d K %d T %d JQ %d w %d simi %d tanh %s masked %s)" % (case, N, K, T, JQ, w, simi, tanh, masked)
+        assert torch.equal(again.cpu(), fast) and torch.equal(op.saved, saved_fast), tag + ": not reproducible"
+        g = torch.randn(N, w, generator=torch.Generator().manual_seed(case)).cuda()
+        grads_fast = [torch.zeros(N, K, T, w, device="cuda"), torch.zeros(N, JQ, w, device="cuda"),
+                      torch.zeros_like(args[4]), torch.zeros(1, device="cuda")]
+        op.backward(*args, g, *grads_fast, accumulate=0)
+        monkeypatch.setenv("FVTA_ATTN_WAVE16", "0")
+        monkeypatch.setenv("FVTA_ATTN_EXACT", "1")
+        exact, _ = op.forward(*args)
+        assert torch.isfinite(fast).all(), tag
+        _close(fast, exact.cpu(), rtol=5e-5, atol=5e-6, msg=tag)
+        nkt = N * K * T
+        amax_f = saved_fast[:4 * nkt].view(torch.float32).cpu()
+        amax_e = op.saved[:4 * nkt].view(torch.float32).cpu()
+        ok = torch.isfinite(amax_e) & (amax_e > -1e29)
+        np.testing.assert_allclose(amax_f[ok].numpy(), amax_e[ok].numpy(), rtol=5e-5, atol=5e-6, err_msg=tag + " amax")
+        grads_exact = [torch.zeros(N, K, T, w, device="cuda"), torch.zeros(N, JQ, w, device="cuda"),
+                       torch.zeros_like(args[4]), torch.zeros(1, device="cuda")]
+        op.backward(*args, g, *grads_exact, accumulate=0)
+        for name, a_, b_ in zip(("d_hinfo", "d_hq", "dW", "db"), grads_fast, grads_exact):
+            _close(a_, b_.cpu(), rtol=2e-4, atol=2e-5, msg=tag + " " + name)
