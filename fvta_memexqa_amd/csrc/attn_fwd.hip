@@ -957,6 +957,25 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(Attn
 // channel blocks b = r (mod 16), so the accumulator is w/256 float4 registers.  No barrier after the prologue, no
 // cross-wave traffic, rows read once; a (n, k, split) item is a wave's own tile stream and ends in the same (m, l, u)
 // partial as the kernels above.  grid: G workgroups per n, XCD-contiguous in n.
+// Sum of each of four values over the 16 lanes of its DPP row, every lane ending with the result: the butterfly of
+// row16_sum as FUSED v_add_f32_dpp (the compiler emits v_mov_b32_dpp + a packed add + s_nop per step: 31 issue slots for
+// what are 17 here).  The four values are interleaved, so a step's DPP read of a register comes three instructions after
+// the previous step wrote it (the hazard wants two wait states; the assembler does not check inside inline asm, hence
+// also the leading s_nop against whatever VALU instruction produced the inputs).
+__device__ __forceinline__ void row16_sum4(f32x4& v) {
+  float a = v[0], b = v[1], c = v[2], d = v[3];
+#define FVTA_DPP4(CTRL)                                                   \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"      \
+  "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"      \
+  "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"      \
+  "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+  asm("s_nop 1\n\t" FVTA_DPP4("quad_perm:[1,0,3,2]") FVTA_DPP4("quad_perm:[2,3,0,1]") FVTA_DPP4("row_half_mirror")
+          FVTA_DPP4("row_mirror")
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef FVTA_DPP4
+  v = f32x4{a, b, c, d};
+}
+
 template <int NBLK, int RMODE>
 __global__ __launch_bounds__(256, 1) void attn_fwd_wave16(AttnFwdArgs a, int G) {
   constexpr int NKS = NBLK / 2;  // K = 32 MFMA steps over the channels
@@ -1141,16 +1160,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_wave16(AttnFwdArgs a, int G) 
         for (int b = 0; b < NBLK; ++b) {
           f32x4 v = h[b] * pr;
           h[b] = *reinterpret_cast<const f32x4*>(rowp_next + 16 * b);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = row16_sum(v[e]);
+          row16_sum4(v);
           if ((b & 15) == l15) u[b >> 4] += v;
         }
       } else {
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) {
           f32x4 v = h[b] * pr;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = row16_sum(v[e]);
+          row16_sum4(v);
           if ((b & 15) == l15) u[b >> 4] += v;
         }
       }
