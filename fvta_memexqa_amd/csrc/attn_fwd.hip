@@ -1185,6 +1185,265 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_wave16(AttnFwdArgs a, int G) 
   }
 }
 
+// ---- two waves per 16-row tile (JQ <= 32, 512 <= w <= 1024, simi 1-3) ---------------------------------------------
+// attn_fwd_wave16 with the tile split over a PAIR of waves (each holds half the channels: w/32 float4 registers per lane),
+// eight waves = four pairs per workgroup, two waves per SIMD: a pair exchanges its partial scores through LDS once per
+// tile (one workgroup barrier on each side of the exchange), everything else -- max / arg-max / softmax (computed by both
+// waves of a pair), the weighted sum of a wave's own channels, the rolling refill of the tile registers -- is as there.
+// Against attn_fwd_rows16 (eight waves per tile): a 2-way instead of an 8-way reduction, four independent tile streams
+// per workgroup, and a quarter of the barriers per byte; against attn_fwd_wave16: a second wave per SIMD to cover the
+// first one's latencies.  The pairs of a workgroup run the same number of barrier rounds (the longest pair's tile count).
+template <int NBH, int RMODE>
+__global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) {
+  constexpr int NKS = NBH / 2;   // MFMA steps over a wave's half of the channels
+  constexpr int NU = NBH / 16;   // accumulator registers (float4) per lane
+  static_assert(NBH % 16 == 0, "a wave's channel blocks are dealt round-robin to the 16 row lanes");
+  extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+  half8(*s_qhi)[2][64] = reinterpret_cast<half8(*)[2][64]>(s_dyn);                                        // [2 NKS][2][64]
+  half8(*s_qlo)[2][64] = reinterpret_cast<half8(*)[2][64]>(s_dyn + (size_t)2 * NKS * 2 * 64 * sizeof(half8));
+  float* s_vec = reinterpret_cast<float*>(s_dyn + (size_t)2 * 2 * NKS * 2 * 64 * sizeof(half8));           // [2][w]
+  __shared__ float s_ct[32];
+  __shared__ __attribute__((aligned(16))) float s_x[8][8 * 64];  // per wave: its partial scores [jt * 4 + i][lane]
+  __shared__ float s_rt[8][16];                                  // per wave: its partial row terms
+  __shared__ int s_tiles[4];
+
+  const AttnShape& s = a.s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int pair = wave >> 1, hv = wave & 1;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int T = s.T, w = s.w, JP = s.JP;
+  const int nwg = s.N * G, per = (nwg + 7) / 8;
+  const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (wg >= nwg || (int)(blockIdx.x >> 3) >= per) return;
+  const int n = wg / G, g0 = wg % G;
+  {
+    const int W4c = w / 4;
+    const uint16_t* qh = a.sv.Qh + (size_t)n * 2 * W4c * 32 * 4;
+    for (int e = tid; e < 2 * 2 * NKS * 2 * 64; e += 512) {
+      const int ln = e & 63, jt = (e >> 6) & 1, ks = (e >> 7) % (2 * NKS), pc = (e >> 7) / (2 * NKS);
+      const int j = (ln & 15) + 16 * jt, q4 = ln >> 4;
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x2 x0 = *reinterpret_cast<const u32x2*>(qh + (((size_t)pc * W4c + 8 * ks + q4) * 32 + j) * 4);
+      const u32x2 x1 = *reinterpret_cast<const u32x2*>(qh + (((size_t)pc * W4c + 8 * ks + 4 + q4) * 32 + j) * 4);
+      const u32x4 xx = __builtin_shufflevector(x0, x1, 0, 1, 2, 3);
+      (pc == 0 ? s_qhi : s_qlo)[ks][jt][ln] = __builtin_bit_cast(half8, xx);
+    }
+    for (int c = tid; c < w; c += 512) {
+      s_vec[c] = a.sv.vecs[VEC_RH * w + c];
+      s_vec[w + c] = a.sv.vecs[VEC_R2 * w + c];
+    }
+    if (tid < 32) s_ct[tid] = a.sv.ct[(size_t)n * JP + tid];
+  }
+  const uint64_t qvalid = a.sv.qvalid[(size_t)n * 2];
+  const int nitems_n = s.K * s.nsplit;
+  // tiles of an item (0: empty split)
+  auto item_tiles = [&](int il, int& nk, int& t0, int& t1, int& cnt) {
+    const int k = il / s.nsplit, split = il % s.nsplit;
+    nk = n * s.K + k;
+    cnt = a.sv.cnt[nk];
+    const int tiles_total = (cnt + 15) >> 4;
+    const int tiles_per = (tiles_total + s.nsplit - 1) / s.nsplit;
+    t0 = split * tiles_per;
+    t1 = min(tiles_total, t0 + tiles_per);
+    return max(0, t1 - t0);
+  };
+  if (hv == 0 && lane == 0) {
+    int tot = 0;
+    for (int il = g0 + G * pair; il < nitems_n; il += 4 * G) {
+      int nk, t0, t1, cnt;
+      tot += item_tiles(il, nk, t0, t1, cnt);
+    }
+    s_tiles[pair] = tot;
+  }
+  __syncthreads();
+  const int rounds = max(max(s_tiles[0], s_tiles[1]), max(s_tiles[2], s_tiles[3]));
+
+  // ---- the pair's tile stream
+  int il = g0 + G * pair - 4 * G;  // advanced to the first non-empty item below
+  int nk = 0, t0 = 0, t1 = 0, cnt = 0, tl = 0;
+  bool active = false, allm = false;
+  const float* hbase = nullptr;
+  const int32_t* idx = nullptr;
+  float* part = nullptr;
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x4 u[NU];
+  f32x4 h[NBH];
+  int t_cur = 0;
+  bool v_cur = false;
+  const int coff = 16 * NBH * hv + 4 * kq;  // this lane's first channel: block b of the wave's half is at coff + 16 b
+  auto next_item = [&]() {  // moves to the pair's next non-empty item and loads its first tile; false: none left
+    for (;;) {
+      il += 4 * G;
+      if (il >= nitems_n) return false;
+      const int ntl = item_tiles(il, nk, t0, t1, cnt);
+      part = a.part + ((size_t)nk * s.nsplit + il % s.nsplit) * (w + 4);
+      if (ntl == 0) {  // empty split
+        if (hv == 0 && lane == 0) {
+          part[0] = -INFINITY;
+          part[1] = 0.f;
+          part[2] = -INFINITY;
+        }
+        continue;
+      }
+      allm = a.sv.allmasked[nk] != 0;
+      hbase = a.hinfo + (size_t)nk * a.hstride;
+      idx = a.sv.idx + (size_t)nk * T;
+      m_run = -INFINITY;
+      l_run = 0.f;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      tl = t0;
+      const int lr = t0 * 16 + l15;
+      v_cur = lr < cnt;
+      t_cur = v_cur ? idx[lr] : 0;
+      const float* rowp = hbase + (size_t)t_cur * w + coff;
+#pragma unroll
+      for (int b = 0; b < NBH; ++b) h[b] = *reinterpret_cast<const f32x4*>(rowp + 16 * b);
+      return true;
+    }
+  };
+  active = next_item();
+
+  for (int g = 0; g < rounds; ++g) {
+    lds_barrier();  // every wave is done with the previous round's exchange area
+    const bool rvalid = v_cur;
+    const int t = t_cur;
+    float xown[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xown[i] = 0.f;
+    if (active && !allm) {
+      f32x4 ahh[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 axx[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 rt4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int c0 = coff + 16 * (2 * ks + q);
+          const f32x4 hv4 = h[2 * ks + q];
+          if (RMODE == 1)
+            rt4 += hv4 * *reinterpret_cast<const f32x4*>(&s_vec[c0]);
+          else if (RMODE == 2)
+            rt4 += (hv4 * hv4) * *reinterpret_cast<const f32x4*>(&s_vec[w + c0]);
+          else
+            rt4 += hv4 * (*reinterpret_cast<const f32x4*>(&s_vec[c0]) + *reinterpret_cast<const f32x4*>(&s_vec[w + c0]) * hv4);
+        }
+        half8 hi, lo;
+        split_f16x8(h[2 * ks], h[2 * ks + 1], hi, lo);
+        const int kg = NKS * hv + ks;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          const half8 bh = s_qhi[kg][jt][lane];
+          ahh[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, bh, ahh[jt], 0, 0, 0);
+          axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, s_qlo[kg][jt][lane], axx[jt], 0, 0, 0);
+          axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, bh, axx[jt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float rtp = (rt4[0] + rt4[1]) + (rt4[2] + rt4[3]);
+      rtp += __shfl_xor(rtp, 16, 64);
+      rtp += __shfl_xor(rtp, 32, 64);
+      if (kq == 0) s_rt[wave][l15] = rtp;
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          xown[jt * 4 + i] = ahh[jt][i] + axx[jt][i] * (1.f / 2048.f);
+          s_x[wave][(jt * 4 + i) * 64 + lane] = xown[jt * 4 + i];
+        }
+    }
+    lds_barrier();  // both halves of every tile are published
+    if (active) {
+      float am = rvalid ? FVTA_NEG : -INFINITY;
+      if (!allm) {
+        const int pw = wave ^ 1;
+        float amr[4];
+        int jmr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float rti = s_rt[wave][4 * kq + i] + s_rt[pw][4 * kq + i];
+          float best = -INFINITY;
+          int bestj = 0;
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            const int j = l15 + 16 * jt;
+            const int pi = (jt * 4 + i) * 64 + lane;
+            // (own + partner: floating-point addition commutes, so both waves of the pair get bit-identical sums)
+            const float x = (xown[jt * 4 + i] + s_x[pw][pi]) + rti + s_ct[j];
+            if (((qvalid >> j) & 1ull) && x > best) {
+              best = x;
+              bestj = j;
+            }
+          }
+          row16_argmax(best, bestj);
+          amr[i] = best;
+          jmr[i] = bestj;
+        }
+        const int src = ((l15 >> 2) << 4) | l15;
+        float bestv = 0.f;
+        int bestj = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = __shfl(amr[i], src, 64);
+          const int jj = __shfl(jmr[i], src, 64);
+          if ((l15 & 3) == i) {
+            bestv = v;
+            bestj = jj;
+          }
+        }
+        am = rvalid ? (s.add_tanh ? fvta_tanh(bestv) : bestv) : -INFINITY;
+        if (hv == 0 && kq == 0 && rvalid) {
+          a.sv.amax[(size_t)nk * T + t] = am;
+          a.sv.jmax[(size_t)nk * T + t] = (uint8_t)bestj;
+        }
+      }
+      const float m_new = fmaxf(m_run, row16_max(am));
+      const float scale = expf(m_run - m_new);
+      const float pr = expf(am - m_new);
+      l_run = l_run * scale + row16_sum(pr);
+      m_run = m_new;
+      if (scale != 1.f) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] *= scale;
+      }
+      const bool has_next = tl + 1 < t1;
+      if (has_next) {
+        const int lrn = (tl + 1) * 16 + l15;
+        const bool v_next = lrn < cnt;
+        const int t_next = v_next ? idx[lrn] : 0;
+        const float* rowp_next = hbase + (size_t)t_next * w + coff;
+#pragma unroll
+        for (int b = 0; b < NBH; ++b) {
+          f32x4 v = h[b] * pr;
+          h[b] = *reinterpret_cast<const f32x4*>(rowp_next + 16 * b);
+          row16_sum4(v);
+          if ((b & 15) == l15) u[b >> 4] += v;
+        }
+        t_cur = t_next;
+        v_cur = v_next;
+        ++tl;
+      } else {
+#pragma unroll
+        for (int b = 0; b < NBH; ++b) {
+          f32x4 v = h[b] * pr;
+          row16_sum4(v);
+          if ((b & 15) == l15) u[b >> 4] += v;
+        }
+        // the item's partial (m, l, u): lane (l15, kq) holds channels coff + 16 (16 i + l15) + (0..3)
+#pragma unroll
+        for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(part + 4 + coff + 16 * (16 * i + l15)) = u[i];
+        if (hv == 0 && lane == 0) {
+          part[0] = m_run;
+          part[1] = l_run;
+          part[2] = m_run;
+        }
+        active = next_item();
+      }
+    }
+  }
+}
+
 // ---- time_warp_att only: the MASKED rows of a (n,k) that has valid rows.  The reference scales the max-pooled logit
 // AFTER exp_mask (model_v2.py:263-275), so a masked row's softmax logit is -1e30 * tscale[n,t]: hugely negative for
 // tscale > 0 (weight exactly 0, as exp underflows), but +huge for tscale < 0 -- then the masked rows take the whole
@@ -1450,7 +1709,34 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   // FVTA_ATTN_WAVE16: the one-wave-per-tile kernel for the shapes it covers (measurement switch)
   const char* w16 = getenv("FVTA_ATTN_WAVE16");  // (read per call, like FVTA_ATTN_EXACT: the tests flip it)
   const int wave16_mode = w16 ? atoi(w16) : FVTA_ATTN_WAVE16_DEFAULT;
-  if (rows16 && wave16_mode && s.simi != 4 && s.w >= 256) {
+  if (rows16 && wave16_mode == 2 && s.simi != 4 && s.w >= 512) {  // two waves per tile (attn_fwd_pair16)
+    int G = (256 + s.N - 1) / s.N;
+    const int maxg = (s.K * s.nsplit + 3) / 4;
+    if (G > maxg) G = maxg;
+    if (G < 1) G = 1;
+    const int nwg = s.N * G;
+    const dim3 grid(((nwg + 7) / 8) * 8);
+    const int rmode = s.simi == 1 ? 1 : (s.simi == 3 ? 3 : 2);
+#define FVTA_P16(NBH)                                                                                                    \
+  do {                                                                                                                   \
+    const size_t lds = (size_t)2 * 2 * (NBH / 2) * 2 * 64 * 16 + (size_t)2 * s.w * sizeof(float);                        \
+    if (rmode == 1) {                                                                                                    \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_pair16<NBH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((attn_fwd_pair16<NBH, 1>), grid, dim3(512), lds, stream, a, G);                                \
+    } else if (rmode == 2) {                                                                                             \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_pair16<NBH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((attn_fwd_pair16<NBH, 2>), grid, dim3(512), lds, stream, a, G);                                \
+    } else {                                                                                                             \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_pair16<NBH, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      hipLaunchKernelGGL((attn_fwd_pair16<NBH, 3>), grid, dim3(512), lds, stream, a, G);                                \
+    }                                                                                                                    \
+  } while (0)
+    switch (s.w) {
+      case 512: FVTA_P16(16); break;
+      case 1024: FVTA_P16(32); break;
+    }
+#undef FVTA_P16
+  } else if (rows16 && wave16_mode && s.simi != 4 && s.w >= 256) {
     int G = (256 + s.N - 1) / s.N;
     const int maxg = (s.K * s.nsplit + 3) / 4;
     if (G > maxg) G = maxg;

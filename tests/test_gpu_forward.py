@@ -247,8 +247,10 @@ def test_attention_fast_path_randomised_differential(monkeypatch):
         np.testing.assert_allclose(amax_f[ok].numpy(), amax_e[ok].numpy(), rtol=5e-5, atol=5e-6, err_msg=tag + " amax")
 
 
-def test_attention_wave16_kernel_randomised_differential(monkeypatch):
-    """FVTA_ATTN_WAVE16=1: the one-wave-per-tile forward kernel (attn_fwd_wave16) on random shapes / maskings / stream
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_attention_wave16_kernel_randomised_differential(monkeypatch, mode):
+    """FVTA_ATTN_WAVE16=1 / 2: the one-wave-per-tile (attn_fwd_wave16) and two-waves-per-tile (attn_fwd_pair16: w >= 512,
+    else the former) forward kernels on random shapes / maskings / stream
     lengths against the exact-fp32 kernel -- values, saved max-pooled logits and arg-max positions -- and against itself
     (bitwise reproducible); then the backward pass on ITS saved state against the backward on the exact kernel's."""
     from fvta_memexqa_amd import ops
@@ -266,7 +268,7 @@ def test_attention_wave16_kernel_randomised_differential(monkeypatch):
         op = ops.FocalAttention(N, K, T, JQ, w, simi, tanh)
         args = (cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)), cu(W.reshape(-1)), cu(b))
         monkeypatch.delenv("FVTA_ATTN_EXACT", raising=False)
-        monkeypatch.setenv("FVTA_ATTN_WAVE16", "1")
+        monkeypatch.setenv("FVTA_ATTN_WAVE16", mode)
         fast, _ = op.forward(*args)
         fast, saved_fast = fast.cpu(), op.saved.clone()
         again, _ = op.forward(*args)
