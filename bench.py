@@ -326,7 +326,9 @@ def main():
         # (the library's profile bracket covers the context attention only, not the K = 1 question attention)
         per_step_ms = ms_a / args.steps
         gbs = att_bytes / (per_step_ms * 1e-3) / 1e9
-        roof_att = dict(kernel=("attn_fwd_rows16" if (L.JQ <= 32 and 128 <= model.wp <= 1024) else "attn_fwd_main") + " (fvta_attn_fwd main kernel)", bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+        roof_att = dict(kernel=(("attn_fwd_pair16" if model.wp >= 512 and model.simi != 4 and os.environ.get("FVTA_ATTN_WAVE16", "2") == "2"
+                                 else "attn_fwd_rows16") if (L.JQ <= 32 and 128 <= model.wp <= 1024) else "attn_fwd_main")
+                        + " (fvta_attn_fwd main kernel)", bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                         frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, algorithmic_bytes=att_bytes,
                         ms_per_step=round(per_step_ms, 4))
     # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of

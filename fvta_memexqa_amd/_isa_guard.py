@@ -66,4 +66,16 @@ def check(hipcc="/opt/rocm/bin/hipcc", src=SRC):
             # where the stream is too short for those buffers ever to be loaded
             ok = i < first_barrier and re.match(r"v_mov_b32_e32 v(19[2-9]|2[0-4]\d|25[0-5]), (0|v\d+)$", l)
             need(ok, "%s line %d: %s" % (name, i, l))
+    # The two-waves-per-tile kernel (attn_fwd_pair16, the default for w >= 512) holds half a tile in registers at two
+    # waves per SIMD: compiler-allocated, but only worth running while the allocation stays spill-free (the same loop
+    # body wrapped in a generic lambda once spilled 1.1 KB per lane and ran 4x slower).
+    pair = re.findall(r"^(_ZN4fvta15attn_fwd_pair16\w*):", txt, re.M)
+    if len(pair) < 6:
+        raise IsaGuardError("expected >= 6 attn_fwd_pair16 instantiations, found %d" % len(pair))
+    for name in pair:
+        a = txt.index(name + ":")
+        body = txt[a:txt.index("s_endpgm", a)]
+        if "scratch_" in body:
+            raise IsaGuardError("%s spills to scratch; compiler: %s.  Work-around: FVTA_ATTN_WAVE16=0 selects "
+                                "attn_fwd_rows16." % (name, hipcc_version(hipcc)))
     return len(names)

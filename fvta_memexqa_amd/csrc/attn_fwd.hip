@@ -15,7 +15,7 @@ namespace fvta {
 
 __device__ __forceinline__ f32x4 ld4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 #ifndef FVTA_ATTN_WAVE16_DEFAULT
-#define FVTA_ATTN_WAVE16_DEFAULT 0
+#define FVTA_ATTN_WAVE16_DEFAULT 2
 #endif
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -1305,6 +1305,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
   };
   active = next_item();
 
+#pragma unroll 2
   for (int g = 0; g < rounds; ++g) {
     lds_barrier();  // every wave is done with the previous round's exchange area
     const bool rvalid = v_cur;
