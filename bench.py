@@ -352,8 +352,8 @@ def main():
         roof["traffic"] = pmc_traffic("r02_lstm_pmc.json", "lstm_step_fwd_bf16")
         roof["traffic_note"] = "bytes per launch, profiles/r02_lstm_pmc.json; algorithmic per launch = algorithmic_bytes_per_call / 30"
     if roof_att is not None and dense_metric:
-        roof_att["traffic"] = pmc_traffic("r02_attention_pmc.json", "attn_fwd_rows16")
-        roof_att["traffic_note"] = "bytes per launch, profiles/r02_attention_pmc.json"
+        roof_att["traffic"] = pmc_traffic("r02c_attention_pmc.json", "attn_fwd_pair16")
+        roof_att["traffic_note"] = "bytes per launch, profiles/r02c_attention_pmc.json"
     out = dict(
         metric="QA-pairs/sec (fwd+bwd) at B=64, 40 photos x 5 streams x 30 tok, h=512" if args.config == "metric" and not args.forward_only
         and args.graph == "fvta" else "QA-pairs/sec (model.py graph, %s, config %s)" % ("fwd" if args.forward_only else "fwd+bwd", args.config)
