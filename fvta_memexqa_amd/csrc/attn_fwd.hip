@@ -1193,7 +1193,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_wave16(AttnFwdArgs a, int G) 
 // Against attn_fwd_rows16 (eight waves per tile): a 2-way instead of an 8-way reduction, four independent tile streams
 // per workgroup, and a quarter of the barriers per byte; against attn_fwd_wave16: a second wave per SIMD to cover the
 // first one's latencies.  The pairs of a workgroup run the same number of barrier rounds (the longest pair's tile count).
-template <int NBH, int RMODE>
+// FLAGS: the two waves of a pair synchronise through LDS flags (published / consumed round numbers, polled with s_sleep)
+// instead of workgroup barriers, so the four pairs of a workgroup drift apart freely (the polls are bounded: a broken
+// hand-shake gives wrong numbers, never a hung GPU).
+template <int NBH, int RMODE, bool FLAGS = false>
 __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) {
   constexpr int NKS = NBH / 2;   // MFMA steps over a wave's half of the channels
   constexpr int NU = NBH / 16;   // accumulator registers (float4) per lane
@@ -1206,6 +1209,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
   __shared__ __attribute__((aligned(16))) float s_x[8][8 * 64];  // per wave: its partial scores [jt * 4 + i][lane]
   __shared__ float s_rt[8][16];                                  // per wave: its partial row terms
   __shared__ int s_tiles[4];
+  __shared__ int s_pub[8], s_done[8];  // FLAGS: last round whose partials a wave has published / whose partner data it has consumed
 
   const AttnShape& s = a.s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1256,8 +1260,19 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
     }
     s_tiles[pair] = tot;
   }
+  if (tid < 8) {
+    s_pub[tid] = 0;
+    s_done[tid] = 0;
+  }
   __syncthreads();
-  const int rounds = max(max(s_tiles[0], s_tiles[1]), max(s_tiles[2], s_tiles[3]));
+  const int rounds = FLAGS ? s_tiles[pair] : max(max(s_tiles[0], s_tiles[1]), max(s_tiles[2], s_tiles[3]));
+  const int pwv = wave ^ 1;
+  auto wait_flag = [&](volatile int* flag, int want) {  // bounded poll of an LDS word
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+      if (*flag >= want) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+  };
 
   // ---- the pair's tile stream
   int il = g0 + G * pair - 4 * G;  // advanced to the first non-empty item below
@@ -1307,7 +1322,10 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
 
 #pragma unroll 2
   for (int g = 0; g < rounds; ++g) {
-    lds_barrier();  // every wave is done with the previous round's exchange area
+    if (FLAGS)
+      wait_flag(&s_done[pwv], g);  // the partner has read my partials of round g - 1 (rounds are numbered from 1)
+    else
+      lds_barrier();  // every wave is done with the previous round's exchange area
     const bool rvalid = v_cur;
     const int t = t_cur;
     float xown[8];
@@ -1354,7 +1372,13 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
           s_x[wave][(jt * 4 + i) * 64 + lane] = xown[jt * 4 + i];
         }
     }
-    lds_barrier();  // both halves of every tile are published
+    if (FLAGS) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my partials are in LDS (a wave's LDS operations complete in order)
+      if (lane == 0) *(volatile int*)&s_pub[wave] = g + 1;
+      wait_flag(&s_pub[pwv], g + 1);
+    } else {
+      lds_barrier();  // both halves of every tile are published
+    }
     if (active) {
       float am = rvalid ? FVTA_NEG : -INFINITY;
       if (!allm) {
@@ -1398,6 +1422,10 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
           a.sv.amax[(size_t)nk * T + t] = am;
           a.sv.jmax[(size_t)nk * T + t] = (uint8_t)bestj;
         }
+      }
+      if (FLAGS) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the partner's partials are in my registers
+        if (lane == 0) *(volatile int*)&s_done[wave] = g + 1;
       }
       const float m_new = fmaxf(m_run, row16_max(am));
       const float scale = expf(m_run - m_new);
@@ -1710,7 +1738,8 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   // FVTA_ATTN_WAVE16: the one-wave-per-tile kernel for the shapes it covers (measurement switch)
   const char* w16 = getenv("FVTA_ATTN_WAVE16");  // (read per call, like FVTA_ATTN_EXACT: the tests flip it)
   const int wave16_mode = w16 ? atoi(w16) : FVTA_ATTN_WAVE16_DEFAULT;
-  if (rows16 && wave16_mode == 2 && s.simi != 4 && s.w >= 512) {  // two waves per tile (attn_fwd_pair16)
+  if (rows16 && (wave16_mode == 2 || wave16_mode == 3) && s.simi != 4 && s.w >= 512) {  // two waves per tile (attn_fwd_pair16)
+    const bool flags = wave16_mode == 3;
     int G = (256 + s.N - 1) / s.N;
     const int maxg = (s.K * s.nsplit + 3) / 4;
     if (G > maxg) G = maxg;
@@ -1718,24 +1747,25 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
     const int nwg = s.N * G;
     const dim3 grid(((nwg + 7) / 8) * 8);
     const int rmode = s.simi == 1 ? 1 : (s.simi == 3 ? 3 : 2);
+#define FVTA_P16K(NBH, RM, FL)                                                                                          \
+  do {                                                                                                                   \
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pair16<NBH, RM, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((attn_fwd_pair16<NBH, RM, FL>), grid, dim3(512), lds, stream, a, G);                             \
+  } while (0)
 #define FVTA_P16(NBH)                                                                                                    \
   do {                                                                                                                   \
     const size_t lds = (size_t)2 * 2 * (NBH / 2) * 2 * 64 * 16 + (size_t)2 * s.w * sizeof(float);                        \
-    if (rmode == 1) {                                                                                                    \
-      (void)hipFuncSetAttribute((const void*)attn_fwd_pair16<NBH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((attn_fwd_pair16<NBH, 1>), grid, dim3(512), lds, stream, a, G);                                \
-    } else if (rmode == 2) {                                                                                             \
-      (void)hipFuncSetAttribute((const void*)attn_fwd_pair16<NBH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((attn_fwd_pair16<NBH, 2>), grid, dim3(512), lds, stream, a, G);                                \
+    if (flags) {                                                                                                         \
+      if (rmode == 1) FVTA_P16K(NBH, 1, true); else if (rmode == 2) FVTA_P16K(NBH, 2, true); else FVTA_P16K(NBH, 3, true); \
     } else {                                                                                                             \
-      (void)hipFuncSetAttribute((const void*)attn_fwd_pair16<NBH, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      hipLaunchKernelGGL((attn_fwd_pair16<NBH, 3>), grid, dim3(512), lds, stream, a, G);                                \
+      if (rmode == 1) FVTA_P16K(NBH, 1, false); else if (rmode == 2) FVTA_P16K(NBH, 2, false); else FVTA_P16K(NBH, 3, false); \
     }                                                                                                                    \
   } while (0)
     switch (s.w) {
       case 512: FVTA_P16(16); break;
       case 1024: FVTA_P16(32); break;
     }
+#undef FVTA_P16K
 #undef FVTA_P16
   } else if (rows16 && wave16_mode && s.simi != 4 && s.w >= 256) {
     int G = (256 + s.N - 1) / s.N;

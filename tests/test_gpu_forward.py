@@ -247,7 +247,7 @@ def test_attention_fast_path_randomised_differential(monkeypatch):
         np.testing.assert_allclose(amax_f[ok].numpy(), amax_e[ok].numpy(), rtol=5e-5, atol=5e-6, err_msg=tag + " amax")
 
 
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1", "2", "3"])
 def test_attention_wave16_kernel_randomised_differential(monkeypatch, mode):
     """FVTA_ATTN_WAVE16=1 / 2: the one-wave-per-tile (attn_fwd_wave16) and two-waves-per-tile (attn_fwd_pair16: w >= 512,
     else the former) forward kernels on random shapes / maskings / stream

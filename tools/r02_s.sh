@@ -5,4 +5,4 @@ timeout 600 python -m pytest tests/test_gpu_forward.py -m gpu -x -q -k "wave16" 
 run() { python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], d['kernel_ms_per_step']['attn_fwd_main'], d['roofline_attention']['frac'])"; }
-for v in 0 1 2 0 2; do FVTA_ATTN_WAVE16=$v run "wave16=$v"; done
+for v in 0 2 3 0 2 3; do FVTA_ATTN_WAVE16=$v run "wave16=$v"; done
