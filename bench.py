@@ -326,7 +326,7 @@ def main():
         # (the library's profile bracket covers the context attention only, not the K = 1 question attention)
         per_step_ms = ms_a / args.steps
         gbs = att_bytes / (per_step_ms * 1e-3) / 1e9
-        roof_att = dict(kernel=(("attn_fwd_pair16" if model.wp >= 512 and model.simi != 4 and os.environ.get("FVTA_ATTN_WAVE16", "2") == "2"
+        roof_att = dict(kernel=(("attn_fwd_pair16" if model.wp >= 512 and model.simi != 4 and os.environ.get("FVTA_ATTN_WAVE16", "3") in ("2", "3")
                                  else "attn_fwd_rows16") if (L.JQ <= 32 and 128 <= model.wp <= 1024) else "attn_fwd_main")
                         + " (fvta_attn_fwd main kernel)", bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                         frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, algorithmic_bytes=att_bytes,

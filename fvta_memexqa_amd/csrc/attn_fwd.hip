@@ -15,7 +15,7 @@ namespace fvta {
 
 __device__ __forceinline__ f32x4 ld4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 #ifndef FVTA_ATTN_WAVE16_DEFAULT
-#define FVTA_ATTN_WAVE16_DEFAULT 2
+#define FVTA_ATTN_WAVE16_DEFAULT 3
 #endif
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
