@@ -1267,12 +1267,17 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
   __syncthreads();
   const int rounds = FLAGS ? s_tiles[pair] : max(max(s_tiles[0], s_tiles[1]), max(s_tiles[2], s_tiles[3]));
   const int pwv = wave ^ 1;
-  auto wait_flag = [&](volatile int* flag, int want) {  // bounded poll of an LDS word
+  // (the flags are accessed through LDS-address-space pointers: through a generic pointer the compiler emits FLAT
+  //  loads/stores, whose s_waitcnt vmcnt(0) would also wait for every outstanding load of the next tile)
+  typedef __attribute__((address_space(3))) int lds_int;
+  auto wait_flag = [&](int* flag, int want) {  // bounded poll of an LDS word
+    volatile lds_int* f = (volatile lds_int*)flag;
     for (int spin = 0; spin < (1 << 22); ++spin) {
-      if (*flag >= want) break;
+      if (*f >= want) break;
       __builtin_amdgcn_s_sleep(2);
     }
   };
+  auto post_flag = [&](int* flag, int v) { *(volatile lds_int*)flag = v; };
 
   // ---- the pair's tile stream
   int il = g0 + G * pair - 4 * G;  // advanced to the first non-empty item below
@@ -1322,10 +1327,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
 
 #pragma unroll 2
   for (int g = 0; g < rounds; ++g) {
-    if (FLAGS)
-      wait_flag(&s_done[pwv], g);  // the partner has read my partials of round g - 1 (rounds are numbered from 1)
-    else
-      lds_barrier();  // every wave is done with the previous round's exchange area
+    if (!FLAGS) lds_barrier();  // every wave is done with the previous round's exchange area
     const bool rvalid = v_cur;
     const int t = t_cur;
     float xown[8];
@@ -1363,6 +1365,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
       float rtp = (rt4[0] + rt4[1]) + (rt4[2] + rt4[3]);
       rtp += __shfl_xor(rtp, 16, 64);
       rtp += __shfl_xor(rtp, 32, 64);
+      if (FLAGS) wait_flag(&s_done[pwv], g);  // the partner has read my partials of round g - 1 (rounds are numbered from 1)
       if (kq == 0) s_rt[wave][l15] = rtp;
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt)
@@ -1374,7 +1377,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
     }
     if (FLAGS) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my partials are in LDS (a wave's LDS operations complete in order)
-      if (lane == 0) *(volatile int*)&s_pub[wave] = g + 1;
+      if (lane == 0) post_flag(&s_pub[wave], g + 1);
       wait_flag(&s_pub[pwv], g + 1);
     } else {
       lds_barrier();  // both halves of every tile are published
@@ -1425,7 +1428,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
       }
       if (FLAGS) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the partner's partials are in my registers
-        if (lane == 0) *(volatile int*)&s_done[wave] = g + 1;
+        if (lane == 0) post_flag(&s_done[wave], g + 1);
       }
       const float m_new = fmaxf(m_run, row16_max(am));
       const float scale = expf(m_run - m_new);
