@@ -24,9 +24,15 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_f16x2(float x0, float x1, half2v& hi, half2v& lo) {
   hi = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-  const f32x2 x = {x0, x1}, hf = {(float)hi[0], (float)hi[1]};
-  const f32x2 r = (x - hf) * 2048.f;  // packed fp32 ops: one v_pk_add + one v_pk_mul per pair
-  lo = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(r[0], r[1]));
+  // lo = fp16((x - hi) * 2048) as ONE mixed-precision FMA per element, 2048 x - 2048 hi with the fp16 hi read in place
+  // (v_fma_mixlo/mixhi_f16 write one half of the destination and keep the other): 4 instructions per pair instead of 6
+  // (2 back-conversions, packed subtract, packed scale, pack).  Exact up to the final rounding, as before (x - hi is exact).
+  const f32x2 xs = f32x2{x0, x1} * 2048.f;
+  const float m2048 = -2048.f;
+  unsigned hw = __builtin_bit_cast(unsigned, hi), lw;
+  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=&v"(lw) : "v"(hw), "s"(m2048), "v"(xs[0]));
+  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw) : "v"(hw), "s"(m2048), "v"(xs[1]));
+  lo = __builtin_bit_cast(half2v, lw);
 }
 __device__ __forceinline__ half8 cat_h2(half2v a, half2v b, half2v c, half2v d) {
   const half4v ab = __builtin_shufflevector(a, b, 0, 1, 2, 3), cd = __builtin_shufflevector(c, d, 0, 1, 2, 3);
@@ -1209,7 +1215,16 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
   __shared__ __attribute__((aligned(16))) float s_x[8][8 * 64];  // per wave: its partial scores [jt * 4 + i][lane]
   __shared__ float s_rt[8][16];                                  // per wave: its partial row terms
   __shared__ int s_tiles[4];
+  __shared__ int s_kstart[65], s_kcnt[64], s_kall[64], s_flat;  // the n's streams: first flat tile, valid rows, fully masked
   __shared__ int s_pub[8], s_done[8];  // FLAGS: last round whose partials a wave has published / whose partner data it has consumed
+#ifdef FVTA_DIAG
+  // FVTA_ATTN_DBG & 16: wave `dbg >> 8` of workgroup 0 stamps the shader clock at the phase boundaries of its first 32
+  // rounds (into LDS, dumped 32 MiB into the workspace at the end) -- tools/attn_phases.py
+  __shared__ unsigned long long s_stamp[32][8];
+#define FVTA_PSTAMP(k) do { if (pstamp && g < 32) s_stamp[g][(k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FVTA_PSTAMP(k) do { } while (0)
+#endif
 
   const AttnShape& s = a.s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1220,6 +1235,18 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
   const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (wg >= nwg || (int)(blockIdx.x >> 3) >= per) return;
   const int n = wg / G, g0 = wg % G;
+  // -DFVTA_PAIR_ABL=bits: compile-time ablations (timing only, results are wrong; a run-time switch makes the compiler
+  // spill): 1 no tile loads after an item's first, 2 no score MFMA loop, 4 no weighted sum (refill only), 8 no pair
+  // hand-shake -- tools/r02_v.sh
+#ifdef FVTA_PAIR_ABL
+  constexpr int abl = FVTA_PAIR_ABL;
+#else
+  constexpr int abl = 0;
+#endif
+#ifdef FVTA_DIAG
+  const bool pstamp = (a.dbg & 16) && wg == 0 && wave == ((a.dbg >> 8) & 7) && lane == 0;
+  const unsigned long long t_entry = __builtin_readcyclecounter();
+#endif
   {
     const int W4c = w / 4;
     const uint16_t* qh = a.sv.Qh + (size_t)n * 2 * W4c * 32 * 4;
@@ -1241,31 +1268,113 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
   }
   const uint64_t qvalid = a.sv.qvalid[(size_t)n * 2];
   const int nitems_n = s.K * s.nsplit;
-  // tiles of an item (0: empty split)
-  auto item_tiles = [&](int il, int& nk, int& t0, int& t1, int& cnt) {
-    const int k = il / s.nsplit, split = il % s.nsplit;
-    nk = n * s.K + k;
-    cnt = a.sv.cnt[nk];
-    const int tiles_total = (cnt + 15) >> 4;
-    const int tiles_per = (tiles_total + s.nsplit - 1) / s.nsplit;
-    t0 = split * tiles_per;
-    t1 = min(tiles_total, t0 + tiles_per);
-    return max(0, t1 - t0);
-  };
-  if (hv == 0 && lane == 0) {
-    int tot = 0;
-    for (int il = g0 + G * pair; il < nitems_n; il += 4 * G) {
-      int nk, t0, t1, cnt;
-      tot += item_tiles(il, nk, t0, t1, cnt);
+  const int P = 4 * G, pg = 4 * g0 + pair;  // pairs that share this n, this pair's index among them
+  // ---- the streams of this n: valid rows, first tile (in the n's flat tile order), fully-masked flag
+  if (tid == 64) {
+    int acc = 0;
+    for (int k = 0; k < s.K; ++k) {
+      const int c = a.sv.cnt[n * s.K + k];
+      s_kcnt[k] = c;
+      s_kall[k] = a.sv.allmasked[n * s.K + k];
+      s_kstart[k] = acc;
+      acc += (c + 15) >> 4;
     }
-    s_tiles[pair] = tot;
+    s_kstart[s.K] = acc;
+    // FLAT dealing: the n's tiles, in (k, tile) order, are cut into P equal runs, one per pair (a run crosses stream
+    // boundaries; pair p's piece of stream k is that stream's partial number p - (first pair that touches k)).  Only if
+    // no stream is cut into more pieces than it has partial slots (nsplit); otherwise the (k, split) items are dealt
+    // round-robin as in the other kernels (pieces of ceil(tiles / nsplit) tiles: unequal sums per pair).
+    int ok = acc > 0;
+    for (int k = 0; k < s.K && ok; ++k) {
+      const int st = s_kstart[k], en = s_kstart[k + 1];
+      if (en > st && ((en * P - 1) / acc) - (((st + 1) * P - 1) / acc) + 1 > s.nsplit) ok = 0;
+    }
+    s_flat = ok;
   }
   if (tid < 8) {
     s_pub[tid] = 0;
     s_done[tid] = 0;
   }
   __syncthreads();
-  const int rounds = FLAGS ? s_tiles[pair] : max(max(s_tiles[0], s_tiles[1]), max(s_tiles[2], s_tiles[3]));
+  const bool flat = s_flat != 0;
+  const int tot = s_kstart[s.K];
+  const int lo = flat ? tot * pg / P : 0, hi = flat ? tot * (pg + 1) / P : 0;  // this pair's run (flat dealing)
+  auto empty_partial = [&](int nk, int split) {
+    float* pp = a.part + ((size_t)nk * s.nsplit + split) * (w + 4);
+    pp[0] = -INFINITY;
+    pp[1] = 0.f;
+    pp[2] = -INFINITY;
+  };
+  if (flat && g0 == 0) {  // the partial slots no pair fills
+    for (int e = tid; e < nitems_n; e += 512) {
+      const int k = e / s.nsplit, sp = e % s.nsplit;
+      const int st = s_kstart[k], en = s_kstart[k + 1];
+      bool filled = false;  // slot sp belongs to pair (first pair that touches k) + sp, if that pair's run meets k at all
+      if (en > st) {
+        const int px = ((st + 1) * P - 1) / tot + sp;
+        filled = px < P && max(tot * px / P, st) < min(tot * (px + 1) / P, en);
+      }
+      if (!filled) empty_partial(n * s.K + k, sp);
+    }
+  }
+  // ---- the pair's pieces ("segments": consecutive tiles [t0, t1) of one stream, summed into one partial)
+  struct Seg {
+    int nk, t0, t1, slot, cnt, allm;
+  };
+  auto item_seg = [&](int il, Seg& sg) {  // round-robin dealing: item il = (k, split)
+    const int k = il / s.nsplit, split = il % s.nsplit;
+    const int c = s_kcnt[k];
+    const int tiles_total = (c + 15) >> 4;
+    const int tiles_per = (tiles_total + s.nsplit - 1) / s.nsplit;
+    sg.nk = n * s.K + k;
+    sg.t0 = split * tiles_per;
+    sg.t1 = min(tiles_total, sg.t0 + tiles_per);
+    sg.slot = split;
+    sg.cnt = c;
+    sg.allm = s_kall[k];
+    return sg.t1 > sg.t0;
+  };
+  int it_k = 0, it_il = g0 + G * pair - 4 * G;
+  auto next_seg = [&](Seg& sg) {  // false: none left
+    if (flat) {
+      while (it_k < s.K) {
+        const int k = it_k++;
+        const int st = s_kstart[k], en = s_kstart[k + 1];
+        if (st >= hi) break;
+        const int x0 = max(lo, st), x1 = min(hi, en);
+        if (x0 < x1) {
+          sg.nk = n * s.K + k;
+          sg.t0 = x0 - st;
+          sg.t1 = x1 - st;
+          sg.slot = pg - ((st + 1) * P - 1) / tot;
+          sg.cnt = s_kcnt[k];
+          sg.allm = s_kall[k];
+          return true;
+        }
+      }
+      it_k = s.K;
+      return false;
+    }
+    for (;;) {
+      it_il += 4 * G;
+      if (it_il >= nitems_n) return false;
+      if (item_seg(it_il, sg)) return true;
+      if (hv == 0 && lane == 0) empty_partial(sg.nk, sg.slot);  // empty split
+    }
+  };
+  int myrounds = hi - lo;
+  if (!flat) {
+    myrounds = 0;
+    Seg sg;
+    for (int il = g0 + G * pair; il < nitems_n; il += 4 * G)
+      if (item_seg(il, sg)) myrounds += sg.t1 - sg.t0;
+  }
+  int rounds = myrounds;
+  if (!FLAGS) {  // the barrier version runs every pair for the longest pair's number of rounds
+    if (hv == 0 && lane == 0) s_tiles[pair] = myrounds;
+    __syncthreads();
+    rounds = max(max(s_tiles[0], s_tiles[1]), max(s_tiles[2], s_tiles[3]));
+  }
   const int pwv = wave ^ 1;
   // (the flags are accessed through LDS-address-space pointers: through a generic pointer the compiler emits FLAT
   //  loads/stores, whose s_waitcnt vmcnt(0) would also wait for every outstanding load of the next tile)
@@ -1279,61 +1388,63 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
   };
   auto post_flag = [&](int* flag, int v) { *(volatile lds_int*)flag = v; };
 
-  // ---- the pair's tile stream
-  int il = g0 + G * pair - 4 * G;  // advanced to the first non-empty item below
-  int nk = 0, t0 = 0, t1 = 0, cnt = 0, tl = 0;
-  bool active = false, allm = false;
-  const float* hbase = nullptr;
-  const int32_t* idx = nullptr;
-  float* part = nullptr;
+  // ---- the pair's tile stream: the CURRENT tile is in h[], the NEXT tile's identity and row numbers are known one
+  // round ahead (its rows replace the current tile's registers during the weighted sum, also across a stream boundary)
+  Seg cs = {0, 0, 0, 0, 0, 0}, ns = {0, 0, 0, 0, 0, 0};
+  int ctl = 0, ntl = 0;  // tile numbers within their streams
+  int t_cur = 0, t_nxt = 0;
+  bool v_cur = false, v_nxt = false;
   float m_run = -INFINITY, l_run = 0.f;
   f32x4 u[NU];
   f32x4 h[NBH];
-  int t_cur = 0;
-  bool v_cur = false;
+#pragma unroll
+  for (int i = 0; i < NU; ++i) u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int coff = 16 * NBH * hv + 4 * kq;  // this lane's first channel: block b of the wave's half is at coff + 16 b
-  auto next_item = [&]() {  // moves to the pair's next non-empty item and loads its first tile; false: none left
-    for (;;) {
-      il += 4 * G;
-      if (il >= nitems_n) return false;
-      const int ntl = item_tiles(il, nk, t0, t1, cnt);
-      part = a.part + ((size_t)nk * s.nsplit + il % s.nsplit) * (w + 4);
-      if (ntl == 0) {  // empty split
-        if (hv == 0 && lane == 0) {
-          part[0] = -INFINITY;
-          part[1] = 0.f;
-          part[2] = -INFINITY;
-        }
-        continue;
-      }
-      allm = a.sv.allmasked[nk] != 0;
-      hbase = a.hinfo + (size_t)nk * a.hstride;
-      idx = a.sv.idx + (size_t)nk * T;
-      m_run = -INFINITY;
-      l_run = 0.f;
-#pragma unroll
-      for (int i = 0; i < NU; ++i) u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      tl = t0;
-      const int lr = t0 * 16 + l15;
-      v_cur = lr < cnt;
-      t_cur = v_cur ? idx[lr] : 0;
-      const float* rowp = hbase + (size_t)t_cur * w + coff;
-#pragma unroll
-      for (int b = 0; b < NBH; ++b) h[b] = *reinterpret_cast<const f32x4*>(rowp + 16 * b);
+  // (an invalid row of a stream's last tile reads the stream's last valid row: finite data, weight 0.  No select on
+  //  the loaded value: the load's destination is the loop-carried register, nothing waits for it before its use)
+  auto rows_of = [&](const Seg& sg, int tl, int& t, bool& v) {
+    const int lr = tl * 16 + l15;
+    v = lr < sg.cnt;
+    t = a.sv.idx[(size_t)sg.nk * T + max(min(lr, sg.cnt - 1), 0)];
+  };
+  auto tile_after = [&](const Seg& from, int ftl, Seg& to, int& ttl) {
+    if (ftl + 1 < from.t1) {
+      to = from;
+      ttl = ftl + 1;
       return true;
     }
+    if (next_seg(to)) {
+      ttl = to.t0;
+      return true;
+    }
+    return false;
   };
-  active = next_item();
+  bool active = next_seg(cs), has_n = false;
+  if (active) {
+    ctl = cs.t0;
+    rows_of(cs, ctl, t_cur, v_cur);
+    const float* rowp = a.hinfo + (size_t)cs.nk * a.hstride + (size_t)t_cur * w + coff;
+#pragma unroll
+    for (int b = 0; b < NBH; ++b) h[b] = *reinterpret_cast<const f32x4*>(rowp + 16 * b);
+    has_n = tile_after(cs, ctl, ns, ntl);
+    if (!has_n) {
+      ns = cs;
+      ntl = ctl;
+    }
+    rows_of(ns, ntl, t_nxt, v_nxt);  // (unconditional: without a next tile it re-reads the current tile's row numbers)
+  }
 
 #pragma unroll 2
   for (int g = 0; g < rounds; ++g) {
+    FVTA_PSTAMP(0);
     if (!FLAGS) lds_barrier();  // every wave is done with the previous round's exchange area
     const bool rvalid = v_cur;
     const int t = t_cur;
+    const bool allm = cs.allm != 0;
     float xown[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) xown[i] = 0.f;
-    if (active && !allm) {
+    if (active && !allm && !(abl & 2)) {
       f32x4 ahh[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       f32x4 axx[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       f32x4 rt4 = {0.f, 0.f, 0.f, 0.f};
@@ -1350,22 +1461,24 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
           else
             rt4 += hv4 * (*reinterpret_cast<const f32x4*>(&s_vec[c0]) + *reinterpret_cast<const f32x4*>(&s_vec[w + c0]) * hv4);
         }
-        half8 hi, lo;
-        split_f16x8(h[2 * ks], h[2 * ks + 1], hi, lo);
+        half8 hi8, lo8;
+        split_f16x8(h[2 * ks], h[2 * ks + 1], hi8, lo8);
         const int kg = NKS * hv + ks;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
           const half8 bh = s_qhi[kg][jt][lane];
-          ahh[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, bh, ahh[jt], 0, 0, 0);
-          axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi, s_qlo[kg][jt][lane], axx[jt], 0, 0, 0);
-          axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo, bh, axx[jt], 0, 0, 0);
+          ahh[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi8, bh, ahh[jt], 0, 0, 0);
+          axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi8, s_qlo[kg][jt][lane], axx[jt], 0, 0, 0);
+          axx[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo8, bh, axx[jt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0) FVTA_PSTAMP(1);
       }
+      FVTA_PSTAMP(2);
       float rtp = (rt4[0] + rt4[1]) + (rt4[2] + rt4[3]);
       rtp += __shfl_xor(rtp, 16, 64);
       rtp += __shfl_xor(rtp, 32, 64);
-      if (FLAGS) wait_flag(&s_done[pwv], g);  // the partner has read my partials of round g - 1 (rounds are numbered from 1)
+      if (FLAGS && !(abl & 8)) wait_flag(&s_done[pwv], g);  // the partner has read my partials of round g - 1 (rounds are numbered from 1)
       if (kq == 0) s_rt[wave][l15] = rtp;
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt)
@@ -1375,13 +1488,18 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
           s_x[wave][(jt * 4 + i) * 64 + lane] = xown[jt * 4 + i];
         }
     }
+    // (the next tile's row numbers were loaded behind the current tile: they have landed with it.  Using them here keeps
+    //  the wait for them from moving behind this round's amax / jmax stores, where it would wait for those too)
+    asm volatile("" ::"v"(t_nxt));
     if (FLAGS) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my partials are in LDS (a wave's LDS operations complete in order)
       if (lane == 0) post_flag(&s_pub[wave], g + 1);
-      wait_flag(&s_pub[pwv], g + 1);
+      FVTA_PSTAMP(3);
+      if (!(abl & 8)) wait_flag(&s_pub[pwv], g + 1);
     } else {
       lds_barrier();  // both halves of every tile are published
     }
+    FVTA_PSTAMP(4);
     if (active) {
       float am = rvalid ? FVTA_NEG : -INFINITY;
       if (!allm) {
@@ -1422,8 +1540,8 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
         }
         am = rvalid ? (s.add_tanh ? fvta_tanh(bestv) : bestv) : -INFINITY;
         if (hv == 0 && kq == 0 && rvalid) {
-          a.sv.amax[(size_t)nk * T + t] = am;
-          a.sv.jmax[(size_t)nk * T + t] = (uint8_t)bestj;
+          a.sv.amax[(size_t)cs.nk * T + t] = am;
+          a.sv.jmax[(size_t)cs.nk * T + t] = (uint8_t)bestj;
         }
       }
       if (FLAGS) {
@@ -1439,12 +1557,22 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] *= scale;
       }
-      const bool has_next = tl + 1 < t1;
-      if (has_next) {
-        const int lrn = (tl + 1) * 16 + l15;
-        const bool v_next = lrn < cnt;
-        const int t_next = v_next ? idx[lrn] : 0;
-        const float* rowp_next = hbase + (size_t)t_next * w + coff;
+      FVTA_PSTAMP(5);
+      if (has_n) {
+        const float* rowp_next = a.hinfo + (size_t)ns.nk * a.hstride + (size_t)t_nxt * w + coff;
+#ifdef FVTA_PAIR_ABL
+        if (abl & 4) {
+#pragma unroll
+          for (int b = 0; b < NBH; ++b) h[b] = *reinterpret_cast<const f32x4*>(rowp_next + 16 * b);
+        } else if (abl & 1) {
+#pragma unroll
+          for (int b = 0; b < NBH; ++b) {
+            f32x4 v = h[b] * pr;
+            row16_sum4(v);
+            if ((b & 15) == l15) u[b >> 4] += v;
+          }
+        } else
+#endif
 #pragma unroll
         for (int b = 0; b < NBH; ++b) {
           f32x4 v = h[b] * pr;
@@ -1452,9 +1580,6 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
           row16_sum4(v);
           if ((b & 15) == l15) u[b >> 4] += v;
         }
-        t_cur = t_next;
-        v_cur = v_next;
-        ++tl;
       } else {
 #pragma unroll
         for (int b = 0; b < NBH; ++b) {
@@ -1462,18 +1587,51 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
           row16_sum4(v);
           if ((b & 15) == l15) u[b >> 4] += v;
         }
-        // the item's partial (m, l, u): lane (l15, kq) holds channels coff + 16 (16 i + l15) + (0..3)
+      }
+      if (ctl + 1 == cs.t1) {
+        // the segment's partial (m, l, u): lane (l15, kq) holds channels coff + 16 (16 i + l15) + (0..3)
+        float* part = a.part + ((size_t)cs.nk * s.nsplit + cs.slot) * (w + 4);
 #pragma unroll
-        for (int i = 0; i < NU; ++i) *reinterpret_cast<f32x4*>(part + 4 + coff + 16 * (16 * i + l15)) = u[i];
+        for (int i = 0; i < NU; ++i) {
+          *reinterpret_cast<f32x4*>(part + 4 + coff + 16 * (16 * i + l15)) = u[i];
+          u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         if (hv == 0 && lane == 0) {
           part[0] = m_run;
           part[1] = l_run;
           part[2] = m_run;
         }
-        active = next_item();
+        m_run = -INFINITY;
+        l_run = 0.f;
+      }
+      // the next tile becomes the current one; look one tile further ahead
+      active = has_n;
+      if (has_n) {
+        cs = ns;
+        ctl = ntl;
+        t_cur = t_nxt;
+        v_cur = v_nxt;
+        has_n = tile_after(cs, ctl, ns, ntl);
+        if (!has_n) {
+          ns = cs;
+          ntl = ctl;
+        }
       }
     }
+    // (at the top level of the loop body, so that the load's destination IS the loop-carried register: inside the
+    //  conditionals above the compiler loads into a temporary and copies it at the loop latch -- behind an
+    //  s_waitcnt vmcnt(0) that also waits for the whole next tile)
+    rows_of(ns, ntl, t_nxt, v_nxt);
+    FVTA_PSTAMP(6);
   }
+#ifdef FVTA_DIAG
+  if (pstamp) {
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.part) + (32u << 20));
+    for (int g = 0; g < 32; ++g)
+      for (int k = 0; k < 8; ++k) stamps[g * 16 + k] = s_stamp[g][k];
+    stamps[15] = t_entry;
+  }
+#endif
 }
 
 // ---- time_warp_att only: the MASKED rows of a (n,k) that has valid rows.  The reference scales the max-pooled logit

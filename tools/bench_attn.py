@@ -15,7 +15,17 @@ def timeit(f, n=5):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-print("attn fwd ms", round(timeit(lambda: op.forward(h, q, hm, qm, W, b)), 3), "dbg", os.environ.get("FVTA_DEBUG_SKIP"))
+def main_kernel_ms(n=20):  # the library's HIP-event bracket around the forward main kernel (FVTA_PROF_ATTN_FWD_MAIN = 4)
+    import ctypes
+    from fvta_memexqa_amd import _lib
+    lib = _lib.load() if hasattr(_lib, "load") else _lib.lib
+    lib.fvta_profile_enable(1)
+    for _ in range(n): op.forward(h, q, hm, qm, W, b)
+    torch.cuda.synchronize(); lib.fvta_profile_enable(0)
+    ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+    lib.fvta_profile_collect(4, ctypes.byref(ms), ctypes.byref(cnt))
+    return ms.value / max(cnt.value, 1)
+print("attn fwd ms", round(timeit(lambda: op.forward(h, q, hm, qm, W, b)), 3), "main kernel ms", round(main_kernel_ms(), 4), "dbg", os.environ.get("FVTA_DEBUG_SKIP"))
 if len(sys.argv) > 1:
     gout = torch.randn(N, w, device="cuda", generator=g)
     dh = torch.zeros_like(h); dq = torch.zeros_like(q); dW = torch.zeros_like(W); db = torch.zeros(1, device="cuda")
