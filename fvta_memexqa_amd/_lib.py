@@ -86,6 +86,9 @@ _SIGS = {
     "fvta_linear_fwd": (c_int, [P, P, P, P, c_int64, c_int32, c_int32, c_int32, P]),
     "fvta_wsum_fwd": (c_int, [P, P, P, c_int64, c_int32, c_int32, P]),
     "fvta_dmn_features": (c_int, [P, P, P, P, c_int32, c_int32, c_int32, P]),
+    "fvta_dmn_features_bwd": (c_int, [P, P, P, P, P, P, P, c_int32, c_int32, c_int32, P]),
+    "fvta_relu_fwd": (c_int, [P, P, c_int64, P]),
+    "fvta_relu_bwd": (c_int, [P, P, P, c_int64, P]),
     "fvta_linear_fwd_blk": (c_int, [P, P, P, P, c_int64, c_int32, c_int32, c_int32, c_int64, c_int64, P]),
     "fvta_linear_bwd_blk": (c_int, [P, P, P, P, P, P, P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, P]),
     "fvta_softmax_bwd": (c_int, [P, P, P, c_int64, c_int32, P]),

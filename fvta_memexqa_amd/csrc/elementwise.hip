@@ -298,6 +298,40 @@ __global__ __launch_bounds__(256) void dmn_features_kernel(const float* __restri
     o[3 * d + c] = fabsf(fv - b);
   }
 }
+// backward of dmn_features_kernel.  d_facts[n,f,c] += dO1 q + dO2 m + dO3 sgn(fact-q) + dO4 sgn(fact-m) (one thread per
+// element of its (n, channel) column, walking the facts), d_q[n,c] += sum_f (dO1 fact - dO3 sgn(fact-q)), d_m likewise
+// (|x| has derivative 0 at 0, as tf.abs).  grid (N, ceil(d/256))
+__global__ __launch_bounds__(256) void dmn_features_bwd_kernel(const float* __restrict__ facts, const float* __restrict__ q,
+                                                              const float* __restrict__ m, const float* __restrict__ d_out,
+                                                              float* __restrict__ d_facts, float* __restrict__ d_q,
+                                                              float* __restrict__ d_m, int F, int d) {
+  const int n = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= d) return;
+  const float a = q[(size_t)n * d + c], b = m[(size_t)n * d + c];
+  float gq = 0.f, gm = 0.f;
+  for (int f = 0; f < F; ++f) {
+    const size_t row = (size_t)n * F + f;
+    const float fv = facts[row * d + c];
+    const float* o = d_out + row * 4 * d;
+    const float g1 = o[c], g2 = o[d + c], g3 = o[2 * d + c], g4 = o[3 * d + c];
+    const float sa = fv > a ? 1.f : (fv < a ? -1.f : 0.f), sb = fv > b ? 1.f : (fv < b ? -1.f : 0.f);
+    d_facts[row * d + c] += g1 * a + g2 * b + g3 * sa + g4 * sb;
+    gq += g1 * fv - g3 * sa;
+    gm += g2 * fv - g4 * sb;
+  }
+  d_q[(size_t)n * d + c] += gq;
+  d_m[(size_t)n * d + c] += gm;
+}
+// relu and its backward (tf.layers.dense(..., activation=tf.nn.relu), model_dmnplus.py:511-514)
+__global__ __launch_bounds__(256) void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = fmaxf(x[i], 0.f);
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
 // out[r, :] (+)= scale * sum_j x[r, j, :]  (tf.reduce_mean over an inner axis, model.py:874-885, :907; with scale 1
 // the backward of a tile).  grid (rows, ceil(d/256))
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ x, float* __restrict__ out, int J, int d,
@@ -372,6 +406,29 @@ extern "C" int fvta_dmn_features(const float* facts, const float* q, const float
   hipLaunchKernelGGL(fvta::dmn_features_kernel, dim3((unsigned)((size_t)N * F)), dim3(256), 0, (hipStream_t)stream, facts, q, m,
                      out, F, d);
   FVTA_CHECK_LAUNCH("dmn_features");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_dmn_features_bwd(const float* facts, const float* q, const float* m, const float* d_out, float* d_facts,
+                                     float* d_q, float* d_m, int32_t N, int32_t F, int32_t d, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(facts && q && m && d_out && d_facts && d_q && d_m && N > 0 && F > 0 && d > 0, "dmn_features_bwd: bad arguments");
+  hipLaunchKernelGGL(fvta::dmn_features_bwd_kernel, dim3((unsigned)N, (unsigned)((d + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, facts, q, m, d_out, d_facts, d_q, d_m, F, d);
+  FVTA_CHECK_LAUNCH("dmn_features_bwd");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_relu_fwd(const float* x, float* y, int64_t n, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(x && y && n > 0, "relu_fwd: bad arguments");
+  hipLaunchKernelGGL(fvta::relu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  FVTA_CHECK_LAUNCH("relu_fwd");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(y && dy && dx && n > 0, "relu_bwd: bad arguments");
+  hipLaunchKernelGGL(fvta::relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, n);
+  FVTA_CHECK_LAUNCH("relu_bwd");
   return FVTA_OK;
 }
 

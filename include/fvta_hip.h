@@ -362,6 +362,14 @@ int fvta_wsum_bwd(const float* target, const float* weights, const float* d_out,
  * fvta_attgru_fwd per fact (functional.generate_episode). */
 int fvta_dmn_features(const float* facts, const float* q, const float* m, float* out, int32_t N, int32_t F, int32_t d,
                       fvta_stream_t stream);
+/* Its backward (d_out [N,F,4d]): d_facts [N,F,d], d_q and d_m [N,d] are ACCUMULATED into (the facts and the question feed
+ * every hop, model_dmnplus.py:507-509); |x| has derivative 0 at 0, as tf.abs. */
+int fvta_dmn_features_bwd(const float* facts, const float* q, const float* m, const float* d_out, float* d_facts, float* d_q,
+                          float* d_m, int32_t N, int32_t F, int32_t d, fvta_stream_t stream);
+/* relu and its backward from the OUTPUT y (the memory update tf.layers.dense(..., activation=tf.nn.relu),
+ * model_dmnplus.py:511-514; the dense itself is fvta_linear_fwd / _bwd). */
+int fvta_relu_fwd(const float* x, float* y, int64_t n, fvta_stream_t stream);
+int fvta_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, fvta_stream_t stream);
 /* The two shape ops the model.py graph (soft-attention baselines) puts between its attentions, forward and backward of
  * each other:
  *   fvta_rows_reduce    : out[r,:] (+)= scale * sum_j x[r,j,:]   x [rows,J,d], out rows `out_ld` floats apart.

@@ -277,6 +277,31 @@ def attention_gru_cell(inputs, state, Wg, bg, Wc, Wi, bi):
     return (1 - g) * state + g * torch.tanh(r + x @ Wi + bi)
 
 
+def dmn_memory(gq, facts, facts_length, params, num_hops):
+    """model_dmnplus.py:503-516 with `_generate_episode` :113-136 / `_get_attention` :89-111: the hop loop of the DMN+
+    episodic memory.  params: TF variable names (memory/attention/fc{1,2}/{weights,biases},
+    memory/attention_gru/rnn/attention_gru_cell/{gates,candidate,input}/..., memory/hop_<i>/dense/{kernel,bias})."""
+    N, F, d = facts.shape
+    cell = "memory/attention_gru/rnn/attention_gru_cell/"
+    live = (torch.arange(F)[None, :] < torch.as_tensor(facts_length)[:, None]).to(facts.dtype)
+    prev = gq
+    for i in range(num_hops):
+        q3, m3 = gq[:, None, :], prev[:, None, :]
+        feats = torch.cat([facts * q3, facts * m3, (facts - q3).abs(), (facts - m3).abs()], 2)             # :93-98
+        a1 = torch.tanh(feats @ params["memory/attention/fc1/weights"] + params["memory/attention/fc1/biases"])
+        logit = (a1 @ params["memory/attention/fc2/weights"] + params["memory/attention/fc2/biases"])[..., 0]
+        att = torch.softmax(logit, 1)                                                                       # :120, all F facts
+        state = torch.zeros(N, d, dtype=facts.dtype)
+        for t in range(F):                                                                                  # dynamic_rnn, :127-131
+            new = attention_gru_cell(torch.cat([facts[:, t], att[:, t:t + 1]], 1), state, params[cell + "gates/weights"],
+                                     params[cell + "gates/biases"], params[cell + "candidate/weights"],
+                                     params[cell + "input/weights"], params[cell + "input/biases"])
+            state = torch.where(live[:, t:t + 1] > 0, new, state)                                            # sequence_length: copy through
+        prev = torch.relu(torch.cat([prev, state, gq], 1) @ params["memory/hop_%d/dense/kernel" % i]
+                          + params["memory/hop_%d/dense/bias" % i])                                          # :510-514
+    return prev
+
+
 def embed_inputs(params, tok, cfg):
     """model_v2.py:524-645 over a whole token-id batch: `tok` has the layout of the encoder-input dict but text
     streams carry ids [..., J] (+ chars [..., J, W]) and the photo stream pis [N, M, JI]; returns the encoder-input

@@ -70,3 +70,43 @@ def test_dmn_generate_episode_two_hops():
         np.testing.assert_allclose(eps[hop].numpy(), ref, rtol=2e-4, atol=2e-5)
         m64 = ref
     assert len([k for k in Fn.variables if k.startswith("memory/")]) == 9          # the second hop created nothing new
+
+
+def test_dmn_episodic_memory_forward_backward():
+    """model_dmnplus.py:503-516: the hop loop (shared attention MLP + AttentionGRU, one dense+relu per hop) -- output and
+    every gradient (question, facts, all 13 variables) against autograd of the fp64 restatement; rows of different lengths,
+    one of length 1."""
+    from fvta_memexqa_amd.dmn import EpisodicMemory
+    from oracle import fvta_fused as O
+    g = torch.Generator().manual_seed(21)
+    N, F, d, hops = 6, 9, 64, 3
+    facts = torch.randn(N, F, d, generator=g) * 0.5
+    gq = torch.randn(N, d, generator=g) * 0.5
+    lens = torch.tensor([9, 5, 1, 9, 3, 7])
+    d_out = torch.randn(N, d, generator=g)
+    mem = EpisodicMemory(d, hops, seed=3)
+    for k in mem.params:                                   # non-zero biases so that their gradients are exercised
+        if k.endswith("biases") or k.endswith("bias"):
+            mem.params[k].copy_(torch.randn(mem.params[k].shape, generator=g) * 0.1)
+    out = mem(gq.cuda(), facts.cuda(), lens)
+    d_gq, d_facts = mem.backward(d_out.cuda())
+    p64 = {k: v.cpu().double().requires_grad_(True) for k, v in mem.params.items()}
+    gq64, f64 = gq.double().requires_grad_(True), facts.double().requires_grad_(True)
+    ref = O.dmn_memory(gq64, f64, lens, p64, hops)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), rtol=2e-4, atol=2e-5)
+    (ref * d_out.double()).sum().backward()
+
+    def close(a, b, tag):
+        a, b = a.cpu().double().numpy(), b.numpy()
+        err = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
+        assert err < 2e-4, "%s: rel-L2 %.3g" % (tag, err)
+
+    close(d_gq, gq64.grad, "d_gq")
+    close(d_facts, f64.grad, "d_facts")
+    for k in mem.params:
+        close(mem.grads[k], p64[k].grad, k)
+    # a second backward accumulates into the parameter gradients
+    before = {k: v.clone() for k, v in mem.grads.items()}
+    mem.backward(d_out.cuda())
+    for k in mem.grads:
+        assert torch.allclose(mem.grads[k], 2 * before[k], rtol=1e-5, atol=1e-6), k
