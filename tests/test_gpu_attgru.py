@@ -98,8 +98,9 @@ def test_dmn_episodic_memory_forward_backward():
 
     def close(a, b, tag):
         a, b = a.cpu().double().numpy(), b.numpy()
-        err = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
-        assert err < 2e-4, "%s: rel-L2 %.3g" % (tag, err)
+        # (fc2's bias shifts every logit of the softmax alike: its true gradient is 0, hence the absolute term)
+        err, ref = np.linalg.norm(a - b), np.linalg.norm(b)
+        assert err <= 2e-4 * ref + 1e-5, "%s: |a-b| %.3g, |b| %.3g" % (tag, err, ref)
 
     close(d_gq, gq64.grad, "d_gq")
     close(d_facts, f64.grad, "d_facts")
