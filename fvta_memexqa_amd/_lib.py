@@ -57,6 +57,9 @@ _SIGS = {
     "fvta_lstm_saved_bytes": (c_size_t, [POINTER(LstmDesc)]),
     "fvta_lstm_workspace_bytes": (c_size_t, [POINTER(LstmDesc)]),
     "fvta_lstm_plan": (c_int, [POINTER(LstmDesc), P, P, P, P, c_int64, P, P]),
+    "fvta_lstm_plan_xdir": (c_int, [POINTER(LstmDesc), P, P, P, P, c_int64, c_int64, P, P]),
+    "fvta_dropout_pair_fwd": (c_int, [P, P, c_int64, c_float, ctypes.c_uint64, P]),
+    "fvta_dropout_pair_bwd": (c_int, [P, P, c_int64, c_float, ctypes.c_uint64, c_int32, P]),
     "fvta_bilstm_fwd": (c_int, [POINTER(LstmDesc), P, P, P, P, P, P, P, P, P, P]),
     "fvta_bilstm_bwd": (c_int, [POINTER(LstmDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_bilstm_bwd_overlap": (c_int, [POINTER(LstmDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),

@@ -322,6 +322,35 @@ __global__ __launch_bounds__(256) void dmn_features_bwd_kernel(const float* __re
   d_q[(size_t)n * d + c] += gq;
   d_m[(size_t)n * d + c] += gm;
 }
+// ---- LSTM input dropout (DropoutWrapper(cell, input_keep_prob), model_v2.py:657-661).  bidirectional_dynamic_rnn calls the
+// wrapped cell in two loops, so every (sequence, position) input is dropped twice, independently: x2[0][e] for the forward
+// direction, x2[1][e] for the backward one, x2[dir][e] = x[e] * keep(dir, e) / keep_prob.  keep() is a counter-based hash
+// (splitmix64 of seed + golden * (dir * n + e + 1), top 32 bits < keep_prob * 2^32): TensorFlow's random stream cannot be
+// reproduced, its distribution is; the oracle evaluates the same hash (oracle/fvta_fused.py dropout_keep_masks).
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, unsigned long long thr) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (z >> 32) < thr;
+}
+__global__ __launch_bounds__(256) void dropout_pair_fwd_kernel(const float* __restrict__ x, float* __restrict__ x2, int64_t n,
+                                                              float scale, unsigned long long thr, unsigned long long seed) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const float v = x[e] * scale;
+  x2[e] = dropout_keep(seed, (unsigned long long)e, thr) ? v : 0.f;
+  x2[n + e] = dropout_keep(seed, (unsigned long long)(n + e), thr) ? v : 0.f;
+}
+__global__ __launch_bounds__(256) void dropout_pair_bwd_kernel(const float* __restrict__ dx2, float* __restrict__ dx, int64_t n,
+                                                              float scale, unsigned long long thr, unsigned long long seed,
+                                                              int accumulate) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const float g = (dropout_keep(seed, (unsigned long long)e, thr) ? dx2[e] * scale : 0.f) +
+                  (dropout_keep(seed, (unsigned long long)(n + e), thr) ? dx2[n + e] * scale : 0.f);
+  dx[e] = accumulate ? dx[e] + g : g;
+}
 // relu and its backward (tf.layers.dense(..., activation=tf.nn.relu), model_dmnplus.py:511-514)
 __global__ __launch_bounds__(256) void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -415,6 +444,25 @@ extern "C" int fvta_dmn_features_bwd(const float* facts, const float* q, const f
   hipLaunchKernelGGL(fvta::dmn_features_bwd_kernel, dim3((unsigned)N, (unsigned)((d + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, facts, q, m, d_out, d_facts, d_q, d_m, F, d);
   FVTA_CHECK_LAUNCH("dmn_features_bwd");
+  return FVTA_OK;
+}
+
+static inline unsigned long long dropout_thr(float keep_prob) { return (unsigned long long)((double)keep_prob * 4294967296.0); }
+
+extern "C" int fvta_dropout_pair_fwd(const float* x, float* x2, int64_t n, float keep_prob, uint64_t seed, fvta_stream_t stream) {
+  FVTA_CHECK_ARG(x && x2 && n > 0 && keep_prob > 0.f && keep_prob <= 1.f, "dropout_pair_fwd: bad arguments (0 < keep_prob <= 1)");
+  hipLaunchKernelGGL(fvta::dropout_pair_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x2, n,
+                     1.0f / keep_prob, dropout_thr(keep_prob), (unsigned long long)seed);
+  FVTA_CHECK_LAUNCH("dropout_pair_fwd");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_dropout_pair_bwd(const float* dx2, float* dx, int64_t n, float keep_prob, uint64_t seed, int32_t accumulate,
+                                     fvta_stream_t stream) {
+  FVTA_CHECK_ARG(dx2 && dx && n > 0 && keep_prob > 0.f && keep_prob <= 1.f, "dropout_pair_bwd: bad arguments (0 < keep_prob <= 1)");
+  hipLaunchKernelGGL(fvta::dropout_pair_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dx2, dx, n,
+                     1.0f / keep_prob, dropout_thr(keep_prob), (unsigned long long)seed, accumulate);
+  FVTA_CHECK_LAUNCH("dropout_pair_bwd");
   return FVTA_OK;
 }
 

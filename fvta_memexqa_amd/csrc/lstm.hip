@@ -41,7 +41,8 @@ __global__ __launch_bounds__(1024) void plan_sort_kernel(PlanView v, const int32
                                                          const int32_t* __restrict__ seq_J_in,
                                                          const int64_t* __restrict__ x_off_in,
                                                          const int64_t* __restrict__ out_off_in,
-                                                         int64_t out_ld, int B, int J, int in, int d) {
+                                                         int64_t out_ld, int B, int J, int in, int d,
+                                                         int64_t x_bw_delta) {
   extern __shared__ int32_t sh[];  // [16][J+1] per-wave histogram, then running bases
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int NW = 16, H = J + 1;
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(1024) void plan_sort_kernel(PlanView v, const int32
     v.hdr->J = J;
     v.hdr->in = in;
     v.hdr->d = d;
+    v.hdr->x_bw_delta = x_bw_delta;
   }
   for (int b = tid; b < B; b += 1024) {
     int L = len_in[b];
@@ -130,7 +132,7 @@ __global__ void plan_fill_kernel(PlanView v, int B, int J, int in, int d) {
   const int b = v.order[i];
   const int L = v.len[b];
   const int pos = dir ? (L - 1 - t) : t;
-  v.xo[idx] = v.x_off[b] + (int64_t)pos * in;
+  v.xo[idx] = v.x_off[b] + (int64_t)pos * in + (dir ? v.hdr->x_bw_delta : 0);
   v.oo[idx] = v.out_off[b] + (int64_t)pos * v.hdr->out_ld + (int64_t)dir * d;
 }
 
@@ -446,15 +448,23 @@ extern "C" size_t fvta_lstm_workspace_bytes(const fvta_lstm_desc* d) { return wo
 extern "C" int fvta_lstm_plan(const fvta_lstm_desc* d, const int32_t* len, const int32_t* seq_J,
                               const int64_t* x_off, const int64_t* out_off, int64_t out_ld, void* plan,
                               fvta_stream_t stream_) {
+  return fvta_lstm_plan_xdir(d, len, seq_J, x_off, out_off, out_ld, 0, plan, stream_);
+}
+
+extern "C" int fvta_lstm_plan_xdir(const fvta_lstm_desc* d, const int32_t* len, const int32_t* seq_J,
+                                   const int64_t* x_off, const int64_t* out_off, int64_t out_ld, int64_t x_bw_delta,
+                                   void* plan, fvta_stream_t stream_) {
   if (int e = check_lstm_desc(d)) return e;
   FVTA_CHECK_ARG(len && seq_J && x_off && out_off && plan, "lstm_plan: null pointer");
+  FVTA_CHECK_ARG(x_bw_delta >= 0 && x_bw_delta % 4 == 0, "lstm_plan: x_bw_delta=%lld must be >= 0 and a multiple of 4",
+                 (long long)x_bw_delta);
   FVTA_CHECK_ARG(out_ld >= 2 * d->d && out_ld % 4 == 0, "lstm_plan: out_ld=%lld must be >= 2d and a multiple of 4",
                  (long long)out_ld);
   hipStream_t stream = (hipStream_t)stream_;
   PlanView v = plan_view(d, plan);
   const size_t sh = (size_t)16 * (d->J + 1) * sizeof(int32_t);
   hipLaunchKernelGGL(plan_sort_kernel, dim3(1), dim3(1024), sh, stream, v, len, seq_J, x_off, out_off, out_ld,
-                     d->B, d->J, d->in, d->d);
+                     d->B, d->J, d->in, d->d, x_bw_delta);
   FVTA_CHECK_LAUNCH("plan_sort");
   hipLaunchKernelGGL(plan_fill_kernel, dim3((d->B + 255) / 256, d->J, 2), dim3(256), 0, stream, v, d->B, d->J,
                      d->in, d->d);

@@ -107,17 +107,19 @@ __global__ void cvt_x_kernel(PlanView pv, const float* __restrict__ x, bf16_t* _
   if (i >= pv.nactive[pos]) return;  // len_i <= pos
   const int len = pv.len[pv.order[i]];
   const float* src = x + pv.xo[(size_t)pos * B + i];  // forward direction, step pos = position pos
+  const int64_t bw_delta = pv.hdr->x_bw_delta;        // != 0: the backward direction has its own input (fvta_lstm_plan_xdir)
   bf16_t* dst_fw = xs + ((size_t)pos * B + i) * in_i;
   bf16_t* dst_bw = xs + (((size_t)J + (len - 1 - pos)) * B + i) * in_i;
   for (int c = lane * 4; c < in_i; c += 256) {
-    bf16x4 o;
+    bf16x4 o, ob;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int k = c + e;
       o[e] = k < in ? (short)f2bf(src[k]) : (k == in ? (short)0x3f80 : (short)0);  // ones column at `in`
+      ob[e] = (bw_delta && k < in) ? (short)f2bf(src[bw_delta + k]) : o[e];
     }
     *reinterpret_cast<bf16x4*>(dst_fw + c) = o;
-    *reinterpret_cast<bf16x4*>(dst_bw + c) = o;
+    *reinterpret_cast<bf16x4*>(dst_bw + c) = ob;
   }
 }
 

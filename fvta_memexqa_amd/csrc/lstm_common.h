@@ -10,7 +10,8 @@ typedef unsigned short bf16_t;
 struct PlanHeader {
   int64_t out_ld;
   int32_t B, J, in, d;
-  int32_t pad[10];
+  int64_t x_bw_delta;  // elements from the forward direction's x (and dx) to the backward direction's: 0 = one shared input
+  int32_t pad[8];
 };
 
 struct PlanView {

@@ -122,8 +122,13 @@ class Model:
         # d logits of softmax_cross_entropy_with_logits (model_v2.py:1088): True = what TF-1's kernel returns,
         # softmax - labels on every row, all-False label rows (padded rows of a short batch, :1270) included
         self.tf_xent_grad = bool(_cfg(config, "tf_xent_grad", True))
-        if float(_cfg(config, "keep_prob", 1.0)) != 1.0:
-            raise NotImplementedError("LSTM input dropout (--keep_prob < 1) is not built yet")
+        # --keep_prob (main.py:102): DropoutWrapper(cell, input_keep_prob) on both cells while training (model_v2.py:657-661);
+        # evaluation layouts never drop (main.py:191 forces 1.0, and :657 gates on is_train)
+        self.keep_prob = float(_cfg(config, "keep_prob", 1.0))
+        if not 0.0 < self.keep_prob <= 1.0:
+            raise ValueError("keep_prob %r is not in (0, 1]" % self.keep_prob)
+        self.dropout_seed = int(_cfg(config, "dropout_seed", 0))
+        self._dropout_calls = 0
         self.use_time_warp = bool(_cfg(config, "use_time_warp", False))
         self.warp_type = int(_cfg(config, "warp_type", 1))
         self.window_t = float(_cfg(config, "window_t", 3.0))     # time_warp_window_t, init 3.0 (model_v2.py:333); no gradient
@@ -155,6 +160,9 @@ class Model:
             self.Wc = int(_cfg(config, "max_word_size", 16))
             self.cdim = int(_cfg(config, "char_emb_size", 8))
             self.cwdim = int(_cfg(config, "char_out_size", 100)) if self.use_char else 0
+            if self.cwdim and self.keep_prob < 1.0:
+                raise NotImplementedError("conv1d's dropout of the char embeddings (model_v2.py:58-62) is not built: "
+                                          "--keep_prob < 1 together with --use_char")
             self.idim = int(_cfg(config, "image_feat_dim", 2537))
             self.use_image_trans = bool(_cfg(config, "use_image_trans", False))
             self.tdim = int(_cfg(config, "image_trans_dim", 100)) if self.use_image_trans else self.idim
@@ -564,6 +572,12 @@ class Model:
             G.B, G.J = B, Jmax
             G.x = torch.zeros(pos, dtype=torch.float32, device=dev)
             G.dx = None
+            # input dropout: each direction of the cell runs on its own dropped copy of G.x (x2 = [fw | bw]); their
+            # gradients come back as dx2 = [fw | bw] and are folded through the same masks (ops.dropout_pair_*)
+            G.dropout = bool(training) and self.keep_prob < 1.0
+            G.x2 = torch.zeros(2 * pos, dtype=torch.float32, device=dev) if G.dropout else None
+            G.dx2 = None
+            G.drop_seed = 0
             if self.token_mode:
                 # one row per sequence position (padding positions included, as the reference embeds them too)
                 t0 = 0
@@ -586,7 +600,7 @@ class Model:
             G.lens = torch.zeros(B, dtype=torch.int32, device=dev)
             G.op = ops.BiLstm(B, Jmax, din, dp, torch.cat(x_off), torch.cat(out_off), torch.cat(seq_J), wp,
                               share_fw_bw=self.share_fw_bw, precision=self.precision, training=training,
-                              prof_tag=0 if cell == "text" else 1)
+                              prof_tag=0 if cell == "text" else 1, x_bw_delta=pos if G.dropout else 0)
             L.groups[cell] = G
         L.q_mask = torch.zeros(N, JQ, dtype=torch.uint8, device=dev)
         self._build_attention(L, training)
@@ -823,7 +837,11 @@ class Model:
             with torch.cuda.stream(side if side is not None else main):
                 G.op.make_plan(G.lens)
                 kf, bf, kb, bb = self._cell_params(cell)
-                G.op.forward(G.x, L.arena, kf, bf, kb, bb)                 # encoders + context tensor
+                if G.dropout:                                              # model_v2.py:657-661
+                    self._dropout_calls += 1
+                    G.drop_seed = (self.dropout_seed * 0x9E3779B1 + self._dropout_calls * 2 + (cell == "image")) & (2 ** 64 - 1)
+                    ops.dropout_pair_fwd(G.x, G.x2, self.keep_prob, G.drop_seed)
+                G.op.forward(G.x2 if G.dropout else G.x, L.arena, kf, bf, kb, bb)   # encoders + context tensor
         main.wait_stream(self._side)
         att, qatt = self._attend(L, want_logits)
         L.logits, L.yp, L.loss_t = ops.scorer_ce_fwd(L.gq, L.g1, L.lch, P.view(self.N_OUT_W), P.view(self.N_OUT_B),
@@ -886,8 +904,18 @@ class Model:
             with torch.cuda.stream(side if side is not None else main):
                 if need_dx:
                     G.dx.zero_()
-                G.op.backward(G.x, L.arena, L.d_arena, kf, kb, G.dx if need_dx else None, dkf, dbf, dkb, dbb,
-                              side_stream=self._side2 if side is None else None)
+                if G.dropout:
+                    if need_dx:
+                        if G.dx2 is None:
+                            G.dx2 = torch.zeros_like(G.x2)
+                        G.dx2.zero_()
+                    G.op.backward(G.x2, L.arena, L.d_arena, kf, kb, G.dx2 if need_dx else None, dkf, dbf, dkb, dbb,
+                                  side_stream=self._side2 if side is None else None)
+                    if need_dx:
+                        ops.dropout_pair_bwd(G.dx2, G.dx, self.keep_prob, G.drop_seed)
+                else:
+                    G.op.backward(G.x, L.arena, L.d_arena, kf, kb, G.dx if need_dx else None, dkf, dbf, dkb, dbb,
+                                  side_stream=self._side2 if side is None else None)
                 if side is not None and not self.wd:
                     # data parallelism: everything in [0, early_numel) of the flat gradient -- scorer, attention(s),
                     # time warp, photo cell -- is final in THIS stream's order now; start its all-reduce on RCCL's

@@ -101,7 +101,10 @@ class BiLstm:
     """
 
     def __init__(self, B, J, in_dim, d, x_off, out_off, seq_J, out_ld, share_fw_bw=True, precision=F32,
-                 training=False, prof_tag=0):
+                 training=False, prof_tag=0, x_bw_delta=0):
+        """x_bw_delta > 0: the backward direction reads x (writes dx) that many elements behind the forward direction's
+        -- x = [x_fw | x_bw], the two dropped copies of DropoutWrapper's inputs (dropout_pair_fwd)."""
+        self.x_bw_delta = int(x_bw_delta)
         self.lib = _lib.load()
         self.dev = require_gpu()
         self.desc = LstmDesc(B, J, in_dim, d, int(share_fw_bw), precision, int(training), int(prof_tag))
@@ -119,8 +122,9 @@ class BiLstm:
 
     def make_plan(self, lens):
         lens = lens.to(self.dev, torch.int32).contiguous()
-        check(self.lib.fvta_lstm_plan(ctypes.byref(self.desc), ptr(lens), ptr(self.seq_J), ptr(self.x_off),
-                                      ptr(self.out_off), self.out_ld, ptr(self.plan), stream_ptr()), "fvta_lstm_plan")
+        check(self.lib.fvta_lstm_plan_xdir(ctypes.byref(self.desc), ptr(lens), ptr(self.seq_J), ptr(self.x_off),
+                                           ptr(self.out_off), self.out_ld, self.x_bw_delta, ptr(self.plan), stream_ptr()),
+              "fvta_lstm_plan")
 
     def forward(self, x, out, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None):
         check(self.lib.fvta_bilstm_fwd(ctypes.byref(self.desc), ptr(self.plan), ptr(_f32c(x)), ptr(_f32c(out)),
@@ -143,6 +147,17 @@ class BiLstm:
     def last_state_bwd(self, d_dst, s0, count, d_out):
         check(self.lib.fvta_lstm_last_state_bwd(ctypes.byref(self.desc), ptr(self.plan), ptr(_f32c(d_dst)), s0, count,
                                                 ptr(d_out), stream_ptr()), "fvta_lstm_last_state_bwd")
+
+
+def dropout_pair_fwd(x, x2, keep_prob, seed):
+    """x2 [2, numel(x)] = the forward / backward direction's dropped copy of x (DropoutWrapper, model_v2.py:657-661)"""
+    check(_lib.load().fvta_dropout_pair_fwd(ptr(x), ptr(x2), x.numel(), float(keep_prob), int(seed) & (2 ** 64 - 1), stream_ptr()),
+          "fvta_dropout_pair_fwd")
+
+
+def dropout_pair_bwd(dx2, dx, keep_prob, seed, accumulate=False):
+    check(_lib.load().fvta_dropout_pair_bwd(ptr(dx2), ptr(dx), dx.numel(), float(keep_prob), int(seed) & (2 ** 64 - 1),
+                                            int(accumulate), stream_ptr()), "fvta_dropout_pair_bwd")
 
 
 def bilstm_simple(x, lens, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None, training=False, precision=F32):

@@ -135,6 +135,22 @@ size_t fvta_lstm_workspace_bytes(const fvta_lstm_desc* d);
 int fvta_lstm_plan(const fvta_lstm_desc* d, const int32_t* len, const int32_t* seq_J, const int64_t* x_off,
                    const int64_t* out_off, int64_t out_ld, void* plan, fvta_stream_t stream);
 
+/* The same with a separate input for the backward direction: its rows are read (and its dx rows written) x_bw_delta
+ * ELEMENTS behind the forward direction's, i.e. the caller passes x = [x_fw | x_bw] and dx = [dx_fw | dx_bw] with
+ * x_bw_delta = the size of one copy (a multiple of 4).  This is how DropoutWrapper(cell, input_keep_prob) enters
+ * (model_v2.py:657-661): bidirectional_dynamic_rnn calls the wrapped cell in two loops, so each direction sees its own
+ * dropped copy of the inputs -- fvta_dropout_pair_fwd makes the two copies, fvta_dropout_pair_bwd folds [dx_fw | dx_bw]
+ * back.  x_bw_delta = 0 is fvta_lstm_plan. */
+int fvta_lstm_plan_xdir(const fvta_lstm_desc* d, const int32_t* len, const int32_t* seq_J, const int64_t* x_off,
+                        const int64_t* out_off, int64_t out_ld, int64_t x_bw_delta, void* plan, fvta_stream_t stream);
+/* x2[dir][e] = x[e] * keep(dir, e) / keep_prob, dir = 0 / 1, e < n (tf.nn.dropout's x / keep_prob * floor(keep_prob + u)
+ * with u from a counter-based hash of (seed, dir, e) -- TensorFlow's random stream is not reproducible, its distribution
+ * is; oracle/fvta_fused.py dropout_keep_masks evaluates the same hash).  Backward: dx[e] (+)= sum_dir dx2[dir][e] *
+ * keep(dir, e) / keep_prob. */
+int fvta_dropout_pair_fwd(const float* x, float* x2, int64_t n, float keep_prob, uint64_t seed, fvta_stream_t stream);
+int fvta_dropout_pair_bwd(const float* dx2, float* dx, int64_t n, float keep_prob, uint64_t seed, int32_t accumulate,
+                          fvta_stream_t stream);
+
 /* kernel [in+d, 4d] gate order i,j,f,o; bias [4d]; forget_bias 1.0 added at
  * run time (BasicLSTMCell).  kernel_bw/bias_bw ignored when
  * share_fw_bw. */

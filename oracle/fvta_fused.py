@@ -133,16 +133,42 @@ def lstm_direction(x, seq_len, kernel, bias, reverse):
     return out, h
 
 
-def encode_stream(x, mask, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None):
-    """model_v2.py:694-826 (one bidirectional_dynamic_rnn call + concats)."""
+def dropout_keep_masks(n, keep_prob, seed):
+    """The keep decisions of the build's LSTM input dropout for an input of n elements: [2, n] bool, row 0 the forward
+    direction's, row 1 the backward direction's (DropoutWrapper(cell, input_keep_prob), model_v2.py:657-661, is called in
+    both loops of bidirectional_dynamic_rnn: two independent masks per input element).  TensorFlow's random stream cannot
+    be restated; this is the counter-based hash the library uses instead (splitmix64 of seed + golden * (index + 1), top 32
+    bits below keep_prob * 2^32) -- same distribution, reproducible."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        idx = np.arange(2 * n, dtype=np.uint64)
+        z = np.uint64(seed & (2 ** 64 - 1)) + np.uint64(0x9E3779B97F4A7C15) * (idx + np.uint64(1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    thr = np.uint64(int(float(np.float32(keep_prob)) * 4294967296.0))
+    return torch.from_numpy(((z >> np.uint64(32)) < thr).reshape(2, n))
+
+
+def encode_stream(x, mask, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None, input_keep=None, keep_prob=1.0):
+    """model_v2.py:694-826 (one bidirectional_dynamic_rnn call + concats).  input_keep [2, *x.shape] bool with keep_prob:
+    the DropoutWrapper of model_v2.py:657-661 -- tf.nn.dropout(inputs, keep_prob) = inputs / keep_prob * keep inside each
+    direction's loop, an independent mask per direction."""
     if kernel_bw is None:
         kernel_bw, bias_bw = kernel_fw, bias_fw
     lead = x.shape[:-2]
     J, din = x.shape[-2], x.shape[-1]
     xf = x.reshape(-1, J, din)
     ln = mask.reshape(-1, J).to(torch.int64).sum(1)
-    of, hf = lstm_direction(xf, ln, kernel_fw, bias_fw, False)
-    ob, hb = lstm_direction(xf, ln, kernel_bw, bias_bw, True)
+    if input_keep is not None:
+        # (the library scales by fp32(1) / fp32(keep_prob))
+        scale = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(keep_prob, dtype=torch.float32))
+        kf = input_keep.reshape(2, -1, J, din).to(xf.dtype)
+        of, hf = lstm_direction(xf * scale * kf[0], ln, kernel_fw, bias_fw, False)
+        ob, hb = lstm_direction(xf * scale * kf[1], ln, kernel_bw, bias_bw, True)
+    else:
+        of, hf = lstm_direction(xf, ln, kernel_fw, bias_fw, False)
+        ob, hb = lstm_direction(xf, ln, kernel_bw, bias_bw, True)
     hcat = torch.cat([of, ob], 2)
     last = torch.cat([hf, hb], 1)
     return hcat.reshape(*lead, J, hcat.shape[-1]), last.reshape(*lead, last.shape[-1])
@@ -331,11 +357,14 @@ def fvta_forward(params, inputs, cfg):
         return (params[name + "_kernel"], params[name + "_bias"],
                 params.get(name + "_kernel_bw"), params.get(name + "_bias_bw"))
 
-    hq, lq = encode_stream(inputs["q"]["x"], inputs["q"]["mask"], *cell("text"))
-    _, lch = encode_stream(inputs["choices"]["x"], inputs["choices"]["mask"], *cell("text"))
+    # (a stream's optional "keep" [2, *x.shape] with cfg["keep_prob"]: the DropoutWrapper masks of a training step)
+    kp = float(cfg.get("keep_prob", 1.0))
+    hq, lq = encode_stream(inputs["q"]["x"], inputs["q"]["mask"], *cell("text"), input_keep=inputs["q"].get("keep"), keep_prob=kp)
+    _, lch = encode_stream(inputs["choices"]["x"], inputs["choices"]["mask"], *cell("text"),
+                           input_keep=inputs["choices"].get("keep"), keep_prob=kp)
     hs, ms = [], []
     for st in inputs["ctx"]:
-        h, _ = encode_stream(st["x"], st["mask"], *cell(st.get("cell", "text")))
+        h, _ = encode_stream(st["x"], st["mask"], *cell(st.get("cell", "text")), input_keep=st.get("keep"), keep_prob=kp)
         m = st["mask"]
         if h.dim() == 5:
             N, M = h.shape[:2]

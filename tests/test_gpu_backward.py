@@ -123,3 +123,82 @@ def test_bilstm_backward_matches_autograd(B, J, din, d, dense, share, need_dx):
     if not share:
         _close(dkb, leaves[3].grad, msg="dkernel_bw")
         _close(dbb, leaves[4].grad, msg="dbias_bw")
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("share", [True, False])
+def test_bilstm_input_dropout(precision, share):
+    """DropoutWrapper(cell, input_keep_prob) (model_v2.py:657-661): each direction of the bi-LSTM runs on its own dropped
+    copy of the inputs.  The two copies (fvta_dropout_pair_fwd) bit for bit against the oracle's masks; outputs, last
+    states and every gradient -- dx folded back through the masks (fvta_dropout_pair_bwd) -- against autograd of the
+    restatement run with those masks."""
+    from fvta_memexqa_amd import ops
+    from fvta_memexqa_amd._lib import BF16, F32
+    from oracle import fvta_fused as F
+    B, J, din, d, keep, seed = 37, 7, 12, 32, 0.7, 0xC0FFEE123456789
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, J, din, generator=g)
+    lens = torch.randint(0, J + 1, (B,), generator=g)
+    lim = (6.0 / (din + d + 4 * d)) ** 0.5
+    mk = lambda: ((torch.rand(din + d, 4 * d, generator=g) * 2 - 1) * lim * 2, torch.randn(4 * d, generator=g) * 0.1)
+    k_fw, b_fw = mk()
+    k_bw, b_bw = (None, None) if share else mk()
+    mask = torch.arange(J)[None, :] < lens[:, None]
+    g_out = torch.randn(B, J, 2 * d, generator=g) * mask[:, :, None]
+    g_last = torch.randn(B, 2 * d, generator=g)
+    n = x.numel()
+    keepm = F.dropout_keep_masks(n, keep, seed)
+    assert 0.6 < keepm.float().mean() < 0.8 and not torch.equal(keepm[0], keepm[1])
+
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    xc = cu(x)
+    x2 = torch.empty(2, n, device="cuda")
+    ops.dropout_pair_fwd(xc, x2, keep, seed)
+    scale = (torch.tensor(1.0) / torch.tensor(keep)).item()
+    expect = torch.where(keepm, (x.reshape(1, n) * torch.tensor(scale, dtype=torch.float32)).expand(2, n), torch.zeros(2, n))
+    assert torch.equal(x2.cpu(), expect)
+
+    leaves = [t.double().requires_grad_() for t in (x, k_fw, b_fw)]
+    if not share:
+        leaves += [k_bw.double().requires_grad_(), b_bw.double().requires_grad_()]
+    ref_out, ref_last = F.encode_stream(leaves[0], mask, leaves[1], leaves[2], *(leaves[3:] if not share else [None, None]),
+                                        input_keep=keepm.reshape(2, B, J, din), keep_prob=keep)
+    ((ref_out * g_out.double()).sum() + (ref_last * g_last.double()).sum()).backward()
+
+    kf, bf, kb, bb = cu(k_fw), cu(b_fw), cu(k_bw), cu(b_bw)
+    ar = torch.arange(B, dtype=torch.int64)
+    op = ops.BiLstm(B, J, din, d, ar * J * din, ar * J * 2 * d, torch.full((B,), J, dtype=torch.int32), 2 * d,
+                    share_fw_bw=share, precision=BF16 if precision == "bf16" else F32, training=True, x_bw_delta=n)
+    op.make_plan(lens)
+    out = torch.empty(B, J, 2 * d, device="cuda")
+    op.forward(x2, out, kf, bf, kb, bb)
+    last = torch.empty(B, 2 * d, device="cuda")
+    op.last_state(out, 0, B, last)
+    tol = dict(rtol=3e-2, atol=3e-2) if precision == "bf16" else {}
+    _close(out, ref_out.detach(), msg="out", **tol)
+    _close(last, ref_last.detach(), msg="last", **tol)
+    d_out = cu(g_out).clone()
+    op.last_state_bwd(cu(g_last), 0, B, d_out)
+    dx2 = torch.zeros(2, n, device="cuda")
+    dkf, dbf = torch.zeros_like(kf), torch.zeros_like(bf)
+    dkb, dbb = (None, None) if share else (torch.zeros_like(kb), torch.zeros_like(bb))
+    op.backward(x2, out, d_out, kf, kb, dx2, dkf, dbf, dkb, dbb)
+    dx = torch.empty(n, device="cuda")
+    ops.dropout_pair_bwd(dx2, dx, keep, seed)
+
+    def close(a, b, tag):
+        a, b = a.cpu().double().flatten(), b.double().flatten()
+        err, ref = (a - b).norm().item(), b.norm().item()
+        lim = 4e-2 if precision == "bf16" else 2e-4
+        assert err <= lim * ref + 1e-6, "%s: |a-b| %.3g, |b| %.3g" % (tag, err, ref)
+
+    close(dx, leaves[0].grad, "dx")
+    close(dkf, leaves[1].grad, "dkernel_fw")
+    close(dbf, leaves[2].grad, "dbias_fw")
+    if not share:
+        close(dkb, leaves[3].grad, "dkernel_bw")
+        close(dbb, leaves[4].grad, "dbias_bw")
+    # and the accumulate form
+    base = torch.full((n,), 0.5, device="cuda")
+    ops.dropout_pair_bwd(dx2, base, keep, seed, accumulate=True)
+    assert torch.allclose(base, dx + 0.5, rtol=1e-6, atol=1e-6)

@@ -63,6 +63,62 @@ def test_small_model_forward_backward(simi, tanh, qatt, share, dense):
     _run(spec)
 
 
+def test_model_with_input_dropout():
+    """--keep_prob < 1 (DropoutWrapper on both cells while training, model_v2.py:657-661): a training step's loss, answers
+    and every parameter gradient against the oracle run with the SAME keep masks (the library's counter-based hash,
+    restated in oracle.fvta_fused.dropout_keep_masks, sliced per stream out of each cell's input arena); the evaluation
+    layout does not drop; a second step draws new masks."""
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params, to_dtype
+    from oracle import fvta_fused as F
+    spec = SynthSpec(N=3, A=2, P=3, S=2, L=5, d=32, SA=1, dense=False, simiMatrix=2, add_tanh=True,
+                     use_question_att=True, share_fw_bw=True, text_in=12, img_in=8)
+    params, inputs, cfg, keep = make_params(spec), make_inputs(spec), spec.cfg(), 0.75
+    model = Model(dict(cfg, batch_size=spec.N, keep_prob=keep, dropout_seed=5), text_in=spec.text_in, img_in=spec.img_in)
+    model.set_oracle_params(params)
+    L = model.load_inputs(inputs, training=True)
+    model.zero_grad()
+    yp = model.forward(L)
+    loss1 = float(model.loss)
+    model.backward(L, need_dx=True)
+
+    def keep_of(name, x):
+        for G in L.groups.values():
+            for sg in G.segs:
+                if sg["name"] == name:
+                    km = F.dropout_keep_masks(G.x.numel(), keep, G.drop_seed)
+                    n = sg["count"] * sg["J"] * G.din
+                    km = km[:, sg["x_elem0"]:sg["x_elem0"] + n].reshape(2, sg["count"], sg["J"], G.din)
+                    return km[..., :x.shape[-1]].reshape(2, *x.shape)
+        raise KeyError(name)
+
+    inp = to_dtype(inputs, torch.float64)
+    inp["q"]["keep"] = keep_of("q", inputs["q"]["x"])
+    inp["choices"]["keep"] = keep_of("choices", inputs["choices"]["x"])
+    for k, st in enumerate(inp["ctx"]):
+        st["keep"] = keep_of("ctx%d" % k, inputs["ctx"][k]["x"])
+    p64 = {k: v.double().requires_grad_() for k, v in params.items()}
+    ref = F.fvta_forward(p64, inp, dict(cfg, keep_prob=keep))
+    ref["loss"].backward()
+    _close(yp, ref["yp"], msg="yp")
+    _close(model.loss, ref["loss"].reshape(1), msg="loss")
+    grads = model.get_oracle_grads()
+    for k, v in p64.items():
+        if v.grad is not None:
+            _close(grads[k].reshape(v.grad.shape), v.grad, rtol=2e-4, atol=2e-5, msg="grad " + k)
+    # evaluation: no dropout
+    ref_eval = F.fvta_forward({k: v.double() for k, v in params.items()}, to_dtype(inputs, torch.float64), cfg)
+    Le = model.load_inputs(inputs, training=False)
+    _close(model.forward(Le), ref_eval["yp"], msg="yp (evaluation layout)")
+    assert abs(float(ref_eval["loss"]) - loss1) > 1e-6
+    # the next training step draws other masks
+    L = model.load_inputs(inputs, training=True)
+    model.forward(L)
+    assert abs(float(model.loss) - loss1) > 1e-7
+    with pytest.raises(ValueError):
+        Model(dict(cfg, batch_size=spec.N, keep_prob=0.0), text_in=spec.text_in, img_in=spec.img_in)
+
+
 def test_hidden_size_padding_is_exact():
     """hidden_size 20 (w=40) runs at the padded width 64; results equal the unpadded oracle."""
     from fvta_memexqa_amd.synth import SynthSpec
