@@ -31,7 +31,8 @@ class TimewarpDesc(Structure):
 
 
 class EmbedDesc(Structure):
-    _fields_ = [(n, c_int32) for n in ("ntok", "W", "cdim", "cwdim", "wdim", "VW", "VT", "VC", "height")]
+    _fields_ = [(n, c_int32) for n in ("ntok", "W", "cdim", "cwdim", "wdim", "VW", "VT", "VC", "height")] + \
+               [("keep_prob", c_float), ("dropout_seed", ctypes.c_uint64)]
 
 
 class ImgTransDesc(Structure):

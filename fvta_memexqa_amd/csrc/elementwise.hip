@@ -327,13 +327,6 @@ __global__ __launch_bounds__(256) void dmn_features_bwd_kernel(const float* __re
 // direction, x2[1][e] for the backward one, x2[dir][e] = x[e] * keep(dir, e) / keep_prob.  keep() is a counter-based hash
 // (splitmix64 of seed + golden * (dir * n + e + 1), top 32 bits < keep_prob * 2^32): TensorFlow's random stream cannot be
 // reproduced, its distribution is; the oracle evaluates the same hash (oracle/fvta_fused.py dropout_keep_masks).
-__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, unsigned long long thr) {
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1ull);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (z >> 32) < thr;
-}
 __global__ __launch_bounds__(256) void dropout_pair_fwd_kernel(const float* __restrict__ x, float* __restrict__ x2, int64_t n,
                                                               float scale, unsigned long long thr, unsigned long long seed) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -446,8 +439,6 @@ extern "C" int fvta_dmn_features_bwd(const float* facts, const float* q, const f
   FVTA_CHECK_LAUNCH("dmn_features_bwd");
   return FVTA_OK;
 }
-
-static inline unsigned long long dropout_thr(float keep_prob) { return (unsigned long long)((double)keep_prob * 4294967296.0); }
 
 extern "C" int fvta_dropout_pair_fwd(const float* x, float* x2, int64_t n, float keep_prob, uint64_t seed, fvta_stream_t stream) {
   FVTA_CHECK_ARG(x && x2 && n > 0 && keep_prob > 0.f && keep_prob <= 1.f, "dropout_pair_fwd: bad arguments (0 < keep_prob <= 1)");

@@ -32,7 +32,21 @@ struct EmbArgs {
   const float* dx;
   float* d_word_emb;
   float* slab;  // [blocks][KC*cwdim + cwdim + VC*cdim]
+  // conv1d's dropout of the gathered char embeddings while training (model_v2.py:58-62): element (tok, pos, c) of the
+  // [ntok, W, cdim] block is kept by the hash of (seed, (tok * W + pos) * cdim + c) and scaled by 1 / keep_prob; thr 0 = off
+  unsigned long long drop_thr, drop_seed;
+  float drop_scale;
 };
+// keep / scale factor of element i = pos * cdim + c of token tok's character block (WC = W * cdim)
+__device__ __forceinline__ float emb_ks(const EmbArgs& a, int tok, int i, int WC) {
+  if (a.drop_thr == 0ull) return 1.f;
+  return dropout_keep(a.drop_seed, (unsigned long long)tok * WC + i, a.drop_thr) ? a.drop_scale : 0.f;
+}
+static inline void emb_set_dropout(EmbArgs& a, const fvta_embed_desc* d) {
+  a.drop_thr = (d->keep_prob > 0.f && d->keep_prob < 1.f) ? dropout_thr(d->keep_prob) : 0ull;
+  a.drop_seed = d->dropout_seed;
+  a.drop_scale = a.drop_thr ? 1.0f / d->keep_prob : 1.f;
+}
 
 __global__ __launch_bounds__(EMB_NT) void embed_fwd_kernel(EmbArgs a) {
   __shared__ float s_E[EMB_MAXWC];
@@ -51,7 +65,7 @@ __global__ __launch_bounds__(EMB_NT) void embed_fwd_kernel(EmbArgs a) {
     if (d.cwdim > 0) {
       __syncthreads();  // the previous token's readers of s_E are done
       for (int i = tid; i < d.W * d.cdim; i += EMB_NT)
-        s_E[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / d.cdim] * d.cdim + i % d.cdim];
+        s_E[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / d.cdim] * d.cdim + i % d.cdim] * emb_ks(a, tok, i, d.W * d.cdim);
       __syncthreads();
       if (tid < d.cwdim) {
         float best = -INFINITY;
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(EMB_NT) void embed_fwd_kernel_5x8(EmbArgs a) {
   for (int tok = blockIdx.x; tok < d.ntok; tok += gridDim.x) {
     float* row = a.x + a.tok_off[tok];
     __syncthreads();  // the previous token's readers of s_E are done
-    if (tid < W * 8) s_E[tid] = a.char_emb[(size_t)a.char_ids[(size_t)tok * W + (tid >> 3)] * 8 + (tid & 7)];
+    if (tid < W * 8) s_E[tid] = a.char_emb[(size_t)a.char_ids[(size_t)tok * W + (tid >> 3)] * 8 + (tid & 7)] * emb_ks(a, tok, tid, W * 8);
     __syncthreads();
     if (tid < d.cwdim) {
       float acc[12];
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel(EmbArgs a) {
     __syncthreads();
     if (tid < d.W) s_ch[tid] = a.char_ids[(size_t)tok * d.W + tid];
     for (int i = tid; i < WC; i += EMB_NT)
-      s_E[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / d.cdim] * d.cdim + i % d.cdim];
+      s_E[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / d.cdim] * d.cdim + i % d.cdim] * emb_ks(a, tok, i, WC);
     float g = 0.f;
     int p = 0;
     if (tid < d.cwdim) {
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel(EmbArgs a) {
         const float g = s_g[f];
         if (g != 0.f && k >= 0 && k < d.height) v += g * s_filt[(k * d.cdim + c) * d.cwdim + f];
       }
-      s_dE[i] = v;
+      s_dE[i] = v * emb_ks(a, tok, i, WC);  // (dropout: the gradient reaches the table through the kept elements only)
     }
     __syncthreads();
     // into the workgroup's char table: thread c walks the positions serially (two positions may hold the same char)
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_5x8(EmbArgs a) {
     __syncthreads();
     if (tid < W * 8) {
       if ((tid & 7) == 0) s_ch[tid >> 3] = ch0;
-      s_E[tid] = s_cemb[ch0 * 8 + (tid & 7)];
+      s_E[tid] = s_cemb[ch0 * 8 + (tid & 7)] * emb_ks(a, tok, tid, W * 8);
     }
     const float g = ap0 != 255 ? g0 : 0.f;
     const int p = ap0 != 255 ? ap0 : 0;
@@ -317,7 +331,7 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_5x8(EmbArgs a) {
         const int pp = pos - k;
         if (pp >= 0 && pp < 12) v += (s_S[0][pp][k * 8 + c] + s_S[1][pp][k * 8 + c]) + s_S[2][pp][k * 8 + c];
       }
-      s_dE[tid] = v;
+      s_dE[tid] = v * emb_ks(a, tok, tid, W * 8);
     }
     __syncthreads();
     // into the workgroup's char table.  Two positions may hold the same character: the FIRST position of a character
@@ -360,7 +374,7 @@ __global__ __launch_bounds__(EMB_NT) void embed_fwd_kernel_big(EmbArgs a) {
     float* row = a.x + a.tok_off[tok];
     __syncthreads();
     for (int i = tid; i < WC; i += EMB_NT)
-      s_dyn[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / d.cdim] * d.cdim + i % d.cdim];
+      s_dyn[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / d.cdim] * d.cdim + i % d.cdim] * emb_ks(a, tok, i, WC);
     __syncthreads();
     if (tid < d.cwdim) {
       float best = -INFINITY;
@@ -507,7 +521,8 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwdw_filt(EmbArgs a) {
       }
     }
     __syncthreads();  // the previous token's readers of s_E are done
-    for (int i = tid; i < WC; i += EMB_NT) s_E[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / cd] * cd + i % cd];
+    for (int i = tid; i < WC; i += EMB_NT)
+      s_E[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / cd] * cd + i % cd] * emb_ks(a, tok, i, WC);
     __syncthreads();
     if (g != 0.f) {
       accb += g;
@@ -588,8 +603,8 @@ __global__ __launch_bounds__(256) void embed_bwdw_char(EmbArgs a) {
       v0 += (oa ? g : 0.f) * fa[(oa ? ka : 0) * (EMBW_CS * ldf) + f];
       v1 += (ob ? g : 0.f) * fa[(ob ? kb : 0) * (EMBW_CS * ldf) + f];
     }
-    s_dE[pg * EMBW_CS + cl] = v0;
-    s_dE[(pg + 8) * EMBW_CS + cl] = v1;
+    s_dE[pg * EMBW_CS + cl] = v0 * emb_ks(a, tok, pg * cd + c0 + cl, W * cd);
+    s_dE[(pg + 8) * EMBW_CS + cl] = v1 * emb_ks(a, tok, (pg + 8) * cd + c0 + cl, W * cd);
     __syncthreads();
     // the first position of a character adds itself and its later duplicates (position order) to the table slice
 #pragma unroll
@@ -638,7 +653,7 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_big(EmbArgs a) {
     __syncthreads();
     if (tid < d.W) s_ch[tid] = a.char_ids[(size_t)tok * d.W + tid];
     for (int i = tid; i < WC; i += EMB_NT)
-      s_E[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / d.cdim] * d.cdim + i % d.cdim];
+      s_E[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / d.cdim] * d.cdim + i % d.cdim] * emb_ks(a, tok, i, WC);
     float g = 0.f;
     int p = 0;
     if (tid < d.cwdim) {
@@ -664,7 +679,7 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_big(EmbArgs a) {
         const float gf = s_g[f];
         if (gf != 0.f && k >= 0 && k < d.height) v += gf * a.filt[(size_t)(k * d.cdim + c) * d.cwdim + f];
       }
-      s_dE[i] = v;
+      s_dE[i] = v * emb_ks(a, tok, i, WC);  // (dropout: the gradient reaches the table through the kept elements only)
     }
     __syncthreads();
     if (tid < d.cdim)
@@ -837,6 +852,7 @@ extern "C" int fvta_embed_fwd(const fvta_embed_desc* d, const int32_t* word_ids,
   a.word_ids = word_ids; a.char_ids = char_ids; a.tok_off = tok_off;
   a.word_emb = word_emb; a.fixed_emb = fixed_emb; a.char_emb = char_emb; a.filt = filt; a.bias = bias;
   a.x = x; a.argpos = argpos;
+  emb_set_dropout(a, d);
   const int blocks = d->ntok < 8192 ? d->ntok : 8192;
   // FVTA_EMBED_MFMA_SMALL=1: the reference's default shape (height 5 x char_emb 8: a 40-deep window) on the matrix-pipe
   // kernel too, instead of the register kernel (measurement switch)
@@ -844,7 +860,8 @@ extern "C" int fvta_embed_fwd(const fvta_embed_desc* d, const int32_t* word_ids,
     const char* e = getenv("FVTA_EMBED_MFMA_SMALL");
     return e ? e[0] == '1' : (FVTA_EMBED_MFMA_SMALL_DEFAULT != 0);
   }();
-  if (embed_mfma_ok(d) && d->cwdim > 0 && (embed_is_big(d) || small_mfma)) {
+  // (with dropout the matrix-pipe kernel, which gathers its A operand straight from the character table, is not used)
+  if (embed_mfma_ok(d) && d->cwdim > 0 && (embed_is_big(d) || small_mfma) && a.drop_thr == 0ull) {
     hipLaunchKernelGGL(embed_fwd_kernel_mfma, dim3((d->ntok + 7) / 8), dim3(256), MmaEmb::LDS_FLOATS * sizeof(float),
                        (hipStream_t)stream_, a);
   } else if (embed_is_big(d)) {
@@ -873,6 +890,7 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
   a.word_ids = word_ids; a.char_ids = char_ids; a.tok_off = tok_off;
   a.char_emb = char_emb; a.filt = filt; a.argpos = const_cast<uint8_t*>(argpos);
   a.dx = dx; a.d_word_emb = d_word_emb; a.slab = (float*)workspace;
+  emb_set_dropout(a, d);
   int blocks;
   const size_t charw_lds = ((size_t)d->height * EMBW_CS * (d->cwdim + 1) + (size_t)d->VC * EMBW_CS + 16 * EMBW_CS) * sizeof(float);
   if (embed_is_big(d) && embed_mfma_ok(d) && charw_lds <= 150 * 1024) {

@@ -137,6 +137,17 @@ __device__ __forceinline__ void row16_argmax(float& best, int& bestj) {
   dpp_argmax_step<DPP_MIRROR>(best, bestj);
 }
 
+// dropout keep decision of element idx: splitmix64 of seed + golden * (idx + 1), top 32 bits below keep_prob * 2^32
+// (oracle/fvta_fused.py dropout_keep_masks / dropout_keep_flat evaluate the same hash)
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, unsigned long long thr) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (z >> 32) < thr;
+}
+static inline unsigned long long dropout_thr(float keep_prob) { return (unsigned long long)((double)keep_prob * 4294967296.0); }
+
 // float -> bf16 (round to nearest even), as raw 16-bit
 __device__ __forceinline__ unsigned short f2bf(float f) {
   unsigned u = __float_as_uint(f);

@@ -160,9 +160,6 @@ class Model:
             self.Wc = int(_cfg(config, "max_word_size", 16))
             self.cdim = int(_cfg(config, "char_emb_size", 8))
             self.cwdim = int(_cfg(config, "char_out_size", 100)) if self.use_char else 0
-            if self.cwdim and self.keep_prob < 1.0:
-                raise NotImplementedError("conv1d's dropout of the char embeddings (model_v2.py:58-62) is not built: "
-                                          "--keep_prob < 1 together with --use_char")
             self.idim = int(_cfg(config, "image_feat_dim", 2537))
             self.use_image_trans = bool(_cfg(config, "use_image_trans", False))
             self.tdim = int(_cfg(config, "image_trans_dim", 100)) if self.use_image_trans else self.idim
@@ -820,6 +817,13 @@ class Model:
         if getattr(L, "token", False):                                      # model_v2.py:524-645
             T_, I_ = L.groups["text"], L.groups.get("image")
             cw = self.cwdim
+            if cw:                                                          # conv1d's dropout (model_v2.py:58-62), training only
+                if T_.dropout:
+                    self._dropout_calls += 1
+                    T_.char_drop_seed = (self.dropout_seed * 0x9E3779B1 + self._dropout_calls * 2 + 0x5851F42D) & (2 ** 64 - 1)
+                    T_.embed.set_dropout(self.keep_prob, T_.char_drop_seed)
+                else:
+                    T_.embed.set_dropout(1.0, 0)
             T_.embed.forward(T_.word_ids, T_.char_ids, T_.tok_off, P.view(self.N_WORD_EMB), self.existing_emb_mat,
                              P.view(self.N_CHAR_EMB) if cw else None, P.view(self.N_CONV_F) if cw else None,
                              P.view(self.N_CONV_B) if cw else None, T_.x)

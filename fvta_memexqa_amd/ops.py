@@ -401,6 +401,12 @@ class TokenEmbed:
         self.argpos = torch.empty(max(ntok * cwdim, 1), dtype=torch.uint8, device=self.dev)
         self.cwdim = cwdim
 
+    def set_dropout(self, keep_prob, seed):
+        """conv1d's dropout of the gathered char embeddings for the NEXT forward / backward pair (model_v2.py:58-62,
+        training only); keep_prob 1.0 switches it off."""
+        self.desc.keep_prob = float(keep_prob)
+        self.desc.dropout_seed = int(seed) & (2 ** 64 - 1)
+
     def forward(self, word_ids, char_ids, tok_off, word_emb, fixed_emb, char_emb, filt, bias, x):
         check(self.lib.fvta_embed_fwd(ctypes.byref(self.desc), ptr(word_ids), ptr(char_ids), ptr(tok_off), ptr(word_emb),
                                       ptr(fixed_emb), ptr(char_emb), ptr(filt), ptr(bias), ptr(x), ptr(self.argpos),

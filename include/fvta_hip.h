@@ -290,6 +290,8 @@ typedef struct fvta_embed_desc {
   int32_t VT;     /* all word rows (trainable + frozen) */
   int32_t VC;     /* char vocabulary */
   int32_t height; /* conv window (5) */
+  float keep_prob;       /* conv1d's dropout of the gathered char embeddings while training (model_v2.py:58-62); 0 or 1: off */
+  uint64_t dropout_seed; /* element (tok, pos, c) is kept by the counter-based hash of (seed, (tok * W + pos) * cdim + c) */
 } fvta_embed_desc;
 
 size_t fvta_embed_workspace_bytes(const fvta_embed_desc* d);

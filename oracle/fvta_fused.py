@@ -139,15 +139,21 @@ def dropout_keep_masks(n, keep_prob, seed):
     both loops of bidirectional_dynamic_rnn: two independent masks per input element).  TensorFlow's random stream cannot
     be restated; this is the counter-based hash the library uses instead (splitmix64 of seed + golden * (index + 1), top 32
     bits below keep_prob * 2^32) -- same distribution, reproducible."""
+    return dropout_keep_flat(2 * n, keep_prob, seed).reshape(2, n)
+
+
+def dropout_keep_flat(n, keep_prob, seed):
+    """keep decisions of elements 0..n-1 of one dropped tensor (the hash of dropout_keep_masks); conv1d's dropout of the
+    gathered char embeddings [ntok, W, cdim] (model_v2.py:58-62) uses it with n = ntok * W * cdim."""
     import numpy as np
     with np.errstate(over="ignore"):
-        idx = np.arange(2 * n, dtype=np.uint64)
+        idx = np.arange(n, dtype=np.uint64)
         z = np.uint64(seed & (2 ** 64 - 1)) + np.uint64(0x9E3779B97F4A7C15) * (idx + np.uint64(1))
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
     thr = np.uint64(int(float(np.float32(keep_prob)) * 4294967296.0))
-    return torch.from_numpy(((z >> np.uint64(32)) < thr).reshape(2, n))
+    return torch.from_numpy((z >> np.uint64(32)) < thr)
 
 
 def encode_stream(x, mask, kernel_fw, bias_fw, kernel_bw=None, bias_bw=None, input_keep=None, keep_prob=1.0):
@@ -238,13 +244,17 @@ def conv1d(x, filt, bias):
     return xc.max(dim=2).values
 
 
-def embed_tokens(word_ids, char_ids, word_emb_mat, existing_emb_mat, char_emb, filt, bias):
-    """model_v2.py:524-620 for one text input; see oracle/fvta_literal.py:embed_tokens."""
+def embed_tokens(word_ids, char_ids, word_emb_mat, existing_emb_mat, char_emb, filt, bias, char_keep=None, keep_prob=1.0):
+    """model_v2.py:524-620 for one text input; see oracle/fvta_literal.py:embed_tokens.  char_keep (bool, shape of
+    char_ids + [cdim]) with keep_prob: conv1d's tf.nn.dropout of the gathered char embeddings while training (:58-62)."""
     table = torch.cat([word_emb_mat, existing_emb_mat], 0)
     A = table[word_ids.long()]
     if char_emb is None:
         return A
     Ac = char_emb[char_ids.long()]
+    if char_keep is not None:
+        scale = float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(keep_prob, dtype=torch.float32))
+        Ac = Ac * scale * char_keep.to(Ac.dtype)
     lead = tuple(char_ids.shape[:-2])
     J, W = char_ids.shape[-2:]
     xc = conv1d(Ac.reshape(-1, J, W, char_emb.shape[1]), filt, bias).reshape(lead + (J, filt.shape[3]))
@@ -334,9 +344,10 @@ def embed_inputs(params, tok, cfg):
     dict fvta_forward takes.  params: word_emb, existing_emb_mat, (char_emb, conv_filter, conv_bias), (img_W, img_b)."""
     use_char = "char_emb" in params and params.get("char_emb") is not None
 
-    def text(st):
+    def text(st):   # (a stream's optional "char_keep" with cfg["keep_prob"]: conv1d's dropout masks of a training step)
         return embed_tokens(st["ids"], st.get("chars"), params["word_emb"], params["existing_emb_mat"],
-                            params["char_emb"] if use_char else None, params.get("conv_filter"), params.get("conv_bias"))
+                            params["char_emb"] if use_char else None, params.get("conv_filter"), params.get("conv_bias"),
+                            char_keep=st.get("char_keep") if use_char else None, keep_prob=float(cfg.get("keep_prob", 1.0)))
 
     ctx = []
     for st in tok["ctx"]:
@@ -345,9 +356,10 @@ def embed_inputs(params, tok, cfg):
                                params.get("img_b"), bool(cfg.get("add_tanh", False)))
         else:
             x = text(st)
-        ctx.append(dict(x=x, mask=st["mask"], cell=st.get("cell", "text")))
-    return dict(ctx=ctx, q=dict(x=text(tok["q"]), mask=tok["q"]["mask"]),
-                choices=dict(x=text(tok["choices"]), mask=tok["choices"]["mask"]), y=tok.get("y"))
+        ctx.append(dict(x=x, mask=st["mask"], cell=st.get("cell", "text"), keep=st.get("keep")))
+    return dict(ctx=ctx, q=dict(x=text(tok["q"]), mask=tok["q"]["mask"], keep=tok["q"].get("keep")),
+                choices=dict(x=text(tok["choices"]), mask=tok["choices"]["mask"], keep=tok["choices"].get("keep")),
+                y=tok.get("y"))
 
 
 # ------------------------------------------------------------- whole path ---

@@ -60,6 +60,51 @@ def test_token_embed_forward_backward(B, J, W, cd, cw, wd, VW, VF, VC):
     assert p64["fixed"].grad is not None  # the oracle differentiates it; the library treats it as frozen (model_v2.py:590)
 
 
+@pytest.mark.parametrize("B,J,W,cd,cw,wd,VW,VF,VC", [(3, 7, 16, 8, 100, 100, 50, 30, 40),    # the 5 x 8 register kernels
+                                                      (5, 4, 9, 4, 24, 300, 7, 5, 11),        # generic kernels
+                                                      (4, 6, 16, 100, 100, 100, 20, 30, 60),  # wide: sparse backward pair
+                                                      (3, 5, 21, 8, 64, 50, 9, 9, 20)])       # W > 16
+def test_token_embed_char_dropout(B, J, W, cd, cw, wd, VW, VF, VC):
+    """conv1d's dropout of the gathered char embeddings while training (model_v2.py:58-62): forward rows and every
+    gradient against the oracle run with the same keep mask (the library's hash, oracle dropout_keep_flat)."""
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    keep, seed = 0.8, 0xABCDEF0123
+    p, ids, ch = _case(B + J + W + 1, B, J, W, cd, cw, wd, VW, VF, VC)
+    ntok = B * J
+    km = F.dropout_keep_flat(ntok * W * cd, keep, seed).reshape(B, J, W, cd)
+    assert 0.7 < km.float().mean() < 0.9
+    p64 = {k: v.double().requires_grad_() for k, v in p.items()}
+    ref = F.embed_tokens(ids, ch, p64["word_emb"], p64["fixed"], p64["char_emb"], p64["filt"], p64["bias"], char_keep=km,
+                         keep_prob=keep)
+    g = torch.Generator().manual_seed(6)
+    gout = torch.randn(B, J, cw + wd, generator=g)
+    (ref * gout.double()).sum().backward()
+    stride = cw + wd
+    op = ops.TokenEmbed(ntok, W, cd, cw, wd, VW, VW + VF, VC)
+    op.set_dropout(keep, seed)
+    cu = lambda t: t.cuda().contiguous()
+    tok_off = cu(torch.arange(ntok, dtype=torch.int64) * stride)
+    x = torch.zeros(ntok * stride, device="cuda")
+    filt = cu(p["filt"].reshape(5, cd, cw))
+    args = (cu(ids.reshape(-1)), cu(ch.reshape(-1, W)), tok_off)
+    op.forward(*args, cu(p["word_emb"]), cu(p["fixed"]), cu(p["char_emb"]), filt, cu(p["bias"]), x)
+    _close(x.view(ntok, stride), ref.reshape(ntok, -1), msg="x")
+    dx = cu(gout.reshape(-1))
+    dwe, dce = torch.zeros(VW, wd, device="cuda"), torch.zeros(VC, cd, device="cuda")
+    dfl, dbi = torch.zeros(5, cd, cw, device="cuda"), torch.zeros(cw, device="cuda")
+    op.backward(*args, cu(p["char_emb"]), filt, dx, dwe, dce, dfl, dbi)
+    _close(dwe, p64["word_emb"].grad, atol=1e-4, msg="d word_emb")
+    _close(dce, p64["char_emb"].grad, atol=1e-4, msg="d char_emb")
+    _close(dfl, p64["filt"].grad.reshape(5, cd, cw), atol=1e-4, msg="d filt")
+    _close(dbi, p64["bias"].grad, atol=1e-4, msg="d bias")
+    # switched off again: the plain rows
+    op.set_dropout(1.0, 0)
+    op.forward(*args, cu(p["word_emb"]), cu(p["fixed"]), cu(p["char_emb"]), filt, cu(p["bias"]), x)
+    plain = F.embed_tokens(ids, ch, p["word_emb"], p["fixed"], p["char_emb"], p["filt"], p["bias"])
+    _close(x.view(ntok, stride), plain.reshape(ntok, -1), msg="x without dropout")
+
+
 def test_token_embed_without_char_cnn():
     from fvta_memexqa_amd import ops
     from oracle import fvta_fused as F

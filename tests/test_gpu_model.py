@@ -291,6 +291,60 @@ def test_token_id_entry_matches_oracle(use_char, use_image_trans):
         _close(np.asarray(grads[k]).reshape(exp.shape), exp, rtol=2e-4, atol=2e-6, msg="grad " + k)
 
 
+def test_token_id_entry_with_dropout():
+    """--keep_prob < 1 on the reference's own feed: conv1d's dropout of the char embeddings (model_v2.py:58-62) AND the
+    cells' input dropout (:657-661) in one training step -- loss, answers and the gradients of the embedding, encoder and
+    scorer parameters against the oracle run with the same masks."""
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import SynthSpec, make_embed_params, make_params, make_token_inputs
+    from oracle import fvta_fused as F
+    VW, VF, VC, W, cd, cw, wd, idim, tdim, keep = 40, 60, 30, 12, 8, 24, 20, 57, 16, 0.8
+    spec = SynthSpec(N=3, A=2, P=3, S=2, L=5, d=32, SA=1, dense=False, text_in=wd + cw, img_in=tdim)
+    params = dict(make_params(spec), **make_embed_params(spec, VW, VF, VC, cd, cw, wd, idim, tdim, True))
+    tok = make_token_inputs(spec, VW, VF, VC, W)
+    g = torch.Generator().manual_seed(3)
+    tok["image_emb_mat"] = torch.randn(tok["n_image_rows"], idim, generator=g) * 0.5
+    cfg = dict(spec.cfg(), batch_size=spec.N, word_vocab_size=VW, word_emb_size=wd, use_char=True, char_vocab_size=VC,
+               max_word_size=W, char_emb_size=cd, char_out_size=cw, image_feat_dim=idim, use_image_trans=True,
+               image_trans_dim=tdim, keep_prob=keep, dropout_seed=11)
+    model = Model(cfg)
+    model.set_oracle_params(params)
+    L = model.load_inputs(tok, training=True)
+    model.zero_grad()
+    yp = model.forward(L)
+    model.backward(L)
+    T_ = L.groups["text"]
+    ckeep = F.dropout_keep_flat(T_.ntok * W * cd, keep, T_.char_drop_seed)
+
+    def masks_of(name, st, cell):
+        G = L.groups[cell]
+        sg = next(x for x in G.segs if x["name"] == name)
+        lead = tuple(st["ids"].shape[:-1]) if "ids" in st else tuple(st["pis"].shape[:-1])
+        J = sg["J"]
+        km = F.dropout_keep_masks(G.x.numel(), keep, G.drop_seed)
+        n = sg["count"] * J * G.din
+        true_in = (wd + cw) if cell == "text" else tdim
+        st["keep"] = km[:, sg["x_elem0"]:sg["x_elem0"] + n].reshape(2, sg["count"], J, G.din)[..., :true_in] \
+            .reshape((2,) + lead + (J, true_in))
+        if cell == "text":
+            m = sg["count"] * J
+            st["char_keep"] = ckeep[sg["tok0"] * W * cd:(sg["tok0"] + m) * W * cd].reshape(lead + (J, W, cd))
+
+    masks_of("q", tok["q"], "text")
+    masks_of("choices", tok["choices"], "text")
+    for k, st in enumerate(tok["ctx"]):
+        masks_of("ctx%d" % k, st, st.get("cell", "text"))
+    p64 = {k: (v.double().requires_grad_() if k != "existing_emb_mat" else v.double()) for k, v in params.items()}
+    ref = F.fvta_forward(p64, F.embed_inputs(p64, tok, cfg), cfg)
+    ref["loss"].backward()
+    _close(yp, ref["yp"], msg="yp")
+    _close(model.loss, ref["loss"].reshape(1), msg="loss")
+    grads = model.get_oracle_grads()
+    for k in ["word_emb", "text_kernel", "out_W", "char_emb", "conv_filter", "conv_bias", "img_W", "img_b"]:
+        exp = p64[k].grad.numpy()
+        _close(np.asarray(grads[k]).reshape(exp.shape), exp, rtol=2e-4, atol=2e-6, msg="grad " + k)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("token", [False, True])
 def test_weight_decay_matches_oracle(token):
