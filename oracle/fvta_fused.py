@@ -313,7 +313,7 @@ def attention_gru_cell(inputs, state, Wg, bg, Wc, Wi, bi):
     return (1 - g) * state + g * torch.tanh(r + x @ Wi + bi)
 
 
-def dmn_memory(gq, facts, facts_length, params, num_hops):
+def dmn_memory(gq, facts, facts_length, params, num_hops, episodes=None):
     """model_dmnplus.py:503-516 with `_generate_episode` :113-136 / `_get_attention` :89-111: the hop loop of the DMN+
     episodic memory.  params: TF variable names (memory/attention/fc{1,2}/{weights,biases},
     memory/attention_gru/rnn/attention_gru_cell/{gates,candidate,input}/..., memory/hop_<i>/dense/{kernel,bias})."""
@@ -333,6 +333,8 @@ def dmn_memory(gq, facts, facts_length, params, num_hops):
                                      params[cell + "gates/biases"], params[cell + "candidate/weights"],
                                      params[cell + "input/weights"], params[cell + "input/biases"])
             state = torch.where(live[:, t:t + 1] > 0, new, state)                                            # sequence_length: copy through
+        if episodes is not None:
+            episodes.append(state)
         prev = torch.relu(torch.cat([prev, state, gq], 1) @ params["memory/hop_%d/dense/kernel" % i]
                           + params["memory/hop_%d/dense/bias" % i])                                          # :510-514
     return prev

@@ -195,3 +195,48 @@ def test_model_v1_rejected_flag_sets():
                   dict(concat=True, use_direct_links=True)):
         with pytest.raises(ValueError):
             F.model_v1_forward(params, inputs, {**spec.cfg(), "use_question_att": False, "add_tanh": False, **flags})
+
+
+def test_dmn_memory_episode_matches_literal():
+    """The fused restatement of the DMN+ hop loop (oracle.fvta_fused.dmn_memory, the checker of fvta_memexqa_amd/dmn.py)
+    against the literal `_generate_episode` (oracle.fvta_literal.dmn_generate_episode) on the first hop's episode."""
+    from oracle import fvta_fused as F
+    from oracle import fvta_literal as L
+    g = torch.Generator().manual_seed(4)
+    N, Fn, d = 4, 6, 16
+    cell = "memory/attention_gru/rnn/attention_gru_cell/"
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64) * 0.3
+    p = {"memory/attention/fc1/weights": rnd(4 * d, d), "memory/attention/fc1/biases": rnd(d),
+         "memory/attention/fc2/weights": rnd(d, 1), "memory/attention/fc2/biases": rnd(1),
+         cell + "gates/weights": rnd(2 * d, d), cell + "gates/biases": rnd(d), cell + "candidate/weights": rnd(d, d),
+         cell + "input/weights": rnd(d, d), cell + "input/biases": rnd(d),
+         "memory/hop_0/dense/kernel": rnd(3 * d, d), "memory/hop_0/dense/bias": rnd(d)}
+    gq, facts, lens = rnd(N, d), rnd(N, Fn, d), torch.tensor([6, 3, 1, 5])
+    eps = []
+    out = F.dmn_memory(gq, facts, lens, p, 1, episodes=eps)
+    lit = L.dmn_generate_episode(gq.numpy(), gq.numpy(), facts.numpy(), lens.numpy(),
+                                 dict(fc1_W=p["memory/attention/fc1/weights"].numpy(), fc1_b=p["memory/attention/fc1/biases"].numpy(),
+                                      fc2_W=p["memory/attention/fc2/weights"].numpy(), fc2_b=p["memory/attention/fc2/biases"].numpy(),
+                                      Wg=p[cell + "gates/weights"].numpy(), bg=p[cell + "gates/biases"].numpy(),
+                                      Wc=p[cell + "candidate/weights"].numpy(), Wi=p[cell + "input/weights"].numpy(),
+                                      bi=p[cell + "input/biases"].numpy()))
+    np.testing.assert_allclose(eps[0].numpy(), lit, rtol=1e-10, atol=1e-12)
+    ref = np.maximum(np.concatenate([gq.numpy(), lit, gq.numpy()], 1) @ p["memory/hop_0/dense/kernel"].numpy()
+                     + p["memory/hop_0/dense/bias"].numpy(), 0.0)
+    np.testing.assert_allclose(out.numpy(), ref, rtol=1e-10, atol=1e-12)
+
+
+def test_dropout_hash_masks():
+    """The counter-based keep masks the library and the oracle share (oracle.fvta_fused.dropout_keep_masks): keep rate,
+    the two directions' independence, determinism, seed sensitivity, keep_prob 1 keeps everything."""
+    from oracle import fvta_fused as F
+    n = 200000
+    a = F.dropout_keep_masks(n, 0.7, 123)
+    assert a.shape == (2, n) and a.dtype == torch.bool
+    assert abs(float(a.float().mean()) - 0.7) < 0.005
+    both = float((a[0] & a[1]).float().mean())
+    assert abs(both - 0.49) < 0.006                     # independent directions: P(both kept) = 0.7^2
+    assert torch.equal(a, F.dropout_keep_masks(n, 0.7, 123))
+    assert not torch.equal(a, F.dropout_keep_masks(n, 0.7, 124))
+    assert bool(F.dropout_keep_masks(1000, 1.0, 5).all())
+    assert torch.equal(F.dropout_keep_flat(2 * n, 0.7, 123).reshape(2, n), a)
