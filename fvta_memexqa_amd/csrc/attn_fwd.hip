@@ -1250,21 +1250,44 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
   {
     const int W4c = w / 4;
     const uint16_t* qh = a.sv.Qh + (size_t)n * 2 * W4c * 32 * 4;
-    for (int e = tid; e < 2 * 2 * NKS * 2 * 64; e += 512) {
+    // every load of the staging is issued before the first LDS write: as a rolled loop (two loads, wait, write) the
+    // 128 KB took 16 dependent round trips per thread, 35-50 k cycles before the first tile was even requested
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int QIT = 2 * 2 * NKS * 2 * 64 / 512;
+    u32x2 x0[QIT], x1[QIT];
+#pragma unroll
+    for (int it = 0; it < QIT; ++it) {
+      const int e = tid + 512 * it;
       const int ln = e & 63, jt = (e >> 6) & 1, ks = (e >> 7) % (2 * NKS), pc = (e >> 7) / (2 * NKS);
       const int j = (ln & 15) + 16 * jt, q4 = ln >> 4;
-      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      const u32x2 x0 = *reinterpret_cast<const u32x2*>(qh + (((size_t)pc * W4c + 8 * ks + q4) * 32 + j) * 4);
-      const u32x2 x1 = *reinterpret_cast<const u32x2*>(qh + (((size_t)pc * W4c + 8 * ks + 4 + q4) * 32 + j) * 4);
-      const u32x4 xx = __builtin_shufflevector(x0, x1, 0, 1, 2, 3);
+      x0[it] = *reinterpret_cast<const u32x2*>(qh + (((size_t)pc * W4c + 8 * ks + q4) * 32 + j) * 4);
+      x1[it] = *reinterpret_cast<const u32x2*>(qh + (((size_t)pc * W4c + 8 * ks + 4 + q4) * 32 + j) * 4);
+    }
+    float v0[2], v1[2];  // w <= 1024: at most two channels of each row-term vector per thread
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c = tid + 512 * it;
+      v0[it] = c < w ? a.sv.vecs[VEC_RH * w + c] : 0.f;
+      v1[it] = c < w ? a.sv.vecs[VEC_R2 * w + c] : 0.f;
+    }
+    const float ctv = tid < 32 ? a.sv.ct[(size_t)n * JP + tid] : 0.f;
+#pragma unroll
+    for (int it = 0; it < QIT; ++it) {
+      const int e = tid + 512 * it;
+      const int ln = e & 63, jt = (e >> 6) & 1, ks = (e >> 7) % (2 * NKS), pc = (e >> 7) / (2 * NKS);
+      const u32x4 xx = __builtin_shufflevector(x0[it], x1[it], 0, 1, 2, 3);
       (pc == 0 ? s_qhi : s_qlo)[ks][jt][ln] = __builtin_bit_cast(half8, xx);
     }
-    for (int c = tid; c < w; c += 512) {
-      s_vec[c] = a.sv.vecs[VEC_RH * w + c];
-      s_vec[w + c] = a.sv.vecs[VEC_R2 * w + c];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c = tid + 512 * it;
+      if (c < w) {
+        s_vec[c] = v0[it];
+        s_vec[w + c] = v1[it];
+      }
     }
-    if (tid < 32) s_ct[tid] = a.sv.ct[(size_t)n * JP + tid];
+    if (tid < 32) s_ct[tid] = ctv;
   }
   const uint64_t qvalid = a.sv.qvalid[(size_t)n * 2];
   const int nitems_n = s.K * s.nsplit;
