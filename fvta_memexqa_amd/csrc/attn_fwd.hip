@@ -1911,6 +1911,8 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   a.hstride = d->hinfo_stride ? (size_t)d->hinfo_stride : (size_t)s.T * s.w;
   a.ipw = 1;
   a.dbg = fvta_diag_env("FVTA_ATTN_DBG", 0);  // -DFVTA_DIAG builds only
+  // (the phase stamps land 32 MiB into the workspace: only where the workspace reaches that far)
+  if ((a.dbg & 16) && fvta_attn_workspace_bytes(d) < ((size_t)32 << 20) + 64 * 16 * 8) a.dbg &= ~16;
   // (the bracket files the context attention only: the K = 1 question attention is a 15 us launch of the same kernel)
   const bool prof_it = (size_t)s.N * s.K * s.T >= 65536;
   if (prof_it) fvta_prof_begin(FVTA_PROF_ATTN_FWD_MAIN, stream);
