@@ -505,12 +505,23 @@ __global__ __launch_bounds__((TileCfgT<WN, TM, WM>::NT), (WN == 1 ? 2 : 1)) void
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir] + (size_t)a.in_i * K, (unsigned)d * K * 2);  // the h rows of wb
     RowSrc<TileCfg::A_GLDS> az;
     RowSrc<TileCfg::B_GLDS> bw;
+#ifdef FVTA_BWD_FAKE_BLOCKED
+    // timing experiment (results are garbage): the A operand addressed AS IF dz were stored k-tile-major
+    // [K/32][rows][32] -- a k-tile's 256 row pieces are then one contiguous 16 KB instead of 64 B every 4 KB
+    az.setup(mma.wave_all, mma.lane, m0, nnext, 64);
+    bw.setup(mma.wave_all, mma.lane, u0, d, K * 2);
+    auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
+      az.issue(rz, As, mma.wave_all, (unsigned)tile * (unsigned)nnext * 64u);
+      bw.issue(rw, Bs, mma.wave_all, tile * 64);
+    };
+#else
     az.setup(mma.wave_all, mma.lane, m0, nnext, K * 2);
     bw.setup(mma.wave_all, mma.lane, u0, d, K * 2);
     auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
       az.issue(rz, As, mma.wave_all, tile * 64);
       bw.issue(rw, Bs, mma.wave_all, tile * 64);
     };
+#endif
     if (st) st[0] = __builtin_readcyclecounter();
     glds_mainloop<false>(mma, issue, K / 32, smem_h, st ? st + 8 : nullptr, a.sp ? 4 : 0);
     if (st) st[1] = __builtin_readcyclecounter();
