@@ -438,6 +438,12 @@ void launch_step_bwd_bf16(const StepBwdArgs& a, hipStream_t s) {
 // WM < 8 / TM: block tiles of fewer rows (64 x 128 on ONE wave, 128 x 128 on two) for calls with few sequences -- the
 // photo cell's 64 rows: a step is then a chain of K/32 k-tiles whose length is the DMA wave-instructions per k-tile
 // (A rows + B rows, at ~40 clocks each whether or not the rows exist), 12 instead of 32.
+#ifndef FVTA_BWD_EPI_ROWS
+#define FVTA_BWD_EPI_ROWS 2  // rows of the epilogue whose loads are in flight together (4: 256 VGPRs + spills, no faster; 8: 2x slower)
+#endif
+#ifndef FVTA_BWD_RC_ONLY
+#define FVTA_BWD_RC_ONLY 0   // 1: compile the "c(t) read back" path out (measurement)
+#endif
 template <int WN, int TM, int WM = 8 / TM>
 __global__ __launch_bounds__((TileCfgT<WN, TM, WM>::NT), (WN == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
   typedef TileCfgT<WN, TM, WM> TileCfg;
@@ -533,51 +539,86 @@ __global__ __launch_bounds__((TileCfgT<WN, TM, WM>::NT), (WN == 1 ? 2 : 1)) void
   const float* __restrict__ cs_t = a.cs + trow * d;
   const float* __restrict__ cs_p = a.cs + (trow - a.B) * d;  // step t-1 (unused at t == 0)
   float* __restrict__ dcs = a.dc + (size_t)dir * a.B * d;
+  // RB rows per batch: ALL their loads are issued before the first of them is used.  (Row by row, two per unrolled
+  // pass, every pass waited for its own loads AND -- vmcnt retires in order, stores included -- for the previous pass's
+  // stores: a chain of 16 memory round trips per workgroup, which is what kept a launch with few active rows as long as a
+  // full one.)
+  constexpr int RB = FVTA_BWD_EPI_ROWS;
+  static_assert(16 % RB == 0, "row batches tile the 16 rows of an accumulator tile");
+  // (one call per batch with compile-time tile / row numbers: as a loop the compiler declines to unroll it and indexes the
+  //  accumulators through scratch)
+  auto epi_batch = [&](auto ti_c, auto r0_c) {
+    {
+      constexpr int ti = decltype(ti_c)::value, r0 = decltype(r0_c)::value;
+      bf16x4 gp[RB][MmaB::TN];
+      float c[RB][MmaB::TN], cp[RB][MmaB::TN], dcv[RB][MmaB::TN], dout[RB][MmaB::TN];
+      // unconditional loads of the four column tiles of the batch's rows, then math, then guarded stores
 #pragma unroll
-  for (int ti = 0; ti < MmaB::TM; ++ti)
-#pragma unroll 2
-    for (int r = 0; r < 16; ++r) {
-      const int row = mma.row_of(ti, r);
-      const int i = m0 + row, ic = min(i, nact - 1);
-      const int64_t oo = s_oo[min(row, nact - 1 - m0)];
-      // unconditional loads of the four column tiles of this row, then math, then guarded stores
-      bf16x4 gp[MmaB::TN];
-      float c[MmaB::TN], cp[MmaB::TN], dcv[MmaB::TN], dout[MmaB::TN];
+      for (int rr = 0; rr < RB; ++rr) {
+        const int row = mma.row_of(ti, r0 + rr);
+        const int ic = min(m0 + row, nact - 1);
+        const int64_t oo = s_oo[min(row, nact - 1 - m0)];
 #pragma unroll
-      for (int tj = 0; tj < MmaB::TN; ++tj) {
-        const int u = min(u0 + mma.col_of(tj), d - 1);
-        if (a.ntl) {
-          gp[tj] = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(a.gatesb + (trow + ic) * (size_t)K + 4 * u));
-          c[tj] = a.rc ? 0.f : __builtin_nontemporal_load(cs_t + (size_t)ic * d + u);
-          cp[tj] = t > 0 ? __builtin_nontemporal_load(cs_p + (size_t)ic * d + u) : 0.f;
-          dout[tj] = __builtin_nontemporal_load(a.d_out + oo + u);
-        } else {
-          gp[tj] = *reinterpret_cast<const bf16x4*>(a.gatesb + (trow + ic) * (size_t)K + 4 * u);
-          c[tj] = a.rc ? 0.f : cs_t[(size_t)ic * d + u];
-          cp[tj] = t > 0 ? cs_p[(size_t)ic * d + u] : 0.f;
-          dout[tj] = a.d_out[oo + u];
+        for (int tj = 0; tj < MmaB::TN; ++tj) {
+          const int u = min(u0 + mma.col_of(tj), d - 1);
+          if (a.ntl) {
+            gp[rr][tj] = __builtin_nontemporal_load(reinterpret_cast<const bf16x4*>(a.gatesb + (trow + ic) * (size_t)K + 4 * u));
+            c[rr][tj] = FVTA_BWD_RC_ONLY ? 0.f : (a.rc ? 0.f : __builtin_nontemporal_load(cs_t + (size_t)ic * d + u));
+            cp[rr][tj] = t > 0 ? __builtin_nontemporal_load(cs_p + (size_t)ic * d + u) : 0.f;
+            dout[rr][tj] = __builtin_nontemporal_load(a.d_out + oo + u);
+          } else {
+            gp[rr][tj] = *reinterpret_cast<const bf16x4*>(a.gatesb + (trow + ic) * (size_t)K + 4 * u);
+            c[rr][tj] = FVTA_BWD_RC_ONLY ? 0.f : (a.rc ? 0.f : cs_t[(size_t)ic * d + u]);
+            cp[rr][tj] = t > 0 ? cs_p[(size_t)ic * d + u] : 0.f;
+            dout[rr][tj] = a.d_out[oo + u];
+          }
+          dcv[rr][tj] = dcs[(size_t)ic * d + u];
         }
-        dcv[tj] = dcs[(size_t)ic * d + u];
       }
 #pragma unroll
-      for (int tj = 0; tj < MmaB::TN; ++tj) {
-        const int u = u0 + mma.col_of(tj);
-        const float ig = bf2f((bf16_t)gp[tj][0]), jg = bf2f((bf16_t)gp[tj][1]), fg = bf2f((bf16_t)gp[tj][2]),
-                    og = bf2f((bf16_t)gp[tj][3]);
-        const float dh = dout[tj] + mma.acc[ti][tj][r];
-        const float tc = fvta_tanh(a.rc ? cp[tj] * fg + ig * jg : c[tj]);
-        const float dc = dcv[tj] + dh * og * (1.f - tc * tc);
-        bf16x4 pk;
-        pk[0] = (short)f2bf(dc * jg * ig * (1.f - ig));
-        pk[1] = (short)f2bf(dc * ig * (1.f - jg * jg));
-        pk[2] = (short)f2bf(dc * cp[tj] * fg * (1.f - fg));
-        pk[3] = (short)f2bf(dh * tc * og * (1.f - og));
-        if (i < nact && u < d) {
-          *reinterpret_cast<bf16x4*>(a.dzb + (trow + i) * (size_t)K + 4 * u) = pk;
-          dcs[(size_t)i * d + u] = dc * fg;
+      for (int rr = 0; rr < RB; ++rr) {
+        const int i = m0 + mma.row_of(ti, r0 + rr);
+#pragma unroll
+        for (int tj = 0; tj < MmaB::TN; ++tj) {
+          const int u = u0 + mma.col_of(tj);
+          const float ig = bf2f((bf16_t)gp[rr][tj][0]), jg = bf2f((bf16_t)gp[rr][tj][1]), fg = bf2f((bf16_t)gp[rr][tj][2]),
+                      og = bf2f((bf16_t)gp[rr][tj][3]);
+          const float dh = dout[rr][tj] + mma.acc[ti][tj][r0 + rr];
+          const float tc = fvta_tanh((FVTA_BWD_RC_ONLY || a.rc) ? cp[rr][tj] * fg + ig * jg : c[rr][tj]);
+          const float dc = dcv[rr][tj] + dh * og * (1.f - tc * tc);
+          bf16x4 pk;
+          pk[0] = (short)f2bf(dc * jg * ig * (1.f - ig));
+          pk[1] = (short)f2bf(dc * ig * (1.f - jg * jg));
+          pk[2] = (short)f2bf(dc * cp[rr][tj] * fg * (1.f - fg));
+          pk[3] = (short)f2bf(dh * tc * og * (1.f - og));
+          if (i < nact && u < d) {
+            *reinterpret_cast<bf16x4*>(a.dzb + (trow + i) * (size_t)K + 4 * u) = pk;
+            dcs[(size_t)i * d + u] = dc * fg;
+          }
         }
       }
     }
+  };
+  auto epi_tile = [&](auto ti_c) {
+    epi_batch(ti_c, std::integral_constant<int, 0>{});
+    if constexpr (RB < 16) epi_batch(ti_c, std::integral_constant<int, RB>{});
+    if constexpr (RB < 8) {
+      epi_batch(ti_c, std::integral_constant<int, 2 * RB>{});
+      epi_batch(ti_c, std::integral_constant<int, 3 * RB>{});
+    }
+    if constexpr (RB < 4) {
+      epi_batch(ti_c, std::integral_constant<int, 4 * RB>{});
+      epi_batch(ti_c, std::integral_constant<int, 5 * RB>{});
+      epi_batch(ti_c, std::integral_constant<int, 6 * RB>{});
+      epi_batch(ti_c, std::integral_constant<int, 7 * RB>{});
+    }
+  };
+  static_assert(RB == 2 || RB == 4 || RB == 8 || RB == 16, "epilogue row batch");
+  static_assert(MmaB::TM <= 4, "epilogue tiles");
+  epi_tile(std::integral_constant<int, 0>{});
+  if constexpr (MmaB::TM > 1) epi_tile(std::integral_constant<int, 1>{});
+  if constexpr (MmaB::TM > 2) epi_tile(std::integral_constant<int, 2>{});
+  if constexpr (MmaB::TM > 3) epi_tile(std::integral_constant<int, 3>{});
   if (st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     st[2] = __builtin_readcyclecounter();
