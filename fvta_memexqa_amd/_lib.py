@@ -47,6 +47,7 @@ P = c_void_p
 _SIGS = {
     "fvta_version": (c_int, []),
     "fvta_last_error": (c_char_p, []),
+    "fvta_abi_struct_bytes": (c_int64, [c_int32]),
     "fvta_attn_workspace_bytes": (c_size_t, [POINTER(AttnDesc)]),
     "fvta_attn_saved_bytes": (c_size_t, [POINTER(AttnDesc)]),
     "fvta_attn_fwd": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P]),
@@ -137,6 +138,12 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # the descriptor structs are declared twice (include/fvta_hip.h and above): refuse a library whose layout differs
+    for which, cls in enumerate((AttnDesc, LstmDesc, ScorerDesc, TimewarpDesc, EmbedDesc, ImgTransDesc)):
+        have, want = ctypes.sizeof(cls), lib.fvta_abi_struct_bytes(which)
+        if have != want:
+            raise FvtaError("%s is %d bytes here but %d in %s: rebuild the library (descriptor layouts differ)"
+                            % (cls.__name__, have, want, LIB_PATH))
     _lib = lib
     return lib
 

@@ -19,6 +19,20 @@ void fvta_set_error(const char* fmt, ...) {
 extern "C" int fvta_version(void) { return 100; }
 extern "C" const char* fvta_last_error(void) { return g_err; }
 
+// sizeof of the descriptor structs as THIS library was compiled: a binding (ctypes, cgo, JNI) checks its own layout
+// against it at load time instead of corrupting a call silently
+extern "C" int64_t fvta_abi_struct_bytes(int32_t which) {
+  switch (which) {
+    case 0: return (int64_t)sizeof(fvta_attn_desc);
+    case 1: return (int64_t)sizeof(fvta_lstm_desc);
+    case 2: return (int64_t)sizeof(fvta_scorer_desc);
+    case 3: return (int64_t)sizeof(fvta_timewarp_desc);
+    case 4: return (int64_t)sizeof(fvta_embed_desc);
+    case 5: return (int64_t)sizeof(fvta_imgtrans_desc);
+    default: return -1;
+  }
+}
+
 // ---- profiling brackets ------------------------------------------------------
 namespace {
 struct Bracket {

@@ -41,6 +41,10 @@ typedef void* fvta_stream_t; /* hipStream_t */
 
 int fvta_version(void);
 const char* fvta_last_error(void);
+/* sizeof of a descriptor struct as the library was compiled: which = 0 fvta_attn_desc, 1 fvta_lstm_desc,
+ * 2 fvta_scorer_desc, 3 fvta_timewarp_desc, 4 fvta_embed_desc, 5 fvta_imgtrans_desc; -1 otherwise.  A binding compares
+ * its own layout with it when it loads the library (fvta_memexqa_amd/_lib.py does). */
+int64_t fvta_abi_struct_bytes(int32_t which);
 
 /* ------------------------------------------------------------------------- *
  * Focal attention: model_v2.py:210-298 `attention_3d` (K modalities) and

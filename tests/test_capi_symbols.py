@@ -75,3 +75,15 @@ def test_ops_refuse_to_run_without_gpu():
     from fvta_memexqa_amd.model_v2 import Model
     with pytest.raises(_lib.FvtaError):
         Model(dict(hidden_size=32))
+
+
+def test_descriptor_struct_sizes_match_the_library():
+    """The ctypes mirrors of the descriptor structs against the library's own sizeof (fvta_abi_struct_bytes): _lib.load()
+    refuses a mismatch; here the table itself is checked, including an unknown id."""
+    import ctypes
+    from fvta_memexqa_amd import _lib
+    lib = _lib.load()
+    for which, cls in enumerate((_lib.AttnDesc, _lib.LstmDesc, _lib.ScorerDesc, _lib.TimewarpDesc, _lib.EmbedDesc, _lib.ImgTransDesc)):
+        assert lib.fvta_abi_struct_bytes(which) == ctypes.sizeof(cls), cls.__name__
+    assert lib.fvta_abi_struct_bytes(99) == -1
+    assert ctypes.sizeof(_lib.EmbedDesc) == 48 and ctypes.sizeof(_lib.AttnDesc) == 40
