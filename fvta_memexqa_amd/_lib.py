@@ -65,6 +65,7 @@ _SIGS = {
     "fvta_bilstm_fwd": (c_int, [POINTER(LstmDesc), P, P, P, P, P, P, P, P, P, P]),
     "fvta_bilstm_bwd": (c_int, [POINTER(LstmDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_bilstm_bwd_overlap": (c_int, [POINTER(LstmDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_bilstm_bwd_hint": (c_int, [POINTER(LstmDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_lstm_last_state": (c_int, [POINTER(LstmDesc), P, P, c_int32, c_int32, P, P]),
     "fvta_lstm_last_state_bwd": (c_int, [POINTER(LstmDesc), P, P, c_int32, c_int32, P, P]),
     "fvta_scorer_ce_fwd": (c_int, [POINTER(ScorerDesc), P, P, P, P, P, P, P, P, P, P]),

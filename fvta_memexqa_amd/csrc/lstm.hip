@@ -546,8 +546,8 @@ extern "C" int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const 
                                const float* d_out, const float* kernel_fw, const float* kernel_bw, void* saved,
                                float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw,
                                float* dbias_bw, void* workspace, fvta_stream_t stream_) {
-  return fvta_bilstm_bwd_overlap(d, plan, x, out, d_out, kernel_fw, kernel_bw, saved, dx, dkernel_fw, dbias_fw, dkernel_bw,
-                                 dbias_bw, workspace, stream_, nullptr);
+  return fvta_bilstm_bwd_hint(d, plan, x, out, d_out, kernel_fw, kernel_bw, saved, dx, dkernel_fw, dbias_fw, dkernel_bw,
+                              dbias_bw, workspace, stream_, nullptr, nullptr);
 }
 
 extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan, const float* x, const float* out,
@@ -555,6 +555,15 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
                                        float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw,
                                        float* dbias_bw, void* workspace, fvta_stream_t stream_,
                                        fvta_stream_t side_stream_) {
+  return fvta_bilstm_bwd_hint(d, plan, x, out, d_out, kernel_fw, kernel_bw, saved, dx, dkernel_fw, dbias_fw, dkernel_bw,
+                              dbias_bw, workspace, stream_, side_stream_, nullptr);
+}
+
+extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, const float* x, const float* out,
+                                    const float* d_out, const float* kernel_fw, const float* kernel_bw, void* saved,
+                                    float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw,
+                                    float* dbias_bw, void* workspace, fvta_stream_t stream_,
+                                    fvta_stream_t side_stream_, const int32_t* nactive_host) {
   if (int e = check_lstm_desc(d)) return e;
   FVTA_CHECK_ARG(d->training, "bilstm_bwd: forward was not run with training=1");
   FVTA_CHECK_ARG(plan && x && out && d_out && kernel_fw && saved && dkernel_fw && dbias_fw && workspace,
@@ -668,6 +677,7 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
     f.dir0 = 0;
     f.ndir = 2;
     f.dxmode = 0;
+    f.nact_hint = -1;
     // dx rides on the step launches (dx_{t+1} next to dh_t: same A operand) unless it goes to the side stream / is off
     f.dx_tiles = (dx && !ov_dx) ? bwd_fused_dx_tiles(in, dd) : 0;
     f.stamp_wg = fvta_diag_env("FVTA_LSTM_STAMP_BWD", -1);  // -DFVTA_DIAG builds only
@@ -684,6 +694,13 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
       }();
       f.rc = rc;
     }
+    // FVTA_LSTM_BWD_HINT=1: act on the host's lengths hint.  OFF by default: on the ragged variant it shortens the text
+    // cell's backward launches (4.02 -> 3.86 ms) but the STEP gets longer (8.28 -> 8.47 ms) -- what ends that step is the
+    // photo cell's chain of 40 small launches on the side stream, and the many small workgroups crowd it (tools/r02_af.sh)
+    static const bool use_hint = [] {
+      const char* e = getenv("FVTA_LSTM_BWD_HINT");
+      return e && e[0] == '1';
+    }();
     if (split_dirs) {
       hipEvent_t e = new_event();
       ev_ok = e && hipEventRecord(e, stream) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess;
@@ -706,6 +723,7 @@ extern "C" int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan
     } else
     for (int t = J - 1; t >= 0; --t) {
       f.t = t;
+      f.nact_hint = (nactive_host && use_hint) ? nactive_host[t] : -1;
       launch_bwd_fused_bf16(f, stream);
       if (overlap && t % w.tgroup == 0) {  // every dz of step group t / tgroup is final once this launch is done
         hipEvent_t e = new_event();

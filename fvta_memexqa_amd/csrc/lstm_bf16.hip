@@ -666,7 +666,12 @@ void launch_bwd_fused_bf16(const FusedBwdArgs& a_, hipStream_t s) {
       allow_big_lds(lstm_bwd_fused_bf16<1, 2, 2>, LDS);
       hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 2, 2>), dim3((a.B + 127) / 128, a.dh_tiles, a.ndir), dim3(128), LDS, s, a);
     }
-  } else if (a.d % 256 == 0 && !narrow) {  // 256 x 256 tile: dz (the A operand, K = 4d wide) is re-read d/256 instead of d/128 times
+  } else if (a.d % 256 == 0 && !narrow &&
+             !(a.nact_hint >= 0 && a.dx_tiles == 0 && 8 * ((a.nact_hint + 255) / 256) <= 256)) {
+    // 256 x 256 tile: dz (the A operand, K = 4d wide) is re-read d/256 instead of d/128 times.  NOT for a step whose
+    // active rows make at most 256 of the 256 x 128 workgroups (host hint): a launch lasts as long as one workgroup's
+    // chain of k-tiles and its epilogue, and the small workgroup alone on a CU is through both sooner (ragged batches:
+    // DESIGN.md 4.3.1)
     constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
     allow_big_lds(lstm_bwd_fused_bf16<2, 2>, LDS);
     a.dh_tiles = a.d / 256;

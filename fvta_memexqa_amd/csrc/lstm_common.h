@@ -483,6 +483,7 @@ struct FusedBwdArgs {
   int dh_tiles, dx_tiles;  // column tiles of the fused step launch: dh_t tiles, then dx_{t+1} tiles (0: separate dx pass)
   int ntl;       // read-once operands of the gate gradient (saved gates, cell states, d_out) through non-temporal loads
   int dxmode;    // lstm_dx: 0 atomicAdd (both directions in one launch); 1 plain store (first direction); 2 load-add-store (second)
+  int nact_hint; // active sequences of step t as the HOST knows them (fvta_bilstm_bwd_hint), -1: unknown -- picks the step's tile
   int rc;        // c_t is not read back but rebuilt from the saved (bf16) gates and c_{t-1}: 4 of the epilogue's 36 B per (row, unit)
 };
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s);

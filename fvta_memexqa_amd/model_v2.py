@@ -760,6 +760,7 @@ class Model:
             for cell, G in L.groups.items():
                 pp = parts[cell]
                 up(G.lens, np.concatenate(pp["lens"]))
+                G.op.set_active_hint(np.concatenate(pp["lens"]))     # the host knows the lengths: see BiLstm.set_active_hint
                 if cell == "text":
                     up(G.word_ids, np.concatenate(pp["ids"]))
                     if G.char_ids is not None:
@@ -785,7 +786,10 @@ class Model:
                     else:
                         G.pidx[s["tok0"]:s["tok0"] + n] = st["pis"].reshape(-1).to(dev, torch.int32)
                 G.lens[s["s0"]:s["s0"] + s["count"]] = mask.reshape(-1, mask.shape[-1]).to(dev).sum(1).to(torch.int32)
+                if not mask.is_cuda:      # masks that live on the host: their row sums are the lengths hint (no device sync)
+                    host_lens.setdefault(cell, {})[si] = mask.reshape(-1, mask.shape[-1]).sum(1).numpy()
 
+            host_lens = {}
             put("text", 0, inputs["q"])
             put("text", 1, inputs["choices"])
             L.q_mask.copy_(inputs["q"]["mask"].to(dev, torch.uint8))
@@ -794,6 +798,9 @@ class Model:
                 cell, si, dims = L.ctx_slots[k]
                 put(cell, si, st)
                 self._put_ctx_mask(L, L.hall_mask, k, st["mask"].to(dev, torch.uint8).reshape(L.N, L.M, -1))
+            for cell, G in L.groups.items():
+                got = host_lens.get(cell, {})
+                G.op.set_active_hint(np.concatenate([got[i] for i in range(len(G.segs))]) if len(got) == len(G.segs) else None)
         if inputs.get("y") is not None:
             y = inputs["y"]
             L.y.copy_((y if torch.is_tensor(y) else torch.from_numpy(np.ascontiguousarray(y))).to(torch.uint8))

@@ -131,14 +131,28 @@ class BiLstm:
                                        ptr(_f32c(kernel_fw)), ptr(_f32c(bias_fw)), ptr(kernel_bw), ptr(bias_bw),
                                        ptr(self.saved), ptr(self.work), stream_ptr()), "fvta_bilstm_fwd")
 
+    def set_active_hint(self, lens_host):
+        """What the host knows about the lengths of the NEXT plan (a numpy / list of the B lengths, or None): the backward
+        recurrence sizes each step's launch by its active sequences (fvta_bilstm_bwd_hint).  Optional; a stale hint costs
+        time, never correctness."""
+        if lens_host is None:
+            self.active_hint = None
+            return
+        import numpy as np
+        ln = np.clip(np.asarray(lens_host, dtype=np.int64).reshape(-1), 0, self.J)
+        below = np.cumsum(np.bincount(ln, minlength=self.J + 1))[:self.J]      # sequences with len <= t
+        self.active_hint = np.ascontiguousarray(ln.size - below, dtype=np.int32)   # nactive[t] = #(len > t)
+
     def backward(self, x, out, d_out, kernel_fw, kernel_bw, dx, dk_fw, db_fw, dk_bw=None, db_bw=None, side_stream=None):
         """side_stream (a torch stream, bf16 engine): dx and the per-step-group weight gradients run there, beside the
         recurrence (fvta_bilstm_bwd_overlap); the current stream has joined it again when this returns."""
         side = ctypes.c_void_p(side_stream.cuda_stream) if side_stream is not None else None
-        check(self.lib.fvta_bilstm_bwd_overlap(ctypes.byref(self.desc), ptr(self.plan), ptr(x), ptr(out), ptr(_f32c(d_out)),
-                                               ptr(kernel_fw), ptr(kernel_bw), ptr(self.saved), ptr(dx), ptr(dk_fw),
-                                               ptr(db_fw), ptr(dk_bw), ptr(db_bw), ptr(self.work), stream_ptr(), side),
-              "fvta_bilstm_bwd_overlap")
+        hint = getattr(self, "active_hint", None)
+        hp = hint.ctypes.data_as(ctypes.c_void_p) if hint is not None else None
+        check(self.lib.fvta_bilstm_bwd_hint(ctypes.byref(self.desc), ptr(self.plan), ptr(x), ptr(out), ptr(_f32c(d_out)),
+                                            ptr(kernel_fw), ptr(kernel_bw), ptr(self.saved), ptr(dx), ptr(dk_fw),
+                                            ptr(db_fw), ptr(dk_bw), ptr(db_bw), ptr(self.work), stream_ptr(), side, hp),
+              "fvta_bilstm_bwd")
 
     def last_state(self, out, s0, count, dst):
         check(self.lib.fvta_lstm_last_state(ctypes.byref(self.desc), ptr(self.plan), ptr(out), s0, count, ptr(dst),

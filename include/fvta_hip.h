@@ -181,6 +181,18 @@ int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan, const flo
                             float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
                             void* workspace, fvta_stream_t stream, fvta_stream_t side_stream);
 
+/* The same with what the HOST knows about the batch: nactive_host[t] (host memory, J entries, or NULL) = sequences with
+ * len > t, read while the call enqueues its launches.  The plan is built on the device without a host sync, so the
+ * library cannot size a step's launch by its active rows itself; with the hint the backward recurrence gives a step
+ * with few active rows the small block tile (bf16 engine; results are bitwise those of fvta_bilstm_bwd_overlap: the
+ * order of every sum is the same).  A wrong hint costs time, never correctness.  The library acts on it only under
+ * FVTA_LSTM_BWD_HINT=1: measured on ragged batches the shorter text-cell launches lengthen the step, whose end is the
+ * photo cell's chain of small launches on the side stream. */
+int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, const float* x, const float* out,
+                         const float* d_out, const float* kernel_fw, const float* kernel_bw, void* saved,
+                         float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
+                         void* workspace, fvta_stream_t stream, fvta_stream_t side_stream, const int32_t* nactive_host);
+
 /* Final states = concat(fw .h at t=len-1, bw .h at t=0) of sequences
  * [s0, s0+count): lq model_v2.py:697, lchoices 807-812.  dst [count, 2d]. */
 int fvta_lstm_last_state(const fvta_lstm_desc* d, const void* plan, const float* out, int32_t s0,

@@ -131,3 +131,37 @@ def test_bilstm_bf16_backward_overlapped_equals_serial(B, J, din, d, dense):
         assert torch.equal(cur[1], ref[1]), "dkernel"
         assert torch.equal(cur[2], ref[2]), "dbias"
         _close(cur[0], ref[0], rtol=1e-5, atol=1e-6, msg="dx")
+
+
+def test_backward_with_host_lengths_hint_is_bitwise_the_same():
+    """fvta_bilstm_bwd_hint: the host's knowledge of the lengths only picks each step's block tile (few active rows: the
+    small one) -- gradients are bitwise those of the unhinted call, also under a WRONG hint (costs time, never
+    correctness)."""
+    from fvta_memexqa_amd import ops
+    from fvta_memexqa_amd._lib import BF16
+    g = torch.Generator().manual_seed(31)
+    B, J, din, d = 700, 9, 16, 256
+    x = torch.randn(B, J, din, generator=g).cuda()
+    lens = torch.randint(0, J + 1, (B,), generator=g)
+    lim = (6.0 / (din + d + 4 * d)) ** 0.5
+    k = ((torch.rand(din + d, 4 * d, generator=g) * 2 - 1) * lim * 2).cuda()
+    b = (torch.randn(4 * d, generator=g) * 0.1).cuda()
+    mask = (torch.arange(J)[None, :] < lens[:, None])
+    g_out = (torch.randn(B, J, 2 * d, generator=g) * mask[:, :, None]).cuda()
+    out, last, op = ops.bilstm_simple(x, lens, k, b, None, None, training=True, precision=BF16)
+
+    def grads(hint):
+        op.set_active_hint(hint)
+        dx, dk, db = torch.zeros_like(x), torch.zeros_like(k), torch.zeros_like(b)
+        op.backward(x, out, g_out.clone(), k, None, dx, dk, db)
+        torch.cuda.synchronize()
+        return dx, dk, db
+
+    base = grads(None)
+    assert float(base[1].abs().max()) > 0
+    for hint in (lens.numpy(), np.zeros(B, np.int64), np.full(B, J)):
+        got = grads(hint)
+        for a, e, tag in zip(got, base, ("dx", "dkernel", "dbias")):
+            assert torch.equal(a, e), tag
+    op.set_active_hint(lens.numpy())
+    assert op.active_hint.tolist() == [int((lens > t).sum()) for t in range(J)]
