@@ -697,10 +697,8 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
     // FVTA_LSTM_BWD_HINT=1: act on the host's lengths hint.  OFF by default: on the ragged variant it shortens the text
     // cell's backward launches (4.02 -> 3.86 ms) but the STEP gets longer (8.28 -> 8.47 ms) -- what ends that step is the
     // photo cell's chain of 40 small launches on the side stream, and the many small workgroups crowd it (tools/r02_af.sh)
-    static const bool use_hint = [] {
-      const char* e = getenv("FVTA_LSTM_BWD_HINT");
-      return e && e[0] == '1';
-    }();
+    const char* hint_env = getenv("FVTA_LSTM_BWD_HINT");  // (read per call: the tests flip it)
+    const bool use_hint = hint_env && hint_env[0] == '1';
     if (split_dirs) {
       hipEvent_t e = new_event();
       ev_ok = e && hipEventRecord(e, stream) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess;

@@ -133,7 +133,7 @@ def test_bilstm_bf16_backward_overlapped_equals_serial(B, J, din, d, dense):
         _close(cur[0], ref[0], rtol=1e-5, atol=1e-6, msg="dx")
 
 
-def test_backward_with_host_lengths_hint_is_bitwise_the_same():
+def test_backward_with_host_lengths_hint_is_bitwise_the_same(monkeypatch):
     """fvta_bilstm_bwd_hint: the host's knowledge of the lengths only picks each step's block tile (few active rows: the
     small one) -- gradients are bitwise those of the unhinted call, also under a WRONG hint (costs time, never
     correctness)."""
@@ -159,6 +159,7 @@ def test_backward_with_host_lengths_hint_is_bitwise_the_same():
 
     base = grads(None)
     assert float(base[1].abs().max()) > 0
+    monkeypatch.setenv("FVTA_LSTM_BWD_HINT", "1")      # the library acts on the hint only under this switch
     for hint in (lens.numpy(), np.zeros(B, np.int64), np.full(B, J)):
         got = grads(hint)
         for a, e, tag in zip(got, base, ("dx", "dkernel", "dbias")):
