@@ -27,6 +27,9 @@
 #define FVTA_LSTM_SEQ_DEFAULT 0
 #define FVTA_LSTM_FWD_DIRECT_DEFAULT 0
 #define FVTA_LSTM_SMALL_ROWS_DEFAULT 1
+#ifndef FVTA_LSTM_SMALL_SK_DEFAULT
+#define FVTA_LSTM_SMALL_SK_DEFAULT 0  // 4: measured slower in the step (its 144 KB of LDS wait for a whole free CU), see launch
+#endif
 #define FVTA_LSTM_DX_2PASS_DEFAULT 0
 #endif
 #ifndef FVTA_GLDS_SP_DEFAULT
@@ -444,13 +447,21 @@ void launch_step_bwd_bf16(const StepBwdArgs& a, hipStream_t s) {
 #ifndef FVTA_BWD_RC_ONLY
 #define FVTA_BWD_RC_ONLY 0   // 1: compile the "c(t) read back" path out (measurement)
 #endif
-template <int WN, int TM, int WM = 8 / TM>
-__global__ __launch_bounds__((TileCfgT<WN, TM, WM>::NT), (WN == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
+// SK > 1 (one-wave block tiles only): SK waves per workgroup, each a complete one-wave pipeline of its own (own LDS
+// stages, own DMA) over ONE SK-th of the k-tiles; the partial accumulators meet in LDS and are summed in wave order by
+// wave 0, which alone runs the epilogue.  For calls of few sequences (the photo cell: 4 workgroups per launch) the launch
+// is a chain of K/32 k-tiles at the latency of one; this cuts the chain by SK.
+template <int WN, int TM, int WM = 8 / TM, int SK = 1>
+__global__ __launch_bounds__((TileCfgT<WN, TM, WM>::NT * SK), (WN == 1 && SK == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
   typedef TileCfgT<WN, TM, WM> TileCfg;
   typedef MmaBT<WN, TM, WM> MmaB;
-  extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
-  int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + TileCfg::STAGES * TileCfg::STAGE_ELEMS);
-  const int tid = threadIdx.x, dir = blockIdx.z + a.dir0;
+  static_assert(SK == 1 || TileCfg::NT == 64, "split-K: one-wave block tiles only");
+  constexpr int NTHREADS = TileCfg::NT * SK;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem_all[];
+  const int skw = SK > 1 ? (int)(threadIdx.x >> 6) : 0;                              // this wave's k-slice / LDS region
+  bf16_t* smem_h = smem_all + (size_t)skw * TileCfg::STAGES * TileCfg::STAGE_ELEMS;
+  int64_t* s_oo = reinterpret_cast<int64_t*>(smem_all + (size_t)SK * TileCfg::STAGES * TileCfg::STAGE_ELEMS);
+  const int tid = SK > 1 ? (int)(threadIdx.x & 63) : (int)threadIdx.x, dir = blockIdx.z + a.dir0;
   const int m0 = blockIdx.x * TileCfg::BM, u0 = blockIdx.y * TileCfg::BN;
   const int t = a.t, d = a.d, K = 4 * d;
   // ---- dx tiles riding on the step launch (a.dx_tiles > 0): the column tiles from d/BN on compute
@@ -500,12 +511,12 @@ __global__ __launch_bounds__((TileCfgT<WN, TM, WM>::NT), (WN == 1 ? 2 : 1)) void
   if (m0 >= nact) return;
   const int nnext = (t + 1 < a.J) ? a.plan.nactive[t + 1] : 0;
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
-  for (int r = tid; r < TileCfg::BM; r += TileCfg::NT) s_oo[r] = a.plan.oo[trow + min(m0 + r, nact - 1)];  // clamped: always a valid row
+  for (int r = (int)threadIdx.x; r < TileCfg::BM; r += NTHREADS) s_oo[r] = a.plan.oo[trow + min(m0 + r, nact - 1)];  // clamped: always a valid row
   MmaB mma;
   mma.init(tid);
   // FVTA_DEBUG_SKIP & 65536-style diagnostics: env FVTA_LSTM_STAMP_BWD=<workgroup> stamps step t = 5 (tools/lstm_phases.py)
   const int lin_wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  unsigned long long* st = (a.stamp_wg >= 0 && lin_wg == a.stamp_wg && tid == 0 && t == 5) ? g_lstm_stamps : nullptr;
+  unsigned long long* st = (a.stamp_wg >= 0 && lin_wg == a.stamp_wg && threadIdx.x == 0 && t == 5) ? g_lstm_stamps : nullptr;
   if (m0 < nnext) {
     const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + (trow + a.B) * (size_t)K, (unsigned)nnext * K * 2);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir] + (size_t)a.in_i * K, (unsigned)d * K * 2);  // the h rows of wb
@@ -523,16 +534,48 @@ __global__ __launch_bounds__((TileCfgT<WN, TM, WM>::NT), (WN == 1 ? 2 : 1)) void
 #else
     az.setup(mma.wave_all, mma.lane, m0, nnext, K * 2);
     bw.setup(mma.wave_all, mma.lane, u0, d, K * 2);
+    const int ktiles = K / 32 / SK, ktile0 = skw * ktiles;   // (K = 4d, d a multiple of 32: K / 32 is a multiple of 4)
     auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
-      az.issue(rz, As, mma.wave_all, tile * 64);
-      bw.issue(rw, Bs, mma.wave_all, tile * 64);
+      az.issue(rz, As, mma.wave_all, (ktile0 + tile) * 64);
+      bw.issue(rw, Bs, mma.wave_all, (ktile0 + tile) * 64);
     };
 #endif
     if (st) st[0] = __builtin_readcyclecounter();
+#ifdef FVTA_BWD_FAKE_BLOCKED
     glds_mainloop<false>(mma, issue, K / 32, smem_h, st ? st + 8 : nullptr, a.sp ? 4 : 0);
+#else
+    glds_mainloop<false>(mma, issue, ktiles, smem_h, st ? st + 8 : nullptr, a.sp ? 4 : 0);
+#endif
     if (st) st[1] = __builtin_readcyclecounter();
   }
   __syncthreads();
+  if constexpr (SK > 1) {
+    // the waves' partial sums: each into ITS OWN stage region (36 KB, the pipeline is drained), [register][lane]; wave 0
+    // adds them in wave order -- one fixed order, whatever the waves' timing -- and carries on alone
+    float* mine = reinterpret_cast<float*>(smem_h);
+    if (skw > 0) {
+#pragma unroll
+      for (int i = 0; i < MmaB::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < MmaB::TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mine[((i * MmaB::TN + j) * 16 + r) * 64 + tid] = mma.acc[i][j][r];
+    }
+    __syncthreads();
+    if (skw > 0) return;
+#pragma unroll
+    for (int i = 0; i < MmaB::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < MmaB::TN; ++j) {
+#pragma unroll
+        for (int w2 = 1; w2 < SK; ++w2) {
+          const float* other = reinterpret_cast<const float*>(smem_all + (size_t)w2 * TileCfg::STAGES * TileCfg::STAGE_ELEMS);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mma.acc[i][j][r] += other[((i * MmaB::TN + j) * 16 + r) * 64 + tid];
+        }
+        asm volatile("" ::: "memory");  // one accumulator tile at a time: hoisting all 384 reads spills
+      }
+  }
   // (An LDS-staged, row-contiguous version of this epilogue -- as in the forward step -- was measured and is NOT
   // faster here: the tile's epilogue moves 36 B per (row, unit), 484 MB per launch, and the kernel already runs at
   // ~4.2 TB/s; it is bound by HBM and by the latency of these loads, not by the number of VMEM instructions.)
@@ -657,7 +700,19 @@ void launch_bwd_fused_bf16(const FusedBwdArgs& a_, hipStream_t s) {
     hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4>), grid, dim3(256), LDS, s, a);
   } else if (a.B <= 128 && small_rows() && a.dx_tiles == 0) {  // few sequences (the photo cell): row tiles of 64 / 128
     a.dh_tiles = (a.d + 127) / 128;
-    if (a.B <= 64) {
+    // FVTA_LSTM_SMALL_SK=4: the k-loop of a 64-row call split over four waves of the workgroup (see the kernel).  Off:
+    // parity-green, but each wave's private three-stage pipeline makes the workgroup 144 KB of LDS -- it no longer fits
+    // beside a text-cell workgroup (96 KB) and waits for a whole free CU: 200 us per launch instead of 132 beside the text
+    // cell's recurrence, dense step 15.0 -> 15.7 ms, ragged 8.22 -> 8.17 (tools/r02_ah.sh, tools/r02_ai.sh)
+    static const int small_sk = [] {
+      const char* e = getenv("FVTA_LSTM_SMALL_SK");
+      return e ? atoi(e) : FVTA_LSTM_SMALL_SK_DEFAULT;
+    }();
+    if (a.B <= 64 && small_sk == 4 && (a.d / 8) % 4 == 0) {
+      constexpr int LDS = 4 * TileCfgT<1, 2, 1>::LDS_BYTES + 64 * 8;
+      allow_big_lds(lstm_bwd_fused_bf16<1, 2, 1, 4>, LDS);
+      hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 2, 1, 4>), dim3((a.B + 63) / 64, a.dh_tiles, a.ndir), dim3(256), LDS, s, a);
+    } else if (a.B <= 64) {
       constexpr int LDS = TileCfgT<1, 2, 1>::LDS_BYTES + 64 * 8;
       allow_big_lds(lstm_bwd_fused_bf16<1, 2, 1>, LDS);
       hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 2, 1>), dim3((a.B + 63) / 64, a.dh_tiles, a.ndir), dim3(64), LDS, s, a);
