@@ -663,6 +663,17 @@ class Model:
         n = s["count"] * s["J"] * G.din
         return G.x[s["x_elem0"]:s["x_elem0"] + n].view(s["count"], s["J"], G.din)
 
+    def get_input_grads(self, L):
+        """d loss / d encoder inputs after backward(L, need_dx=True): one [count, J, in] view per stream, context
+        streams in their order, then the question, then the choices (the gradients the embedding front-end consumes)"""
+        def seg(cell, si):
+            G = L.groups[cell]
+            s = G.segs[si]
+            n = s["count"] * s["J"] * G.din
+            din = self.text_in if cell == "text" else self.img_in
+            return G.dx[s["x_elem0"]:s["x_elem0"] + n].view(s["count"], s["J"], G.din)[:, :, :din]
+        return [seg(cell, si) for cell, si, _ in L.ctx_slots] + [seg("text", 0), seg("text", 1)]
+
     @staticmethod
     def _lead(st):
         """leading (sequence) shape of a stream in either entry form: encoder inputs `x`, word ids, photo indices"""
