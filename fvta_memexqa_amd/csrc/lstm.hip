@@ -517,12 +517,19 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
     a.nt = nt & 1;
   }
   a.Wt[0] = a.Wt[1] = nullptr;
+  a.Wf[0] = a.Wf[1] = nullptr;
   if (bf) {  // refresh the bf16 weight shadows (the optimiser has just changed the fp32 masters)
     const int ndir = d->share_fw_bw ? 1 : 2;
     for (int i = 0; i < ndir; ++i)
       launch_cvt_weights_bf16(a.W[i], wv.wt[i], wv.wb[i], d->in, in_internal(d), d->d, stream);
     a.Wt[0] = wv.wt[0];
     a.Wt[1] = d->share_fw_bw ? wv.wt[0] : wv.wt[1];
+    if (wreg_nct(in_internal(d), d->d)) {
+      for (int i = 0; i < ndir; ++i)
+        launch_cvt_weights_frag(a.W[i], a.bias[i], wv.wf[i], d->in, in_internal(d), d->d, stream);
+      a.Wf[0] = wv.wf[0];
+      a.Wf[1] = d->share_fw_bw ? wv.wf[0] : wv.wf[1];
+    }
     launch_cvt_x_bf16(pv, x, sv.xs, d->B, d->J, d->in, in_internal(d), stream);
   }
   int launches = d->J;
@@ -531,9 +538,9 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   } else {
     for (int t = 0; t < d->J; ++t) {
       a.t = t;
-      if (bf)
-        launch_step_fwd_bf16(a, stream);
-      else
+      if (bf) {
+        if (!launch_step_fwd_wreg(a, stream)) launch_step_fwd_bf16(a, stream);
+      } else
         hipLaunchKernelGGL(lstm_step_fwd_f32, grid, dim3(256), sh, stream, a);
     }
   }

@@ -118,7 +118,9 @@ __global__ void cvt_x_kernel(PlanView pv, const float* __restrict__ x, bf16_t* _
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int k = c + e;
-      o[e] = k < in ? (short)f2bf(src[k]) : (k == in ? (short)0x3f80 : (short)0);  // ones column at `in`
+      // ones columns at `in` (its weight-gradient row is dbias) and `in + 1` (the second bias term of lstm_wreg.hip;
+      // in % 4 == 0, so in + 1 < in_i always)
+      o[e] = k < in ? (short)f2bf(src[k]) : ((k == in || k == in + 1) ? (short)0x3f80 : (short)0);
       ob[e] = (bw_delta && k < in) ? (short)f2bf(src[bw_delta + k]) : o[e];
     }
     *reinterpret_cast<bf16x4*>(dst_fw + c) = o;

@@ -93,6 +93,7 @@ struct WorkView {
   bf16_t* wt[2];   // [4d][in_i+d]  kernel^T in the internal row order, k contiguous (forward B operand)
   bf16_t* wb[2];   // [in_i+d][4d]  kernel in the internal row order (backward B operand)
   bf16_t* dzb;     // [2][J][B][d][4] gate pre-activation gradients, unit-major like gatesb (wb's k order matches)
+  bf16_t* wf[2];   // [4d * (in_i+d)] the kernel in MFMA-fragment order + split bias rows (lstm_wreg.hip)
   size_t bytes;
 };
 static inline WorkView work_view(const fvta_lstm_desc* d, void* p) {
@@ -104,12 +105,14 @@ static inline WorkView work_view(const fvta_lstm_desc* d, void* p) {
   w.slabs = c.take<float>((size_t)2 * dw_nsplit(d) * slab_rows * 4 * d->d);
   w.wt[0] = w.wt[1] = w.wb[0] = w.wb[1] = nullptr;
   w.dzb = nullptr;
+  w.wf[0] = w.wf[1] = nullptr;
   if (d->precision == FVTA_BF16) {
     for (int i = 0; i < 2; ++i) {
       w.wt[i] = c.take<bf16_t>((size_t)4 * d->d * kpad8(d));
       w.wb[i] = c.take<bf16_t>((size_t)kpad8(d) * 4 * d->d);
     }
     if (d->training) w.dzb = c.take<bf16_t>((size_t)2 * d->J * d->B * 4 * d->d);
+    for (int i = 0; i < 2; ++i) w.wf[i] = c.take<bf16_t>((size_t)4 * d->d * kpad8(d));
   }
   w.bytes = c.off;
   return w;
@@ -122,6 +125,7 @@ struct StepArgs {
   float* out;
   const float* W[2];
   const bf16_t* Wt[2];  // bf16 engine
+  const bf16_t* Wf[2];  // bf16 engine: fragment-order shadow for the weights-in-registers step kernel (null: shape not built)
   const bf16_t* xs;     // bf16 engine
   bf16_t* hs;           // bf16 engine
   const float* bias[2];
@@ -464,6 +468,10 @@ __device__ __forceinline__ void lstm_gate_epilogue_direct(const Mma& mma, const 
 void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int in, int in_i, int d, hipStream_t s);
 void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, int J, int in, int in_i, hipStream_t s);
 void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s);
+// weights-in-registers forward step (lstm_wreg.hip): false = shape not built, the tiled kernel runs instead
+int wreg_nct(int in_i, int d);
+void launch_cvt_weights_frag(const float* W, const float* bias, bf16_t* wf, int in, int in_i, int d, hipStream_t s);
+bool launch_step_fwd_wreg(const StepArgs& a, hipStream_t s);
 bool launch_seq_fwd_bf16(const StepArgs& a, hipStream_t s);  // all J steps in one launch; false: shape not covered / switched off
 void launch_step_bwd_bf16(const StepBwdArgs& a, hipStream_t s);
 struct FusedBwdArgs {

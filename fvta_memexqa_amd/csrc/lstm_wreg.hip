@@ -1,0 +1,504 @@
+// bi-LSTM forward step with the WEIGHTS STATIONARY IN REGISTERS (bf16 engine, BASELINE.json configs[2]).
+//
+// Replaces the recurrence of model_v2.py:652-661, 694-823 (BasicLSTMCell under bidirectional_dynamic_rnn) for the
+// shapes it is instantiated for; same arithmetic contract as lstm_step_fwd_bf16 (bf16 operands, fp32 accumulate,
+// fp32 gates / c / h).
+//
+// Why: the tiled step kernel brings BOTH operands of z = [x_t | h_{t-1}] * kernel into LDS for every 256 x 128 output
+// tile -- 1.2 GB of L2 -> LDS traffic per step at the metric shape, and a CU ingests ~65 GB/s.  Here a workgroup (one per
+// CU, four waves, one per SIMD, 512 registers each) owns 32 NCT hidden units x 4 gates of ONE direction and keeps that
+// slice of the kernel in its registers for the whole launch (K/2 registers per lane at NCT = 2: the B fragments of
+// v_mfma_f32_32x32x16_bf16 for every k-step); only the activations stream:
+//   * rows come in tiles of 32 sorted sequences, as 8 KB ring slots [32 rows][128 k] filled by LDS-DMA
+//     (buffer_load_dwordx4 ... lds, XOR-swizzled source addresses, counted vmcnt + one s_barrier per slot), eleven
+//     slots ahead of the MFMAs;
+//   * every wave multiplies the SAME A fragments (ds_read_b128) with ITS columns: no B traffic at all;
+//   * the tile's pre-activations go through a 33 KB LDS slab [32 rows][4 gates][units] and the gate math of tile i - 1
+//     runs inside the k-loop of tile i, in the matrix pipe's shadow, every global access 16 bytes of a row
+//     (4 rows x 256 B per wave-instruction);
+//   * the bias rides in the GEMM: the input shadow carries TWO ones columns (in, in + 1) and the fragment-order weight
+//     shadow holds bf16(bias) and bf16(bias - bf16(bias)) in those rows (relative error 2^-17): no bias registers.
+// Operand traffic per step: the activations x (column blocks per direction) + one pass over the weights = ~0.4 GB at
+// the metric shape, a third of the tiled kernel's.  Workgroups that share rows share an XCD (blockIdx & 7).
+#include "gemm_bf16.h"
+#include <type_traits>
+#include "lstm_common.h"
+
+namespace fvta {
+
+// two floats -> packed bf16 pair (round to nearest even, v_cvt_pk_bf16_f32): a in the low half
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+template <int NX16_, int ND16_, int NCT_>
+struct WregCfg {
+  static constexpr int NX16 = NX16_, ND16 = ND16_, NCT = NCT_;
+  static constexpr int NK16 = NX16 + ND16;            // k-steps of 16
+  static constexpr int NU = 8 * NCT, UB = 4 * NU;     // units per wave / per workgroup
+  static constexpr int D = 16 * ND16, IN_I = 16 * NX16;
+  static constexpr int CB = D / UB;                   // column blocks per direction
+  static constexpr int SX = (NX16 + 7) / 8, SH = ND16 / 8, S = SX + SH;  // ring slots per row tile (x part, h part)
+  static constexpr int XLAST = NX16 - 8 * (SX - 1);   // k-steps of the last x slot (1 .. 8)
+  // the ring holds RT whole tiles (so that a slot's LDS address is tile base + a compile-time offset); the DMA stream runs
+  // LOOK slots ahead of the hand-over
+  static constexpr int RT = S >= 12 ? 1 : 12 / S, RING = RT * S, LOOK = RING - 2;
+  static constexpr int SLOT_ELEMS = 32 * 128;         // bf16 per slot: 32 rows x 128 k
+  static constexpr int TILE_ELEMS = S * SLOT_ELEMS;
+  static constexpr int W_AGPR_FRAGS = (256 - 16 * NCT) / 4;  // weight fragments kept in AGPRs (beside the accumulators)
+  static constexpr int ZS = 4 * UB + 4;               // floats per row of the pre-activation slab
+  static constexpr int LDS_BYTES = RING * SLOT_ELEMS * 2 + 32 * ZS * 4;
+  static constexpr int LPR = UB / 4, RPP = 64 / LPR, PASSES = 8 / RPP;  // epilogue: lanes per row, rows per pass
+  // k-step q of a tile: its ring slot, its position in the slot, its fragment buffer (NK16 = 1 mod 3: the last k-step takes
+  // the fourth buffer, so that the next tile's first two k-steps find buffers 0 and 1 free)
+  static constexpr int slot_of(int q) { return q < NX16 ? q / 8 : SX + (q - NX16) / 8; }
+  static constexpr int ks_of(int q) { return q < NX16 ? q % 8 : (q - NX16) % 8; }
+  static constexpr int buf_of(int q) { return (NK16 % 3 == 1 && q == NK16 - 1) ? 3 : q % 3; }
+  // gate-math stages (see the kernel): per pass 1 read + 4 cells x CELL_STAGES + 1 store.  A k-step has NCT places for a
+  // stage (one behind each of its MFMAs); stage st runs at place HLO + st * HW / NSTAGES -- from the k-step after the
+  // hand-over of slot 1 (every wave's slab write lies before it); the second pass's first slab read must come before the
+  // hand-over of the next tile's slot 0 (k-step NK16 - 2, which precedes this tile's slab write)
+  static constexpr int CELL_STAGES = 7, PASS_STAGES = 2 + 4 * CELL_STAGES, NSTAGES = PASSES * PASS_STAGES;
+  static constexpr int QLO = SX > 1 ? 8 : NX16, HLO = NCT * QLO, HW = NCT * NK16 - HLO;
+  static constexpr int stage_begin(int h) { return h <= HLO ? 0 : (h >= NCT * NK16 ? NSTAGES : ((h - HLO) * NSTAGES + HW - 1) / HW); }
+  static constexpr int stage_place(int st) { return HLO + st * HW / NSTAGES; }
+  // (the last slab read is cell 3's, requested at stage k = 2 of cell 2 of the last pass; shapes with too few k-steps for
+  //  that put an extra barrier in front of the slab write instead)
+  static constexpr bool SLAB_SAFE = stage_place((PASSES - 1) * PASS_STAGES + 1 + 2 * CELL_STAGES + 2) / NCT <= NK16 - 3;
+  static_assert(ND16 % 8 == 0, "hidden size must be a multiple of 128");
+  static_assert(D % UB == 0, "column blocks");
+  static_assert(NK16 * NCT * 4 <= 400, "weight slice must fit the register file");
+  static_assert(NK16 % 3 != 2, "fragment rotation: NK16 = 0 or 1 (mod 3)");
+  static_assert(NX16 >= 2, "the first slot holds at least two k-steps");
+  static_assert(PASSES <= 2 && LOOK >= 2 && RING <= 12, "geometry");
+};
+
+// ---- fragment-order weight shadow ---------------------------------------------------------------
+// wf[cb][wave][ks][ct][lane][8]: the B fragment (32 columns x 16 k) of wave `wave` of column block `cb` for k-step ks,
+// column tile ct, as ONE contiguous 1 KiB piece.  Column idx = 32 ct + (lane & 31) of the wave is gate idx / NU of unit
+// cb UB + wave NU + idx % NU; k = 16 ks + 8 (lane >> 5) + e in the internal row order [x | 1 | 1 | 0.. | h]; rows `in`
+// and `in + 1` hold the bias split in two bf16 terms.  One thread per (cb, wave, ks, ct, lane).
+template <int NCT>
+__global__ void cvt_weights_frag_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                        bf16_t* __restrict__ wf, int in, int in_i, int d, int nk16) {
+  constexpr int NU = 8 * NCT, UB = 4 * NU;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int CB = d / UB;
+  const size_t total = (size_t)CB * 4 * nk16 * NCT * 64;
+  if (gid >= total) return;
+  const int lane = (int)(gid & 63);
+  size_t r = gid >> 6;
+  const int ct = (int)(r % NCT);
+  r /= NCT;
+  const int ks = (int)(r % nk16);
+  r /= nk16;
+  const int wave = (int)(r & 3), cb = (int)(r >> 2);
+  const int idx = ct * 32 + (lane & 31);
+  const int n = (idx / NU) * d + cb * UB + wave * NU + idx % NU;  // kernel column g d + u
+  const int N4 = 4 * d;
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 16 * ks + 8 * (lane >> 5) + e;
+    float v = 0.f;
+    if (k < in)
+      v = W[(size_t)k * N4 + n];
+    else if (k >= in_i)
+      v = W[(size_t)(in + k - in_i) * N4 + n];
+    else if (k == in)
+      v = bf2f(f2bf(bias[n]));
+    else if (k == in + 1)
+      v = bias[n] - bf2f(f2bf(bias[n]));
+    o[e] = (short)f2bf(v);
+  }
+  *reinterpret_cast<bf16x8*>(wf + gid * 8) = o;
+}
+
+// ---- the step kernel ------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+  float* zs = reinterpret_cast<float*>(smem + C::RING * C::SLOT_ELEMS);
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA destinations and row bases are wave-uniform
+  // workgroups are dealt round-robin over the 8 XCDs: the CB column blocks that stream the same rows share one
+  const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3;
+  const int pair = xcd + 8 * (wslot / C::CB), cb = wslot % C::CB;
+  const int dir = pair & 1, rg = pair >> 1;
+  const int t = a.t;
+#ifdef FVTA_DIAG
+  const int abl = a.dbg;  // FVTA_DEBUG_SKIP: 1 no gate stages, 2 no MFMAs, 4 no activation DMA, 8 no weight load, 16 no stores
+#else
+  constexpr int abl = 0;
+#endif
+  constexpr int d = C::D, IN_I = C::IN_I, NCT = C::NCT;
+  const int nact = a.plan.nactive[t];
+  const int ntiles = (nact + 31) >> 5;
+  if (rg >= ntiles) return;
+  const int nmine = (ntiles - rg + RG - 1) / RG;  // row tiles rg, rg + RG, ...
+  const size_t trow = ((size_t)dir * a.J + t) * a.B;
+
+  // ---- the weight slice: NK16 x NCT fragments, static indices only (registers)
+  bf16x8_t w[C::NK16][NCT];
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.Wf[dir]) + (size_t)(cb * 4 + wave) * C::NK16 * NCT * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < C::NK16; ++ks)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        Pack8 p;
+        p.f = (abl & 8) ? f32x4{0.f, 0.f, 0.f, 0.f} : src[(ks * NCT + ct) * 64];
+        w[ks][ct] = p.b;
+      }
+  }
+
+  // ---- activation stream: per-lane source offsets of this wave's two DMA pieces per slot (rows 8 wave .. + 7)
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xs + trow * IN_I, (unsigned)nact * IN_I * 2);
+  const __amdgpu_buffer_rsrc_t rh =
+      make_rsrc(t > 0 ? a.hs + (trow - a.B) * d : a.hs, t > 0 ? (unsigned)nact * d * 2 : 0u);  // h_{-1} = 0
+  unsigned voff_x[2], voff_h[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = 4 * (2 * wave + j) + (lane >> 4), c = (lane & 15) ^ (r & 15);
+    voff_x[j] = (unsigned)r * (IN_I * 2) + 16u * c;
+    voff_h[j] = (unsigned)r * (d * 2) + 16u * c;
+  }
+  // slot cs of the workgroup's tile number `ord` -> its place in the ring (tile ord % RT)
+  auto issue = [&](auto cs_c, int ord) {
+    constexpr int cs = decltype(cs_c)::value;
+    if (abl & 4) return;
+    // the row base goes into the VECTOR offset (scalar offset 0): rows past the active prefix, every tile past the
+    // workgroup's last, and -- through its zero-record descriptor -- step 0's h_{-1} then fall off the descriptor and read
+    // as zeros whichever way the range check treats a scalar offset
+    const unsigned m0c = 32u * (unsigned)(rg + RG * ord);
+    bf16_t* dst = smem + (ord % C::RT) * C::TILE_ELEMS + cs * C::SLOT_ELEMS + (2 * wave) * 512;
+    if constexpr (cs < C::SX) {
+      const unsigned rowb = m0c * (IN_I * 2) + cs * 256;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        unsigned v = voff_x[j] + rowb;
+        if constexpr (cs == C::SX - 1 && C::XLAST < 8) {  // the last x slot is narrower than 128 k: its tail chunks read zeros
+          const int r = 4 * (2 * wave + j) + (lane >> 4), c = (lane & 15) ^ (r & 15);
+          v = (c < 2 * C::XLAST) ? v : GLDS_OOB;
+        }
+        glds16(rx, dst + j * 512, v, 0);
+      }
+    } else {
+      const unsigned rowb = m0c * (d * 2) + (cs - C::SX) * 256;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) glds16(rh, dst + j * 512, voff_h[j] + rowb, 0);
+    }
+  };
+  static_for<0, C::LOOK>([&](auto g_c) {  // slots 0 .. LOOK-1 of the stream
+    constexpr int g = decltype(g_c)::value;
+    issue(std::integral_constant<int, g % C::S>{}, g / C::S);
+  });
+
+  // ---- gate math of a tile, cut into STAGES of a few vector instructions each.  The stages of tile i - 1 are dealt over
+  // the MFMAs of tile i (C::stage_begin), at most one behind each MFMA, so that they issue in its shadow (~24 free issue
+  // cycles): the hand-written MFMA statements fix the instruction order, and a whole pass in one place would leave the
+  // matrix pipe idle for its ~2,500 cycles.  lane = (row of the pass, four consecutive units).
+  //   per pass: stage 0 reads cell 0's pre-activations from the slab, stages 1 + 7 e + k do cell e's sigmoids / tanhs
+  //   (k = 0 .. 6; the next cell's pre-activations are requested at k = 2), the last stage stores c, h, the bf16 h shadow
+  //   and the packed gates: every global access 16 bytes of a row.
+  // What a tile's passes need from memory -- c_{t-1} and the output offsets of their rows -- is requested one whole tile
+  // ahead (own_rows at the tile's first k-step): vmcnt retires in order, so a wait for a YOUNG load would drain the DMA
+  // stream's look-ahead.
+  const int e_rsub = lane / C::LPR, e_q = lane % C::LPR;
+  const int u_lane = cb * C::UB + 4 * e_q;  // first of the lane's four units
+  const float* cprev_base = a.cs ? (t > 0 ? a.cs + (trow - a.B) * (size_t)d : nullptr) : a.cstate + (size_t)dir * a.B * d;
+  float* c_base = a.cs ? a.cs + trow * (size_t)d : a.cstate + (size_t)dir * a.B * d;
+  f32x4 cp_next[C::PASSES], cp_cur[C::PASSES];
+  int64_t oo_cur[C::PASSES];
+  auto prev_rows = [&](int m0p) {  // output offsets of the previous tile's rows: wave-uniform addresses, scalar cache
+#pragma unroll
+    for (int p = 0; p < C::PASSES; ++p) {
+      const int i0 = m0p + 8 * wave + C::RPP * p;
+      int64_t o = a.plan.oo[trow + min(i0, a.B - 1)];
+#pragma unroll
+      for (int j = 1; j < C::RPP; ++j) {
+        const int64_t oj = a.plan.oo[trow + min(i0 + j, a.B - 1)];
+        o = (e_rsub == j) ? oj : o;
+      }
+      oo_cur[p] = o;
+    }
+  };
+  auto own_rows = [&](int m0t) {
+#pragma unroll
+    for (int p = 0; p < C::PASSES; ++p) {
+      const int i = min(m0t + 8 * wave + C::RPP * p + e_rsub, nact - 1);  // clamped: always a valid row
+      if (t > 0)
+        cp_next[p] = *reinterpret_cast<const f32x4*>(cprev_base + (size_t)i * d + u_lane);
+      else
+        cp_next[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  f32x4 cv, hv;
+  unsigned gpk[8];
+  float zn[4], zjk, ti, tf, to, tj, ig, jg, fg, og, cc, te;  // zn: the pre-activations of the NEXT cell (read one cell ahead)
+  auto read_cell = [&](auto p_c, auto e_c) {
+    constexpr int p = decltype(p_c)::value, e = decltype(e_c)::value;
+    const float* zr = zs + (8 * wave + C::RPP * p + e_rsub) * C::ZS + 4 * e_q + e;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) zn[g] = zr[g * C::UB];
+  };
+  // (the empty asm statements pin a stage's results to its place in the MFMA stream: the compiler would otherwise sink the
+  //  whole computation down to the stores.  The sigmoid / tanh forms are fvta_sigmoid / fvta_tanh cut in two.)
+  auto run_stage = [&](auto s_c, int m0p) {
+    constexpr int st = decltype(s_c)::value, p = st / C::PASS_STAGES, r = st % C::PASS_STAGES;
+    if constexpr (r == 0) {
+      read_cell(std::integral_constant<int, p>{}, std::integral_constant<int, 0>{});
+    } else if constexpr (r == C::PASS_STAGES - 1) {
+      const int i = m0p + 8 * wave + C::RPP * p + e_rsub;
+      if (i < nact && !(abl & 16)) {
+        st16(c_base + (size_t)i * d + u_lane, cv, a.nt != 0);
+        const int64_t oo = oo_cur[p];
+        if (oo >= 0) {
+          float* o = a.out + oo + u_lane;
+          if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+            st16(o, hv, a.nt != 0);
+          } else {  // an output row that is not 16-byte aligned
+            o[0] = hv[0]; o[1] = hv[1]; o[2] = hv[2]; o[3] = hv[3];
+          }
+        }
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(a.hs + (trow + i) * (size_t)d + u_lane) = u32x2{pk_bf16(hv[0], hv[1]), pk_bf16(hv[2], hv[3])};
+        if (a.gatesb) {  // unit-major [u][i,j,f,o]
+          float* gp = reinterpret_cast<float*>(a.gatesb + (trow + i) * (size_t)(4 * d) + 4 * u_lane);
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          st16(gp, __builtin_bit_cast(f32x4, u32x4{gpk[0], gpk[1], gpk[2], gpk[3]}), a.nt != 0);
+          st16(gp + 4, __builtin_bit_cast(f32x4, u32x4{gpk[4], gpk[5], gpk[6], gpk[7]}), a.nt != 0);
+        }
+      }
+    } else {
+      constexpr int e = (r - 1) / C::CELL_STAGES, k = (r - 1) % C::CELL_STAGES;
+      if constexpr (k == 0) {
+        ti = __expf(-zn[0]);
+        tf = __expf(-(zn[2] + 1.0f));  // forget_bias
+        asm volatile("" : "+v"(ti), "+v"(tf));
+      } else if constexpr (k == 1) {
+        to = __expf(-zn[3]);
+        zjk = zn[1];
+        tj = __expf(-2.0f * fabsf(zjk));
+        asm volatile("" : "+v"(to), "+v"(tj), "+v"(zjk));
+      } else if constexpr (k == 2) {
+        if constexpr (e < 3) read_cell(std::integral_constant<int, p>{}, std::integral_constant<int, e + 1>{});
+        ig = __builtin_amdgcn_rcpf(1.0f + ti);
+        fg = __builtin_amdgcn_rcpf(1.0f + tf);
+        asm volatile("" : "+v"(ig), "+v"(fg));
+      } else if constexpr (k == 3) {
+        og = __builtin_amdgcn_rcpf(1.0f + to);
+        jg = copysignf((1.0f - tj) * __builtin_amdgcn_rcpf(1.0f + tj), zjk);
+        asm volatile("" : "+v"(og), "+v"(jg));
+      } else if constexpr (k == 4) {
+        cc = cp_cur[p][e] * fg + ig * jg;
+        te = __expf(-2.0f * fabsf(cc));
+        asm volatile("" : "+v"(cc), "+v"(te));
+        cv[e] = cc;
+      } else if constexpr (k == 5) {
+        float h = copysignf((1.0f - te) * __builtin_amdgcn_rcpf(1.0f + te), cc) * og;
+        asm volatile("" : "+v"(h));
+        hv[e] = h;
+      } else {
+        unsigned g0 = pk_bf16(ig, jg), g1 = pk_bf16(fg, og);
+        asm volatile("" : "+v"(g0), "+v"(g1));
+        gpk[2 * e] = g0;
+        gpk[2 * e + 1] = g1;
+      }
+    }
+  };
+
+  // ---- accumulators (AGPRs) and the MFMA, by hand: the weight fragments live partly in AGPRs, partly in VGPRs, and the
+  // matrix pipe reads either directly (the compiler's own allocation shuttles AGPR-resident operands through VGPRs, four
+  // v_accvgpr_read per MFMA).  The asm statements are opaque to the hazard recogniser: an s_nop run covers the XDL write ->
+  // VALU / LDS read distance before the accumulators are read.
+  f32x16 acc[NCT];
+  auto mfma = [&](auto q_c, auto ct_c, const bf16x8_t afr) {
+    constexpr int q = decltype(q_c)::value, ct = decltype(ct_c)::value;
+    constexpr bool in_agpr = (q * NCT + ct) < C::W_AGPR_FRAGS;
+    if (abl & 2) return;
+    if constexpr (q == 0) {
+      if constexpr (in_agpr)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[ct]) : "v"(afr), "a"(w[q][ct]));
+      else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[ct]) : "v"(afr), "v"(w[q][ct]));
+    } else {
+      if constexpr (in_agpr)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[ct]) : "v"(afr), "a"(w[q][ct]));
+      else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[ct]) : "v"(afr), "v"(w[q][ct]));
+    }
+  };
+
+  // ---- the k-step pipeline of a tile.  k-step q (of NK16) lies in ring slot slot_of(q); its A fragment is read TWO
+  // k-steps ahead of its MFMAs (four rotating fragment buffers), also across slot and tile boundaries: the hand-over of
+  // slot g -- wait for its DMA, barrier, refill of the slot consumed two slots ago -- is therefore done while the MFMAs of
+  // slot g - 1's last two k-steps are still to come, and the matrix pipe never waits for a fresh LDS read.
+  // ap[ks]: this lane's fragment address for position ks of a slot in the CURRENT tile's ring place (row l31, 16-byte
+  // chunk (2 ks + hf) ^ (l31 & 15)); the slot is a compile-time offset on top.
+  const bf16_t* ap[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) ap[ks] = smem + l31 * 128 + (((2 * ks + hf) ^ (l31 & 15)) << 3);
+  Pack8 fr[4];
+  auto handover = [&](auto s_c, int ord) {  // after it slot s_c of tile `ord` may be read
+    constexpr int s = decltype(s_c)::value;
+    wait_vmcnt<2 * (C::LOOK - 1)>();  // every younger DMA piece may still fly; everything older has landed
+    __builtin_amdgcn_s_barrier();     // visible to all waves; the slot consumed two slots ago is free
+    asm volatile("" ::: "memory");
+    issue(std::integral_constant<int, (s + C::LOOK) % C::S>{}, ord + (s + C::LOOK) / C::S);
+  };
+
+  handover(std::integral_constant<int, 0>{}, 0);
+  fr[C::buf_of(0)].f = *reinterpret_cast<const f32x4*>(ap[0]);
+  fr[C::buf_of(1)].f = *reinterpret_cast<const f32x4*>(ap[1]);
+  int prev_m0 = 1 << 30;  // no previous tile yet: the first tile's stages run on an undefined slab and store nothing
+#pragma unroll
+  for (int p = 0; p < C::PASSES; ++p) {
+    cp_cur[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    oo_cur[p] = -1;
+  }
+  for (int it = 0; it < nmine; ++it) {
+    const int m0 = 32 * (rg + RG * it);
+    // ring place of the next tile relative to this one (elements)
+    const int tb_delta = (((it + 1) % C::RT) - (it % C::RT)) * C::TILE_ELEMS;
+    auto kstep = [&](auto q_c) {
+      constexpr int q = decltype(q_c)::value;
+      constexpr int n = q + 2;
+      if constexpr (n < C::NK16) {
+        if constexpr (C::ks_of(n) == 0) handover(std::integral_constant<int, C::slot_of(n)>{}, it);
+        fr[C::buf_of(n)].f = *reinterpret_cast<const f32x4*>(ap[C::ks_of(n)] + C::slot_of(n) * C::SLOT_ELEMS);
+      } else {  // the next tile's first two k-steps (past the workgroup's last tile: zeros nobody uses)
+        if constexpr (n == C::NK16) handover(std::integral_constant<int, 0>{}, it + 1);
+        fr[C::buf_of(n - C::NK16)].f = *reinterpret_cast<const f32x4*>(ap[n - C::NK16] + tb_delta);
+      }
+      if constexpr (q == 0) {
+        own_rows(m0);
+        prev_rows(it > 0 ? prev_m0 : 0);
+      }
+      mfma(q_c, std::integral_constant<int, 0>{}, fr[C::buf_of(q)].b);  // (step 0: the h slots hold zeros)
+      if constexpr (C::stage_begin(NCT * q) < C::stage_begin(NCT * q + 1)) {
+        if (!(abl & 1)) static_for<C::stage_begin(NCT * q), C::stage_begin(NCT * q + 1)>([&](auto s_c) { run_stage(s_c, prev_m0); });
+      }
+      if constexpr (NCT > 1) {
+        mfma(q_c, std::integral_constant<int, 1>{}, fr[C::buf_of(q)].b);
+        if constexpr (C::stage_begin(NCT * q + 1) < C::stage_begin(NCT * q + 2)) {
+          if (!(abl & 1)) static_for<C::stage_begin(NCT * q + 1), C::stage_begin(NCT * q + 2)>([&](auto s_c) { run_stage(s_c, prev_m0); });
+        }
+      }
+    };
+    static_for<0, C::NK16>(kstep);
+    // the tile's pre-activations -> slab [row][gate][unit of the workgroup]
+    if constexpr (!C::SLAB_SAFE) {  // few k-steps: the previous tile's last slab reads may not lie before the last hand-over
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    if constexpr (NCT > 1)
+      asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[NCT - 1]));
+    else
+      asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]));
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int idx = ct * 32 + l31;
+      float* zc = zs + (idx / C::NU) * C::UB + wave * C::NU + idx % C::NU;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zc[((r & 3) + 8 * (r >> 2) + 4 * hf) * C::ZS] = acc[ct][r];
+    }
+    prev_m0 = m0;
+#pragma unroll
+    for (int p = 0; p < C::PASSES; ++p) {
+      cp_cur[p] = cp_next[p];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) ap[ks] += tb_delta;
+  }
+  // ---- the last tile's gate math
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  prev_rows(prev_m0);
+  static_for<0, C::NSTAGES>([&](auto s_c) { run_stage(s_c, prev_m0); });
+  wait_vmcnt<0>();  // the ring's trailing DMA pieces must not outlive the workgroup's LDS allocation
+}
+
+// ---- host side --------------------------------------------------------------------------------------
+template <class K>
+static void wreg_allow_lds(K kernel, int bytes) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+static int wreg_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  return cus;
+}
+
+// column tiles per wave for a shape, 0: not built
+int wreg_nct(int in_i, int d) {
+  static const bool on = [] {
+    const char* e = getenv("FVTA_LSTM_WREG");  // 0: the tiled step kernel for every shape (A/B measurements)
+    return !(e && e[0] == '0');
+  }();
+  if (!on) return 0;
+  const int nx = in_i / 16, nd = d / 16;
+  if (in_i % 16 || d % 128) return 0;
+  if (nd == 32 && (nx == 14 || nx == 8)) return 2;
+  if (nd == 64 && (nx == 14 || nx == 8)) return 1;
+  if (nd == 8 && (nx == 8 || nx == 2)) return 2;
+  return 0;
+}
+
+void launch_cvt_weights_frag(const float* W, const float* bias, bf16_t* wf, int in, int in_i, int d, hipStream_t s) {
+  const int nct = wreg_nct(in_i, d);
+  if (!nct) return;
+  const int nk16 = (in_i + d) / 16;
+  const size_t total = (size_t)(d / (32 * nct)) * 4 * nk16 * nct * 64;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (nct == 2)
+    hipLaunchKernelGGL(cvt_weights_frag_kernel<2>, dim3(grid), dim3(256), 0, s, W, bias, wf, in, in_i, d, nk16);
+  else
+    hipLaunchKernelGGL(cvt_weights_frag_kernel<1>, dim3(grid), dim3(256), 0, s, W, bias, wf, in, in_i, d, nk16);
+}
+
+template <class C>
+static void launch_wreg(const StepArgs& a, hipStream_t s) {
+  wreg_allow_lds(lstm_fwd_wreg_bf16<C>, C::LDS_BYTES);
+  // row groups: as many as fill the CUs, (2 directions x RG) a multiple of 8 (one (direction, row group) pair per XCD
+  // slot), and no more than there are row tiles
+  int rg = wreg_cus() / (2 * C::CB);
+  rg = rg / 4 * 4;
+  if (rg < 4) rg = 4;
+  const int tiles = (a.B + 31) / 32;
+  while (rg > 4 && rg - 4 >= tiles) rg -= 4;
+  hipLaunchKernelGGL(lstm_fwd_wreg_bf16<C>, dim3(2 * rg * C::CB), dim3(256), C::LDS_BYTES, s, a, rg);
+}
+
+bool launch_step_fwd_wreg(const StepArgs& a, hipStream_t s) {
+  const int in_i = a.Kp - a.d;
+  const int nct = wreg_nct(in_i, a.d);
+  if (!nct || !a.Wf[0] || !a.hs) return false;
+  const int nx = in_i / 16, nd = a.d / 16;
+  if (nd == 32 && nx == 14) launch_wreg<WregCfg<14, 32, 2>>(a, s);
+  else if (nd == 32 && nx == 8) launch_wreg<WregCfg<8, 32, 2>>(a, s);
+  else if (nd == 64 && nx == 14) launch_wreg<WregCfg<14, 64, 1>>(a, s);
+  else if (nd == 64 && nx == 8) launch_wreg<WregCfg<8, 64, 1>>(a, s);
+  else if (nd == 8 && nx == 8) launch_wreg<WregCfg<8, 8, 2>>(a, s);
+  else if (nd == 8 && nx == 2) launch_wreg<WregCfg<2, 8, 2>>(a, s);
+  else return false;
+  return true;
+}
+
+}  // namespace fvta
