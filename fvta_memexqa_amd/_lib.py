@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfvta_hip.so")
+# FVTA_LIB_PATH: a diagnostics build of the same library (tools/: stamped / ablated kernels), never a different backend
+LIB_PATH = os.environ.get("FVTA_LIB_PATH") or os.path.join(_HERE, "csrc", "libfvta_hip.so")
 
 F32, BF16 = 0, 1
 

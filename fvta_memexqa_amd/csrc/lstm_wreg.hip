@@ -124,6 +124,24 @@ __global__ void cvt_weights_frag_kernel(const float* __restrict__ W, const float
   *reinterpret_cast<bf16x8*>(wf + gid * 8) = o;
 }
 
+// Diagnostics (-DFVTA_WREG_STAMP builds only, tools/r03_wreg_stamps.py): shader-clock sums of one workgroup's wave 0 at
+// step t = 5: [0] kernel start, [1] after the weight load + first hand-over, [2] end, [3] tiles, [4] sum over hand-overs of
+// the vmcnt wait, [5] of the barrier wait, [6] sum over tiles of the slab write section, [7] hand-overs, [8] DMA issue,
+// [9] gate stages, [10] own_rows / prev_rows
+__device__ unsigned long long g_wreg_stamps[64];
+int wreg_read_stamp(int i, long long* v) {
+  if (i < 0 || i >= 64) return FVTA_ERR_INVALID_ARG;
+  unsigned long long x = 0;
+  if (hipMemcpyFromSymbol(&x, HIP_SYMBOL(g_wreg_stamps), 8, (size_t)i * 8, hipMemcpyDeviceToHost) != hipSuccess) return FVTA_ERR_INVALID_ARG;
+  *v = (long long)x;
+  return FVTA_OK;
+}
+#ifdef FVTA_WREG_STAMP
+#define WREG_CLOCK() __builtin_readcyclecounter()
+#else
+#define WREG_CLOCK() 0ull
+#endif
+
 // ---- the step kernel ------------------------------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG) {
@@ -136,8 +154,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
   const int pair = xcd + 8 * (wslot / C::CB), cb = wslot % C::CB;
   const int dir = pair & 1, rg = pair >> 1;
   const int t = a.t;
-#ifdef FVTA_DIAG
-  const int abl = a.dbg;  // FVTA_DEBUG_SKIP: 1 no gate stages, 2 no MFMAs, 4 no activation DMA, 8 no weight load, 16 no stores
+  // compile-time ablations (timing experiments, -DFVTA_WREG_ABL=bits; results are garbage): 1 no gate stages, 2 no MFMAs,
+  // 4 no activation DMA, 8 no weight load, 16 no stores, 32 no gate math (stores only), 64 no slab write
+#ifdef FVTA_WREG_ABL
+  constexpr int abl = FVTA_WREG_ABL;
 #else
   constexpr int abl = 0;
 #endif
@@ -147,6 +167,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
   if (rg >= ntiles) return;
   const int nmine = (ntiles - rg + RG - 1) / RG;  // row tiles rg, rg + RG, ...
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
+  unsigned long long st_wait = 0, st_bar = 0, st_slab = 0, st_n = 0, st_issue = 0, st_stage = 0, st_rows = 0;
+  const unsigned long long st_t0 = WREG_CLOCK();
 
   // ---- the weight slice: NK16 x NCT fragments, static indices only (registers)
   bf16x8_t w[C::NK16][NCT];
@@ -176,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
   // slot cs of the workgroup's tile number `ord` -> its place in the ring (tile ord % RT)
   auto issue = [&](auto cs_c, int ord) {
     constexpr int cs = decltype(cs_c)::value;
-    if (abl & 4) return;
+    if constexpr ((abl & 4) != 0) return;
     // the row base goes into the VECTOR offset (scalar offset 0): rows past the active prefix, every tile past the
     // workgroup's last, and -- through its zero-record descriptor -- step 0's h_{-1} then fall off the descriptor and read
     // as zeros whichever way the range check treats a scalar offset
@@ -261,9 +283,9 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
     } else if constexpr (r == C::PASS_STAGES - 1) {
       const int i = m0p + 8 * wave + C::RPP * p + e_rsub;
       if (i < nact && !(abl & 16)) {
-        st16(c_base + (size_t)i * d + u_lane, cv, a.nt != 0);
+        if constexpr (!(abl & 128)) st16(c_base + (size_t)i * d + u_lane, cv, a.nt != 0);
         const int64_t oo = oo_cur[p];
-        if (oo >= 0) {
+        if (oo >= 0 && !(abl & 256)) {
           float* o = a.out + oo + u_lane;
           if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
             st16(o, hv, a.nt != 0);
@@ -272,8 +294,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
           }
         }
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<u32x2*>(a.hs + (trow + i) * (size_t)d + u_lane) = u32x2{pk_bf16(hv[0], hv[1]), pk_bf16(hv[2], hv[3])};
-        if (a.gatesb) {  // unit-major [u][i,j,f,o]
+        if constexpr (!(abl & 512)) *reinterpret_cast<u32x2*>(a.hs + (trow + i) * (size_t)d + u_lane) = u32x2{pk_bf16(hv[0], hv[1]), pk_bf16(hv[2], hv[3])};
+        if (a.gatesb && !(abl & 1024)) {  // unit-major [u][i,j,f,o]
           float* gp = reinterpret_cast<float*>(a.gatesb + (trow + i) * (size_t)(4 * d) + 4 * u_lane);
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
           st16(gp, __builtin_bit_cast(f32x4, u32x4{gpk[0], gpk[1], gpk[2], gpk[3]}), a.nt != 0);
@@ -282,6 +304,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
       }
     } else {
       constexpr int e = (r - 1) / C::CELL_STAGES, k = (r - 1) % C::CELL_STAGES;
+      if constexpr ((abl & 32) != 0) {
+        if constexpr (k == 0) { cv[e] = zn[0]; hv[e] = zn[1]; gpk[2 * e] = __float_as_uint(zn[2]); gpk[2 * e + 1] = __float_as_uint(zn[3]); }
+        if constexpr (k == 2 && e < 3) read_cell(std::integral_constant<int, p>{}, std::integral_constant<int, e + 1>{});
+      } else
       if constexpr (k == 0) {
         ti = __expf(-zn[0]);
         tf = __expf(-(zn[2] + 1.0f));  // forget_bias
@@ -326,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
   auto mfma = [&](auto q_c, auto ct_c, const bf16x8_t afr) {
     constexpr int q = decltype(q_c)::value, ct = decltype(ct_c)::value;
     constexpr bool in_agpr = (q * NCT + ct) < C::W_AGPR_FRAGS;
-    if (abl & 2) return;
+    if constexpr ((abl & 2) != 0) return;
     if constexpr (q == 0) {
       if constexpr (in_agpr)
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[ct]) : "v"(afr), "a"(w[q][ct]));
@@ -352,13 +378,21 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
   Pack8 fr[4];
   auto handover = [&](auto s_c, int ord) {  // after it slot s_c of tile `ord` may be read
     constexpr int s = decltype(s_c)::value;
+    const unsigned long long c0 = WREG_CLOCK();
     wait_vmcnt<2 * (C::LOOK - 1)>();  // every younger DMA piece may still fly; everything older has landed
+    const unsigned long long c1 = WREG_CLOCK();
     __builtin_amdgcn_s_barrier();     // visible to all waves; the slot consumed two slots ago is free
     asm volatile("" ::: "memory");
+    const unsigned long long c2 = WREG_CLOCK();
     issue(std::integral_constant<int, (s + C::LOOK) % C::S>{}, ord + (s + C::LOOK) / C::S);
+    st_wait += c1 - c0;
+    st_bar += c2 - c1;
+    st_issue += WREG_CLOCK() - c2;
+    st_n += 1;
   };
 
   handover(std::integral_constant<int, 0>{}, 0);
+  const unsigned long long st_t1 = WREG_CLOCK();
   fr[C::buf_of(0)].f = *reinterpret_cast<const f32x4*>(ap[0]);
   fr[C::buf_of(1)].f = *reinterpret_cast<const f32x4*>(ap[1]);
   int prev_m0 = 1 << 30;  // no previous tile yet: the first tile's stages run on an undefined slab and store nothing
@@ -382,22 +416,29 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
         fr[C::buf_of(n - C::NK16)].f = *reinterpret_cast<const f32x4*>(ap[n - C::NK16] + tb_delta);
       }
       if constexpr (q == 0) {
+        const unsigned long long r0 = WREG_CLOCK();
         own_rows(m0);
         prev_rows(it > 0 ? prev_m0 : 0);
+        st_rows += WREG_CLOCK() - r0;
       }
       mfma(q_c, std::integral_constant<int, 0>{}, fr[C::buf_of(q)].b);  // (step 0: the h slots hold zeros)
       if constexpr (C::stage_begin(NCT * q) < C::stage_begin(NCT * q + 1)) {
-        if (!(abl & 1)) static_for<C::stage_begin(NCT * q), C::stage_begin(NCT * q + 1)>([&](auto s_c) { run_stage(s_c, prev_m0); });
+        const unsigned long long g0 = WREG_CLOCK();
+        if constexpr (!(abl & 1)) static_for<C::stage_begin(NCT * q), C::stage_begin(NCT * q + 1)>([&](auto s_c) { run_stage(s_c, prev_m0); });
+        st_stage += WREG_CLOCK() - g0;
       }
       if constexpr (NCT > 1) {
         mfma(q_c, std::integral_constant<int, 1>{}, fr[C::buf_of(q)].b);
         if constexpr (C::stage_begin(NCT * q + 1) < C::stage_begin(NCT * q + 2)) {
-          if (!(abl & 1)) static_for<C::stage_begin(NCT * q + 1), C::stage_begin(NCT * q + 2)>([&](auto s_c) { run_stage(s_c, prev_m0); });
+          const unsigned long long g0 = WREG_CLOCK();
+          if constexpr (!(abl & 1)) static_for<C::stage_begin(NCT * q + 1), C::stage_begin(NCT * q + 2)>([&](auto s_c) { run_stage(s_c, prev_m0); });
+          st_stage += WREG_CLOCK() - g0;
         }
       }
     };
     static_for<0, C::NK16>(kstep);
     // the tile's pre-activations -> slab [row][gate][unit of the workgroup]
+    const unsigned long long sl0 = WREG_CLOCK();
     if constexpr (!C::SLAB_SAFE) {  // few k-steps: the previous tile's last slab reads may not lie before the last hand-over
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -407,6 +448,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
       asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[NCT - 1]));
     else
       asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]));
+    if constexpr (!(abl & 64)) {
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       const int idx = ct * 32 + l31;
@@ -414,6 +456,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
 #pragma unroll
       for (int r = 0; r < 16; ++r) zc[((r & 3) + 8 * (r >> 2) + 4 * hf) * C::ZS] = acc[ct][r];
     }
+    }
+    st_slab += WREG_CLOCK() - sl0;
     prev_m0 = m0;
 #pragma unroll
     for (int p = 0; p < C::PASSES; ++p) {
@@ -429,6 +473,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
   prev_rows(prev_m0);
   static_for<0, C::NSTAGES>([&](auto s_c) { run_stage(s_c, prev_m0); });
   wait_vmcnt<0>();  // the ring's trailing DMA pieces must not outlive the workgroup's LDS allocation
+#ifdef FVTA_WREG_STAMP
+  if (t == 5 && (int)blockIdx.x == a.dbg && tid == 0) {
+    g_wreg_stamps[0] = st_t0; g_wreg_stamps[1] = st_t1; g_wreg_stamps[2] = WREG_CLOCK(); g_wreg_stamps[3] = nmine;
+    g_wreg_stamps[4] = st_wait; g_wreg_stamps[5] = st_bar; g_wreg_stamps[6] = st_slab; g_wreg_stamps[7] = st_n;
+    g_wreg_stamps[8] = st_issue; g_wreg_stamps[9] = st_stage; g_wreg_stamps[10] = st_rows;
+  }
+#endif
 }
 
 // ---- host side --------------------------------------------------------------------------------------
