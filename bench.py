@@ -66,8 +66,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--side-priority", type=int, default=None,
                     help="priority of the photo cell's side stream (default: the highest the device offers; 0 = normal)")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="serial LSTM backward: dx and the weight gradient after the recurrence instead of beside it on a side stream")
     ap.add_argument("--cpu-sample", type=int, default=4, help="QA pairs in the CPU-baseline sample (4: ~10-15 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch-CPU threads of the baseline; 16 is the fastest setting measured on the 2x EPYC 9575F host "
@@ -139,20 +137,20 @@ def cpu_baseline(spec_kw, sample_n, forward_only, threads, literal_n=1):
                           note="oracle/fvta_fused.py, torch-CPU fp32, %d threads, median (1 warm-up)" % torch.get_num_threads()))
     if t_fb is not None:
         out["fused"]["fwd_bwd"] = round(sample_n / t_fb, 3)
-    # the literal mirror: one pass per timing (a pass is ~10 s per QA pair at the metric shape)
+    # the literal mirror: 1 warm-up + 3 timed passes, median (a pass is ~1.6 s per QA pair at the metric shape)
     lspec = SynthSpec(**dict(spec_kw, N=literal_n))
     lp = to_numpy(make_params(lspec), np.float32)
     li = to_numpy(make_inputs(lspec), np.float32)
-    t_l = _median_time(lambda: Lit.fvta_forward(lp, li, lspec.cfg()), 1)
+    t_l = _median_time(lambda: Lit.fvta_forward(lp, li, lspec.cfg()), 3)
     out["literal"] = dict(fwd_only=round(literal_n / t_l, 3), sample_qa_pairs=literal_n,
-                          note="oracle/fvta_literal.py, NumPy fp32 op-for-op mirror, forward only (no autograd), 1 warm-up + 1 timed pass")
+                          note="oracle/fvta_literal.py, NumPy fp32 op-for-op mirror, forward only (no autograd), 1 warm-up + 3 timed passes, median")
     out["faster_forward"] = "fused" if out["fused"]["fwd_only"] >= out["literal"]["fwd_only"] else "literal"
     if forward_only:
         out["value"] = max(out["fused"]["fwd_only"], out["literal"]["fwd_only"])
     else:
         out["value"] = out["fused"]["fwd_bwd"]
     out["sample"] = ("%d QA pairs of the same shape through the fused torch-CPU oracle (%s, median of 3, %.2f s each); "
-                     "%d QA pair through the NumPy literal mirror (forward only, %.1f s)"
+                     "%d QA pair through the NumPy literal mirror (forward only, median of 3, %.1f s each)"
                      % (sample_n, "forward only" if forward_only else "forward+backward", t_f if forward_only else t_fb,
                         literal_n, t_l))
     try:
@@ -186,7 +184,7 @@ def main():
         kw["N"] = hi - lo
     spec = SynthSpec(**kw)
     cfg = dict(spec.cfg(), batch_size=spec.N, precision=args.precision, optimizer=args.optimizer,
-               init_lr=0.001 if args.optimizer == "adam" else 0.5, overlap_bwd_tails=not args.no_overlap)
+               init_lr=0.001 if args.optimizer == "adam" else 0.5)
     if args.side_priority is not None:
         cfg["side_stream_priority"] = args.side_priority
     if args.front_end:   # README.MD:144-147 sizes: 100-d GloVe + 100-d char-CNN, 2537-d photo features -> 100
@@ -238,7 +236,9 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
+    rank_elapsed = dist.gather_over_ranks(elapsed, dev)      # every rank's own wall clock over the timed region
     elapsed = dist.max_over_ranks(elapsed, dev)
+    pg = dist.describe()
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     log('timed region done: %.3f s for %d steps (per-step HIP events: median %.3f ms)'
         % (elapsed, args.steps, statistics.median(step_ms)))
@@ -303,7 +303,8 @@ def main():
     if n_f:
         tf = fl_text * calls / (ms_f * 1e-3) / 1e12
         gbs = by_text * calls / (ms_f * 1e-3) / 1e9
-        roof = dict(kernel="lstm_step_fwd_%s" % args.precision, bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS,
+        wreg = args.precision == "bf16" and dp % 128 == 0 and (dp, in_i) in ((512, 224), (512, 128), (1024, 224), (1024, 128), (128, 128), (128, 32))
+        roof = dict(kernel=("lstm_fwd_wreg_bf16 (forward step, weights in registers)" if wreg else "lstm_step_fwd_%s" % args.precision), bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS,
                     unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, algorithmic_bytes_per_call=by_text,
                     mfma_tflops=round(tf, 1), mfma_frac=round(tf / peak_tf, 4), launches=n_f,
                     avg_launch_ms=round(ms_f / n_f, 4))
@@ -349,8 +350,19 @@ def main():
             r_["frac_of_achievable"] = round(r_["achieved"] / probe_gbs, 4)
     dense_metric = args.config == "metric" and args.variant == "dense" and not args.batch and args.graph == "fvta"
     if roof is not None and dense_metric and args.precision == "bf16":
-        roof["traffic"] = pmc_traffic("r02_lstm_pmc.json", "lstm_step_fwd_bf16")
-        roof["traffic_note"] = "bytes per launch, profiles/r02_lstm_pmc.json; algorithmic per launch = algorithmic_bytes_per_call / 30"
+        roof["traffic"] = pmc_traffic("r03_lstm_pmc.json", "lstm_fwd_wreg_bf16")
+        roof["traffic_note"] = "bytes per launch, profiles/r03_lstm_pmc.json; algorithmic per launch = algorithmic_bytes_per_call / 30"
+    # the fused backward step (now the longest kernel family of the step): per active (row, unit) it reads the saved bf16
+    # gates (8 B), c_{t-1} (4), d_out (4) and the running dc (4) and writes dz (8) and dc (4): 32 B -- DESIGN.md 4.3
+    roof_bwd = None
+    ms_b, n_b = prof["lstm_step_bwd"]
+    if n_b and args.precision == "bf16" and not args.forward_only:
+        by_bwd = float((2 * lens * dp * 32).sum().item())
+        gbs_b = by_bwd * calls / (ms_b * 1e-3) / 1e9
+        roof_bwd = dict(kernel="lstm_bwd_fused_bf16 + lstm_dx_bf16 (bracket: the recurrence's launches and the dx pass)", bound="hbm",
+                        achieved=round(gbs_b, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs_b / PEAK_HBM_GBS, 4), traffic=None,
+                        algorithmic_bytes_per_call=by_bwd, ms_per_step=round(ms_b / args.steps, 4),
+                        note="algorithmic bytes: the gate-gradient epilogue only (32 B per row and unit); the dx pass re-reads dz")
     if roof_att is not None and dense_metric:
         roof_att["traffic"] = pmc_traffic("r02c_attention_pmc.json", "attn_fwd_pair16")
         roof_att["traffic_note"] = "bytes per launch, profiles/r02c_attention_pmc.json"
@@ -371,7 +383,8 @@ def main():
                     qa_pairs_per_gpu=spec.N, albums=spec.A, photos=spec.P, text_streams=spec.S, tokens=spec.L, hidden=spec.d,
                     global_batch=spec.N * ws, K=L.K, T=L.T, JQ=L.JQ,
                     parallelism="dp%d (QA pairs sharded, flat-gradient all-reduce)" % ws),
-        roofline=roof, roofline_attention=roof_att,
+        roofline=roof, roofline_attention=roof_att, roofline_lstm_bwd=roof_bwd,
+        process_group=pg, rank_seconds=[round(v, 4) for v in rank_elapsed],
         kernel_ms_per_step={k: round(v[0] / args.steps, 4) for k, v in prof.items()},
         kernel_ms_note="HIP-event brackets on the launch streams, over a second pass of the same %d steps right after the "
                        "timed region (the timed region itself carries no brackets)" % args.steps,

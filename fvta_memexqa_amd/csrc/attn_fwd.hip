@@ -1404,12 +1404,25 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
   typedef __attribute__((address_space(3))) int lds_int;
   auto wait_flag = [&](int* flag, int want) {  // bounded poll of an LDS word
     volatile lds_int* f = (volatile lds_int*)flag;
+    bool arrived = false;
     for (int spin = 0; spin < (1 << 22); ++spin) {
-      if (*f >= want) break;
+      if (*f >= want) {
+        arrived = true;
+        break;
+      }
       __builtin_amdgcn_s_sleep(2);
     }
+    // a partner that never arrives is a bug (or a wedged wave): fail the launch -- the host sees a launch error at its
+    // next call -- rather than fall through and fold stale partials into amax / jmax / h_a
+    if (!arrived) __builtin_trap();
+    // acquire: the partner's published area (plain LDS loads below) is read only after the poll has matched; workgroup
+    // scope lowers to s_waitcnt lgkmcnt(0) and, unlike an empty asm, is a compiler fence for __shared__ accesses too
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   };
-  auto post_flag = [&](int* flag, int v) { *(volatile lds_int*)flag = v; };
+  auto post_flag = [&](int* flag, int v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // my partials are written before the flag says so
+    *(volatile lds_int*)flag = v;
+  };
 
   // ---- the pair's tile stream: the CURRENT tile is in h[], the NEXT tile's identity and row numbers are known one
   // round ahead (its rows replace the current tile's registers during the weighted sum, also across a stream boundary)

@@ -70,14 +70,13 @@ extern "C" int fvta_profile_enable(int32_t on) {
 }
 
 // Sum of elapsed ms and launch count of every closed bracket of `id`; consumes them.
-namespace fvta { int lstm_read_stamp(int i, long long* v); }  // lstm_bf16.hip (diagnostics)
 namespace fvta { int wreg_read_stamp(int i, long long* v); }  // lstm_wreg.hip (diagnostics, -DFVTA_WREG_STAMP builds)
 
 extern "C" int fvta_profile_collect(int32_t id, double* total_ms, int64_t* launches) {
   FVTA_CHECK_ARG(total_ms && launches, "profile_collect: null pointer");
-  if (id >= 100000) {  // diagnostics: shader-clock stamp id - 100000 of the LSTM step kernel (tools/lstm_phases.py)
+  if (id >= 200000) {  // diagnostics: shader-clock stamp id - 200000 of lstm_fwd_wreg_bf16 (tools/r03_wreg_stamps.py)
     long long v = 0;
-    const int e = id >= 200000 ? fvta::wreg_read_stamp(id - 200000, &v) : fvta::lstm_read_stamp(id - 100000, &v);
+    const int e = fvta::wreg_read_stamp(id - 200000, &v);
     *total_ms = 0;
     *launches = v;
     return e;

@@ -49,16 +49,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // WN = wave columns: 1 -> 256 x 128 block tile, 4 waves, 72 KiB (two workgroups per CU);
 //                    2 -> 256 x 256 block tile, 8 waves (4 x 2), 96 KiB (one workgroup per CU).  The wave tile is
-// 64 x 128 either way; the wider block tile re-reads the A operand half as often (the operand DMA runs at the CU's
-// address-unit rate, ~24 B/clk, which a 256 x 128 tile saturates before the matrix pipe).
-// TM = MFMA row tiles per wave: 2 -> four wave rows of 64 (the wave tile is 64 x 128, 6 LDS fragments per 8 MFMAs);
-//                             4 -> two wave rows of 128 (wave tile 128 x 128, 8 fragments per 16 MFMAs: a third less
-// LDS read traffic per flop; 256 accumulator registers, so one wave per SIMD with the accumulators in AGPRs).  With
-// WN = 2, TM = 4 the 256 x 256 block tile runs on FOUR waves.
-//  TM = 1 with WM = 4 wave rows: a 128 x 128 block tile (wave tile 32 x 128), the half-size unit the forward step uses for
-//  the rows that do not fill a whole round of 256-row tiles (launch_step_fwd_bf16).
+// 64 x 128 either way (TM = 2 MFMA row tiles: 6 LDS fragments per 8 MFMAs); the wider block tile re-reads the A operand
+// half as often.  WM < 4 wave rows: block tiles of 64 / 128 rows for calls with few sequences (the photo cell's backward
+// step: a step is then a chain of K/32 k-tiles whose length is the DMA wave-instructions per k-tile).
 template <int WN, int TM_ = 2, int WM_ = 8 / TM_>
 struct TileCfgT {
+  static_assert(TM_ == 2, "wave tile: two MFMA row tiles");
   static constexpr int TM = TM_, WAVES_M = WM_, NWAVES = WAVES_M * WN;
   static constexpr int BM = 32 * TM_ * WM_, BN = 128 * WN, BK = 32, STAGES = 3, NT = 64 * NWAVES;
   static constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;  // per stage
@@ -70,39 +66,16 @@ struct TileCfgT {
 typedef TileCfgT<1> TileCfg;
 
 // ---- accumulators + fragment reads -------------------------------------------------------------
-// SWAP: the two fragment operands trade places in the MFMA (the row-image fragments of A and B have the same lane layout:
-// row l & 31, k-octet l >> 5), so the accumulators hold the TRANSPOSED tile: register r of lane l is B-row (column of the
-// product) (r & 3) + 8 (r >> 2) + 4 (l >> 5) and A-row l & 31 -- four CONSECUTIVE columns of ONE row per register quad, i.e.
-// 16 contiguous bytes of a row-major fp32 output per lane without a trip through LDS (lstm_gate_epilogue_direct).
-template <int WN, int TM_ = 2, int WM_ = 8 / TM_, bool SWAP_ = false>
+template <int WN, int TM_ = 2, int WM_ = 8 / TM_>
 struct MmaBT {
   typedef TileCfgT<WN, TM_, WM_> Cfg;
-  static constexpr bool SWAP = SWAP_;
   static constexpr int TM = TM_, TN = 4, WAVES_M = Cfg::WAVES_M, WAVES_N = 1, BM = Cfg::BM, BN = Cfg::BN;  // WAVES_N: per wave column
   static constexpr int WROWS = 32 * TM;  // rows of a wave tile
   f32x16 acc[TM][TN];
   int wave_all, wave, wn, lane, l31, hf;  // wave = row of the WAVES_M x WN wave grid (the M position), wn = its column
 
-  // TM = 4: 256 accumulator registers.  Left to itself the compiler keeps them in VGPRs across the loop and shuttles
-  // them through AGPRs around every MFMA (~440 v_accvgpr moves per k-tile); the asm form pins the accumulators to
-  // AGPRs ("+a"), where the matrix pipe reads and writes them directly.  A/B fragments stay compiler-scheduled VGPRs.
   static __device__ __forceinline__ void mfma(f32x16& c, bf16x8_t a, bf16x8_t b) {
-#ifdef FVTA_MFMA_ASM
-    if constexpr (TM == 4)
-      asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    else
-#endif
-    if constexpr (SWAP)
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0);
-    else
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-  // the asm MFMAs are opaque to the hazard recogniser: before the accumulators are read by VALU code the last
-  // MFMA's passes must have retired (XDL write -> VALU read, up to 18 wait states for a 16-pass MFMA)
-  static __device__ __forceinline__ void drain() {
-#ifdef FVTA_MFMA_ASM
-    if constexpr (TM == 4) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#endif
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
 
   __device__ __forceinline__ void init(int tid) {
@@ -112,11 +85,6 @@ struct MmaBT {
     lane = tid & 63;
     l31 = lane & 31;
     hf = lane >> 5;
-#ifndef FVTA_MFMA_ASM
-    // an explicit AGPR operand keeps the compiler from marking the kernel "amdgpu-no-agpr", under which it selects
-    // the VGPR-destination MFMA forms and uses the AGPRs as spill space only
-    if constexpr (TM == 4) asm volatile("; accumulators live in AGPRs %0" ::"a"(0));
-#endif
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -169,12 +137,6 @@ struct MmaBT {
       p.f = *reinterpret_cast<const f32x4*>(Bs + r * 32 + ((c ^ ((r >> 2) & 3)) << 3));
       f.b[j] = p.b;
     }
-  }
-  __device__ __forceinline__ void load_kmajor(const bf16_t* __restrict__ As, const bf16_t* __restrict__ Bs, int ks, Frags& f) const {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) f.a[i] = tr_frag<BM>(As, ks * 16, wave * WROWS + i * 32);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) f.b[j] = tr_frag<BN>(Bs, ks * 16, wn * 128 + j * 32);
   }
   __device__ __forceinline__ void mma_frags(const Frags& f) {
 #pragma unroll
@@ -273,25 +235,22 @@ struct KMajorSrc {
 // Every wave issues exactly A_GLDS + B_GLDS = 6 wave-instructions per tile, so "all but the newest
 // tile have landed" is s_waitcnt vmcnt(6).  The barrier after the wait both publishes tile t to all
 // waves and retires every wave's reads of stage (t-1)%3, which the next issue overwrites.
-// `stamps` (diagnostics, normally null): shader-clock stamps per k-tile: [4t] before the wait, [4t+1] after it,
-// [4t+2] after the barrier + next issue, [4t+3] after the MFMAs were issued.
-// Software-pipelined variant (FVTA_GLDS_SP, TM <= 2).  A k-tile is two k-steps of fragments; the loop keeps ONE k-step of
-// fragments in flight at all times, across the barrier:
+//
+// Software-pipelined variant (row images only; the forward step's loop).  A k-tile is two k-steps of fragments; the loop
+// keeps ONE k-step of fragments in flight at all times, across the barrier:
 //     read F1 <- (tile t, step 1) | MFMA F0 | wait tile t+1, barrier | DMA tile t+3 -> stage t | read F0 <- (t+1, step 0) | MFMA F1
 // so (a) the LDS latency of a k-step's fragment reads hides behind the other k-step's eight MFMAs also at the tile
 // boundary, where the plain loop stalls on freshly issued reads after every barrier, and (b) a stage is released in the
 // MIDDLE of its tile (both k-steps are in registers by then), which puts THREE tiles in flight on the same three stages.
-template <bool KMAJOR, class Mma, class Issue>
+// (Measured: forward -2.7 %; the backward / dx loops no faster, the k-major loop spills with it.)
+template <class Mma, class Issue>
 __device__ __forceinline__ void glds_mainloop_sp(Mma& mma, Issue&& issue, int ntiles, bf16_t* smem) {
   typedef typename Mma::Cfg TileCfg;
   constexpr int G = TileCfg::A_GLDS + TileCfg::B_GLDS;  // DMA wave-instructions per wave and tile
   auto a_stage = [&](int t) { return smem + (t % TileCfg::STAGES) * TileCfg::STAGE_ELEMS; };
   auto load = [&](int t, int ks, typename Mma::Frags& f) {
     const bf16_t* As = a_stage(t);
-    if (KMAJOR)
-      mma.load_kmajor(As, As + TileCfg::A_ELEMS, ks, f);
-    else
-      mma.load_rows(As, As + TileCfg::A_ELEMS, ks, f);
+    mma.load_rows(As, As + TileCfg::A_ELEMS, ks, f);
   };
   if (ntiles <= 0) return;
   issue(0, a_stage(0), a_stage(0) + TileCfg::A_ELEMS);
@@ -328,77 +287,29 @@ __device__ __forceinline__ void glds_mainloop_sp(Mma& mma, Issue&& issue, int nt
     mma.mma_frags(f1);
     __builtin_amdgcn_sched_barrier(0);
   }
-  Mma::drain();
 }
 
 template <bool KMAJOR, class Mma, class Issue>
-__device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntiles, bf16_t* smem,
-                                              unsigned long long* stamps = nullptr, int xdbg = 0) {
+__device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntiles, bf16_t* smem) {
   typedef typename Mma::Cfg TileCfg;
   auto a_stage = [&](int t) { return smem + (t % TileCfg::STAGES) * TileCfg::STAGE_ELEMS; };
   if (ntiles <= 0) return;
-  if constexpr (Mma::TM <= 2 && !KMAJOR) {  // (the k-major loop, two transposing reads per fragment, spills with it)
-    if (xdbg & 4) {  // bit 2 of xdbg: the software-pipelined loop (runtime switch while both are measured)
-      glds_mainloop_sp<KMAJOR>(mma, issue, ntiles, smem);
-      return;
-    }
-  }
-  if constexpr (Mma::TM == 4) {
-    // the same pipeline with a single-block steady-state loop and the last two tiles peeled: with 256 accumulator
-    // registers the loop-carried values must stay in AGPRs, which the compiler manages only for a plain loop body
-    auto compute = [&](int t) {
-      const bf16_t* As = a_stage(t);
-      if (KMAJOR)
-        mma.compute_kmajor(As, As + TileCfg::A_ELEMS);
-      else
-        mma.compute_rows(As, As + TileCfg::A_ELEMS);
-    };
-    issue(0, a_stage(0), a_stage(0) + TileCfg::A_ELEMS);
-    if (ntiles > 1) issue(1, a_stage(1), a_stage(1) + TileCfg::A_ELEMS);
-    int t = 0;
-    for (; t + 2 < ntiles; ++t) {
-      wait_vmcnt<TileCfg::A_GLDS + TileCfg::B_GLDS>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      issue(t + 2, a_stage(t + 2), a_stage(t + 2) + TileCfg::A_ELEMS);
-      compute(t);
-    }
-    if (t + 1 < ntiles) {
-      wait_vmcnt<TileCfg::A_GLDS + TileCfg::B_GLDS>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      compute(t);
-      ++t;
-    }
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    compute(t);
-    Mma::drain();
-    return;
-  }
   issue(0, a_stage(0), a_stage(0) + TileCfg::A_ELEMS);
   if (ntiles > 1) issue(1, a_stage(1), a_stage(1) + TileCfg::A_ELEMS);
   for (int t = 0; t < ntiles; ++t) {
-    if (stamps) stamps[4 * t] = __builtin_readcyclecounter();
     if (t + 1 < ntiles)
       wait_vmcnt<TileCfg::A_GLDS + TileCfg::B_GLDS>();
     else
       wait_vmcnt<0>();
-    if (stamps) stamps[4 * t + 1] = __builtin_readcyclecounter();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + 2 < ntiles && !(xdbg & 1)) issue(t + 2, a_stage(t + 2), a_stage(t + 2) + TileCfg::A_ELEMS);  // xdbg: experiments
-    if (stamps) stamps[4 * t + 2] = __builtin_readcyclecounter();
+    if (t + 2 < ntiles) issue(t + 2, a_stage(t + 2), a_stage(t + 2) + TileCfg::A_ELEMS);
     const bf16_t* As = a_stage(t);
-    if (xdbg & 2) continue;
     if (KMAJOR)
       mma.compute_kmajor(As, As + TileCfg::A_ELEMS);
     else
       mma.compute_rows(As, As + TileCfg::A_ELEMS);
-    if (stamps) stamps[4 * t + 3] = __builtin_readcyclecounter();
   }
-  Mma::drain();
 }
 
 }  // namespace fvta

@@ -16,16 +16,6 @@
 #include "fvta_prof.h"
 #include <vector>
 
-#ifndef FVTA_LSTM_BWD_RC_DEFAULT
-#define FVTA_LSTM_BWD_RC_DEFAULT 1
-#endif
-#ifndef FVTA_LSTM_NT_DEFAULT
-#define FVTA_LSTM_NT_DEFAULT 2
-#endif
-#ifndef FVTA_LSTM_OVERLAP_DEFAULT
-#define FVTA_LSTM_OVERLAP_DEFAULT 0
-#endif
-
 #include "lstm_common.h"
 
 namespace fvta {
@@ -509,13 +499,7 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   const bool bf = d->precision == FVTA_BF16;
   a.Kp = kpad8(d);
   a.dbg = fvta_diag_env("FVTA_DEBUG_SKIP", 0);  // -DFVTA_DIAG builds only
-  {
-    static const int nt = [] {
-      const char* e = getenv("FVTA_LSTM_NT");
-      return e ? atoi(e) : FVTA_LSTM_NT_DEFAULT;
-    }();
-    a.nt = nt & 1;
-  }
+  a.nt = 0;
   a.Wt[0] = a.Wt[1] = nullptr;
   a.Wf[0] = a.Wf[1] = nullptr;
   if (bf) {  // refresh the bf16 weight shadows (the optimiser has just changed the fp32 masters)
@@ -532,17 +516,13 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
     }
     launch_cvt_x_bf16(pv, x, sv.xs, d->B, d->J, d->in, in_internal(d), stream);
   }
-  int launches = d->J;
-  if (bf && launch_seq_fwd_bf16(a, stream)) {
-    launches = 1;  // the sequence-stationary kernel: all J steps in one launch
-  } else {
-    for (int t = 0; t < d->J; ++t) {
-      a.t = t;
-      if (bf) {
-        if (!launch_step_fwd_wreg(a, stream)) launch_step_fwd_bf16(a, stream);
-      } else
-        hipLaunchKernelGGL(lstm_step_fwd_f32, grid, dim3(256), sh, stream, a);
-    }
+  const int launches = d->J;
+  for (int t = 0; t < d->J; ++t) {
+    a.t = t;
+    if (bf) {  // weights-in-registers kernel where it is built for the shape, the tiled one otherwise
+      if (!launch_step_fwd_wreg(a, stream)) launch_step_fwd_bf16(a, stream);
+    } else
+      hipLaunchKernelGGL(lstm_step_fwd_f32, grid, dim3(256), sh, stream, a);
   }
   fvta_prof_end(FVTA_PROF_LSTM_STEP_FWD + 16 * d->reserved, launches, stream);
   FVTA_CHECK_LAUNCH("lstm_step_fwd");
@@ -632,37 +612,14 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
   w.in_i = in_internal(d);
   w.xs = sv.xs;
   w.hs = sv.hs;
-  w.split0 = 0;
-  w.nsl = w.nsplit;
-  w.xcd_aware = 1;
-  // Overlap mode (bf16 engine, side stream given): dx and the weight gradient of a step group do not depend on the
-  // rest of the recurrence -- they are launched on `side` as soon as the group's dz is final and run on the CUs the
-  // single-round step kernel leaves idle (one 8-wave workgroup per CU on 204 of 256 CUs at the metric shape), reading
-  // dz while it is still in the memory-side cache, instead of as a serial tail after step 0.
-  hipStream_t side = (hipStream_t)side_stream_;
-  // what goes to the side stream: bit 0 dx, bit 1 the weight gradient (FVTA_LSTM_OVERLAP overrides: measurement switch)
-  static const int ov_mask = [] {
-    const char* e = getenv("FVTA_LSTM_OVERLAP");
-    return e ? atoi(e) : FVTA_LSTM_OVERLAP_DEFAULT;
-  }();
-  const bool overlap = bf && !(dbg & 2048) && side != nullptr && side != stream && (ov_mask & 3);
-  const bool ov_dx = overlap && (ov_mask & 1), ov_dw = overlap && (ov_mask & 2);
-  // bit 2: the two directions' recurrences on two streams (main: forward direction, side: backward direction), the
-  // side one started half a step late -- the directions are independent chains, and apart in phase one direction's
-  // HBM-bound epilogue runs beside the other's k-loop instead of the whole chip alternating between the two
-  const bool split_dirs = bf && !(dbg & 2048) && side != nullptr && side != stream && (ov_mask & 4) && !overlap;
-  std::vector<hipEvent_t> events;
-  auto new_event = [&]() -> hipEvent_t {
-    hipEvent_t e = nullptr;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    events.push_back(e);
-    return e;
-  };
-  bool ev_ok = true, join_side = false;
+  // (side_stream_ / nactive_host: accepted for ABI stability, unused -- running dx / the weight gradient beside the
+  //  recurrence and choosing the step's tile from the host's lengths were both measured slower)
+  (void)side_stream_;
+  (void)nactive_host;
   fvta_prof_begin(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, stream);
-  if (bf && !(dbg & 2048)) {
+  if (bf) {
     // bf16 engine: ONE launch per step -- dh_{t} = dz_{t+1} * wb_h^T in the k-loop, the gate gradient
-    // (dz_t, dc) as its epilogue -- and dx = dz * wb_x^T batched over steps
+    // (dz_t, dc) as its epilogue -- and dx = dz * wb_x^T batched over all steps
     FusedBwdArgs f;
     f.plan = pv;
     f.Wb[0] = wv.wb[0];
@@ -678,123 +635,24 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
     f.in = in;
     f.d = dd;
     f.in_i = in_internal(d);
-    f.t0 = 0;
-    f.nt = J;
-    f.dh_tiles = 0;
-    f.dir0 = 0;
-    f.ndir = 2;
-    f.dxmode = 0;
-    f.nact_hint = -1;
-    // dx rides on the step launches (dx_{t+1} next to dh_t: same A operand) unless it goes to the side stream / is off
-    f.dx_tiles = (dx && !ov_dx) ? bwd_fused_dx_tiles(in, dd) : 0;
-    f.stamp_wg = fvta_diag_env("FVTA_LSTM_STAMP_BWD", -1);  // -DFVTA_DIAG builds only
-    {
-      static const int nt = [] {
-        const char* e = getenv("FVTA_LSTM_NT");
-        return e ? atoi(e) : FVTA_LSTM_NT_DEFAULT;
-      }();
-      f.ntl = (nt & 2) != 0;
-      // FVTA_LSTM_BWD_RC: rebuild c_t from the saved gates instead of reading it back (see FusedBwdArgs.rc)
-      static const int rc = [] {
-        const char* e = getenv("FVTA_LSTM_BWD_RC");
-        return e ? atoi(e) : FVTA_LSTM_BWD_RC_DEFAULT;
-      }();
-      f.rc = rc;
-    }
-    // FVTA_LSTM_BWD_HINT=1: act on the host's lengths hint.  OFF by default: on the ragged variant it shortens the text
-    // cell's backward launches (4.02 -> 3.86 ms) but the STEP gets longer (8.28 -> 8.47 ms) -- what ends that step is the
-    // photo cell's chain of 40 small launches on the side stream, and the many small workgroups crowd it (tools/r02_af.sh)
-    const char* hint_env = getenv("FVTA_LSTM_BWD_HINT");  // (read per call: the tests flip it)
-    const bool use_hint = hint_env && hint_env[0] == '1';
-    if (split_dirs) {
-      hipEvent_t e = new_event();
-      ev_ok = e && hipEventRecord(e, stream) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess;
-      const int delay_us = (ov_mask >> 8) & 0xFFF;  // bits 8..19: head start of the main stream's direction, in us
-      if (ev_ok && delay_us > 0) (void)fvta_probe_spin(delay_us, side);
-      FusedBwdArgs f0 = f, f1 = f;
-      f0.ndir = f1.ndir = 1;
-      f1.dir0 = 1;
-      f0.dx_tiles = f1.dx_tiles = 0;
-      for (int t = J - 1; t >= 0 && ev_ok; --t) {
-        f0.t = f1.t = t;
-        launch_bwd_fused_bf16(f0, stream);
-        launch_bwd_fused_bf16(f1, side);
-      }
-      f.dx_tiles = 0;
-      if (ev_ok) {
-        hipEvent_t e2 = new_event();
-        ev_ok = e2 && hipEventRecord(e2, side) == hipSuccess && hipStreamWaitEvent(stream, e2, 0) == hipSuccess;
-      }
-    } else
     for (int t = J - 1; t >= 0; --t) {
       f.t = t;
-      f.nact_hint = (nactive_host && use_hint) ? nactive_host[t] : -1;
       launch_bwd_fused_bf16(f, stream);
-      if (overlap && t % w.tgroup == 0) {  // every dz of step group t / tgroup is final once this launch is done
-        hipEvent_t e = new_event();
-        if (!e || hipEventRecord(e, stream) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) {
-          ev_ok = false;
-          break;
-        }
-        FusedBwdArgs fx = f;
-        fx.t0 = t;
-        fx.nt = (t + w.tgroup <= J ? w.tgroup : J - t);
-        if (dx && ov_dx) launch_dx_bf16(fx, side);
-        if (!(dbg & 1024) && ov_dw) {
-          DwArgs wg = w;
-          wg.split0 = t / w.tgroup;
-          wg.nsl = 1;
-          wg.xcd_aware = 0;
-          fvta_prof_begin(FVTA_PROF_LSTM_DW + 16 * d->reserved, side);
-          launch_dw_bf16(wg, side);
-          fvta_prof_end(FVTA_PROF_LSTM_DW + 16 * d->reserved, 1, side);
-        }
-      }
     }
-    // bit 3 of the overlap mask: after the recurrence, dx (HBM bound on re-reading dz) runs on the side stream BESIDE
-    // the weight gradient (matrix-pipe / LDS bound) instead of before it -- two kernels with different bottlenecks
-    const bool dx_beside_dw = dx && !ov_dx && side != nullptr && side != stream && (ov_mask & 8) && f.dx_tiles == 0;
-    if (dx_beside_dw) {
-      hipEvent_t e = new_event();
-      ev_ok = ev_ok && e && hipEventRecord(e, stream) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess;
-      if (ev_ok) launch_dx_bf16(f, side);
-      join_side = true;
-    } else if (dx && !ov_dx) {
-      if (f.dx_tiles > 0) {
-        f.t = -1;  // dx_0: the dx tiles of one more launch
-        launch_bwd_fused_bf16(f, stream);
-      } else {
-        launch_dx_bf16(f, stream);
-      }
-    }
+    if (dx) launch_dx_bf16(f, stream);
   } else
   for (int t = J - 1; t >= 0; --t) {
     g.t = t;
     s.t = t;
     if (!(dbg & 512)) hipLaunchKernelGGL(lstm_gate_bwd, ggrid, dim3(256), 0, stream, g);
-    if (t > 0 || dx) {
-      if (bf)
-        launch_step_bwd_bf16(s, stream);
-      else
-        hipLaunchKernelGGL(lstm_step_bwd_f32, sgrid, dim3(256), sh, stream, s);
-    }
+    if (t > 0 || dx) hipLaunchKernelGGL(lstm_step_bwd_f32, sgrid, dim3(256), sh, stream, s);
   }
   fvta_prof_end(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, 2 * J, stream);
-  if (overlap && ev_ok) {  // the main stream takes the side stream's work back before the slab reduce
-    hipEvent_t e = new_event();
-    ev_ok = e && hipEventRecord(e, side) == hipSuccess && hipStreamWaitEvent(stream, e, 0) == hipSuccess;
-  }
-  if (!ev_ok) {
-    for (hipEvent_t e : events) (void)hipEventDestroy(e);
-    fvta_set_error("bilstm_bwd: event plumbing between the main and the side stream failed: %s",
-                   hipGetErrorString(hipGetLastError()));
-    return FVTA_ERR_LAUNCH;
-  }
   FVTA_CHECK_LAUNCH("lstm_step_bwd");
   const int MM = in + dd + 1, N4 = 4 * dd;
   const dim3 wgrid((MM + MmaSq::BM - 1) / MmaSq::BM, N4 / MmaSq::BN, 2 * w.nsplit);
-  if (!ov_dw) fvta_prof_begin(FVTA_PROF_LSTM_DW + 16 * d->reserved, stream);
-  if ((dbg & 1024) || ov_dw) {
+  fvta_prof_begin(FVTA_PROF_LSTM_DW + 16 * d->reserved, stream);
+  if (dbg & 1024) {
   } else if (bf)
     launch_dw_bf16(w, stream);
   else
@@ -817,16 +675,7 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
     hipLaunchKernelGGL(lstm_dw_reduce, dim3(rgrid), dim3(256), 0, stream, wv.slabs + (size_t)w.nsplit * slab_elems,
                        w.nsplit, slab_elems, in + dd, N4, dkernel_bw, dbias_bw);
   }
-  if (!ov_dw) fvta_prof_end(FVTA_PROF_LSTM_DW + 16 * d->reserved, 1, stream);
-  if (join_side) {  // dx ran beside the weight gradient: the call's stream takes it back
-    hipEvent_t e = new_event();
-    ev_ok = e && hipEventRecord(e, side) == hipSuccess && hipStreamWaitEvent(stream, e, 0) == hipSuccess;
-  }
-  for (hipEvent_t e : events) (void)hipEventDestroy(e);  // released by the runtime once the recorded work completes
-  if (!ev_ok) {
-    fvta_set_error("bilstm_bwd: joining the side stream failed: %s", hipGetErrorString(hipGetLastError()));
-    return FVTA_ERR_LAUNCH;
-  }
+  fvta_prof_end(FVTA_PROF_LSTM_DW + 16 * d->reserved, 1, stream);
   FVTA_CHECK_LAUNCH("lstm_dw_reduce");
   return FVTA_OK;
 }

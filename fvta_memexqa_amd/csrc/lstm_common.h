@@ -134,10 +134,9 @@ struct StepArgs {
   float* cs;      // may be null
   float* cstate;  // used when cs is null
   int t, B, J, in, d, Kp;
-  int dbg;  // diagnostics only (FVTA_DEBUG_SKIP): 1 = skip the k-loop, 2 = skip the epilogue
-  int sp;   // bf16 engine: software-pipelined main loop (gemm_bf16.h glds_mainloop_sp)
-  int nt;   // bf16 engine: stream-once data (saved gates, cell states, fp32 h rows) with non-temporal stores / loads,
-            // so that what the NEXT step re-reads through L2 -- the h shadow and the weights -- is not evicted by it
+  int dbg;  // diagnostics only (-DFVTA_DIAG builds, FVTA_DEBUG_SKIP): fp32 engine ablations
+  int nt;   // bf16 engine: stream-once data (saved gates, cell states, fp32 h rows) with non-temporal stores (measured: no
+            // effect on the forward step; 0)
 };
 
 struct GateBwdArgs {
@@ -174,11 +173,6 @@ struct DwArgs {
   const bf16_t* hs;
   float* slabs;
   int B, J, in, d, tgroup, nsplit, in_i;
-  // the launch covers step groups [split0, split0 + nsl) of both directions (whole call: 0, nsplit)
-  int sp;  // software-pipelined main loop
-  int split0, nsl;
-  int xcd_aware;  // 1: a (direction, group) slice's tiles share one XCD (whole-call launch); 0: tiles dealt round-robin
-                  // over the XCDs (per-group launches that fill the CUs the recurrence leaves idle on EVERY XCD)
 };
 
 #ifdef __HIPCC__
@@ -376,92 +370,6 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
   }
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// The gate math on a TRANSPOSED accumulator tile (MmaBT<..., SWAP = true>): lane l holds sequence (A row) l & 31 of each
-// 32-row slice and, per register quad q, the four consecutive units u0 + 8 q + 4 (l >> 5) .. + 3 of every gate.  Every
-// global access is then 16 bytes of one row straight from / into registers -- c_{t-1} in (4 per slice), c_t and h_t out
-// as fp32 quads, the bf16 shadow as 8 bytes, the unit-major gate record [u][i,j,f,o] as 32 contiguous bytes -- 48 VMEM
-// instructions per wave and tile against the staged version's 44, and NO LDS traffic, no lgkmcnt waits: the k-loop of
-// the co-resident workgroup keeps the LDS port to itself.  The biases (and the forget bias) are the accumulators'
-// initial values (lstm_direct_bias_init), so the epilogue adds nothing.
-//   cprev[ti][q]: c_{t-1} of row ti*32 + (lane & 31), units 8 q + 4 (lane >> 5) .. + 3.
-template <class Mma>
-__device__ __forceinline__ void lstm_direct_bias_init(Mma& mma, const float* __restrict__ bias, int d, int u0) {
-  static_assert(Mma::SWAP && Mma::TN == 4, "transposed accumulators, four gate strips");
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 b = *reinterpret_cast<const f32x4*>(bias + g * d + u0 + 8 * q + 4 * mma.hf);
-      if (g == 2) b += 1.0f;  // forget_bias
-#pragma unroll
-      for (int ti = 0; ti < Mma::TM; ++ti)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mma.acc[ti][g][4 * q + e] = b[e];
-    }
-}
-
-template <class Mma>
-__device__ __forceinline__ void lstm_gate_epilogue_direct(const Mma& mma, const StepArgs& a, int dir, int m0, int u0, int nact,
-                                                          size_t trow, const int64_t* s_oo,
-                                                          const f32x4 (&cprev)[Mma::TM][4], int t) {
-  static_assert(Mma::SWAP && Mma::TN == 4 && Mma::WAVES_N == 1, "transposed wave tile: 32 TM rows x the four gate strips");
-  const int d = a.d;
-  float* cdst = a.cs ? a.cs + trow * d : a.cstate + (size_t)dir * a.B * d;
-#pragma unroll
-  for (int ti = 0; ti < Mma::TM; ++ti) {
-    const int lrow = mma.wave * Mma::WROWS + ti * 32 + mma.l31, i = m0 + lrow;
-    const bool live = i < nact;
-    const int64_t oo = s_oo[lrow];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int uq = u0 + 8 * q + 4 * mma.hf;
-      f32x4 cv, hv, g01, g23;
-      bf16x4 hb;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * q + e;
-        const float ig = fvta_sigmoid(mma.acc[ti][0][r]);
-        const float jg = fvta_tanh(mma.acc[ti][1][r]);
-        const float fg = fvta_sigmoid(mma.acc[ti][2][r]);
-        const float og = fvta_sigmoid(mma.acc[ti][3][r]);
-        const float c = (t > 0 ? cprev[ti][q][e] * fg : 0.f) + ig * jg;
-        const float h = fvta_tanh(c) * og;
-        cv[e] = c;
-        hv[e] = h;
-        hb[e] = (short)f2bf(h);
-        bf16x4 g4;
-        g4[0] = (short)f2bf(ig);
-        g4[1] = (short)f2bf(jg);
-        g4[2] = (short)f2bf(fg);
-        g4[3] = (short)f2bf(og);
-        const f32x2 gw = __builtin_bit_cast(f32x2, g4);
-        if (e < 2) {
-          g01[2 * e] = gw[0];
-          g01[2 * e + 1] = gw[1];
-        } else {
-          g23[2 * (e - 2)] = gw[0];
-          g23[2 * (e - 2) + 1] = gw[1];
-        }
-      }
-      if (live) st16(cdst + (size_t)i * d + uq, cv, a.nt != 0);
-      if (oo >= 0) {
-        float* o = a.out + oo + uq;
-        if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
-          st16(o, hv, a.nt != 0);
-        } else {  // an output row that is not 16-byte aligned
-          o[0] = hv[0]; o[1] = hv[1]; o[2] = hv[2]; o[3] = hv[3];
-        }
-      }
-      if (live && a.hs) *reinterpret_cast<bf16x4*>(a.hs + (trow + i) * d + uq) = hb;
-      if (live && a.gatesb) {
-        float* gp = reinterpret_cast<float*>(a.gatesb + (trow + i) * (size_t)(4 * d) + 4 * uq);
-        st16(gp, g01, a.nt != 0);
-        st16(gp + 4, g23, a.nt != 0);
-      }
-    }
-  }
-}
 #endif
 
 // bf16 engine launchers (lstm_bf16.hip)
@@ -472,8 +380,6 @@ void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s);
 int wreg_nct(int in_i, int d);
 void launch_cvt_weights_frag(const float* W, const float* bias, bf16_t* wf, int in, int in_i, int d, hipStream_t s);
 bool launch_step_fwd_wreg(const StepArgs& a, hipStream_t s);
-bool launch_seq_fwd_bf16(const StepArgs& a, hipStream_t s);  // all J steps in one launch; false: shape not covered / switched off
-void launch_step_bwd_bf16(const StepBwdArgs& a, hipStream_t s);
 struct FusedBwdArgs {
   PlanView plan;
   const bf16_t* Wb[2];
@@ -483,20 +389,10 @@ struct FusedBwdArgs {
   bf16_t* dzb;
   float* dc;  // [2][B][d]
   float* dx;  // lstm_dx only
-  int t0, nt; // lstm_dx only: the launch covers steps [t0, t0 + nt) of both directions
   int t, B, J, in, d, in_i;
-  int stamp_wg;  // diagnostics: workgroup that stamps the shader clock (-1: none)
-  int sp;        // software-pipelined main loop
-  int dir0, ndir;          // directions this launch covers: [dir0, dir0 + ndir) (2 streams: one direction each)
-  int dh_tiles, dx_tiles;  // column tiles of the fused step launch: dh_t tiles, then dx_{t+1} tiles (0: separate dx pass)
-  int ntl;       // read-once operands of the gate gradient (saved gates, cell states, d_out) through non-temporal loads
-  int dxmode;    // lstm_dx: 0 atomicAdd (both directions in one launch); 1 plain store (first direction); 2 load-add-store (second)
-  int nact_hint; // active sequences of step t as the HOST knows them (fvta_bilstm_bwd_hint), -1: unknown -- picks the step's tile
-  int rc;        // c_t is not read back but rebuilt from the saved (bf16) gates and c_{t-1}: 4 of the epilogue's 36 B per (row, unit)
 };
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s);
 void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s);
-int bwd_fused_dx_tiles(int in, int d);
 void launch_dw_bf16(const DwArgs& a, hipStream_t s);
 void launch_dw_reduce_bf16(const float* slabs, int nslab, int in, int in_i, int d, float* dW, float* dbias, hipStream_t s);
 int test_gemm_bf16(int layout, int M, int N, int K, const float* A, const float* B, float* C, hipStream_t s);

@@ -41,11 +41,15 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// (An EIGHT-wave form of this kernel -- two waves per SIMD of 256 registers, 32 columns each, nine weight fragments per
+//  wave in LDS, ring of six slots -- was built and measured: 4.10 ms against 3.75 ms per text-cell forward; what it gains in
+//  issue slots it loses to the shallow ring and the 8-wave barriers.  DESIGN.md appendix.)
 template <int NX16_, int ND16_, int NCT_>
 struct WregCfg {
-  static constexpr int NX16 = NX16_, ND16 = ND16_, NCT = NCT_;
+  static constexpr int NX16 = NX16_, ND16 = ND16_, NCT = NCT_, NW = 4;
   static constexpr int NK16 = NX16 + ND16;            // k-steps of 16
-  static constexpr int NU = 8 * NCT, UB = 4 * NU;     // units per wave / per workgroup
+  static constexpr int NU = 8 * NCT, UB = NW * NU;    // units per wave / per workgroup
+  static constexpr int RW = 32 / NW, DP = 8 / NW;     // rows of a tile whose gate math a wave does / DMA pieces per wave and slot
   static constexpr int D = 16 * ND16, IN_I = 16 * NX16;
   static constexpr int CB = D / UB;                   // column blocks per direction
   static constexpr int SX = (NX16 + 7) / 8, SH = ND16 / 8, S = SX + SH;  // ring slots per row tile (x part, h part)
@@ -57,8 +61,14 @@ struct WregCfg {
   static constexpr int TILE_ELEMS = S * SLOT_ELEMS;
   static constexpr int W_AGPR_FRAGS = (256 - 16 * NCT) / 4;  // weight fragments kept in AGPRs (beside the accumulators)
   static constexpr int ZS = 4 * UB + 4;               // floats per row of the pre-activation slab
-  static constexpr int LDS_BYTES = RING * SLOT_ELEMS * 2 + 32 * ZS * 4;
-  static constexpr int LPR = UB / 4, RPP = 64 / LPR, PASSES = 8 / RPP;  // epilogue: lanes per row, rows per pass
+  // the LAST W_LDS_FRAGS weight fragments of a wave live in LDS (the space the ring and the slab leave), read one k-step
+  // ahead of their MFMAs: 28 registers per lane that the gate stages need at the widest shape
+  static constexpr int W_FRAGS = NK16 * NCT;
+  static constexpr int W_LDS_FRAGS = W_FRAGS > 84 ? 7 : 0, W_REG_FRAGS = W_FRAGS - W_LDS_FRAGS;
+  static constexpr int Z_OFF = RING * SLOT_ELEMS * 2, WL_OFF = Z_OFF + 32 * ZS * 4;  // byte offsets of the slab / the weight tail
+  static constexpr int LDS_BYTES = WL_OFF + NW * W_LDS_FRAGS * 1024;
+  static_assert(LDS_BYTES <= 163840, "LDS");
+  static constexpr int LPR = UB / 4, RPP = 64 / LPR, PASSES = RW / RPP;  // epilogue: lanes per row, rows per pass
   // k-step q of a tile: its ring slot, its position in the slot, its fragment buffer (NK16 = 1 mod 3: the last k-step takes
   // the fourth buffer, so that the next tile's first two k-steps find buffers 0 and 1 free)
   static constexpr int slot_of(int q) { return q < NX16 ? q / 8 : SX + (q - NX16) / 8; }
@@ -77,24 +87,24 @@ struct WregCfg {
   static constexpr bool SLAB_SAFE = stage_place((PASSES - 1) * PASS_STAGES + 1 + 2 * CELL_STAGES + 2) / NCT <= NK16 - 3;
   static_assert(ND16 % 8 == 0, "hidden size must be a multiple of 128");
   static_assert(D % UB == 0, "column blocks");
-  static_assert(NK16 * NCT * 4 <= 400, "weight slice must fit the register file");
+  static_assert(W_REG_FRAGS * 4 <= 400, "weight slice must fit the register file");
   static_assert(NK16 % 3 != 2, "fragment rotation: NK16 = 0 or 1 (mod 3)");
   static_assert(NX16 >= 2, "the first slot holds at least two k-steps");
-  static_assert(PASSES <= 2 && LOOK >= 2 && RING <= 12, "geometry");
+  static_assert(PASSES >= 1 && PASSES <= 2 && LOOK >= 2 && RING <= 12, "geometry");
 };
 
 // ---- fragment-order weight shadow ---------------------------------------------------------------
-// wf[cb][wave][ks][ct][lane][8]: the B fragment (32 columns x 16 k) of wave `wave` of column block `cb` for k-step ks,
+// wf[cb][wave (NW)][ks][ct][lane][8]: the B fragment (32 columns x 16 k) of wave `wave` of column block `cb` for k-step ks,
 // column tile ct, as ONE contiguous 1 KiB piece.  Column idx = 32 ct + (lane & 31) of the wave is gate idx / NU of unit
 // cb UB + wave NU + idx % NU; k = 16 ks + 8 (lane >> 5) + e in the internal row order [x | 1 | 1 | 0.. | h]; rows `in`
 // and `in + 1` hold the bias split in two bf16 terms.  One thread per (cb, wave, ks, ct, lane).
 template <int NCT>
 __global__ void cvt_weights_frag_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                         bf16_t* __restrict__ wf, int in, int in_i, int d, int nk16) {
-  constexpr int NU = 8 * NCT, UB = 4 * NU;
+  constexpr int NW = 4, NU = 8 * NCT, UB = NW * NU;
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int CB = d / UB;
-  const size_t total = (size_t)CB * 4 * nk16 * NCT * 64;
+  const size_t total = (size_t)CB * NW * nk16 * NCT * 64;
   if (gid >= total) return;
   const int lane = (int)(gid & 63);
   size_t r = gid >> 6;
@@ -102,7 +112,7 @@ __global__ void cvt_weights_frag_kernel(const float* __restrict__ W, const float
   r /= NCT;
   const int ks = (int)(r % nk16);
   r /= nk16;
-  const int wave = (int)(r & 3), cb = (int)(r >> 2);
+  const int wave = (int)(r % NW), cb = (int)(r / NW);
   const int idx = ct * 32 + (lane & 31);
   const int n = (idx / NU) * d + cb * UB + wave * NU + idx % NU;  // kernel column g d + u
   const int N4 = 4 * d;
@@ -144,9 +154,9 @@ int wreg_read_stamp(int i, long long* v) {
 
 // ---- the step kernel ------------------------------------------------------------------------------
 template <class C>
-__global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG) {
+__global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(StepArgs a, int RG) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-  float* zs = reinterpret_cast<float*>(smem + C::RING * C::SLOT_ELEMS);
+  float* zs = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + C::Z_OFF);
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA destinations and row bases are wave-uniform
   // workgroups are dealt round-robin over the 8 XCDs: the CB column blocks that stream the same rows share one
@@ -172,26 +182,30 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
 
   // ---- the weight slice: NK16 x NCT fragments, static indices only (registers)
   bf16x8_t w[C::NK16][NCT];
+  f32x4* wlds = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + C::WL_OFF) + wave * C::W_LDS_FRAGS * 64 + lane;
   {
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.Wf[dir]) + (size_t)(cb * 4 + wave) * C::NK16 * NCT * 64 + lane;
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.Wf[dir]) + (size_t)(cb * C::NW + wave) * C::NK16 * NCT * 64 + lane;
 #pragma unroll
     for (int ks = 0; ks < C::NK16; ++ks)
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
         Pack8 p;
         p.f = (abl & 8) ? f32x4{0.f, 0.f, 0.f, 0.f} : src[(ks * NCT + ct) * 64];
-        w[ks][ct] = p.b;
+        if (ks * NCT + ct < C::W_REG_FRAGS)
+          w[ks][ct] = p.b;
+        else
+          wlds[(ks * NCT + ct - C::W_REG_FRAGS) * 64] = p.f;  // (read back by this wave only)
       }
   }
 
-  // ---- activation stream: per-lane source offsets of this wave's two DMA pieces per slot (rows 8 wave .. + 7)
+  // ---- activation stream: per-lane source offsets of this wave's DP DMA pieces per slot (rows 4 DP wave .. )
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xs + trow * IN_I, (unsigned)nact * IN_I * 2);
   const __amdgpu_buffer_rsrc_t rh =
       make_rsrc(t > 0 ? a.hs + (trow - a.B) * d : a.hs, t > 0 ? (unsigned)nact * d * 2 : 0u);  // h_{-1} = 0
-  unsigned voff_x[2], voff_h[2];
+  unsigned voff_x[C::DP], voff_h[C::DP];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = 4 * (2 * wave + j) + (lane >> 4), c = (lane & 15) ^ (r & 15);
+  for (int j = 0; j < C::DP; ++j) {
+    const int r = 4 * (C::DP * wave + j) + (lane >> 4), c = (lane & 15) ^ (r & 15);
     voff_x[j] = (unsigned)r * (IN_I * 2) + 16u * c;
     voff_h[j] = (unsigned)r * (d * 2) + 16u * c;
   }
@@ -203,14 +217,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
     // workgroup's last, and -- through its zero-record descriptor -- step 0's h_{-1} then fall off the descriptor and read
     // as zeros whichever way the range check treats a scalar offset
     const unsigned m0c = 32u * (unsigned)(rg + RG * ord);
-    bf16_t* dst = smem + (ord % C::RT) * C::TILE_ELEMS + cs * C::SLOT_ELEMS + (2 * wave) * 512;
+    bf16_t* dst = smem + (ord % C::RT) * C::TILE_ELEMS + cs * C::SLOT_ELEMS + (C::DP * wave) * 512;
     if constexpr (cs < C::SX) {
       const unsigned rowb = m0c * (IN_I * 2) + cs * 256;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < C::DP; ++j) {
         unsigned v = voff_x[j] + rowb;
         if constexpr (cs == C::SX - 1 && C::XLAST < 8) {  // the last x slot is narrower than 128 k: its tail chunks read zeros
-          const int r = 4 * (2 * wave + j) + (lane >> 4), c = (lane & 15) ^ (r & 15);
+          const int r = 4 * (C::DP * wave + j) + (lane >> 4), c = (lane & 15) ^ (r & 15);
           v = (c < 2 * C::XLAST) ? v : GLDS_OOB;
         }
         glds16(rx, dst + j * 512, v, 0);
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
     } else {
       const unsigned rowb = m0c * (d * 2) + (cs - C::SX) * 256;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) glds16(rh, dst + j * 512, voff_h[j] + rowb, 0);
+      for (int j = 0; j < C::DP; ++j) glds16(rh, dst + j * 512, voff_h[j] + rowb, 0);
     }
   };
   static_for<0, C::LOOK>([&](auto g_c) {  // slots 0 .. LOOK-1 of the stream
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
   auto prev_rows = [&](int m0p) {  // output offsets of the previous tile's rows: wave-uniform addresses, scalar cache
 #pragma unroll
     for (int p = 0; p < C::PASSES; ++p) {
-      const int i0 = m0p + 8 * wave + C::RPP * p;
+      const int i0 = m0p + C::RW * wave + C::RPP * p;
       int64_t o = a.plan.oo[trow + min(i0, a.B - 1)];
 #pragma unroll
       for (int j = 1; j < C::RPP; ++j) {
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
   auto own_rows = [&](int m0t) {
 #pragma unroll
     for (int p = 0; p < C::PASSES; ++p) {
-      const int i = min(m0t + 8 * wave + C::RPP * p + e_rsub, nact - 1);  // clamped: always a valid row
+      const int i = min(m0t + C::RW * wave + C::RPP * p + e_rsub, nact - 1);  // clamped: always a valid row
       if (t > 0)
         cp_next[p] = *reinterpret_cast<const f32x4*>(cprev_base + (size_t)i * d + u_lane);
       else
@@ -267,21 +281,22 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
   };
   f32x4 cv, hv;
   unsigned gpk[8];
-  float zn[4], zjk, ti, tf, to, tj, ig, jg, fg, og, cc, te;  // zn: the pre-activations of the NEXT cell (read one cell ahead)
-  auto read_cell = [&](auto p_c, auto e_c) {
-    constexpr int p = decltype(p_c)::value, e = decltype(e_c)::value;
-    const float* zr = zs + (8 * wave + C::RPP * p + e_rsub) * C::ZS + 4 * e_q + e;
+  f32x4 zg[4];  // the pass's pre-activations: gate g of the lane's four units (conflict-free 16-byte slab reads)
+  float zjk, ti, tf, to, tj, ig, jg, fg, og, cc, te;
+  auto read_pass = [&](auto p_c) {
+    constexpr int p = decltype(p_c)::value;
+    const float* zr = zs + (C::RW * wave + C::RPP * p + e_rsub) * C::ZS + 4 * e_q;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) zn[g] = zr[g * C::UB];
+    for (int g = 0; g < 4; ++g) zg[g] = *reinterpret_cast<const f32x4*>(zr + g * C::UB);
   };
   // (the empty asm statements pin a stage's results to its place in the MFMA stream: the compiler would otherwise sink the
   //  whole computation down to the stores.  The sigmoid / tanh forms are fvta_sigmoid / fvta_tanh cut in two.)
   auto run_stage = [&](auto s_c, int m0p) {
     constexpr int st = decltype(s_c)::value, p = st / C::PASS_STAGES, r = st % C::PASS_STAGES;
     if constexpr (r == 0) {
-      read_cell(std::integral_constant<int, p>{}, std::integral_constant<int, 0>{});
+      read_pass(std::integral_constant<int, p>{});
     } else if constexpr (r == C::PASS_STAGES - 1) {
-      const int i = m0p + 8 * wave + C::RPP * p + e_rsub;
+      const int i = m0p + C::RW * wave + C::RPP * p + e_rsub;
       if (i < nact && !(abl & 16)) {
         if constexpr (!(abl & 128)) st16(c_base + (size_t)i * d + u_lane, cv, a.nt != 0);
         const int64_t oo = oo_cur[p];
@@ -305,20 +320,18 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
     } else {
       constexpr int e = (r - 1) / C::CELL_STAGES, k = (r - 1) % C::CELL_STAGES;
       if constexpr ((abl & 32) != 0) {
-        if constexpr (k == 0) { cv[e] = zn[0]; hv[e] = zn[1]; gpk[2 * e] = __float_as_uint(zn[2]); gpk[2 * e + 1] = __float_as_uint(zn[3]); }
-        if constexpr (k == 2 && e < 3) read_cell(std::integral_constant<int, p>{}, std::integral_constant<int, e + 1>{});
+        if constexpr (k == 0) { cv[e] = zg[0][e]; hv[e] = zg[1][e]; gpk[2 * e] = __float_as_uint(zg[2][e]); gpk[2 * e + 1] = __float_as_uint(zg[3][e]); }
       } else
       if constexpr (k == 0) {
-        ti = __expf(-zn[0]);
-        tf = __expf(-(zn[2] + 1.0f));  // forget_bias
+        ti = __expf(-zg[0][e]);
+        tf = __expf(-(zg[2][e] + 1.0f));  // forget_bias
         asm volatile("" : "+v"(ti), "+v"(tf));
       } else if constexpr (k == 1) {
-        to = __expf(-zn[3]);
-        zjk = zn[1];
+        to = __expf(-zg[3][e]);
+        zjk = zg[1][e];
         tj = __expf(-2.0f * fabsf(zjk));
         asm volatile("" : "+v"(to), "+v"(tj), "+v"(zjk));
       } else if constexpr (k == 2) {
-        if constexpr (e < 3) read_cell(std::integral_constant<int, p>{}, std::integral_constant<int, e + 1>{});
         ig = __builtin_amdgcn_rcpf(1.0f + ti);
         fg = __builtin_amdgcn_rcpf(1.0f + tf);
         asm volatile("" : "+v"(ig), "+v"(fg));
@@ -349,11 +362,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
   // v_accvgpr_read per MFMA).  The asm statements are opaque to the hazard recogniser: an s_nop run covers the XDL write ->
   // VALU / LDS read distance before the accumulators are read.
   f32x16 acc[NCT];
+  Pack8 wl[NCT];  // LDS-resident weight fragments of the NEXT k-step
   auto mfma = [&](auto q_c, auto ct_c, const bf16x8_t afr) {
     constexpr int q = decltype(q_c)::value, ct = decltype(ct_c)::value;
     constexpr bool in_agpr = (q * NCT + ct) < C::W_AGPR_FRAGS;
     if constexpr ((abl & 2) != 0) return;
-    if constexpr (q == 0) {
+    if constexpr (q * NCT + ct >= C::W_REG_FRAGS) {
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[ct]) : "v"(afr), "v"(wl[ct].b));
+    } else if constexpr (q == 0) {
       if constexpr (in_agpr)
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[ct]) : "v"(afr), "a"(w[q][ct]));
       else
@@ -379,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
   auto handover = [&](auto s_c, int ord) {  // after it slot s_c of tile `ord` may be read
     constexpr int s = decltype(s_c)::value;
     const unsigned long long c0 = WREG_CLOCK();
-    wait_vmcnt<2 * (C::LOOK - 1)>();  // every younger DMA piece may still fly; everything older has landed
+    wait_vmcnt<C::DP * (C::LOOK - 1)>();  // every younger DMA piece may still fly; everything older has landed
     const unsigned long long c1 = WREG_CLOCK();
     __builtin_amdgcn_s_barrier();     // visible to all waves; the slot consumed two slots ago is free
     asm volatile("" ::: "memory");
@@ -436,7 +452,15 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_wreg_bf16(StepArgs a, int RG)
         }
       }
     };
-    static_for<0, C::NK16>(kstep);
+    static_for<0, C::NK16>([&](auto q_c) {
+      kstep(q_c);
+      constexpr int q1 = decltype(q_c)::value + 1;
+      if constexpr (q1 < C::NK16) {  // LDS-resident weight fragments of the next k-step
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+          if (q1 * NCT + ct >= C::W_REG_FRAGS) wl[ct].f = wlds[(q1 * NCT + ct - C::W_REG_FRAGS) * 64];
+      }
+    });
     // the tile's pre-activations -> slab [row][gate][unit of the workgroup]
     const unsigned long long sl0 = WREG_CLOCK();
     if constexpr (!C::SLAB_SAFE) {  // few k-steps: the previous tile's last slab reads may not lie before the last hand-over
@@ -497,6 +521,7 @@ static int wreg_cus() {
   return cus;
 }
 
+// waves per workgroup of the configuration a shape runs on
 // column tiles per wave for a shape, 0: not built
 int wreg_nct(int in_i, int d) {
   static const bool on = [] {
@@ -516,7 +541,7 @@ void launch_cvt_weights_frag(const float* W, const float* bias, bf16_t* wf, int 
   const int nct = wreg_nct(in_i, d);
   if (!nct) return;
   const int nk16 = (in_i + d) / 16;
-  const size_t total = (size_t)(d / (32 * nct)) * 4 * nk16 * nct * 64;
+  const size_t total = (size_t)d * nk16 * 8;  // one thread per 8 weights of the [4d][K] kernel
   const unsigned grid = (unsigned)((total + 255) / 256);
   if (nct == 2)
     hipLaunchKernelGGL(cvt_weights_frag_kernel<2>, dim3(grid), dim3(256), 0, s, W, bias, wf, in, in_i, d, nk16);
@@ -534,7 +559,7 @@ static void launch_wreg(const StepArgs& a, hipStream_t s) {
   if (rg < 4) rg = 4;
   const int tiles = (a.B + 31) / 32;
   while (rg > 4 && rg - 4 >= tiles) rg -= 4;
-  hipLaunchKernelGGL(lstm_fwd_wreg_bf16<C>, dim3(2 * rg * C::CB), dim3(256), C::LDS_BYTES, s, a, rg);
+  hipLaunchKernelGGL(lstm_fwd_wreg_bf16<C>, dim3(2 * rg * C::CB), dim3(64 * C::NW), C::LDS_BYTES, s, a, rg);
 }
 
 bool launch_step_fwd_wreg(const StepArgs& a, hipStream_t s) {

@@ -92,6 +92,23 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def gather_over_ranks(value, device):
+    """every rank's `value` (a float), in rank order -- bench.py's per-rank step times"""
+    if not is_dist():
+        return [value]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def describe():
+    """what the process group itself reports (not the environment): backend and world size"""
+    if not is_dist():
+        return dict(backend=None, world_size=1, rank=0)
+    return dict(backend=str(dist.get_backend()), world_size=int(dist.get_world_size()), rank=int(dist.get_rank()))
+
+
 def shutdown():
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()

@@ -128,7 +128,9 @@ class Model:
         if not 0.0 < self.keep_prob <= 1.0:
             raise ValueError("keep_prob %r is not in (0, 1]" % self.keep_prob)
         self.dropout_seed = int(_cfg(config, "dropout_seed", 0))
-        self._dropout_calls = 0
+        self._dropout_calls = 0      # persisted by Trainer.save / restore: a resumed run continues the mask sequence
+        from . import dist as _dist   # data-parallel ranks draw DIFFERENT masks for their shards
+        self._dropout_rank_salt = (_dist.world()[1] * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
         self.use_time_warp = bool(_cfg(config, "use_time_warp", False))
         self.warp_type = int(_cfg(config, "warp_type", 1))
         self.window_t = float(_cfg(config, "window_t", 3.0))     # time_warp_window_t, init 3.0 (model_v2.py:333); no gradient
@@ -184,16 +186,6 @@ class Model:
         except Exception:
             hi = 0
         self._side, self.side_stream_ratio = ops.pick_side_stream(self.dev, priority=int(_cfg(config, "side_stream_priority", hi)))
-        # a second one, lowest priority, for the text cell's backward tails (dx, weight gradient per step group:
-        # fvta_bilstm_bwd_overlap); it has to run beside the main stream AND the photo cell's stream
-        self._side2 = None
-        if self.precision == BF16 and bool(_cfg(config, "overlap_bwd_tails", True)):
-            try:
-                lo = torch.cuda.Stream.priority_range()[0]
-            except Exception:
-                lo = 0
-            self._side2, self.side2_stream_ratio = ops.pick_side_stream(self.dev, others=(self._side,), priority=lo)
-
         dp, wp = self.dp, self.wp
         F = {1: 3 * wp, 2: 2 * wp, 3: 4 * wp, 4: 0}[self.simi]
         dirs = ["fw"] if self.share_fw_bw else ["fw", "bw"]
@@ -838,7 +830,7 @@ class Model:
             if cw:                                                          # conv1d's dropout (model_v2.py:58-62), training only
                 if T_.dropout:
                     self._dropout_calls += 1
-                    T_.char_drop_seed = (self.dropout_seed * 0x9E3779B1 + self._dropout_calls * 2 + 0x5851F42D) & (2 ** 64 - 1)
+                    T_.char_drop_seed = ((self.dropout_seed * 0x9E3779B1 + self._dropout_calls * 2 + 0x5851F42D) ^ self._dropout_rank_salt) & (2 ** 64 - 1)
                     T_.embed.set_dropout(self.keep_prob, T_.char_drop_seed)
                 else:
                     T_.embed.set_dropout(1.0, 0)
@@ -861,7 +853,7 @@ class Model:
                 kf, bf, kb, bb = self._cell_params(cell)
                 if G.dropout:                                              # model_v2.py:657-661
                     self._dropout_calls += 1
-                    G.drop_seed = (self.dropout_seed * 0x9E3779B1 + self._dropout_calls * 2 + (cell == "image")) & (2 ** 64 - 1)
+                    G.drop_seed = ((self.dropout_seed * 0x9E3779B1 + self._dropout_calls * 2 + (cell == "image")) ^ self._dropout_rank_salt) & (2 ** 64 - 1)
                     ops.dropout_pair_fwd(G.x, G.x2, self.keep_prob, G.drop_seed)
                 G.op.forward(G.x2 if G.dropout else G.x, L.arena, kf, bf, kb, bb)   # encoders + context tensor
         main.wait_stream(self._side)
@@ -931,13 +923,11 @@ class Model:
                         if G.dx2 is None:
                             G.dx2 = torch.zeros_like(G.x2)
                         G.dx2.zero_()
-                    G.op.backward(G.x2, L.arena, L.d_arena, kf, kb, G.dx2 if need_dx else None, dkf, dbf, dkb, dbb,
-                                  side_stream=self._side2 if side is None else None)
+                    G.op.backward(G.x2, L.arena, L.d_arena, kf, kb, G.dx2 if need_dx else None, dkf, dbf, dkb, dbb)
                     if need_dx:
                         ops.dropout_pair_bwd(G.dx2, G.dx, self.keep_prob, G.drop_seed)
                 else:
-                    G.op.backward(G.x, L.arena, L.d_arena, kf, kb, G.dx if need_dx else None, dkf, dbf, dkb, dbb,
-                                  side_stream=self._side2 if side is None else None)
+                    G.op.backward(G.x, L.arena, L.d_arena, kf, kb, G.dx if need_dx else None, dkf, dbf, dkb, dbb)
                 if side is not None and not self.wd:
                     # data parallelism: everything in [0, early_numel) of the flat gradient -- scorer, attention(s),
                     # time warp, photo cell -- is final in THIS stream's order now; start its all-reduce on RCCL's

@@ -86,6 +86,7 @@ class Trainer:
                     out["%s/%s/%s:0" % (m.scope, k, slot)] = v
         if hasattr(self.opt, "t"):
             out["step_count"] = np.int64(self.opt.t)
+        out["dropout_calls"] = np.array(int(getattr(m, "_dropout_calls", 0)))   # the dropout mask sequence continues on resume
         np.savez(os.path.join(path, "optimizer.npz"), **out)
         return path
 
@@ -120,6 +121,8 @@ class Trainer:
                 self.opt.state = state
             if "step_count" in z.files and hasattr(self.opt, "t"):
                 self.opt.t = int(z["step_count"])
+            if "dropout_calls" in z.files:
+                m._dropout_calls = int(z["dropout_calls"])
         return True
 
     def restore_tf_checkpoint(self, path):

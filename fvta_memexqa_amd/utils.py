@@ -73,7 +73,8 @@ class Dataset:
 
         Data parallelism (no counterpart in the reference): with world > 1 every rank must pass the same
         `seed`; all ranks then walk ONE shuffled order in global batches of batch_size * world and rank r takes the r-th
-        contiguous batch_size slice of each, so an epoch covers every example exactly once across ranks.  The
+        contiguous batch_size slice of each (a short last group is dealt round-robin instead, every rank gets at least one
+        example; fewer examples than ranks raise), so an epoch covers every example exactly once across ranks.  The
         single-process call (world = 1, seed None) is the reference's: one draw from the global `random`."""
         if world > 1 and shuffle and seed is None:
             raise ValueError("get_batches: data-parallel ranks need a common shuffle seed")
@@ -86,8 +87,16 @@ class Dataset:
         order = rng.sample(list(self.valid_idxs), len(self.valid_idxs)) if shuffle else list(self.valid_idxs)
         groups = chain.from_iterable(grouper(order, gbs) for _ in range(num_epochs))
         for _ in range(num_steps):
-            group = next(groups)[rank * batch_size:(rank + 1) * batch_size]
-            batch_idxs = tuple(i for i in group if i is not None)
+            group = [i for i in next(groups) if i is not None]
+            if world > 1 and len(group) < gbs:
+                # the short last global group of an epoch: dealt round-robin, so that EVERY rank gets a batch (a rank
+                # with no examples would leave the step's collectives one participant short)
+                if len(group) < world:
+                    raise ValueError("get_batches: %d examples left for %d ranks (num_examples %% (batch_size * world) "
+                                     "must be 0 or >= world)" % (len(group), world))
+                batch_idxs = tuple(group[rank::world])
+            else:
+                batch_idxs = tuple(group[rank * batch_size:(rank + 1) * batch_size])
             yield batch_idxs, self._mini_batch(batch_idxs)
 
 

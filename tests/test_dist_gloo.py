@@ -153,6 +153,21 @@ def test_rank_aware_batches_cover_an_epoch_once():
     assert sorted(seen) == list(range(n))
     with pytest.raises(ValueError):
         next(ds.get_batches(4, 1, shuffle=True, rank=0, world=2))
+    # the short last global group (23 examples; 3 ranks x 4: the tail holds 11; 4 ranks x 4: it holds 7): every rank gets a
+    # non-empty batch, the tail is covered once
+    for world, bs in ((3, 4), (4, 4)):
+        tails, seen = [], []
+        for rank in range(world):
+            batches = [idxs for idxs, _ in ds.get_batches(bs, 100, shuffle=False, cap=True, rank=rank, world=world)]
+            assert all(len(b) > 0 for b in batches), (world, rank, batches)
+            tails.append(batches[-1])
+            seen += [i for b in batches for i in b]
+        assert sorted(seen) == list(range(n))
+        assert max(len(t) for t in tails) - min(len(t) for t in tails) <= 1
+    # fewer examples left than ranks: no way to give every rank a batch -- refused rather than hung
+    small = Dataset({"q": list(range(9)), "aid": [[] for _ in range(9)]}, "train", shared=shared)
+    with pytest.raises(ValueError):
+        list(small.get_batches(4, 100, shuffle=False, cap=True, rank=0, world=2))   # 9 = 8 + 1: one example for two ranks
     a = [i for i, _ in ds.get_batches(5, 5, shuffle=False)]
     assert a[0] == (0, 1, 2, 3, 4) and a[4] == (20, 21, 22)
 
