@@ -58,14 +58,16 @@ def parse():
     ap.add_argument("--config", default="metric", choices=["metric", "plumbing", "long_album"])
     ap.add_argument("--variant", default="dense", choices=["dense", "ragged"],
                     help="dense: every length = max (no padding to skip; the headline). ragged: SURVEY 8d length distribution")
-    ap.add_argument("--precision", default="bf16", choices=["f32", "bf16"],
+    ap.add_argument("--precision", default="bf16", choices=["f32", "bf16", "bf16x3"],
                     help="bf16: BASELINE.json configs[2] (bf16 MFMA operands in the bi-LSTM, fp32 accumulate, fp32 attention); "
-                         "f32: exact-fp32 engine (the 1e-4 parity path)")
+                         "f32: exact-fp32 engine (the 1e-4 parity path); bf16x3: the bi-LSTM's operands split in two bf16 terms, "
+                         "three MFMA products per GEMM -- 1e-4 parity on the bf16 matrix pipe")
     ap.add_argument("--optimizer", default="adam", choices=["adam", "adadelta"])
     ap.add_argument("--batch", type=int, default=None, help="QA pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--side-priority", type=int, default=None,
                     help="priority of the photo cell's side stream (default: the highest the device offers; 0 = normal)")
+    ap.add_argument("--serial-photo-forward", type=int, default=None, help="1 / 0: the photo cell's forward in front of / beside the text cell")
     ap.add_argument("--cpu-sample", type=int, default=4, help="QA pairs in the CPU-baseline sample (4: ~10-15 s of CPU work)")
     ap.add_argument("--cpu-threads", type=int, default=16,
                     help="torch-CPU threads of the baseline; 16 is the fastest setting measured on the 2x EPYC 9575F host "
@@ -187,6 +189,8 @@ def main():
                init_lr=0.001 if args.optimizer == "adam" else 0.5)
     if args.side_priority is not None:
         cfg["side_stream_priority"] = args.side_priority
+    if args.serial_photo_forward is not None:
+        cfg["serial_photo_forward"] = bool(args.serial_photo_forward)
     if args.front_end:   # README.MD:144-147 sizes: 100-d GloVe + 100-d char-CNN, 2537-d photo features -> 100
         from fvta_memexqa_amd.synth import make_token_inputs
         cfg.update(word_vocab_size=400, word_emb_size=100, use_char=True, char_vocab_size=100, max_word_size=16,

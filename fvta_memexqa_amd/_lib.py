@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FVTA_LIB_PATH: a diagnostics build of the same library (tools/: stamped / ablated kernels), never a different backend
 LIB_PATH = os.environ.get("FVTA_LIB_PATH") or os.path.join(_HERE, "csrc", "libfvta_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2
 
 
 class FvtaError(RuntimeError):

@@ -427,7 +427,8 @@ static int check_lstm_desc(const fvta_lstm_desc* d) {
   FVTA_CHECK_ARG(d->B > 0 && d->J > 0 && d->J <= 1024, "lstm: need B>0 and 0<J<=1024 (B=%d J=%d)", d->B, d->J);
   FVTA_CHECK_ARG(d->in > 0 && d->in % 4 == 0, "lstm: input width must be a positive multiple of 4 (in=%d)", d->in);
   FVTA_CHECK_ARG(d->d > 0 && d->d % 32 == 0, "lstm: hidden size must be a positive multiple of 32 (d=%d)", d->d);
-  FVTA_CHECK_ARG(d->precision == FVTA_F32 || d->precision == FVTA_BF16, "lstm: unknown precision %d", d->precision);
+  FVTA_CHECK_ARG(d->precision == FVTA_F32 || d->precision == FVTA_BF16 || d->precision == FVTA_BF16X3,
+                 "lstm: unknown precision %d", d->precision);
   return FVTA_OK;
 }
 
@@ -496,8 +497,9 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   const dim3 grid((d->B + MmaStep::BM - 1) / MmaStep::BM, d->d / 32, 2);
   const size_t sh = MmaStep::LDS_FLOATS * sizeof(float);
   fvta_prof_begin(FVTA_PROF_LSTM_STEP_FWD + 16 * d->reserved, stream);
-  const bool bf = d->precision == FVTA_BF16;
+  const bool bf = lstm_is_bf(d);
   a.Kp = kpad8(d);
+  a.xm = lstm_xm(d);
   a.dbg = fvta_diag_env("FVTA_DEBUG_SKIP", 0);  // -DFVTA_DIAG builds only
   a.nt = 0;
   a.Wt[0] = a.Wt[1] = nullptr;
@@ -505,16 +507,16 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   if (bf) {  // refresh the bf16 weight shadows (the optimiser has just changed the fp32 masters)
     const int ndir = d->share_fw_bw ? 1 : 2;
     for (int i = 0; i < ndir; ++i)
-      launch_cvt_weights_bf16(a.W[i], wv.wt[i], wv.wb[i], d->in, in_internal(d), d->d, stream);
+      launch_cvt_weights_bf16(a.W[i], wv.wt[i], wv.wb[i], d->in, in_internal(d), d->d, a.xm, stream);
     a.Wt[0] = wv.wt[0];
     a.Wt[1] = d->share_fw_bw ? wv.wt[0] : wv.wt[1];
-    if (wreg_nct(in_internal(d), d->d)) {
+    if (a.xm == 1 && wreg_nct(in_internal(d), d->d)) {
       for (int i = 0; i < ndir; ++i)
         launch_cvt_weights_frag(a.W[i], a.bias[i], wv.wf[i], d->in, in_internal(d), d->d, stream);
       a.Wf[0] = wv.wf[0];
       a.Wf[1] = d->share_fw_bw ? wv.wf[0] : wv.wf[1];
     }
-    launch_cvt_x_bf16(pv, x, sv.xs, d->B, d->J, d->in, in_internal(d), stream);
+    launch_cvt_x_bf16(pv, x, sv.xs, d->B, d->J, d->in, in_internal(d), a.xm, stream);
   }
   const int launches = d->J;
   for (int t = 0; t < d->J; ++t) {
@@ -570,7 +572,7 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
   g.cs = sv.cs;
   g.dc = wv.cstate;
   g.dh_rec = wv.dh_rec;
-  const bool bf = d->precision == FVTA_BF16;
+  const bool bf = lstm_is_bf(d);
   g.dzb = bf ? wv.dzb : nullptr;
   g.B = B;
   g.J = J;
@@ -612,6 +614,7 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
   w.in_i = in_internal(d);
   w.xs = sv.xs;
   w.hs = sv.hs;
+  w.xm = lstm_xm(d);
   // (side_stream_ / nactive_host: accepted for ABI stability, unused -- running dx / the weight gradient beside the
   //  recurrence and choosing the step's tile from the host's lengths were both measured slower)
   (void)side_stream_;
@@ -635,6 +638,8 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
     f.in = in;
     f.d = dd;
     f.in_i = in_internal(d);
+    f.gates32 = sv.gates;  // split engine: fp32 gates (sv.gatesb is null there)
+    f.xm = lstm_xm(d);
     for (int t = J - 1; t >= 0; --t) {
       f.t = t;
       launch_bwd_fused_bf16(f, stream);

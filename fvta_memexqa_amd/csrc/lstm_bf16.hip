@@ -30,9 +30,11 @@ static void allow_big_lds(K kernel, int bytes) {  // > 64 KB of dynamic LDS must
 }
 
 // ---- weight shadows in the internal row order [x rows | ones row | zero pad | h rows] -----------
-// kernel [in+d][N4] fp32 -> wb [in_i+d][N4] bf16, wt [N4][in_i+d] bf16.  grid (N4/32, (in_i+d)/32), 256 threads
+// kernel [in+d][N4] fp32 -> wb [in_i+d][xm N4] bf16, wt [N4][xm (in_i+d)] bf16.  grid (N4/32, (in_i+d)/32), 256 threads
+// xm = 3 (split engine): wt rows hold (hi, lo, hi) thirds per operand part -- [x: in_i | in_i | in_i][h: d | d | d], the
+// order the (hi, hi, lo) activation shadows pair with -- and wb rows (hi, hi, lo) thirds of N4, pairing with dz's (hi, lo, hi).
 __global__ void cvt_weights_kernel(const float* __restrict__ W, bf16_t* __restrict__ wt, bf16_t* __restrict__ wb,
-                                   int in, int in_i, int d) {
+                                   int in, int in_i, int d, int xm) {
   __shared__ float tile[32][33];
   const int N4 = 4 * d, Ki = in_i + d;
   const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -42,46 +44,88 @@ __global__ void cvt_weights_kernel(const float* __restrict__ W, bf16_t* __restri
     const int src = k < in ? k : (k >= in_i ? in + (k - in_i) : -1);  // internal row -> kernel row
     const float v = src >= 0 ? W[(size_t)src * N4 + n] : 0.f;
     tile[r][tx] = v;
-    wb[(size_t)k * N4 + 4 * (n % d) + n / d] = f2bf(v);  // column g*d+u -> 4u+g: dz rows are unit-major
+    const int c = 4 * (n % d) + n / d;  // column g*d+u -> 4u+g: dz rows are unit-major
+    const bf16_t hi = f2bf(v);
+    bf16_t* row = wb + (size_t)k * N4 * xm;
+    row[c] = hi;
+    if (xm == 3) {
+      row[N4 + c] = hi;
+      row[2 * N4 + c] = f2bf(v - bf2f(hi));
+    }
   }
   __syncthreads();
-  for (int r = ty; r < 32; r += 8) wt[(size_t)(n0 + r) * Ki + k0 + tx] = f2bf(tile[tx][r]);
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + tx;
+    const float v = tile[tx][r];
+    const bf16_t hi = f2bf(v);
+    bf16_t* row = wt + (size_t)(n0 + r) * Ki * xm;
+    if (xm == 1) {
+      row[k] = hi;
+    } else {  // part base, part width: the x part's thirds are in_i wide, the h part's d
+      const int base = k < in_i ? 0 : 3 * in_i, wd = k < in_i ? in_i : d, kk = k < in_i ? k : k - in_i;
+      row[base + kk] = hi;
+      row[base + wd + kk] = f2bf(v - bf2f(hi));
+      row[base + 2 * wd + kk] = hi;
+    }
+  }
 }
 
-void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int in, int in_i, int d, hipStream_t s) {
-  hipLaunchKernelGGL(cvt_weights_kernel, dim3(4 * d / 32, (in_i + d) / 32), dim3(256), 0, s, W, wt, wb, in, in_i, d);
+void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int in, int in_i, int d, int xm, hipStream_t s) {
+  hipLaunchKernelGGL(cvt_weights_kernel, dim3(4 * d / 32, (in_i + d) / 32), dim3(256), 0, s, W, wt, wb, in, in_i, d, xm);
 }
 
-// ---- input shadow: xs[dir][t][i][:] for every active (dir, t, i).  grid (ceil(B/4), J) ----------
-// One wave per (sorted row i, position pos): the row is read ONCE and written to both places it is needed -- step pos
-// of the forward direction and step len - 1 - pos of the backward direction (reverse_sequence).
-__global__ void cvt_x_kernel(PlanView pv, const float* __restrict__ x, bf16_t* __restrict__ xs, int B, int J, int in,
-                             int in_i) {
+// ---- input shadow: xs[dir][t][i][:] for every active (dir, t, i).  grid (ceil(B/16), J), 256 threads ----------
+// Sixteen lanes per (sorted row i, position pos), 16 bytes of the fp32 row per lane and pass: the row is read ONCE and
+// written to both places it is needed -- step pos of the forward direction and step len - 1 - pos of the backward
+// direction (reverse_sequence).
+// xm = 3 (split engine): the shadow row holds (hi, hi, lo) thirds of in_i.
+__global__ __launch_bounds__(256) void cvt_x_kernel(PlanView pv, const float* __restrict__ x, bf16_t* __restrict__ xs, int B,
+                                                    int J, int in, int in_i, int xm) {
   const int pos = blockIdx.y;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4), c16 = threadIdx.x & 15;
   if (i >= pv.nactive[pos]) return;  // len_i <= pos
   const int len = pv.len[pv.order[i]];
   const float* src = x + pv.xo[(size_t)pos * B + i];  // forward direction, step pos = position pos
   const int64_t bw_delta = pv.hdr->x_bw_delta;        // != 0: the backward direction has its own input (fvta_lstm_plan_xdir)
-  bf16_t* dst_fw = xs + ((size_t)pos * B + i) * in_i;
-  bf16_t* dst_bw = xs + (((size_t)J + (len - 1 - pos)) * B + i) * in_i;
-  for (int c = lane * 4; c < in_i; c += 256) {
-    bf16x4 o, ob;
+  bf16_t* dst_fw = xs + ((size_t)pos * B + i) * in_i * xm;
+  bf16_t* dst_bw = xs + (((size_t)J + (len - 1 - pos)) * B + i) * in_i * xm;
+  const bool al = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)(bw_delta * 4)) & 15) == 0;  // 16-byte aligned rows
+  for (int c = c16 * 4; c < in_i; c += 64) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f}, vb;
+    if (c + 4 <= in && al) {
+      v = *reinterpret_cast<const f32x4*>(src + c);
+      vb = bw_delta ? *reinterpret_cast<const f32x4*>(src + bw_delta + c) : v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = c + e;
+        // ones columns at `in` (its weight-gradient row is dbias) and `in + 1` (the second bias term of lstm_wreg.hip;
+        // in % 4 == 0, so in + 1 < in_i always)
+        v[e] = k < in ? src[k] : ((k == in || k == in + 1) ? 1.0f : 0.f);
+        vb[e] = (bw_delta && k < in) ? src[bw_delta + k] : v[e];
+      }
+    }
+    bf16x4 o, ob, l, lb;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int k = c + e;
-      // ones columns at `in` (its weight-gradient row is dbias) and `in + 1` (the second bias term of lstm_wreg.hip;
-      // in % 4 == 0, so in + 1 < in_i always)
-      o[e] = k < in ? (short)f2bf(src[k]) : ((k == in || k == in + 1) ? (short)0x3f80 : (short)0);
-      ob[e] = (bw_delta && k < in) ? (short)f2bf(src[bw_delta + k]) : o[e];
+      o[e] = (short)f2bf(v[e]);
+      ob[e] = (short)f2bf(vb[e]);
+      l[e] = (short)f2bf(v[e] - bf2f((bf16_t)o[e]));
+      lb[e] = (short)f2bf(vb[e] - bf2f((bf16_t)ob[e]));
     }
     *reinterpret_cast<bf16x4*>(dst_fw + c) = o;
     *reinterpret_cast<bf16x4*>(dst_bw + c) = ob;
+    if (xm == 3) {
+      *reinterpret_cast<bf16x4*>(dst_fw + in_i + c) = o;
+      *reinterpret_cast<bf16x4*>(dst_bw + in_i + c) = ob;
+      *reinterpret_cast<bf16x4*>(dst_fw + 2 * in_i + c) = l;
+      *reinterpret_cast<bf16x4*>(dst_bw + 2 * in_i + c) = lb;
+    }
   }
 }
 
-void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, int J, int in, int in_i, hipStream_t s) {
-  hipLaunchKernelGGL(cvt_x_kernel, dim3((B + 3) / 4, J), dim3(256), 0, s, pv, x, xs, B, J, in, in_i);
+void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, int J, int in, int in_i, int xm, hipStream_t s) {
+  hipLaunchKernelGGL(cvt_x_kernel, dim3((B + 15) / 16, J), dim3(256), 0, s, pv, x, xs, B, J, in, in_i, xm);
 }
 
 // ------------------------------------------------------------ forward step --
@@ -101,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step_fwd_bf16(StepArgs a) {
   if (m0 >= nact) return;
   const int tid = threadIdx.x;
   const int d = a.d, in_i = a.Kp - a.d;
+  const int in_k = in_i * a.xm, d_k = d * a.xm, Kk = a.Kp * a.xm;  // K extents of the x / h operand rows (split engine: three terms)
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
   for (int r = tid; r < Cfg::BM; r += Cfg::NT) s_oo[r] = (m0 + r < nact) ? a.plan.oo[trow + m0 + r] : -1;
 
@@ -108,20 +153,20 @@ __global__ __launch_bounds__(256, 2) void lstm_step_fwd_bf16(StepArgs a) {
   mma.init(tid);
   const int u0 = ub;
   // A rows m0.. of xs[dir][t] (nact rows) and of hs[dir][t-1]; B rows = the 4 gate strips of wt
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xs + trow * in_i, (unsigned)nact * in_i * 2);
-  const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (t > 0 ? trow - a.B : trow) * d, (unsigned)nact * d * 2);
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wt[dir], (unsigned)(4 * d) * a.Kp * 2);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xs + trow * in_k, (unsigned)nact * in_k * 2);
+  const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (t > 0 ? trow - a.B : trow) * d_k, (unsigned)nact * d_k * 2);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wt[dir], (unsigned)(4 * d) * Kk * 2);
   RowSrc<Cfg::A_GLDS> ax, ah;
   RowSrc<Cfg::B_GLDS> bw;
-  ax.setup(mma.wave_all, mma.lane, m0, nact, in_i * 2);
-  ah.setup(mma.wave_all, mma.lane, m0, nact, d * 2);
+  ax.setup(mma.wave_all, mma.lane, m0, nact, in_k * 2);
+  ah.setup(mma.wave_all, mma.lane, m0, nact, d_k * 2);
 #pragma unroll
   for (int j = 0; j < Cfg::B_GLDS; ++j) {  // B row r = gate strip (r>>5)&3, unit ub + (r&31)
     const int U = (mma.wave_all * Cfg::B_GLDS + j) * 64 + mma.lane;
     const int r = U >> 2, c = (U & 3) ^ ((r >> 2) & 3);
-    bw.voff[j] = (unsigned)(((r >> 5) & 3) * d + ub + (r & 31)) * (unsigned)(a.Kp * 2) + 16u * c;
+    bw.voff[j] = (unsigned)(((r >> 5) & 3) * d + ub + (r & 31)) * (unsigned)(Kk * 2) + 16u * c;
   }
-  const int nx = in_i / 32, nt = (t == 0) ? nx : nx + d / 32;
+  const int nx = in_k / 32, nt = (t == 0) ? nx : nx + d_k / 32;
   auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
     if (tile < nx)
       ax.issue(rx, As, mma.wave_all, tile * 64);
@@ -166,7 +211,7 @@ void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s) {
 // WM < 4: block tiles of fewer rows (64 x 128 on ONE wave, 128 x 128 on two) for calls with few sequences -- the photo
 // cell's 64 rows: a step is then a chain of K/32 k-tiles whose length is the DMA wave-instructions per k-tile (A rows + B
 // rows, at ~40 clocks each whether or not the rows exist), 12 instead of 32.
-template <int WN, int WM = 4>
+template <int WN, int WM = 4, int XM = 1>  // XM = 3: the split engine (three bf16 terms per operand value, fp32 saved gates)
 __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
   typedef TileCfgT<WN, 2, WM> TileCfg;
   typedef MmaBT<WN, 2, WM> MmaB;
@@ -174,7 +219,7 @@ __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void 
   int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + (size_t)TileCfg::STAGES * TileCfg::STAGE_ELEMS);
   const int tid = (int)threadIdx.x, dir = blockIdx.z;
   const int m0 = blockIdx.x * TileCfg::BM, u0 = blockIdx.y * TileCfg::BN;
-  const int t = a.t, d = a.d, K = 4 * d;
+  const int t = a.t, d = a.d, N4 = 4 * d, K = N4 * XM;  // K: the dz row (split engine: (hi, lo, hi) thirds of 4d)
   const int nact = a.plan.nactive[t];
   if (m0 >= nact) return;
   const int nnext = (t + 1 < a.J) ? a.plan.nactive[t + 1] : 0;
@@ -211,7 +256,7 @@ __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void 
     __builtin_amdgcn_wave_barrier();
   };
   struct In {
-    f32x4 g0, g1, cp, dout, dcv;
+    f32x4 g0, g1, g2, g3, cp, dout, dcv;  // g0, g1: packed bf16 gates of four units; split engine: g0..g3 fp32 gates, one unit each
   };
   auto ldnt = [](const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); };  // read once
 #pragma unroll
@@ -228,9 +273,17 @@ __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void 
         const int lr = it * 8 + io_row, row = mma.wave * MmaB::WROWS + ti * 32 + lr;
         const int ic = min(m0 + row, nact - 1);  // clamped: always a valid row
         const int64_t oo = s_oo[min(row, nact - 1 - m0)];
-        const float* gp = reinterpret_cast<const float*>(a.gatesb + (trow + ic) * (size_t)K + 4 * u);
-        in.g0 = ldnt(gp);
-        in.g1 = ldnt(gp + 4);
+        if constexpr (XM == 1) {
+          const float* gp = reinterpret_cast<const float*>(a.gatesb + (trow + ic) * (size_t)N4 + 4 * u);
+          in.g0 = ldnt(gp);
+          in.g1 = ldnt(gp + 4);
+        } else {
+          const float* gp = a.gates32 + (trow + ic) * (size_t)N4 + 4 * u;
+          in.g0 = ldnt(gp);
+          in.g1 = ldnt(gp + 4);
+          in.g2 = ldnt(gp + 8);
+          in.g3 = ldnt(gp + 12);
+        }
         in.cp = t > 0 ? ldnt(cs_p + (size_t)ic * d + u) : f32x4{0.f, 0.f, 0.f, 0.f};
         const float* dp = a.d_out + oo + u;
         if ((reinterpret_cast<uintptr_t>(dp) & 15) == 0)
@@ -244,24 +297,34 @@ __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void 
         const f32x4 dh4 = *reinterpret_cast<const f32x4*>(&pl[lr * LDP + 4 * io_c4]);
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 ga = __builtin_bit_cast(u32x4, in.g0), gb = __builtin_bit_cast(u32x4, in.g1);
-        u32x4 za, zb;
+        u32x4 za, zb, la, lb;  // dz of the four units, packed bf16 (i, j | f, o); la / lb: the low terms (split engine)
         f32x4 dco;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const unsigned w0 = e < 2 ? ga[2 * e] : gb[2 * (e - 2)], w1 = e < 2 ? ga[2 * e + 1] : gb[2 * (e - 2) + 1];
-          const float ig = bf2f((bf16_t)(w0 & 0xffff)), jg = bf2f((bf16_t)(w0 >> 16)), fg = bf2f((bf16_t)(w1 & 0xffff)),
-                      og = bf2f((bf16_t)(w1 >> 16));
+          float ig, jg, fg, og;
+          if constexpr (XM == 1) {
+            const unsigned w0 = e < 2 ? ga[2 * e] : gb[2 * (e - 2)], w1 = e < 2 ? ga[2 * e + 1] : gb[2 * (e - 2) + 1];
+            ig = bf2f((bf16_t)(w0 & 0xffff)), jg = bf2f((bf16_t)(w0 >> 16)), fg = bf2f((bf16_t)(w1 & 0xffff)), og = bf2f((bf16_t)(w1 >> 16));
+          } else {
+            const f32x4 g4 = e == 0 ? in.g0 : (e == 1 ? in.g1 : (e == 2 ? in.g2 : in.g3));
+            ig = g4[0], jg = g4[1], fg = g4[2], og = g4[3];
+          }
           const float dh = in.dout[e] + dh4[e];
           const float tc = fvta_tanh(in.cp[e] * fg + ig * jg);
           const float dc = in.dcv[e] + dh * og * (1.f - tc * tc);
-          const unsigned z0 = (unsigned)f2bf(dc * jg * ig * (1.f - ig)) | ((unsigned)f2bf(dc * ig * (1.f - jg * jg)) << 16);
-          const unsigned z1 = (unsigned)f2bf(dc * in.cp[e] * fg * (1.f - fg)) | ((unsigned)f2bf(dh * tc * og * (1.f - og)) << 16);
+          const float dzi = dc * jg * ig * (1.f - ig), dzj = dc * ig * (1.f - jg * jg), dzf = dc * in.cp[e] * fg * (1.f - fg),
+                      dzo = dh * tc * og * (1.f - og);
+          const bf16_t hi_i = f2bf(dzi), hi_j = f2bf(dzj), hi_f = f2bf(dzf), hi_o = f2bf(dzo);
+          const unsigned z0 = (unsigned)hi_i | ((unsigned)hi_j << 16), z1 = (unsigned)hi_f | ((unsigned)hi_o << 16);
+          unsigned l0 = 0, l1 = 0;
+          if constexpr (XM == 3) {
+            l0 = (unsigned)f2bf(dzi - bf2f(hi_i)) | ((unsigned)f2bf(dzj - bf2f(hi_j)) << 16);
+            l1 = (unsigned)f2bf(dzf - bf2f(hi_f)) | ((unsigned)f2bf(dzo - bf2f(hi_o)) << 16);
+          }
           if (e < 2) {
-            za[2 * e] = z0;
-            za[2 * e + 1] = z1;
+            za[2 * e] = z0, za[2 * e + 1] = z1, la[2 * e] = l0, la[2 * e + 1] = l1;
           } else {
-            zb[2 * (e - 2)] = z0;
-            zb[2 * (e - 2) + 1] = z1;
+            zb[2 * (e - 2)] = z0, zb[2 * (e - 2) + 1] = z1, lb[2 * (e - 2)] = l0, lb[2 * (e - 2) + 1] = l1;
           }
           dco[e] = dc * fg;
         }
@@ -269,6 +332,12 @@ __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void 
           float* zp = reinterpret_cast<float*>(a.dzb + (trow + i) * (size_t)K + 4 * u);
           *reinterpret_cast<f32x4*>(zp) = __builtin_bit_cast(f32x4, za);
           *reinterpret_cast<f32x4*>(zp + 4) = __builtin_bit_cast(f32x4, zb);
+          if constexpr (XM == 3) {  // (hi, lo, hi) thirds of 4d bf16 = 2d floats
+            *reinterpret_cast<f32x4*>(zp + 2 * d) = __builtin_bit_cast(f32x4, la);
+            *reinterpret_cast<f32x4*>(zp + 2 * d + 4) = __builtin_bit_cast(f32x4, lb);
+            *reinterpret_cast<f32x4*>(zp + 4 * d) = __builtin_bit_cast(f32x4, za);
+            *reinterpret_cast<f32x4*>(zp + 4 * d + 4) = __builtin_bit_cast(f32x4, zb);
+          }
           *reinterpret_cast<f32x4*>(dcs + (size_t)i * d + u) = dco;
         }
       };
@@ -285,25 +354,33 @@ __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void 
     }
 }
 
-void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
+template <int XM>
+static void launch_bwd_fused_xm(const FusedBwdArgs& a, hipStream_t s) {
   if (a.B <= 64) {  // few sequences (the photo cell): row tiles of 64 / 128
     constexpr int LDS = TileCfgT<1, 2, 1>::LDS_BYTES + 64 * 8;
-    allow_big_lds(lstm_bwd_fused_bf16<1, 1>, LDS);
-    hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 1>), dim3((a.B + 63) / 64, (a.d + 127) / 128, 2), dim3(64), LDS, s, a);
+    allow_big_lds(lstm_bwd_fused_bf16<1, 1, XM>, LDS);
+    hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 1, XM>), dim3((a.B + 63) / 64, (a.d + 127) / 128, 2), dim3(64), LDS, s, a);
   } else if (a.B <= 128) {
     constexpr int LDS = TileCfgT<1, 2, 2>::LDS_BYTES + 128 * 8;
-    allow_big_lds(lstm_bwd_fused_bf16<1, 2>, LDS);
-    hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 2>), dim3((a.B + 127) / 128, (a.d + 127) / 128, 2), dim3(128), LDS, s, a);
+    allow_big_lds(lstm_bwd_fused_bf16<1, 2, XM>, LDS);
+    hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 2, XM>), dim3((a.B + 127) / 128, (a.d + 127) / 128, 2), dim3(128), LDS, s, a);
   } else if (a.d % 256 == 0) {
     // 256 x 256 tile: dz (the A operand, K = 4d wide) is re-read d/256 instead of d/128 times
     constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
-    allow_big_lds(lstm_bwd_fused_bf16<2>, LDS);
-    hipLaunchKernelGGL((lstm_bwd_fused_bf16<2>), dim3(pad8((a.B + 255) / 256), a.d / 256, 2), dim3(512), LDS, s, a);
+    allow_big_lds(lstm_bwd_fused_bf16<2, 4, XM>, LDS);
+    hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4, XM>), dim3(pad8((a.B + 255) / 256), a.d / 256, 2), dim3(512), LDS, s, a);
   } else {
     constexpr int LDS = TileCfgT<1>::LDS_BYTES + 256 * 8;
-    allow_big_lds(lstm_bwd_fused_bf16<1>, LDS);
-    hipLaunchKernelGGL((lstm_bwd_fused_bf16<1>), dim3(pad8((a.B + 255) / 256), (a.d + 127) / 128, 2), dim3(256), LDS, s, a);
+    allow_big_lds(lstm_bwd_fused_bf16<1, 4, XM>, LDS);
+    hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 4, XM>), dim3(pad8((a.B + 255) / 256), (a.d + 127) / 128, 2), dim3(256), LDS, s, a);
   }
+}
+
+void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
+  if (a.xm == 3)
+    launch_bwd_fused_xm<3>(a, s);
+  else
+    launch_bwd_fused_xm<1>(a, s);
 }
 
 // dx = dz * wb_x^T for every step of both directions in one launch.  grid (pad8(ceil(B/256)), ceil(in/128), 2 J)
@@ -314,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void lstm_dx_bf16(FusedBwdArgs a) {
   const int m0 = blockIdx.x * TileCfg::BM, n0 = blockIdx.y * TileCfg::BN;
   const int nact = a.plan.nactive[t];
   if (m0 >= nact) return;
-  const int d = a.d, K = 4 * d, in = a.in;
+  const int d = a.d, K = 4 * d * a.xm, in = a.in;
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
   MmaB mma;
   mma.init(tid);
@@ -389,11 +466,11 @@ __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dw
   sb.setup(mma.wave_all, mma.lane, n0, N4, (unsigned)N4 * 2);
   const int t_begin = split * a.tgroup, t_end = min(a.J, t_begin + a.tgroup);
   for (int t = t_begin; t < t_end; ++t) {
-    const int nact = a.plan.nactive[t];
+    const int nact = a.plan.nactive[t] * a.xm;  // k-rows: a sequence row's xm terms are xm consecutive rows of both operands
     if (nact == 0) break;
     if (!isx && t == 0) continue;  // h_{-1} = 0
-    const size_t trow = ((size_t)dir * a.J + t) * a.B;
-    const bf16_t* A = isx ? a.xs + trow * in_i : a.hs + (trow - a.B) * d;
+    const size_t trow = ((size_t)dir * a.J + t) * a.B * a.xm;
+    const bf16_t* A = isx ? a.xs + trow * in_i : a.hs + (trow - (size_t)a.B * a.xm) * d;
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(A, (unsigned)nact * ncols * 2);
     const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + trow * (size_t)N4, (unsigned)nact * N4 * 2);
     auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {

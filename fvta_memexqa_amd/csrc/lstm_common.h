@@ -43,6 +43,15 @@ static inline PlanView plan_view(const fvta_lstm_desc* d, void* p) {
   return v;
 }
 
+// the bf16 engines (FVTA_BF16, FVTA_BF16X3) share kernels and layouts; XM = 3 in the split engine: every MFMA operand
+// row holds three bf16 terms per value -- (hi, hi, lo) for the activation shadows xs / hs, (hi, lo, hi) for the forward
+// weights wt and for dz, (hi, hi, lo) for the backward weights wb -- so that the SAME GEMM kernels, run over a K extent
+// three times as long, sum hi hi + hi lo + lo hi.  The term order is chosen so that every GEMM pairs an (a, a, b)
+// operand with an (a, b, a) one: xs/hs x wt (forward), dz x wb (backward, dx), xs/hs x dz (weight gradient, where the
+// three terms of a row are three consecutive k-rows).
+static inline bool lstm_is_bf(const fvta_lstm_desc* d) { return d->precision == FVTA_BF16 || d->precision == FVTA_BF16X3; }
+static inline int lstm_xm(const fvta_lstm_desc* d) { return d->precision == FVTA_BF16X3 ? 3 : 1; }
+
 // bf16 engine: internal input width = in + a ones column (dbias) + zero pad to a multiple of 32, so that
 // every 32-deep k-tile is wholly x or wholly h
 static inline int in_internal(const fvta_lstm_desc* d) { return (d->in + 1 + 31) / 32 * 32; }
@@ -65,13 +74,13 @@ static inline SavedView saved_view(const fvta_lstm_desc* d, void* p) {
   if (d->training) {
     if (d->precision == FVTA_BF16)
       s.gatesb = c.take<bf16_t>((size_t)2 * d->J * d->B * 4 * d->d);
-    else
+    else  // fp32 engine: [..][4][d]; split-bf16 engine: unit-major [..][d][4] like gatesb, fp32
       s.gates = c.take<float>((size_t)2 * d->J * d->B * 4 * d->d);
     s.cs = c.take<float>((size_t)2 * d->J * d->B * d->d);
   }
-  if (d->precision == FVTA_BF16) {
-    s.xs = c.take<bf16_t>((size_t)2 * d->J * d->B * in_internal(d));
-    s.hs = c.take<bf16_t>((size_t)2 * d->J * d->B * d->d);
+  if (lstm_is_bf(d)) {
+    s.xs = c.take<bf16_t>((size_t)2 * d->J * d->B * in_internal(d) * lstm_xm(d));
+    s.hs = c.take<bf16_t>((size_t)2 * d->J * d->B * d->d * lstm_xm(d));
   }
   s.bytes = c.off < 256 ? 256 : c.off;
   return s;
@@ -101,17 +110,18 @@ static inline WorkView work_view(const fvta_lstm_desc* d, void* p) {
   WorkView w;
   w.cstate = c.take<float>((size_t)2 * d->B * d->d);
   w.dh_rec = c.take<float>((size_t)2 * d->B * d->d);
-  const size_t slab_rows = d->precision == FVTA_BF16 ? (size_t)kpad8(d) : (size_t)(d->in + d->d + 1);
+  const size_t slab_rows = lstm_is_bf(d) ? (size_t)kpad8(d) : (size_t)(d->in + d->d + 1);
   w.slabs = c.take<float>((size_t)2 * dw_nsplit(d) * slab_rows * 4 * d->d);
   w.wt[0] = w.wt[1] = w.wb[0] = w.wb[1] = nullptr;
   w.dzb = nullptr;
   w.wf[0] = w.wf[1] = nullptr;
-  if (d->precision == FVTA_BF16) {
+  if (lstm_is_bf(d)) {
+    const size_t xm = (size_t)lstm_xm(d);
     for (int i = 0; i < 2; ++i) {
-      w.wt[i] = c.take<bf16_t>((size_t)4 * d->d * kpad8(d));
-      w.wb[i] = c.take<bf16_t>((size_t)kpad8(d) * 4 * d->d);
+      w.wt[i] = c.take<bf16_t>((size_t)4 * d->d * kpad8(d) * xm);
+      w.wb[i] = c.take<bf16_t>((size_t)kpad8(d) * 4 * d->d * xm);
     }
-    if (d->training) w.dzb = c.take<bf16_t>((size_t)2 * d->J * d->B * 4 * d->d);
+    if (d->training) w.dzb = c.take<bf16_t>((size_t)2 * d->J * d->B * 4 * d->d * xm);
     for (int i = 0; i < 2; ++i) w.wf[i] = c.take<bf16_t>((size_t)4 * d->d * kpad8(d));
   }
   w.bytes = c.off;
@@ -135,6 +145,7 @@ struct StepArgs {
   float* cstate;  // used when cs is null
   int t, B, J, in, d, Kp;
   int dbg;  // diagnostics only (-DFVTA_DIAG builds, FVTA_DEBUG_SKIP): fp32 engine ablations
+  int xm;   // bf16 engines: bf16 terms per operand value (1; 3 in the split engine, which saves fp32 gates in `gates`)
   int nt;   // bf16 engine: stream-once data (saved gates, cell states, fp32 h rows) with non-temporal stores (measured: no
             // effect on the forward step; 0)
 };
@@ -173,6 +184,7 @@ struct DwArgs {
   const bf16_t* hs;
   float* slabs;
   int B, J, in, d, tgroup, nsplit, in_i;
+  int xm;  // bf16 terms per operand value: the weight gradient contracts over xm k-rows per sequence row
 };
 
 #ifdef __HIPCC__
@@ -290,6 +302,7 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
     }
     float cv[16], hv[16];
     bf16x4 gv[16];
+    const bool x3 = a.xm == 3;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float ig = fvta_sigmoid(mma.acc[ti][0][r] + bi);
@@ -302,6 +315,10 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
       gv[r][1] = (short)f2bf(jg);
       gv[r][2] = (short)f2bf(fg);
       gv[r][3] = (short)f2bf(og);
+      if (x3 && a.gates) {  // split engine: fp32 gates, unit-major [row][u][i,j,f,o] -- 16 B per lane, 512 B per half-wave
+        const int i = m0 + wrow0 + (r & 3) + 8 * (r >> 2) + 4 * mma.hf;
+        if (i < nact) *reinterpret_cast<f32x4*>(a.gates + (trow + i) * (size_t)(4 * d) + 4 * u) = f32x4{ig, jg, fg, og};
+      }
     }
     // ---- c_t -> cs (training) or the rolling cstate
     {
@@ -338,19 +355,29 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
       }
       wave_sync();
     }
-    // ---- bf16 shadow of h_t (next step's MFMA operand): 4 lanes x 16 B per row, 16 rows per instruction
+    // ---- bf16 shadow of h_t (next step's MFMA operand): 4 lanes x 16 B per row, 16 rows per instruction.  Split engine:
+    // the row holds three terms per unit, [hi | hi | lo] in thirds of d
     if (a.hs) {
       constexpr int LDH = 40;  // bf16 per staged row (32 + pad)
+      const size_t hld = (size_t)d * a.xm;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) plh[((r & 3) + 8 * (r >> 2) + 4 * mma.hf) * LDH + mma.l31] = f2bf(hv[r]);
-      wave_sync();
+      for (int term = 0; term < 3; ++term) {
+        if (term >= a.xm) break;
+        const bool lo = term == 2;
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int lr = it * 16 + (lane >> 2), c8 = lane & 3, i = m0 + wrow0 + lr;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&plh[lr * LDH + 8 * c8]);
-        if (i < nact) *reinterpret_cast<f32x4*>(a.hs + (trow + i) * d + u0 + 8 * c8) = v;
+        for (int r = 0; r < 16; ++r) {
+          const bf16_t hi = f2bf(hv[r]);
+          plh[((r & 3) + 8 * (r >> 2) + 4 * mma.hf) * LDH + mma.l31] = lo ? f2bf(hv[r] - bf2f(hi)) : hi;
+        }
+        wave_sync();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int lr = it * 16 + (lane >> 2), c8 = lane & 3, i = m0 + wrow0 + lr;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&plh[lr * LDH + 8 * c8]);
+          if (i < nact) *reinterpret_cast<f32x4*>(a.hs + (trow + i) * hld + (size_t)term * d + u0 + 8 * c8) = v;
+        }
+        wave_sync();
       }
-      wave_sync();
     }
     // ---- gates, unit-major [row][u][i,j,f,o] bf16: 16 lanes x 16 B per row, 4 rows per instruction
     if (a.gatesb) {
@@ -373,8 +400,8 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
 #endif
 
 // bf16 engine launchers (lstm_bf16.hip)
-void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int in, int in_i, int d, hipStream_t s);
-void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, int J, int in, int in_i, hipStream_t s);
+void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int in, int in_i, int d, int xm, hipStream_t s);
+void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, int J, int in, int in_i, int xm, hipStream_t s);
 void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s);
 // weights-in-registers forward step (lstm_wreg.hip): false = shape not built, the tiled kernel runs instead
 int wreg_nct(int in_i, int d);
@@ -390,6 +417,8 @@ struct FusedBwdArgs {
   float* dc;  // [2][B][d]
   float* dx;  // lstm_dx only
   int t, B, J, in, d, in_i;
+  const float* gates32;  // split engine: fp32 gates, unit-major (gatesb null)
+  int xm;                // bf16 terms per operand value
 };
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s);
 void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s);

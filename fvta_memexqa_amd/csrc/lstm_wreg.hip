@@ -297,12 +297,22 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
       read_pass(std::integral_constant<int, p>{});
     } else if constexpr (r == C::PASS_STAGES - 1) {
       const int i = m0p + C::RW * wave + C::RPP * p + e_rsub;
-      if (i < nact && !(abl & 16)) {
+      if constexpr ((abl & 4096) != 0) {  // timing experiment: the same stores into a small L2-resident region
+        float* dump = reinterpret_cast<float*>(a.hs) + ((size_t)blockIdx.x * 4 + wave) * 2048 + lane * 4;
+        st16(dump, cv, false);
+        st16(dump + 256, hv, false);
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(dump + 512 + lane * 2 - lane * 4) = u32x2{pk_bf16(hv[0], hv[1]), pk_bf16(hv[2], hv[3])};
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        st16(dump + 1024, __builtin_bit_cast(f32x4, u32x4{gpk[0], gpk[1], gpk[2], gpk[3]}), false);
+        st16(dump + 1280, __builtin_bit_cast(f32x4, u32x4{gpk[4], gpk[5], gpk[6], gpk[7]}), false);
+      } else
+      if (((abl & 8192) || i < nact) && !(abl & 16)) {
         if constexpr (!(abl & 128)) st16(c_base + (size_t)i * d + u_lane, cv, a.nt != 0);
         const int64_t oo = oo_cur[p];
-        if (oo >= 0 && !(abl & 256)) {
+        if (((abl & 8192) || oo >= 0) && !(abl & 256)) {
           float* o = a.out + oo + u_lane;
-          if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+          if ((abl & 8192) || (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
             st16(o, hv, a.nt != 0);
           } else {  // an output row that is not 16-byte aligned
             o[0] = hv[0]; o[1] = hv[1]; o[2] = hv[2]; o[3] = hv[3];

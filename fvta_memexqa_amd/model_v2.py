@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 from . import ops
-from ._lib import F32, BF16
+from ._lib import F32, BF16, BF16X3
 
 SUPPORTED_W = (64, 128, 256, 512, 1024, 2048)
 
@@ -117,7 +117,7 @@ class Model:
         self.use_question_att = bool(_cfg(config, "use_question_att", False))
         self.use_eu_output = bool(_cfg(config, "use_eu_output", False))
         self.share_fw_bw = bool(_cfg(config, "share_fw_bw", True))
-        self.precision = {"f32": F32, "bf16": BF16}[_cfg(config, "precision", "f32")]
+        self.precision = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3}[_cfg(config, "precision", "f32")]
         self.wd = float(_cfg(config, "wd", None) or 0.0)                # --wd (main.py:105); None / 0.0: no l2 terms
         # d logits of softmax_cross_entropy_with_logits (model_v2.py:1088): True = what TF-1's kernel returns,
         # softmax - labels on every row, all-False label rows (padded rows of a short batch, :1270) included
@@ -186,6 +186,10 @@ class Model:
         except Exception:
             hi = 0
         self._side, self.side_stream_ratio = ops.pick_side_stream(self.dev, priority=int(_cfg(config, "side_stream_priority", hi)))
+        # the photo cell's FORWARD on the main stream, in front of the text cell, instead of beside it (its backward chain
+        # stays on the side stream): the weights-in-registers step kernel takes a whole CU per workgroup, so two cells'
+        # launches side by side only take CUs from each other
+        self.serial_photo_forward = bool(_cfg(config, "serial_photo_forward", False))
         dp, wp = self.dp, self.wp
         F = {1: 3 * wp, 2: 2 * wp, 3: 4 * wp, 4: 0}[self.simi]
         dirs = ["fw"] if self.share_fw_bw else ["fw", "bw"]
@@ -845,7 +849,7 @@ class Model:
         # HIP stream: the two write disjoint rows of the arena and meet again before the attention.  It is
         # enqueued FIRST -- a side stream that waits for main after the text launches are queued runs after them.
         for cell, G in sorted(L.groups.items(), key=lambda kv: kv[0] != "image"):
-            side = self._side if (cell == "image" and "text" in L.groups) else None
+            side = self._side if (cell == "image" and "text" in L.groups and not self.serial_photo_forward) else None
             if side is not None:
                 side.wait_stream(main)
             with torch.cuda.stream(side if side is not None else main):

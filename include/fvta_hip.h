@@ -36,6 +36,9 @@ extern "C" {
 
 #define FVTA_F32 0  /* exact fp32 arithmetic (v_mfma_f32_32x32x2_f32 + VALU) */
 #define FVTA_BF16 1 /* bf16 MFMA operands, fp32 accumulate (BASELINE.json configs[2]) */
+#define FVTA_BF16X3 2 /* bi-LSTM only: every MFMA operand split in two bf16 terms, three products per GEMM (hi hi + hi lo +
+                         lo hi, fp32 accumulate; what is dropped is <= 3 * 2^-17 of |a||b| per product), saved gates fp32:
+                         the 1e-4 parity engine on the bf16 matrix pipe (model_v2.py:652-661 computes in fp32) */
 
 typedef void* fvta_stream_t; /* hipStream_t */
 
@@ -124,7 +127,7 @@ typedef struct fvta_lstm_desc {
   int32_t in;          /* input features, multiple of 4 */
   int32_t d;           /* hidden size, multiple of 32 */
   int32_t share_fw_bw; /* 1: TF>=1.2 cell reuse, one kernel for both directions */
-  int32_t precision;   /* FVTA_F32 | FVTA_BF16 */
+  int32_t precision;   /* FVTA_F32 | FVTA_BF16 | FVTA_BF16X3 */
   int32_t training;    /* 1: keep gate activations for fvta_bilstm_bwd */
   int32_t reserved;    /* profiling tag: this call's brackets are filed under id + 16*reserved */
 } fvta_lstm_desc;

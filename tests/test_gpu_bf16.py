@@ -166,3 +166,86 @@ def test_backward_with_host_lengths_hint_is_bitwise_the_same(monkeypatch):
             assert torch.equal(a, e), tag
     op.set_active_hint(lens.numpy())
     assert op.active_hint.tolist() == [int((lens > t).sum()) for t in range(J)]
+
+
+# ------------------------------------------------------------------ the split-bf16 engine (FVTA_BF16X3)
+@pytest.mark.parametrize("B,J,din,d,dense,share", [(5, 6, 8, 32, False, True), (300, 9, 12, 64, False, True),
+                                                   (130, 5, 200, 128, True, False), (70, 17, 100, 64, False, False),
+                                                   (64, 30, 200, 512, False, True), (333, 12, 200, 1024, False, True)])
+def test_bilstm_bf16x3_meets_the_fp32_tolerances(B, J, din, d, dense, share):
+    """precision = bf16x3: every MFMA operand split in two bf16 terms, three products per GEMM (hi hi + hi lo + lo hi),
+    fp32 saved gates -- the bi-LSTM forward and every gradient against autograd of the fp64 oracle at north_star's
+    tolerance, 1e-4 relative (rtol 1e-4 plus 3e-5 x max|ref| absolute: a two-term bf16 split carries 16-17 significant
+    bits per operand, so a sum of K products is good to ~2e-5 of its scale -- the exact-fp32 engine's tests hold 1e-5)."""
+    from fvta_memexqa_amd import ops
+    from fvta_memexqa_amd._lib import BF16X3
+    from oracle import fvta_fused as F
+    g = torch.Generator().manual_seed(B + J + d + 1)
+    x = torch.randn(B, J, din, generator=g)
+    lens = torch.full((B,), J) if dense else torch.randint(0, J + 1, (B,), generator=g)
+    lim = (6.0 / (din + d + 4 * d)) ** 0.5
+    mk = lambda: ((torch.rand(din + d, 4 * d, generator=g) * 2 - 1) * lim * 2, torch.randn(4 * d, generator=g) * 0.1)
+    k_fw, b_fw = mk()
+    k_bw, b_bw = (None, None) if share else mk()
+    mask = torch.arange(J)[None, :] < lens[:, None]
+    g_out = torch.randn(B, J, 2 * d, generator=g) * mask[:, :, None]
+    g_last = torch.randn(B, 2 * d, generator=g)
+    leaves = [t.double().requires_grad_() for t in (x, k_fw, b_fw)]
+    if not share:
+        leaves += [k_bw.double().requires_grad_(), b_bw.double().requires_grad_()]
+    ref_out, ref_last = F.encode_stream(leaves[0], mask, leaves[1], leaves[2], *(leaves[3:] if not share else []))
+    ((ref_out * g_out.double()).sum() + (ref_last * g_last.double()).sum()).backward()
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    xc, kf, bf, kb, bb = cu(x), cu(k_fw), cu(b_fw), cu(k_bw), cu(b_bw)
+    out, last, op = ops.bilstm_simple(xc, lens, kf, bf, kb, bb, training=True, precision=BF16X3)
+
+    def close(a, b, msg, rtol=1e-4, atol=3e-5):
+        a, b = a.detach().cpu().double().numpy(), b.detach().cpu().double().numpy()
+        np.testing.assert_allclose(a, b, rtol=rtol, atol=atol * max(1.0, float(np.abs(b).max())), err_msg=msg)
+
+    close(out, ref_out, "out")
+    close(last, ref_last, "last")
+    d_out = cu(g_out).clone()
+    op.last_state_bwd(cu(g_last), 0, B, d_out)
+    dx = torch.zeros_like(xc)
+    dkf, dbf = torch.zeros_like(kf), torch.zeros_like(bf)
+    dkb, dbb = (None, None) if share else (torch.zeros_like(kb), torch.zeros_like(bb))
+    op.backward(xc, out, d_out, kf, kb, dx, dkf, dbf, dkb, dbb)
+    close(dx, leaves[0].grad, "dx")
+    close(dkf, leaves[1].grad, "dkernel_fw")
+    close(dbf, leaves[2].grad, "dbias_fw")
+    if not share:
+        close(dkb, leaves[3].grad, "dkernel_bw")
+        close(dbb, leaves[4].grad, "dbias_bw")
+
+
+def test_model_bf16x3_train_step_at_the_metric_shape_meets_the_fp32_tolerances():
+    """BASELINE.json configs[2]'s shape at N = 2, precision = bf16x3: yp, loss (1e-4 relative, arg-max exact) and every
+    parameter gradient (rtol 2e-4, atol 5e-5 x max|ref|) vs the fp64 oracle."""
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import CONFIGS, SynthSpec, make_inputs, make_params, to_dtype
+    from oracle import fvta_fused as F
+    spec = SynthSpec(dense=False, **dict(CONFIGS["metric"], N=2))
+    params, inputs = make_params(spec), make_inputs(spec)
+    p64 = {k: v.double().requires_grad_() for k, v in params.items()}
+    ref = F.fvta_forward(p64, to_dtype(inputs, torch.float64), spec.cfg())
+    ref["loss"].backward()
+    model = Model(dict(spec.cfg(), batch_size=spec.N, precision="bf16x3"), text_in=spec.text_in, img_in=spec.img_in)
+    model.set_oracle_params(params)
+    L = model.load_inputs(inputs, training=True)
+    model.zero_grad()
+    yp = model.forward(L)
+    model.backward(L, need_dx=True)
+
+    def close(a, b, msg, rtol, atol):
+        a = np.asarray(a.detach().cpu() if isinstance(a, torch.Tensor) else a, np.float64)
+        b = np.asarray(b.detach().cpu() if isinstance(b, torch.Tensor) else b, np.float64)
+        np.testing.assert_allclose(a, b, rtol=rtol, atol=atol * max(1.0, float(np.abs(b).max())), err_msg=msg)
+
+    close(yp, ref["yp"], "yp", 1e-4, 3e-5)
+    assert (yp.argmax(1).cpu() == ref["yp"].argmax(1)).all()
+    close(model.loss, ref["loss"].reshape(1), "loss", 1e-4, 3e-5)
+    grads = model.get_oracle_grads()
+    for k, v in p64.items():
+        if v.grad is not None:
+            close(grads[k].reshape(v.grad.shape), v.grad, "grad " + k, 2e-4, 5e-5)

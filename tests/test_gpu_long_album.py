@@ -4,7 +4,7 @@ selects (`attn_fwd_main` / `attn_bwd_main` at w = 2048 / JQ = 60, the LSTM engin
 
   * one ragged long-album QA pair, forward + backward: every parameter gradient and the encoder-input gradients
     against autograd of the fp64 oracle (reference: model_v2.py:210-298 attention_3d, 652-833 encoders, 1029-1096
-    scorer / loss) -- fp32 engine at the 1e-4 class, bf16 engine at relative L2 4e-2;
+    scorer / loss) -- fp32 and split-bf16 (bf16x3) engines at the 1e-4 class, bf16 engine at relative L2 4e-2;
   * op level: the bi-LSTM backward at (B >= 300, J = 60, in = 200, d = 1024), both engines; attention_3d backward at
     (N = 1, K = 7, T = 7200, JQ = 60, w = 2048), masked;
   * the N = 32 dense long-album train step (the configuration's own batch): finite, bitwise reproducible, bf16 answer
@@ -62,7 +62,7 @@ def _one_pair_oracle():
     return _ONE_PAIR
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16"])
 def test_long_album_one_pair_gradients_vs_oracle(precision):
     from fvta_memexqa_amd.model_v2 import Model
     R = _one_pair_oracle()
@@ -77,15 +77,17 @@ def test_long_album_one_pair_gradients_vs_oracle(precision):
     grads = model.get_oracle_grads()
     dxs = model.get_input_grads(L)
     assert len(dxs) == len(R["dx"])
-    if precision == "f32":
-        _close(yp, R["yp"], rtol=1e-4, atol=1e-5, msg="yp")
+    if precision in ("f32", "bf16x3"):
+        # (the split-bf16 engine carries 16-17 significant bits per MFMA operand: a little wider absolute bounds, same class)
+        wa, wg = (1e-5, 2e-5) if precision == "f32" else (3e-5, 5e-5)
+        _close(yp, R["yp"], rtol=1e-4, atol=wa, msg="yp")
         assert (yp.argmax(1).cpu() == R["yp"].argmax(1)).all()
-        _close(model.loss, R["loss"].reshape(1), rtol=1e-4, atol=1e-5, msg="loss")
+        _close(model.loss, R["loss"].reshape(1), rtol=1e-4, atol=wa, msg="loss")
         for k, g in R["grads"].items():
             if g is not None:
-                _close(grads[k].reshape(g.shape), g, rtol=2e-4, atol=2e-5, msg="grad " + k)
+                _close(grads[k].reshape(g.shape), g, rtol=2e-4, atol=wg, msg="grad " + k)
         for i, (a, b) in enumerate(zip(dxs, R["dx"])):
-            _close(a.reshape(b.shape), b, rtol=2e-4, atol=2e-5, msg="dx stream %d" % i)
+            _close(a.reshape(b.shape), b, rtol=2e-4, atol=wg, msg="dx stream %d" % i)
     else:
         _close(yp, R["yp"], rtol=0, atol=3e-2, msg="yp (bf16 engine)")
         worst, worst_scalar = {}, {}
