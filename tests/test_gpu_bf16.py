@@ -35,8 +35,11 @@ def test_mfma_bf16_gemm_layouts(layout, shape):
     _close(C, ref, rtol=1e-5, atol=1e-4 * K ** 0.5)
 
 
+# (the last four shapes run the weights-in-registers forward step kernel, csrc/lstm_wreg.hip: in_i / d = 128 / 128,
+#  224 / 512, 224 / 512 with separate fw / bw kernels, 32 / 128 with a ragged tail tile; the others the tiled one)
 @pytest.mark.parametrize("B,J,din,d,dense,share", [(5, 6, 8, 32, False, True), (300, 9, 16, 64, False, False),
-                                                   (130, 7, 104, 128, True, True), (64, 30, 200, 512, False, True)])
+                                                   (130, 7, 104, 128, True, True), (64, 30, 200, 512, False, True),
+                                                   (70, 6, 200, 512, False, False), (33, 5, 12, 128, False, True)])
 def test_bilstm_bf16_forward_backward(B, J, din, d, dense, share):
     from fvta_memexqa_amd import ops
     from oracle import fvta_fused as F
