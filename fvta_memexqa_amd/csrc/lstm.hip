@@ -615,10 +615,9 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
   w.xs = sv.xs;
   w.hs = sv.hs;
   w.xm = lstm_xm(d);
-  // (side_stream_ / nactive_host: accepted for ABI stability, unused -- running dx / the weight gradient beside the
-  //  recurrence and choosing the step's tile from the host's lengths were both measured slower)
+  // (side_stream_: accepted for ABI stability, unused -- running dx / the weight gradient beside the recurrence was
+  //  measured slower, DESIGN.md appendix.  nactive_host, when given, picks each backward step's block tile.)
   (void)side_stream_;
-  (void)nactive_host;
   fvta_prof_begin(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, stream);
   if (bf) {
     // bf16 engine: ONE launch per step -- dh_{t} = dz_{t+1} * wb_h^T in the k-loop, the gate gradient
@@ -642,6 +641,7 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
     f.xm = lstm_xm(d);
     for (int t = J - 1; t >= 0; --t) {
       f.t = t;
+      f.nact_hint = nactive_host ? nactive_host[t] : -1;
       launch_bwd_fused_bf16(f, stream);
     }
     if (dx) launch_dx_bf16(f, stream);

@@ -364,8 +364,12 @@ static void launch_bwd_fused_xm(const FusedBwdArgs& a, hipStream_t s) {
     constexpr int LDS = TileCfgT<1, 2, 2>::LDS_BYTES + 128 * 8;
     allow_big_lds(lstm_bwd_fused_bf16<1, 2, XM>, LDS);
     hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 2, XM>), dim3((a.B + 127) / 128, (a.d + 127) / 128, 2), dim3(128), LDS, s, a);
-  } else if (a.d % 256 == 0) {
-    // 256 x 256 tile: dz (the A operand, K = 4d wide) is re-read d/256 instead of d/128 times
+  } else if (a.d % 256 == 0 && !(a.nact_hint >= 0 && 4 * ((a.nact_hint + 255) / 256) <= 160)) {
+    // 256 x 256 tile: dz (the A operand, K = 4d wide) is re-read d/256 instead of d/128 times.  NOT for a step whose
+    // active rows (the host's lengths, when it has them: fvta_bilstm_bwd_hint) fill at most 160 of the CUs with such
+    // tiles: a launch lasts as long as one workgroup's chain of 64 k-tiles plus its epilogue, and the 256 x 128 tiles, two
+    // workgroups per CU, spread the same rows over twice as many (ragged batches: 7.06 -> 6.74 ms per step; dense
+    // batches keep the wide tile: 5.48 vs 5.72 ms per backward)
     constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
     allow_big_lds(lstm_bwd_fused_bf16<2, 4, XM>, LDS);
     hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4, XM>), dim3(pad8((a.B + 255) / 256), a.d / 256, 2), dim3(512), LDS, s, a);

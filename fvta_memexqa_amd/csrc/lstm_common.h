@@ -417,6 +417,7 @@ struct FusedBwdArgs {
   float* dc;  // [2][B][d]
   float* dx;  // lstm_dx only
   int t, B, J, in, d, in_i;
+  int nact_hint;         // active sequences of step t as the HOST knows them (fvta_bilstm_bwd_hint), -1: unknown -- picks the step's tile
   const float* gates32;  // split engine: fp32 gates, unit-major (gatesb null)
   int xm;                // bf16 terms per operand value
 };

@@ -162,7 +162,6 @@ def test_backward_with_host_lengths_hint_is_bitwise_the_same(monkeypatch):
 
     base = grads(None)
     assert float(base[1].abs().max()) > 0
-    monkeypatch.setenv("FVTA_LSTM_BWD_HINT", "1")      # the library acts on the hint only under this switch
     for hint in (lens.numpy(), np.zeros(B, np.int64), np.full(B, J)):
         got = grads(hint)
         for a, e, tag in zip(got, base, ("dx", "dkernel", "dbias")):
