@@ -69,27 +69,29 @@ struct WregCfg {
   static constexpr int LDS_BYTES = WL_OFF + NW * W_LDS_FRAGS * 1024;
   static_assert(LDS_BYTES <= 163840, "LDS");
   static constexpr int LPR = UB / 4, RPP = 64 / LPR, PASSES = RW / RPP;  // epilogue: lanes per row, rows per pass
-  // k-step q of a tile: its ring slot, its position in the slot, its fragment buffer (NK16 = 1 mod 3: the last k-step takes
-  // the fourth buffer, so that the next tile's first two k-steps find buffers 0 and 1 free)
+  // k-step q of a tile: its ring slot, its position in the slot, its fragment buffer
   static constexpr int slot_of(int q) { return q < NX16 ? q / 8 : SX + (q - NX16) / 8; }
   static constexpr int ks_of(int q) { return q < NX16 ? q % 8 : (q - NX16) % 8; }
-  static constexpr int buf_of(int q) { return (NK16 % 3 == 1 && q == NK16 - 1) ? 3 : q % 3; }
+  // A fragments are read PF k-steps ahead of their MFMAs into NB = PF + 1 rotating buffers; the k-step sequence of a tile
+  // is padded to NV, a multiple of NB (the padding steps read and multiply nothing), so that the rotation continues
+  // seamlessly into the next tile's first PF k-steps
+  static constexpr int PF = NX16 >= 3 ? 3 : 2, NB = PF + 1, NV = (NK16 + NB - 1) / NB * NB;
+  static constexpr int buf_of(int q) { return q % NB; }
   // gate-math stages (see the kernel): per pass 1 read + 4 cells x CELL_STAGES + 1 store.  A k-step has NCT places for a
   // stage (one behind each of its MFMAs); stage st runs at place HLO + st * HW / NSTAGES -- from the k-step after the
   // hand-over of slot 1 (every wave's slab write lies before it); the second pass's first slab read must come before the
-  // hand-over of the next tile's slot 0 (k-step NK16 - 2, which precedes this tile's slab write)
+  // hand-over of the next tile's slot 0 (k-step NV - PF, which precedes this tile's slab write)
   static constexpr int CELL_STAGES = 7, PASS_STAGES = 2 + 4 * CELL_STAGES, NSTAGES = PASSES * PASS_STAGES;
   static constexpr int QLO = SX > 1 ? 8 : NX16, HLO = NCT * QLO, HW = NCT * NK16 - HLO;
   static constexpr int stage_begin(int h) { return h <= HLO ? 0 : (h >= NCT * NK16 ? NSTAGES : ((h - HLO) * NSTAGES + HW - 1) / HW); }
   static constexpr int stage_place(int st) { return HLO + st * HW / NSTAGES; }
   // (the last slab read is cell 3's, requested at stage k = 2 of cell 2 of the last pass; shapes with too few k-steps for
   //  that put an extra barrier in front of the slab write instead)
-  static constexpr bool SLAB_SAFE = stage_place((PASSES - 1) * PASS_STAGES + 1 + 2 * CELL_STAGES + 2) / NCT <= NK16 - 3;
+  static constexpr bool SLAB_SAFE = stage_place((PASSES - 1) * PASS_STAGES + 1 + 2 * CELL_STAGES + 2) / NCT <= NV - PF - 1;
   static_assert(ND16 % 8 == 0, "hidden size must be a multiple of 128");
   static_assert(D % UB == 0, "column blocks");
   static_assert(W_REG_FRAGS * 4 <= 400, "weight slice must fit the register file");
-  static_assert(NK16 % 3 != 2, "fragment rotation: NK16 = 0 or 1 (mod 3)");
-  static_assert(NX16 >= 2, "the first slot holds at least two k-steps");
+  static_assert(NX16 >= PF, "the first slot holds the k-steps read ahead across a tile boundary");
   static_assert(PASSES >= 1 && PASSES <= 2 && LOOK >= 2 && RING <= 12, "geometry");
 };
 
@@ -392,16 +394,16 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
     }
   };
 
-  // ---- the k-step pipeline of a tile.  k-step q (of NK16) lies in ring slot slot_of(q); its A fragment is read TWO
-  // k-steps ahead of its MFMAs (four rotating fragment buffers), also across slot and tile boundaries: the hand-over of
+  // ---- the k-step pipeline of a tile.  k-step q (of NK16) lies in ring slot slot_of(q); its A fragment is read PF (three)
+  // k-steps ahead of its MFMAs (NB rotating fragment buffers), also across slot and tile boundaries: the hand-over of
   // slot g -- wait for its DMA, barrier, refill of the slot consumed two slots ago -- is therefore done while the MFMAs of
-  // slot g - 1's last two k-steps are still to come, and the matrix pipe never waits for a fresh LDS read.
+  // slot g - 1's last PF k-steps are still to come, and the matrix pipe never waits for a fresh LDS read.
   // ap[ks]: this lane's fragment address for position ks of a slot in the CURRENT tile's ring place (row l31, 16-byte
   // chunk (2 ks + hf) ^ (l31 & 15)); the slot is a compile-time offset on top.
   const bf16_t* ap[8];
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) ap[ks] = smem + l31 * 128 + (((2 * ks + hf) ^ (l31 & 15)) << 3);
-  Pack8 fr[4];
+  Pack8 fr[C::NB];
   auto handover = [&](auto s_c, int ord) {  // after it slot s_c of tile `ord` may be read
     constexpr int s = decltype(s_c)::value;
     const unsigned long long c0 = WREG_CLOCK();
@@ -419,8 +421,8 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
 
   handover(std::integral_constant<int, 0>{}, 0);
   const unsigned long long st_t1 = WREG_CLOCK();
-  fr[C::buf_of(0)].f = *reinterpret_cast<const f32x4*>(ap[0]);
-  fr[C::buf_of(1)].f = *reinterpret_cast<const f32x4*>(ap[1]);
+#pragma unroll
+  for (int q = 0; q < C::PF; ++q) fr[C::buf_of(q)].f = *reinterpret_cast<const f32x4*>(ap[q]);
   int prev_m0 = 1 << 30;  // no previous tile yet: the first tile's stages run on an undefined slab and store nothing
 #pragma unroll
   for (int p = 0; p < C::PASSES; ++p) {
@@ -433,14 +435,16 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
     const int tb_delta = (((it + 1) % C::RT) - (it % C::RT)) * C::TILE_ELEMS;
     auto kstep = [&](auto q_c) {
       constexpr int q = decltype(q_c)::value;
-      constexpr int n = q + 2;
+      constexpr int n = q + C::PF;
       if constexpr (n < C::NK16) {
         if constexpr (C::ks_of(n) == 0) handover(std::integral_constant<int, C::slot_of(n)>{}, it);
         fr[C::buf_of(n)].f = *reinterpret_cast<const f32x4*>(ap[C::ks_of(n)] + C::slot_of(n) * C::SLOT_ELEMS);
-      } else {  // the next tile's first two k-steps (past the workgroup's last tile: zeros nobody uses)
-        if constexpr (n == C::NK16) handover(std::integral_constant<int, 0>{}, it + 1);
-        fr[C::buf_of(n - C::NK16)].f = *reinterpret_cast<const f32x4*>(ap[n - C::NK16] + tb_delta);
+      } else if constexpr (n >= C::NV) {  // the next tile's first k-steps (past the workgroup's last tile: zeros nobody uses)
+        if constexpr (n == C::NV) handover(std::integral_constant<int, 0>{}, it + 1);
+        fr[C::buf_of(n - C::NV)].f = *reinterpret_cast<const f32x4*>(ap[n - C::NV] + tb_delta);
       }
+      if constexpr (q >= C::NK16) return;  // a padding step of the fragment rotation
+      else {
       if constexpr (q == 0) {
         const unsigned long long r0 = WREG_CLOCK();
         own_rows(m0);
@@ -461,8 +465,9 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
           st_stage += WREG_CLOCK() - g0;
         }
       }
+      }
     };
-    static_for<0, C::NK16>([&](auto q_c) {
+    static_for<0, C::NV>([&](auto q_c) {
       kstep(q_c);
       constexpr int q1 = decltype(q_c)::value + 1;
       if constexpr (q1 < C::NK16) {  // LDS-resident weight fragments of the next k-step
