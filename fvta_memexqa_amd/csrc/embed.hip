@@ -800,6 +800,166 @@ __global__ __launch_bounds__(256) void img_dw_kernel(fvta_imgtrans_desc d, const
   if (blockIdx.x == 0 && ty == 0) db[n] += colsum;
 }
 
+
+// ---- photo features on the matrix pipe -------------------------------------------------------------------------
+// The transform 2537 -> 100 of 2560 photos is a 0.65 GMAC GEMM: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, an fmaf
+// chain per output), operands straight from global memory into the one-register fragments, no LDS staging.  A workgroup
+// owns 16 output rows and all (<= 128) columns; its IMG_NW waves split the reduction index and combine in wave order
+// through LDS.  Column tile (u, e) of a lane's 16-byte loads holds the columns n = 64 u + 4 j + e (j = lane & 15), so
+// the B operand of a step is two dwordx4 loads per lane instead of eight dword loads.
+// Needs tdim % 4 == 0, tdim <= 128 and 16-byte aligned W / workspace rows (the launcher checks).
+constexpr int IMG_NW = 8;
+
+__device__ __forceinline__ f32x4 img_ld4(const float* p, bool ok) {
+  return ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// sum of the IMG_NW waves' accumulators: element (t, r, lane) of the 16 x 128 output tile, in wave order
+__device__ __forceinline__ float img_reduce(const float (*red)[8][4][64], int t, int r, int ln) {
+  float v = red[0][t][r][ln];
+#pragma unroll
+  for (int w = 1; w < IMG_NW; ++w) v += red[w][t][r][ln];
+  return v;
+}
+
+__global__ __launch_bounds__(64 * IMG_NW) void img_fwd_mfma(fvta_imgtrans_desc d, const int32_t* __restrict__ pidx,
+                                                           const int64_t* __restrict__ row_off,
+                                                           const float* __restrict__ feat, const float* __restrict__ W,
+                                                           const float* __restrict__ b, float* __restrict__ x) {
+  __shared__ float s_red[IMG_NW][8][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int m = m0 + i < d.M ? m0 + i : d.M - 1;
+  const float* arow = feat + (size_t)pidx[m] * d.idim;
+  const bool c0 = 4 * i < d.tdim, c1 = 64 + 4 * i < d.tdim;
+  const int nchunk = (d.idim + 15) / 16;
+  f32x4 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float a[4], an[4];
+  f32x4 b0[4], b1[4], b0n[4], b1n[4];
+  auto load = [&](int c, float* av, f32x4* v0, f32x4* v1) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = c * 16 + 4 * q + s;
+      const bool ok = c < nchunk && k < d.idim;
+      av[s] = ok ? arow[k] : 0.f;
+      const float* wr = W + (size_t)(ok ? k : 0) * d.tdim + 4 * i;
+      v0[s] = img_ld4(wr, ok && c0);
+      v1[s] = img_ld4(wr + 64, ok && c1);
+    }
+  };
+  load(wv, a, b0, b1);
+  for (int c = wv; c < nchunk; c += IMG_NW) {
+    load(c + IMG_NW, an, b0n, b1n);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b0[s][e], acc[e], 0, 0, 0);
+        acc[4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[s][e], acc[4 + e], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      a[s] = an[s];
+      b0[s] = b0n[s];
+      b1[s] = b1n[s];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_red[wv][t][r][lane] = acc[t][r];
+  __syncthreads();
+#pragma unroll
+  for (int z = 0; z < 2048 / (64 * IMG_NW); ++z) {
+    const int idx = threadIdx.x + 64 * IMG_NW * z;
+    const int t = idx >> 8, r = (idx >> 6) & 3, ln = idx & 63;
+    const int row = m0 + 4 * (ln >> 4) + r, n = 64 * (t >> 2) + 4 * (ln & 15) + (t & 3);
+    if (row >= d.M || n >= d.tdim) continue;
+    const float v = img_reduce(s_red, t, r, ln) + b[n];
+    x[row_off[row] + n] = d.add_tanh ? tanhf(v) : v;
+  }
+}
+
+// dW[k][n] += sum_m feat[pidx[m]][k] dpre[m][n]: a workgroup owns 16 rows k and all columns, its waves split m
+// (wave w takes the steps w, w + IMG_NW, ...: four photos a step) and combine in wave order; db by workgroup 0.
+__global__ __launch_bounds__(64 * IMG_NW) void img_dw_mfma(fvta_imgtrans_desc d, const int32_t* __restrict__ pidx,
+                                                          const float* __restrict__ feat, const float* __restrict__ dpre,
+                                                          float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float s_red[IMG_NW][8][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int k0 = blockIdx.x * 16;
+  const bool kok = k0 + i < d.idim;
+  const bool c0 = 4 * i < d.tdim, c1 = 64 + 4 * i < d.tdim;
+  const int nstep = (d.M + 3) / 4;
+  f32x4 acc[8], cs[2];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  cs[0] = cs[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 4;  // steps in flight
+  float a[U];
+  f32x4 b0[U], b1[U];
+  auto load = [&](int st, float& av, f32x4& v0, f32x4& v1) {
+    const int m = 4 * st + q;
+    const bool ok = st < nstep && m < d.M;
+    const int row = ok ? pidx[m] : 0;
+    av = (ok && kok) ? feat[(size_t)row * d.idim + k0 + i] : 0.f;
+    const float* pr = dpre + (size_t)(ok ? m : 0) * d.tdim + 4 * i;
+    v0 = img_ld4(pr, ok && c0);
+    v1 = img_ld4(pr + 64, ok && c1);
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u) load(wv + IMG_NW * u, a[u], b0[u], b1[u]);
+  for (int st = wv; st < nstep; st += IMG_NW * U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float av = a[u];
+      const f32x4 v0 = b0[u], v1 = b1[u];
+      load(st + IMG_NW * (u + U), a[u], b0[u], b1[u]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v0[e], acc[e], 0, 0, 0);
+        acc[4 + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, v1[e], acc[4 + e], 0, 0, 0);
+      }
+      cs[0] += v0;
+      cs[1] += v1;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_red[wv][t][r][lane] = acc[t][r];
+  __syncthreads();
+#pragma unroll
+  for (int z = 0; z < 2048 / (64 * IMG_NW); ++z) {
+    const int idx = threadIdx.x + 64 * IMG_NW * z;
+    const int t = idx >> 8, r = (idx >> 6) & 3, ln = idx & 63;
+    const int k = k0 + 4 * (ln >> 4) + r, n = 64 * (t >> 2) + 4 * (ln & 15) + (t & 3);
+    if (k >= d.idim || n >= d.tdim) continue;
+    dW[(size_t)k * d.tdim + n] += img_reduce(s_red, t, r, ln);
+  }
+  if (blockIdx.x != 0) return;
+  __syncthreads();
+  // column sums: lane (j, q) of wave w holds the sum over ITS photos of columns 64 u + 4 j + e; combine q, then waves
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_red[wv][u * 4 + e][0][lane] = cs[u][e];
+  __syncthreads();
+  const int n = threadIdx.x;
+  if (n < d.tdim && n < 128) {
+    const int t = (n >> 6) * 4 + (n & 3), j = (n & 63) >> 2;
+    float v = 0.f;
+    for (int w = 0; w < IMG_NW; ++w)
+      for (int qq = 0; qq < 4; ++qq) v += s_red[w][t][0][qq * 16 + j];
+    db[n] += v;
+  }
+}
+
 }  // namespace fvta
 using namespace fvta;
 
@@ -940,6 +1100,11 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
   return FVTA_OK;
 }
 
+// shapes the matrix-pipe photo kernels take: rows of `mat` (W [idim][tdim] or dpre [M][tdim]) read 16 bytes at a time
+static bool img_mfma_ok(const fvta_imgtrans_desc* d, const float* mat) {
+  return d->tdim % 4 == 0 && d->tdim <= 128 && ((uintptr_t)mat & 15) == 0;
+}
+
 extern "C" int fvta_image_trans_fwd(const fvta_imgtrans_desc* d, const int32_t* pidx, const int64_t* row_off,
                                     const float* image_emb_mat, const float* W, const float* b, float* x,
                                     fvta_stream_t stream_) {
@@ -947,6 +1112,12 @@ extern "C" int fvta_image_trans_fwd(const fvta_imgtrans_desc* d, const int32_t* 
                  "image_trans_fwd: bad argument");
   FVTA_CHECK_ARG(W ? b != nullptr : d->tdim == d->idim, "image_trans_fwd: W without b, or tdim != idim without W");
   const int nd = W ? d->tdim : d->idim;
+  if (W && img_mfma_ok(d, W)) {
+    hipLaunchKernelGGL(img_fwd_mfma, dim3((d->M + 15) / 16), dim3(64 * IMG_NW), 0, (hipStream_t)stream_, *d, pidx, row_off,
+                       image_emb_mat, W, b, x);
+    FVTA_CHECK_LAUNCH("image_trans_fwd");
+    return FVTA_OK;
+  }
   hipLaunchKernelGGL(img_fwd_kernel, dim3((d->M + 31) / 32, (nd + 31) / 32), dim3(256), 0, (hipStream_t)stream_, *d, pidx,
                      row_off, image_emb_mat, W, b, x);
   FVTA_CHECK_LAUNCH("image_trans_fwd");
@@ -963,8 +1134,12 @@ extern "C" int fvta_image_trans_bwd(const fvta_imgtrans_desc* d, const int32_t* 
   float* dpre = (float*)workspace;
   const size_t n = (size_t)d->M * d->tdim;
   hipLaunchKernelGGL(img_dpre_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *d, row_off, x, dx, dpre);
-  hipLaunchKernelGGL(img_dw_kernel, dim3((d->idim + 31) / 32, (d->tdim + 31) / 32), dim3(256), 0, stream, *d, pidx,
-                     image_emb_mat, dpre, dW, db);
+  if (img_mfma_ok(d, dpre))
+    hipLaunchKernelGGL(img_dw_mfma, dim3((d->idim + 15) / 16), dim3(64 * IMG_NW), 0, stream, *d, pidx, image_emb_mat, dpre,
+                       dW, db);
+  else
+    hipLaunchKernelGGL(img_dw_kernel, dim3((d->idim + 31) / 32, (d->tdim + 31) / 32), dim3(256), 0, stream, *d, pidx,
+                       image_emb_mat, dpre, dW, db);
   FVTA_CHECK_LAUNCH("image_trans_bwd");
   return FVTA_OK;
 }

@@ -119,12 +119,17 @@ def test_token_embed_without_char_cnn():
     _close(x.view(ntok, 50), ref.reshape(ntok, 50))
 
 
-@pytest.mark.parametrize("trans,tanh", [(True, True), (True, False), (False, False)])
-def test_image_features(trans, tanh):
+@pytest.mark.parametrize("trans,tanh,shape", [(True, True, (37, 157, 100, 45)), (True, False, (37, 157, 100, 45)),
+                                              (False, False, (37, 157, 157, 45)),
+                                              (True, True, (300, 2537, 100, 2560)),   # the metric shape (matrix-pipe kernels)
+                                              (True, True, (20, 61, 8, 33)),          # narrow: one column group
+                                              (True, False, (20, 61, 128, 19)),       # widest the matrix-pipe kernels take
+                                              (True, True, (20, 61, 30, 33))])        # tdim % 4 != 0: generic kernels
+def test_image_features(trans, tanh, shape):
     from fvta_memexqa_amd import ops
     from oracle import fvta_fused as F
     g = torch.Generator().manual_seed(11)
-    VI, idim, tdim, M = 37, 157, 100 if trans else 157, 45
+    VI, idim, tdim, M = shape
     feat = torch.randn(VI, idim, generator=g)
     W = (torch.randn(idim, tdim, generator=g) * 0.1).double().requires_grad_() if trans else None
     b = (torch.randn(tdim, generator=g) * 0.1).double().requires_grad_() if trans else None
