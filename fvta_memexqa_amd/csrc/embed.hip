@@ -360,6 +360,377 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_5x8(EmbArgs a) {
   for (int i = tid; i < d.VC * 8; i += EMB_NT) slab[40 * cw + cw + i] = s_dC[i];
 }
 
+// ---- the reference's shape on the matrix pipe: one WAVE per token ------------------------------------------------------
+// The register kernels above spend their time waiting (two to four workgroup barriers and an LDS read-modify-write chain
+// per token), not computing.  Here a wave owns a token from its ids to its gradients and never meets a workgroup barrier:
+//  * forward: Y[p][f] = sum_kc E[p*8 + kc] filt[kc][f] is a 16 x 40 x CW product on v_mfma_f32_16x16x4_f32 (an exact fmaf
+//    chain per output): rows = window positions (12 of 16 used), the filter fragments live in registers for the whole
+//    launch, the A operand is the token's character block read from LDS; max / first arg-max over the rows of an
+//    accumulator tile, then across the three lane groups that hold a column's rows;
+//  * backward: the scatter of each active filter's 5 x 8 weights to its arg-max window is the product
+//    T[p][kc] = sum_f G[p][f] filt[kc][f] with the one-hot G[p][f] = g_f [argpos_f == p] built on the fly from the staged
+//    gradient row (12 x more MACs than the scatter, no dependent LDS chain); dE[p*8 + kc] += T[p][kc] by LDS float adds whose
+//    addresses are distinct within an instruction and ordered between instructions (one wave, in-order LDS: a fixed
+//    order), then into the wave's own char-gradient table; d filt stays the sparse form (lane f: 40 FMAs against the
+//    window of ITS arg-max position).  Every wave writes its own slab; embed_bwd_reduce_kernel sums them in order.
+// Word part as in the register kernels.  Shape: height 5, cdim 8, W <= 16, cwdim == CW (a multiple of 4, <= 128).
+#ifndef FVTA_EMB_ABL
+#define FVTA_EMB_ABL 0  // timing ablations (tools/r03_build_abl.sh): 1 no MFMA, 2 no LDS adds / no arg-max epilogue, 4 no stores
+#endif
+template <int CW>
+struct Emb5x8 {
+  static constexpr int NW = 4;                    // waves per workgroup
+  static constexpr int NKS = CW / 4;              // backward: k-steps over the filters
+  static constexpr int GP = (NKS + 3) / 4 * 4;    // staged gradient row: run of one k phase (f & 3), padded to 16 bytes
+  static constexpr int NCF = (CW + 15) / 16;      // forward: column tiles over the filters
+  static_assert(CW % 4 == 0 && CW > 64 && CW <= 128 && GP <= 32, "cwdim of the matrix-pipe char-CNN kernels");
+};
+
+__device__ __forceinline__ void wave_lds_fence() {  // orders this wave's LDS traffic for the compiler (the unit is in-order)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void lds_fadd(float* p, float v) {  // ds_add_f32, no return value
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int CW>
+__global__ __launch_bounds__(256, 2) void embed_fwd_5x8_mfma(EmbArgs a) {
+  using C = Emb5x8<CW>;
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // char_emb [VC][8]
+  __shared__ __attribute__((aligned(16))) float s_E[C::NW][160], s_Y[C::NW][128];
+  __shared__ uint8_t s_A[C::NW][128];
+  const fvta_embed_desc& d = a.d;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int W = d.W, P = W - 4;
+  for (int i = threadIdx.x; i < d.VC * 8; i += 256) s_dyn[i] = a.char_emb[i];
+  float* E = s_E[wv];
+  if (lane < 32) E[128 + lane] = 0.f;  // rows 12..15 of the product read past the block
+  float Bf[10][C::NCF], bj[C::NCF];
+#pragma unroll
+  for (int ct = 0; ct < C::NCF; ++ct) {
+    const int f = 16 * ct + j;
+    bj[ct] = f < CW ? a.bias[f] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) Bf[ks][ct] = f < CW ? a.filt[(size_t)(4 * ks + q) * CW + f] : 0.f;
+  }
+  __syncthreads();
+  const int step = gridDim.x * C::NW;
+  const int pos = lane >> 3, c = lane & 7;
+  // Loads are branch-free (indices clamped, never predicated): in straight-line code the compiler counts the loads in
+  // flight exactly, so waiting for the oldest leaves the newer ones flying; behind branches it waits for all of them and
+  // every token pays a memory round trip.  Pipeline: ids of token i+2, word row of token i+1, product of token i.
+  const int posA = pos < W ? pos : W - 1, posB = pos + 8 < W ? pos + 8 : W - 1;
+  const int wl0 = lane < d.wdim ? lane : d.wdim - 1, wl1 = lane + 64 < d.wdim ? lane + 64 : d.wdim - 1;
+  auto load_ids = [&](int tok, int& cA, int& cB, int& wid, int64_t& off) {
+    const int t = tok < d.ntok ? tok : d.ntok - 1;
+    cA = a.char_ids[(size_t)t * W + posA];
+    cB = a.char_ids[(size_t)t * W + posB];
+    wid = a.word_ids[t];
+    off = a.tok_off[t];
+  };
+  auto word_src = [&](int wid) {
+    return wid < d.VW ? a.word_emb + (size_t)wid * d.wdim : a.fixed_emb + (size_t)(wid - d.VW) * d.wdim;
+  };
+  int tok = blockIdx.x * C::NW + wv;
+  int cA0, cB0, wid0, cA1, cB1, wid1, cA2, cB2, wid2;
+  int64_t off0, off1, off2;
+  float w0, w1, w0n, w1n;
+  load_ids(tok, cA0, cB0, wid0, off0);
+  load_ids(tok + step, cA1, cB1, wid1, off1);
+  w0 = word_src(wid0)[wl0];
+  w1 = word_src(wid0)[wl1];
+  for (; tok < d.ntok; tok += step) {
+    load_ids(tok + 2 * step, cA2, cB2, wid2, off2);
+    w0n = word_src(wid1)[wl0];
+    w1n = word_src(wid1)[wl1];
+    float* row = a.x + off0;
+    E[lane] = pos < W ? s_dyn[cA0 * 8 + c] * emb_ks(a, tok, lane, W * 8) : 0.f;
+    E[64 + lane] = pos + 8 < W ? s_dyn[cB0 * 8 + c] * emb_ks(a, tok, 64 + lane, W * 8) : 0.f;
+    wave_lds_fence();
+    f32x4 acc[C::NCF];
+#pragma unroll
+    for (int ct = 0; ct < C::NCF; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 10; ++ks) {
+      const float av = E[j * 8 + 4 * ks + q];
+#pragma unroll
+      for (int ct = 0; ct < C::NCF; ++ct) {
+        if constexpr (FVTA_EMB_ABL & 1) acc[ct][ks & 3] += av * Bf[ks][ct];
+        else acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bf[ks][ct], acc[ct], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < C::NCF; ++ct) {
+      float best = -INFINITY;
+      int bp = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = 4 * q + r;
+        if (p < P && acc[ct][r] > best) {  // first arg-max
+          best = acc[ct][r];
+          bp = p;
+        }
+      }
+      if constexpr (!(FVTA_EMB_ABL & 2)) {
+        // the rows of lane groups 1 and 2 (positions 4..7, 8..11) of this column, brought to group 0 by the row / half
+        // swaps of the vector pipe (no LDS traffic), folded in position order
+        const float v1 = __uint_as_float(__builtin_amdgcn_permlane16_swap(__float_as_uint(best), __float_as_uint(best), false, false)[1]);
+        const int p1 = (int)__builtin_amdgcn_permlane16_swap((unsigned)bp, (unsigned)bp, false, false)[1];
+        const float v2 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false)[1]);
+        const int p2 = (int)__builtin_amdgcn_permlane32_swap((unsigned)bp, (unsigned)bp, false, false)[1];
+        if (v1 > best) {
+          best = v1;
+          bp = p1;
+        }
+        if (v2 > best) {
+          best = v2;
+          bp = p2;
+        }
+      }
+      const int f = 16 * ct + j;
+      if (q == 0 && f < CW) {
+        const float y = best + bj[ct];
+        s_Y[wv][f] = y > 0.f ? y : 0.f;
+        s_A[wv][f] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
+      }
+    }
+    wave_lds_fence();
+    row[lane] = s_Y[wv][lane];
+    a.argpos[(size_t)tok * CW + lane] = s_A[wv][lane];
+    if (lane + 64 < CW) {
+      row[64 + lane] = s_Y[wv][64 + lane];
+      a.argpos[(size_t)tok * CW + 64 + lane] = s_A[wv][64 + lane];
+    }
+    if (lane < d.wdim) row[CW + lane] = w0;
+    if (lane + 64 < d.wdim) row[CW + 64 + lane] = w1;
+    if (d.wdim > 128) {
+      const float* src = word_src(wid0);
+      for (int i = lane + 128; i < d.wdim; i += 64) row[CW + i] = src[i];
+    }
+    wave_lds_fence();
+    cA0 = cA1; cB0 = cB1; wid0 = wid1; off0 = off1;
+    cA1 = cA2; cB1 = cB2; wid1 = wid2; off1 = off2;
+    w0 = w0n; w1 = w1n;
+  }
+}
+
+// backward, part 1 (matrix pipe): d char_emb.  Slab part [40 CW + CW ..) of this wave.
+template <int CW>
+__global__ __launch_bounds__(256, 2) void embed_bwd_5x8_char(EmbArgs a) {
+  using C = Emb5x8<CW>;
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // char_emb [VC][8], then dC [VC][8] per wave
+  __shared__ __attribute__((aligned(16))) float s_T[C::NW][40 * 16], s_G[C::NW][4 * C::GP];
+  __shared__ __attribute__((aligned(16))) uint8_t s_P[C::NW][4 * 32];
+  const fvta_embed_desc& d = a.d;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int W = d.W;
+  float* dC = s_dyn + (size_t)d.VC * 8 * wv;
+  for (int i = lane; i < d.VC * 8; i += 64) dC[i] = 0.f;
+  float* Tt = s_T[wv];
+  for (int i = lane; i < 4 * C::GP; i += 64) s_G[wv][i] = 0.f;
+  for (int i = lane; i < 128; i += 64) s_P[wv][i] = 255;
+  float Bf[C::NKS][3];
+#pragma unroll
+  for (int ct = 0; ct < 3; ++ct) {
+    const int kc = 16 * ct + j;
+#pragma unroll
+    for (int ks = 0; ks < C::NKS; ++ks) Bf[ks][ct] = kc < 40 ? a.filt[(size_t)kc * CW + 4 * ks + q] : 0.f;
+  }
+  const int step = gridDim.x * C::NW;
+  const int pos = lane >> 3, c = lane & 7;
+  const bool has2 = lane + 64 < CW;
+  // branch-free loads (see embed_fwd_5x8_mfma)
+  const int posA = pos < W ? pos : W - 1, posB = pos + 8 < W ? pos + 8 : W - 1;
+  const int lane2 = has2 ? 64 + lane : lane;
+  auto load_ids = [&](int tok, int& cA, int& cB, int64_t& off) {
+    const int t = tok < d.ntok ? tok : d.ntok - 1;
+    cA = a.char_ids[(size_t)t * W + posA];
+    cB = a.char_ids[(size_t)t * W + posB];
+    off = a.tok_off[t];
+  };
+  auto load_grad = [&](int tok, int64_t off, int& ap1, int& ap2, float& g1, float& g2) {
+    const int t = tok < d.ntok ? tok : d.ntok - 1;
+    const float* row = a.dx + off;
+    ap1 = a.argpos[(size_t)t * CW + lane];
+    const int b2 = a.argpos[(size_t)t * CW + lane2];
+    g1 = row[lane];
+    g2 = row[lane2];
+    ap2 = has2 ? b2 : 255;
+  };
+  int tok = blockIdx.x * C::NW + wv;
+  int cA0, cB0, cA1, cB1, cA2, cB2, ap1, ap2, ap1n, ap2n;
+  int64_t off0, off1, off2;
+  float g1, g2, g1n, g2n;
+  load_ids(tok, cA0, cB0, off0);
+  load_ids(tok + step, cA1, cB1, off1);
+  load_grad(tok, off0, ap1, ap2, g1, g2);
+  for (; tok < d.ntok; tok += step) {
+    load_ids(tok + 2 * step, cA2, cB2, off2);
+    load_grad(tok + step, off1, ap1n, ap2n, g1n, g2n);
+    // stage the gradient row in k-phase order (filter f at [(f & 3)][f >> 2])
+    s_G[wv][(lane & 3) * C::GP + (lane >> 2)] = ap1 == 255 ? 0.f : g1;
+    s_P[wv][(lane & 3) * 32 + (lane >> 2)] = (uint8_t)ap1;
+    if (has2) {
+      s_G[wv][(lane & 3) * C::GP + 16 + (lane >> 2)] = ap2 == 255 ? 0.f : g2;
+      s_P[wv][(lane & 3) * 32 + 16 + (lane >> 2)] = (uint8_t)ap2;
+    }
+    wave_lds_fence();
+    // T[p][kc] = sum_f G[p][f] filt[kc][f]: lane (p = j, k phase q) builds G from the staged row
+    uint32_t Pv[8];
+    {
+      const uint4 p0 = *reinterpret_cast<const uint4*>(&s_P[wv][q * 32]);
+      const uint4 p1 = *reinterpret_cast<const uint4*>(&s_P[wv][q * 32 + 16]);
+      Pv[0] = p0.x; Pv[1] = p0.y; Pv[2] = p0.z; Pv[3] = p0.w;
+      Pv[4] = p1.x; Pv[5] = p1.y; Pv[6] = p1.z; Pv[7] = p1.w;
+    }
+    f32x4 accT[3];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) accT[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < C::GP / 4; ++v) {
+      const f32x4 Gv = *reinterpret_cast<const f32x4*>(&s_G[wv][q * C::GP + 4 * v]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ks = 4 * v + i;
+        if (ks < C::NKS) {
+          const int pb = (int)((Pv[v] >> (8 * i)) & 255u);
+          const float av = pb == j ? Gv[i] : 0.f;
+#pragma unroll
+          for (int ct = 0; ct < 3; ++ct) {
+            if constexpr (FVTA_EMB_ABL & 1) accT[ct][ks & 3] += av * Bf[ks][ct];
+            else accT[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bf[ks][ct], accT[ct], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // T -> LDS as [kc][p] (a lane's four rows p = 4 q + r are one 16-byte store; rows 12..15 are zero: no arg-max there),
+    // then dE[pos][c] = sum_k T[pos - k][8 k + c] by the lane of (pos, c): plain stores and loads, no LDS atomics
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct)
+      if (16 * ct + j < 40) *reinterpret_cast<f32x4*>(&Tt[(16 * ct + j) * 16 + 4 * q]) = accT[ct];
+    wave_lds_fence();
+    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float t0 = Tt[(8 * k + c) * 16 + (pos >= k ? pos - k : 0)];
+      const float t1 = Tt[(8 * k + c) * 16 + pos + 8 - k];
+      v0 += pos >= k ? t0 : 0.f;
+      v1 += t1;
+    }
+    v0 *= emb_ks(a, tok, lane, W * 8);
+    v1 *= emb_ks(a, tok, 64 + lane, W * 8);
+    // into the wave's char table; positions of one character meet inside the instruction (the LDS unit serialises them)
+    if (pos < W) lds_fadd(&dC[cA0 * 8 + c], v0);
+    if (pos + 8 < W) lds_fadd(&dC[cB0 * 8 + c], v1);
+    wave_lds_fence();
+    cA0 = cA1; cB0 = cB1; off0 = off1;
+    cA1 = cA2; cB1 = cB2; off1 = off2;
+    ap1 = ap1n; ap2 = ap2n; g1 = g1n; g2 = g2n;
+  }
+  float* slab = a.slab + (size_t)(blockIdx.x * C::NW + wv) * (40 * CW + CW + d.VC * 8);
+  wave_lds_fence();
+  for (int i = lane; i < d.VC * 8; i += 64) slab[40 * CW + CW + i] = dC[i];
+}
+
+// backward, part 2 (sparse form, vector pipe): d filt, d bias -- lane l owns filters l and 64 + l -- and the word rows.
+// Slab part [0, 40 CW + CW) of this wave.
+template <int CW>
+__global__ __launch_bounds__(256, 2) void embed_bwd_5x8_filt(EmbArgs a) {
+  using C = Emb5x8<CW>;
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // char_emb [VC][8]
+  __shared__ __attribute__((aligned(16))) float s_E[C::NW][160];
+  const fvta_embed_desc& d = a.d;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int W = d.W;
+  for (int i = threadIdx.x; i < d.VC * 8; i += 256) s_dyn[i] = a.char_emb[i];
+  float* E = s_E[wv];
+  if (lane < 32) E[128 + lane] = 0.f;  // a window read may run 4 positions past W - 5 + 4
+  float acc1[40], acc2[40];
+#pragma unroll
+  for (int i = 0; i < 40; ++i) acc1[i] = acc2[i] = 0.f;
+  float accb1 = 0.f, accb2 = 0.f;
+  __syncthreads();
+  const int step = gridDim.x * C::NW;
+  const int pos = lane >> 3, c = lane & 7;
+  const bool has2 = lane + 64 < CW;
+  // branch-free loads (see embed_fwd_5x8_mfma)
+  const int posA = pos < W ? pos : W - 1, posB = pos + 8 < W ? pos + 8 : W - 1;
+  const int lane2 = has2 ? 64 + lane : lane;
+  const int wl0 = lane < d.wdim ? lane : d.wdim - 1, wl1 = lane + 64 < d.wdim ? lane + 64 : d.wdim - 1;
+  auto load_ids = [&](int tok, int& cA, int& cB, int& wid, int64_t& off) {
+    const int t = tok < d.ntok ? tok : d.ntok - 1;
+    cA = a.char_ids[(size_t)t * W + posA];
+    cB = a.char_ids[(size_t)t * W + posB];
+    wid = a.word_ids[t];
+    off = a.tok_off[t];
+  };
+  auto load_grad = [&](int tok, int64_t off, int& ap1, int& ap2, float& g1, float& g2, float& w0, float& w1) {
+    const int t = tok < d.ntok ? tok : d.ntok - 1;
+    const float* row = a.dx + off;
+    ap1 = a.argpos[(size_t)t * CW + lane];
+    const int b2 = a.argpos[(size_t)t * CW + lane2];
+    g1 = row[lane];
+    g2 = row[lane2];
+    w0 = row[CW + wl0];
+    w1 = row[CW + wl1];
+    ap2 = has2 ? b2 : 255;
+  };
+  int tok = blockIdx.x * C::NW + wv;
+  int cA0, cB0, wid0, cA1, cB1, wid1, cA2, cB2, wid2, ap1, ap2, ap1n, ap2n;
+  int64_t off0, off1, off2;
+  float g1, g2, w0, w1, g1n, g2n, w0n, w1n;
+  load_ids(tok, cA0, cB0, wid0, off0);
+  load_ids(tok + step, cA1, cB1, wid1, off1);
+  load_grad(tok, off0, ap1, ap2, g1, g2, w0, w1);
+  for (; tok < d.ntok; tok += step) {
+    load_ids(tok + 2 * step, cA2, cB2, wid2, off2);
+    load_grad(tok + step, off1, ap1n, ap2n, g1n, g2n, w0n, w1n);
+    if (wid0 < d.VW) {
+      float* dst = a.d_word_emb + (size_t)wid0 * d.wdim;
+      if (lane < d.wdim) atomicAdd(dst + lane, w0);
+      if (lane + 64 < d.wdim) atomicAdd(dst + lane + 64, w1);
+      for (int i = lane + 128; i < d.wdim; i += 64) atomicAdd(dst + i, a.dx[off0 + CW + i]);
+    }
+    E[lane] = pos < W ? s_dyn[cA0 * 8 + c] * emb_ks(a, tok, lane, W * 8) : 0.f;
+    E[64 + lane] = pos + 8 < W ? s_dyn[cB0 * 8 + c] * emb_ks(a, tok, 64 + lane, W * 8) : 0.f;
+    wave_lds_fence();
+    {  // d filt[:, :, f] += g_f * window(argpos_f) (40 contiguous values); inactive filters carry g = 0
+      if (ap1 == 255) g1 = 0.f;
+      if (ap2 == 255) g2 = 0.f;
+      const float* e1 = E + (ap1 == 255 ? 0 : ap1) * 8;
+      const float* e2 = E + (ap2 == 255 ? 0 : ap2) * 8;
+      accb1 += g1;
+      accb2 += g2;
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(e1 + 4 * i);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(e2 + 4 * i);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          acc1[4 * i + cc] += g1 * v1[cc];
+          acc2[4 * i + cc] += g2 * v2[cc];
+        }
+      }
+    }
+    wave_lds_fence();
+    cA0 = cA1; cB0 = cB1; wid0 = wid1; off0 = off1;
+    cA1 = cA2; cB1 = cB2; wid1 = wid2; off1 = off2;
+    ap1 = ap1n; ap2 = ap2n; g1 = g1n; g2 = g2n; w0 = w0n; w1 = w1n;
+  }
+  float* slab = a.slab + (size_t)(blockIdx.x * C::NW + wv) * (40 * CW + CW + d.VC * 8);
+#pragma unroll
+  for (int i = 0; i < 40; ++i) {
+    slab[(size_t)i * CW + lane] = acc1[i];
+    if (has2) slab[(size_t)i * CW + 64 + lane] = acc2[i];
+  }
+  slab[40 * CW + lane] = accb1;
+  if (has2) slab[40 * CW + 64 + lane] = accb2;
+}
+
 // ---- general shape (any height * cdim, e.g. README.MD:144's --char_emb_size 100: a 500-deep window) ------------
 // Correct and order-fixed, not fast: the filter does not fit registers or LDS, so it is streamed from L2
 // (coalesced over the filter index) and the workgroup's filter-gradient slab is accumulated in global memory by
@@ -687,21 +1058,27 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_big(EmbArgs a) {
   }
 }
 
-// slabs -> d_filt, d_bias, d_char_emb (accumulate), fixed order over workgroups
-// 256 threads = 64 elements x 4 slab groups (group g sums slabs g, g+4, ...; the four partials combine in order)
-__global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float* __restrict__ slab, int nblk, int nfb, int nchar,
-                                                               float* __restrict__ d_filt, float* __restrict__ d_bias,
-                                                               int nfilt, float* __restrict__ d_char) {
-  __shared__ float s_part[4][64];
+// slabs -> d_filt, d_bias, d_char_emb (accumulate), fixed order over slabs
+// 1024 threads = 64 elements x 16 slab groups (group g sums slabs g, g+16, ...; the partials combine pairwise in order)
+constexpr int EMB_RED_G = 16;
+__global__ __launch_bounds__(64 * EMB_RED_G) void embed_bwd_reduce_kernel(const float* __restrict__ slab, int nblk, int nfb,
+                                                                         int nchar, float* __restrict__ d_filt,
+                                                                         float* __restrict__ d_bias, int nfilt,
+                                                                         float* __restrict__ d_char) {
+  __shared__ float s_part[EMB_RED_G][64];
   const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + el, per = nfb + nchar;
   float part = 0.f;
   if (i < per)
-    for (int b = grp; b < nblk; b += 4) part += slab[(size_t)b * per + i];
+    for (int b = grp; b < nblk; b += EMB_RED_G) part += slab[(size_t)b * per + i];
   s_part[grp][el] = part;
   __syncthreads();
+  for (int w = EMB_RED_G / 2; w >= 1; w >>= 1) {
+    if (grp < w) s_part[grp][el] += s_part[grp + w][el];
+    __syncthreads();
+  }
   if (grp != 0 || i >= per) return;
-  const float v = (s_part[0][el] + s_part[1][el]) + (s_part[2][el] + s_part[3][el]);
+  const float v = s_part[0][el];
   if (i < nfilt) d_filt[i] += v;
   else if (i < nfb) d_bias[i - nfilt] += v;
   else d_char[i - nfb] += v;
@@ -960,6 +1337,9 @@ __global__ __launch_bounds__(64 * IMG_NW) void img_dw_mfma(fvta_imgtrans_desc d,
   }
 }
 
+template __global__ void embed_fwd_5x8_mfma<100>(EmbArgs);
+template __global__ void embed_bwd_5x8_char<100>(EmbArgs);
+template __global__ void embed_bwd_5x8_filt<100>(EmbArgs);
 }  // namespace fvta
 using namespace fvta;
 
@@ -986,6 +1366,12 @@ static bool embed_mfma_ok(const fvta_embed_desc* d) {  // shapes the matrix-pipe
     return e && e[0] == '0';
   }();
   return !off && d->W <= 16 && d->cdim % 4 == 0 && d->cwdim % 4 == 0 && d->cwdim <= 128;
+}
+
+// the reference's default shape (height 5, char_emb 8, 100 filters): wave-per-token kernels on the matrix pipe
+constexpr int EMB_WAVE_FWD_BLOCKS = 768;
+static bool embed_wave_ok(const fvta_embed_desc* d) {
+  return d->cwdim == 100 && d->height == 5 && d->cdim == 8 && d->W <= 16 && d->VC <= 256;
 }
 
 static size_t embed_slab_floats(const fvta_embed_desc* d) {
@@ -1027,6 +1413,9 @@ extern "C" int fvta_embed_fwd(const fvta_embed_desc* d, const int32_t* word_ids,
   } else if (embed_is_big(d)) {
     const size_t dyn = (size_t)d->W * d->cdim * sizeof(float);
     hipLaunchKernelGGL(embed_fwd_kernel_big, dim3(blocks), dim3(EMB_NT), dyn, (hipStream_t)stream_, a);
+  } else if (embed_wave_ok(d)) {
+    const int nb = (d->ntok + 3) / 4 < EMB_WAVE_FWD_BLOCKS ? (d->ntok + 3) / 4 : EMB_WAVE_FWD_BLOCKS;
+    hipLaunchKernelGGL(embed_fwd_5x8_mfma<100>, dim3(nb), dim3(256), (size_t)d->VC * 8 * sizeof(float), (hipStream_t)stream_, a);
   } else if (d->cwdim > 0 && d->height == 5 && d->cdim == 8 && d->W <= 16)
     hipLaunchKernelGGL(embed_fwd_kernel_5x8, dim3(blocks), dim3(EMB_NT), 0, (hipStream_t)stream_, a);
   else
@@ -1069,6 +1458,13 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel_big),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     hipLaunchKernelGGL(embed_bwd_kernel_big, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
+  } else if (embed_wave_ok(d)) {
+    // one slab per WAVE: 4 * blocks <= EMB_BWD_BLOCKS slabs
+    blocks = (d->ntok + 3) / 4 < EMB_BWD_BLOCKS / 4 ? (d->ntok + 3) / 4 : EMB_BWD_BLOCKS / 4;
+    const size_t tab = (size_t)d->VC * 8 * sizeof(float);
+    hipLaunchKernelGGL(embed_bwd_5x8_filt<100>, dim3(blocks), dim3(256), tab, stream, a);
+    hipLaunchKernelGGL(embed_bwd_5x8_char<100>, dim3(blocks), dim3(256), 4 * tab, stream, a);
+    blocks *= 4;
   } else {
     const bool k5x8 = d->cwdim > 0 && d->height == 5 && d->cdim == 8 && d->W <= 16;
     const size_t dyn = ((size_t)d->height * d->cdim * d->cwdim + (size_t)(k5x8 ? 2 : 1) * d->VC * d->cdim) * sizeof(float);
@@ -1093,7 +1489,7 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
   }
   if (d->cwdim > 0) {
     const int nfilt = d->height * d->cdim * d->cwdim, nfb = nfilt + d->cwdim, nchar = d->VC * d->cdim;
-    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((nfb + nchar + 63) / 64), dim3(256), 0, stream,
+    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((nfb + nchar + 63) / 64), dim3(64 * EMB_RED_G), 0, stream,
                        (const float*)workspace, blocks, nfb, nchar, d_filt, d_bias, nfilt, d_char_emb);
   }
   FVTA_CHECK_LAUNCH("embed_bwd");

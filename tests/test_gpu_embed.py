@@ -26,7 +26,9 @@ def _case(seed, B, J, W, cd, cw, wd, VW, VF, VC):
 @pytest.mark.parametrize("B,J,W,cd,cw,wd,VW,VF,VC", [(3, 7, 16, 8, 100, 100, 50, 30, 40), (5, 4, 9, 4, 24, 300, 7, 5, 11),
                                                       (64, 30, 16, 8, 100, 100, 500, 2000, 97),
                                                       (4, 6, 16, 100, 100, 100, 20, 30, 60),   # README.MD:144 flags
-                                                      (3, 5, 21, 8, 64, 50, 9, 9, 20)])         # W > 16: general kernels
+                                                      (3, 5, 21, 8, 64, 50, 9, 9, 20),          # W > 16: general kernels
+                                                      (7, 9, 9, 8, 100, 60, 30, 20, 50),        # short words, 100 filters
+                                                      (33, 30, 16, 8, 100, 100, 40, 2000, 256)])
 def test_token_embed_forward_backward(B, J, W, cd, cw, wd, VW, VF, VC):
     from fvta_memexqa_amd import ops
     from oracle import fvta_fused as F
@@ -63,7 +65,8 @@ def test_token_embed_forward_backward(B, J, W, cd, cw, wd, VW, VF, VC):
 @pytest.mark.parametrize("B,J,W,cd,cw,wd,VW,VF,VC", [(3, 7, 16, 8, 100, 100, 50, 30, 40),    # the 5 x 8 register kernels
                                                       (5, 4, 9, 4, 24, 300, 7, 5, 11),        # generic kernels
                                                       (4, 6, 16, 100, 100, 100, 20, 30, 60),  # wide: sparse backward pair
-                                                      (3, 5, 21, 8, 64, 50, 9, 9, 20)])       # W > 16
+                                                      (3, 5, 21, 8, 64, 50, 9, 9, 20),        # W > 16
+                                                      (7, 9, 9, 8, 100, 60, 30, 20, 50)])     # short words, 100 filters
 def test_token_embed_char_dropout(B, J, W, cd, cw, wd, VW, VF, VC):
     """conv1d's dropout of the gathered char embeddings while training (model_v2.py:58-62): forward rows and every
     gradient against the oracle run with the same keep mask (the library's hash, oracle dropout_keep_flat)."""
