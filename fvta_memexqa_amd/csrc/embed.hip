@@ -14,7 +14,7 @@ constexpr int EMB_MAXKC = 64;     // height * cdim of the register-resident kern
 constexpr int EMB_MAXWC = 1024;   // W * cdim of the register-resident kernels
 constexpr int EMB_BIG_WC = 8192;  // W * cdim of the general kernels (the published flag set: char_emb_size 100)
 constexpr int EMB_MAXVC = 1024;   // char vocabulary (backward's per-workgroup table)
-constexpr int EMB_BWD_BLOCKS = 2048;
+constexpr int EMB_BWD_BLOCKS = 2048;  // slabs of the backward workspace (one per workgroup, or per wave of the wave-per-token kernels)
 
 struct EmbArgs {
   fvta_embed_desc d;
@@ -396,23 +396,23 @@ __device__ __forceinline__ void lds_fadd(float* p, float v) {  // ds_add_f32, no
 }
 
 template <int CW>
-__global__ __launch_bounds__(256, 2) void embed_fwd_5x8_mfma(EmbArgs a) {
+__global__ __launch_bounds__(256, 3) void embed_fwd_5x8_mfma(EmbArgs a) {
   using C = Emb5x8<CW>;
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // char_emb [VC][8]
   __shared__ __attribute__((aligned(16))) float s_E[C::NW][160], s_Y[C::NW][128];
   __shared__ uint8_t s_A[C::NW][128];
+  __shared__ float s_bias[128];
   const fvta_embed_desc& d = a.d;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int W = d.W, P = W - 4;
   for (int i = threadIdx.x; i < d.VC * 8; i += 256) s_dyn[i] = a.char_emb[i];
-  float* E = s_E[wv];
-  if (lane < 32) E[128 + lane] = 0.f;  // rows 12..15 of the product read past the block
-  float Bf[10][C::NCF], bj[C::NCF];
+  if (lane < 32) s_E[wv][128 + lane] = 0.f;  // rows 12..15 of the product read past the block
+  if (threadIdx.x < 128) s_bias[threadIdx.x] = threadIdx.x < CW ? a.bias[threadIdx.x] : 0.f;
+  float Bf[10][C::NCF];
 #pragma unroll
   for (int ct = 0; ct < C::NCF; ++ct) {
     const int f = 16 * ct + j;
-    bj[ct] = f < CW ? a.bias[f] : 0.f;
 #pragma unroll
     for (int ks = 0; ks < 10; ++ks) Bf[ks][ct] = f < CW ? a.filt[(size_t)(4 * ks + q) * CW + f] : 0.f;
   }
@@ -421,7 +421,10 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_5x8_mfma(EmbArgs a) {
   const int pos = lane >> 3, c = lane & 7;
   // Loads are branch-free (indices clamped, never predicated): in straight-line code the compiler counts the loads in
   // flight exactly, so waiting for the oldest leaves the newer ones flying; behind branches it waits for all of them and
-  // every token pays a memory round trip.  Pipeline: ids of token i+2, word row of token i+1, product of token i.
+  // every token pays a memory round trip.  Pipeline: ids of token i+2, word row and product of token i.
+  // (The fp32 MFMA runs at the vector pipe's fp32 rate and does not overlap vector work -- neither another wave's nor,
+  // interleaved by sched_group_barrier, this wave's: measured, the product's and the arg-max's times add up.  So the
+  // kernel is kept short and at three waves per SIMD.)
   const int posA = pos < W ? pos : W - 1, posB = pos + 8 < W ? pos + 8 : W - 1;
   const int wl0 = lane < d.wdim ? lane : d.wdim - 1, wl1 = lane + 64 < d.wdim ? lane + 64 : d.wdim - 1;
   auto load_ids = [&](int tok, int& cA, int& cB, int& wid, int64_t& off) {
@@ -434,23 +437,11 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_5x8_mfma(EmbArgs a) {
   auto word_src = [&](int wid) {
     return wid < d.VW ? a.word_emb + (size_t)wid * d.wdim : a.fixed_emb + (size_t)(wid - d.VW) * d.wdim;
   };
-  int tok = blockIdx.x * C::NW + wv;
-  int cA0, cB0, wid0, cA1, cB1, wid1, cA2, cB2, wid2;
-  int64_t off0, off1, off2;
-  float w0, w1, w0n, w1n;
-  load_ids(tok, cA0, cB0, wid0, off0);
-  load_ids(tok + step, cA1, cB1, wid1, off1);
-  w0 = word_src(wid0)[wl0];
-  w1 = word_src(wid0)[wl1];
-  for (; tok < d.ntok; tok += step) {
-    load_ids(tok + 2 * step, cA2, cB2, wid2, off2);
-    w0n = word_src(wid1)[wl0];
-    w1n = word_src(wid1)[wl1];
-    float* row = a.x + off0;
-    E[lane] = pos < W ? s_dyn[cA0 * 8 + c] * emb_ks(a, tok, lane, W * 8) : 0.f;
-    E[64 + lane] = pos + 8 < W ? s_dyn[cB0 * 8 + c] * emb_ks(a, tok, 64 + lane, W * 8) : 0.f;
-    wave_lds_fence();
-    f32x4 acc[C::NCF];
+  auto stage = [&](float* E, int tok, int cA, int cB) {
+    E[lane] = pos < W ? s_dyn[cA * 8 + c] * emb_ks(a, tok, lane, W * 8) : 0.f;
+    E[64 + lane] = pos + 8 < W ? s_dyn[cB * 8 + c] * emb_ks(a, tok, 64 + lane, W * 8) : 0.f;
+  };
+  auto product = [&](const float* E, f32x4 (&acc)[C::NCF]) {
 #pragma unroll
     for (int ct = 0; ct < C::NCF; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -462,17 +453,21 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_5x8_mfma(EmbArgs a) {
         else acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bf[ks][ct], acc[ct], 0, 0, 0);
       }
     }
+  };
+  // max / first arg-max over the window positions of every filter -> s_Y / s_A (branch-free: lanes without a result
+  // write a spare slot)
+  auto argmax = [&](const f32x4 (&acc)[C::NCF]) {
 #pragma unroll
-    for (int ct = 0; ct < C::NCF; ++ct) {
+    for (int ct = 0; ct < ((FVTA_EMB_ABL & 4) ? 0 : C::NCF); ++ct) {
       float best = -INFINITY;
       int bp = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int p = 4 * q + r;
-        if (p < P && acc[ct][r] > best) {  // first arg-max
-          best = acc[ct][r];
-          bp = p;
-        }
+        const float v = p < P ? acc[ct][r] : -INFINITY;
+        const bool up = v > best;  // first arg-max
+        best = up ? v : best;
+        bp = up ? p : bp;
       }
       if constexpr (!(FVTA_EMB_ABL & 2)) {
         // the rows of lane groups 1 and 2 (positions 4..7, 8..11) of this column, brought to group 0 by the row / half
@@ -481,23 +476,28 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_5x8_mfma(EmbArgs a) {
         const int p1 = (int)__builtin_amdgcn_permlane16_swap((unsigned)bp, (unsigned)bp, false, false)[1];
         const float v2 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false)[1]);
         const int p2 = (int)__builtin_amdgcn_permlane32_swap((unsigned)bp, (unsigned)bp, false, false)[1];
-        if (v1 > best) {
-          best = v1;
-          bp = p1;
-        }
-        if (v2 > best) {
-          best = v2;
-          bp = p2;
-        }
+        const bool u1 = v1 > best;
+        best = u1 ? v1 : best;
+        bp = u1 ? p1 : bp;
+        const bool u2 = v2 > best;
+        best = u2 ? v2 : best;
+        bp = u2 ? p2 : bp;
       }
       const int f = 16 * ct + j;
-      if (q == 0 && f < CW) {
-        const float y = best + bj[ct];
-        s_Y[wv][f] = y > 0.f ? y : 0.f;
-        s_A[wv][f] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
-      }
+      const int slot = (q == 0 && f < CW) ? f : 112 + j;
+      const float y = best + s_bias[16 * ct + j];
+      s_Y[wv][slot] = y > 0.f ? y : 0.f;
+      s_A[wv][slot] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
     }
-    wave_lds_fence();
+    if constexpr (FVTA_EMB_ABL & 4) {
+      float t = 0.f;
+#pragma unroll
+      for (int ct = 0; ct < C::NCF; ++ct) t += acc[ct][0] + acc[ct][1] + acc[ct][2] + acc[ct][3];
+      s_Y[wv][lane] = t;
+    }
+  };
+  auto flush = [&](int tok, int64_t off, int wid, float w0, float w1) {
+    float* row = a.x + off;
     row[lane] = s_Y[wv][lane];
     a.argpos[(size_t)tok * CW + lane] = s_A[wv][lane];
     if (lane + 64 < CW) {
@@ -507,19 +507,34 @@ __global__ __launch_bounds__(256, 2) void embed_fwd_5x8_mfma(EmbArgs a) {
     if (lane < d.wdim) row[CW + lane] = w0;
     if (lane + 64 < d.wdim) row[CW + 64 + lane] = w1;
     if (d.wdim > 128) {
-      const float* src = word_src(wid0);
+      const float* src = word_src(wid);
       for (int i = lane + 128; i < d.wdim; i += 64) row[CW + i] = src[i];
     }
+  };
+  int tok = blockIdx.x * C::NW + wv;
+  int cA0, cB0, wid0, cA1, cB1, wid1, cA2, cB2, wid2;
+  int64_t off0, off1, off2;
+  load_ids(tok, cA0, cB0, wid0, off0);
+  load_ids(tok + step, cA1, cB1, wid1, off1);
+  for (; tok < d.ntok; tok += step) {
+    load_ids(tok + 2 * step, cA2, cB2, wid2, off2);
+    const float w0 = word_src(wid0)[wl0], w1 = word_src(wid0)[wl1];  // stored after the product
+    stage(s_E[wv], tok, cA0, cB0);
+    wave_lds_fence();
+    f32x4 acc[C::NCF];
+    product(s_E[wv], acc);
+    argmax(acc);
+    wave_lds_fence();
+    flush(tok, off0, wid0, w0, w1);
     wave_lds_fence();
     cA0 = cA1; cB0 = cB1; wid0 = wid1; off0 = off1;
     cA1 = cA2; cB1 = cB2; wid1 = wid2; off1 = off2;
-    w0 = w0n; w1 = w1n;
   }
 }
 
 // backward, part 1 (matrix pipe): d char_emb.  Slab part [40 CW + CW ..) of this wave.
 template <int CW>
-__global__ __launch_bounds__(256, 2) void embed_bwd_5x8_char(EmbArgs a) {
+__global__ __launch_bounds__(256, 3) void embed_bwd_5x8_char(EmbArgs a) {
   using C = Emb5x8<CW>;
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // char_emb [VC][8], then dC [VC][8] per wave
   __shared__ __attribute__((aligned(16))) float s_T[C::NW][40 * 16], s_G[C::NW][4 * C::GP];

@@ -1,7 +1,5 @@
 cd /root/repo
 export PYTHONPATH=/root/repo
-timeout 600 python -m pytest tests/test_gpu_embed.py -x -q 2>&1 | tail -5
-timeout 200 python tools/r03_frontend_ab.py 10 2>&1 | grep "embed" | sed 's/^/product: /'
-for b in 1; do
-FVTA_LIB_PATH=$PWD/fvta_memexqa_amd/csrc/diag/libfvta_hip_embed_abl$b.so timeout 200 python tools/r03_frontend_ab.py 10 2>&1 | grep "embed" | sed "s/^/abl $b: /"
-done
+timeout 900 python -m pytest tests/test_gpu_embed.py tests/test_gpu_model.py tests/test_gpu_feed.py -x -q 2>&1 | tail -5
+timeout 300 python bench.py --front-end 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['kernel_ms_per_step'])"
+timeout 300 python bench.py 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['kernel_ms_per_step'])"
