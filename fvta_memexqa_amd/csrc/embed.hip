@@ -1368,9 +1368,6 @@ static int check_embed(const fvta_embed_desc* d) {
   return FVTA_OK;
 }
 
-#ifndef FVTA_EMBED_MFMA_SMALL_DEFAULT
-#define FVTA_EMBED_MFMA_SMALL_DEFAULT 0
-#endif
 static bool embed_is_big(const fvta_embed_desc* d) {
   return d->cwdim > 0 && (d->height * d->cdim > EMB_MAXKC || d->W * d->cdim > EMB_MAXWC);
 }
@@ -1415,14 +1412,8 @@ extern "C" int fvta_embed_fwd(const fvta_embed_desc* d, const int32_t* word_ids,
   a.x = x; a.argpos = argpos;
   emb_set_dropout(a, d);
   const int blocks = d->ntok < 8192 ? d->ntok : 8192;
-  // FVTA_EMBED_MFMA_SMALL=1: the reference's default shape (height 5 x char_emb 8: a 40-deep window) on the matrix-pipe
-  // kernel too, instead of the register kernel (measurement switch)
-  static const bool small_mfma = [] {
-    const char* e = getenv("FVTA_EMBED_MFMA_SMALL");
-    return e ? e[0] == '1' : (FVTA_EMBED_MFMA_SMALL_DEFAULT != 0);
-  }();
   // (with dropout the matrix-pipe kernel, which gathers its A operand straight from the character table, is not used)
-  if (embed_mfma_ok(d) && d->cwdim > 0 && (embed_is_big(d) || small_mfma) && a.drop_thr == 0ull) {
+  if (embed_mfma_ok(d) && d->cwdim > 0 && embed_is_big(d) && a.drop_thr == 0ull) {
     hipLaunchKernelGGL(embed_fwd_kernel_mfma, dim3((d->ntok + 7) / 8), dim3(256), MmaEmb::LDS_FLOATS * sizeof(float),
                        (hipStream_t)stream_, a);
   } else if (embed_is_big(d)) {
