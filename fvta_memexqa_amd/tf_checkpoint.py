@@ -79,7 +79,7 @@ def _signed(v):
 
 
 def _parse_entry(buf):
-    e = dict(dtype=0, shape=[], shard_id=0, offset=0, size=0, crc32c=None)
+    e = dict(dtype=0, shape=[], shard_id=0, offset=0, size=0, crc32c=None, slices=0)
     for f, _, v in _proto_fields(buf):
         if f == 1:
             e["dtype"] = v
@@ -99,6 +99,8 @@ def _parse_entry(buf):
             e["size"] = v
         elif f == 6:
             e["crc32c"] = v
+        elif f == 7:                                   # repeated TensorSliceProto: a partitioned variable
+            e["slices"] += 1
     return e
 
 
@@ -134,6 +136,8 @@ def _read_block(f, offset, size):
         raise ValueError("truncated table block")
     if raw[size] != 0:
         raise ValueError("compressed table block (type %d): TensorFlow writes checkpoints uncompressed" % raw[size])
+    if struct.unpack_from("<I", raw, size + 1)[0] != _mask(crc32c(raw[:size + 1])):    # block + type byte, masked
+        raise ValueError("table block at offset %d fails its crc32c" % offset)
     return raw[:size]
 
 
@@ -196,9 +200,10 @@ def latest_checkpoint(path):
     return path[:-6] if path.endswith(".index") else path
 
 
-def read_checkpoint(path, names=None):
+def read_checkpoint(path, names=None, verify=True):
     """{variable name: ndarray} of a V2 checkpoint (`path`: directory with a `checkpoint` state file, a prefix, or the
-    .index file).  `names`: read only these."""
+    .index file).  `names`: read only these.  `verify`: check every tensor's masked crc32c (the index blocks' are always
+    checked); entries that carry slices (partitioned variables: the reference saves none) are rejected."""
     prefix = latest_checkpoint(path)
     if not os.path.exists(prefix + ".index"):
         raise Exception("Model not exists")                                      # main.py:665
@@ -211,6 +216,8 @@ def read_checkpoint(path, names=None):
                 continue
             if e["dtype"] not in _DTYPES:
                 continue                                # strings etc.: nothing the model stores
+            if e["slices"]:
+                raise ValueError("%s is stored in slices (a partitioned variable): not supported" % name)
             sid = e["shard_id"]
             if sid not in files:
                 files[sid] = open("%s.data-%05d-of-%05d" % (prefix, sid, nshards), "rb")
@@ -219,6 +226,8 @@ def read_checkpoint(path, names=None):
             raw = f.read(e["size"])
             if len(raw) != e["size"]:
                 raise ValueError("truncated tensor data for %s" % name)
+            if verify and e["crc32c"] is not None and e["crc32c"] != _mask(crc32c(raw)):
+                raise ValueError("tensor data of %s fails its crc32c" % name)
             out[name] = np.frombuffer(raw, dtype=np.dtype(_DTYPES[e["dtype"]]).newbyteorder("<")).reshape(e["shape"]).copy()
     finally:
         for f in files.values():

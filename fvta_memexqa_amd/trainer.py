@@ -131,7 +131,7 @@ class Trainer:
         m = self.model
         slots = m.load_tf_checkpoint(path)
         state = (torch.zeros_like(m.params.flat), torch.zeros_like(m.params.flat))
-        found = 0
+        found, partial = 0, []
         for slot, flat in zip(self.opt.SLOTS, state):
             named = {}
             for key, val in slots.get(slot, {}).items():
@@ -142,8 +142,23 @@ class Trainer:
             if len(named) == len(m.params.specs):
                 m.set_weights(named, flat=flat)
                 found += 1
+            elif named:
+                partial.append("%s (%d of %d variables)" % (slot, len(named), len(m.params.specs)))
+        # all slots -> resume; none -> a weights-only file, the optimiser starts fresh (returns False); anything in
+        # between is a file written for another model or another optimiser: refuse rather than resume half a state
+        if partial or 0 < found < len(self.opt.SLOTS):
+            raise KeyError("checkpoint %s holds part of this optimiser's state only: %s" %
+                           (path, ", ".join(partial) or "%d of %d slots" % (found, len(self.opt.SLOTS))))
         if found == len(self.opt.SLOTS):
             self.opt.state = state
             if hasattr(self.opt, "t"):
                 self.opt.t = m.global_step           # beta powers = beta ** global_step (one apply per step)
+                b1p = slots.get("beta1_power", {}).get("")
+                if b1p is not None and 0.0 < float(b1p) < 1.0:
+                    import math
+                    t = int(round(math.log(float(b1p)) / math.log(self.opt.b1)))    # AdamOptimizer's own count
+                    if abs(self.opt.b1 ** t - float(b1p)) > 1e-3 * float(b1p):
+                        raise ValueError("checkpoint %s: beta1_power %g is not a power of beta1 = %g" %
+                                         (path, float(b1p), self.opt.b1))
+                    self.opt.t = t
         return found == len(self.opt.SLOTS)

@@ -103,3 +103,30 @@ def test_tf_checkpoint_reader_round_trip(tmp_path):
     for missing in (str(tmp_path / "empty"), str(tmp_path / "model-999")):
         with pytest.raises(Exception, match="Model not exists"):
             tc.read_checkpoint(missing)
+
+
+def test_tf_checkpoint_reader_rejects_corruption(tmp_path):
+    """Every table block and every tensor carries a masked crc32c (LevelDB block trailer; BundleEntryProto field 6): a
+    flipped byte in the data shard or in the index is an error, not a silently different weight; entries stored in
+    slices (field 7) are refused."""
+    from fvta_memexqa_amd import tf_checkpoint as tc
+    assert tc._mask(tc.crc32c(b"123456789")) == (((0xE3069283 >> 15) | (0xE3069283 << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+    rng = np.random.RandomState(1)
+    tensors = {"m/a": rng.randn(5, 3).astype(np.float32), "m/b": rng.randn(7).astype(np.float32)}
+    prefix = tc.write_checkpoint(str(tmp_path / "model-1"), tensors)
+    data = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(data, "rb").read())
+    raw[9] ^= 0x40
+    open(data, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="crc32c"):
+        tc.read_checkpoint(prefix)
+    got = tc.read_checkpoint(prefix, verify=False)                    # the caller may opt out (large files: pure-Python CRC)
+    assert not np.array_equal(got["m/a"], tensors["m/a"]) or not np.array_equal(got["m/b"], tensors["m/b"])
+    prefix = tc.write_checkpoint(str(tmp_path / "model-2"), tensors)
+    idx = bytearray(open(prefix + ".index", "rb").read())
+    idx[12] ^= 0x01                                                   # inside the first data block of the table
+    open(prefix + ".index", "wb").write(bytes(idx))
+    with pytest.raises(ValueError, match="crc32c"):
+        tc.read_checkpoint(prefix)
+    e = tc._parse_entry(tc._entry_proto(tensors["m/a"], 0, 0) + tc._field(7, 2, tc._put_varint(0)))
+    assert e["slices"] == 1
