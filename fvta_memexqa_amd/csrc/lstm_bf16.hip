@@ -381,6 +381,7 @@ static void launch_bwd_fused_xm(const FusedBwdArgs& a, hipStream_t s) {
 }
 
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
+  if (launch_bwd_wreg(a, s)) return;  // few rows: the weights-stationary step
   if (a.xm == 3)
     launch_bwd_fused_xm<3>(a, s);
   else

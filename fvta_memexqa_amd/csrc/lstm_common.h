@@ -405,6 +405,7 @@ void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, in
 void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s);
 // weights-in-registers forward step (lstm_wreg.hip): false = shape not built, the tiled kernel runs instead
 int wreg_nct(int in_i, int d);
+int wreg_mode();
 void launch_cvt_weights_frag(const float* W, const float* bias, bf16_t* wf, int in, int in_i, int d, hipStream_t s);
 bool launch_step_fwd_wreg(const StepArgs& a, hipStream_t s);
 struct FusedBwdArgs {
@@ -422,6 +423,7 @@ struct FusedBwdArgs {
   int xm;                // bf16 terms per operand value
 };
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s);
+bool launch_bwd_wreg(const FusedBwdArgs& a, hipStream_t s);  // lstm_wreg_bwd.hip: steps with few rows, false: not taken
 void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s);
 void launch_dw_bf16(const DwArgs& a, hipStream_t s);
 void launch_dw_reduce_bf16(const float* slabs, int nslab, int in, int in_i, int d, float* dW, float* dbias, hipStream_t s);

@@ -538,12 +538,18 @@ static int wreg_cus() {
 
 // waves per workgroup of the configuration a shape runs on
 // column tiles per wave for a shape, 0: not built
-int wreg_nct(int in_i, int d) {
-  static const bool on = [] {
-    const char* e = getenv("FVTA_LSTM_WREG");  // 0: the tiled step kernel for every shape (A/B measurements)
-    return !(e && e[0] == '0');
+// FVTA_LSTM_WREG (A/B measurements): bit 0 the weights-stationary forward, bit 1 the weights-stationary backward of steps
+// with few rows; default 3, 0: the tiled step kernels for every shape
+int wreg_mode() {
+  static const int mode = [] {
+    const char* e = getenv("FVTA_LSTM_WREG");
+    return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 3;
   }();
-  if (!on) return 0;
+  return mode;
+}
+
+int wreg_nct(int in_i, int d) {
+  if (!(wreg_mode() & 1)) return 0;
   const int nx = in_i / 16, nd = d / 16;
   if (in_i % 16 || d % 128) return 0;
   if (nd == 32 && (nx == 14 || nx == 8)) return 2;
