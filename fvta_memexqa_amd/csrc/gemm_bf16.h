@@ -52,11 +52,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 // 64 x 128 either way (TM = 2 MFMA row tiles: 6 LDS fragments per 8 MFMAs); the wider block tile re-reads the A operand
 // half as often.  WM < 4 wave rows: block tiles of 64 / 128 rows for calls with few sequences (the photo cell's backward
 // step: a step is then a chain of K/32 k-tiles whose length is the DMA wave-instructions per k-tile).
-template <int WN, int TM_ = 2, int WM_ = 8 / TM_>
+template <int WN, int TM_ = 2, int WM_ = 8 / TM_, int ST_ = 3>
 struct TileCfgT {
   static_assert(TM_ == 2, "wave tile: two MFMA row tiles");
   static constexpr int TM = TM_, WAVES_M = WM_, NWAVES = WAVES_M * WN;
-  static constexpr int BM = 32 * TM_ * WM_, BN = 128 * WN, BK = 32, STAGES = 3, NT = 64 * NWAVES;
+  // ST_ = ring depth.  A k-loop's tile rate is (tiles in flight) / (load latency) -- a lone k-loop does not fill the
+  // CU's load path -- so the weight-gradient GEMM (one 256 x 256 workgroup per CU, 32 KB per stage) runs a deeper ring;
+  // the backward step measured no faster with four stages, and the 256 x 128 tile needs two workgroups per CU to fit.
+  static constexpr int BM = 32 * TM_ * WM_, BN = 128 * WN, BK = 32, STAGES = ST_, NT = 64 * NWAVES;
   static constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;  // per stage
   static constexpr int STAGE_ELEMS = A_ELEMS + B_ELEMS;
   static constexpr int LDS_BYTES = STAGES * STAGE_ELEMS * 2;        // 73,728 (WN = 1)
@@ -66,9 +69,9 @@ struct TileCfgT {
 typedef TileCfgT<1> TileCfg;
 
 // ---- accumulators + fragment reads -------------------------------------------------------------
-template <int WN, int TM_ = 2, int WM_ = 8 / TM_>
+template <int WN, int TM_ = 2, int WM_ = 8 / TM_, int ST_ = 3>
 struct MmaBT {
-  typedef TileCfgT<WN, TM_, WM_> Cfg;
+  typedef TileCfgT<WN, TM_, WM_, ST_> Cfg;
   static constexpr int TM = TM_, TN = 4, WAVES_M = Cfg::WAVES_M, WAVES_N = 1, BM = Cfg::BM, BN = Cfg::BN;  // WAVES_N: per wave column
   static constexpr int WROWS = 32 * TM;  // rows of a wave tile
   f32x16 acc[TM][TN];
@@ -292,18 +295,27 @@ __device__ __forceinline__ void glds_mainloop_sp(Mma& mma, Issue&& issue, int nt
 template <bool KMAJOR, class Mma, class Issue>
 __device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntiles, bf16_t* smem) {
   typedef typename Mma::Cfg TileCfg;
-  auto a_stage = [&](int t) { return smem + (t % TileCfg::STAGES) * TileCfg::STAGE_ELEMS; };
+  constexpr int S = TileCfg::STAGES, G = TileCfg::A_GLDS + TileCfg::B_GLDS;
+  static_assert(S >= 3 && S <= 5, "ring depth");
+  auto a_stage = [&](int t) { return smem + (t % S) * TileCfg::STAGE_ELEMS; };
   if (ntiles <= 0) return;
-  issue(0, a_stage(0), a_stage(0) + TileCfg::A_ELEMS);
-  if (ntiles > 1) issue(1, a_stage(1), a_stage(1) + TileCfg::A_ELEMS);
+#pragma unroll
+  for (int p = 0; p < S - 1; ++p)
+    if (p < ntiles) issue(p, a_stage(p), a_stage(p) + TileCfg::A_ELEMS);
   for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles)
-      wait_vmcnt<TileCfg::A_GLDS + TileCfg::B_GLDS>();
+    // tiles up to t + S - 2 are issued; tile t has landed once only the newer ones are outstanding
+    const int ahead = min(S - 2, ntiles - 1 - t);
+    if (ahead >= 3)
+      wait_vmcnt<3 * G>();
+    else if (ahead == 2)
+      wait_vmcnt<2 * G>();
+    else if (ahead == 1)
+      wait_vmcnt<G>();
     else
       wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave's reads of stage (t - 1) % S are retired
     asm volatile("" ::: "memory");
-    if (t + 2 < ntiles) issue(t + 2, a_stage(t + 2), a_stage(t + 2) + TileCfg::A_ELEMS);
+    if (t + S - 1 < ntiles) issue(t + S - 1, a_stage(t + S - 1), a_stage(t + S - 1) + TileCfg::A_ELEMS);
     const bf16_t* As = a_stage(t);
     if (KMAJOR)
       mma.compute_kmajor(As, As + TileCfg::A_ELEMS);

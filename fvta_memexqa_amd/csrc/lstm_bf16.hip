@@ -436,6 +436,11 @@ void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
 }
 
 // -------------------------------------------------------- weight gradient --
+#ifndef FVTA_DW_STAGES
+#define FVTA_DW_STAGES 4
+#endif
+constexpr int dw_stages(int wn) { return wn == 2 ? FVTA_DW_STAGES : 3; }  // ring depth (TileCfgT)
+
 // slab(dir, split) [in_i+d][4d] = sum over the split's steps of [xs_t | hs_{t-1}]^T * dz_t.  Both operands
 // are k-major in memory: staged as they lie, read through the transposing LDS read.
 // 1-D grid over (slice = (direction, step group), m-tile, n-tile): m-tiles never mix x and h columns.
@@ -443,8 +448,8 @@ void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
 // at the rate the address unit feeds the LDS).
 template <int WN>
 __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dw_bf16(DwArgs a) {
-  typedef TileCfgT<WN> TileCfg;
-  typedef MmaBT<WN> MmaB;
+  typedef TileCfgT<WN, 2, 4, dw_stages(WN)> TileCfg;
+  typedef MmaBT<WN, 2, 4, dw_stages(WN)> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   const int tid = threadIdx.x;
   const int d = a.d, in_i = a.in_i, N4 = 4 * d;
@@ -501,9 +506,10 @@ __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dw
 void launch_dw_bf16(const DwArgs& a, hipStream_t s) {
   const int slices8 = (2 * a.nsplit + 7) / 8;  // slices per XCD
   if ((4 * a.d) % 256 == 0) {
-    allow_big_lds(lstm_dw_bf16<2>, TileCfgT<2>::LDS_BYTES);
+    constexpr int LDS2 = TileCfgT<2, 2, 4, dw_stages(2)>::LDS_BYTES;
+    allow_big_lds(lstm_dw_bf16<2>, LDS2);
     const int per = ((a.in_i + 255) / 256 + (a.d + 255) / 256) * (4 * a.d / 256);
-    hipLaunchKernelGGL((lstm_dw_bf16<2>), dim3(8 * per * slices8), dim3(512), TileCfgT<2>::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((lstm_dw_bf16<2>), dim3(8 * per * slices8), dim3(512), LDS2, s, a);
   } else {
     allow_big_lds(lstm_dw_bf16<1>, TileCfgT<1>::LDS_BYTES);
     const int per = ((a.in_i + 255) / 256 + (a.d + 255) / 256) * (4 * a.d / 128);
