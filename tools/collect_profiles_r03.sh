@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-3 measurement set (runs on the GPU box via gpurun): the default bench line, rocprofv3 kernel stats of the same
-# command, the LSTM forward counter passes (tools/r03_pmc_wreg.sh) -- copied into profiles/r03_* afterwards.
+# command, the LSTM forward counter passes (tools/r03_pmc_wreg.sh) -- copied into profiles/r03_* afterwards
+# (tools/collect_profiles_r03.sh <tag> full; then: for f in gpurun_out/<tag>/*.{json,csv,txt}; do cp $f profiles/r03_$(basename $f); done).
 tag=${1:-r03}
 out=gpurun_out/$tag
 mkdir -p $out
@@ -18,5 +19,9 @@ if [ "$2" = "full" ]; then
   timeout 600 python3 bench.py --config long_album --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_long_train.json 2>/dev/null
   timeout 600 python3 bench.py --config plumbing --precision f32 --steps 50 --warmup 10 --no-cpu-baseline > $out/bench_plumbing.json 2>/dev/null
   timeout 600 python3 bench.py --front-end --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_frontend.json 2>/dev/null
+  timeout 600 python3 bench.py --precision bf16x3 --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_bf16x3_train.json 2>/dev/null
+  # one rank through the launcher: the collective path (RCCL communicator, flat-gradient all-reduce) on the one GPU there is
+  FVTA_DIST_FORCE=1 timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_rccl_one_rank.json 2>/dev/null
+  PYTHONPATH=$GRAFT_REPO_ROOT timeout 300 python3 tools/r03_frontend_ab.py 10 > $out/frontend_kernels.txt 2>/dev/null
 fi
 head -30 $out/kernel_stats.csv | cut -c1-150
