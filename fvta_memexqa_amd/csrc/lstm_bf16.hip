@@ -518,28 +518,33 @@ void launch_dw_bf16(const DwArgs& a, hipStream_t s) {
 }
 
 // slabs (internal row order) -> dkernel [in+d][4d] and dbias [4d], accumulated, fixed summation order
-__global__ void lstm_dw_reduce_bf16(const float* __restrict__ slabs, int nslab, int in, int in_i, int d,
-                                    float* __restrict__ dW, float* __restrict__ dbias) {
+// (a thread takes the four gates of one unit: 16-byte slab reads, eight in flight)
+__global__ __launch_bounds__(256) void lstm_dw_reduce_bf16(const float* __restrict__ slabs, int nslab, int in, int in_i, int d,
+                                                            float* __restrict__ dW, float* __restrict__ dbias) {
   const int N4 = 4 * d;
   const size_t slab_elems = (size_t)(in_i + d) * N4;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (idx >= slab_elems) return;
-  const int row = (int)(idx / N4), np = (int)(idx % N4);
-  const int n = (np & 3) * d + (np >> 2);  // slab columns follow dz's unit-major order 4u+g
-  if (row > in && row < in_i) return;     // zero pad rows
-  float s = 0.f;
-  for (int k = 0; k < nslab; ++k) s += slabs[(size_t)k * slab_elems + idx];
-  if (row < in)
-    dW[(size_t)row * N4 + n] += s;
-  else if (row == in)
-    dbias[n] += s;  // the ones column
-  else
-    dW[(size_t)(in + row - in_i) * N4 + n] += s;
+  const int row = (int)(idx / N4), u = (int)(idx % N4) >> 2;  // slab columns follow dz's unit-major order 4u+g
+  if (row > in && row < in_i) return;                           // zero pad rows
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= nslab; k += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(slabs + (size_t)(k + j) * slab_elems + idx);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; k < nslab; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * slab_elems + idx);
+  float* dst = row < in ? dW + (size_t)row * N4 : (row == in ? dbias : dW + (size_t)(in + row - in_i) * N4);  // row == in: the ones column
+#pragma unroll
+  for (int g = 0; g < 4; ++g) dst[g * d + u] += s[g];
 }
 
 void launch_dw_reduce_bf16(const float* slabs, int nslab, int in, int in_i, int d, float* dW, float* dbias,
                            hipStream_t s) {
-  const size_t n = (size_t)(in_i + d) * 4 * d;
+  const size_t n = (size_t)(in_i + d) * d;  // threads: one per (row, unit)
   hipLaunchKernelGGL(lstm_dw_reduce_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, nslab, in, in_i, d, dW,
                      dbias);
 }
