@@ -354,7 +354,7 @@ def main():
             r_["frac_of_achievable"] = round(r_["achieved"] / probe_gbs, 4)
     dense_metric = args.config == "metric" and args.variant == "dense" and not args.batch and args.graph == "fvta"
     if roof is not None and dense_metric and args.precision == "bf16":
-        roof["traffic"] = pmc_traffic("r03_lstm_pmc.json", "lstm_fwd_wreg_bf16")
+        roof["traffic"] = pmc_traffic("r03_lstm_pmc.json", "lstm_fwd_wreg_bf16<fvta::WregCfg<14, 32, 2>")  # the text cell's instantiation
         roof["traffic_note"] = "bytes per launch, profiles/r03_lstm_pmc.json; algorithmic per launch = algorithmic_bytes_per_call / 30"
     # the fused backward step (now the longest kernel family of the step): per active (row, unit) it reads the saved bf16
     # gates (8 B), c_{t-1} (4), d_out (4) and the running dc (4) and writes dz (8) and dc (4): 32 B -- DESIGN.md 4.3
