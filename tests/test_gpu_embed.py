@@ -157,3 +157,47 @@ def test_image_features(trans, tanh, shape):
         op.backward(cu(pis).int(), row_off, cu(feat), x, dx, dW, db)
         _close(dW, W.grad, atol=1e-4, msg="dW")
         _close(db, b.grad, atol=1e-4, msg="db")
+
+
+def test_token_embed_metric_size_properties():
+    """BASELINE.json configs[2] size (385,920 tokens of 16 characters): every wave of the wave-per-token kernels walks
+    ~190 tokens and 2,048 slabs are reduced.  Forward: a random sample of 3,000 tokens against the oracle (tokens are
+    independent).  Backward: additivity over a split of the token list -- the parameter gradients of all tokens equal the
+    sum of the two halves' (size-independent; fixed-order sums, so only rounding differs) -- and a bitwise repeat."""
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    B, J, W, cd, cw, wd, VW, VF, VC = 12864, 30, 16, 8, 100, 100, 400, 20000, 100
+    p, ids, ch = _case(77, B, J, W, cd, cw, wd, VW, VF, VC)
+    ntok, stride = B * J, cw + wd + 24
+    cu = lambda t: t.cuda().contiguous()
+    ids_d, ch_d = cu(ids.reshape(-1)), cu(ch.reshape(-1, W))
+    tok_off = cu(torch.arange(ntok, dtype=torch.int64) * stride)
+    x = torch.zeros(ntok * stride, device="cuda")
+    filt = cu(p["filt"].reshape(5, cd, cw))
+    we, fe, ce, bi = cu(p["word_emb"]), cu(p["fixed"]), cu(p["char_emb"]), cu(p["bias"])
+    op = ops.TokenEmbed(ntok, W, cd, cw, wd, VW, VW + VF, VC)
+    op.forward(ids_d, ch_d, tok_off, we, fe, ce, filt, bi, x)
+    g = torch.Generator().manual_seed(9)
+    pick = torch.randperm(ntok, generator=g)[:3000]
+    ref = F.embed_tokens(ids.reshape(-1)[pick].reshape(1, -1), ch.reshape(-1, W)[pick].reshape(1, -1, W),
+                         p["word_emb"].double(), p["fixed"].double(), p["char_emb"].double(), p["filt"].double(),
+                         p["bias"].double())
+    _close(x.view(ntok, stride)[pick.cuda(), :cw + wd], ref.reshape(3000, -1), msg="x (sample)")
+    dx = torch.randn(ntok * stride, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+
+    def grads(lo, hi):
+        n = hi - lo
+        o = ops.TokenEmbed(n, W, cd, cw, wd, VW, VW + VF, VC)
+        o.argpos.copy_(op.argpos.view(ntok, cw)[lo:hi].reshape(-1))
+        out = [torch.zeros(VW, wd, device="cuda"), torch.zeros(VC, cd, device="cuda"), torch.zeros(5, cd, cw, device="cuda"),
+               torch.zeros(cw, device="cuda")]
+        o.backward(ids_d[lo:hi].contiguous(), ch_d[lo:hi].contiguous(), tok_off[lo:hi].contiguous(), ce, filt, dx, *out)
+        return out
+    whole, again = grads(0, ntok), grads(0, ntok)
+    half = ntok // 2 + 7
+    a, b = grads(0, half), grads(half, ntok)
+    for name, w_, r_, a_, b_ in zip(("d word_emb", "d char_emb", "d filt", "d bias"), whole, again, a, b):
+        if name != "d word_emb":                       # (the word rows are atomics: summation order varies)
+            assert torch.equal(w_, r_), name + " repeat"
+        scale = float(w_.abs().max())
+        _close(w_, a_ + b_, rtol=1e-4, atol=2e-5 * scale, msg=name + " additivity")
