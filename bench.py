@@ -282,7 +282,7 @@ def main():
             log("hbm probe failed: %r" % (exc,))
 
     prof = {name: collect(pid) for name, pid in [("lstm_step_fwd", 1), ("lstm_step_bwd", 2), ("lstm_dw", 3),
-                                                 ("attn_fwd_main", 4), ("attn_bwd_main", 5),
+                                                 ("attn_fwd_main", 4), ("attn_bwd_main", 5), ("lstm_dx", 6),
                                                  ("lstm_step_fwd_photo_cell", 17)]}
     if rank != 0:
         dist.shutdown()
@@ -363,10 +363,15 @@ def main():
     if n_b and args.precision == "bf16" and not args.forward_only:
         by_bwd = float((2 * lens * dp * 32).sum().item())
         gbs_b = by_bwd * calls / (ms_b * 1e-3) / 1e9
-        roof_bwd = dict(kernel="lstm_bwd_fused_bf16 + lstm_dx_bf16 (bracket: the recurrence's launches and the dx pass)", bound="hbm",
+        roof_bwd = dict(kernel="lstm_bwd_fused_bf16 (backward step of the text cell: dz(t+1) Wh^T + gate gradient)", bound="hbm",
                         achieved=round(gbs_b, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs_b / PEAK_HBM_GBS, 4), traffic=None,
-                        algorithmic_bytes_per_call=by_bwd, ms_per_step=round(ms_b / args.steps, 4),
-                        note="algorithmic bytes: the gate-gradient epilogue only (32 B per row and unit); the dx pass re-reads dz")
+                        algorithmic_bytes_per_call=by_bwd, ms_per_step=round(ms_b / args.steps, 4), launches=int(n_b),
+                        avg_launch_ms=round(ms_b / max(1, n_b), 4),
+                        note="algorithmic bytes: the gate-gradient epilogue (32 B per row and unit: gates 8, c 4, d_out 4, dc 4 + 4, "
+                             "dz 8); the k-loop's re-read of dz(t+1) (8 B) not counted; the dx pass has its own bracket (lstm_dx)")
+    if roof_bwd is not None and dense_metric:
+        roof_bwd["traffic"] = pmc_traffic("r03_lstm_bwd_pmc.json", "lstm_bwd_fused_bf16<2, 4, 1>")
+        roof_bwd["traffic_note"] = "bytes per launch, profiles/r03_lstm_bwd_pmc.json; algorithmic per launch = algorithmic_bytes_per_call / 30"
     if roof_att is not None and dense_metric:
         roof_att["traffic"] = pmc_traffic("r02c_attention_pmc.json", "attn_fwd_pair16")
         roof_att["traffic_note"] = "bytes per launch, profiles/r02c_attention_pmc.json"

@@ -644,7 +644,12 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
       f.nact_hint = nactive_host ? nactive_host[t] : -1;
       launch_bwd_fused_bf16(f, stream);
     }
-    if (dx) launch_dx_bf16(f, stream);
+    fvta_prof_end(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, J, stream);
+    if (dx) {
+      fvta_prof_begin(FVTA_PROF_LSTM_DX + 16 * d->reserved, stream);
+      launch_dx_bf16(f, stream);
+      fvta_prof_end(FVTA_PROF_LSTM_DX + 16 * d->reserved, 1, stream);
+    }
   } else
   for (int t = J - 1; t >= 0; --t) {
     g.t = t;
@@ -652,7 +657,7 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
     if (!(dbg & 512)) hipLaunchKernelGGL(lstm_gate_bwd, ggrid, dim3(256), 0, stream, g);
     if (t > 0 || dx) hipLaunchKernelGGL(lstm_step_bwd_f32, sgrid, dim3(256), sh, stream, s);
   }
-  fvta_prof_end(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, 2 * J, stream);
+  if (!bf) fvta_prof_end(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, 2 * J, stream);
   FVTA_CHECK_LAUNCH("lstm_step_bwd");
   const int MM = in + dd + 1, N4 = 4 * dd;
   const dim3 wgrid((MM + MmaSq::BM - 1) / MmaSq::BM, N4 / MmaSq::BN, 2 * w.nsplit);

@@ -454,10 +454,11 @@ int fvta_test_gemm(int32_t precision, int32_t layout, int32_t M, int32_t N, int3
  * bracket the whole per-step launch sequence of one call (J launches).
  * ------------------------------------------------------------------------- */
 #define FVTA_PROF_LSTM_STEP_FWD 1 /* lstm_step_fwd_*  : J launches per fvta_bilstm_fwd */
-#define FVTA_PROF_LSTM_STEP_BWD 2 /* gate + step GEMM : 2J launches per fvta_bilstm_bwd */
+#define FVTA_PROF_LSTM_STEP_BWD 2 /* the recurrence's step launches of one fvta_bilstm_bwd (fp32 engine: gate + step GEMM, with dx) */
 #define FVTA_PROF_LSTM_DW 3       /* weight-gradient GEMM + slab reduce */
 #define FVTA_PROF_ATTN_FWD_MAIN 4 /* attn_fwd_main */
 #define FVTA_PROF_ATTN_BWD_MAIN 5 /* attn_bwd_main */
+#define FVTA_PROF_LSTM_DX 6       /* lstm_dx_bf16: the input gradient of all steps, one launch (bf16 engine) */
 int fvta_profile_enable(int32_t on);
 int fvta_profile_collect(int32_t id, double* total_ms, int64_t* launches);
 /* Measurement hook (bench.py, SURVEY 8d "achievable peak"): one read-only, fully coalesced, non-temporal pass over

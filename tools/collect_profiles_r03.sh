@@ -12,6 +12,7 @@ cp $(find $out/ks -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv 2>/
 if [ "$2" = "full" ]; then
   bash tools/r03_pmc_wreg.sh > $out/pmc_wreg.log 2>&1
   cp gpurun_out/r03_pmc_wreg/summary.json $out/lstm_pmc.json 2>/dev/null
+  cp gpurun_out/r03_pmc_bwd/summary.json $out/lstm_bwd_pmc.json 2>/dev/null
   timeout 600 python3 bench.py --variant ragged --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_ragged.json 2>/dev/null
   timeout 600 python3 bench.py --forward-only --precision f32 --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_fwd_f32.json 2>/dev/null
   timeout 600 python3 bench.py --forward-only --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_fwd_bf16.json 2>/dev/null

@@ -19,3 +19,11 @@ for k, v in sorted(d.items()):
     print(k[:70])
     for c, x in sorted(v.items()): print("    %-32s %14.1f" % (c, x))
 PY
+# ---- the backward kernels of the text cell (fused step, dx, dW): tools/bench_lstm.py bf16 bwd, FETCH / WRITE / SQ passes
+outb=gpurun_out/r03_pmc_bwd
+mkdir -p $outb
+passb() { name=$1; shift; timeout 400 rocprofv3 --pmc "$@" --output-format csv -d $outb/$name -o p -- python3 tools/bench_lstm.py bf16 bwd > $outb/$name.log 2> $outb/$name.err; tail -1 $outb/$name.log; }
+passb sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT
+passb fetch FETCH_SIZE
+passb write WRITE_SIZE
+python3 tools/pmc_summary.py $outb/summary.json $outb/sq $outb/fetch $outb/write > /dev/null
