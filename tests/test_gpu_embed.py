@@ -31,7 +31,8 @@ def _case(seed, B, J, W, cd, cw, wd, VW, VF, VC):
                                                       (33, 30, 16, 8, 100, 100, 40, 2000, 256),
                                                       (1, 1, 16, 8, 100, 100, 5, 5, 30),        # one token: three idle waves
                                                       (2, 3, 5, 8, 100, 100, 10, 10, 20),       # W = height: one window
-                                                      (2, 5, 16, 8, 100, 140, 10, 10, 300)])    # wdim > 128; VC > 256: register kernels
+                                                      (2, 5, 16, 8, 100, 140, 10, 10, 300),     # wdim > 128; VC > 256: register kernels
+                                                      (3, 5, 16, 8, 100, 140, 10, 10, 30)])     # wdim > 128 on the wave kernels
 def test_token_embed_forward_backward(B, J, W, cd, cw, wd, VW, VF, VC):
     from fvta_memexqa_amd import ops
     from oracle import fvta_fused as F
