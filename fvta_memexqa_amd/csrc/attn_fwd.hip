@@ -200,6 +200,56 @@ __global__ void fill_kernel(float* __restrict__ p, size_t n, float v) {
   if (i < n) p[i] = v;
 }
 
+// ---- workgroups per n in proportion to the n's valid 16-row tiles (pair kernel, N <= 64).  One wave: lane n holds n's
+// tile count; every n gets floor(share) >= 1 workgroups (at most maxg), the remainder goes one at a time to the n with
+// the most tiles per workgroup.  tab[wg] = n | g << 16 | G_n << 24 in n order (an n's workgroups stay XCD-contiguous),
+// 0xffffffff for workgroups left over.
+__global__ __launch_bounds__(64) void attn_balance_kernel(AttnShape s, AttnSaved sv, int nwg, int maxg, uint32_t* __restrict__ tab) {
+  const int lane = threadIdx.x;
+  int tiles = 0;
+  if (lane < s.N)
+    for (int k = 0; k < s.K; ++k) tiles += (sv.cnt[lane * s.K + k] + 15) >> 4;
+  if (lane < s.N && tiles < 1) tiles = 1;
+  int total = tiles;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+  int G = 0;
+  if (lane < s.N) {
+    G = (int)((long long)tiles * nwg / total);
+    G = G < 1 ? 1 : (G > maxg ? maxg : G);
+  }
+  int used = G;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) used += __shfl_xor(used, o, 64);
+  for (int it = 0; it < 256 && used != nwg; ++it) {
+    // load per workgroup of each n (scaled); give to the most loaded (used < nwg) or take from the least (used > nwg)
+    const bool give = used < nwg;
+    const bool can = lane < s.N && (give ? G < maxg : G > 1);
+    long long key = can ? ((long long)tiles << 20) / (give ? G : G - 1) : (give ? -1 : (1ll << 62));
+    long long best = key;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const long long other = __shfl_xor(best, o, 64);
+      best = give ? (other > best ? other : best) : (other < best ? other : best);
+    }
+    if (give ? best < 0 : best == (1ll << 62)) break;  // nobody can take / give
+    const unsigned long long who = __ballot(can && key == best);
+    if (lane == __ffsll((long long)who) - 1) G += give ? 1 : -1;
+    used += give ? 1 : -1;
+  }
+  int first = G;  // exclusive prefix sum over n
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(first, o, 64);
+    if (lane >= o) first += v;
+  }
+  first -= G;
+  if (lane < s.N)
+    for (int g = 0; g < G; ++g) tab[first + g] = (uint32_t)lane | ((uint32_t)g << 16) | ((uint32_t)G << 24);
+  const int tot = __shfl(first + G, 63, 64);
+  for (int i = tot + lane; i < nwg; i += 64) tab[i] = 0xffffffffu;
+}
+
 // ---- main kernel -----------------------------------------------------------
 struct AttnFwdArgs {
   AttnShape s;
@@ -211,6 +261,7 @@ struct AttnFwdArgs {
   int ipw;          // 16-row kernel: items per workgroup
   int dbg;          // FVTA_ATTN_DBG experiment bits (diagnostics only)
   size_t hstride;   // elements between the row blocks of consecutive (n,k): T*w, or fvta_attn_desc.hinfo_stride (K == 1)
+  const uint32_t* wgtab;  // pair kernel: workgroup -> n | g << 16 | G_n << 24 (attn_balance_kernel), null: G workgroups for every n
 };
 
 // w = 4 * SCW * NSC * NW * NSLAB.  A workgroup is NW waves; a wave owns NSC
@@ -1203,7 +1254,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_wave16(AttnFwdArgs a, int G) 
 // instead of workgroup barriers, so the four pairs of a workgroup drift apart freely (the polls are bounded: a broken
 // hand-shake gives wrong numbers, never a hung GPU).
 template <int NBH, int RMODE, bool FLAGS = false>
-__global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) {
+__global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G_all) {
   constexpr int NKS = NBH / 2;   // MFMA steps over a wave's half of the channels
   constexpr int NU = NBH / 16;   // accumulator registers (float4) per lane
   static_assert(NBH % 16 == 0, "a wave's channel blocks are dealt round-robin to the 16 row lanes");
@@ -1231,10 +1282,19 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G) 
   const int pair = wave >> 1, hv = wave & 1;
   const int l15 = lane & 15, kq = lane >> 4;
   const int T = s.T, w = s.w, JP = s.JP;
-  const int nwg = s.N * G, per = (nwg + 7) / 8;
+  const int nwg = s.N * G_all, per = (nwg + 7) / 8;
   const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (wg >= nwg || (int)(blockIdx.x >> 3) >= per) return;
-  const int n = wg / G, g0 = wg % G;
+  // the n this workgroup serves, its index among that n's workgroups and their number: uniform (G_all each), or dealt in
+  // proportion to the n's valid tiles (masked batches: albums differ in rows)
+  int n = wg / G_all, g0 = wg % G_all, G = G_all;
+  if (a.wgtab) {
+    const uint32_t e = a.wgtab[wg];
+    if (e == 0xffffffffu) return;
+    n = (int)(e & 0xffffu);
+    g0 = (int)((e >> 16) & 0xffu);
+    G = (int)(e >> 24);
+  }
   // -DFVTA_PAIR_ABL=bits: compile-time ablations (timing only, results are wrong; a run-time switch makes the compiler
   // spill): 1 no tile loads after an item's first, 2 no score MFMA loop, 4 no weighted sum (refill only), 8 no pair
   // hand-shake -- tools/r02_v.sh
@@ -1879,11 +1939,13 @@ extern "C" size_t fvta_attn_saved_bytes(const fvta_attn_desc* d) {
 
 size_t fvta_attn_bwd_workspace_bytes(const AttnShape& s);  // attn_bwd.hip
 
+constexpr size_t ATTN_WGTAB_BYTES = 4096 * sizeof(uint32_t);  // the pair kernel's workgroup table, behind the partials
+
 extern "C" size_t fvta_attn_workspace_bytes(const fvta_attn_desc* d) {
   if (fvta_attn_check_desc(d)) return 0;
   const AttnShape s = attn_shape(d, true);
   // forward: the split partials, then one more partial per (n,k) for the masked rows' share under time_warp_att
-  const size_t fwd = fvta_align_up((size_t)s.N * s.K * (s.nsplit + 1) * (s.w + 4) * sizeof(float), 256);
+  const size_t fwd = fvta_align_up((size_t)s.N * s.K * (s.nsplit + 1) * (s.w + 4) * sizeof(float), 256) + ATTN_WGTAB_BYTES;
   const size_t bwd = fvta_attn_bwd_workspace_bytes(s);
   return fwd > bwd ? fwd : bwd;
 }
@@ -1923,6 +1985,7 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   a.tscale = tscale;
   a.hstride = d->hinfo_stride ? (size_t)d->hinfo_stride : (size_t)s.T * s.w;
   a.ipw = 1;
+  a.wgtab = nullptr;
   a.dbg = fvta_diag_env("FVTA_ATTN_DBG", 0);  // -DFVTA_DIAG builds only
   // (the phase stamps land 32 MiB into the workspace: only where the workspace reaches that far)
   if ((a.dbg & 16) && fvta_attn_workspace_bytes(d) < ((size_t)32 << 20) + 64 * 16 * 8) a.dbg &= ~16;
@@ -1946,6 +2009,12 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
     const int nwg = s.N * G;
     const dim3 grid(((nwg + 7) / 8) * 8);
     const int rmode = s.simi == 1 ? 1 : (s.simi == 3 ? 3 : 2);
+    if (use_mask && s.N <= 64 && s.N > 1 && nwg <= 4096 && maxg <= 255) {  // ragged albums: workgroups in proportion to the rows
+      uint32_t* tab = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) +
+                                                 fvta_align_up((size_t)s.N * s.K * (s.nsplit + 1) * (s.w + 4) * sizeof(float), 256));
+      hipLaunchKernelGGL(attn_balance_kernel, dim3(1), dim3(64), 0, stream, s, sv, nwg, maxg, tab);
+      a.wgtab = tab;
+    }
 #define FVTA_P16K(NBH, RM, FL)                                                                                          \
   do {                                                                                                                   \
     (void)hipFuncSetAttribute((const void*)attn_fwd_pair16<NBH, RM, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
