@@ -3,28 +3,32 @@
 (forward + backward + optimiser update) at BASELINE.json's metric shape
 (batch 64 per GPU, 40 photos x 5 text streams x 30 tokens, hidden 512).
 
-  python bench.py --gpus N --steps K --warmup W          (N=1)
+  python bench.py --gpus N --steps K --warmup W          (N=1; N>1 without a launcher: the ranks are spawned here)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One rank per GPU; albums/questions are sharded over ranks (weak scaling: 64 QA
 pairs per GPU), the only collective is the all-reduce of the flat gradient
 buffer.  Inputs (synthetic, seeded) are resident in HBM before the timed region.
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the bi-LSTM
-step GEMM, MFMA bound); `roofline_attention` is the fused focal-attention
-kernel against HBM.  Kernel durations come from HIP events recorded on the
-launch stream inside the library (fvta_profile_*), live over the timed region.
+Rank 0 prints ONE JSON line.  `roofline` is for the DOMINANT kernel of the step
+(largest `kernel_ms_per_step` entry; today the bi-LSTM backward step), every other
+bracketed kernel has its own `roofline_<name>` object.  Kernel durations come from
+HIP events recorded on the launch stream inside the library (fvta_profile_*), live,
+over a second pass of the same steps right after the timed region.
 `cpu_baseline` times the CPU oracle ("port") on a bounded sample of the same
-workload on this box's host cores (rank 0, N=1 only).
+workload on this box's host cores (rank 0, N=1 only).  After the headline, the
+default N=1 run also times the other BASELINE.json configurations that fit one GPU
+(short runs, attached under `also`): configs[1] forward only (fp32 and bf16 engines),
+the 1e-4-parity `bf16x3` train step, ragged lengths, configs[4] long album, the
+token-id entry, and the published flag set (time warp type 5, char_emb_size 100).
 """
 import argparse
 import ctypes
 import json
 import os
 import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 if HERE not in sys.path:
@@ -34,13 +38,12 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F32_TFLOPS = 157.3        # fp32 MFMA (v_mfma_f32_32x32x2_f32)
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA
 
+_T0 = time.perf_counter()
+
 
 def log(msg):
     if os.environ.get("FVTA_BENCH_VERBOSE", "1") != "0":
         print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
-
-
-_T0 = time.perf_counter()
 
 
 def host_cores():
@@ -50,7 +53,7 @@ def host_cores():
         return os.cpu_count() or 1
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -87,14 +90,46 @@ def parse():
     ap.add_argument("--char-emb-size", type=int, default=8,
                     help="--front-end only: char embedding width (8: the reference's default; 100: the published flag set, "
                          "README.MD:144 -- a 500-deep char-CNN window, run on the fp32 MFMA engine)")
-    return ap.parse_args()
+    ap.add_argument("--time-warp", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help="--use_time_warp --warp_type N (model_v2.py:953-1009); 5 is the published FVTA flag set (README.MD:144-147)")
+    ap.add_argument("--also", default="auto", choices=["auto", "on", "off"],
+                    help="after the headline, time the other BASELINE.json configurations that fit one GPU in short runs and "
+                         "attach them as `also` (auto: for the default N=1 headline only)")
+    return ap.parse_args(argv)
 
 
-def lstm_flops(spec, B, J, din, d):
-    """algorithmic flops of one bi-LSTM forward call, dense: 2 dirs x steps x 2*B*(in+d)*4d (h part absent at t=0)"""
-    return 2 * (J * 2.0 * B * (din + d) * 4 * d - 2.0 * B * d * 4 * d)
+# ------------------------------------------------------------------------------------------------ self-launch --
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start N ranks as fresh child processes -- the parent has not
+    touched the GPU -- with the rendezvous environment torch.distributed.run would give them, and exit with the worst
+    of their codes.  Only rank 0 prints the JSON line (the children share this process's stdout)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:              # a rank that dies takes the others with it (they would wait in the rendezvous otherwise)
+        time.sleep(0.2)
+        for p in list(live):
+            if p.poll() is not None:
+                live.remove(p)
+                if p.returncode and not rc:
+                    rc = p.returncode
+                    for q in live:
+                        q.terminate()
+    if rc:
+        print("bench.py: a rank of the self-launched %d-GPU run failed (exit code %d); no line was printed for %d GPUs" %
+              (args.gpus, rc, args.gpus), file=sys.stderr, flush=True)
+    sys.exit(rc if 0 <= rc < 256 else 1)
 
 
+# ---------------------------------------------------------------------------------------------- cpu baseline --
 def _median_time(fn, passes):
     """1 warm-up + `passes` timed calls, median seconds"""
     times = []
@@ -115,6 +150,7 @@ def cpu_baseline(spec_kw, sample_n, forward_only, threads, literal_n=1):
               it has no autograd.
     `value` is the fused forward+backward rate (forward-only runs: the faster of the two forward rates)."""
     import numpy as np
+    import torch
     from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params, to_numpy
     from oracle import fvta_fused as F
     from oracle import fvta_literal as Lit
@@ -163,21 +199,34 @@ def cpu_baseline(spec_kw, sample_n, forward_only, threads, literal_n=1):
     return out
 
 
-def main():
-    args = parse()
-    from fvta_memexqa_amd import _lib, dist
+# --------------------------------------------------------------------------------------------------- one case --
+PROF_IDS = [("lstm_step_fwd", 1), ("lstm_step_bwd", 2), ("lstm_dw", 3), ("attn_fwd_main", 4), ("attn_bwd_main", 5),
+            ("lstm_dx", 6), ("lstm_step_fwd_photo_cell", 17)]
+
+
+def pmc_traffic(fname, key):
+    """HBM bytes per launch from a committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs at this same
+    shape; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  Not collected live: counters need their own
+    profiler pass."""
+    try:
+        d = json.load(open(os.path.join(HERE, "profiles", fname)))
+        for k, v in d.items():
+            if key in k:
+                return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]
+    except Exception:
+        pass
+    return None
+
+
+def run_case(args, lib, ws, rank, local, probe_gbs=None):
+    """Builds the model of one configuration, runs warm-up + the timed region + the bracketed pass; returns
+    (result dict for rank 0 or None, spec keywords for the CPU baseline)."""
+    import torch
+    from fvta_memexqa_amd import dist
     from fvta_memexqa_amd.model_v2 import Model
     from fvta_memexqa_amd.synth import CONFIGS, SynthSpec, make_inputs
     from fvta_memexqa_amd.trainer import Trainer
-
-    ws, rank, local = dist.init()
-    if ws != args.gpus and ws > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, ws))
-    local %= max(1, torch.cuda.device_count())      # (more ranks than GPUs only under FVTA_DIST_BACKEND=gloo, a test set-up)
-    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    lib = _lib.load()
-
     kw = dict(CONFIGS[args.config], dense=(args.variant == "dense"))
     if args.batch:
         kw["N"] = args.batch
@@ -187,6 +236,8 @@ def main():
     spec = SynthSpec(**kw)
     cfg = dict(spec.cfg(), batch_size=spec.N, precision=args.precision, optimizer=args.optimizer,
                init_lr=0.001 if args.optimizer == "adam" else 0.5)
+    if args.time_warp:
+        cfg.update(use_time_warp=True, warp_type=args.time_warp)
     if args.side_priority is not None:
         cfg["side_stream_priority"] = args.side_priority
     if args.serial_photo_forward is not None:
@@ -260,6 +311,169 @@ def main():
         lib.fvta_profile_collect(pid, ctypes.byref(ms), ctypes.byref(n))
         return ms.value, n.value
 
+    prof = {name: collect(pid) for name, pid in PROF_IDS}
+    if rank != 0:
+        return None, kw
+    total_qa = spec.N * ws * args.steps
+    value = total_qa / elapsed
+    # ---- rooflines.  The bi-LSTM step kernels of the text cell move, per active (row, direction) and launch:
+    #   forward   x shadow in_i*2 B + h shadow read d*2 + c_prev d*4 + c d*4 + h (fp32, into the context tensor) d*4
+    #             + h shadow d*2 + saved gates 4d*2, and do 2*(in+d)*4d flops                             
+    #   backward  saved bf16 gates 8 B + c_{t-1} 4 + d_out 4 + dc 4 + 4 + dz 8 = 32 B per unit (the re-read of dz(t+1),
+    #             8 B, is not counted)
+    #   dx        dz read once (8 B per unit) + the input gradient written;   dW   2*(in+d)*4d flops per (row, direction)
+    T = L.groups["text"]
+    calls = args.steps
+    lens = T.lens.float()
+    dp = model.dp
+    in_i = ((spec.text_in + 1 + 31) // 32) * 32
+    fl_text = float((2 * (lens * 2.0 * (spec.text_in + dp) * 4 * dp - (lens > 0).float() * 2.0 * dp * 4 * dp)).sum().item())
+    by_fwd = float((2 * lens * (in_i * 2 + dp * 2 + dp * 4 * 3 + dp * 2 + 4 * dp * 2)).sum().item())
+    by_bwd = float((2 * lens * dp * 32).sum().item())
+    by_dx = float((2 * lens * dp * 8 + lens * spec.text_in * 4).sum().item())
+    is_bf = args.precision in ("bf16", "bf16x3")
+    # the matrix pipe's peak for this engine, and the hardware flops per algorithmic flop (the split engine runs three
+    # bf16 products per logical one)
+    peak_tf, hw_mult = (PEAK_BF16_TFLOPS, 3.0 if args.precision == "bf16x3" else 1.0) if is_bf else (PEAK_F32_TFLOPS, 1.0)
+    wreg_fwd = args.precision == "bf16" and (dp, in_i) in ((512, 224), (512, 128), (1024, 224), (1024, 128), (128, 128), (128, 32))
+    ring_bwd = args.precision == "bf16" and dp == 512
+    dense_metric = args.config == "metric" and args.variant == "dense" and not args.batch and args.graph == "fvta" and args.precision == "bf16"
+    roofs = {}
+
+    def hbm_roof(name, kernel, prof_key, bytes_per_call, flops_per_call=None, note=None, traffic=None):
+        ms, n = prof[prof_key]
+        if not n:
+            return
+        gbs = bytes_per_call * calls / (ms * 1e-3) / 1e9
+        r = dict(kernel=kernel, bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
+                 traffic=None, algorithmic_bytes_per_call=bytes_per_call, ms_per_step=round(ms / args.steps, 4), launches=int(n),
+                 avg_launch_ms=round(ms / n, 4))
+        if flops_per_call:
+            tf = flops_per_call * calls / (ms * 1e-3) / 1e12
+            r.update(mfma_tflops=round(tf, 1), mfma_frac=round(hw_mult * tf / peak_tf, 4))
+        if note:
+            r["note"] = note
+        if traffic and dense_metric:
+            r["traffic"] = pmc_traffic(*traffic)
+            r["traffic_note"] = "bytes per launch, profiles/%s" % traffic[0]
+        if probe_gbs:
+            r["achievable_peak"] = probe_gbs
+            r["frac_of_achievable"] = round(gbs / probe_gbs, 4)
+        roofs[name] = r
+
+    def mfma_roof(name, kernel, prof_key, flops_per_call, note=None):
+        ms, n = prof[prof_key]
+        if not n:
+            return
+        tf = flops_per_call * calls / (ms * 1e-3) / 1e12
+        roofs[name] = dict(kernel=kernel, bound="mfma", achieved=round(hw_mult * tf, 1), peak=peak_tf, unit="TFLOP/s",
+                           frac=round(hw_mult * tf / peak_tf, 4), traffic=None, algorithmic_flops_per_call=flops_per_call,
+                           ms_per_step=round(ms / args.steps, 4), launches=int(n), avg_launch_ms=round(ms / n, 4))
+        if hw_mult != 1.0:
+            roofs[name]["note"] = "hardware flops = %.0f x the algorithmic flops (split-bf16 products), against the bf16 peak" % hw_mult
+        if note:
+            roofs[name]["note"] = note
+
+    if args.precision == "f32":   # exact-fp32 MFMA: 64 flop/clk/SIMD -- the matrix pipe bounds this engine, not HBM
+        mfma_roof("lstm_fwd", "lstm_step_fwd_f32", "lstm_step_fwd", fl_text)
+    else:
+        hbm_roof("lstm_fwd", "lstm_fwd_wreg_bf16 (forward step, weights in registers)" if wreg_fwd else "lstm_step_fwd_bf16",
+                 "lstm_step_fwd", by_fwd, fl_text, traffic=("r04_lstm_pmc.json", "lstm_fwd_wreg_bf16<fvta::WregCfg<14, 32, 2>"))
+        ms_p, n_p = prof["lstm_step_fwd_photo_cell"]
+        if n_p and "lstm_fwd" in roofs:
+            # rocprofv3 --stats averages per kernel SYMBOL: the photo cell (side stream, small launches) runs the same
+            # symbol, so its launches are reported too -- the all-launch mean is the figure to hold against AverageNs
+            ms_f, n_f = prof["lstm_step_fwd"]
+            roofs["lstm_fwd"].update(launches_photo_cell=int(n_p), avg_launch_ms_photo_cell=round(ms_p / n_p, 4),
+                                     avg_launch_ms_all_launches=round((ms_f + ms_p) / (n_f + n_p), 4))
+    if not args.forward_only and is_bf:
+        hbm_roof("lstm_bwd", ("lstm_bwd_ring_bf16 (backward step, weights in registers, pipelined)" if ring_bwd else
+                              "lstm_bwd_fused_bf16 (backward step: dz(t+1) Wh^T + gate gradient)"),
+                 "lstm_step_bwd", by_bwd, fl_text * dp / (spec.text_in + dp),
+                 note="algorithmic bytes: the gate gradient (32 B per row and unit: gates 8, c 4, d_out 4, dc 4 + 4, dz 8); the "
+                      "re-read of dz(t+1) (8 B) is not counted; dx has its own bracket",
+                 traffic=("r04_lstm_bwd_pmc.json", "lstm_bwd_ring_bf16" if ring_bwd else "lstm_bwd_fused_bf16<2, 4, 1>"))
+        hbm_roof("lstm_dx", "lstm_dx_bf16 (input gradient of all steps, one launch)", "lstm_dx", by_dx,
+                 fl_text * spec.text_in / (spec.text_in + dp), traffic=("r04_lstm_bwd_pmc.json", "lstm_dx_bf16"))
+        mfma_roof("lstm_dw", "lstm_dw_bf16 (weight gradient: [x|h|1]^T dz over every row and step)", "lstm_dw", fl_text)
+    # ---- attention kernels against HBM: algorithmic bytes = valid rows * w * 4 + question + output; the
+    # backward reads the rows and writes their gradient
+    valid_rows = int(L.hall_mask.sum().item())
+    att_bytes = (valid_rows * model.wp + spec.N * L.JQ * model.wp + spec.N * model.wp) * 4.0
+    if args.graph == "fvta":   # (model.py's graph runs seven large 1-D attentions under the same bracket)
+        kname = (("attn_fwd_pair16" if model.wp >= 512 and model.simi != 4 and os.environ.get("FVTA_ATTN_WAVE16", "3") in ("2", "3")
+                  else "attn_fwd_rows16") if (L.JQ <= 32 and 128 <= model.wp <= 1024) else "attn_fwd_main")
+        # (the library's profile bracket covers the context attention only, not the K = 1 question attention)
+        hbm_roof("attention", kname + " (fvta_attn_fwd main kernel)", "attn_fwd_main", att_bytes,
+                 traffic=("r04_attention_pmc.json", "attn_fwd_pair16"))
+        if not args.forward_only:
+            hbm_roof("attention_bwd", "attn_bwd_main", "attn_bwd_main", 2.0 * valid_rows * model.wp * 4.0,
+                     traffic=("r04_attention_pmc.json", "attn_bwd_main"))
+    # the DOMINANT kernel of the step (largest bracketed time per step) is `roofline`; the rest are roofline_<name>
+    kms = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
+    order = sorted(roofs, key=lambda k: -roofs[k]["ms_per_step"])
+    out = dict(
+        metric="QA-pairs/sec (fwd+bwd) at B=64, 40 photos x 5 streams x 30 tok, h=512" if args.config == "metric" and not args.forward_only
+        and args.graph == "fvta" else "QA-pairs/sec (model.py graph, %s, config %s)" % ("fwd" if args.forward_only else "fwd+bwd", args.config)
+        if args.graph == "model_py" else "QA-pairs/sec (%s, config %s)" % ("fwd" if args.forward_only else "fwd+bwd", args.config),
+        value=round(value, 2), unit="QA-pairs/s", n_gpus=ws, steps=args.steps, warmup=args.warmup,
+        ms_per_step=round(elapsed / args.steps * 1e3, 3), ms_per_step_event_median=round(statistics.median(step_ms), 3),
+        higher_is_better=True, scaling=args.scaling, vs_baseline=None,
+        dtype=args.precision, data="synthetic",
+        config=dict(workload=("BASELINE.json configs[2] train step (fwd+bwd+%s)" % args.optimizer if not args.forward_only
+                              else "BASELINE.json configs[1] forward only") + ", shape '%s', %s lengths" % (args.config, args.variant)
+                    + (", token-id entry (embedding front-end inside the step, char_emb_size %d)" % args.char_emb_size
+                       if args.front_end else "")
+                    + (", --use_time_warp --warp_type %d" % args.time_warp if args.time_warp else "")
+                    + (" -- model.py's soft-attention baseline graph (multi-layer + multi-modal + direct-link + choices + "
+                       "question attention) instead of the FVTA model" if args.graph == "model_py" else ""),
+                    qa_pairs_per_gpu=spec.N, albums=spec.A, photos=spec.P, text_streams=spec.S, tokens=spec.L, hidden=spec.d,
+                    global_batch=spec.N * ws, K=L.K, T=L.T, JQ=L.JQ,
+                    parallelism="dp%d (QA pairs sharded, flat-gradient all-reduce)" % ws),
+        roofline=roofs[order[0]] if order else None,
+        roofline_is="roofline_%s: the bracketed kernel with the largest time per step" % order[0] if order else None,
+    )
+    for k in order[1:]:
+        out["roofline_" + k] = roofs[k]
+    out["roofline_fracs"] = {k: [roofs[k]["frac"], roofs[k]["bound"]] for k in order}   # every bracketed kernel, dominant first
+    out.update(process_group=pg, rank_seconds=[round(v, 4) for v in rank_elapsed], kernel_ms_per_step=kms,
+               kernel_ms_note="HIP-event brackets on the launch streams, over a second pass of the same %d steps right after the "
+                              "timed region (the timed region itself carries no brackets)" % args.steps)
+    del trainer, model, L
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out, kw
+
+
+ALSO_CASES = [   # (name, argument overrides, steps, warm-up)
+    ("configs1_forward_fp32", dict(forward_only=True, precision="f32"), 3, 1),
+    ("configs1_forward_bf16", dict(forward_only=True), 5, 2),
+    ("train_bf16x3", dict(precision="bf16x3"), 3, 1),
+    ("train_ragged_lengths", dict(variant="ragged"), 5, 2),
+    ("configs4_long_album", dict(config="long_album"), 3, 1),
+    ("token_id_entry", dict(front_end=True), 5, 2),
+    ("time_warp_5", dict(time_warp=5), 5, 2),
+    ("published_flag_set", dict(front_end=True, char_emb_size=100, time_warp=5), 3, 1),
+]
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)          # never returns
+    import torch
+    from fvta_memexqa_amd import _lib, dist
+
+    ws, rank, local = dist.init()
+    if ws != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or plain `python bench.py --gpus N`, "
+                         "which spawns them)" % (args.gpus, ws))
+    local %= max(1, torch.cuda.device_count())      # (more ranks than GPUs only under FVTA_DIST_BACKEND=gloo, a test set-up)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    lib = _lib.load()
+
     # achievable HBM read rate on THIS device: one coalesced read-only pass over 1.5 GiB, median of 5
     probe_gbs = None
     if rank == 0:
@@ -278,126 +492,36 @@ def main():
                     ts.append(e0.elapsed_time(e1))
             probe_gbs = round(pbuf.numel() * 4 / (statistics.median(ts) * 1e-3) / 1e9, 1)
             del pbuf
+            torch.cuda.empty_cache()
         except Exception as exc:                                                        # measurement aid only
             log("hbm probe failed: %r" % (exc,))
 
-    prof = {name: collect(pid) for name, pid in [("lstm_step_fwd", 1), ("lstm_step_bwd", 2), ("lstm_dw", 3),
-                                                 ("attn_fwd_main", 4), ("attn_bwd_main", 5), ("lstm_dx", 6),
-                                                 ("lstm_step_fwd_photo_cell", 17)]}
+    out, kw = run_case(args, lib, ws, rank, local, probe_gbs)
     if rank != 0:
         dist.shutdown()
         return
-    total_qa = spec.N * ws * args.steps
-    value = total_qa / elapsed
-    # ---- roofline of the dominant kernel family: the bi-LSTM step kernels of the text cell.
-    # lstm_step_fwd (GEMM + fused gate epilogue) per launch moves, per active (row, direction):
-    #   x shadow in_i*2 B + h shadow read d*2 + c_prev d*4 + c d*4 + h (fp32, into the context tensor) d*4
-    #   + h shadow d*2 + saved gates 4d*2      
-    # and does 2*(in+d)*4d flops.  Intensity 265 flop/B < the machine's 312 (2.5 PFLOP/s / 8 TB/s): HBM bound.
-    T = L.groups["text"]
-    calls = args.steps
-    lens = T.lens.float()
-    dp = model.dp
-    in_i = ((spec.text_in + 1 + 31) // 32) * 32
-    fl_text = float((2 * (lens * 2.0 * (spec.text_in + dp) * 4 * dp - (lens > 0).float() * 2.0 * dp * 4 * dp)).sum().item())
-    by_text = float((2 * lens * (in_i * 2 + dp * 2 + dp * 4 * 3 + dp * 2 + 4 * dp * 2)).sum().item())
-    ms_f, n_f = prof["lstm_step_fwd"]
-    peak_tf = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
-    roof = None
-    if n_f:
-        tf = fl_text * calls / (ms_f * 1e-3) / 1e12
-        gbs = by_text * calls / (ms_f * 1e-3) / 1e9
-        wreg = args.precision == "bf16" and dp % 128 == 0 and (dp, in_i) in ((512, 224), (512, 128), (1024, 224), (1024, 128), (128, 128), (128, 32))
-        roof = dict(kernel=("lstm_fwd_wreg_bf16 (forward step, weights in registers)" if wreg else "lstm_step_fwd_%s" % args.precision), bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS,
-                    unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, algorithmic_bytes_per_call=by_text,
-                    mfma_tflops=round(tf, 1), mfma_frac=round(tf / peak_tf, 4), launches=n_f,
-                    avg_launch_ms=round(ms_f / n_f, 4))
-        # rocprofv3 --stats averages per kernel SYMBOL: the photo cell (side stream, small launches) runs the same
-        # lstm_step_fwd symbol, so its launches are reported too -- the all-launch mean is the figure to hold against
-        # the profiler's AverageNs (profiles/README.md)
-        ms_p, n_p = prof["lstm_step_fwd_photo_cell"]
-        if n_p:
-            roof.update(launches_photo_cell=n_p, avg_launch_ms_photo_cell=round(ms_p / n_p, 4),
-                        avg_launch_ms_all_launches=round((ms_f + ms_p) / (n_f + n_p), 4))
-        if args.precision == "f32":   # exact-fp32 MFMA: 64 flop/clk/SIMD -- the matrix pipe bounds this engine, not HBM
-            roof.update(bound="mfma", achieved=round(tf, 1), peak=PEAK_F32_TFLOPS, unit="TFLOP/s", frac=round(tf / peak_tf, 4),
-                        hbm_gbs=round(gbs, 1))
-    # ---- attention kernel against HBM: algorithmic bytes = valid rows * w * 4 + question + output
-    valid_rows = int(L.hall_mask.sum().item())
-    att_bytes = (valid_rows * model.wp + spec.N * L.JQ * model.wp + spec.N * model.wp) * 4.0
-    ms_a, n_a = prof["attn_fwd_main"]
-    roof_att = None
-    if n_a and args.graph == "fvta":   # (model.py's graph runs seven large 1-D attentions under the same bracket)
-        # (the library's profile bracket covers the context attention only, not the K = 1 question attention)
-        per_step_ms = ms_a / args.steps
-        gbs = att_bytes / (per_step_ms * 1e-3) / 1e9
-        roof_att = dict(kernel=(("attn_fwd_pair16" if model.wp >= 512 and model.simi != 4 and os.environ.get("FVTA_ATTN_WAVE16", "3") in ("2", "3")
-                                 else "attn_fwd_rows16") if (L.JQ <= 32 and 128 <= model.wp <= 1024) else "attn_fwd_main")
-                        + " (fvta_attn_fwd main kernel)", bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                        frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None, algorithmic_bytes=att_bytes,
-                        ms_per_step=round(per_step_ms, 4))
-    # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
-    # tools/bench_lstm.py / tools/bench_attn.py at this same shape; FETCH_SIZE doubled per the gfx950 note of
-    # MI355X_MICROARCH.md).  Not collected live: counters need their own profiler pass.
-    def pmc_traffic(fname, key):
-        try:
-            d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", fname)))
-            for k, v in d.items():
-                if key in k:
-                    return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]
-        except Exception:
-            pass
-        return None
-    for r_ in (roof, roof_att):
-        if r_ is not None and probe_gbs and r_["bound"] == "hbm":
-            r_["achievable_peak"] = probe_gbs
-            r_["frac_of_achievable"] = round(r_["achieved"] / probe_gbs, 4)
-    dense_metric = args.config == "metric" and args.variant == "dense" and not args.batch and args.graph == "fvta"
-    if roof is not None and dense_metric and args.precision == "bf16":
-        roof["traffic"] = pmc_traffic("r03_lstm_pmc.json", "lstm_fwd_wreg_bf16<fvta::WregCfg<14, 32, 2>")  # the text cell's instantiation
-        roof["traffic_note"] = "bytes per launch, profiles/r03_lstm_pmc.json; algorithmic per launch = algorithmic_bytes_per_call / 30"
-    # the fused backward step (now the longest kernel family of the step): per active (row, unit) it reads the saved bf16
-    # gates (8 B), c_{t-1} (4), d_out (4) and the running dc (4) and writes dz (8) and dc (4): 32 B -- DESIGN.md 4.3
-    roof_bwd = None
-    ms_b, n_b = prof["lstm_step_bwd"]
-    if n_b and args.precision == "bf16" and not args.forward_only:
-        by_bwd = float((2 * lens * dp * 32).sum().item())
-        gbs_b = by_bwd * calls / (ms_b * 1e-3) / 1e9
-        roof_bwd = dict(kernel="lstm_bwd_fused_bf16 (backward step of the text cell: dz(t+1) Wh^T + gate gradient)", bound="hbm",
-                        achieved=round(gbs_b, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs_b / PEAK_HBM_GBS, 4), traffic=None,
-                        algorithmic_bytes_per_call=by_bwd, ms_per_step=round(ms_b / args.steps, 4), launches=int(n_b),
-                        avg_launch_ms=round(ms_b / max(1, n_b), 4),
-                        note="algorithmic bytes: the gate-gradient epilogue (32 B per row and unit: gates 8, c 4, d_out 4, dc 4 + 4, "
-                             "dz 8); the k-loop's re-read of dz(t+1) (8 B) not counted; the dx pass has its own bracket (lstm_dx)")
-    if roof_bwd is not None and dense_metric:
-        roof_bwd["traffic"] = pmc_traffic("r03_lstm_bwd_pmc.json", "lstm_bwd_fused_bf16<2, 4, 1>")
-        roof_bwd["traffic_note"] = "bytes per launch, profiles/r03_lstm_bwd_pmc.json; algorithmic per launch = algorithmic_bytes_per_call / 30"
-    if roof_att is not None and dense_metric:
-        roof_att["traffic"] = pmc_traffic("r02c_attention_pmc.json", "attn_fwd_pair16")
-        roof_att["traffic_note"] = "bytes per launch, profiles/r02c_attention_pmc.json"
-    out = dict(
-        metric="QA-pairs/sec (fwd+bwd) at B=64, 40 photos x 5 streams x 30 tok, h=512" if args.config == "metric" and not args.forward_only
-        and args.graph == "fvta" else "QA-pairs/sec (model.py graph, %s, config %s)" % ("fwd" if args.forward_only else "fwd+bwd", args.config)
-        if args.graph == "model_py" else "QA-pairs/sec (%s, config %s)" % ("fwd" if args.forward_only else "fwd+bwd", args.config),
-        value=round(value, 2), unit="QA-pairs/s", n_gpus=ws, steps=args.steps, warmup=args.warmup,
-        ms_per_step=round(elapsed / args.steps * 1e3, 3), ms_per_step_event_median=round(statistics.median(step_ms), 3),
-        higher_is_better=True, scaling=args.scaling, vs_baseline=None,
-        dtype=args.precision, data="synthetic",
-        config=dict(workload=("BASELINE.json configs[2] train step (fwd+bwd+%s)" % args.optimizer if not args.forward_only
-                              else "BASELINE.json configs[1] forward only") + ", shape '%s', %s lengths" % (args.config, args.variant)
-                    + (", token-id entry (embedding front-end inside the step, char_emb_size %d)" % args.char_emb_size
-                       if args.front_end else "")
-                    + (" -- model.py's soft-attention baseline graph (multi-layer + multi-modal + direct-link + choices + "
-                       "question attention) instead of the FVTA model" if args.graph == "model_py" else ""),
-                    qa_pairs_per_gpu=spec.N, albums=spec.A, photos=spec.P, text_streams=spec.S, tokens=spec.L, hidden=spec.d,
-                    global_batch=spec.N * ws, K=L.K, T=L.T, JQ=L.JQ,
-                    parallelism="dp%d (QA pairs sharded, flat-gradient all-reduce)" % ws),
-        roofline=roof, roofline_attention=roof_att, roofline_lstm_bwd=roof_bwd,
-        process_group=pg, rank_seconds=[round(v, 4) for v in rank_elapsed],
-        kernel_ms_per_step={k: round(v[0] / args.steps, 4) for k, v in prof.items()},
-        kernel_ms_note="HIP-event brackets on the launch streams, over a second pass of the same %d steps right after the "
-                       "timed region (the timed region itself carries no brackets)" % args.steps,
-    )
+    default_headline = (args.config == "metric" and args.variant == "dense" and args.precision == "bf16" and not args.forward_only
+                        and args.graph == "fvta" and not args.front_end and not args.batch and args.scaling == "weak"
+                        and not args.time_warp)
+    if ws == 1 and (args.also == "on" or (args.also == "auto" and default_headline)):
+        also = {}
+        for name, over, steps, warm in ALSO_CASES:
+            a2 = argparse.Namespace(**dict(vars(args), **dict(over, steps=steps, warmup=warm)))
+            log("also: %s" % name)
+            try:
+                r, _ = run_case(a2, lib, ws, rank, local, probe_gbs)
+                also[name] = dict(value=r["value"], unit=r["unit"], ms_per_step=r["ms_per_step"],
+                                  ms_per_step_event_median=r["ms_per_step_event_median"], steps=steps, warmup=warm,
+                                  dtype=r["dtype"], workload=r["config"]["workload"],
+                                  shape={k: r["config"][k] for k in ("qa_pairs_per_gpu", "photos", "text_streams", "tokens", "hidden", "K", "T", "JQ")},
+                                  kernel_ms_per_step=r["kernel_ms_per_step"],
+                                  roofline_fracs=r["roofline_fracs"])
+            except Exception as exc:   # a side measurement must not take the headline down
+                also[name] = dict(error=repr(exc))
+                torch.cuda.empty_cache()
+        out["also"] = also
+        out["also_note"] = ("the other BASELINE.json configurations that fit one GPU, timed in this same invocation after the "
+                            "headline (short runs: steps / warm-up as listed); same code path, same timing method")
     if ws == 1 and not args.no_cpu_baseline and args.graph == "fvta":
         log('timing the CPU oracle (%d threads of %d host CPUs)' % (args.cpu_threads, host_cores()))
         out["cpu_baseline"] = cpu_baseline(kw, args.cpu_sample, args.forward_only, args.cpu_threads)

@@ -111,6 +111,7 @@ _SIGS = {
     "fvta_attn_read_u": (c_int, [POINTER(AttnDesc), P, P, P]),
     "fvta_test_gemm": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),
     "fvta_profile_enable": (c_int, [c_int32]),
+    "fvta_lstm_kernel_select": (c_int, [c_int32]),
     "fvta_profile_collect": (c_int, [c_int32, POINTER(ctypes.c_double), POINTER(c_int64)]),
 }
 

@@ -71,6 +71,9 @@ extern "C" int fvta_profile_enable(int32_t on) {
 
 // Sum of elapsed ms and launch count of every closed bracket of `id`; consumes them.
 namespace fvta { int wreg_read_stamp(int i, long long* v); }  // lstm_wreg.hip (diagnostics, -DFVTA_WREG_STAMP builds)
+namespace fvta { int wreg_set_mode(int mode); }  // lstm_wreg.hip
+
+extern "C" int fvta_lstm_kernel_select(int32_t mask) { return fvta::wreg_set_mode(mask); }
 
 extern "C" int fvta_profile_collect(int32_t id, double* total_ms, int64_t* launches) {
   FVTA_CHECK_ARG(total_ms && launches, "profile_collect: null pointer");

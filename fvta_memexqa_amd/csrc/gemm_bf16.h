@@ -52,14 +52,18 @@ __device__ __forceinline__ void wait_vmcnt() {
 // 64 x 128 either way (TM = 2 MFMA row tiles: 6 LDS fragments per 8 MFMAs); the wider block tile re-reads the A operand
 // half as often.  WM < 4 wave rows: block tiles of 64 / 128 rows for calls with few sequences (the photo cell's backward
 // step: a step is then a chain of K/32 k-tiles whose length is the DMA wave-instructions per k-tile).
-template <int WN, int TM_ = 2, int WM_ = 8 / TM_, int ST_ = 3>
+// BK_ = k extent of a ring stage: 32 (64-byte rows; 1 KiB DMA pieces of 16 rows) or 64 (128-byte rows: a DMA piece is 8
+// rows x one whole 128-byte line -- the CU's address unit takes a wave-instruction per ~31 cycles whatever it touches, but a
+// piece of 16 half lines costs it more; row images only).
+template <int WN, int TM_ = 2, int WM_ = 8 / TM_, int ST_ = 3, int BK_ = 32>
 struct TileCfgT {
   static_assert(TM_ == 2, "wave tile: two MFMA row tiles");
+  static_assert(BK_ == 32 || BK_ == 64, "stage depth");
   static constexpr int TM = TM_, WAVES_M = WM_, NWAVES = WAVES_M * WN;
   // ST_ = ring depth.  A k-loop's tile rate is (tiles in flight) / (load latency) -- a lone k-loop does not fill the
   // CU's load path -- so the weight-gradient GEMM (one 256 x 256 workgroup per CU, 32 KB per stage) runs a deeper ring;
   // the backward step measured no faster with four stages, and the 256 x 128 tile needs two workgroups per CU to fit.
-  static constexpr int BM = 32 * TM_ * WM_, BN = 128 * WN, BK = 32, STAGES = ST_, NT = 64 * NWAVES;
+  static constexpr int BM = 32 * TM_ * WM_, BN = 128 * WN, BK = BK_, STAGES = ST_, NT = 64 * NWAVES;
   static constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;  // per stage
   static constexpr int STAGE_ELEMS = A_ELEMS + B_ELEMS;
   static constexpr int LDS_BYTES = STAGES * STAGE_ELEMS * 2;        // 73,728 (WN = 1)
@@ -69,9 +73,14 @@ struct TileCfgT {
 typedef TileCfgT<1> TileCfg;
 
 // ---- accumulators + fragment reads -------------------------------------------------------------
-template <int WN, int TM_ = 2, int WM_ = 8 / TM_, int ST_ = 3>
+// chunk (16 bytes) c of row r of a row image is stored at chunk c ^ row_swz<BK>(r)
+template <int BK>
+__device__ __forceinline__ constexpr int row_swz(int r) { return BK == 32 ? ((r >> 2) & 3) : ((r >> 1) & 7); }
+
+template <int WN, int TM_ = 2, int WM_ = 8 / TM_, int ST_ = 3, int BK_ = 32>
 struct MmaBT {
-  typedef TileCfgT<WN, TM_, WM_, ST_> Cfg;
+  typedef TileCfgT<WN, TM_, WM_, ST_, BK_> Cfg;
+  static constexpr int BK = BK_;
   static constexpr int TM = TM_, TN = 4, WAVES_M = Cfg::WAVES_M, WAVES_N = 1, BM = Cfg::BM, BN = Cfg::BN;  // WAVES_N: per wave column
   static constexpr int WROWS = 32 * TM;  // rows of a wave tile
   f32x16 acc[TM][TN];
@@ -96,21 +105,21 @@ struct MmaBT {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  // row images, 64-byte rows, chunk c of row r stored at chunk c ^ ((r >> 2) & 3)
+  // row images, BK-element rows, chunk c of row r stored at chunk c ^ row_swz<BK>(r)
   __device__ __forceinline__ void compute_rows(const bf16_t* __restrict__ As, const bf16_t* __restrict__ Bs) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 16; ++ks) {
       Pack8 a[TM], b[TN];
       const int c = 2 * ks + hf;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int r = wave * WROWS + i * 32 + l31;
-        a[i].f = *reinterpret_cast<const f32x4*>(As + r * 32 + ((c ^ ((r >> 2) & 3)) << 3));
+        a[i].f = *reinterpret_cast<const f32x4*>(As + r * BK + ((c ^ row_swz<BK>(r)) << 3));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int r = wn * 128 + j * 32 + l31;
-        b[j].f = *reinterpret_cast<const f32x4*>(Bs + r * 32 + ((c ^ ((r >> 2) & 3)) << 3));
+        b[j].f = *reinterpret_cast<const f32x4*>(Bs + r * BK + ((c ^ row_swz<BK>(r)) << 3));
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -125,6 +134,7 @@ struct MmaBT {
     bf16x8_t a[TM], b[TN];
   };
   __device__ __forceinline__ void load_rows(const bf16_t* __restrict__ As, const bf16_t* __restrict__ Bs, int ks, Frags& f) const {
+    static_assert(BK == 32, "the software-pipelined loop is built for 32-deep stages");
     const int c = 2 * ks + hf;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -194,14 +204,15 @@ typedef MmaBT<1> MmaB;
 // U = 64n + lane -> row U>>2, physical chunk U&3, i.e. logical chunk (U&3) ^ ((row>>2)&3).
 // voff[j] (instruction n = wave*PER + j) = row * ld_bytes + 16 * logical chunk, or GLDS_OOB for rows
 // >= nrows.  The k position is added through the scalar offset at issue time.
-template <int PER>
+template <int PER, int BK = 32>
 struct RowSrc {
   unsigned voff[PER];
   __device__ __forceinline__ void setup(int wave, int lane, int row0, int nrows, unsigned ld_bytes) {
+    constexpr int CPR = BK / 8;  // 16-byte chunks per image row
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int U = (wave * PER + j) * 64 + lane;
-      const int row = U >> 2, c = (U & 3) ^ ((row >> 2) & 3);
+      const int row = U / CPR, c = (U % CPR) ^ row_swz<BK>(row);
       voff[j] = (row0 + row < nrows) ? (unsigned)(row0 + row) * ld_bytes + 16u * c : GLDS_OOB;
     }
   }
@@ -296,7 +307,7 @@ template <bool KMAJOR, class Mma, class Issue>
 __device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntiles, bf16_t* smem) {
   typedef typename Mma::Cfg TileCfg;
   constexpr int S = TileCfg::STAGES, G = TileCfg::A_GLDS + TileCfg::B_GLDS;
-  static_assert(S >= 3 && S <= 5, "ring depth");
+  static_assert(S >= 2 && S <= 5, "ring depth");
   auto a_stage = [&](int t) { return smem + (t % S) * TileCfg::STAGE_ELEMS; };
   if (ntiles <= 0) return;
 #pragma unroll

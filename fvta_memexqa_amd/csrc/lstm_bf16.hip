@@ -24,6 +24,14 @@ namespace fvta {
 
 static inline int pad8(int v) { return (v + 7) / 8 * 8; }
 
+template <int B, int E, class F>
+__device__ __forceinline__ void bf_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    bf_static_for<B + 1, E>(f);
+  }
+}
+
 template <class K>
 static void allow_big_lds(K kernel, int bytes) {  // > 64 KB of dynamic LDS must be opted into, per kernel symbol
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -211,10 +219,11 @@ void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s) {
 // WM < 4: block tiles of fewer rows (64 x 128 on ONE wave, 128 x 128 on two) for calls with few sequences -- the photo
 // cell's 64 rows: a step is then a chain of K/32 k-tiles whose length is the DMA wave-instructions per k-tile (A rows + B
 // rows, at ~40 clocks each whether or not the rows exist), 12 instead of 32.
-template <int WN, int WM = 4, int XM = 1>  // XM = 3: the split engine (three bf16 terms per operand value, fp32 saved gates)
+// BK = 64 (two stages): the wide tile's ring in whole-line DMA pieces (gemm_bf16.h)
+template <int WN, int WM = 4, int XM = 1, int BK = 32, int ST = 3>  // XM = 3: the split engine (three bf16 terms per operand value, fp32 saved gates)
 __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
-  typedef TileCfgT<WN, 2, WM> TileCfg;
-  typedef MmaBT<WN, 2, WM> MmaB;
+  typedef TileCfgT<WN, 2, WM, ST, BK> TileCfg;
+  typedef MmaBT<WN, 2, WM, ST, BK> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + (size_t)TileCfg::STAGES * TileCfg::STAGE_ELEMS);
   const int tid = (int)threadIdx.x, dir = blockIdx.z;
@@ -230,15 +239,15 @@ __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void 
   if (m0 < nnext) {
     const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + (trow + a.B) * (size_t)K, (unsigned)nnext * K * 2);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir] + (size_t)a.in_i * K, (unsigned)d * K * 2);  // the h rows of wb
-    RowSrc<TileCfg::A_GLDS> az;
-    RowSrc<TileCfg::B_GLDS> bw;
+    RowSrc<TileCfg::A_GLDS, BK> az;
+    RowSrc<TileCfg::B_GLDS, BK> bw;
     az.setup(mma.wave_all, mma.lane, m0, nnext, K * 2);
     bw.setup(mma.wave_all, mma.lane, u0, d, K * 2);
     auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
-      az.issue(rz, As, mma.wave_all, tile * 64);
-      bw.issue(rw, Bs, mma.wave_all, tile * 64);
+      az.issue(rz, As, mma.wave_all, tile * (BK * 2));
+      bw.issue(rw, Bs, mma.wave_all, tile * (BK * 2));
     };
-    glds_mainloop<false>(mma, issue, K / 32, smem_h);
+    glds_mainloop<false>(mma, issue, K / BK, smem_h);
   }
   __syncthreads();
   // ---- gate gradient with every global access 16 bytes of a row: each 32-row x 32-unit plane of dh goes through a
@@ -247,7 +256,7 @@ __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void 
   // eight-byte accesses the MFMA C layout would give (a wave stands ~124 cycles at every one, whatever its width:
   // tools/probes/store_issue_probe.hip).  Measured -1.7 %: the epilogue's 538 MB per launch sit on the HBM roof.
   constexpr int LDP = 36;  // floats per scratch row (32 + pad, keeps 16-byte alignment)
-  float* pl = reinterpret_cast<float*>(smem_h) + (size_t)mma.wave_all * (32 * LDP);
+  float* pl_ = reinterpret_cast<float*>(smem_h) + (size_t)mma.wave_all * (32 * LDP);
   const int io_row = mma.lane >> 3, io_c4 = mma.lane & 7;
   const float* __restrict__ cs_p = a.cs + (trow - a.B) * d;  // step t-1 (unused at t == 0)
   float* __restrict__ dcs = a.dc + (size_t)dir * a.B * d;
@@ -259,99 +268,105 @@ __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void 
     f32x4 g0, g1, g2, g3, cp, dout, dcv;  // g0, g1: packed bf16 gates of four units; split engine: g0..g3 fp32 gates, one unit each
   };
   auto ldnt = [](const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); };  // read once
-#pragma unroll
-  for (int ti = 0; ti < MmaB::TM; ++ti)
-#pragma unroll
-    for (int tj = 0; tj < MmaB::TN; ++tj) {
-      const int up = u0 + mma.wn * 128 + tj * 32;  // first unit of the plane
-      if (up >= d) continue;                        // (d is a multiple of 32: a plane is wholly inside or outside)
-      const int u = up + 4 * io_c4;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pl[((r & 3) + 8 * (r >> 2) + 4 * mma.hf) * LDP + mma.l31] = mma.acc[ti][tj][r];
-      wave_sync();
-      auto load_pass = [&](int it, In& in) {
-        const int lr = it * 8 + io_row, row = mma.wave * MmaB::WROWS + ti * 32 + lr;
-        const int ic = min(m0 + row, nact - 1);  // clamped: always a valid row
-        const int64_t oo = s_oo[min(row, nact - 1 - m0)];
-        if constexpr (XM == 1) {
-          const float* gp = reinterpret_cast<const float*>(a.gatesb + (trow + ic) * (size_t)N4 + 4 * u);
-          in.g0 = ldnt(gp);
-          in.g1 = ldnt(gp + 4);
-        } else {
-          const float* gp = a.gates32 + (trow + ic) * (size_t)N4 + 4 * u;
-          in.g0 = ldnt(gp);
-          in.g1 = ldnt(gp + 4);
-          in.g2 = ldnt(gp + 8);
-          in.g3 = ldnt(gp + 12);
-        }
-        in.cp = t > 0 ? ldnt(cs_p + (size_t)ic * d + u) : f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* dp = a.d_out + oo + u;
-        if ((reinterpret_cast<uintptr_t>(dp) & 15) == 0)
-          in.dout = ldnt(dp);
-        else
-          in.dout = f32x4{dp[0], dp[1], dp[2], dp[3]};  // an output row that is not 16-byte aligned
-        in.dcv = *reinterpret_cast<const f32x4*>(dcs + (size_t)ic * d + u);
-      };
-      auto do_pass = [&](int it, const In& in) {
-        const int lr = it * 8 + io_row, i = m0 + mma.wave * MmaB::WROWS + ti * 32 + lr;
-        const f32x4 dh4 = *reinterpret_cast<const f32x4*>(&pl[lr * LDP + 4 * io_c4]);
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 ga = __builtin_bit_cast(u32x4, in.g0), gb = __builtin_bit_cast(u32x4, in.g1);
-        u32x4 za, zb, la, lb;  // dz of the four units, packed bf16 (i, j | f, o); la / lb: the low terms (split engine)
-        f32x4 dco;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float ig, jg, fg, og;
-          if constexpr (XM == 1) {
-            const unsigned w0 = e < 2 ? ga[2 * e] : gb[2 * (e - 2)], w1 = e < 2 ? ga[2 * e + 1] : gb[2 * (e - 2) + 1];
-            ig = bf2f((bf16_t)(w0 & 0xffff)), jg = bf2f((bf16_t)(w0 >> 16)), fg = bf2f((bf16_t)(w1 & 0xffff)), og = bf2f((bf16_t)(w1 >> 16));
-          } else {
-            const f32x4 g4 = e == 0 ? in.g0 : (e == 1 ? in.g1 : (e == 2 ? in.g2 : in.g3));
-            ig = g4[0], jg = g4[1], fg = g4[2], og = g4[3];
-          }
-          const float dh = in.dout[e] + dh4[e];
-          const float tc = fvta_tanh(in.cp[e] * fg + ig * jg);
-          const float dc = in.dcv[e] + dh * og * (1.f - tc * tc);
-          const float dzi = dc * jg * ig * (1.f - ig), dzj = dc * ig * (1.f - jg * jg), dzf = dc * in.cp[e] * fg * (1.f - fg),
-                      dzo = dh * tc * og * (1.f - og);
-          const bf16_t hi_i = f2bf(dzi), hi_j = f2bf(dzj), hi_f = f2bf(dzf), hi_o = f2bf(dzo);
-          const unsigned z0 = (unsigned)hi_i | ((unsigned)hi_j << 16), z1 = (unsigned)hi_f | ((unsigned)hi_o << 16);
-          unsigned l0 = 0, l1 = 0;
-          if constexpr (XM == 3) {
-            l0 = (unsigned)f2bf(dzi - bf2f(hi_i)) | ((unsigned)f2bf(dzj - bf2f(hi_j)) << 16);
-            l1 = (unsigned)f2bf(dzf - bf2f(hi_f)) | ((unsigned)f2bf(dzo - bf2f(hi_o)) << 16);
-          }
-          if (e < 2) {
-            za[2 * e] = z0, za[2 * e + 1] = z1, la[2 * e] = l0, la[2 * e + 1] = l1;
-          } else {
-            zb[2 * (e - 2)] = z0, zb[2 * (e - 2) + 1] = z1, lb[2 * (e - 2)] = l0, lb[2 * (e - 2) + 1] = l1;
-          }
-          dco[e] = dc * fg;
-        }
-        if (i < nact) {
-          float* zp = reinterpret_cast<float*>(a.dzb + (trow + i) * (size_t)K + 4 * u);
-          *reinterpret_cast<f32x4*>(zp) = __builtin_bit_cast(f32x4, za);
-          *reinterpret_cast<f32x4*>(zp + 4) = __builtin_bit_cast(f32x4, zb);
-          if constexpr (XM == 3) {  // (hi, lo, hi) thirds of 4d bf16 = 2d floats
-            *reinterpret_cast<f32x4*>(zp + 2 * d) = __builtin_bit_cast(f32x4, la);
-            *reinterpret_cast<f32x4*>(zp + 2 * d + 4) = __builtin_bit_cast(f32x4, lb);
-            *reinterpret_cast<f32x4*>(zp + 4 * d) = __builtin_bit_cast(f32x4, za);
-            *reinterpret_cast<f32x4*>(zp + 4 * d + 4) = __builtin_bit_cast(f32x4, zb);
-          }
-          *reinterpret_cast<f32x4*>(dcs + (size_t)i * d + u) = dco;
-        }
-      };
-      In in0, in1;  // two passes' loads in flight
-      load_pass(0, in0);
-      load_pass(1, in1);
-      do_pass(0, in0);
-      load_pass(2, in0);
-      do_pass(1, in1);
-      load_pass(3, in1);
-      do_pass(2, in0);
-      do_pass(3, in1);
-      wave_sync();  // the plane's reads are done before the next plane overwrites the scratch
+  // The wave tile's TM x TN planes of four passes each form ONE sequence of passes; the loads of pass P + EPD are requested
+  // when pass P is done, also across plane boundaries (the loads do not depend on the plane's scratch): EPD passes of
+  // 5 KB are in flight per wave all through the epilogue.
+#ifndef FVTA_BWD_EPD
+#define FVTA_BWD_EPD 2
+#endif
+  constexpr int EPD = FVTA_BWD_EPD, NPASS = MmaB::TM * MmaB::TN * 4;
+  auto plane_u = [&](int pl) { return u0 + mma.wn * 128 + (pl % MmaB::TN) * 32 + 4 * io_c4; };
+  auto load_pass = [&](int P, In& in) {
+    const int pl = P >> 2, it = P & 3, ti = pl / MmaB::TN;
+    const int u = plane_u(pl);
+    const int lr = it * 8 + io_row, row = mma.wave * MmaB::WROWS + ti * 32 + lr;
+    const int ic = min(m0 + row, nact - 1);  // clamped: always a valid row
+    const int64_t oo = s_oo[min(row, nact - 1 - m0)];
+    const int uc = min(u, d - 4);            // (a plane past the last unit: loads a valid address, stores nothing)
+    if constexpr (XM == 1) {
+      const float* gp = reinterpret_cast<const float*>(a.gatesb + (trow + ic) * (size_t)N4 + 4 * uc);
+      in.g0 = ldnt(gp);
+      in.g1 = ldnt(gp + 4);
+    } else {
+      const float* gp = a.gates32 + (trow + ic) * (size_t)N4 + 4 * uc;
+      in.g0 = ldnt(gp);
+      in.g1 = ldnt(gp + 4);
+      in.g2 = ldnt(gp + 8);
+      in.g3 = ldnt(gp + 12);
     }
+    in.cp = t > 0 ? ldnt(cs_p + (size_t)ic * d + uc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* dp = a.d_out + oo + uc;
+    if ((reinterpret_cast<uintptr_t>(dp) & 15) == 0)
+      in.dout = ldnt(dp);
+    else
+      in.dout = f32x4{dp[0], dp[1], dp[2], dp[3]};  // an output row that is not 16-byte aligned
+    in.dcv = *reinterpret_cast<const f32x4*>(dcs + (size_t)ic * d + uc);
+  };
+  auto do_pass = [&](int P, const In& in) {
+    const int pl = P >> 2, it = P & 3, ti = pl / MmaB::TN;
+    const int u = plane_u(pl);
+    const int lr = it * 8 + io_row, i = m0 + mma.wave * MmaB::WROWS + ti * 32 + lr;
+    const f32x4 dh4 = *reinterpret_cast<const f32x4*>(&pl_[lr * LDP + 4 * io_c4]);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 ga = __builtin_bit_cast(u32x4, in.g0), gb = __builtin_bit_cast(u32x4, in.g1);
+    u32x4 za, zb, la, lb;  // dz of the four units, packed bf16 (i, j | f, o); la / lb: the low terms (split engine)
+    f32x4 dco;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float ig, jg, fg, og;
+      if constexpr (XM == 1) {
+        const unsigned w0 = e < 2 ? ga[2 * e] : gb[2 * (e - 2)], w1 = e < 2 ? ga[2 * e + 1] : gb[2 * (e - 2) + 1];
+        ig = bf2f((bf16_t)(w0 & 0xffff)), jg = bf2f((bf16_t)(w0 >> 16)), fg = bf2f((bf16_t)(w1 & 0xffff)), og = bf2f((bf16_t)(w1 >> 16));
+      } else {
+        const f32x4 g4 = e == 0 ? in.g0 : (e == 1 ? in.g1 : (e == 2 ? in.g2 : in.g3));
+        ig = g4[0], jg = g4[1], fg = g4[2], og = g4[3];
+      }
+      const float dh = in.dout[e] + dh4[e];
+      const float tc = fvta_tanh(in.cp[e] * fg + ig * jg);
+      const float dc = in.dcv[e] + dh * og * (1.f - tc * tc);
+      const float dzi = dc * jg * ig * (1.f - ig), dzj = dc * ig * (1.f - jg * jg), dzf = dc * in.cp[e] * fg * (1.f - fg),
+                  dzo = dh * tc * og * (1.f - og);
+      const bf16_t hi_i = f2bf(dzi), hi_j = f2bf(dzj), hi_f = f2bf(dzf), hi_o = f2bf(dzo);
+      const unsigned z0 = (unsigned)hi_i | ((unsigned)hi_j << 16), z1 = (unsigned)hi_f | ((unsigned)hi_o << 16);
+      unsigned l0 = 0, l1 = 0;
+      if constexpr (XM == 3) {
+        l0 = (unsigned)f2bf(dzi - bf2f(hi_i)) | ((unsigned)f2bf(dzj - bf2f(hi_j)) << 16);
+        l1 = (unsigned)f2bf(dzf - bf2f(hi_f)) | ((unsigned)f2bf(dzo - bf2f(hi_o)) << 16);
+      }
+      if (e < 2) {
+        za[2 * e] = z0, za[2 * e + 1] = z1, la[2 * e] = l0, la[2 * e + 1] = l1;
+      } else {
+        zb[2 * (e - 2)] = z0, zb[2 * (e - 2) + 1] = z1, lb[2 * (e - 2)] = l0, lb[2 * (e - 2) + 1] = l1;
+      }
+      dco[e] = dc * fg;
+    }
+    if (i < nact && u < d) {
+      float* zp = reinterpret_cast<float*>(a.dzb + (trow + i) * (size_t)K + 4 * u);
+      *reinterpret_cast<f32x4*>(zp) = __builtin_bit_cast(f32x4, za);
+      *reinterpret_cast<f32x4*>(zp + 4) = __builtin_bit_cast(f32x4, zb);
+      if constexpr (XM == 3) {  // (hi, lo, hi) thirds of 4d bf16 = 2d floats
+        *reinterpret_cast<f32x4*>(zp + 2 * d) = __builtin_bit_cast(f32x4, la);
+        *reinterpret_cast<f32x4*>(zp + 2 * d + 4) = __builtin_bit_cast(f32x4, lb);
+        *reinterpret_cast<f32x4*>(zp + 4 * d) = __builtin_bit_cast(f32x4, za);
+        *reinterpret_cast<f32x4*>(zp + 4 * d + 4) = __builtin_bit_cast(f32x4, zb);
+      }
+      *reinterpret_cast<f32x4*>(dcs + (size_t)i * d + u) = dco;
+    }
+  };
+  In ins[EPD];
+  bf_static_for<0, EPD>([&](auto P_c) { load_pass(decltype(P_c)::value, ins[decltype(P_c)::value]); });
+  bf_static_for<0, NPASS>([&](auto P_c) {  // (compile-time indices: the pass buffers stay in registers)
+    constexpr int P = decltype(P_c)::value;
+    if constexpr ((P & 3) == 0) {  // a new plane: its 32 x 32 accumulators -> scratch, row-contiguous
+      constexpr int pl = P >> 2, ti = pl / MmaB::TN, tj = pl % MmaB::TN;
+      if constexpr (P != 0) wave_sync();  // the previous plane's reads are done
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pl_[((r & 3) + 8 * (r >> 2) + 4 * mma.hf) * LDP + mma.l31] = mma.acc[ti][tj][r];
+      wave_sync();
+    }
+    do_pass(P, ins[P % EPD]);
+    if constexpr (P + EPD < NPASS) load_pass(P + EPD, ins[P % EPD]);
+  });
 }
 
 template <int XM>
@@ -370,6 +385,16 @@ static void launch_bwd_fused_xm(const FusedBwdArgs& a, hipStream_t s) {
     // tiles: a launch lasts as long as one workgroup's chain of 64 k-tiles plus its epilogue, and the 256 x 128 tiles, two
     // workgroups per CU, spread the same rows over twice as many (ragged batches: 7.06 -> 6.74 ms per step; dense
     // batches keep the wide tile: 5.48 vs 5.72 ms per backward)
+#ifndef FVTA_BWD_BK
+#define FVTA_BWD_BK 64
+#endif
+    constexpr int BK = FVTA_BWD_BK, ST = BK == 64 ? 2 : 3;
+    if ((4 * a.d * XM) % BK == 0) {
+      constexpr int LDS = TileCfgT<2, 2, 4, ST, BK>::LDS_BYTES + 256 * 8;
+      allow_big_lds(lstm_bwd_fused_bf16<2, 4, XM, BK, ST>, LDS);
+      hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4, XM, BK, ST>), dim3(pad8((a.B + 255) / 256), a.d / 256, 2), dim3(512), LDS, s, a);
+      return;
+    }
     constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
     allow_big_lds(lstm_bwd_fused_bf16<2, 4, XM>, LDS);
     hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4, XM>), dim3(pad8((a.B + 255) / 256), a.d / 256, 2), dim3(512), LDS, s, a);

@@ -258,14 +258,19 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
   float* c_base = a.cs ? a.cs + trow * (size_t)d : a.cstate + (size_t)dir * a.B * d;
   f32x4 cp_next[C::PASSES], cp_cur[C::PASSES];
   int64_t oo_cur[C::PASSES];
+  // (the plan is read-only here: through the constant address space its wave-uniform reads ARE scalar loads; as plain
+  //  global reads the compiler made them vector loads -- 8 of a row tile's ~32 vector-memory instructions, and the CU's
+  //  address unit takes one wave-instruction per ~31 cycles whatever its width)
+  typedef const int64_t __attribute__((address_space(4)))* const_i64_ptr;
+  const const_i64_ptr oo_c = (const_i64_ptr)(a.plan.oo + trow);
   auto prev_rows = [&](int m0p) {  // output offsets of the previous tile's rows: wave-uniform addresses, scalar cache
 #pragma unroll
     for (int p = 0; p < C::PASSES; ++p) {
       const int i0 = m0p + C::RW * wave + C::RPP * p;
-      int64_t o = a.plan.oo[trow + min(i0, a.B - 1)];
+      int64_t o = oo_c[min(i0, a.B - 1)];
 #pragma unroll
       for (int j = 1; j < C::RPP; ++j) {
-        const int64_t oj = a.plan.oo[trow + min(i0 + j, a.B - 1)];
+        const int64_t oj = oo_c[min(i0 + j, a.B - 1)];
         o = (e_rsub == j) ? oj : o;
       }
       oo_cur[p] = o;
@@ -539,13 +544,20 @@ static int wreg_cus() {
 // waves per workgroup of the configuration a shape runs on
 // column tiles per wave for a shape, 0: not built
 // FVTA_LSTM_WREG (A/B measurements): bit 0 the weights-stationary forward, bit 1 the weights-stationary backward of steps
-// with few rows; default 3, 0: the tiled step kernels for every shape
+// with few rows, bit 2 the pipelined weights-stationary backward (d = 512, every row count); default 7, 0: the tiled step
+// kernels for every shape
+static int g_wreg_override = -1;  // fvta_lstm_kernel_select (tests, A/B measurements)
 int wreg_mode() {
-  static const int mode = [] {
+  static const int env_mode = [] {
     const char* e = getenv("FVTA_LSTM_WREG");
-    return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 3;
+    return (e && e[0] >= '0' && e[0] <= '7') ? e[0] - '0' : 7;
   }();
-  return mode;
+  return g_wreg_override >= 0 ? g_wreg_override : env_mode;
+}
+int wreg_set_mode(int mode) {
+  const int prev = wreg_mode();
+  g_wreg_override = mode < 0 ? -1 : (mode & 7);
+  return prev;
 }
 
 int wreg_nct(int in_i, int d) {

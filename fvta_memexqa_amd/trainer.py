@@ -153,12 +153,16 @@ class Trainer:
             self.opt.state = state
             if hasattr(self.opt, "t"):
                 self.opt.t = m.global_step           # beta powers = beta ** global_step (one apply per step)
+                # AdamOptimizer initialises beta1_power to beta1 and multiplies it once per apply (_finish): after k
+                # applies the file holds beta1 ** (k + 1).  AdamW.step does t += 1 before it uses beta ** t, so the
+                # resumed count is k = (exponent - 1).  A float32 power below ~1e-37 is denormal (no longer a clean
+                # power of beta1): keep global_step there.
                 b1p = slots.get("beta1_power", {}).get("")
-                if b1p is not None and 0.0 < float(b1p) < 1.0:
+                if b1p is not None and 1e-37 < float(b1p) < 1.0:
                     import math
-                    t = int(round(math.log(float(b1p)) / math.log(self.opt.b1)))    # AdamOptimizer's own count
-                    if abs(self.opt.b1 ** t - float(b1p)) > 1e-3 * float(b1p):
+                    e = int(round(math.log(float(b1p)) / math.log(self.opt.b1)))
+                    if e < 1 or abs(self.opt.b1 ** e - float(b1p)) > 1e-3 * float(b1p):
                         raise ValueError("checkpoint %s: beta1_power %g is not a power of beta1 = %g" %
                                          (path, float(b1p), self.opt.b1))
-                    self.opt.t = t
+                    self.opt.t = e - 1
         return found == len(self.opt.SLOTS)

@@ -461,6 +461,13 @@ int fvta_test_gemm(int32_t precision, int32_t layout, int32_t M, int32_t N, int3
 #define FVTA_PROF_LSTM_DX 6       /* lstm_dx_bf16: the input gradient of all steps, one launch (bf16 engine) */
 int fvta_profile_enable(int32_t on);
 int fvta_profile_collect(int32_t id, double* total_ms, int64_t* launches);
+/* Test / measurement hook: which bi-LSTM step kernels the bf16 engine may use -- bit 0 the weights-stationary forward
+ * (lstm_fwd_wreg_bf16), bit 1 the weights-stationary backward of steps with few rows (lstm_bwd_wreg_bf16), bit 2 the
+ * pipelined weights-stationary backward (lstm_bwd_ring_bf16, d = 512); 0 = the tiled kernels for every shape; a negative
+ * mask returns to the default (the FVTA_LSTM_WREG environment variable, else every bit set).  Returns the previous mask.
+ * Every choice computes the same step (model_v2.py:652-661, 694-823); results differ in the last bits (summation order).
+ * Process-wide, not thread-safe.  Not part of the reference surface. */
+int fvta_lstm_kernel_select(int32_t mask);
 /* Measurement hook (bench.py, SURVEY 8d "achievable peak"): one read-only, fully coalesced, non-temporal pass over
  * `bytes` of device memory; the caller times it.  Not part of the reference surface. */
 int fvta_probe_hbm_read(const void* buf, size_t bytes, float* sink, fvta_stream_t stream);

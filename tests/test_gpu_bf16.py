@@ -35,11 +35,14 @@ def test_mfma_bf16_gemm_layouts(layout, shape):
     _close(C, ref, rtol=1e-5, atol=1e-4 * K ** 0.5)
 
 
-# (the last four shapes run the weights-in-registers forward step kernel, csrc/lstm_wreg.hip: in_i / d = 128 / 128,
-#  224 / 512, 224 / 512 with separate fw / bw kernels, 32 / 128 with a ragged tail tile; the others the tiled one)
+# (shapes 3-6 run the weights-in-registers forward step kernel, csrc/lstm_wreg.hip: in_i / d = 128 / 128,
+#  224 / 512, 224 / 512 with separate fw / bw kernels, 32 / 128 with a ragged tail tile; the first two the tiled one.
+#  Every d = 512 shape runs the pipelined backward step lstm_bwd_ring_bf16; the last two give its workgroups two and
+#  three row tiles each -- both exits of the loop unrolled by two -- with a ragged / a dense tail)
 @pytest.mark.parametrize("B,J,din,d,dense,share", [(5, 6, 8, 32, False, True), (300, 9, 16, 64, False, False),
                                                    (130, 7, 104, 128, True, True), (64, 30, 200, 512, False, True),
-                                                   (70, 6, 200, 512, False, False), (33, 5, 12, 128, False, True)])
+                                                   (70, 6, 200, 512, False, False), (33, 5, 12, 128, False, True),
+                                                   (1500, 4, 200, 512, False, True), (1030, 3, 100, 512, True, False)])
 def test_bilstm_bf16_forward_backward(B, J, din, d, dense, share):
     from fvta_memexqa_amd import ops
     from oracle import fvta_fused as F
@@ -251,3 +254,40 @@ def test_model_bf16x3_train_step_at_the_metric_shape_meets_the_fp32_tolerances()
     for k, v in p64.items():
         if v.grad is not None:
             close(grads[k].reshape(v.grad.shape), v.grad, "grad " + k, 2e-4, 5e-5)
+
+
+@pytest.mark.parametrize("B,J,din,dense", [(2100, 5, 200, False), (1500, 3, 100, True), (40, 7, 200, False)])
+def test_bilstm_bf16_backward_step_kernels_agree(B, J, din, dense):
+    """The pipelined weights-stationary backward step (lstm_bwd_ring_bf16, d = 512) against the tiled one
+    (lstm_bwd_fused_bf16) on the same saved state: the two differ in the summation order of dh_rec only (four partial
+    sums per output), so dz agrees up to rounding flips of single bf16 values -- gradients within 2e-3 relative L2, far
+    inside what a stale operand tile (a mis-counted hand-over) would do.  The pipelined kernel twice: bitwise."""
+    from fvta_memexqa_amd import _lib, ops
+    lib = _lib.load()
+    d = 512
+    g = torch.Generator().manual_seed(B + J)
+    x = torch.randn(B, J, din, generator=g).cuda()
+    lens = torch.full((B,), J) if dense else torch.randint(0, J + 1, (B,), generator=g)
+    lim = (6.0 / (din + 5 * d)) ** 0.5
+    kf = ((torch.rand(din + d, 4 * d, generator=g) * 2 - 1) * lim).cuda()
+    bf = (torch.randn(4 * d, generator=g) * 0.1).cuda()
+    mask = torch.arange(J)[None, :] < lens[:, None]
+    g_out = (torch.randn(B, J, 2 * d, generator=g) * mask[:, :, None]).cuda()
+    out, last, op = ops.bilstm_simple(x, lens, kf, bf, None, None, training=True, precision=BF16)
+    res = {}
+    prev = lib.fvta_lstm_kernel_select(-1)
+    try:
+        for name, mode in (("ring", 7), ("tiled", 1), ("ring2", 7)):
+            lib.fvta_lstm_kernel_select(mode)
+            dx, dk, db = torch.zeros_like(x), torch.zeros_like(kf), torch.zeros_like(bf)
+            op.backward(x, out, g_out, kf, None, dx, dk, db, None, None)
+            torch.cuda.synchronize()
+            res[name] = (dx, dk, db)
+    finally:
+        lib.fvta_lstm_kernel_select(-1 if prev == 7 else prev)
+    for a, b in zip(res["ring"], res["ring2"]):
+        if a is not res["ring"][0]:        # (dx meets its two directions with float atomics: order-dependent last bits)
+            assert torch.equal(a, b)
+    for name, a, b in zip(("dx", "dkernel", "dbias"), res["ring"], res["tiled"]):
+        err = ((a - b).double().norm() / (b.double().norm() + 1e-30)).item()
+        assert err < 2e-3, "%s: pipelined vs tiled backward step differ by %.5f (relative L2)" % (name, err)

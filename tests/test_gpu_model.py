@@ -474,6 +474,35 @@ def test_trainer_checkpoint_resume_continues_bitwise(tmp_path, optimizer):
         other.restore(str(tmp_path))
 
 
+def test_restore_adam_step_count_from_beta1_power(tmp_path):
+    """tf.train.AdamOptimizer keeps beta1_power = beta1 ** (applies + 1) (initialised to beta1, multiplied once per
+    apply): a checkpoint written after k applies resumes with opt.t == k -- the next step corrects with beta ** (k + 1),
+    as TensorFlow's would -- whatever global_step says; a denormal power falls back to global_step."""
+    from fvta_memexqa_amd import tf_checkpoint as tc
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import SynthSpec, make_inputs, make_params
+    from fvta_memexqa_amd.trainer import Trainer
+    spec = SynthSpec(N=4, A=1, P=3, S=2, L=5, d=20, dense=False, text_in=12, img_in=8)
+    cfg = dict(spec.cfg(), batch_size=spec.N, init_lr=0.001, optimizer="adam")
+    m1 = Model(cfg, scope="model_memoryqa", text_in=spec.text_in, img_in=spec.img_in)
+    m1.set_oracle_params(make_params(spec))
+    t1 = Trainer(m1, cfg)
+    t1.step(None, (None, dict(make_inputs(spec), num_examples=4)))      # (creates the slot buffers)
+    b1 = t1.opt.b1
+    for k, b1p, want in ((5, np.float32(b1 ** 6), 5), (0, np.float32(b1), 0), (900, np.float32(b1 ** 901), 7)):
+        tensors = {"%s/%s" % (m1.scope, n): v for n, v in m1.get_weights().items()}
+        for slot, flat in zip(t1.opt.SLOTS, t1.opt.state):
+            tensors.update({"%s/%s/%s" % (m1.scope, n, slot): v for n, v in m1.get_weights(flat=flat).items()})
+        tensors["%s/global_step" % m1.scope] = np.int64(7)
+        tensors["beta1_power"] = b1p
+        tensors["beta2_power"] = np.float32(0.999 ** (k + 1))
+        d = tmp_path / ("save%d" % k)
+        tc.write_checkpoint(str(d / "model-7"), tensors)
+        m2 = Model(cfg, scope="model_memoryqa", text_in=spec.text_in, img_in=spec.img_in)
+        t2 = Trainer(m2, cfg)
+        assert t2.restore_tf_checkpoint(str(d)) and t2.opt.t == want, (k, t2.opt.t)
+
+
 def test_restore_from_tf_checkpoint_files(tmp_path):
     """main.py:640-665: a V2 checkpoint under the reference's variable names (model + Adadelta slots + global_step, as its
     Saver writes them) restores into Model / Trainer and continues like the run that wrote it.  The files come from

@@ -130,3 +130,24 @@ def test_tf_checkpoint_reader_rejects_corruption(tmp_path):
         tc.read_checkpoint(prefix)
     e = tc._parse_entry(tc._entry_proto(tensors["m/a"], 0, 0) + tc._field(7, 2, tc._put_varint(0)))
     assert e["slices"] == 1
+
+
+def test_bench_gpus_n_without_launcher_never_reports_one_rank():
+    """`python bench.py --gpus 2` started plainly must either run two ranks (it spawns them itself, before the parent
+    touches the GPU) or fail: a line that says n_gpus 1 for a --gpus 2 request would let a scaling record measure one GPU
+    seven times.  Here (no GPU) the spawned ranks fail -> non-zero exit, nothing on stdout."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert all(l.get("n_gpus") == 2 for l in lines)
+    assert lines or r.returncode != 0
+    # a launcher's world size that contradicts --gpus is refused too
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                        env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and not [l for l in r2.stdout.splitlines() if l.startswith("{")]

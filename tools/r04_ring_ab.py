@@ -1,0 +1,40 @@
+"""Times the text-cell bi-LSTM backward STEP launches alone (the library's HIP-event bracket FVTA_PROF_LSTM_STEP_BWD) at
+the metric shape, plus dx and dW, for the library named by FVTA_LIB_PATH / the kernel set of FVTA_LSTM_WREG.
+  python tools/r04_ring_ab.py [B J din d [ragged]]"""
+import ctypes, os, sys, time, torch
+sys.path.insert(0, os.getcwd())
+from fvta_memexqa_amd import _lib, ops
+B, J, din, d = (int(v) for v in (sys.argv[1:5] if len(sys.argv) > 4 else (12864, 30, 200, 512)))
+dense = not (len(sys.argv) > 5 and sys.argv[5] == "ragged")
+lib = _lib.load()
+g = torch.Generator(device="cuda").manual_seed(0)
+x = torch.randn(B, J, din, device="cuda", generator=g)
+lens = torch.full((B,), J) if dense else torch.randint(0, J + 1, (B,), generator=torch.Generator().manual_seed(1))
+k = (torch.rand(din + d, 4 * d, device="cuda", generator=g) * 2 - 1) * 0.05
+b = torch.randn(4 * d, device="cuda", generator=g) * 0.1
+ar = torch.arange(B, dtype=torch.int64)
+op = ops.BiLstm(B, J, din, d, ar * J * din, ar * J * 2 * d, torch.full((B,), J, dtype=torch.int32), 2 * d,
+                share_fw_bw=True, precision=1, training=True)
+op.make_plan(lens)
+out = torch.zeros(B, J, 2 * d, device="cuda")
+dout = torch.randn(B, J, 2 * d, device="cuda", generator=g)
+dx = torch.zeros_like(x); dk = torch.zeros_like(k); db = torch.zeros_like(b)
+op.forward(x, out, k, b)
+run = lambda: op.backward(x, out, dout, k, None, dx, dk, db)
+for _ in range(2): run()
+torch.cuda.synchronize()
+lib.fvta_profile_enable(1)
+n = 5
+t0 = time.perf_counter()
+for _ in range(n): run()
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / n * 1e3
+lib.fvta_profile_enable(0)
+def collect(pid):
+    ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+    lib.fvta_profile_collect(pid, ctypes.byref(ms), ctypes.byref(cnt))
+    return ms.value / n, cnt.value // n
+s_ms, s_n = collect(2)
+print("lib=%s WREG=%s: step %.3f ms (%d launches, %.1f us each)  dx %.3f  dW %.3f  wall %.3f  finite %s" % (
+    os.path.basename(os.environ.get("FVTA_LIB_PATH", "product")), os.environ.get("FVTA_LSTM_WREG", "-"), s_ms, s_n,
+    1e3 * s_ms / max(1, s_n), collect(6)[0], collect(3)[0], wall, bool(torch.isfinite(dk).all())))
