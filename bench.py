@@ -436,6 +436,7 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     for k in order[1:]:
         out["roofline_" + k] = roofs[k]
     out["roofline_fracs"] = {k: [roofs[k]["frac"], roofs[k]["bound"]] for k in order}   # every bracketed kernel, dominant first
+    out["side_stream_ratio"] = round(float(getattr(model, "side_stream_ratio", 0.0)), 3)   # < 1.4: the photo cell's stream runs beside the main one
     out.update(process_group=pg, rank_seconds=[round(v, 4) for v in rank_elapsed], kernel_ms_per_step=kms,
                kernel_ms_note="HIP-event brackets on the launch streams, over a second pass of the same %d steps right after the "
                               "timed region (the timed region itself carries no brackets)" % args.steps)
@@ -462,6 +463,10 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)          # never returns
+    # stdout carries ONE JSON line: whatever a C library prints there (RCCL's version banner, flushed at exit) goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     from fvta_memexqa_amd import _lib, dist
 
@@ -505,7 +510,10 @@ def main():
                         and not args.time_warp)
     if ws == 1 and (args.also == "on" or (args.also == "auto" and default_headline)):
         also = {}
+        only = [v for v in os.environ.get("FVTA_BENCH_ALSO", "").split(",") if v]      # (diagnostics: a subset of the cases)
         for name, over, steps, warm in ALSO_CASES:
+            if only and name not in only:
+                continue
             a2 = argparse.Namespace(**dict(vars(args), **dict(over, steps=steps, warmup=warm)))
             log("also: %s" % name)
             try:
@@ -514,7 +522,7 @@ def main():
                                   ms_per_step_event_median=r["ms_per_step_event_median"], steps=steps, warmup=warm,
                                   dtype=r["dtype"], workload=r["config"]["workload"],
                                   shape={k: r["config"][k] for k in ("qa_pairs_per_gpu", "photos", "text_streams", "tokens", "hidden", "K", "T", "JQ")},
-                                  kernel_ms_per_step=r["kernel_ms_per_step"],
+                                  kernel_ms_per_step=r["kernel_ms_per_step"], side_stream_ratio=r["side_stream_ratio"],
                                   roofline_fracs=r["roofline_fracs"])
             except Exception as exc:   # a side measurement must not take the headline down
                 also[name] = dict(error=repr(exc))
@@ -527,7 +535,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(kw, args.cpu_sample, args.forward_only, args.cpu_threads)
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out), flush=True)
+    json_out.write(json.dumps(out) + "\n")
+    json_out.flush()
     dist.shutdown()
 
 

@@ -219,6 +219,7 @@ class Model:
         late = {n for n in specs if "/utext/" in n} | self._plain      # text cell; embeddings and photo transform (off dx)
         self.params = ParamStore(specs, self.dev, late=late)
         self.early_work = None      # pending all-reduce of the early gradient bucket (data parallelism), see backward()
+        self.early_allreduce = bool(_cfg(config, "early_allreduce", False))
         self.init_parameters(int(_cfg(config, "weight_seed", 42)))
         self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self.dev)
 
@@ -932,10 +933,14 @@ class Model:
                         ops.dropout_pair_bwd(G.dx2, G.dx, self.keep_prob, G.drop_seed)
                 else:
                     G.op.backward(G.x, L.arena, L.d_arena, kf, kb, G.dx if need_dx else None, dkf, dbf, dkb, dbb)
-                if side is not None and not self.wd:
-                    # data parallelism: everything in [0, early_numel) of the flat gradient -- scorer, attention(s),
-                    # time warp, photo cell -- is final in THIS stream's order now; start its all-reduce on RCCL's
-                    # stream while the text cell's recurrence (enqueued next, on the main stream) runs
+                if side is not None and not self.wd and self.early_allreduce:
+                    # data parallelism, `early_allreduce=True` only: everything in [0, early_numel) of the flat gradient --
+                    # scorer, attention(s), time warp, photo cell -- is final in THIS stream's order now; start its
+                    # all-reduce on RCCL's stream while the text cell's recurrence (enqueued next, on the main stream)
+                    # runs.  OFF by default: measured with one RCCL rank (tools/r04_rccl_probe.py), a collective in flight
+                    # beside the recurrence costs the step 0.7 ms (14.0 vs 13.3 ms) -- more than the whole 12 MB bucket
+                    # costs on the wire -- while ONE all-reduce of the whole bucket after the backward costs nothing
+                    # measurable (13.33 vs 13.32 ms with the collectives stubbed out)
                     from . import dist
                     self.early_work = dist.allreduce_async(P.grad[:P.early_numel])
         main.wait_stream(self._side)            # both cells' gradients are in params.grad
