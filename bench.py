@@ -336,7 +336,7 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     # bf16 products per logical one)
     peak_tf, hw_mult = (PEAK_BF16_TFLOPS, 3.0 if args.precision == "bf16x3" else 1.0) if is_bf else (PEAK_F32_TFLOPS, 1.0)
     wreg_fwd = args.precision == "bf16" and (dp, in_i) in ((512, 224), (512, 128), (1024, 224), (1024, 128), (128, 128), (128, 32))
-    ring_bwd = args.precision == "bf16" and dp == 512
+    ring_bwd = args.precision == "bf16" and dp == 512 and int((lens > 0).sum().item()) <= 8192   # (lstm_wreg_bwd.hip RING_MAX_ROWS)
     dense_metric = args.config == "metric" and args.variant == "dense" and not args.batch and args.graph == "fvta" and args.precision == "bf16"
     roofs = {}
 

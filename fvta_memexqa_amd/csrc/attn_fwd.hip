@@ -1465,15 +1465,18 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G_a
   auto wait_flag = [&](int* flag, int want) {  // bounded poll of an LDS word
     volatile lds_int* f = (volatile lds_int*)flag;
     bool arrived = false;
-    for (int spin = 0; spin < (1 << 22); ++spin) {
+    // (the partner wave is resident in this very workgroup: it can only be DELAYED -- counter collection serialising waves,
+    //  pre-emption, a debugger -- so the bound is generous: 2^28 polls of s_sleep 2, tens of seconds)
+    for (int spin = 0; spin < (1 << 28); ++spin) {
       if (*f >= want) {
         arrived = true;
         break;
       }
       __builtin_amdgcn_s_sleep(2);
     }
-    // a partner that never arrives is a bug (or a wedged wave): fail the launch -- the host sees a launch error at its
-    // next call -- rather than fall through and fold stale partials into amax / jmax / h_a
+    // a partner that never arrives is a bug (a wedged wave).  The trap aborts the queue -- on ROCm that usually ends the
+    // process, it is NOT a recoverable launch error -- which is still better than folding stale partials into amax /
+    // jmax / h_a and training on them
     if (!arrived) __builtin_trap();
     // acquire: the partner's published area (plain LDS loads below) is read only after the poll has matched; workgroup
     // scope lowers to s_waitcnt lgkmcnt(0) and, unlike an empty asm, is a compiler fence for __shared__ accesses too
@@ -2009,6 +2012,10 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
     const int nwg = s.N * G;
     const dim3 grid(((nwg + 7) / 8) * 8);
     const int rmode = s.simi == 1 ? 1 : (s.simi == 3 ? 3 : 2);
+    // NOTE on rounding: with the table an album's workgroup count -- hence the split points of its partial sums, hence
+    // the fp32 rounding of its h_a (nothing else: arg-max positions and logits do not move) -- depends on the OTHER albums
+    // of the batch.  The same batch always gives the same bits; an album moved into another batch may differ in the last
+    // bits (tests/test_gpu_forward.py::test_attention_pair_kernel_balance_on_skewed_batches).
     if (use_mask && s.N <= 64 && s.N > 1 && nwg <= 4096 && maxg <= 255) {  // ragged albums: workgroups in proportion to the rows
       uint32_t* tab = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) +
                                                  fvta_align_up((size_t)s.N * s.K * (s.nsplit + 1) * (s.w + 4) * sizeof(float), 256));

@@ -413,11 +413,19 @@ void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
     launch_bwd_fused_xm<1>(a, s);
 }
 
-// dx = dz * wb_x^T for every step of both directions in one launch.  grid (pad8(ceil(B/256)), ceil(in/128), 2 J)
-__global__ __launch_bounds__(256, 2) void lstm_dx_bf16(FusedBwdArgs a) {
+// dx = dz * wb_x^T for every step of ONE direction per launch.  grid (pad8(ceil(B/256)), ceil(in/BN), J)
+// The two directions meet at every input position (the backward direction visits position len - 1 - t at step t): the
+// forward direction's launch STORES its product, the backward direction's launch, behind it in stream order, adds to it
+// with a plain load / store -- each element has exactly one contribution per direction, so no atomics (617 MB of float
+// atomics at the memory side's ~1.3 TB/s were 0.4 ms of this kernel's 1.28) and a fixed summation order.
+// WN = 2: one 256-wide column tile when the input fits it (dz, K = 4d wide, is read once), 64-deep stages.
+template <int WN, int BK, int ST>
+__global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dx_bf16(FusedBwdArgs a, int dir, int accumulate) {
+  typedef TileCfgT<WN, 2, 4, ST, BK> TileCfg;
+  typedef MmaBT<WN, 2, 4, ST, BK> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   const int tid = threadIdx.x;
-  const int t = blockIdx.z % a.J, dir = blockIdx.z / a.J;
+  const int t = blockIdx.z;
   const int m0 = blockIdx.x * TileCfg::BM, n0 = blockIdx.y * TileCfg::BN;
   const int nact = a.plan.nactive[t];
   if (m0 >= nact) return;
@@ -427,37 +435,87 @@ __global__ __launch_bounds__(256, 2) void lstm_dx_bf16(FusedBwdArgs a) {
   mma.init(tid);
   const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + trow * (size_t)K, (unsigned)nact * K * 2);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir], (unsigned)in * K * 2);  // the x rows of wb
-  RowSrc<TileCfg::A_GLDS> az;
-  RowSrc<TileCfg::B_GLDS> bw;
+  RowSrc<TileCfg::A_GLDS, BK> az;
+  RowSrc<TileCfg::B_GLDS, BK> bw;
   az.setup(mma.wave_all, mma.lane, m0, nact, K * 2);
   bw.setup(mma.wave_all, mma.lane, n0, in, K * 2);
   auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
-    az.issue(rz, As, mma.wave_all, tile * 64);
-    bw.issue(rw, Bs, mma.wave_all, tile * 64);
+    az.issue(rz, As, mma.wave_all, tile * (BK * 2));
+    bw.issue(rw, Bs, mma.wave_all, tile * (BK * 2));
   };
-  glds_mainloop<false>(mma, issue, K / 32, smem_h);
+  // the rows' input offsets (step t of this direction visits them), staged once: every lane of the epilogue needs its row's
+  int64_t* s_xo = reinterpret_cast<int64_t*>(smem_h + (size_t)TileCfg::STAGES * TileCfg::STAGE_ELEMS);  // [BM]
+  for (int r = tid; r < TileCfg::BM; r += TileCfg::NT) s_xo[r] = a.plan.xo[trow + min(m0 + r, nact - 1)];  // clamped: always a valid row
+  glds_mainloop<false>(mma, issue, K / BK, smem_h);
+  __syncthreads();  // s_xo visible; every wave is done with the stage buffers, which become the epilogue's scratch
+  // ---- epilogue with every global access 16 bytes of a row: each 32 x 32 plane goes through a wave-private LDS scratch and
+  // comes back row-contiguous (lane = row lane / 8 of a pass of 8 rows, columns 4 (lane % 8) ..): a quarter of the
+  // vector-memory instructions of the accumulator layout's 4-byte accesses, which is what bounds this epilogue
+  constexpr int LDP = 36;
+  float* pl = reinterpret_cast<float*>(smem_h) + (size_t)mma.wave_all * (32 * LDP);
+  const int io_row = mma.lane >> 3, io_c4 = mma.lane & 7;
+  auto wave_sync = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
 #pragma unroll
-  for (int ti = 0; ti < MmaB::TM; ++ti) {
-    int64_t xos[16];
+  for (int ti = 0; ti < MmaB::TM; ++ti)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) xos[r] = a.plan.xo[trow + min(m0 + mma.row_of(ti, r), nact - 1)];
+    for (int tj = 0; tj < MmaB::TN; ++tj) {
+      const int nb = n0 + mma.wn * 128 + tj * 32;  // first column of the plane
+      if (nb >= in) continue;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = m0 + mma.row_of(ti, r);
-      if (i >= nact) continue;
+      for (int r = 0; r < 16; ++r) pl[((r & 3) + 8 * (r >> 2) + 4 * mma.hf) * LDP + mma.l31] = mma.acc[ti][tj][r];
+      wave_sync();
+      const int n = nb + 4 * io_c4;
+      f32x4 old[4];
+      float* ptr[4];
+      bool ok[4];
 #pragma unroll
-      for (int tj = 0; tj < MmaB::TN; ++tj) {
-        const int n = n0 + mma.col_of(tj);
-        if (n < in) atomicAdd(a.dx + xos[r] + n, mma.acc[ti][tj][r]);  // fw and bw meet at a position: two addends
+      for (int it = 0; it < 4; ++it) {
+        const int row = mma.wave * MmaB::WROWS + ti * 32 + it * 8 + io_row;
+        ptr[it] = a.dx + s_xo[row] + n;
+        ok[it] = m0 + row < nact && n < in;  // (in is a multiple of 4: a 4-column group is wholly inside or outside)
+        old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok[it] && accumulate) {
+          if ((reinterpret_cast<uintptr_t>(ptr[it]) & 15) == 0)
+            old[it] = *reinterpret_cast<const f32x4*>(ptr[it]);
+          else
+            old[it] = f32x4{ptr[it][0], ptr[it][1], ptr[it][2], ptr[it][3]};
+        }
       }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const f32x4 v = old[it] + *reinterpret_cast<const f32x4*>(&pl[(it * 8 + io_row) * LDP + 4 * io_c4]);
+        if (ok[it]) {
+          if ((reinterpret_cast<uintptr_t>(ptr[it]) & 15) == 0) {
+            *reinterpret_cast<f32x4*>(ptr[it]) = v;
+          } else {
+            ptr[it][0] = v[0]; ptr[it][1] = v[1]; ptr[it][2] = v[2]; ptr[it][3] = v[3];
+          }
+        }
+      }
+      wave_sync();  // the plane's reads are done before the next plane overwrites the scratch
     }
-  }
 }
 
+#ifndef FVTA_DX_WIDE
+#define FVTA_DX_WIDE 1
+#endif
 void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
-  allow_big_lds(lstm_dx_bf16, TileCfg::LDS_BYTES);
-  const dim3 grid(pad8((a.B + 255) / 256), (a.in + 127) / 128, 2 * a.J);
-  hipLaunchKernelGGL(lstm_dx_bf16, grid, dim3(256), TileCfg::LDS_BYTES, s, a);
+  if (FVTA_DX_WIDE && a.in > 128 && a.in <= 256 && (4 * a.d * a.xm) % 64 == 0) {
+    typedef TileCfgT<2, 2, 4, 2, 64> Cfg;
+    constexpr int LDS = Cfg::LDS_BYTES + 256 * 8;
+    allow_big_lds(lstm_dx_bf16<2, 64, 2>, LDS);
+    for (int dir = 0; dir < 2; ++dir)
+      hipLaunchKernelGGL((lstm_dx_bf16<2, 64, 2>), dim3(pad8((a.B + 255) / 256), 1, a.J), dim3(512), LDS, s, a, dir, a.dx_accumulate || dir);
+    return;
+  }
+  constexpr int LDS1 = TileCfg::LDS_BYTES + 256 * 8;
+  allow_big_lds(lstm_dx_bf16<1, 32, 3>, LDS1);
+  const dim3 grid(pad8((a.B + 255) / 256), (a.in + 127) / 128, a.J);
+  for (int dir = 0; dir < 2; ++dir)
+    hipLaunchKernelGGL((lstm_dx_bf16<1, 32, 3>), grid, dim3(256), LDS1, s, a, dir, a.dx_accumulate || dir);
 }
 
 // -------------------------------------------------------- weight gradient --

@@ -421,6 +421,7 @@ struct FusedBwdArgs {
   int nact_hint;         // active sequences of step t as the HOST knows them (fvta_bilstm_bwd_hint), -1: unknown -- picks the step's tile
   const float* gates32;  // split engine: fp32 gates, unit-major (gatesb null)
   int xm;                // bf16 terms per operand value
+  int dx_accumulate;     // lstm_dx: 1 = the forward direction's launch adds to dx too (the C ABI's contract: dx is accumulated)
 };
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s);
 bool launch_bwd_wreg(const FusedBwdArgs& a, hipStream_t s);  // lstm_wreg_bwd.hip: steps with few rows, false: not taken

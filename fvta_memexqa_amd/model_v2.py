@@ -391,14 +391,14 @@ class Model:
 
     OPTIMIZER_SLOTS = ("Adadelta", "Adadelta_1", "Adam", "Adam_1")       # tf.train.*Optimizer slot variable suffixes
 
-    def load_tf_checkpoint(self, path):
+    def load_tf_checkpoint(self, path, verify=True):
         """main.py:640-665 (`saver.restore(sess, ckpt.model_checkpoint_path)`): `path` is the reference's save directory
         (its `checkpoint` state file names the latest prefix), a checkpoint prefix or its .index file.  Restores every
         variable of this model by name plus global_step; returns the optimiser's slot variables found in the file,
         {slot suffix: {variable name: array}} (Trainer.restore_tf_checkpoint puts them back).  The file format is
         restated in tf_checkpoint.py (unpinned: no TensorFlow here to write a reference file)."""
         from .tf_checkpoint import read_checkpoint
-        arrays = read_checkpoint(path)
+        arrays = read_checkpoint(path, verify=verify)      # verify: every tensor's crc32c (about 70 MB/s; False skips it)
         slots, model_vars = {}, {}
         for key, val in arrays.items():
             base, _, last = key.rpartition("/")

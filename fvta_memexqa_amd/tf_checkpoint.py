@@ -108,7 +108,7 @@ def _parse_entry(buf):
 _CRC_TABLE = None
 
 
-def crc32c(data, crc=0):
+def _crc_table():
     global _CRC_TABLE
     if _CRC_TABLE is None:
         tbl = []
@@ -118,10 +118,57 @@ def crc32c(data, crc=0):
                 c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
             tbl.append(c)
         _CRC_TABLE = tbl
-    c = crc ^ 0xFFFFFFFF
+    return _CRC_TABLE
+
+
+def _crc_raw(data, c):
+    """the CRC register after `data`, starting from register c (no pre / post inversion): byte at a time"""
+    tbl = _crc_table()
     for b in bytes(data):
-        c = _CRC_TABLE[(c ^ b) & 0xFF] ^ (c >> 8)
-    return c ^ 0xFFFFFFFF
+        c = tbl[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c
+
+
+def _gf2_apply(cols, v):
+    """cols[i] = image of bit i; the image of v"""
+    r, i = 0, 0
+    while v:
+        if v & 1:
+            r ^= cols[i]
+        v >>= 1
+        i += 1
+    return r
+
+
+def crc32c(data, crc=0):
+    """CRC-32C (Castagnoli) of `data`, continuing from `crc`.  Long buffers (a checkpoint's LSTM kernels and optimiser
+    slots are tens of MB) are cut into 4096 equal chunks whose registers advance TOGETHER, one numpy table lookup per
+    byte position, and are then folded left to right: the register is linear over GF(2), so
+    reg(A || B) = shift_len(B)(reg(A)) xor reg_0(B), with the shift by a chunk's length as four 256-entry tables."""
+    import numpy as np
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data.view(np.uint8).reshape(-1)
+    n, lanes = buf.size, 4096
+    c = crc ^ 0xFFFFFFFF
+    if n < 64 * lanes:
+        return _crc_raw(buf.tobytes(), c) ^ 0xFFFFFFFF
+    L = n // lanes
+    tbl = np.array(_crc_table(), dtype=np.uint32)
+    body = buf[:L * lanes].reshape(lanes, L)
+    reg = np.zeros(lanes, dtype=np.uint32)
+    for i in range(L):                      # every lane's register from 0 over its own chunk
+        reg = tbl[(reg ^ body[:, i]) & 0xFF] ^ (reg >> np.uint32(8))
+    # the operator "advance the register over L zero bytes": one zero byte, then square-and-multiply on L
+    one = [_crc_raw(b"\0", 1 << i) for i in range(32)]
+    op, sq, e = [1 << i for i in range(32)], one, L
+    while e:
+        if e & 1:
+            op = [_gf2_apply(sq, col) for col in op]
+        sq = [_gf2_apply(sq, col) for col in sq]
+        e >>= 1
+    shift = [[_gf2_apply(op, b << (8 * k)) for b in range(256)] for k in range(4)]
+    for r in reg.tolist():
+        c = shift[0][c & 0xFF] ^ shift[1][(c >> 8) & 0xFF] ^ shift[2][(c >> 16) & 0xFF] ^ shift[3][c >> 24] ^ r
+    return _crc_raw(buf[L * lanes:].tobytes(), c) ^ 0xFFFFFFFF
 
 
 def _mask(crc):

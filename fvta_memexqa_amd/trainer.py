@@ -125,11 +125,11 @@ class Trainer:
                 m._dropout_calls = int(z["dropout_calls"])
         return True
 
-    def restore_tf_checkpoint(self, path):
+    def restore_tf_checkpoint(self, path, verify=True):
         """main.py:640-665: restore a checkpoint the reference's `saver.save` wrote -- the model's variables by name,
         global_step and, when present, this optimiser's slot variables (the Saver stores them with the trainables)."""
         m = self.model
-        slots = m.load_tf_checkpoint(path)
+        slots = m.load_tf_checkpoint(path, verify=verify)
         state = (torch.zeros_like(m.params.flat), torch.zeros_like(m.params.flat))
         found, partial = 0, []
         for slot, flat in zip(self.opt.SLOTS, state):

@@ -79,6 +79,12 @@ class Dataset:
         if world > 1 and shuffle and seed is None:
             raise ValueError("get_batches: data-parallel ranks need a common shuffle seed")
         gbs = batch_size * world
+        tail = self.num_examples % gbs
+        if world > 1 and 0 < tail < world and num_steps >= int(math.ceil(self.num_examples / float(gbs))):
+            # (checked before the first batch: the short last group would otherwise end an epoch of training with every
+            #  rank crashing)
+            raise ValueError("get_batches: the last global batch of an epoch would hold %d examples for %d ranks "
+                             "(num_examples %% (batch_size * world) must be 0 or >= world)" % (tail, world))
         per_epoch = int(math.ceil(self.num_examples / float(gbs)))
         if cap and num_steps > per_epoch:
             num_steps = per_epoch

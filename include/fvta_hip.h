@@ -177,8 +177,8 @@ int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const float* x, c
  * soon as that group's gate gradients are -- is launched on `side_stream` behind an event and joins `stream` again
  * before the call's last kernel, so the caller sees the same stream-ordered semantics on `stream`.  It runs on the CUs
  * the one-round step kernel leaves idle.  `side_stream` should not carry other work of the caller's during the call
- * and is best created with the lowest priority.  Results are bitwise those of fvta_bilstm_bwd, except dx where its two
- * directions meet (float atomics, two addends: order-free). */
+ * and is best created with the lowest priority.  Results are bitwise those of fvta_bilstm_bwd (bf16 engine: dx too --
+ * its two directions are added in a fixed order, forward first, by two launches in stream order; no atomics). */
 int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan, const float* x, const float* out,
                             const float* d_out, const float* kernel_fw, const float* kernel_bw, void* saved,
                             float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,

@@ -247,6 +247,52 @@ def test_attention_fast_path_randomised_differential(monkeypatch):
         np.testing.assert_allclose(amax_f[ok].numpy(), amax_e[ok].numpy(), rtol=5e-5, atol=5e-6, err_msg=tag + " amax")
 
 
+@pytest.mark.parametrize("skew", ["one_long", "all_but_one_empty", "two_sizes"])
+def test_attention_pair_kernel_balance_on_skewed_batches(monkeypatch, skew):
+    """With masks the pair kernel deals workgroups to albums in proportion to their valid row tiles (attn_balance_kernel),
+    so the split points of an album's partial sums -- the fp32 rounding of its h_a, nothing else -- depend on the OTHER
+    albums of the batch.  The table's edge cases at N = 64: one album holding nearly every tile (its share clamps at the
+    per-album maximum), every other album empty or fully masked, and two sizes; each against the exact-fp32 kernel, and
+    an album's result against the same album in a batch of different neighbours (equal up to that rounding)."""
+    from fvta_memexqa_amd import ops
+    N, K, T, JQ, w = 64, 6, 1200, 30, 1024
+    g = torch.Generator().manual_seed(4242)
+    h = torch.randn(N, K, T, w, generator=g) * 0.5
+    q = torch.randn(N, JQ, w, generator=g) * 0.5
+    W = torch.randn(2 * w, 1, generator=g) * 0.1
+    b = torch.randn(1, generator=g) * 0.1
+    hm = torch.zeros(N, K, T, dtype=torch.bool)
+    qm = torch.ones(N, JQ, dtype=torch.bool)
+    if skew == "one_long":
+        hm[5] = True                                   # every row of one album
+        hm[:, :, :3] |= torch.rand(N, K, 3, generator=g) < 0.5          # the others: at most three rows per modality
+    elif skew == "all_but_one_empty":
+        hm[17, :, :700] = True
+        qm[40:] = False                                # padded batch rows
+    else:
+        hm[::2, :, :1000] = True
+        hm[1::2, :2, :40] = True
+    cu = lambda t: t.cuda().contiguous()
+    op = ops.FocalAttention(N, K, T, JQ, w, 2, True)
+    args = (cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)), cu(W.reshape(-1)), cu(b))
+    monkeypatch.delenv("FVTA_ATTN_EXACT", raising=False)
+    fast, _ = op.forward(*args)
+    fast = fast.cpu()
+    again, _ = op.forward(*args)
+    assert torch.equal(again.cpu(), fast)              # the same batch: bitwise
+    monkeypatch.setenv("FVTA_ATTN_EXACT", "1")
+    exact, _ = op.forward(*args)
+    assert torch.isfinite(fast).all()
+    _close(fast, exact.cpu(), rtol=5e-5, atol=5e-6, msg=skew)
+    # the long album among other neighbours: only the rounding of its partial sums may move
+    monkeypatch.delenv("FVTA_ATTN_EXACT", raising=False)
+    n0 = {"one_long": 5, "all_but_one_empty": 17, "two_sizes": 0}[skew]
+    hm2 = hm.clone()
+    hm2[(n0 + 1) % N] = True
+    other, _ = op.forward(args[0], args[1], cu(ops.as_mask_u8(hm2)), *args[3:])
+    _close(other.cpu()[n0], fast[n0], rtol=2e-5, atol=2e-6, msg=skew + ": album among other neighbours")
+
+
 @pytest.mark.parametrize("mode", ["1", "2", "3"])
 def test_attention_wave16_kernel_randomised_differential(monkeypatch, mode):
     """FVTA_ATTN_WAVE16=1 / 2: the one-wave-per-tile (attn_fwd_wave16) and two-waves-per-tile (attn_fwd_pair16: w >= 512,

@@ -151,3 +151,28 @@ def test_bench_gpus_n_without_launcher_never_reports_one_rank():
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                         env=env2, capture_output=True, text=True, timeout=300)
     assert r2.returncode != 0 and not [l for l in r2.stdout.splitlines() if l.startswith("{")]
+
+
+def test_crc32c_chunked_form_equals_bytewise():
+    """tf_checkpoint.crc32c: the 4096-lane numpy form (long buffers) against the byte-at-a-time register, at the lane
+    boundary sizes, with continuation from a previous crc; the Castagnoli check value."""
+    from fvta_memexqa_amd import tf_checkpoint as tc
+    assert tc.crc32c(b"123456789") == 0xE3069283
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 100, 64 * 4096 - 1, 64 * 4096, 64 * 4096 + 5, 1_000_003):
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        ref = tc._crc_raw(d, 0xFFFFFFFF) ^ 0xFFFFFFFF
+        assert tc.crc32c(d) == ref, n
+        assert tc.crc32c(d[n // 3:], tc.crc32c(d[:n // 3])) == ref, n
+
+
+def test_get_batches_refuses_a_tail_smaller_than_the_world_before_the_first_batch():
+    """data parallelism: num_examples % (batch_size * world) in (0, world) would leave a rank without a batch in the last
+    group of an epoch -- refused at the first next(), not after an epoch of training"""
+    from fvta_memexqa_amd.utils import Dataset
+    data = {"q": list(range(9)), "idxs": list(range(9))}
+    ds = Dataset.__new__(Dataset)
+    ds.data, ds.datatype, ds.shared = data, "train", {}
+    ds.valid_idxs, ds.num_examples = list(range(9)), 9
+    with pytest.raises(ValueError):
+        next(ds.get_batches(2, 10, rank=0, world=4, seed=3))      # 9 % 8 = 1 < 4

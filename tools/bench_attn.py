@@ -33,3 +33,12 @@ if len(sys.argv) > 1:
     # mode 1 additionally READS every d_hinfo row -- which is what doubled the fetch figure of profiles/r01d_attention_pmc.json
     mode = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     print("attn bwd ms (accumulate=%d)" % mode, round(timeit(lambda: op.backward(h, q, hm, qm, W, b, gout, dh, dq, dW, db, mode)), 3))
+    import ctypes
+    from fvta_memexqa_amd import _lib
+    lib = _lib.load()
+    lib.fvta_profile_enable(1)
+    for _ in range(10): op.backward(h, q, hm, qm, W, b, gout, dh, dq, dW, db, mode)
+    torch.cuda.synchronize(); lib.fvta_profile_enable(0)
+    ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+    lib.fvta_profile_collect(5, ctypes.byref(ms), ctypes.byref(cnt))
+    print("attn_bwd_main kernel ms", round(ms.value / max(cnt.value, 1), 4))
