@@ -119,7 +119,12 @@ struct AttnBwdArgs {
 // TPR threads cover one row (16 B each, G float4 per thread when w > 1024);
 // RH = 256/TPR row groups; a tile is TR rows, each thread holds TR/RH of them.
 // COS: cosine similarity (simi 4) -- a compile-time flag so that the bilinear shapes do not carry its registers.
-template <int TPR, int G, int TR, bool COS>
+// ACC: d_hinfo is accumulated into (accumulate == 1).  Compile-time: as a run-time switch every row's store sat behind a
+// (possibly executed) load of its destination, i.e. behind an s_waitcnt vmcnt(0) that also waits for every EARLIER row's
+// store -- the write stream of the kernel was one store round trip per row.  Without the load (and with the question
+// operand of the current j in registers, below) the rows' stores stream.
+// (16-row tiles with four workgroups per CU: 0.96 ms against 0.77 at the metric shape -- the 128-register budget spills)
+template <int TPR, int G, int TR, bool COS, bool ACC>
 __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   constexpr int RH = 256 / TPR;
   constexpr int RPT = TR / RH;
@@ -250,6 +255,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   }
   int cur_j = -1;
   float acc_ct = 0.f;
+  f32x4 qs_cur[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) qs_cur[g] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto flush = [&]() {
     if (cur_j >= 0) {
 #pragma unroll
@@ -369,20 +377,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
       if (t < 0) continue;
       const int j = s_jj[row];
       const float pr = s_pr[row], dx = s_dx[row], self = cosine ? s_self[row] : 0.f;
-      if (j != cur_j) {
+      if (j != cur_j) {  // (rows come sorted by j: at most JQ changes per chunk)
         flush();
         cur_j = j;
+        // The question operand of the current j stays in registers.  As a per-row load it was a gather of 64 cache lines per
+        // wave-instruction (consecutive threads lie JP * 16 bytes apart): 107 M line requests per launch against 28 M for
+        // the rows themselves, and the CU's address unit takes ~0.26 lines per clock -- that gather WAS the kernel's time.
+        // (The empty asm makes the load's wait happen HERE, inside the branch: left pending across the merge point the
+        // compiler must wait vmcnt(0) at every row's first use, which drains the row stores one by one.)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          qs_cur[g] = ld4b(Qs + ((size_t)(cq + g * TPR) * JP + j) * 4);
+          asm volatile("" : "+v"(qs_cur[g]));
+        }
       }
       acc_ct += dx;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const int c4 = cq + g * TPR;
         const f32x4 h = hreg[i][g];
+#ifdef FVTA_ATTN_BWD_QS_PER_ROW  // (A/B: the per-row gather this replaced)
         const f32x4 qs = ld4b(Qs + ((size_t)c4 * JP + j) * 4);
+#else
+        const f32x4 qs = qs_cur[g];
+#endif
         f32x4 dh = cosine ? gv[g] * pr + qs * dx + h * self : gv[g] * pr + (qs + rh4[g] + r24[g] * h * 2.f) * dx;
         float* dst = dhbase + (size_t)t * w + 4 * c4;
-        if (a.accumulate == 1) dh += ld4b(dst);
-        if ((a.nt & 1) && a.accumulate != 1)
+        if constexpr (ACC) dh += ld4b(dst);
+        if ((a.nt & 1) && !ACC)
           __builtin_nontemporal_store(dh, reinterpret_cast<f32x4*>(dst));
         else
           *reinterpret_cast<f32x4*>(dst) = dh;
@@ -676,21 +698,27 @@ extern "C" int fvta_attn_bwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   const bool prof_it = (size_t)s.N * s.K * s.T >= 65536;  // the context attention, see attn_fwd.hip
   if (prof_it) fvta_prof_begin(FVTA_PROF_ATTN_BWD_MAIN, stream);
   switch (s.w) {
+#define FVTA_BWD_LAUNCH2(TPR, G, TR, COS)                                                                             \
+  do {                                                                                                              \
+    if (accumulate == 1) hipLaunchKernelGGL((attn_bwd_main<TPR, G, TR, COS, true>), grid, dim3(256), 0, stream, a);  \
+    else hipLaunchKernelGGL((attn_bwd_main<TPR, G, TR, COS, false>), grid, dim3(256), 0, stream, a);                 \
+  } while (0)
 #define FVTA_BWD_LAUNCH(TPR, G, TR)                                                                      \
   do {                                                                                                   \
-    if (s.simi == 4) hipLaunchKernelGGL((attn_bwd_main<TPR, G, TR, true>), grid, dim3(256), 0, stream, a); \
-    else hipLaunchKernelGGL((attn_bwd_main<TPR, G, TR, false>), grid, dim3(256), 0, stream, a);           \
+    if (s.simi == 4) FVTA_BWD_LAUNCH2(TPR, G, TR, true);                                                 \
+    else FVTA_BWD_LAUNCH2(TPR, G, TR, false);                                                            \
   } while (0)
     case 64: FVTA_BWD_LAUNCH(16, 1, 32); break;
     case 128: FVTA_BWD_LAUNCH(32, 1, 32); break;
     case 256: FVTA_BWD_LAUNCH(64, 1, 32); break;
     case 512: FVTA_BWD_LAUNCH(128, 1, 32); break;
     case 1024:  // (the cosine variant of the 32-row tile would spill: 16 rows)
-      if (s.simi == 4) hipLaunchKernelGGL((attn_bwd_main<256, 1, 16, true>), grid, dim3(256), 0, stream, a);
-      else hipLaunchKernelGGL((attn_bwd_main<256, 1, 32, false>), grid, dim3(256), 0, stream, a);
+      if (s.simi == 4) FVTA_BWD_LAUNCH2(256, 1, 16, true);
+      else FVTA_BWD_LAUNCH2(256, 1, 32, false);
       break;
     case 2048: FVTA_BWD_LAUNCH(256, 2, 16); break;
 #undef FVTA_BWD_LAUNCH
+#undef FVTA_BWD_LAUNCH2
   }
   if (prof_it) fvta_prof_end(FVTA_PROF_ATTN_BWD_MAIN, 1, stream);
   FVTA_CHECK_LAUNCH("attn_bwd_main");
