@@ -294,7 +294,10 @@ __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void 
       in.g2 = ldnt(gp + 8);
       in.g3 = ldnt(gp + 12);
     }
-    in.cp = t > 0 ? ldnt(cs_p + (size_t)ic * d + uc) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // c_{t-1}: an UNCONDITIONAL load, scaled by 0 at step 0 (which reads its own, finite, c_0 slab).  Under
+    // `t > 0 ? load : 0` the compiler branches around the load and waits vmcnt(0) inside the branch -- which drains every
+    // load of the passes in flight and every store of the pass before: the pass pipeline ran one pass at a time
+    in.cp = ldnt((t > 0 ? cs_p : a.cs + trow * d) + (size_t)ic * d + uc) * (t > 0 ? 1.f : 0.f);
     const float* dp = a.d_out + oo + uc;
     if ((reinterpret_cast<uintptr_t>(dp) & 15) == 0)
       in.dout = ldnt(dp);
