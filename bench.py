@@ -95,6 +95,7 @@ def parse(argv=None):
     ap.add_argument("--also", default="auto", choices=["auto", "on", "off"],
                     help="after the headline, time the other BASELINE.json configurations that fit one GPU in short runs and "
                          "attach them as `also` (auto: for the default N=1 headline only)")
+    ap.add_argument("--also-helper", action="store_true", help=argparse.SUPPRESS)   # internal: the `also` orchestrator (no GPU)
     return ap.parse_args(argv)
 
 
@@ -288,6 +289,7 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     for i in range(args.steps):
         step()
         marks[i + 1].record()
+    host_enqueue = time.perf_counter() - t0      # the host's share: when it equals the step time the run is launch bound
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -436,6 +438,7 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     for k in order[1:]:
         out["roofline_" + k] = roofs[k]
     out["roofline_fracs"] = {k: [roofs[k]["frac"], roofs[k]["bound"]] for k in order}   # every bracketed kernel, dominant first
+    out["host_enqueue_ms_per_step"] = round(host_enqueue / args.steps * 1e3, 3)
     out["side_stream_ratio"] = round(float(getattr(model, "side_stream_ratio", 0.0)), 3)   # < 1.4: the photo cell's stream runs beside the main one
     out.update(process_group=pg, rank_seconds=[round(v, 4) for v in rank_elapsed], kernel_ms_per_step=kms,
                kernel_ms_note="HIP-event brackets on the launch streams, over a second pass of the same %d steps right after the "
@@ -447,22 +450,67 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     return out, kw
 
 
-ALSO_CASES = [   # (name, argument overrides, steps, warm-up)
-    ("configs1_forward_fp32", dict(forward_only=True, precision="f32"), 3, 1),
-    ("configs1_forward_bf16", dict(forward_only=True), 5, 2),
-    ("train_bf16x3", dict(precision="bf16x3"), 3, 1),
-    ("train_ragged_lengths", dict(variant="ragged"), 5, 2),
-    ("configs4_long_album", dict(config="long_album"), 3, 1),
-    ("token_id_entry", dict(front_end=True), 5, 2),
-    ("time_warp_5", dict(time_warp=5), 5, 2),
-    ("published_flag_set", dict(front_end=True, char_emb_size=100, time_warp=5), 3, 1),
+ALSO_CASES = [   # (name, command-line overrides, steps, warm-up)
+    ("configs1_forward_fp32", ["--forward-only", "--precision", "f32"], 3, 1),
+    ("configs1_forward_bf16", ["--forward-only"], 5, 2),
+    ("train_bf16x3", ["--precision", "bf16x3"], 3, 1),
+    ("train_ragged_lengths", ["--variant", "ragged"], 10, 3),
+    ("configs4_long_album", ["--config", "long_album"], 3, 1),
+    ("token_id_entry", ["--front-end"], 5, 2),
+    ("time_warp_5", ["--time-warp", "5"], 5, 2),
+    ("published_flag_set", ["--front-end", "--char-emb-size", "100", "--time-warp", "5"], 3, 1),
 ]
+
+
+def also_helper():
+    """The `also` orchestrator: started by the headline process BEFORE that process touches the GPU (a process that has
+    initialised the GPU may not start other programs on these boxes), it waits for "go" on stdin, then runs every other
+    configuration as its own `python bench.py ... --also off` child -- a fresh process each, so that no case inherits the
+    stream-to-hardware-queue mapping, allocator state or clocks of the one before (in one process the ragged case ran at
+    8.8 ms after three other models against 4.9-5.0 ms alone) -- and prints ONE JSON object with their compact results."""
+    if sys.stdin.readline().strip() != "go":
+        return
+    only = [v for v in os.environ.get("FVTA_BENCH_ALSO", "").split(",") if v]      # (diagnostics: a subset of the cases)
+    also = {}
+    for name, over, steps, warm in ALSO_CASES:
+        if only and name not in only:
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warm),
+               "--also", "off", "--no-cpu-baseline"] + over
+        t0 = time.perf_counter()
+        try:
+            pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900,
+                                env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+            line = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+            if pr.returncode or not line:
+                raise RuntimeError("exit code %d, %d JSON lines" % (pr.returncode, len(line)))
+            r = json.loads(line[-1])
+            also[name] = dict(value=r["value"], unit=r["unit"], ms_per_step=r["ms_per_step"],
+                              ms_per_step_event_median=r["ms_per_step_event_median"], steps=steps, warmup=warm,
+                              dtype=r["dtype"], workload=r["config"]["workload"],
+                              shape={k: r["config"][k] for k in ("qa_pairs_per_gpu", "photos", "text_streams", "tokens", "hidden", "K", "T", "JQ")},
+                              kernel_ms_per_step=r["kernel_ms_per_step"], side_stream_ratio=r["side_stream_ratio"],
+                              host_enqueue_ms_per_step=r["host_enqueue_ms_per_step"], roofline_fracs=r["roofline_fracs"],
+                              command="python bench.py " + " ".join(cmd[2:]), process_seconds=round(time.perf_counter() - t0, 1))
+        except Exception as exc:   # a side measurement must not take the headline down
+            also[name] = dict(error=repr(exc), command="python bench.py " + " ".join(cmd[2:]))
+    print(json.dumps(also), flush=True)
 
 
 def main():
     args = parse()
+    if args.also_helper:
+        return also_helper()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)          # never returns
+    default_headline = (args.config == "metric" and args.variant == "dense" and args.precision == "bf16" and not args.forward_only
+                        and args.graph == "fvta" and not args.front_end and not args.batch and args.scaling == "weak"
+                        and not args.time_warp)
+    helper = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and (args.also == "on" or (args.also == "auto" and default_headline)):
+        # the `also` orchestrator must exist before this process initialises the GPU; it sleeps until told to go
+        helper = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--also-helper"], stdin=subprocess.PIPE,
+                                  stdout=subprocess.PIPE, text=True)
     # stdout carries ONE JSON line: whatever a C library prints there (RCCL's version banner, flushed at exit) goes to stderr
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), "w")
@@ -505,31 +553,21 @@ def main():
     if rank != 0:
         dist.shutdown()
         return
-    default_headline = (args.config == "metric" and args.variant == "dense" and args.precision == "bf16" and not args.forward_only
-                        and args.graph == "fvta" and not args.front_end and not args.batch and args.scaling == "weak"
-                        and not args.time_warp)
-    if ws == 1 and (args.also == "on" or (args.also == "auto" and default_headline)):
-        also = {}
-        only = [v for v in os.environ.get("FVTA_BENCH_ALSO", "").split(",") if v]      # (diagnostics: a subset of the cases)
-        for name, over, steps, warm in ALSO_CASES:
-            if only and name not in only:
-                continue
-            a2 = argparse.Namespace(**dict(vars(args), **dict(over, steps=steps, warmup=warm)))
-            log("also: %s" % name)
-            try:
-                r, _ = run_case(a2, lib, ws, rank, local, probe_gbs)
-                also[name] = dict(value=r["value"], unit=r["unit"], ms_per_step=r["ms_per_step"],
-                                  ms_per_step_event_median=r["ms_per_step_event_median"], steps=steps, warmup=warm,
-                                  dtype=r["dtype"], workload=r["config"]["workload"],
-                                  shape={k: r["config"][k] for k in ("qa_pairs_per_gpu", "photos", "text_streams", "tokens", "hidden", "K", "T", "JQ")},
-                                  kernel_ms_per_step=r["kernel_ms_per_step"], side_stream_ratio=r["side_stream_ratio"],
-                                  roofline_fracs=r["roofline_fracs"])
-            except Exception as exc:   # a side measurement must not take the headline down
-                also[name] = dict(error=repr(exc))
-                torch.cuda.empty_cache()
-        out["also"] = also
-        out["also_note"] = ("the other BASELINE.json configurations that fit one GPU, timed in this same invocation after the "
-                            "headline (short runs: steps / warm-up as listed); same code path, same timing method")
+    if helper is not None:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()       # (this process keeps its context; the cases get the whole memory)
+        try:
+            helper.stdin.write("go\n")
+            helper.stdin.flush()
+            line = helper.stdout.readline()
+            helper.wait(timeout=60)
+            out["also"] = json.loads(line)
+        except Exception as exc:
+            out["also"] = dict(error=repr(exc))
+        out["also_note"] = ("the other BASELINE.json configurations that fit one GPU, timed right after the headline by this same "
+                            "invocation, each in a fresh `python bench.py ... --also off` process (short runs: steps / warm-up as "
+                            "listed); same code path, same timing method")
     if ws == 1 and not args.no_cpu_baseline and args.graph == "fvta":
         log('timing the CPU oracle (%d threads of %d host CPUs)' % (args.cpu_threads, host_cores()))
         out["cpu_baseline"] = cpu_baseline(kw, args.cpu_sample, args.forward_only, args.cpu_threads)
