@@ -220,23 +220,34 @@ void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s) {
 // cell's 64 rows: a step is then a chain of K/32 k-tiles whose length is the DMA wave-instructions per k-tile (A rows + B
 // rows, at ~40 clocks each whether or not the rows exist), 12 instead of 32.
 // BK = 64 (two stages): the wide tile's ring in whole-line DMA pieces (gemm_bf16.h)
-template <int WN, int WM = 4, int XM = 1, int BK = 32, int ST = 3>  // XM = 3: the split engine (three bf16 terms per operand value, fp32 saved gates)
-__global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
+// One step of one block tile.  (A sequence-stationary kernel -- one launch for all J steps, a workgroup owning 128 rows x all
+// 512 units so that it depends on nobody else's dz, workgroups started out of phase so that k-loops and epilogues mix on
+// the chip -- ran this same body in a t loop: 134.7 us per step against 129.0 for the per-step launches, staggered or not.)
+#ifndef FVTA_BWD_EPD
+#define FVTA_BWD_EPD 2
+#endif
+template <int WN, int WM, int XM, int BK, int ST, int EPD_ = FVTA_BWD_EPD>  // XM = 3: the split engine (three bf16 terms per operand value, fp32 saved gates)
+__device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t, int dir, int m0, int u0, bf16_t* smem_h) {
   typedef TileCfgT<WN, 2, WM, ST, BK> TileCfg;
   typedef MmaBT<WN, 2, WM, ST, BK> MmaB;
-  extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + (size_t)TileCfg::STAGES * TileCfg::STAGE_ELEMS);
-  const int tid = (int)threadIdx.x, dir = blockIdx.z;
-  const int m0 = blockIdx.x * TileCfg::BM, u0 = blockIdx.y * TileCfg::BN;
-  const int t = a.t, d = a.d, N4 = 4 * d, K = N4 * XM;  // K: the dz row (split engine: (hi, lo, hi) thirds of 4d)
+  const int tid = (int)threadIdx.x;
+  const int d = a.d, N4 = 4 * d, K = N4 * XM;  // K: the dz row (split engine: (hi, lo, hi) thirds of 4d)
   const int nact = a.plan.nactive[t];
   if (m0 >= nact) return;
   const int nnext = (t + 1 < a.J) ? a.plan.nactive[t + 1] : 0;
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
   for (int r = tid; r < TileCfg::BM; r += TileCfg::NT) s_oo[r] = a.plan.oo[trow + min(m0 + r, nact - 1)];  // clamped: always a valid row
+  // compile-time ablations (timing experiments, -DFVTA_TBWD_ABL=bits; results are garbage): 1 no k-loop, 2 no epilogue
+  // stores, 4 no epilogue loads
+#ifdef FVTA_TBWD_ABL
+  constexpr int abl = FVTA_TBWD_ABL;
+#else
+  constexpr int abl = 0;
+#endif
   MmaB mma;
   mma.init(tid);
-  if (m0 < nnext) {
+  if (m0 < nnext && !(abl & 1)) {
     const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + (trow + a.B) * (size_t)K, (unsigned)nnext * K * 2);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir] + (size_t)a.in_i * K, (unsigned)d * K * 2);  // the h rows of wb
     RowSrc<TileCfg::A_GLDS, BK> az;
@@ -271,12 +282,13 @@ __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void 
   // The wave tile's TM x TN planes of four passes each form ONE sequence of passes; the loads of pass P + EPD are requested
   // when pass P is done, also across plane boundaries (the loads do not depend on the plane's scratch): EPD passes of
   // 5 KB are in flight per wave all through the epilogue.
-#ifndef FVTA_BWD_EPD
-#define FVTA_BWD_EPD 2
-#endif
-  constexpr int EPD = FVTA_BWD_EPD, NPASS = MmaB::TM * MmaB::TN * 4;
+  constexpr int EPD = EPD_, NPASS = MmaB::TM * MmaB::TN * 4;
   auto plane_u = [&](int pl) { return u0 + mma.wn * 128 + (pl % MmaB::TN) * 32 + 4 * io_c4; };
   auto load_pass = [&](int P, In& in) {
+    if constexpr ((abl & 4) != 0) {
+      in.g0 = in.g1 = in.g2 = in.g3 = in.cp = in.dout = in.dcv = f32x4{0.5f, 0.25f, 0.125f, 0.75f};
+      return;
+    }
     const int pl = P >> 2, it = P & 3, ti = pl / MmaB::TN;
     const int u = plane_u(pl);
     const int lr = it * 8 + io_row, row = mma.wave * MmaB::WROWS + ti * 32 + lr;
@@ -343,7 +355,7 @@ __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void 
       }
       dco[e] = dc * fg;
     }
-    if (i < nact && u < d) {
+    if (i < nact && u < d && (!(abl & 2) || dco[0] == 1234.5f)) {
       float* zp = reinterpret_cast<float*>(a.dzb + (trow + i) * (size_t)K + 4 * u);
       *reinterpret_cast<f32x4*>(zp) = __builtin_bit_cast(f32x4, za);
       *reinterpret_cast<f32x4*>(zp + 4) = __builtin_bit_cast(f32x4, zb);
@@ -370,6 +382,13 @@ __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void 
     do_pass(P, ins[P % EPD]);
     if constexpr (P + EPD < NPASS) load_pass(P + EPD, ins[P % EPD]);
   });
+}
+
+template <int WN, int WM = 4, int XM = 1, int BK = 32, int ST = 3>
+__global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
+  typedef TileCfgT<WN, 2, WM, ST, BK> TileCfg;
+  lstm_bwd_tile_step<WN, WM, XM, BK, ST>(a, a.t, blockIdx.z, blockIdx.x * TileCfg::BM, blockIdx.y * TileCfg::BN, smem_h);
 }
 
 template <int XM>
