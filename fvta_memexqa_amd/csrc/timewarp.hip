@@ -158,6 +158,118 @@ __global__ __launch_bounds__(256) void tw_apply_bwd_kernel(fvta_timewarp_desc d,
   }
 }
 
+// ---- fused forms (w a multiple of 256, K <= TW_KMAX): ONE pass over the context tensor per direction of the step.
+// A WAVE owns a position (n, t): its K rows (K x w floats: 24 KB at the metric shape) sit in registers between the
+// reduction over (k, c) that gives c[n,t] / dz[n,t] and the scaling that uses it, so hall (and d_warp) cross HBM once
+// instead of twice -- the separate kernels above are all on the HBM roof already (4.6-5.4 TB/s), only bytes are left to save.
+// Lane l holds channels 256 g + 4 l .. + 3 of a row (G4 = w / 256 quads): every access 16 bytes, 1 KB per wave-instruction.
+constexpr int TW_KMAX = 8;
+
+template <int G4>
+__global__ __launch_bounds__(256) void tw_fwd_fused_kernel(fvta_timewarp_desc d, int win, const float* __restrict__ hall,
+                                                           TwWork wk, float* __restrict__ c_out, float* __restrict__ scale,
+                                                           float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6), nwv = gridDim.x * 4;
+  f32x4 v[G4];
+#pragma unroll
+  for (int g = 0; g < G4; ++g) v[g] = ld4t(wk.v + 256 * g + 4 * lane);
+  const float s0 = wk.s0[0];
+  for (int pos = wv; pos < d.N * d.T; pos += nwv) {
+    const int n = pos / d.T, t = pos % d.T;
+    f32x4 h[TW_KMAX][G4];
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < TW_KMAX; ++k)
+      if (k < d.K) {
+        const float* row = hall + (((size_t)n * d.K + k) * d.T + t) * d.w + 4 * lane;
+#pragma unroll
+        for (int g = 0; g < G4; ++g) h[k][g] = ld4t(row + 256 * g);
+      }
+#pragma unroll
+    for (int k = 0; k < TW_KMAX; ++k)
+      if (k < d.K) {
+#pragma unroll
+        for (int g = 0; g < G4; ++g) {
+          const f32x4 p = h[k][g] * h[k][g] * v[g];
+          acc += (p[0] + p[1]) + (p[2] + p[3]);
+        }
+      }
+    acc = wave_sum(acc);
+    const float c = tanhf(acc + (float)d.K * (s0 + wk.sq[n]));
+    const float sc = c * tw_count(t, d.T, d.warp_type, win);
+    if (lane == 0) {
+      c_out[pos] = c;
+      scale[pos] = sc;
+    }
+#pragma unroll
+    for (int k = 0; k < TW_KMAX; ++k)
+      if (k < d.K) {
+        float* row = out + (((size_t)n * d.K + k) * d.T + t) * d.w + 4 * lane;
+#pragma unroll
+        for (int g = 0; g < G4; ++g) *reinterpret_cast<f32x4*>(row + 256 * g) = h[k][g] * sc;
+      }
+  }
+}
+
+// backward: dz[n,t] = (d_scale_att + sum_k d_warp . h) cnt (1 - c^2);  d_hall = scale d_warp + dz 2 v h;  dv partials per
+// wave slot (gridDim.x * 4 == wk.nwg slots).
+template <int G4>
+__global__ __launch_bounds__(256) void tw_bwd_fused_kernel(fvta_timewarp_desc d, int win, const float* __restrict__ hall,
+                                                           const float* __restrict__ d_warp, const float* __restrict__ c_saved,
+                                                           const float* __restrict__ d_scale_att, TwWork wk,
+                                                           float* __restrict__ d_hall) {
+  const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6), nwv = gridDim.x * 4;
+  f32x4 v[G4], dvacc[G4];
+#pragma unroll
+  for (int g = 0; g < G4; ++g) {
+    v[g] = ld4t(wk.v + 256 * g + 4 * lane);
+    dvacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int pos = wv; pos < d.N * d.T; pos += nwv) {
+    const int n = pos / d.T, t = pos % d.T;
+    f32x4 h[TW_KMAX][G4], gw[TW_KMAX][G4];
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < TW_KMAX; ++k)
+      if (k < d.K) {
+        const size_t ro = (((size_t)n * d.K + k) * d.T + t) * d.w + 4 * lane;
+#pragma unroll
+        for (int g = 0; g < G4; ++g) {
+          h[k][g] = ld4t(hall + ro + 256 * g);
+          gw[k][g] = ld4t(d_warp + ro + 256 * g);
+        }
+      }
+    // (per-row dots in k order, then the sum over k: the order of the separate kernels)
+#pragma unroll
+    for (int k = 0; k < TW_KMAX; ++k)
+      if (k < d.K) {
+        float dk = 0.f;
+#pragma unroll
+        for (int g = 0; g < G4; ++g) {
+          const f32x4 p = h[k][g] * gw[k][g];
+          dk += (p[0] + p[1]) + (p[2] + p[3]);
+        }
+        acc += wave_sum(dk);
+      }
+    const float c = c_saved[pos], cnt = tw_count(t, d.T, d.warp_type, win);
+    const float dz = ((d_scale_att ? d_scale_att[pos] : 0.f) + acc) * cnt * (1.f - c * c);
+    const float sc = c * cnt;
+    if (lane == 0) wk.dz[pos] = dz;
+#pragma unroll
+    for (int k = 0; k < TW_KMAX; ++k)
+      if (k < d.K) {
+        float* row = d_hall + (((size_t)n * d.K + k) * d.T + t) * d.w + 4 * lane;
+#pragma unroll
+        for (int g = 0; g < G4; ++g) {
+          *reinterpret_cast<f32x4*>(row + 256 * g) = gw[k][g] * sc + h[k][g] * v[g] * (2.f * dz);
+          dvacc[g] += h[k][g] * h[k][g] * dz;
+        }
+      }
+  }
+#pragma unroll
+  for (int g = 0; g < G4; ++g) *reinterpret_cast<f32x4*>(wk.dvp + (size_t)wv * d.w + 256 * g + 4 * lane) = dvacc[g];
+}
+
 // dv[c] = sum over workgroups; dsq[n] = K sum_t dz.  grid w + N, 256 threads: one output per block, strided partial
 // sums folded by a fixed tree (a single thread walking all partials was a ~1000-deep chain of L2 latencies)
 __global__ __launch_bounds__(256) void tw_reduce_kernel(fvta_timewarp_desc d, TwWork wk) {
@@ -238,6 +350,19 @@ extern "C" int fvta_timewarp_fwd(const fvta_timewarp_desc* d, const float* hall,
   const int win = (int)ceilf(d->window_t);
   hipLaunchKernelGGL(tw_vec_kernel, dim3((d->w + d->N + 1 + 3) / 4), dim3(256), 0, s, d->N, d->w, WH_W, WH_b, WC_W, WC_b, lq,
                      wk);
+  if (d->w % 256 == 0 && d->w <= 2048 && d->K <= TW_KMAX) {  // one pass: c, the row scale and the scaled rows
+    const dim3 g(wk.nwg / 4);
+    switch (d->w / 256) {
+      case 1: hipLaunchKernelGGL(tw_fwd_fused_kernel<1>, g, dim3(256), 0, s, *d, win, hall, wk, c_out, scale_out, warp_h); break;
+      case 2: hipLaunchKernelGGL(tw_fwd_fused_kernel<2>, g, dim3(256), 0, s, *d, win, hall, wk, c_out, scale_out, warp_h); break;
+      case 4: hipLaunchKernelGGL(tw_fwd_fused_kernel<4>, g, dim3(256), 0, s, *d, win, hall, wk, c_out, scale_out, warp_h); break;
+      case 8: hipLaunchKernelGGL(tw_fwd_fused_kernel<8>, g, dim3(256), 0, s, *d, win, hall, wk, c_out, scale_out, warp_h); break;
+      default: goto separate_fwd;
+    }
+    FVTA_CHECK_LAUNCH("timewarp_fwd");
+    return FVTA_OK;
+  }
+separate_fwd:
   hipLaunchKernelGGL(tw_coef_kernel, dim3((d->N * d->T + 3) / 4), dim3(256), 0, s, *d, win, hall, wk, c_out, scale_out);
   const size_t total4 = (size_t)d->N * d->K * d->T * (d->w / 4);
   hipLaunchKernelGGL(tw_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, *d, hall, scale_out, warp_h);
@@ -269,9 +394,21 @@ extern "C" int fvta_timewarp_bwd_att(const fvta_timewarp_desc* d, const float* h
   hipLaunchKernelGGL(tw_vec_kernel, dim3((d->w + d->N + 1 + 3) / 4), dim3(256), 0, s, d->N, d->w, WH_W, WH_b, WC_W, WC_b, lq,
                      wk);
   const size_t rows = (size_t)d->N * d->K * d->T;
-  hipLaunchKernelGGL(tw_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *d, hall, d_warp, wk.dsk);
-  hipLaunchKernelGGL(tw_dz_kernel, dim3((d->N * d->T + 255) / 256), dim3(256), 0, s, *d, win, c_saved, wk, d_scale_att);
-  hipLaunchKernelGGL(tw_apply_bwd_kernel, dim3(wk.nwg), dim3(256), 0, s, *d, win, hall, d_warp, c_saved, wk, d_hall);
+  bool fused = d->w % 256 == 0 && d->w <= 2048 && d->K <= TW_KMAX;
+  if (fused) {  // one pass over hall and d_warp (wk.nwg wave slots of dv partials)
+    const dim3 g(wk.nwg / 4);
+    switch (d->w / 256) {
+      case 1: hipLaunchKernelGGL(tw_bwd_fused_kernel<1>, g, dim3(256), 0, s, *d, win, hall, d_warp, c_saved, d_scale_att, wk, d_hall); break;
+      case 2: hipLaunchKernelGGL(tw_bwd_fused_kernel<2>, g, dim3(256), 0, s, *d, win, hall, d_warp, c_saved, d_scale_att, wk, d_hall); break;
+      case 4: hipLaunchKernelGGL(tw_bwd_fused_kernel<4>, g, dim3(256), 0, s, *d, win, hall, d_warp, c_saved, d_scale_att, wk, d_hall); break;
+      default: fused = false;  // (w = 2048: two K x w row sets do not fit the register file -- the separate kernels)
+    }
+  }
+  if (!fused) {
+    hipLaunchKernelGGL(tw_rowdot_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *d, hall, d_warp, wk.dsk);
+    hipLaunchKernelGGL(tw_dz_kernel, dim3((d->N * d->T + 255) / 256), dim3(256), 0, s, *d, win, c_saved, wk, d_scale_att);
+    hipLaunchKernelGGL(tw_apply_bwd_kernel, dim3(wk.nwg), dim3(256), 0, s, *d, win, hall, d_warp, c_saved, wk, d_hall);
+  }
   hipLaunchKernelGGL(tw_reduce_kernel, dim3(d->w + d->N), dim3(256), 0, s, *d, wk);
   hipLaunchKernelGGL(tw_param_bwd_kernel, dim3(d->w), dim3(256), 0, s, *d, WH_W, WH_b, WC_W, lq, wk, d_lq, dWH_W, dWH_b,
                      dWC_W, dWC_b);
