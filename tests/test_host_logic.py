@@ -176,3 +176,14 @@ def test_get_batches_refuses_a_tail_smaller_than_the_world_before_the_first_batc
     ds.valid_idxs, ds.num_examples = list(range(9)), 9
     with pytest.raises(ValueError):
         next(ds.get_batches(2, 10, rank=0, world=4, seed=3))      # 9 % 8 = 1 < 4
+
+
+def test_bench_also_helper_exits_quietly_without_go():
+    """bench.py's `also` orchestrator (started before the headline process touches the GPU) waits for "go" on stdin; when
+    the headline process dies first it sees EOF and must leave without starting anything or printing a line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--also-helper"], input="", capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == ""
