@@ -45,4 +45,10 @@ if dist.is_dist():
     print("   late all-reduce only (whole bucket): %.3f ms" % timeit())
     D.allreduce_async = keep[0]
     print("   as shipped again: %.3f ms" % timeit())
+    # the round-3 form: the early bucket (scorer / attention / photo cell) reduced asynchronously from the side stream while
+    # the text cell's recurrence runs, the rest after the backward
+    model.early_allreduce = True
+    print("   early bucket beside the recurrence (early_allreduce=True): %.3f ms" % timeit())
+    model.early_allreduce = False
+    print("   as shipped once more: %.3f ms" % timeit())
 dist.shutdown()
