@@ -20,7 +20,8 @@ out = torch.zeros(B, J, 2 * d, device="cuda")
 dout = torch.randn(B, J, 2 * d, device="cuda", generator=g)
 dx = torch.zeros_like(x); dk = torch.zeros_like(k); db = torch.zeros_like(b)
 op.forward(x, out, k, b)
-run = lambda: op.backward(x, out, dout, k, None, dx, dk, db)
+side = ops.pick_side_stream(torch.device("cuda", 0))[0] if os.environ.get("FVTA_AB_SIDE") else None   # a second stream: the split step
+run = lambda: op.backward(x, out, dout, k, None, dx, dk, db, side_stream=side)
 for _ in range(2): run()
 torch.cuda.synchronize()
 lib.fvta_profile_enable(1)
