@@ -1,13 +1,13 @@
 """The embedding front-end's kernels alone at the metric shape (385,920 tokens of 16 characters, 2,560 photos):
 HIP-event time per call of the char-CNN forward / backward and the photo transform forward / backward.
-  python tools/r03_frontend_ab.py [reps]"""
+  python tools/r03_frontend_ab.py [reps [char_emb_size]]"""
 import sys
 import torch
 from fvta_memexqa_amd import ops
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 g = torch.Generator().manual_seed(3)
-ntok, W, cd, cw, wd, VW, VF, VC = 12864 * 30, 16, 8, 100, 100, 400, 20000, 100
+ntok, W, cd, cw, wd, VW, VF, VC = 12864 * 30, 16, (int(sys.argv[2]) if len(sys.argv) > 2 else 8), 100, 100, 400, 20000, 100   # argv[2]: char_emb_size (100: the published flag set)
 cu = lambda t: t.cuda().contiguous()
 ids = cu(torch.randint(0, VW + VF, (ntok,), generator=g, dtype=torch.int32))
 ch = cu(torch.randint(0, VC, (ntok, W), generator=g, dtype=torch.int32))
