@@ -912,10 +912,12 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwdw_filt(EmbArgs a) {
     __syncthreads();
     if (g != 0.f) {
       accb += g;
+      // branch-free: under `if (k0 + i < KC)` every element was a scalar branch around ONE LDS read and its FMA -- 128 exposed
+      // LDS latencies per token (~8 us).  The chunk's tail reads a clamped (valid) address and adds nothing.
       const float* e = s_E + p * cd + k0;
+      const int nv = min(EMBW_KCH, KC - k0);  // valid elements of this chunk
 #pragma unroll
-      for (int i = 0; i < EMBW_KCH; ++i)
-        if (k0 + i < KC) acc[i] += g * e[i];
+      for (int i = 0; i < EMBW_KCH; ++i) acc[i] += (i < nv ? g : 0.f) * e[min(i, nv - 1)];
     }
   }
   float* slab = a.slab + (size_t)blockIdx.y * ((size_t)KC * cw + cw + (size_t)d.VC * cd);
