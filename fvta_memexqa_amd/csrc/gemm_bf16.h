@@ -87,7 +87,11 @@ struct MmaBT {
   int wave_all, wave, wn, lane, l31, hf;  // wave = row of the WAVES_M x WN wave grid (the M position), wn = its column
 
   static __device__ __forceinline__ void mfma(f32x16& c, bf16x8_t a, bf16x8_t b) {
+#ifdef FVTA_GEMM_NO_MMA  // timing experiments: the operand stream without the matrix pipe
+    asm volatile("" ::"v"(a), "v"(b));
+#else
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
   }
 
   __device__ __forceinline__ void init(int tid) {

@@ -662,6 +662,7 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
     f.gates32 = sv.gates;  // split engine: fp32 gates (sv.gatesb is null there)
     f.xm = lstm_xm(d);
     f.dx_accumulate = 1;  // the ABI's contract: dx is accumulated into
+    f.dx_both = 0;
     for (int t = J - 1; t >= 0; --t) {
       f.t = t;
       f.nact_hint = nactive_host ? nactive_host[t] : -1;

@@ -226,6 +226,17 @@ void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s) {
 #ifndef FVTA_BWD_EPD
 #define FVTA_BWD_EPD 2
 #endif
+// first k-tile of a workgroup's rotated k-loop (lstm_dx_bf16): every workgroup would otherwise read the SAME 128-byte column
+// of its 4-KB dz rows at the same moment -- the same few L2 channels.  Workgroups are dealt round-robin over the 8 XCDs (each
+// with its own L2), so the workgroups of ONE XCD get consecutive rotations.  Only the order of a dot product's partial sums
+// changes (fixed per tile: dx stays bitwise reproducible).
+#ifndef FVTA_KT_ROT
+#define FVTA_KT_ROT 1
+#endif
+__device__ __forceinline__ int kt_rot(int nkt) {
+  const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  return FVTA_KT_ROT ? (int)((bid >> 3) * FVTA_KT_ROT % (unsigned)nkt) : 0;
+}
 template <int WN, int WM, int XM, int BK, int ST, int EPD_ = FVTA_BWD_EPD>  // XM = 3: the split engine (three bf16 terms per operand value, fp32 saved gates)
 __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t, int dir, int m0, int u0, bf16_t* smem_h) {
   typedef TileCfgT<WN, 2, WM, ST, BK> TileCfg;
@@ -254,6 +265,7 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
     RowSrc<TileCfg::B_GLDS, BK> bw;
     az.setup(mma.wave_all, mma.lane, m0, nnext, K * 2);
     bw.setup(mma.wave_all, mma.lane, u0, d, K * 2);
+    // (a k-tile order rotated per workgroup, as in lstm_dx_bf16 and the pipelined kernel: 134.5 vs 132.3 us here)
     auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
       az.issue(rz, As, mma.wave_all, tile * (BK * 2));
       bw.issue(rw, Bs, mma.wave_all, tile * (BK * 2));
@@ -435,13 +447,18 @@ void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
     launch_bwd_fused_xm<1>(a, s);
 }
 
-// dx = dz * wb_x^T for every step of ONE direction per launch.  grid (pad8(ceil(B/256)), ceil(in/BN), J)
-// The two directions meet at every input position (the backward direction visits position len - 1 - t at step t): the
-// forward direction's launch STORES its product, the backward direction's launch, behind it in stream order, adds to it
-// with a plain load / store -- each element has exactly one contribution per direction, so no atomics (617 MB of float
-// atomics at the memory side's ~1.3 TB/s were 0.4 ms of this kernel's 1.28) and a fixed summation order.
+// dx = dz * wb_x^T.  grid (pad8(ceil(B/256)), ceil(in/BN), J)
+// The two directions meet at every input position (the backward direction visits position len - 1 - t at step t).
+// BOTH (one shared input, x_bw_delta = 0 -- no input dropout): ONE launch per position p sums both directions in the
+// accumulators -- a k-loop over [dz_fw(step p) | dz_bw(step len_i - 1 - p)] x [wb_fw ; wb_bw], the backward direction's rows
+// gathered through per-lane row addresses (sorted row i is row i of every step it is active in) -- and touches dx once
+// (k-loop 0.39 ms + epilogue 0.17 ms per direction and launch before: one epilogue less).
+// Otherwise one launch per direction: the forward direction's launch adds its product to dx, the backward direction's launch,
+// behind it in stream order, adds to that with a plain load / store -- each element has exactly one contribution per
+// direction, so no atomics (617 MB of float atomics at the memory side's ~1.3 TB/s were 0.4 ms of this kernel's 1.28) and a
+// fixed summation order either way.
 // WN = 2: one 256-wide column tile when the input fits it (dz, K = 4d wide, is read once), 64-deep stages.
-template <int WN, int BK, int ST>
+template <int WN, int BK, int ST, bool BOTH = false>
 __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dx_bf16(FusedBwdArgs a, int dir, int accumulate) {
   typedef TileCfgT<WN, 2, 4, ST, BK> TileCfg;
   typedef MmaBT<WN, 2, 4, ST, BK> MmaB;
@@ -451,24 +468,61 @@ __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dx
   const int m0 = blockIdx.x * TileCfg::BM, n0 = blockIdx.y * TileCfg::BN;
   const int nact = a.plan.nactive[t];
   if (m0 >= nact) return;
+  // (the launcher cannot see the plan's header: with separate inputs per direction the BOTH launch serves the forward
+  //  direction alone and the launch behind it the backward direction; with one input that second launch returns here)
+  const bool shared_x = a.plan.hdr->x_bw_delta == 0;
+  if (!BOTH && a.dx_both && dir == 1 && shared_x) return;
+  const bool both = BOTH && shared_x;
   const int d = a.d, K = 4 * d * a.xm, in = a.in;
-  const size_t trow = ((size_t)dir * a.J + t) * a.B;
+  const size_t trow = ((size_t)(BOTH ? 0 : dir) * a.J + t) * a.B;
   MmaB mma;
   mma.init(tid);
   const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + trow * (size_t)K, (unsigned)nact * K * 2);
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir], (unsigned)in * K * 2);  // the x rows of wb
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[BOTH ? 0 : dir], (unsigned)in * K * 2);  // the x rows of wb
   RowSrc<TileCfg::A_GLDS, BK> az;
   RowSrc<TileCfg::B_GLDS, BK> bw;
   az.setup(mma.wave_all, mma.lane, m0, nact, K * 2);
   bw.setup(mma.wave_all, mma.lane, n0, in, K * 2);
+  // BOTH: the backward direction's dz (all steps: one descriptor, < 4 GB) and its rows of this position
+  const __amdgpu_buffer_rsrc_t rz1 = make_rsrc(a.dzb + (size_t)a.J * a.B * K, BOTH ? (unsigned)((size_t)a.J * a.B * K * 2) : 0u);
+  const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(a.Wb[1], (unsigned)in * K * 2);
+  RowSrc<TileCfg::A_GLDS, BK> az1;
+  if (BOTH) {
+    constexpr int CPR = BK / 8;
+#pragma unroll
+    for (int j = 0; j < TileCfg::A_GLDS; ++j) {
+      const int U = (mma.wave_all * TileCfg::A_GLDS + j) * 64 + mma.lane;
+      const int row = U / CPR, c = (U % CPR) ^ row_swz<BK>(row);
+      const int i = m0 + row;
+      unsigned v = GLDS_OOB;
+      if (i < nact) {
+        const int sb = a.plan.len[a.plan.order[i]] - 1 - t;  // the backward direction's step at this position (>= 0: i is active)
+        v = (unsigned)(((size_t)sb * a.B + i) * (size_t)(K * 2)) + 16u * c;
+      }
+      az1.voff[j] = v;
+    }
+  }
+  const int nkt = K / BK, nkt_all = both ? 2 * nkt : nkt;
+  const int rot = kt_rot(nkt_all);  // measured 1.11-1.16 vs 1.17-1.24 ms without
   auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
-    az.issue(rz, As, mma.wave_all, tile * (BK * 2));
-    bw.issue(rw, Bs, mma.wave_all, tile * (BK * 2));
+    const int kt = tile + rot - (tile + rot >= nkt_all ? nkt_all : 0);
+    if (!BOTH || kt < nkt) {
+      az.issue(rz, As, mma.wave_all, kt * (BK * 2));
+      bw.issue(rw, Bs, mma.wave_all, kt * (BK * 2));
+    } else {
+      az1.issue(rz1, As, mma.wave_all, (kt - nkt) * (BK * 2));
+      bw.issue(rw1, Bs, mma.wave_all, (kt - nkt) * (BK * 2));
+    }
   };
   // the rows' input offsets (step t of this direction visits them), staged once: every lane of the epilogue needs its row's
   int64_t* s_xo = reinterpret_cast<int64_t*>(smem_h + (size_t)TileCfg::STAGES * TileCfg::STAGE_ELEMS);  // [BM]
   for (int r = tid; r < TileCfg::BM; r += TileCfg::NT) s_xo[r] = a.plan.xo[trow + min(m0 + r, nact - 1)];  // clamped: always a valid row
-  glds_mainloop<false>(mma, issue, K / BK, smem_h);
+#ifdef FVTA_DX_ABL  // timing experiments (results are garbage): 1 no k-loop, 2 no epilogue loads, 4 no epilogue stores
+  constexpr int abl = FVTA_DX_ABL;
+#else
+  constexpr int abl = 0;
+#endif
+  if (!(abl & 1)) glds_mainloop<false>(mma, issue, nkt_all, smem_h);
   __syncthreads();  // s_xo visible; every wave is done with the stage buffers, which become the epilogue's scratch
   // ---- epilogue with every global access 16 bytes of a row: each 32 x 32 plane goes through a wave-private LDS scratch and
   // comes back row-contiguous (lane = row lane / 8 of a pass of 8 rows, columns 4 (lane % 8) ..): a quarter of the
@@ -499,7 +553,7 @@ __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dx
         ptr[it] = a.dx + s_xo[row] + n;
         ok[it] = m0 + row < nact && n < in;  // (in is a multiple of 4: a 4-column group is wholly inside or outside)
         old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok[it] && accumulate) {
+        if (ok[it] && accumulate && !(abl & 2)) {
           if ((reinterpret_cast<uintptr_t>(ptr[it]) & 15) == 0)
             old[it] = *reinterpret_cast<const f32x4*>(ptr[it]);
           else
@@ -509,7 +563,7 @@ __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dx
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const f32x4 v = old[it] + *reinterpret_cast<const f32x4*>(&pl[(it * 8 + io_row) * LDP + 4 * io_c4]);
-        if (ok[it]) {
+        if (ok[it] && (!(abl & 4) || v[0] == 1234.5f)) {
           if ((reinterpret_cast<uintptr_t>(ptr[it]) & 15) == 0) {
             *reinterpret_cast<f32x4*>(ptr[it]) = v;
           } else {
@@ -524,13 +578,31 @@ __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dx
 #ifndef FVTA_DX_WIDE
 #define FVTA_DX_WIDE 1
 #endif
+#ifndef FVTA_DX_BOTH
+#define FVTA_DX_BOTH 1
+#endif
 void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
   if (FVTA_DX_WIDE && a.in > 128 && a.in <= 256 && (4 * a.d * a.xm) % 64 == 0) {
-    typedef TileCfgT<2, 2, 4, 2, 64> Cfg;
+#ifndef FVTA_DX_BK
+#define FVTA_DX_BK 64
+#define FVTA_DX_ST 2
+#endif
+    typedef TileCfgT<2, 2, 4, FVTA_DX_ST, FVTA_DX_BK> Cfg;
     constexpr int LDS = Cfg::LDS_BYTES + 256 * 8;
-    allow_big_lds(lstm_dx_bf16<2, 64, 2>, LDS);
+    allow_big_lds(lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST>, LDS);
+    const dim3 grid(pad8((a.B + 255) / 256), 1, a.J);
+    // both directions in one launch when one descriptor covers a direction's dz (the kernel falls back by itself when the
+    // directions have separate inputs)
+    if (FVTA_DX_BOTH && (size_t)a.J * a.B * (4 * a.d * a.xm) * 2 < ((size_t)1 << 32)) {
+      FusedBwdArgs b = a;
+      b.dx_both = 1;
+      allow_big_lds(lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true>, LDS);
+      hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true>), grid, dim3(512), LDS, s, b, 0, a.dx_accumulate);
+      hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST>), grid, dim3(512), LDS, s, b, 1, 1);
+      return;
+    }
     for (int dir = 0; dir < 2; ++dir)
-      hipLaunchKernelGGL((lstm_dx_bf16<2, 64, 2>), dim3(pad8((a.B + 255) / 256), 1, a.J), dim3(512), LDS, s, a, dir, a.dx_accumulate || dir);
+      hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST>), grid, dim3(512), LDS, s, a, dir, a.dx_accumulate || dir);
     return;
   }
   constexpr int LDS1 = TileCfg::LDS_BYTES + 256 * 8;

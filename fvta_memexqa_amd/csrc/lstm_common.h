@@ -422,6 +422,7 @@ struct FusedBwdArgs {
   const float* gates32;  // split engine: fp32 gates, unit-major (gatesb null)
   int xm;                // bf16 terms per operand value
   int dx_accumulate;     // lstm_dx: 1 = the forward direction's launch adds to dx too (the C ABI's contract: dx is accumulated)
+  int dx_both;           // lstm_dx: set by its launcher -- the first launch sums both directions when they share one input
 };
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s);
 bool launch_bwd_wreg(const FusedBwdArgs& a, hipStream_t s);  // lstm_wreg_bwd.hip: steps with few rows, false: not taken
