@@ -45,22 +45,67 @@ __global__ __launch_bounds__(1024) void plan_sort_kernel(PlanView v, const int32
     v.hdr->d = d;
     v.hdr->x_bw_delta = x_bw_delta;
   }
-  for (int b = tid; b < B; b += 1024) {
-    int L = len_in[b];
-    L = L < 0 ? 0 : (L > J ? J : L);
-    v.len[b] = L;
-    v.seq_J[b] = seq_J_in[b];
-    v.x_off[b] = x_off_in[b];
-    v.out_off[b] = out_off_in[b];
+  // the plan's copies of the caller's arrays, four sequences per thread and round (sixteen loads in flight, then the stores)
+  for (int bb = tid; bb < B; bb += 4096) {
+    int Lc[4], Jc[4];
+    int64_t xo_[4], oo_[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = min(bb + 1024 * r, B - 1);
+      Lc[r] = len_in[b];
+      Jc[r] = seq_J_in[b];
+      xo_[r] = x_off_in[b];
+      oo_[r] = out_off_in[b];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = bb + 1024 * r;
+      if (b < B) {
+        v.len[b] = Lc[r] < 0 ? 0 : (Lc[r] > J ? J : Lc[r]);
+        v.seq_J[b] = Jc[r];
+        v.x_off[b] = xo_[r];
+        v.out_off[b] = oo_[r];
+      }
+    }
   }
-  __syncthreads();
   const int chunk = (B + NW - 1) / NW;
   const int b0 = wave * chunk, b1 = min(B, b0 + chunk);
-  // pass 1: per-wave histogram.  J + 1 <= 64 (every shape of the model): lane v counts the sequences of length v of its
-  // wave in a register -- one ballot per possible length, no LDS update between them (the leader-by-leader form below
-  // pays an LDS round trip per distinct length of every 64 sequences: 69 us on a ragged batch, 30 us of it here)
+  // J + 1 <= 64 (every shape of the model): lane v counts the sequences of length v of its wave in a register -- one ballot
+  // per possible length, no LDS update between them (the leader-by-leader form below pays an LDS round trip per distinct
+  // length of every 64 sequences).  Chunks of <= 1024 sequences per wave (B <= 16384) keep their lengths in registers for
+  // both passes, read straight from the caller's array (all loads in flight at once); the exclusive prefix over (length,
+  // wave) is one wave's work (lane = length), and the scatter's running bases move by v_readlane.  (91 -> ~25 us at
+  // B = 12,864: the old form walked its chunk with one dependent global load per 64 sequences and pass, and thread 0 alone
+  // ran the 16 x (J + 1) prefix through LDS.)
   const bool lanes_hold = H <= 64;
+  constexpr int MAXIT = 16;
+  const int iters = b1 > b0 ? (b1 - b0 + 63) / 64 : 0;
+  const bool in_regs = lanes_hold && chunk <= 64 * MAXIT;
+  int Lr[MAXIT];
+  if (in_regs) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int b = b0 + 64 * it + lane;
+      int L = -1;
+      if (it < iters && b < b1) {
+        L = len_in[b];
+        L = L < 0 ? 0 : (L > J ? J : L);
+      }
+      Lr[it] = L;
+    }
+  }
+  __syncthreads();  // sh is zero; v.len is written (the paths below that read it back)
+  // pass 1: per-wave histogram
   int hist = 0;
+  if (in_regs) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < iters)
+        for (int val = 0; val < H; ++val) {
+          const unsigned long long same = __ballot(Lr[it] == val);
+          if (lane == val) hist += __popcll(same);
+        }
+  } else
   for (int base = b0; base < b1; base += 64) {
     const int b = base + lane;
     const bool ok = b < b1;
@@ -83,8 +128,31 @@ __global__ __launch_bounds__(1024) void plan_sort_kernel(PlanView v, const int32
   }
   if (lanes_hold && lane < H) sh[wave * H + lane] = hist;
   __syncthreads();
-  // exclusive prefix over (L descending, wave ascending); thread 0 is enough (16*(J+1) adds)
-  if (tid == 0) {
+  // exclusive prefix over (L descending, wave ascending)
+  if (lanes_hold) {
+    if (wave == 0) {  // lane = length
+      int cnt[NW], total = 0;
+#pragma unroll
+      for (int wv = 0; wv < NW; ++wv) {
+        cnt[wv] = lane < H ? sh[wv * H + lane] : 0;
+        total += cnt[wv];
+      }
+      int run = 0, mine = 0;  // run: sequences longer than L (uniform)
+      for (int L = J; L >= 0; --L) {
+        if (lane == L) mine = run;
+        run += __builtin_amdgcn_readlane(total, L);
+      }
+      if (lane < J) v.nactive[lane] = mine;  // sequences with len > lane
+      if (lane == J) v.nactive[J] = 0;
+      if (lane < H) {
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) {
+          sh[wv * H + lane] = mine;
+          mine += cnt[wv];
+        }
+      }
+    }
+  } else if (tid == 0) {
     int run = 0;
     for (int L = J; L >= 0; --L) {
       if (L < J) v.nactive[L] = run;  // sequences with len > L
@@ -99,6 +167,22 @@ __global__ __launch_bounds__(1024) void plan_sort_kernel(PlanView v, const int32
   __syncthreads();
   // pass 2: scatter, each wave walking its chunk in order (lane v carries the running base of length v)
   int basev = (lanes_hold && lane < H) ? sh[wave * H + lane] : 0;
+  if (in_regs) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it)
+      if (it < iters) {
+        const int b = b0 + 64 * it + lane;
+        const int L = Lr[it];
+        for (int val = 0; val < H; ++val) {
+          const unsigned long long same = __ballot(L == val);
+          if (!same) continue;
+          const int bp = __builtin_amdgcn_readlane(basev, val);
+          if (L == val) v.order[bp + __popcll(same & ((1ull << lane) - 1ull))] = b;
+          if (lane == val) basev += __popcll(same);
+        }
+      }
+    return;
+  }
   for (int base = b0; base < b1; base += 64) {
     const int b = base + lane;
     const bool ok = b < b1;
