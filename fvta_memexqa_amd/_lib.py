@@ -24,7 +24,7 @@ class AttnDesc(Structure):
 
 
 class LstmDesc(Structure):
-    _fields_ = [(n, c_int32) for n in ("B", "J", "in_", "d", "share_fw_bw", "precision", "training", "reserved")]
+    _fields_ = [(n, c_int32) for n in ("B", "J", "in_", "d", "share_fw_bw", "precision", "training", "reserved", "dx_overwrite")]
 
 
 class TimewarpDesc(Structure):

@@ -244,6 +244,30 @@ __global__ void pad_zero_kernel(PlanView v, float* __restrict__ out, int d) {
   }
 }
 
+// desc.dx_overwrite: rows [t0, seq_J) of every sequence's dx are zeroed -- t0 = len (the padded positions: the dx kernel
+// writes the rest) or 0 (all rows: the dx kernels of this engine / shape add to dx).  Both copies under a separate input per
+// direction.  grid (B, 4)
+__global__ void dx_zero_rows_kernel(PlanView v, float* __restrict__ dx, int in, int pads_only) {
+  const int b = blockIdx.x;
+  const int L = pads_only ? v.len[b] : 0, Jb = v.seq_J[b];
+  const int64_t delta = v.hdr->x_bw_delta;
+  const int w4 = in / 4;
+  for (int t = L + blockIdx.y; t < Jb; t += gridDim.y) {
+    float* row = dx + v.x_off[b] + (int64_t)t * in;
+    if ((reinterpret_cast<uintptr_t>(row) & 15) == 0 && (delta & 3) == 0) {
+      for (int c = threadIdx.x; c < w4; c += blockDim.x) {
+        reinterpret_cast<f32x4*>(row)[c] = zero4();
+        if (delta) reinterpret_cast<f32x4*>(row + delta)[c] = zero4();
+      }
+    } else {
+      for (int c = threadIdx.x; c < in; c += blockDim.x) {
+        row[c] = 0.f;
+        if (delta) row[delta + c] = 0.f;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------- saved state --
 
 // --------------------------------------------------------- forward step -----
@@ -747,6 +771,11 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
     f.xm = lstm_xm(d);
     f.dx_accumulate = 1;  // the ABI's contract: dx is accumulated into
     f.dx_both = 0;
+    if (dx && d->dx_overwrite) {  // ... or written: the padded rows zeroed here, the rest by the dx kernel where it can
+      const bool direct = dx_writes_whole_rows(f);
+      hipLaunchKernelGGL(dx_zero_rows_kernel, dim3(B, 4), dim3(64), 0, stream, pv, dx, in, direct ? 1 : 0);
+      f.dx_accumulate = direct ? 0 : 1;
+    }
     for (int t = J - 1; t >= 0; --t) {
       f.t = t;
       f.nact_hint = nactive_host ? nactive_host[t] : -1;
@@ -758,12 +787,14 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
       launch_dx_bf16(f, stream);
       fvta_prof_end(FVTA_PROF_LSTM_DX + 16 * d->reserved, 1, stream);
     }
-  } else
+  } else {
+  if (dx && d->dx_overwrite) hipLaunchKernelGGL(dx_zero_rows_kernel, dim3(B, 4), dim3(64), 0, stream, pv, dx, in, 0);
   for (int t = J - 1; t >= 0; --t) {
     g.t = t;
     s.t = t;
     if (!(dbg & 512)) hipLaunchKernelGGL(lstm_gate_bwd, ggrid, dim3(256), 0, stream, g);
     if (t > 0 || dx) hipLaunchKernelGGL(lstm_step_bwd_f32, sgrid, dim3(256), sh, stream, s);
+  }
   }
   if (!bf) fvta_prof_end(FVTA_PROF_LSTM_STEP_BWD + 16 * d->reserved, 2 * J, stream);
   FVTA_CHECK_LAUNCH("lstm_step_bwd");

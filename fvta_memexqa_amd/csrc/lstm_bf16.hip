@@ -581,6 +581,14 @@ __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dx
 #ifndef FVTA_DX_BOTH
 #define FVTA_DX_BOTH 1
 #endif
+// the wide path with both directions in one launch: every element of a valid dx row is written exactly once
+// (desc.dx_overwrite: no zero fill, no read of dx)
+static bool dx_wide_both(const FusedBwdArgs& a) {
+  return FVTA_DX_WIDE && FVTA_DX_BOTH && a.in > 128 && a.in <= 256 && (4 * a.d * a.xm) % 64 == 0 &&
+         (size_t)a.J * a.B * (4 * a.d * a.xm) * 2 < ((size_t)1 << 32);
+}
+bool dx_writes_whole_rows(const FusedBwdArgs& a) { return dx_wide_both(a); }
+
 void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
   if (FVTA_DX_WIDE && a.in > 128 && a.in <= 256 && (4 * a.d * a.xm) % 64 == 0) {
 #ifndef FVTA_DX_BK
@@ -593,12 +601,12 @@ void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
     const dim3 grid(pad8((a.B + 255) / 256), 1, a.J);
     // both directions in one launch when one descriptor covers a direction's dz (the kernel falls back by itself when the
     // directions have separate inputs)
-    if (FVTA_DX_BOTH && (size_t)a.J * a.B * (4 * a.d * a.xm) * 2 < ((size_t)1 << 32)) {
+    if (dx_wide_both(a)) {
       FusedBwdArgs b = a;
       b.dx_both = 1;
       allow_big_lds(lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true>, LDS);
       hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true>), grid, dim3(512), LDS, s, b, 0, a.dx_accumulate);
-      hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST>), grid, dim3(512), LDS, s, b, 1, 1);
+      hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST>), grid, dim3(512), LDS, s, b, 1, a.dx_accumulate);  // (separate inputs: its own dx copy)
       return;
     }
     for (int dir = 0; dir < 2; ++dir)

@@ -427,6 +427,7 @@ struct FusedBwdArgs {
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s);
 bool launch_bwd_wreg(const FusedBwdArgs& a, hipStream_t s);  // lstm_wreg_bwd.hip: steps with few rows, false: not taken
 void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s);
+bool dx_writes_whole_rows(const FusedBwdArgs& a);  // lstm_dx_bf16 writes every element of a valid row once (dx_overwrite)
 void launch_dw_bf16(const DwArgs& a, hipStream_t s);
 void launch_dw_reduce_bf16(const float* slabs, int nslab, int in, int in_i, int d, float* dW, float* dbias, hipStream_t s);
 int test_gemm_bf16(int layout, int M, int N, int K, const float* A, const float* B, float* C, hipStream_t s);

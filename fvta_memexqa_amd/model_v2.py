@@ -594,7 +594,8 @@ class Model:
             G.lens = torch.zeros(B, dtype=torch.int32, device=dev)
             G.op = ops.BiLstm(B, Jmax, din, dp, torch.cat(x_off), torch.cat(out_off), torch.cat(seq_J), wp,
                               share_fw_bw=self.share_fw_bw, precision=self.precision, training=training,
-                              prof_tag=0 if cell == "text" else 1, x_bw_delta=pos if G.dropout else 0)
+                              prof_tag=0 if cell == "text" else 1, x_bw_delta=pos if G.dropout else 0,
+                              dx_overwrite=True)   # backward() writes dx: no zero fill per step
             L.groups[cell] = G
         L.q_mask = torch.zeros(N, JQ, dtype=torch.uint8, device=dev)
         self._build_attention(L, training)
@@ -921,13 +922,10 @@ class Model:
             if side is not None:
                 side.wait_stream(main)      # d_arena is complete
             with torch.cuda.stream(side if side is not None else main):
-                if need_dx:
-                    G.dx.zero_()
+                # (dx / dx2 are WRITTEN by the op -- desc.dx_overwrite, zeros at padded positions -- not added to)
                 if G.dropout:
-                    if need_dx:
-                        if G.dx2 is None:
-                            G.dx2 = torch.zeros_like(G.x2)
-                        G.dx2.zero_()
+                    if need_dx and G.dx2 is None:
+                        G.dx2 = torch.zeros_like(G.x2)
                     G.op.backward(G.x2, L.arena, L.d_arena, kf, kb, G.dx2 if need_dx else None, dkf, dbf, dkb, dbb)
                     if need_dx:
                         ops.dropout_pair_bwd(G.dx2, G.dx, self.keep_prob, G.drop_seed)

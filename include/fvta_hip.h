@@ -130,6 +130,10 @@ typedef struct fvta_lstm_desc {
   int32_t precision;   /* FVTA_F32 | FVTA_BF16 | FVTA_BF16X3 */
   int32_t training;    /* 1: keep gate activations for fvta_bilstm_bwd */
   int32_t reserved;    /* profiling tag: this call's brackets are filed under id + 16*reserved */
+  int32_t dx_overwrite; /* fvta_bilstm_bwd*: 0 = dx is accumulated into (the caller zeroes it), 1 = dx is WRITTEN: every row
+                        * t < seq_J of every sequence (both copies under fvta_lstm_plan_xdir) holds the input gradient
+                        * afterwards, zeros at t >= len, whatever it held before -- the caller's memset and, where the
+                        * kernel writes both directions' sum at once, the read of dx go away */
 } fvta_lstm_desc;
 
 size_t fvta_lstm_plan_bytes(const fvta_lstm_desc* d);
@@ -166,7 +170,7 @@ int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const float* x, f
                     const float* bias_bw, void* saved, void* workspace, fvta_stream_t stream);
 
 /* d_out has out's layout.  dx (x's layout, may be NULL), dkernel and dbias are
- * all ACCUMULATED INTO (the caller zeroes them once per step). */
+ * all ACCUMULATED INTO (the caller zeroes them once per step); dx is written instead under desc.dx_overwrite. */
 int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const float* x, const float* out,
                     const float* d_out, const float* kernel_fw, const float* kernel_bw, void* saved,
                     float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-BF16 = 1
+F32, BF16 = 0, 1
 
 
 def _close(a, b, rtol, atol, msg=""):
@@ -291,3 +291,44 @@ def test_bilstm_bf16_backward_step_kernels_agree(B, J, din, dense):
     for name, a, b in zip(("dx", "dkernel", "dbias"), res["ring"], res["tiled"]):
         err = ((a - b).double().norm() / (b.double().norm() + 1e-30)).item()
         assert err < 2e-3, "%s: pipelined vs tiled backward step differ by %.5f (relative L2)" % (name, err)
+
+
+@pytest.mark.parametrize("precision", [F32, BF16])
+@pytest.mark.parametrize("B,J,din,d,dense,xdir", [(700, 5, 200, 512, False, False), (300, 4, 200, 512, True, False),
+                                                   (300, 6, 100, 128, False, False), (260, 5, 200, 512, False, True)])
+def test_bilstm_dx_overwrite_equals_zero_fill_and_accumulate(precision, B, J, din, d, dense, xdir):
+    """fvta_lstm_desc.dx_overwrite: backward() WRITES dx -- the input gradient at t < len, zeros at len <= t < seq_J,
+    whatever the buffer held -- bitwise what the accumulate contract gives on a zeroed buffer.  Wide input (both directions in
+    one lstm_dx_bf16 launch, dx never read), narrow input and the fp32 engine (rows zeroed by the library, then added to),
+    and a separate input per direction (fvta_lstm_plan_xdir: both copies)."""
+    from fvta_memexqa_amd import ops
+    g = torch.Generator().manual_seed(B + J + din)
+    lens = torch.full((B,), J) if dense else torch.randint(0, J + 1, (B,), generator=g)
+    n = B * J * din
+    x = torch.randn((2 if xdir else 1) * n, generator=g).cuda()
+    lim = (6.0 / (din + 5 * d)) ** 0.5
+    kf = ((torch.rand(din + d, 4 * d, generator=g) * 2 - 1) * lim).cuda()
+    bf = (torch.randn(4 * d, generator=g) * 0.1).cuda()
+    mask = torch.arange(J)[None, :] < lens[:, None]
+    g_out = (torch.randn(B, J, 2 * d, generator=g) * mask[:, :, None]).cuda()
+    ar = torch.arange(B, dtype=torch.int64)
+    res = []
+    for overwrite in (False, True):
+        op = ops.BiLstm(B, J, din, d, ar * J * din, ar * J * 2 * d, torch.full((B,), J, dtype=torch.int32), 2 * d,
+                        share_fw_bw=True, precision=precision, training=True, x_bw_delta=n if xdir else 0,
+                        dx_overwrite=overwrite)
+        op.make_plan(lens)
+        out = torch.zeros(B, J, 2 * d, device="cuda")
+        op.forward(x, out, kf, bf)
+        dx = torch.full_like(x, float("nan")) if overwrite else torch.zeros_like(x)
+        dk, db = torch.zeros_like(kf), torch.zeros_like(bf)
+        op.backward(x, out, g_out, kf, None, dx, dk, db, None, None)
+        torch.cuda.synchronize()
+        res.append((dx, dk, db))
+    assert torch.isfinite(res[1][0]).all(), "dx_overwrite left rows unwritten"
+    pad = (~mask).cuda()
+    for half in range(2 if xdir else 1):
+        assert (res[1][0][half * n:(half + 1) * n].view(B, J, din)[pad] == 0).all()
+    assert res[0][0].abs().max() > 0
+    for name, a, b in zip(("dx", "dkernel", "dbias"), res[0], res[1]):
+        assert torch.equal(a, b), "%s differs between the accumulate and the overwrite contract" % name
