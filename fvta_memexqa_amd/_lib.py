@@ -24,7 +24,7 @@ class AttnDesc(Structure):
 
 
 class LstmDesc(Structure):
-    _fields_ = [(n, c_int32) for n in ("B", "J", "in_", "d", "share_fw_bw", "precision", "training", "reserved", "dx_overwrite")]
+    _fields_ = [(n, c_int32) for n in ("B", "J", "in_", "d", "share_fw_bw", "precision", "training", "reserved", "dx_overwrite", "out_pads_persist")]
 
 
 class TimewarpDesc(Structure):

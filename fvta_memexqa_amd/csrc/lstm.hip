@@ -37,6 +37,9 @@ __global__ __launch_bounds__(1024) void plan_sort_kernel(PlanView v, const int32
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int NW = 16, H = J + 1;
   for (int i = tid; i < NW * H; i += 1024) sh[i] = 0;
+  // (memory that has not been a plan of this shape before knows nothing about the caller's output buffer)
+  const bool fresh = v.hdr->magic != PLAN_MAGIC || v.hdr->B != B || v.hdr->J != J || v.hdr->d != d || v.hdr->out_ld != out_ld;
+  __syncthreads();
   if (tid == 0) {
     v.hdr->out_ld = out_ld;
     v.hdr->B = B;
@@ -44,6 +47,7 @@ __global__ __launch_bounds__(1024) void plan_sort_kernel(PlanView v, const int32
     v.hdr->in = in;
     v.hdr->d = d;
     v.hdr->x_bw_delta = x_bw_delta;
+    v.hdr->magic = PLAN_MAGIC;
   }
   // the plan's copies of the caller's arrays, four sequences per thread and round (sixteen loads in flight, then the stores)
   for (int bb = tid; bb < B; bb += 4096) {
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(1024) void plan_sort_kernel(PlanView v, const int32
     for (int r = 0; r < 4; ++r) {
       const int b = bb + 1024 * r;
       if (b < B) {
+        if (fresh || v.out_off[b] != oo_[r] || v.seq_J[b] != Jc[r]) v.dirty_out[b] = 0;  // another layout: nothing known
         v.len[b] = Lc[r] < 0 ? 0 : (Lc[r] > J ? J : Lc[r]);
         v.seq_J[b] = Jc[r];
         v.x_off[b] = xo_[r];
@@ -232,14 +237,25 @@ __global__ void plan_fill_kernel(PlanView v, int B, int J, int in, int d) {
   v.oo[idx] = v.out_off[b] + (int64_t)pos * v.hdr->out_ld + (int64_t)dir * d;
 }
 
-// rows t in [len, seq_J) of both halves are zero (dynamic_rnn zero_output)
-__global__ void pad_zero_kernel(PlanView v, float* __restrict__ out, int d) {
+// rows t in [len, seq_J) of both halves are zero (dynamic_rnn zero_output).  grid B
+// persist (desc.out_pads_persist: nobody but this op writes the output buffer between forward calls): only the rows the
+// LAST forward on this plan memory wrote and this one will not -- [len, dirty) -- are zeroed; the plan remembers per sequence
+// how far it has written into which buffer.  (A ragged metric-shape batch: 0.79 GB of zeros per step otherwise, 161 us.)
+__global__ __launch_bounds__(256) void pad_zero_kernel(PlanView v, float* __restrict__ out, int d, int persist) {
   const int b = blockIdx.x;
   const int L = v.len[b], Jb = v.seq_J[b];
   const int64_t ld = v.hdr->out_ld;
+  float* first = out + v.out_off[b];
+  const bool known = persist && v.dirty_out[b] == (int64_t)reinterpret_cast<uintptr_t>(first);
+  const int hi = known ? min(v.dirty[b], Jb) : Jb;
+  __syncthreads();  // every thread has read the sequence's state
+  if (threadIdx.x == 0) {
+    v.dirty[b] = L;
+    v.dirty_out[b] = (int64_t)reinterpret_cast<uintptr_t>(first);
+  }
   const int w4 = (2 * d) / 4;
-  for (int t = L + blockIdx.y; t < Jb; t += gridDim.y) {
-    f32x4* row = reinterpret_cast<f32x4*>(out + v.out_off[b] + (int64_t)t * ld);
+  for (int t = L; t < hi; ++t) {
+    f32x4* row = reinterpret_cast<f32x4*>(first + (int64_t)t * ld);
     for (int c = threadIdx.x; c < w4; c += blockDim.x) row[c] = zero4();
   }
 }
@@ -622,7 +638,7 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   a.J = d->J;
   a.in = d->in;
   a.d = d->d;
-  hipLaunchKernelGGL(pad_zero_kernel, dim3(d->B, 4), dim3(256), 0, stream, pv, out, d->d);
+  hipLaunchKernelGGL(pad_zero_kernel, dim3(d->B), dim3(256), 0, stream, pv, out, d->d, d->out_pads_persist);
   FVTA_CHECK_LAUNCH("pad_zero");
   const dim3 grid((d->B + MmaStep::BM - 1) / MmaStep::BM, d->d / 32, 2);
   const size_t sh = MmaStep::LDS_FLOATS * sizeof(float);

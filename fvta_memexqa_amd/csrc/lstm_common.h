@@ -11,8 +11,10 @@ struct PlanHeader {
   int64_t out_ld;
   int32_t B, J, in, d;
   int64_t x_bw_delta;  // elements from the forward direction's x (and dx) to the backward direction's: 0 = one shared input
-  int32_t pad[8];
+  uint32_t magic;      // PLAN_MAGIC once plan_sort has run on this memory: `dirty` / `dirty_out` below hold real state
+  int32_t pad[7];
 };
+constexpr uint32_t PLAN_MAGIC = 0x46565441u;
 
 struct PlanView {
   PlanHeader* hdr;
@@ -24,6 +26,10 @@ struct PlanView {
   int64_t* out_off;  // [B]
   int64_t* xo;       // [2][J][B] element offset of x row for (dir,t,sorted i), -1 = inactive
   int64_t* oo;       // [2][J][B] element offset of the output half-row
+  // desc.out_pads_persist: what the LAST forward on this plan memory left in the caller's output -- rows [0, dirty[b]) of
+  // sequence b may be non-zero in the buffer `dirty_out[b]` points into (everything beyond is zero); survives re-planning
+  int32_t* dirty;      // [B]
+  int64_t* dirty_out;  // [B] the sequence's first output row (address), 0 = nothing known
   size_t bytes;
 };
 
@@ -39,6 +45,8 @@ static inline PlanView plan_view(const fvta_lstm_desc* d, void* p) {
   v.out_off = c.take<int64_t>(d->B);
   v.xo = c.take<int64_t>((size_t)2 * d->J * d->B);
   v.oo = c.take<int64_t>((size_t)2 * d->J * d->B);
+  v.dirty = c.take<int32_t>(d->B);
+  v.dirty_out = c.take<int64_t>(d->B);
   v.bytes = c.off;
   return v;
 }

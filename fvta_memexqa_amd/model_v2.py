@@ -595,7 +595,8 @@ class Model:
             G.op = ops.BiLstm(B, Jmax, din, dp, torch.cat(x_off), torch.cat(out_off), torch.cat(seq_J), wp,
                               share_fw_bw=self.share_fw_bw, precision=self.precision, training=training,
                               prof_tag=0 if cell == "text" else 1, x_bw_delta=pos if G.dropout else 0,
-                              dx_overwrite=True)   # backward() writes dx: no zero fill per step
+                              dx_overwrite=True,   # backward() writes dx: no zero fill per step
+                              out_pads_persist=True)   # L.arena is written by this op only
             L.groups[cell] = G
         L.q_mask = torch.zeros(N, JQ, dtype=torch.uint8, device=dev)
         self._build_attention(L, training)

@@ -101,14 +101,15 @@ class BiLstm:
     """
 
     def __init__(self, B, J, in_dim, d, x_off, out_off, seq_J, out_ld, share_fw_bw=True, precision=F32,
-                 training=False, prof_tag=0, x_bw_delta=0, dx_overwrite=False):
+                 training=False, prof_tag=0, x_bw_delta=0, dx_overwrite=False, out_pads_persist=False):
         """x_bw_delta > 0: the backward direction reads x (writes dx) that many elements behind the forward direction's
         -- x = [x_fw | x_bw], the two dropped copies of DropoutWrapper's inputs (dropout_pair_fwd).
-        dx_overwrite: backward() writes dx (zeros at padded positions) instead of adding to it: no memset by the caller."""
+        dx_overwrite: backward() writes dx (zeros at padded positions) instead of adding to it: no memset by the caller.
+        out_pads_persist: the caller leaves `out` alone between forward calls: only rows that turn into padding are zeroed."""
         self.x_bw_delta = int(x_bw_delta)
         self.lib = _lib.load()
         self.dev = require_gpu()
-        self.desc = LstmDesc(B, J, in_dim, d, int(share_fw_bw), precision, int(training), int(prof_tag), int(dx_overwrite))
+        self.desc = LstmDesc(B, J, in_dim, d, int(share_fw_bw), precision, int(training), int(prof_tag), int(dx_overwrite), int(out_pads_persist))
         self.B, self.J, self.in_dim, self.d = B, J, in_dim, d
         self.x_off = x_off.to(self.dev, torch.int64).contiguous()
         self.out_off = out_off.to(self.dev, torch.int64).contiguous()

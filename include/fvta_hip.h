@@ -134,6 +134,9 @@ typedef struct fvta_lstm_desc {
                         * t < seq_J of every sequence (both copies under fvta_lstm_plan_xdir) holds the input gradient
                         * afterwards, zeros at t >= len, whatever it held before -- the caller's memset and, where the
                         * kernel writes both directions' sum at once, the read of dx go away */
+  int32_t out_pads_persist; /* fvta_bilstm_fwd: 1 = the caller promises that nothing but this op writes `out` between forward
+                        * calls on this plan memory: only the rows the previous call wrote and this one does not are zeroed
+                        * (rows t >= len are zero after every call either way) */
 } fvta_lstm_desc;
 
 size_t fvta_lstm_plan_bytes(const fvta_lstm_desc* d);

@@ -332,3 +332,36 @@ def test_bilstm_dx_overwrite_equals_zero_fill_and_accumulate(precision, B, J, di
     assert res[0][0].abs().max() > 0
     for name, a, b in zip(("dx", "dkernel", "dbias"), res[0], res[1]):
         assert torch.equal(a, b), "%s differs between the accumulate and the overwrite contract" % name
+
+
+@pytest.mark.parametrize("precision", [F32, BF16])
+def test_bilstm_out_pads_persist_zeroes_what_turns_into_padding(precision):
+    """fvta_lstm_desc.out_pads_persist: the plan remembers how far the last forward wrote into which buffer and zeroes only
+    [len, that) -- the output must equal a fresh op's (which zeroes every padded row) for any sequence of batches: shrinking
+    and growing lengths, a plan that is replaced before any forward ran on it, another output buffer in between."""
+    from fvta_memexqa_amd import ops
+    B, J, din, d = 300, 7, 40, 128
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, J, din, generator=g).cuda()
+    kf = ((torch.rand(din + d, 4 * d, generator=g) * 2 - 1) * 0.1).cuda()
+    bf = (torch.randn(4 * d, generator=g) * 0.1).cuda()
+    ar = torch.arange(B, dtype=torch.int64)
+    mk = lambda persist: ops.BiLstm(B, J, din, d, ar * J * din, ar * J * 2 * d, torch.full((B,), J, dtype=torch.int32), 2 * d,
+                                    share_fw_bw=True, precision=precision, training=False, out_pads_persist=persist)
+    op = mk(True)
+    outs = [torch.full((B, J, 2 * d), 7.0, device="cuda") for _ in range(2)]   # garbage the first call must clear
+    script = [("fwd", 0), ("fwd", 0), ("plan", 0), ("fwd", 0), ("fwd", 1), ("fwd", 0), ("fwd", 0), ("fwd", 1)]
+    for step, (what, which) in enumerate(script):
+        lens = torch.randint(0, J + 1, (B,), generator=g)
+        if step == 1:
+            lens = torch.full((B,), J)
+        op.make_plan(lens)
+        if what == "plan":
+            continue
+        op.forward(x, outs[which], kf, bf)
+        ref_op = mk(False)
+        ref_op.make_plan(lens)
+        ref = torch.full((B, J, 2 * d), -3.0, device="cuda")
+        ref_op.forward(x, ref, kf, bf)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[which], ref), "step %d: stale rows survived in the padded part of the output" % step
