@@ -307,6 +307,19 @@ __device__ __forceinline__ void glds_mainloop_sp(Mma& mma, Issue&& issue, int nt
   }
 }
 
+// What the stamps show (lstm_dx_bf16, 256 x 256 tile, 64-deep stages, per k-tile and wave, shader-clock counts): behind the
+// barrier the eight waves' 64 DMA pieces queue at the CU's address unit, which accepts one 1-KB piece per ~35 cycles -- waves
+// 0-3 are through after ~680, their SIMD partners 4-7 after ~2150 -- and a wave issues no MFMA while it stands there; then
+// ~1300 of fragment reads + MFMAs.  A k-tile costs the address unit's time PLUS the matrix time (~4300), not their maximum.
+// Spreading the refill over the MFMA groups (one piece per four MFMAs, SIMD partners in opposite phase; two 64-deep or four
+// 32-deep stages) only moves the queueing: every piece then blocks its wave ~300 cycles, 4650-4950 per k-tile.
+#ifdef FVTA_LOOP_STAMP  // -DFVTA_LOOP_STAMP (tools/r04_loop_stamps.py): where a k-tile's cycles go, per wave of one workgroup
+static __device__ unsigned long long g_loop_stamp[16][4];  // [wave][wait, barrier, issue, compute] summed over the k-tiles
+#define FVTA_LS(i) do { if (ls_on) { const unsigned long long now_ = __builtin_readcyclecounter(); ls_sum[i] += now_ - ls_t; ls_t = now_; } } while (0)
+#else
+#define FVTA_LS(i) do { } while (0)
+#endif
+
 template <bool KMAJOR, class Mma, class Issue>
 __device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntiles, bf16_t* smem) {
   typedef typename Mma::Cfg TileCfg;
@@ -314,9 +327,14 @@ __device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntile
   static_assert(S >= 2 && S <= 5, "ring depth");
   auto a_stage = [&](int t) { return smem + (t % S) * TileCfg::STAGE_ELEMS; };
   if (ntiles <= 0) return;
+#ifdef FVTA_LOOP_STAMP
+  const bool ls_on = blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 3;
+  unsigned long long ls_sum[4] = {0, 0, 0, 0}, ls_t = __builtin_readcyclecounter();
+#endif
 #pragma unroll
   for (int p = 0; p < S - 1; ++p)
     if (p < ntiles) issue(p, a_stage(p), a_stage(p) + TileCfg::A_ELEMS);
+  FVTA_LS(2);
   for (int t = 0; t < ntiles; ++t) {
     // tiles up to t + S - 2 are issued; tile t has landed once only the newer ones are outstanding
     const int ahead = min(S - 2, ntiles - 1 - t);
@@ -328,15 +346,26 @@ __device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntile
       wait_vmcnt<G>();
     else
       wait_vmcnt<0>();
+    FVTA_LS(0);
     __builtin_amdgcn_s_barrier();  // tile t visible to all waves; every wave's reads of stage (t - 1) % S are retired
     asm volatile("" ::: "memory");
+    FVTA_LS(1);
     if (t + S - 1 < ntiles) issue(t + S - 1, a_stage(t + S - 1), a_stage(t + S - 1) + TileCfg::A_ELEMS);
+    FVTA_LS(2);
     const bf16_t* As = a_stage(t);
     if (KMAJOR)
       mma.compute_kmajor(As, As + TileCfg::A_ELEMS);
     else
       mma.compute_rows(As, As + TileCfg::A_ELEMS);
+#ifdef FVTA_LOOP_STAMP
+    asm volatile("s_nop 0" ::: "memory");
+#endif
+    FVTA_LS(3);
   }
+#ifdef FVTA_LOOP_STAMP
+  if (ls_on && mma.lane == 0)
+    for (int i = 0; i < 4; ++i) g_loop_stamp[mma.wave_all][i] = ls_sum[i];
+#endif
 }
 
 }  // namespace fvta

@@ -810,3 +810,10 @@ int test_gemm_bf16(int layout, int M, int N, int K, const float* A, const float*
 }
 
 }  // namespace fvta
+
+#ifdef FVTA_LOOP_STAMP
+// the k-loop stamps of the LAST launch of a tiled kernel of this file (workgroup (8, 0, 3)): out[wave][4] cycles
+extern "C" int fvta_debug_loop_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fvta::g_loop_stamp), sizeof(unsigned long long) * 16 * 4);
+}
+#endif
