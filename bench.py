@@ -395,8 +395,8 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
                  note="algorithmic bytes: the gate gradient (32 B per row and unit: gates 8, c 4, d_out 4, dc 4 + 4, dz 8); the "
                       "re-read of dz(t+1) (8 B) is not counted; dx has its own bracket",
                  traffic=("r04_lstm_bwd_pmc.json", "lstm_bwd_ring_bf16" if ring_bwd else "lstm_bwd_fused_bf16<2, 4, 1,"))
-        hbm_roof("lstm_dx", "lstm_dx_bf16 (input gradient of all steps, one launch)", "lstm_dx", by_dx,
-                 fl_text * spec.text_in / (spec.text_in + dp), traffic=("r04_lstm_bwd_pmc.json", "lstm_dx_bf16<2, 64, 2>"))
+        hbm_roof("lstm_dx", "lstm_dx_bf16 (input gradient of all steps, both directions in one launch)", "lstm_dx", by_dx,
+                 fl_text * spec.text_in / (spec.text_in + dp), traffic=("r04_lstm_bwd_pmc.json", "lstm_dx_bf16<2, 64, 2, true>"))
         mfma_roof("lstm_dw", "lstm_dw_bf16 (weight gradient: [x|h|1]^T dz over every row and step)", "lstm_dw", fl_text)
     # ---- attention kernels against HBM: algorithmic bytes = valid rows * w * 4 + question + output; the
     # backward reads the rows and writes their gradient
