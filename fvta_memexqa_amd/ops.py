@@ -116,7 +116,7 @@ class BiLstm:
         self.seq_J = seq_J.to(self.dev, torch.int32).contiguous()
         self.out_ld = int(out_ld)
         r = ctypes.byref(self.desc)
-        self.plan = _bytes(self.lib.fvta_lstm_plan_bytes(r), self.dev)
+        self.plan = _bytes(self.lib.fvta_lstm_plan_bytes(r), self.dev).zero_()   # (no stale plan state: out_pads_persist)
         self.saved = _bytes(self.lib.fvta_lstm_saved_bytes(r), self.dev)
         self.work = _bytes(self.lib.fvta_lstm_workspace_bytes(r), self.dev)
         self.training = training
