@@ -878,6 +878,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel_mfma(EmbArgs a) {
 //    adds into the workgroup's char table slice.
 // Both write the SAME slab layout as the other kernels ([KC*cwdim | cwdim | VC*cdim] per block), so
 // embed_bwd_reduce_kernel finishes the job in a fixed order.
+#ifndef FVTA_EMBW_CHAR_MFMA
+#define FVTA_EMBW_CHAR_MFMA 1
+#endif
 constexpr int EMBW_KCH = 128;   // k values per chunk (registers)
 constexpr int EMBW_CS = 32;     // channels per slice
 __global__ __launch_bounds__(EMB_NT) void embed_bwdw_filt(EmbArgs a) {
@@ -1018,6 +1021,131 @@ __global__ __launch_bounds__(256) void embed_bwdw_char(EmbArgs a) {
     if (c < nc) slab_c[(size_t)v * cd + c0 + c] = s_dC[i];
   }
 }
+
+// d char_emb of the wide shape on the matrix pipe (height 5, CW = 100 filters, W <= 16; any cdim in slices of 25 channels):
+// embed_bwd_5x8_char's scheme with a channel slice in place of the 8 channels.  One WAVE per token: the scatter of each active
+// filter's 5 x CS weights to its arg-max window is the product T[p][l] = sum_f G[p][f] filt[kc(l)][f], l = k CS + c (125 of 128
+// columns), with the one-hot G[p][f] = g_f [argpos_f = p] built from the staged gradient row -- 25 k-steps x 8 column tiles
+// of v_mfma_f32_16x16x4_f32, the slice's filter fragments in 200 registers for the whole launch; T goes through a transposed
+// LDS tile, dE[pos][c] = sum_k T[pos - k][k CS + c], and is added into the workgroup's char-table slice (LDS float adds: 7 per
+// lane and token beside 200 MFMAs).  embed_bwdw_char (vector pipe, two filter reads + two broadcast reads per filter and
+// thread, two in three of them multiplied by zero) took 27.7 ms at char_emb_size 100; this one is bound by its 6400 cycles
+// of fp32 MFMA per token and slice.  grid (ceil(cdim / 25), blocks), 256 threads, slab part [KC cw + cw ..) of block y.
+constexpr int EMBM_CS = 25;
+template <int CW>
+__global__ __launch_bounds__(256, 1) void embed_bwdw_char_mfma(EmbArgs a) {
+  using C = Emb5x8<CW>;
+  constexpr int CS = EMBM_CS, NCT = 8;  // 5 CS = 125 local columns l = k CS + c in 8 tiles of 16
+  extern __shared__ __attribute__((aligned(16))) float s_dCall[];  // [4 waves][VC][CS]: a table per wave (one summation order)
+  __shared__ __attribute__((aligned(16))) float s_T[C::NW][NCT * 16 * 16], s_G[C::NW][4 * C::GP];
+  __shared__ __attribute__((aligned(16))) uint8_t s_P[C::NW][4 * 32];
+  __shared__ int s_ch[C::NW][16];
+  const fvta_embed_desc& d = a.d;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int W = d.W, cd = d.cdim;
+  const int c0 = blockIdx.x * CS, nc = min(CS, cd - c0);
+  float* s_dC = s_dCall + (size_t)wv * d.VC * CS;
+  for (int i = lane; i < d.VC * CS; i += 64) s_dC[i] = 0.f;
+  float* Tt = s_T[wv];
+  for (int i = lane; i < 4 * C::GP; i += 64) s_G[wv][i] = 0.f;
+  for (int i = lane; i < 128; i += 64) s_P[wv][i] = 255;
+  // the slice's filter fragments: B[k = 4 ks + q][n = 16 ct + j] = filt[kc(l = 16 ct + j)][4 ks + q], zero beyond the slice
+  float Bf[C::NKS][NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int l = 16 * ct + j, k = l / CS, c = l % CS;
+    const bool ok = l < 5 * CS && c < nc;
+    const float* src = a.filt + (size_t)(k * cd + c0 + c) * CW + q;
+#pragma unroll
+    for (int ks = 0; ks < C::NKS; ++ks) Bf[ks][ct] = ok ? src[4 * ks] : 0.f;
+  }
+  __syncthreads();
+  const int step = gridDim.y * C::NW;
+  const bool has2 = lane + 64 < CW;
+  const int lane2 = has2 ? 64 + lane : lane;
+  const int posc = lane < W ? lane : W - 1;
+  auto load_tok = [&](int tok, int& ap1, int& ap2, float& g1, float& g2, int& ch) {  // branch-free: clamped token
+    const int t = tok < d.ntok ? tok : d.ntok - 1;
+    const float* row = a.dx + a.tok_off[t];
+    ap1 = a.argpos[(size_t)t * CW + lane];
+    const int b2 = a.argpos[(size_t)t * CW + lane2];
+    g1 = row[lane];
+    g2 = row[lane2];
+    ap2 = has2 ? b2 : 255;
+    ch = a.char_ids[(size_t)t * W + posc];
+  };
+  int tok = blockIdx.y * C::NW + wv;
+  int ap1, ap2, ch, ap1n, ap2n, chn;
+  float g1, g2, g1n, g2n;
+  load_tok(tok, ap1, ap2, g1, g2, ch);
+  for (; tok < d.ntok; tok += step) {
+    load_tok(tok + step, ap1n, ap2n, g1n, g2n, chn);
+    // stage the gradient row in k-phase order (filter f at [(f & 3)][f >> 2]) and the word's characters
+    s_G[wv][(lane & 3) * C::GP + (lane >> 2)] = ap1 == 255 ? 0.f : g1;
+    s_P[wv][(lane & 3) * 32 + (lane >> 2)] = (uint8_t)ap1;
+    if (has2) {
+      s_G[wv][(lane & 3) * C::GP + 16 + (lane >> 2)] = ap2 == 255 ? 0.f : g2;
+      s_P[wv][(lane & 3) * 32 + 16 + (lane >> 2)] = (uint8_t)ap2;
+    }
+    if (lane < 16) s_ch[wv][lane] = lane < W ? ch : -1;
+    wave_lds_fence();
+    // T[p][l] = sum_f G[p][f] filt[kc(l)][f]: lane (p = j, k phase q) builds G from the staged row
+    uint32_t Pv[8];
+    {
+      const uint4 p0 = *reinterpret_cast<const uint4*>(&s_P[wv][q * 32]);
+      const uint4 p1 = *reinterpret_cast<const uint4*>(&s_P[wv][q * 32 + 16]);
+      Pv[0] = p0.x; Pv[1] = p0.y; Pv[2] = p0.z; Pv[3] = p0.w;
+      Pv[4] = p1.x; Pv[5] = p1.y; Pv[6] = p1.z; Pv[7] = p1.w;
+    }
+    f32x4 accT[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) accT[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < C::GP / 4; ++v) {
+      const f32x4 Gv = *reinterpret_cast<const f32x4*>(&s_G[wv][q * C::GP + 4 * v]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ks = 4 * v + i;
+        if (ks < C::NKS) {
+          const int pb = (int)((Pv[v] >> (8 * i)) & 255u);
+          const float av = pb == j ? Gv[i] : 0.f;
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) accT[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bf[ks][ct], accT[ct], 0, 0, 0);
+        }
+      }
+    }
+    // T -> LDS as [l][p] (a lane's four rows p = 4 q + r are one 16-byte store), then dE[pos][c] = sum_k T[pos - k][k CS + c]
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(&Tt[(16 * ct + j) * 16 + 4 * q]) = accT[ct];
+    wave_lds_fence();
+    for (int it = lane; it < 16 * CS; it += 64) {
+      const int pos = it / CS, c = it % CS;
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const float tv = Tt[(k * CS + c) * 16 + (pos >= k ? pos - k : 0)];
+        v += pos >= k ? tv : 0.f;
+      }
+      const int me = s_ch[wv][pos];
+      if (me >= 0 && c < nc) lds_fadd(&s_dC[me * CS + c], v * emb_ks(a, tok, pos * cd + c0 + c, W * cd));
+    }
+    wave_lds_fence();
+    ap1 = ap1n; ap2 = ap2n; g1 = g1n; g2 = g2n; ch = chn;
+  }
+  __syncthreads();
+  const int KC = 5 * cd;
+  float* slab_c = a.slab + (size_t)blockIdx.y * ((size_t)KC * CW + CW + (size_t)d.VC * cd) + (size_t)KC * CW + CW;
+  for (int i = threadIdx.x; i < d.VC * CS; i += 256) {
+    const int v = i / CS, c = i % CS;
+    if (c < nc) {
+      float t = 0.f;
+      for (int w4 = 0; w4 < C::NW; ++w4) t += s_dCall[(size_t)w4 * d.VC * CS + i];  // wave order
+      slab_c[(size_t)v * cd + c0 + c] = t;
+    }
+  }
+}
+template __global__ void embed_bwdw_char_mfma<100>(EmbArgs);
 
 // the slab [KC*cwdim | cwdim | VC*cdim] of this workgroup is zeroed by the launcher and accumulated in place
 __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_big(EmbArgs a) {
@@ -1455,9 +1583,16 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
     const int KC = d->height * d->cdim;
     hipLaunchKernelGGL(embed_bwdw_filt, dim3((KC + EMBW_KCH - 1) / EMBW_KCH, blocks), dim3(EMB_NT),
                        (size_t)d->W * d->cdim * sizeof(float), stream, a);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)charw_lds);
-    hipLaunchKernelGGL(embed_bwdw_char, dim3((d->cdim + EMBW_CS - 1) / EMBW_CS, blocks), dim3(256), charw_lds, stream, a);
+    const size_t tabm = (size_t)4 * d->VC * EMBM_CS * sizeof(float);  // a char-table slice per wave
+    if (FVTA_EMBW_CHAR_MFMA && d->cwdim == 100 && d->height == 5 && tabm <= 112 * 1024) {  // the matrix-pipe form
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char_mfma<100>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)tabm);
+      hipLaunchKernelGGL(embed_bwdw_char_mfma<100>, dim3((d->cdim + EMBM_CS - 1) / EMBM_CS, blocks), dim3(256), tabm, stream, a);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)charw_lds);
+      hipLaunchKernelGGL(embed_bwdw_char, dim3((d->cdim + EMBW_CS - 1) / EMBW_CS, blocks), dim3(256), charw_lds, stream, a);
+    }
   } else if (embed_is_big(d)) {
     blocks = d->ntok < EMB_BIG_BLOCKS ? d->ntok : EMB_BIG_BLOCKS;
     FVTA_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)blocks * embed_slab_floats(d) * sizeof(float), stream));
