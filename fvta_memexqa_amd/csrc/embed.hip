@@ -1147,6 +1147,154 @@ __global__ __launch_bounds__(256, 1) void embed_bwdw_char_mfma(EmbArgs a) {
 }
 template __global__ void embed_bwdw_char_mfma<100>(EmbArgs);
 
+// d filt / d bias of the wide shape on the matrix pipe (same shapes and slices as embed_bwdw_char_mfma).  One WAVE per token:
+//   dFilt[l = k CS + c][f] += sum_p E[p + k][c0 + c] G[p][f],   G[p][f] = g_f [argpos_f = p]
+// as 8 row tiles x 7 filter tiles x 3 k-steps (arg-max positions 0 .. 11 at W <= 16) of v_mfma_f32_16x16x4_f32, the
+// slice's 128 x 112 accumulator tile in 224 registers of every wave for the whole launch; the token's (dropped) character
+// block slice goes through LDS, the one-hot operand is built from the gradient row in registers.  The four waves' tiles meet
+// in LDS in wave order at the end.  embed_bwdw_filt (vector pipe: 128 register accumulators per thread, one LDS read per FMA)
+// took 11.5 ms at char_emb_size 100.  grid (ceil(cdim / 25), blocks), 256 threads, slab part [0, KC cw + cw) of block y.
+template <int CW>
+__global__ __launch_bounds__(256, 1) void embed_bwdw_filt_mfma(EmbArgs a) {
+  constexpr int CS = EMBM_CS, NMT = 8, NNT = (CW + 15) / 16, NKS = 3, NW = 4;
+  extern __shared__ __attribute__((aligned(16))) float s_red[];  // [NMT][NNT][64 lanes][4]: the waves' tiles summed at the end
+  __shared__ float s_E[NW][16 * CS];
+  const fvta_embed_desc& d = a.d;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int W = d.W, cd = d.cdim;
+  const int c0 = blockIdx.x * CS, nc = min(CS, cd - c0);
+  f32x4 acc[NMT][NNT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NNT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float accb[NNT];
+#pragma unroll
+  for (int nt = 0; nt < NNT; ++nt) accb[nt] = 0.f;
+  // A operand addresses: lane (row l = 16 mt + j, k phase q) reads E[(4 ks + q) + k(l)][c(l)]; rows l >= 5 CS and channels
+  // beyond the slice read a zero row (position 16 of the staged block)
+  int aoff[NMT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) {
+    const int l = 16 * mt + j, k = l / CS, c = l % CS;
+    aoff[mt] = (l < 5 * CS && c < nc) ? (k + q) * CS + c : -1;
+  }
+  constexpr int NE = (16 * CS + 63) / 64;  // staged values per lane and token
+  const int step = gridDim.y * NW;
+  float* Es = s_E[wv];
+  auto load_E = [&](int tok, float (&e)[NE]) {  // the token's character block slice (dropped as in the forward), clamped token
+    const int t = tok < d.ntok ? tok : d.ntok - 1;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int it = lane + 64 * i, pos = it / CS, c = it % CS;
+      float v = 0.f;
+      if (it < 16 * CS && pos < W && c < nc)
+        v = a.char_emb[(size_t)a.char_ids[(size_t)t * W + pos] * cd + c0 + c] * emb_ks(a, t, pos * cd + c0 + c, W * cd);
+      e[i] = v;
+    }
+  };
+  auto load_G = [&](int tok, float (&g)[NNT], int (&ap)[NNT]) {
+    const int t = tok < d.ntok ? tok : d.ntok - 1;
+    const float* row = a.dx + a.tok_off[t];
+#pragma unroll
+    for (int nt = 0; nt < NNT; ++nt) {
+      const int f = 16 * nt + j, fc = f < CW ? f : CW - 1;
+      const int p = a.argpos[(size_t)t * CW + fc];
+      const float r = row[fc];
+      ap[nt] = f < CW ? p : 255;
+      g[nt] = (f < CW && p != 255) ? r : 0.f;
+    }
+  };
+  int tok = blockIdx.y * NW + wv;
+  float e_n[NE], g_n[NNT];
+  int ap_n[NNT];
+  load_E(tok, e_n);
+  load_G(tok, g_n, ap_n);
+  for (; tok < d.ntok; tok += step) {
+    float g_c[NNT];
+    int ap_c[NNT];
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+      if (lane + 64 * i < 16 * CS) Es[lane + 64 * i] = e_n[i];
+#pragma unroll
+    for (int nt = 0; nt < NNT; ++nt) {
+      g_c[nt] = g_n[nt];
+      ap_c[nt] = ap_n[nt];
+    }
+    if (blockIdx.x == 0) {  // the word rows ride along with the first slice
+      const int id = a.word_ids[tok];
+      if (id < d.VW) {
+        const float* row = a.dx + a.tok_off[tok];
+        for (int i = lane; i < d.wdim; i += 64) atomicAdd(a.d_word_emb + (size_t)id * d.wdim + i, row[CW + i]);
+      }
+    }
+    load_E(tok + step, e_n);
+    load_G(tok + step, g_n, ap_n);
+    wave_lds_fence();
+    if (q == 0)
+#pragma unroll
+      for (int nt = 0; nt < NNT; ++nt) accb[nt] += g_c[nt];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      float av[NMT], bv[NNT];
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) {
+        const float v = Es[aoff[mt] >= 0 ? aoff[mt] + 4 * ks * CS : 0];
+        av[mt] = aoff[mt] >= 0 ? v : 0.f;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NNT; ++nt) bv[nt] = ap_c[nt] == 4 * ks + q ? g_c[nt] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+    }
+    wave_lds_fence();  // the block's readers are done before the next token overwrites it
+  }
+  // ---- the four waves' tiles, in wave order, then the slab
+  f32x4* red = reinterpret_cast<f32x4*>(s_red);
+  for (int w4 = 0; w4 < NW; ++w4) {
+    if (wv == w4) {
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt) {
+          f32x4* cell = red + (mt * NNT + nt) * 64 + lane;
+          *cell = w4 == 0 ? acc[mt][nt] : *cell + acc[mt][nt];
+        }
+    }
+    __syncthreads();
+  }
+  const int KC = 5 * cd;
+  float* slab = a.slab + (size_t)blockIdx.y * ((size_t)KC * CW + CW + (size_t)d.VC * cd);
+  // tile (mt, nt), lane (j, q), element r: row l = 16 mt + 4 q + r, filter f = 16 nt + j
+  for (int idx = threadIdx.x; idx < NMT * NNT * 64; idx += 256) {
+    const int ln = idx & 63, tile = idx >> 6, nt = tile % NNT, mt = tile / NNT;
+    const int f = 16 * nt + (ln & 15);
+    const f32x4 v = red[idx];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int l = 16 * mt + 4 * (ln >> 4) + r, k = l / CS, c = l % CS;
+      if (l < 5 * CS && c < nc && f < CW) slab[(size_t)(k * cd + c0 + c) * CW + f] = v[r];
+    }
+  }
+  if (blockIdx.x == 0) {  // d bias: lanes q = 0 of the four waves, wave order
+    __syncthreads();
+    float* sb = s_red;  // [NW][NNT * 16]
+    if (q == 0)
+#pragma unroll
+      for (int nt = 0; nt < NNT; ++nt) sb[wv * NNT * 16 + 16 * nt + j] = accb[nt];
+    __syncthreads();
+    for (int f = threadIdx.x; f < CW; f += 256) {
+      float t = 0.f;
+      for (int w4 = 0; w4 < NW; ++w4) t += sb[w4 * NNT * 16 + f];
+      slab[(size_t)KC * CW + f] = t;
+    }
+  }
+}
+template __global__ void embed_bwdw_filt_mfma<100>(EmbArgs);
+
 // the slab [KC*cwdim | cwdim | VC*cdim] of this workgroup is zeroed by the launcher and accumulated in place
 __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_big(EmbArgs a) {
   extern __shared__ float s_dyn[];  // E [W*cdim], dE [W*cdim]
@@ -1581,6 +1729,12 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
   if (embed_is_big(d) && embed_mfma_ok(d) && charw_lds <= 150 * 1024) {
     blocks = d->ntok < EMB_BIG_BLOCKS ? d->ntok : EMB_BIG_BLOCKS;
     const int KC = d->height * d->cdim;
+    if (FVTA_EMBW_CHAR_MFMA && d->cwdim == 100 && d->height == 5) {  // the matrix-pipe form
+      constexpr int red_bytes = 8 * 7 * 64 * 16;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_filt_mfma<100>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                red_bytes);
+      hipLaunchKernelGGL(embed_bwdw_filt_mfma<100>, dim3((d->cdim + EMBM_CS - 1) / EMBM_CS, blocks), dim3(256), red_bytes, stream, a);
+    } else
     hipLaunchKernelGGL(embed_bwdw_filt, dim3((KC + EMBW_KCH - 1) / EMBW_KCH, blocks), dim3(EMB_NT),
                        (size_t)d->W * d->cdim * sizeof(float), stream, a);
     const size_t tabm = (size_t)4 * d->VC * EMBM_CS * sizeof(float);  // a char-table slice per wave
