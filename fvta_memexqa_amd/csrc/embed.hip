@@ -1075,6 +1075,17 @@ __global__ __launch_bounds__(256, 1) void embed_bwdw_char_mfma(EmbArgs a) {
     ap2 = has2 ? b2 : 255;
     ch = a.char_ids[(size_t)t * W + posc];
   };
+  // the lane's cells of dE[pos][c]: T index of k = 0 (column l = c, row pos), position (-1: no cell), channel
+  constexpr int NIT = (16 * CS + 63) / 64;
+  int tb[NIT], ps[NIT], cs_[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int it = lane + 64 * i, pos = it / CS, c = it % CS;
+    const bool ok = it < 16 * CS && c < nc;
+    tb[i] = ok ? c * 16 + pos : 0;
+    ps[i] = ok ? pos : -1;
+    cs_[i] = ok ? c : 0;
+  }
   int tok = blockIdx.y * C::NW + wv;
   int ap1, ap2, ch, ap1n, ap2n, chn;
   float g1, g2, g1n, g2n;
@@ -1119,16 +1130,22 @@ __global__ __launch_bounds__(256, 1) void embed_bwdw_char_mfma(EmbArgs a) {
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(&Tt[(16 * ct + j) * 16 + 4 * q]) = accT[ct];
     wave_lds_fence();
-    for (int it = lane; it < 16 * CS; it += 64) {
-      const int pos = it / CS, c = it % CS;
+    // (the lane's NIT cells (pos, c): indices precomputed, all 5 NIT reads of the tile in flight together)
+    float dv[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
       float v = 0.f;
 #pragma unroll
       for (int k = 0; k < 5; ++k) {
-        const float tv = Tt[(k * CS + c) * 16 + (pos >= k ? pos - k : 0)];
-        v += pos >= k ? tv : 0.f;
+        const float tv = Tt[tb[i] + (ps[i] >= k ? k * (16 * CS - 1) : 0)];
+        v += ps[i] >= k ? tv : 0.f;
       }
-      const int me = s_ch[wv][pos];
-      if (me >= 0 && c < nc) lds_fadd(&s_dC[me * CS + c], v * emb_ks(a, tok, pos * cd + c0 + c, W * cd));
+      dv[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int me = s_ch[wv][ps[i] & 15];
+      if (ps[i] >= 0 && me >= 0) lds_fadd(&s_dC[me * CS + cs_[i]], dv[i] * emb_ks(a, tok, ps[i] * cd + c0 + cs_[i], W * cd));
     }
     wave_lds_fence();
     ap1 = ap1n; ap2 = ap2n; g1 = g1n; g2 = g2n; ch = chn;
