@@ -293,7 +293,7 @@ def test_bilstm_bf16_backward_step_kernels_agree(B, J, din, dense):
         assert err < 2e-3, "%s: pipelined vs tiled backward step differ by %.5f (relative L2)" % (name, err)
 
 
-@pytest.mark.parametrize("precision", [F32, BF16])
+@pytest.mark.parametrize("precision", [F32, BF16, 2])   # 2: the split-bf16 engine (its dx kernels add: rows zeroed by the library)
 @pytest.mark.parametrize("B,J,din,d,dense,xdir", [(700, 5, 200, 512, False, False), (300, 4, 200, 512, True, False),
                                                    (300, 6, 100, 128, False, False), (260, 5, 200, 512, False, True)])
 def test_bilstm_dx_overwrite_equals_zero_fill_and_accumulate(precision, B, J, din, d, dense, xdir):
