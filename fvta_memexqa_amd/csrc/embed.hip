@@ -1022,7 +1022,8 @@ __global__ __launch_bounds__(256) void embed_bwdw_char(EmbArgs a) {
   }
 }
 
-// d char_emb of the wide shape on the matrix pipe (height 5, CW = 100 filters, W <= 16; any cdim in slices of 25 channels):
+// d char_emb of the wide shape on the matrix pipe (height 5, CW = 100 filters, W <= 16; any cdim in slices of EMBM_CS channels;
+// the counts below are those of 25-channel slices):
 // embed_bwd_5x8_char's scheme with a channel slice in place of the 8 channels.  One WAVE per token: the scatter of each active
 // filter's 5 x CS weights to its arg-max window is the product T[p][l] = sum_f G[p][f] filt[kc(l)][f], l = k CS + c (125 of 128
 // columns), with the one-hot G[p][f] = g_f [argpos_f = p] built from the staged gradient row -- 25 k-steps x 8 column tiles
@@ -1031,11 +1032,16 @@ __global__ __launch_bounds__(256) void embed_bwdw_char(EmbArgs a) {
 // lane and token beside 200 MFMAs).  embed_bwdw_char (vector pipe, two filter reads + two broadcast reads per filter and
 // thread, two in three of them multiplied by zero) took 27.7 ms at char_emb_size 100; this one is bound by its 6400 cycles
 // of fp32 MFMA per token and slice.  grid (ceil(cdim / 25), blocks), 256 threads, slab part [KC cw + cw ..) of block y.
-constexpr int EMBM_CS = 25;
+// channels per slice: 16 (80 of 80 columns in 5 tiles, <= 256 registers: TWO waves per SIMD -- d filt 7.4 -> 6.1 ms, d char 8.0 ->
+// 7.6 at char_emb_size 100, although 7 slices of 5 tiles are 9 % more MFMAs than 4 of 8 at 25 channels, one wave per SIMD)
+#ifndef FVTA_EMBM_CS
+#define FVTA_EMBM_CS 16
+#endif
+constexpr int EMBM_CS = FVTA_EMBM_CS, EMBM_NT = (5 * EMBM_CS + 15) / 16, EMBM_OCC = EMBM_CS <= 16 ? 2 : 1;
 template <int CW>
-__global__ __launch_bounds__(256, 1) void embed_bwdw_char_mfma(EmbArgs a) {
+__global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_char_mfma(EmbArgs a) {
   using C = Emb5x8<CW>;
-  constexpr int CS = EMBM_CS, NCT = 8;  // 5 CS = 125 local columns l = k CS + c in 8 tiles of 16
+  constexpr int CS = EMBM_CS, NCT = EMBM_NT;  // 5 CS = 125 local columns l = k CS + c in 8 tiles of 16
   extern __shared__ __attribute__((aligned(16))) float s_dCall[];  // [4 waves][VC][CS]: a table per wave (one summation order)
   __shared__ __attribute__((aligned(16))) float s_T[C::NW][NCT * 16 * 16], s_G[C::NW][4 * C::GP];
   __shared__ __attribute__((aligned(16))) uint8_t s_P[C::NW][4 * 32];
@@ -1172,8 +1178,8 @@ template __global__ void embed_bwdw_char_mfma<100>(EmbArgs);
 // in LDS in wave order at the end.  embed_bwdw_filt (vector pipe: 128 register accumulators per thread, one LDS read per FMA)
 // took 11.5 ms at char_emb_size 100.  grid (ceil(cdim / 25), blocks), 256 threads, slab part [0, KC cw + cw) of block y.
 template <int CW>
-__global__ __launch_bounds__(256, 1) void embed_bwdw_filt_mfma(EmbArgs a) {
-  constexpr int CS = EMBM_CS, NMT = 8, NNT = (CW + 15) / 16, NKS = 3, NW = 4;
+__global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_filt_mfma(EmbArgs a) {
+  constexpr int CS = EMBM_CS, NMT = EMBM_NT, NNT = (CW + 15) / 16, NKS = 3, NW = 4;
   extern __shared__ __attribute__((aligned(16))) float s_red[];  // [NMT][NNT][64 lanes][4]: the waves' tiles summed at the end
   __shared__ float s_E[NW][16 * CS];
   const fvta_embed_desc& d = a.d;
@@ -1747,7 +1753,7 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
     blocks = d->ntok < EMB_BIG_BLOCKS ? d->ntok : EMB_BIG_BLOCKS;
     const int KC = d->height * d->cdim;
     if (FVTA_EMBW_CHAR_MFMA && d->cwdim == 100 && d->height == 5) {  // the matrix-pipe form
-      constexpr int red_bytes = 8 * 7 * 64 * 16;
+      constexpr int red_bytes = EMBM_NT * 7 * 64 * 16;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_filt_mfma<100>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 red_bytes);
       hipLaunchKernelGGL(embed_bwdw_filt_mfma<100>, dim3((d->cdim + EMBM_CS - 1) / EMBM_CS, blocks), dim3(256), red_bytes, stream, a);
