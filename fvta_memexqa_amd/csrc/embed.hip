@@ -867,6 +867,111 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel_mfma(EmbArgs a) {
   }
 }
 
+// The same convolution with the FILTERS in registers (height 5, char_emb_size 100, CW = 100, W <= 16): one WAVE per token and
+// slice of 16 filters -- Y[p][f] = sum_kc E[p cd + kc] filt[kc][f] as 128 k-steps of ONE v_mfma_f32_16x16x4_f32 tile (16 window
+// positions x 16 filters; four partial accumulators break the dependent chain), the slice's filter fragments in 128 registers
+// for the whole launch (two waves per SIMD), the token's character block [16][cd] staged once in LDS and read as the A operand
+// 16 bytes at a time: k is permuted so that a lane's float4 E[p cd + 16 g + 4 q ..] feeds k-steps 4 g .. 4 g + 3 (the filter
+// fragments are loaded in the same order; kc >= 500 multiplies by zero).  Max / first arg-max over the positions: 4 per lane,
+// then across the four lane groups.  grid (ceil(CW / 16), blocks).  The tile engine above spends 0.75 x 0.78 of its tile on
+// padding and gathers its A operand element by element: 11.3 ms at the published flag set's token count.
+template <int CW, int CD>
+__global__ __launch_bounds__(256, 2) void embed_fwdw_mfma(EmbArgs a) {
+  constexpr int KC = 5 * CD, NG = (KC + 15) / 16, NW = 4, EB = 15 * CD + 16 * NG;  // floats of a staged block (the last window's reach)
+  constexpr int EBP = (EB + 3) / 4 * 4, NL4 = (16 * CD / 4 + 63) / 64;             // float4 loads per lane and token
+  static_assert(CD % 4 == 0, "character rows are read 16 bytes at a time");
+  __shared__ __attribute__((aligned(16))) float s_E[NW][EBP];
+  const fvta_embed_desc& d = a.d;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int W = d.W, P = W - 4;
+  const int f = blockIdx.x * 16 + j;
+  float Bf[4 * NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kc = 16 * g + 4 * q + i;
+      Bf[4 * g + i] = (kc < KC && f < CW) ? a.filt[(size_t)kc * CW + f] : 0.f;
+    }
+  const float bias = f < CW ? a.bias[f] : 0.f;
+  float* Es = s_E[wv];
+  for (int i = lane; i < EBP; i += 64) Es[i] = 0.f;  // (positions >= W and the reach beyond the block stay zero)
+  auto word_src = [&](int id) { return id < d.VW ? a.word_emb + (size_t)id * d.wdim : a.fixed_emb + (size_t)(id - d.VW) * d.wdim; };
+  auto load_E = [&](int tok, f32x4 (&e)[NL4]) {  // clamped token: branch-free
+    const int t = tok < d.ntok ? tok : d.ntok - 1;
+#pragma unroll
+    for (int i = 0; i < NL4; ++i) {
+      const int u = lane + 64 * i, pos = u / (CD / 4), c4 = u % (CD / 4);
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (u < 16 * CD / 4 && pos < W) {
+        v = *reinterpret_cast<const f32x4*>(a.char_emb + (size_t)a.char_ids[(size_t)t * W + pos] * CD + 4 * c4);
+        if (a.drop_thr != 0ull)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) v[x] *= emb_ks(a, t, pos * CD + 4 * c4 + x, W * CD);
+      }
+      e[i] = v;
+    }
+  };
+  const int step = gridDim.y * NW;
+  int tok = blockIdx.y * NW + wv;
+  f32x4 e_n[NL4];
+  load_E(tok, e_n);
+  wave_lds_fence();
+  for (; tok < d.ntok; tok += step) {
+#pragma unroll
+    for (int i = 0; i < NL4; ++i) {
+      const int u = lane + 64 * i;
+      if (u < 16 * CD / 4) *reinterpret_cast<f32x4*>(Es + 4 * u) = e_n[i];
+    }
+    load_E(tok + step, e_n);
+    wave_lds_fence();
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ap = Es + j * CD + 4 * q;  // window position p = j
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 16 * g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], Bf[4 * g + i], acc[i], 0, 0, 0);
+    }
+    // D[p = 4 q + r][f = j]: max / FIRST arg-max over the valid positions
+    float best = -INFINITY;
+    int bp = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+      const int p = 4 * q + r;
+      if (p < P && v > best) {
+        best = v;
+        bp = p;
+      }
+    }
+#pragma unroll
+    for (int sh = 16; sh <= 32; sh <<= 1) {
+      const float ob = __shfl_xor(best, sh, 64);
+      const int op = __shfl_xor(bp, sh, 64);
+      if (ob > best || (ob == best && op < bp)) {
+        best = ob;
+        bp = op;
+      }
+    }
+    float* row = a.x + a.tok_off[tok];
+    if (q == 0 && f < CW) {
+      const float y = best + bias;
+      row[f] = y > 0.f ? y : 0.f;
+      a.argpos[(size_t)tok * CW + f] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
+    }
+    if (blockIdx.x == 0) {  // the word part of the row rides along with the first slice
+      const float* src = word_src(a.word_ids[tok]);
+      for (int i = lane; i < d.wdim; i += 64) row[CW + i] = src[i];
+    }
+    wave_lds_fence();  // the block's readers are done before the next token overwrites it
+  }
+}
+template __global__ void embed_fwdw_mfma<100, 100>(EmbArgs);
+
 // Backward of the wide shape, in the SPARSE form (one window per token and filter carries gradient: 12x fewer MACs than
 // the GEMM form), split so that every accumulator lives in registers / LDS instead of a global slab:
 //  * embed_bwdw_filt: d filter / d bias.  grid (k chunks of 128, blocks); thread f keeps its 128 filter-gradient
@@ -880,6 +985,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel_mfma(EmbArgs a) {
 // embed_bwd_reduce_kernel finishes the job in a fixed order.
 #ifndef FVTA_EMBW_CHAR_MFMA
 #define FVTA_EMBW_CHAR_MFMA 1
+#endif
+#ifndef FVTA_EMBW_FWD_WAVE
+#define FVTA_EMBW_FWD_WAVE 1
 #endif
 constexpr int EMBW_KCH = 128;   // k values per chunk (registers)
 constexpr int EMBW_CS = 32;     // channels per slice
@@ -1714,7 +1822,11 @@ extern "C" int fvta_embed_fwd(const fvta_embed_desc* d, const int32_t* word_ids,
   emb_set_dropout(a, d);
   const int blocks = d->ntok < 8192 ? d->ntok : 8192;
   // (with dropout the matrix-pipe kernel, which gathers its A operand straight from the character table, is not used)
-  if (embed_mfma_ok(d) && d->cwdim > 0 && embed_is_big(d) && a.drop_thr == 0ull) {
+  if (FVTA_EMBW_FWD_WAVE && embed_mfma_ok(d) && d->cwdim == 100 && d->cdim == 100 && d->height == 5 && d->W >= 5) {
+    // the published --char_emb_size 100: filters in registers, a wave per token (with or without dropout)
+    const int nb = (d->ntok + 3) / 4 < 1024 ? (d->ntok + 3) / 4 : 1024;
+    hipLaunchKernelGGL((embed_fwdw_mfma<100, 100>), dim3(7, nb), dim3(256), 0, (hipStream_t)stream_, a);
+  } else if (embed_mfma_ok(d) && d->cwdim > 0 && embed_is_big(d) && a.drop_thr == 0ull) {
     hipLaunchKernelGGL(embed_fwd_kernel_mfma, dim3((d->ntok + 7) / 8), dim3(256), MmaEmb::LDS_FLOATS * sizeof(float),
                        (hipStream_t)stream_, a);
   } else if (embed_is_big(d)) {
