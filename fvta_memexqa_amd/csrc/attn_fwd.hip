@@ -106,9 +106,11 @@ __global__ __launch_bounds__(256) void attn_prep_q_kernel(AttnShape s, AttnSaved
   const float* Cq = sv.vecs + VEC_CQ * w;
   const float* C2 = sv.vecs + VEC_C2 * w;
   const float bias = (s.simi == 4 || bptr == nullptr) ? 0.f : bptr[0];
-  // grid (N, slices): slice 0 owns ct / the valid-j bits; the question norms are needed by every slice (cosine only)
-  if (blockIdx.y == 0 || s.simi == 4)
-  for (int j = wave; j < s.JP; j += 4) {
+  // grid (N, slices): the question norms are needed by every slice (cosine only: every slice walks every j and slice 0
+  // writes ct); otherwise the slices share the positions (ct of position j by slice (j / 4) % slices: one position per wave
+  // and round -- slice 0 alone walked all JP positions, 8 per wave, while seven slices waited at the barrier: 45 us)
+  const bool every = s.simi == 4;
+  for (int j = (every ? 0 : 4 * (int)blockIdx.y) + wave; j < s.JP; j += every ? 4 : 4 * (int)gridDim.y) {
     float s1 = 0.f, s2 = 0.f;
     if (j < s.JQ)
       for (int c = lane; c < w; c += 64) {
@@ -119,8 +121,8 @@ __global__ __launch_bounds__(256) void attn_prep_q_kernel(AttnShape s, AttnSaved
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
     if (lane == 0) {
-      if (blockIdx.y == 0) sv.ct[(size_t)n * s.JP + j] = (j < s.JQ && s.simi != 4) ? s1 + bias : 0.f;
-      s_rq[j] = rsqrtf(fmaxf(s2, 1e-12f));  // tf.nn.l2_normalize eps
+      if (blockIdx.y == 0 || !every) sv.ct[(size_t)n * s.JP + j] = (j < s.JQ && s.simi != 4) ? s1 + bias : 0.f;
+      s_rq[j] = rsqrtf(fmaxf(s2, 1e-12f));  // tf.nn.l2_normalize eps (read back under the cosine similarity only)
     }
   }
   if (tid == 0 && blockIdx.y == 0) {
