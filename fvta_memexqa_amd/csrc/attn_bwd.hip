@@ -65,15 +65,16 @@ static AttnBwdWork bwd_work_view(const AttnShape& s, void* p) {
   return v;
 }
 
-// ---- per-(n,k) scalars.  grid N, 256 threads; a wave per k (no workgroup barrier inside the k loop)
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnShape s, AttnSaved sv, AttnBwdWork wk,
+// ---- per-(n,k) scalars.  grid N, 1024 threads; a wave per k (no workgroup barrier inside the k loop; 16 waves: a stream's
+// dot product and tie count are one chain of load latencies, 10 streams per wave took 20 us at K = 40)
+__global__ __launch_bounds__(1024) void attn_bwd_prep_kernel(AttnShape s, AttnSaved sv, AttnBwdWork wk,
                                                             const float* __restrict__ d_h_a) {
   __shared__ float s_gu[64];
   __shared__ int s_ties[64];
   const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int w = s.w, K = s.K, T = s.T;
   const float* g = d_h_a + (size_t)n * w;
-  for (int k = wave; k < K; k += 4) {
+  for (int k = wave; k < K; k += (int)(blockDim.x >> 6)) {
     const float* u = sv.u + ((size_t)n * K + k) * w;
     float acc = 0.f;
     for (int c = lane; c < w; c += 64) acc += g[c] * u[c];
@@ -89,17 +90,25 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnShape s, AttnSav
       s_ties[k] = ties;
     }
   }
+  // thread k finishes stream k (one thread walked all K with three dependent global loads each: ~20 of the launch's 25 us);
+  // the mean is summed in k order by every thread from LDS
+  __shared__ float s_r[64];
+  float r = 0.f, L = 1.f;
+  int am_ = 0;
+  if (tid < K) {
+    r = sv.r[n * K + tid];
+    L = sv.L[n * K + tid];
+    am_ = sv.allmasked[n * K + tid];
+    s_r[tid] = r;
+  }
   __syncthreads();
-  if (tid == 0) {
+  if (tid < K) {
     float mean = 0.f;
-    for (int k = 0; k < K; ++k) mean += sv.r[n * K + k] * s_gu[k];
-    for (int k = 0; k < K; ++k) {
-      const float r = sv.r[n * K + k];
-      wk.coef[n * K + k] = r / sv.L[n * K + k];
-      wk.gu[n * K + k] = s_gu[k];
-      const float ds = r * (s_gu[k] - mean);
-      wk.dss[n * K + k] = sv.allmasked[n * K + k] ? 0.f : ds / (float)max(1, s_ties[k]);
-    }
+    for (int k = 0; k < K; ++k) mean += s_r[k] * s_gu[k];
+    wk.coef[n * K + tid] = r / L;
+    wk.gu[n * K + tid] = s_gu[tid];
+    const float ds = r * (s_gu[tid] - mean);
+    wk.dss[n * K + tid] = am_ ? 0.f : ds / (float)max(1, s_ties[tid]);
   }
 }
 
@@ -561,10 +570,24 @@ __global__ __launch_bounds__(256) void attn_bwd_params_kernel(AttnShape s, AttnB
   }
   const int cl = tid & 63, grp = tid >> 6, c = blockIdx.x * 64 + cl;
   float v[VEC_COUNT] = {0, 0, 0, 0, 0};
-  if (c < w)
-    for (int n = grp; n < s.N * attn_bwd_jz(s); n += 4)   // rows = (n, group of question positions)
+  if (c < w) {
+    const int rows = s.N * attn_bwd_jz(s);   // rows = (n, group of question positions)
+    int n = grp;
+    for (; n + 12 < rows; n += 16) {         // four rows per round, their 20 loads in flight together; same order of sums
+      float x[4][VEC_COUNT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < VEC_COUNT; ++k) x[i][k] = wk.pvec[((size_t)(n + 4 * i) * VEC_COUNT + k) * w + c];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < VEC_COUNT; ++k) v[k] += x[i][k];
+    }
+    for (; n < rows; n += 4)
 #pragma unroll
       for (int k = 0; k < VEC_COUNT; ++k) v[k] += wk.pvec[((size_t)n * VEC_COUNT + k) * w + c];
+  }
 #pragma unroll
   for (int k = 0; k < VEC_COUNT; ++k) s_p[grp][k][cl] = v[k];
   __syncthreads();
@@ -709,7 +732,7 @@ extern "C" int fvta_attn_bwd_tw(const fvta_attn_desc* d, const float* hinfo, con
     else
       FVTA_CHECK_HIP(hipMemsetAsync(d_hinfo, 0, (size_t)s.N * s.K * s.T * s.w * sizeof(float), stream));
   }
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(s.N), dim3(256), 0, stream, s, sv, wk, d_h_a);
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(s.N), dim3(s.K > 4 ? 1024 : 256), 0, stream, s, sv, wk, d_h_a);
   AttnBwdArgs a;
   a.s = s;
   a.sv = sv;
