@@ -25,7 +25,8 @@ __device__ __forceinline__ f32x4 ld4b(const float* p) { return *reinterpret_cast
 
 constexpr int BWD_CHMAX = 1024;  // rows per backward workgroup chunk (LDS sort capacity)
 
-static inline __host__ __device__ int attn_bwd_jz(const AttnShape& s) { return (s.JQ + 7) / 8; }
+constexpr int ATTN_BWD_JG = 8;  // question positions per workgroup of the slab fold: two per wave (four, one per wave: no faster)
+static inline __host__ __device__ int attn_bwd_jz(const AttnShape& s) { return (s.JQ + ATTN_BWD_JG - 1) / ATTN_BWD_JG; }
 
 struct AttnBwdWork {
   float* coef;   // [N,K]  r / L
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_q_kernel(AttnShape s, Att
   };
   const f32x4 U = ld4(sv.vecs + VEC_U * w + c), Cq = ld4(sv.vecs + VEC_CQ * w + c), C2 = ld4(sv.vecs + VEC_C2 * w + c);
   f32x4 pU = zero, pCq = zero, pC2 = zero;
-  const int jz = blockIdx.z, j_lo = jz * 8, j_hi = min(JQ, j_lo + 8);
+  const int jz = blockIdx.z, j_lo = jz * ATTN_BWD_JG, j_hi = min(JQ, j_lo + ATTN_BWD_JG);
   for (int j = j_lo + wave; j < j_hi; j += 4) {
     const f32x4 dQ = fold(wk.slabs + (slot0 * JP + j) * w + c, (size_t)JP * w);
     const f32x4 qv = ld4(hq + ((size_t)n * JQ + j) * w + c);

@@ -241,42 +241,44 @@ __global__ void plan_fill_kernel(PlanView v, int B, int J, int in, int d) {
 // persist (desc.out_pads_persist: nobody but this op writes the output buffer between forward calls): only the rows the
 // LAST forward on this plan memory wrote and this one will not -- [len, dirty) -- are zeroed; the plan remembers per sequence
 // how far it has written into which buffer.  (A ragged metric-shape batch: 0.79 GB of zeros per step otherwise, 161 us.)
-__global__ __launch_bounds__(256) void pad_zero_kernel(PlanView v, float* __restrict__ out, int d, int persist) {
-  const int b = blockIdx.x;
+__global__ __launch_bounds__(256) void pad_zero_kernel(PlanView v, float* __restrict__ out, int d, int persist, int B) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // a wave per sequence
+  if (b >= B) return;
   const int L = v.len[b], Jb = v.seq_J[b];
   const int64_t ld = v.hdr->out_ld;
   float* first = out + v.out_off[b];
   const bool known = persist && v.dirty_out[b] == (int64_t)reinterpret_cast<uintptr_t>(first);
   const int hi = known ? min(v.dirty[b], Jb) : Jb;
-  __syncthreads();  // every thread has read the sequence's state
-  if (threadIdx.x == 0) {
+  // (the update is behind the reads of the sequence's state: same wave, program order, and its predicate needs their data)
+  if (lane == 0 && hi >= 0) {
     v.dirty[b] = L;
     v.dirty_out[b] = (int64_t)reinterpret_cast<uintptr_t>(first);
   }
   const int w4 = (2 * d) / 4;
   for (int t = L; t < hi; ++t) {
     f32x4* row = reinterpret_cast<f32x4*>(first + (int64_t)t * ld);
-    for (int c = threadIdx.x; c < w4; c += blockDim.x) row[c] = zero4();
+    for (int c = lane; c < w4; c += 64) row[c] = zero4();
   }
 }
 
 // desc.dx_overwrite: rows [t0, seq_J) of every sequence's dx are zeroed -- t0 = len (the padded positions: the dx kernel
 // writes the rest) or 0 (all rows: the dx kernels of this engine / shape add to dx).  Both copies under a separate input per
 // direction.  grid (B, 4)
-__global__ void dx_zero_rows_kernel(PlanView v, float* __restrict__ dx, int in, int pads_only) {
-  const int b = blockIdx.x;
+__global__ __launch_bounds__(256) void dx_zero_rows_kernel(PlanView v, float* __restrict__ dx, int in, int pads_only, int B) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // a wave per sequence
+  if (b >= B) return;
   const int L = pads_only ? v.len[b] : 0, Jb = v.seq_J[b];
   const int64_t delta = v.hdr->x_bw_delta;
   const int w4 = in / 4;
-  for (int t = L + blockIdx.y; t < Jb; t += gridDim.y) {
+  for (int t = L; t < Jb; ++t) {
     float* row = dx + v.x_off[b] + (int64_t)t * in;
     if ((reinterpret_cast<uintptr_t>(row) & 15) == 0 && (delta & 3) == 0) {
-      for (int c = threadIdx.x; c < w4; c += blockDim.x) {
+      for (int c = lane; c < w4; c += 64) {
         reinterpret_cast<f32x4*>(row)[c] = zero4();
         if (delta) reinterpret_cast<f32x4*>(row + delta)[c] = zero4();
       }
     } else {
-      for (int c = threadIdx.x; c < in; c += blockDim.x) {
+      for (int c = lane; c < in; c += 64) {
         row[c] = 0.f;
         if (delta) row[delta + c] = 0.f;
       }
@@ -638,7 +640,7 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   a.J = d->J;
   a.in = d->in;
   a.d = d->d;
-  hipLaunchKernelGGL(pad_zero_kernel, dim3(d->B), dim3(256), 0, stream, pv, out, d->d, d->out_pads_persist);
+  hipLaunchKernelGGL(pad_zero_kernel, dim3((d->B + 3) / 4), dim3(256), 0, stream, pv, out, d->d, d->out_pads_persist, d->B);
   FVTA_CHECK_LAUNCH("pad_zero");
   const dim3 grid((d->B + MmaStep::BM - 1) / MmaStep::BM, d->d / 32, 2);
   const size_t sh = MmaStep::LDS_FLOATS * sizeof(float);
@@ -789,7 +791,7 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
     f.dx_both = 0;
     if (dx && d->dx_overwrite) {  // ... or written: the padded rows zeroed here, the rest by the dx kernel where it can
       const bool direct = dx_writes_whole_rows(f);
-      hipLaunchKernelGGL(dx_zero_rows_kernel, dim3(B, 4), dim3(64), 0, stream, pv, dx, in, direct ? 1 : 0);
+      hipLaunchKernelGGL(dx_zero_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, pv, dx, in, direct ? 1 : 0, B);
       f.dx_accumulate = direct ? 0 : 1;
     }
     for (int t = J - 1; t >= 0; --t) {
@@ -804,7 +806,7 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
       fvta_prof_end(FVTA_PROF_LSTM_DX + 16 * d->reserved, 1, stream);
     }
   } else {
-  if (dx && d->dx_overwrite) hipLaunchKernelGGL(dx_zero_rows_kernel, dim3(B, 4), dim3(64), 0, stream, pv, dx, in, 0);
+  if (dx && d->dx_overwrite) hipLaunchKernelGGL(dx_zero_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, pv, dx, in, 0, B);
   for (int t = J - 1; t >= 0; --t) {
     g.t = t;
     s.t = t;
