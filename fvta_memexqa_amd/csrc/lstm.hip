@@ -711,7 +711,9 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
   SavedView sv = saved_view(d, saved);
   WorkView wv = work_view(d, workspace);
   const int B = d->B, J = d->J, in = d->in, dd = d->d;
-  FVTA_CHECK_HIP(hipMemsetAsync(wv.cstate, 0, (size_t)2 * B * dd * sizeof(float) * 2, stream));  // dc and dh_rec
+  // dc and dh_rec start at zero (fp32 engine).  The bf16 engines' step kernels read dc of rows that were not active at
+  // step t + 1 as zero themselves and have no dh_rec round trip: no 105 MB fill per call at the metric shape
+  if (!lstm_is_bf(d)) FVTA_CHECK_HIP(hipMemsetAsync(wv.cstate, 0, (size_t)2 * B * dd * sizeof(float) * 2, stream));
   GateBwdArgs g;
   g.plan = pv;
   g.d_out = d_out;

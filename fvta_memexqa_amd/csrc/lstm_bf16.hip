@@ -327,7 +327,10 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
       in.dout = ldnt(dp);
     else
       in.dout = f32x4{dp[0], dp[1], dp[2], dp[3]};  // an output row that is not 16-byte aligned
-    in.dcv = *reinterpret_cast<const f32x4*>(dcs + (size_t)ic * d + uc);
+    // dc of a row that was not active at step t + 1 is zero by definition (the engine does not zero the buffer): an
+    // unconditional load + select
+    const f32x4 dcl = *reinterpret_cast<const f32x4*>(dcs + (size_t)ic * d + uc);
+    in.dcv = (m0 + row) < nnext ? dcl : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto do_pass = [&](int P, const In& in) {
     const int pl = P >> 2, it = P & 3, ti = pl / MmaB::TN;

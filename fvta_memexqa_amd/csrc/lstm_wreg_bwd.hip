@@ -106,7 +106,10 @@ __global__ __launch_bounds__(64 * C::NW, 1) void lstm_bwd_wreg_bf16(FusedBwdArgs
         x[g].dout = ldnt(dp);
       else
         x[g].dout = f32x4{dp[0], dp[1], dp[2], dp[3]};  // an output row that is not 16-byte aligned
-      x[g].dcv = *reinterpret_cast<const f32x4*>(dcs + (size_t)ic * d + u);
+      // dc of a row that was not active at step t + 1 is zero BY DEFINITION (nothing has written it in this call: the
+      // engine does not zero the buffer); an unconditional load + select, no branch around the load
+      const f32x4 dcl = *reinterpret_cast<const f32x4*>(dcs + (size_t)ic * d + u);
+      x[g].dcv = (32 * rt + er) < nnext ? dcl : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto lda = [&](unsigned voff, int ks) {
@@ -318,6 +321,9 @@ __global__ __launch_bounds__(64 * C::NW, 1) void lstm_bwd_ring_bf16(FusedBwdArgs
   const __amdgpu_buffer_rsrc_t rgt = make_rsrc(a.gatesb + trow * (size_t)K, (unsigned)nact * K * 2);
   const __amdgpu_buffer_rsrc_t rcs = make_rsrc(t > 0 ? a.cs + (trow - a.B) * (size_t)D : a.cs, t > 0 ? (unsigned)nact * D * 4 : 0u);
   const __amdgpu_buffer_rsrc_t rdc = make_rsrc(a.dc + (size_t)dir * a.B * D, (unsigned)nact * D * 4);
+  // (loads: only rows that were active at step t + 1 hold a dc of this call -- the others read 0 off this descriptor's end;
+  //  the engine does not zero the buffer)
+  const __amdgpu_buffer_rsrc_t rdc_ld = make_rsrc(a.dc + (size_t)dir * a.B * D, (unsigned)nnext * D * 4);
   const __amdgpu_buffer_rsrc_t rzo = make_rsrc(a.dzb + trow * (size_t)K, (unsigned)nact * K * 2);  // dz_t
 
   // ---- the operand stream: piece j of a slot = rows 8 j + (lane >> 3), 16-byte chunk (lane & 7) of the LDS row; the
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void lstm_bwd_ring_bf16(FusedBwdArgs
         in.dout[g] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dp));
       else
         in.dout[g] = f32x4{dp[0], dp[1], dp[2], dp[3]};  // an output row that is not 16-byte aligned (more operations: the count stays safe)
-    } else in.dcv[g] = __builtin_bit_cast(f32x4, ld4(rdc, vo_f + rf_, 128 * g));
+    } else in.dcv[g] = __builtin_bit_cast(f32x4, ld4(rdc_ld, vo_f + rf_, 128 * g));
   };
   auto epi_store = [&](auto n_c, int m0p) {
     constexpr int n = decltype(n_c)::value, g = n / 3, what = n % 3;
