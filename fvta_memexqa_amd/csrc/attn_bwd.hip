@@ -450,7 +450,15 @@ __global__ __launch_bounds__(256) void attn_bwd_reduce_q_kernel(AttnShape s, Att
   const size_t slot0 = (size_t)n * nslot;
   if (threadIdx.x < JP) {
     float acc = 0.f;
-    for (int sl = 0; sl < nslot; ++sl) acc += wk.dctp[(slot0 + sl) * JP + threadIdx.x];
+    int sl = 0;
+    for (; sl + 8 <= nslot; sl += 8) {  // eight slots in flight, summed in slot order
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = wk.dctp[(slot0 + sl + i) * JP + threadIdx.x];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += v[i];
+    }
+    for (; sl < nslot; ++sl) acc += wk.dctp[(slot0 + sl) * JP + threadIdx.x];
     s_dct[threadIdx.x] = acc;
     if (blockIdx.y == 0 && blockIdx.z == 0) wk.dctn[(size_t)n * JP + threadIdx.x] = acc;
   }
