@@ -95,6 +95,10 @@ def parse(argv=None):
     ap.add_argument("--also", default="auto", choices=["auto", "on", "off"],
                     help="after the headline, time the other BASELINE.json configurations that fit one GPU in short runs and "
                          "attach them as `also` (auto: for the default N=1 headline only)")
+    ap.add_argument("--gc", default="freeze", choices=["freeze", "default"],
+                    help="freeze: gc.collect(); gc.freeze(); gc.disable() once the model and the batch are built, as a training "
+                         "loop that owns its process does (a generation-2 pass over torch's and numpy's heaps is a pause of tens of "
+                         "milliseconds on the host); default: CPython's collector left alone (diagnosis)")
     ap.add_argument("--also-helper", action="store_true", help=argparse.SUPPRESS)   # internal: the `also` orchestrator (no GPU)
     return ap.parse_args(argv)
 
@@ -201,6 +205,7 @@ def cpu_baseline(spec_kw, sample_n, forward_only, threads, literal_n=1):
 
 
 # --------------------------------------------------------------------------------------------------- one case --
+GC_MODE = "default"
 PROF_IDS = [("lstm_step_fwd", 1), ("lstm_step_bwd", 2), ("lstm_dw", 3), ("attn_fwd_main", 4), ("attn_bwd_main", 5),
             ("lstm_dx", 6), ("lstm_step_fwd_photo_cell", 17)]
 
@@ -274,6 +279,13 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
         else:
             trainer.step_device(L)
 
+    global GC_MODE
+    GC_MODE = args.gc
+    import gc
+    if args.gc == "freeze":      # everything alive now is the model / the batch: nothing for a collector to find
+        gc.collect()
+        gc.freeze()
+        gc.disable()
     for i in range(args.warmup):
         step()
         torch.cuda.synchronize()
@@ -282,17 +294,38 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     # one HIP event per step on the main stream (every side stream has joined it when a step ends) gives the
     # per-step device times whose median is reported beside the wall-clock mean
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    for m in marks:          # (an event's HIP object is created by its first record: not inside the timed region)
+        m.record()
+    # the host side of the timed region is watched too: the collector's pauses (gc.callbacks), the process's page faults
+    # and context switches (getrusage), and the host's enqueue time of every single step
+    import gc
+    import resource
+    gc_log = []
+
+    def gc_watch(phase, info, _t=[0.0]):
+        if phase == "start":
+            _t[0] = time.perf_counter()
+        else:
+            gc_log.append((info.get("generation"), round((time.perf_counter() - _t[0]) * 1e3, 3), round((_t[0] - t0) * 1e3, 3)))
+
+    host_t = [0.0] * (args.steps + 1)
     dist.barrier()
     torch.cuda.synchronize()
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    gc.callbacks.append(gc_watch)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
         step()
         marks[i + 1].record()
+        host_t[i + 1] = time.perf_counter() - t0
     host_enqueue = time.perf_counter() - t0      # the host's share: when it equals the step time the run is launch bound
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.callbacks.remove(gc_watch)
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_step_ms = [round((host_t[i + 1] - host_t[i]) * 1e3, 3) for i in range(args.steps)]
     rank_elapsed = dist.gather_over_ranks(elapsed, dev)      # every rank's own wall clock over the timed region
     elapsed = dist.max_over_ranks(elapsed, dev)
     pg = dist.describe()
@@ -439,12 +472,23 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
         out["roofline_" + k] = roofs[k]
     out["roofline_fracs"] = {k: [roofs[k]["frac"], roofs[k]["bound"]] for k in order}   # every bracketed kernel, dominant first
     out["host_enqueue_ms_per_step"] = round(host_enqueue / args.steps * 1e3, 3)
+    # the evidence behind ms_per_step: every step's device time (HIP events on the main stream) and host enqueue time,
+    # where their maxima fell, and what the host did meanwhile
+    out["step_ms"] = [round(v, 3) for v in step_ms]
+    out["step_ms_max"] = [round(max(step_ms), 3), step_ms.index(max(step_ms))]
+    out["host_step_ms"] = host_step_ms
+    out["host_step_ms_max"] = [max(host_step_ms), host_step_ms.index(max(host_step_ms))]
+    out["host_watch"] = dict(gc_mode=GC_MODE, gc_enabled=gc.isenabled(), gc_collections=gc_log[:32],
+                             gc_note="[generation, pause ms, ms since the timed region began]",
+                             minor_faults=ru1.ru_minflt - ru0.ru_minflt, major_faults=ru1.ru_majflt - ru0.ru_majflt,
+                             vol_ctx_switches=ru1.ru_nvcsw - ru0.ru_nvcsw, invol_ctx_switches=ru1.ru_nivcsw - ru0.ru_nivcsw)
     out["side_stream_ratio"] = round(float(getattr(model, "side_stream_ratio", 0.0)), 3)   # < 1.4: the photo cell's stream runs beside the main one
     out.update(process_group=pg, rank_seconds=[round(v, 4) for v in rank_elapsed], kernel_ms_per_step=kms,
                kernel_ms_note="HIP-event brackets on the launch streams, over a second pass of the same %d steps right after the "
                               "timed region (the timed region itself carries no brackets)" % args.steps)
     del trainer, model, L
-    import gc
+    gc.enable()
+    gc.unfreeze()
     gc.collect()
     torch.cuda.empty_cache()
     return out, kw
@@ -476,7 +520,7 @@ def also_helper():
         if only and name not in only:
             continue
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warm),
-               "--also", "off", "--no-cpu-baseline"] + over
+               "--also", "off", "--no-cpu-baseline", "--gc", os.environ.get("FVTA_BENCH_GC", "freeze")] + over
         t0 = time.perf_counter()
         try:
             pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900,
@@ -491,6 +535,8 @@ def also_helper():
                               shape={k: r["config"][k] for k in ("qa_pairs_per_gpu", "photos", "text_streams", "tokens", "hidden", "K", "T", "JQ")},
                               kernel_ms_per_step=r["kernel_ms_per_step"], side_stream_ratio=r["side_stream_ratio"],
                               host_enqueue_ms_per_step=r["host_enqueue_ms_per_step"], roofline_fracs=r["roofline_fracs"],
+                              step_ms=r["step_ms"], host_step_ms=r["host_step_ms"], step_ms_max=r["step_ms_max"],
+                              host_step_ms_max=r["host_step_ms_max"], host_watch=r["host_watch"],
                               command="python bench.py " + " ".join(cmd[2:]), process_seconds=round(time.perf_counter() - t0, 1))
         except Exception as exc:   # a side measurement must not take the headline down
             also[name] = dict(error=repr(exc), command="python bench.py " + " ".join(cmd[2:]))
@@ -510,7 +556,7 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and (args.also == "on" or (args.also == "auto" and default_headline)):
         # the `also` orchestrator must exist before this process initialises the GPU; it sleeps until told to go
         helper = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--also-helper"], stdin=subprocess.PIPE,
-                                  stdout=subprocess.PIPE, text=True)
+                                  stdout=subprocess.PIPE, text=True, env=dict(os.environ, FVTA_BENCH_GC=args.gc))
     # stdout carries ONE JSON line: whatever a C library prints there (RCCL's version banner, flushed at exit) goes to stderr
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), "w")

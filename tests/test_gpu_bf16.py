@@ -42,7 +42,11 @@ def test_mfma_bf16_gemm_layouts(layout, shape):
 @pytest.mark.parametrize("B,J,din,d,dense,share", [(5, 6, 8, 32, False, True), (300, 9, 16, 64, False, False),
                                                    (130, 7, 104, 128, True, True), (64, 30, 200, 512, False, True),
                                                    (70, 6, 200, 512, False, False), (33, 5, 12, 128, False, True),
-                                                   (1500, 4, 200, 512, False, True), (1030, 3, 100, 512, True, False)])
+                                                   (1500, 4, 200, 512, False, True), (1030, 3, 100, 512, True, False),
+                                                   # more than 8192 active rows per step: the regime bench.py times, i.e.
+                                                   # the tiled backward step kernel lstm_bwd_fused_bf16 (dense steps) --
+                                                   # and, ragged, its hand-over to the pipelined one below 8192 rows
+                                                   (9000, 3, 200, 512, True, True), (9100, 4, 200, 512, False, True)])
 def test_bilstm_bf16_forward_backward(B, J, din, d, dense, share):
     from fvta_memexqa_amd import ops
     from oracle import fvta_fused as F

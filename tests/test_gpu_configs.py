@@ -30,6 +30,11 @@ def _rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+def _param_slices(model):
+    """name -> (offset, shape) of every parameter in the model's flat buffers"""
+    return {name: (model.params.offsets[name], model.params.specs[name]) for name in model.params.specs}
+
+
 def _subset(inputs, n):
     return dict(ctx=[dict(x=s["x"][:n], mask=s["mask"][:n], cell=s["cell"]) for s in inputs["ctx"]],
                 q=dict(x=inputs["q"]["x"][:n], mask=inputs["q"]["mask"][:n]),
@@ -92,10 +97,22 @@ def test_metric_shape_n64_dense_is_finite_reproducible_and_matches_f32_engine_ar
             assert torch.equal(a, b), "%s engine: %s differs between two runs on the same batch" % (prec, name)
         assert torch.isfinite(runs[0][1]).all() and torch.isfinite(runs[0][2]).all() and torch.isfinite(runs[0][0]).all()
         assert float(runs[0][2].abs().max()) > 0
-        out[prec] = (runs[0][0].cpu().double(), float(runs[0][1]))
+        slices = {name: (off, off + int(np.prod(shape))) for name, (off, shape) in _param_slices(model).items()}
+        out[prec] = (runs[0][0].cpu().double(), float(runs[0][1]), runs[0][2].cpu().double(), slices)
         del model, L, runs
         torch.cuda.empty_cache()
     yb, yf = out["bf16"][0], out["f32"][0]
+    # the flat gradient of the timed regime -- more than 8192 active rows per step, i.e. the tiled backward step kernel
+    # `lstm_bwd_fused_bf16`, which no oracle-level test reaches -- against the exact-fp32 engine, per parameter slice
+    gb, gf, slices = out["bf16"][2], out["f32"][2], out["f32"][3]
+    assert out["bf16"][3] == slices
+    worst = {}
+    for name, (lo, hi) in slices.items():
+        if float(gf[lo:hi].norm()) < 1e-9:
+            assert float(gb[lo:hi].abs().max()) < 1e-5, name
+            continue
+        worst[name] = _rel_l2(gb[lo:hi], gf[lo:hi])
+    assert worst and max(worst.values()) < 4e-2, "bf16 vs f32 engine, relative L2 per parameter slice: %r" % worst
     assert float((yb - yf).abs().max()) < 3e-2
     assert abs(out["bf16"][1] - out["f32"][1]) < 3e-2
     top2 = yf.topk(2, dim=1).values
