@@ -211,17 +211,24 @@ PROF_IDS = [("lstm_step_fwd", 1), ("lstm_step_bwd", 2), ("lstm_dw", 3), ("attn_f
 
 
 def pmc_traffic(fname, key):
-    """HBM bytes per launch from a committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs at this same
-    shape; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  Not collected live: counters need their own
-    profiler pass."""
+    """(HBM bytes per launch, provenance) from a committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs
+    at this same shape; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  Not collected live: counters need
+    their own profiler pass -- so the note says WHEN and on WHICH commit the file was collected (profiles/pmc_meta.json),
+    and a kernel that has changed since shows as a stale commit there, not as a silently wrong number."""
     try:
         d = json.load(open(os.path.join(HERE, "profiles", fname)))
+        meta = {}
+        try:
+            meta = json.load(open(os.path.join(HERE, "profiles", "pmc_meta.json"))).get(fname, {})
+        except Exception:
+            pass
+        note = "bytes per launch, profiles/%s (collected %s at commit %s)" % (fname, meta.get("date", "?"), meta.get("commit", "?"))
         for k, v in d.items():
             if key in k:
-                return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]
+                return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"], note
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def run_case(args, lib, ws, rank, local, probe_gbs=None):
@@ -335,6 +342,7 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     # ---- a second pass of the same steps with the library's HIP-event brackets around the kernels the rooflines
     # are quoted for (events on the launch streams); kept out of the headline
     lib.fvta_profile_enable(1)
+    lib.fvta_lstm_bwd_kernel_counts((ctypes.c_int64 * 3)())      # (reading resets the counters)
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
@@ -347,6 +355,9 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
         return ms.value, n.value
 
     prof = {name: collect(pid) for name, pid in PROF_IDS}
+    bwd_counts = (ctypes.c_int64 * 3)()
+    lib.fvta_lstm_bwd_kernel_counts(bwd_counts)     # text-cell backward-step launches by kernel since the bracketed pass began
+    bwd_counts = dict(zip(("lstm_bwd_fused_bf16", "lstm_bwd_ring_bf16", "lstm_bwd_wreg_bf16"), (int(v) for v in bwd_counts)))
     if rank != 0:
         return None, kw
     total_qa = spec.N * ws * args.steps
@@ -371,7 +382,9 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     # bf16 products per logical one)
     peak_tf, hw_mult = (PEAK_BF16_TFLOPS, 3.0 if args.precision == "bf16x3" else 1.0) if is_bf else (PEAK_F32_TFLOPS, 1.0)
     wreg_fwd = args.precision == "bf16" and (dp, in_i) in ((512, 224), (512, 128), (1024, 224), (1024, 128), (128, 128), (128, 32))
-    ring_bwd = args.precision == "bf16" and dp == 512 and int((lens > 0).sum().item()) <= 8192   # (lstm_wreg_bwd.hip RING_MAX_ROWS)
+    # which kernel ran the backward step is the LIBRARY's word (fvta_lstm_bwd_kernel_counts), not re-derived here
+    bwd_main = max(bwd_counts, key=lambda k: bwd_counts[k]) if sum(bwd_counts.values()) else "lstm_bwd_fused_bf16"
+    ring_bwd = bwd_main == "lstm_bwd_ring_bf16"
     dense_metric = args.config == "metric" and args.variant == "dense" and not args.batch and args.graph == "fvta" and args.precision == "bf16"
     roofs = {}
 
@@ -389,8 +402,7 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
         if note:
             r["note"] = note
         if traffic and dense_metric:
-            r["traffic"] = pmc_traffic(*traffic)
-            r["traffic_note"] = "bytes per launch, profiles/%s" % traffic[0]
+            r["traffic"], r["traffic_note"] = pmc_traffic(*traffic)
         if probe_gbs:
             r["achievable_peak"] = probe_gbs
             r["frac_of_achievable"] = round(gbs / probe_gbs, 4)
@@ -422,8 +434,10 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
             roofs["lstm_fwd"].update(launches_photo_cell=int(n_p), avg_launch_ms_photo_cell=round(ms_p / n_p, 4),
                                      avg_launch_ms_all_launches=round((ms_f + ms_p) / (n_f + n_p), 4))
     if not args.forward_only and is_bf:
-        hbm_roof("lstm_bwd", ("lstm_bwd_ring_bf16 (backward step, weights in registers, pipelined)" if ring_bwd else
-                              "lstm_bwd_fused_bf16 (backward step: dz(t+1) Wh^T + gate gradient)"),
+        hbm_roof("lstm_bwd", {"lstm_bwd_ring_bf16": "lstm_bwd_ring_bf16 (backward step, weights in registers, pipelined)",
+                              "lstm_bwd_wreg_bf16": "lstm_bwd_wreg_bf16 (backward step, weights in registers)",
+                              "lstm_bwd_fused_bf16": "lstm_bwd_fused_bf16 (backward step: dz(t+1) Wh^T + gate gradient)"}[bwd_main]
+                 + "; text-cell launches by kernel in the bracketed pass: %r" % bwd_counts,
                  "lstm_step_bwd", by_bwd, fl_text * dp / (spec.text_in + dp),
                  note="algorithmic bytes: the gate gradient (32 B per row and unit: gates 8, c 4, d_out 4, dc 4 + 4, dz 8); the "
                       "re-read of dz(t+1) (8 B) is not counted; dx has its own bracket",

@@ -112,6 +112,8 @@ _SIGS = {
     "fvta_test_gemm": (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),
     "fvta_profile_enable": (c_int, [c_int32]),
     "fvta_lstm_kernel_select": (c_int, [c_int32]),
+    "fvta_lstm_bwd_kernel_counts": (c_int, [POINTER(c_int64)]),
+    "fvta_attn_kernel_select": (c_int, [c_int32, c_int32]),
     "fvta_profile_collect": (c_int, [c_int32, POINTER(ctypes.c_double), POINTER(c_int64)]),
 }
 

@@ -1923,6 +1923,23 @@ static int launch_main(const AttnFwdArgs& a, hipStream_t stream) {
 
 using namespace fvta;
 
+// Which forward main kernel runs: the environment (FVTA_ATTN_EXACT, FVTA_ATTN_WAVE16) is read ONCE; tests and A/B
+// measurements switch inside a process through fvta_attn_kernel_select.
+static int g_attn_exact_override = -1, g_attn_wave16_override = -1;
+static int attn_exact_mode() {
+  static const int env = [] { const char* e = getenv("FVTA_ATTN_EXACT"); return (e && e[0] == '1') ? 1 : 0; }();
+  return g_attn_exact_override >= 0 ? g_attn_exact_override : env;
+}
+static int attn_wave16_mode() {
+  static const int env = [] { const char* e = getenv("FVTA_ATTN_WAVE16"); return e ? atoi(e) : FVTA_ATTN_WAVE16_DEFAULT; }();
+  return g_attn_wave16_override >= 0 ? g_attn_wave16_override : env;
+}
+extern "C" int fvta_attn_kernel_select(int32_t exact, int32_t wave16) {
+  g_attn_exact_override = exact < 0 ? -1 : (exact ? 1 : 0);
+  g_attn_wave16_override = wave16 < 0 ? -1 : wave16;
+  return FVTA_OK;
+}
+
 int fvta_attn_check_desc(const fvta_attn_desc* d) {
   FVTA_CHECK_ARG(d != nullptr, "attn: null descriptor");
   FVTA_CHECK_ARG(d->N > 0 && d->K > 0 && d->K <= 64 && d->T > 0, "attn: bad N/K/T (%d,%d,%d), need K<=64", d->N, d->K,
@@ -1997,14 +2014,13 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   // (the bracket files the context attention only: the K = 1 question attention is a 15 us launch of the same kernel)
   const bool prof_it = (size_t)s.N * s.K * s.T >= 65536;
   if (prof_it) fvta_prof_begin(FVTA_PROF_ATTN_FWD_MAIN, stream);
-  const char* exact = getenv("FVTA_ATTN_EXACT");
+  const bool exact_kernel = attn_exact_mode() != 0;
   // (the full logit tensor is an inspection output: only the general kernel writes it)
   // (time_warp_att runs on the general kernel: the 16-row kernel's softmax logits are amax itself)
   const bool rows16 = s.JT == 1 && s.w >= 128 && s.w <= 1024 && !a_logits && !tscale && !d->hinfo_stride &&
-                      !(exact && exact[0] == '1');
+                      !exact_kernel;
   // FVTA_ATTN_WAVE16: the one-wave-per-tile kernel for the shapes it covers (measurement switch)
-  const char* w16 = getenv("FVTA_ATTN_WAVE16");  // (read per call, like FVTA_ATTN_EXACT: the tests flip it)
-  const int wave16_mode = w16 ? atoi(w16) : FVTA_ATTN_WAVE16_DEFAULT;
+  const int wave16_mode = attn_wave16_mode();
   if (rows16 && (wave16_mode == 2 || wave16_mode == 3) && s.simi != 4 && s.w >= 512) {  // two waves per tile (attn_fwd_pair16)
     const bool flags = wave16_mode == 3;
     int G = (256 + s.N - 1) / s.N;

@@ -75,6 +75,16 @@ namespace fvta { int wreg_set_mode(int mode); }  // lstm_wreg.hip
 
 extern "C" int fvta_lstm_kernel_select(int32_t mask) { return fvta::wreg_set_mode(mask); }
 
+namespace fvta { extern long long g_bwd_step_counts[3]; }  // lstm_wreg_bwd.hip
+extern "C" int fvta_lstm_bwd_kernel_counts(int64_t* counts) {
+  FVTA_CHECK_ARG(counts, "lstm_bwd_kernel_counts: null pointer");
+  for (int i = 0; i < 3; ++i) {
+    counts[i] = fvta::g_bwd_step_counts[i];
+    fvta::g_bwd_step_counts[i] = 0;
+  }
+  return FVTA_OK;
+}
+
 extern "C" int fvta_profile_collect(int32_t id, double* total_ms, int64_t* launches) {
   FVTA_CHECK_ARG(total_ms && launches, "profile_collect: null pointer");
   if (id >= 200000) {  // diagnostics: shader-clock stamp id - 200000 of lstm_fwd_wreg_bf16 (tools/r03_wreg_stamps.py)

@@ -442,8 +442,10 @@ static void launch_bwd_fused_xm(const FusedBwdArgs& a, hipStream_t s) {
   }
 }
 
+extern long long g_bwd_step_counts[3];  // lstm_wreg_bwd.hip
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
   if (launch_bwd_wreg(a, s)) return;  // few rows: the weights-stationary step
+  if (a.B > 64) ++g_bwd_step_counts[0];  // (calls of more than 64 sequences: the photo cell's 64 rows are not what the roofline is quoted for)
   if (a.xm == 3)
     launch_bwd_fused_xm<3>(a, s);
   else

@@ -609,6 +609,10 @@ static bool launch_bwd_ring(const FusedBwdArgs& a, int rows, hipStream_t s) {
 #endif
 constexpr int RING_MAX_ROWS = FVTA_RING_MAX_ROWS;
 
+// launches of the text / photo cell's backward step by kernel since the last read: [tiled, pipelined, round-3 weights-stationary]
+// (fvta_lstm_bwd_kernel_counts: bench.py labels its roofline by what actually ran)
+long long g_bwd_step_counts[3] = {0, 0, 0};
+
 bool launch_bwd_wreg(const FusedBwdArgs& a, hipStream_t s) {
   if (a.xm != 1 || !a.gatesb || a.in_i % 16) return false;
   const int rows = a.nact_hint >= 0 ? a.nact_hint : a.B;
@@ -616,13 +620,17 @@ bool launch_bwd_wreg(const FusedBwdArgs& a, hipStream_t s) {
   // above.  At the dense metric shape (12,864 rows) the two take the same time alone (134-135 us per launch); the tiled one
   // leaves 52 CUs to the photo cell's side stream, the pipelined one (160 KB of LDS on every CU) does not: step 13.07 vs
   // 13.41 ms.  Ragged batches (SURVEY 8d lengths): 4.92 ms per step with the limit at 8192, 5.03 at 6144, 5.48 tiled only.
-  if ((wreg_mode() & 4) && rows <= RING_MAX_ROWS && launch_bwd_ring(a, rows > 0 ? rows : 1, s)) return true;
+  if ((wreg_mode() & 4) && rows <= RING_MAX_ROWS && launch_bwd_ring(a, rows > 0 ? rows : 1, s)) {
+    if (a.B > 64) ++g_bwd_step_counts[1];
+    return true;
+  }
   if (!(wreg_mode() & 2)) return false;
   if (rows > WBWD_MAX_ROWS) return false;
   if (a.d == 512) launch_wbwd<WbwdCfg<32, 2>>(a, rows > 0 ? rows : 1, s);
   else if (a.d == 1024) launch_wbwd<WbwdCfg<64, 1>>(a, rows > 0 ? rows : 1, s);
   else if (a.d == 128) launch_wbwd<WbwdCfg<8, 2>>(a, rows > 0 ? rows : 1, s);
   else return false;
+  if (a.B > 64) ++g_bwd_step_counts[2];
   return true;
 }
 

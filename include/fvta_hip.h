@@ -475,6 +475,17 @@ int fvta_profile_collect(int32_t id, double* total_ms, int64_t* launches);
  * Every choice computes the same step (model_v2.py:652-661, 694-823); results differ in the last bits (summation order).
  * Process-wide, not thread-safe.  Not part of the reference surface. */
 int fvta_lstm_kernel_select(int32_t mask);
+/* Measurement hook: how many backward-step launches of calls with more than 64 sequences (the text cell) ran on which
+ * kernel since the last call -- counts[0] the tiled step (lstm_bwd_fused_bf16), counts[1] the pipelined weights-stationary
+ * step (lstm_bwd_ring_bf16), counts[2] the round-3 weights-stationary step (lstm_bwd_wreg_bf16); reading resets them.
+ * bench.py labels its backward-step roofline by these instead of re-deriving the library's choice.  Process-wide. */
+int fvta_lstm_bwd_kernel_counts(int64_t* counts);
+/* Test / measurement hook: which focal-attention forward main kernel runs (every choice computes model_v2.py:210-298; the
+ * fast kernels' logits carry the 3-term fp16 split, <= 3 2^-22 |h||q| per product).  exact: 1 the exact-fp32 kernel
+ * (attn_fwd_main) for every shape, 0 the fast kernels where they cover the shape, negative: the default (environment
+ * FVTA_ATTN_EXACT, read once, else 0).  wave16: 0 attn_fwd_rows16, 1 attn_fwd_wave16, 2 / 3 attn_fwd_pair16 with barriers /
+ * with its flag hand-shake, negative: the default (FVTA_ATTN_WAVE16, read once, else 3).  Process-wide, not thread-safe. */
+int fvta_attn_kernel_select(int32_t exact, int32_t wave16);
 /* Measurement hook (bench.py, SURVEY 8d "achievable peak"): one read-only, fully coalesced, non-temporal pass over
  * `bytes` of device memory; the caller times it.  Not part of the reference surface. */
 int fvta_probe_hbm_read(const void* buf, size_t bytes, float* sink, fvta_stream_t stream);

@@ -197,8 +197,33 @@ def test_attention_forward_is_bitwise_reproducible(w, JQ):
             assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1])
 
 
-def test_attention_fast_path_matches_exact_path(monkeypatch):
-    """JQ <= 32, 128 <= w <= 1024 runs the fp16 3-term-split kernel; FVTA_ATTN_EXACT=1 routes to the fp32-MFMA kernel.
+class _AttnSelect:
+    """fvta_attn_kernel_select for the duration of a test: exact() / fast(wave16) switch the focal-attention forward main
+    kernel inside the process (the library reads FVTA_ATTN_EXACT / FVTA_ATTN_WAVE16 once); the default returns afterwards."""
+
+    def __init__(self):
+        from fvta_memexqa_amd import _lib
+        self.lib = _lib.load()
+
+    def exact(self):
+        self.lib.fvta_attn_kernel_select(1, 0)
+
+    def fast(self, wave16=-1):
+        self.lib.fvta_attn_kernel_select(0, int(wave16))
+
+    def default(self):
+        self.lib.fvta_attn_kernel_select(-1, -1)
+
+
+@pytest.fixture
+def attn_select():
+    sel = _AttnSelect()
+    yield sel
+    sel.default()
+
+
+def test_attention_fast_path_matches_exact_path(attn_select):
+    """JQ <= 32, 128 <= w <= 1024 runs the fp16 3-term-split kernel; fvta_attn_kernel_select(1, .) routes to the fp32-MFMA kernel.
     The two must agree far inside the 1e-4 parity tolerance."""
     from fvta_memexqa_amd import ops
     N, K, T, JQ, w = 3, 5, 200, 30, 1024
@@ -207,12 +232,12 @@ def test_attention_fast_path_matches_exact_path(monkeypatch):
     op = ops.FocalAttention(N, K, T, JQ, w, 2, True)
     args = (cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)), cu(W.reshape(-1)), cu(b))
     fast, _ = op.forward(*args)
-    monkeypatch.setenv("FVTA_ATTN_EXACT", "1")
+    attn_select.exact()
     exact, _ = op.forward(*args)
     _close(fast, exact.cpu(), rtol=2e-5, atol=2e-6, msg="fast vs exact")
 
 
-def test_attention_fast_path_randomised_differential(monkeypatch):
+def test_attention_fast_path_randomised_differential(attn_select):
     """The 16-row kernel loads its rows through inline asm into pinned registers with hand-counted waits (a misplaced
     wait or a moved register shows as garbage in SOME stream position): 24 random shapes / maskings / stream lengths
     (1 to many tiles per workgroup, several items per workgroup, fully masked and single-row modalities, n changing inside
@@ -230,12 +255,12 @@ def test_attention_fast_path_randomised_differential(monkeypatch):
         h, q, W, b, hm, qm = _att_case(N, K, T, JQ, w, simi, True, masked, seed=1000 + case, p_valid=float(rng.choice([0.1, 0.6, 0.95])))
         op = ops.FocalAttention(N, K, T, JQ, w, simi, True)
         args = (cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)), cu(W.reshape(-1)) if W is not None else None, cu(b))
-        monkeypatch.delenv("FVTA_ATTN_EXACT", raising=False)
+        attn_select.fast()
         fast, _ = op.forward(*args)
         fast, saved_fast = fast.cpu(), op.saved.clone()
         again, _ = op.forward(*args)
         assert torch.equal(again.cpu(), fast), "case %d: not reproducible" % case
-        monkeypatch.setenv("FVTA_ATTN_EXACT", "1")
+        attn_select.exact()
         exact, _ = op.forward(*args)
         tag = "case %d (N %d K %d T %d JQ %d w %d simi %d masked %s)" % (case, N, K, T, JQ, w, simi, masked)
         assert torch.isfinite(fast).all(), tag
@@ -248,7 +273,7 @@ def test_attention_fast_path_randomised_differential(monkeypatch):
 
 
 @pytest.mark.parametrize("skew", ["one_long", "all_but_one_empty", "two_sizes"])
-def test_attention_pair_kernel_balance_on_skewed_batches(monkeypatch, skew):
+def test_attention_pair_kernel_balance_on_skewed_batches(attn_select, skew):
     """With masks the pair kernel deals workgroups to albums in proportion to their valid row tiles (attn_balance_kernel),
     so the split points of an album's partial sums -- the fp32 rounding of its h_a, nothing else -- depend on the OTHER
     albums of the batch.  The table's edge cases at N = 64: one album holding nearly every tile (its share clamps at the
@@ -275,17 +300,17 @@ def test_attention_pair_kernel_balance_on_skewed_batches(monkeypatch, skew):
     cu = lambda t: t.cuda().contiguous()
     op = ops.FocalAttention(N, K, T, JQ, w, 2, True)
     args = (cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)), cu(W.reshape(-1)), cu(b))
-    monkeypatch.delenv("FVTA_ATTN_EXACT", raising=False)
+    attn_select.fast()
     fast, _ = op.forward(*args)
     fast = fast.cpu()
     again, _ = op.forward(*args)
     assert torch.equal(again.cpu(), fast)              # the same batch: bitwise
-    monkeypatch.setenv("FVTA_ATTN_EXACT", "1")
+    attn_select.exact()
     exact, _ = op.forward(*args)
     assert torch.isfinite(fast).all()
     _close(fast, exact.cpu(), rtol=5e-5, atol=5e-6, msg=skew)
     # the long album among other neighbours: only the rounding of its partial sums may move
-    monkeypatch.delenv("FVTA_ATTN_EXACT", raising=False)
+    attn_select.fast()
     n0 = {"one_long": 5, "all_but_one_empty": 17, "two_sizes": 0}[skew]
     hm2 = hm.clone()
     hm2[(n0 + 1) % N] = True
@@ -294,8 +319,8 @@ def test_attention_pair_kernel_balance_on_skewed_batches(monkeypatch, skew):
 
 
 @pytest.mark.parametrize("mode", ["1", "2", "3"])
-def test_attention_wave16_kernel_randomised_differential(monkeypatch, mode):
-    """FVTA_ATTN_WAVE16=1 / 2: the one-wave-per-tile (attn_fwd_wave16) and two-waves-per-tile (attn_fwd_pair16: w >= 512,
+def test_attention_wave16_kernel_randomised_differential(attn_select, mode):
+    """fvta_attn_kernel_select(0, 1 / 2 / 3): the one-wave-per-tile (attn_fwd_wave16) and two-waves-per-tile (attn_fwd_pair16: w >= 512,
     else the former) forward kernels on random shapes / maskings / stream
     lengths against the exact-fp32 kernel -- values, saved max-pooled logits and arg-max positions -- and against itself
     (bitwise reproducible); then the backward pass on ITS saved state against the backward on the exact kernel's."""
@@ -313,8 +338,7 @@ def test_attention_wave16_kernel_randomised_differential(monkeypatch, mode):
         h, q, W, b, hm, qm = _att_case(N, K, T, JQ, w, simi, tanh, masked, seed=3000 + case, p_valid=float(rng.choice([0.1, 0.6, 0.95])))
         op = ops.FocalAttention(N, K, T, JQ, w, simi, tanh)
         args = (cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)), cu(W.reshape(-1)), cu(b))
-        monkeypatch.delenv("FVTA_ATTN_EXACT", raising=False)
-        monkeypatch.setenv("FVTA_ATTN_WAVE16", mode)
+        attn_select.fast(mode)
         fast, _ = op.forward(*args)
         fast, saved_fast = fast.cpu(), op.saved.clone()
         again, _ = op.forward(*args)
@@ -324,8 +348,7 @@ def test_attention_wave16_kernel_randomised_differential(monkeypatch, mode):
         grads_fast = [torch.zeros(N, K, T, w, device="cuda"), torch.zeros(N, JQ, w, device="cuda"),
                       torch.zeros_like(args[4]), torch.zeros(1, device="cuda")]
         op.backward(*args, g, *grads_fast, accumulate=0)
-        monkeypatch.setenv("FVTA_ATTN_WAVE16", "0")
-        monkeypatch.setenv("FVTA_ATTN_EXACT", "1")
+        attn_select.exact()
         exact, _ = op.forward(*args)
         assert torch.isfinite(fast).all(), tag
         _close(fast, exact.cpu(), rtol=5e-5, atol=5e-6, msg=tag)

@@ -16,11 +16,13 @@ L = model.load_inputs(make_inputs(spec), training=True)
 def fb():
     model.zero_grad(); model.forward(L); model.backward(L, need_dx=True)
 def timeit(f, n=20):
+    """(ms per call, host enqueue ms per call)"""
     for _ in range(3): f()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): f()
-    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-print("eager fwd+bwd ms", round(timeit(fb), 3))
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize(); return round((time.perf_counter() - t0) / n * 1e3, 3), round(host / n * 1e3, 3)
+print("eager fwd+bwd (ms, host enqueue ms)", timeit(fb))
 s = torch.cuda.Stream()
 s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s):
@@ -30,6 +32,6 @@ g = torch.cuda.CUDAGraph()
 try:
     with torch.cuda.graph(g):
         fb()
-    print("graph fwd+bwd ms", round(timeit(g.replay), 3))
+    print("graph fwd+bwd (ms, host enqueue ms)", timeit(g.replay))
 except Exception as e:
     print("capture failed:", repr(e)[:400])
