@@ -9,6 +9,7 @@
 // straight from L2), takes max_j, and folds the rows into an online softmax /
 // weighted-sum accumulator from the same registers.  Masked rows are never read.
 #include "attn_common.h"
+#include "attn_fwd_shared.h"
 #include "fvta_prof.h"
 
 namespace fvta {
@@ -17,38 +18,6 @@ __device__ __forceinline__ f32x4 ld4g(const float* p) { return *reinterpret_cast
 #ifndef FVTA_ATTN_WAVE16_DEFAULT
 #define FVTA_ATTN_WAVE16_DEFAULT 3
 #endif
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4v __attribute__((ext_vector_type(4)));
-// x[0..7] = (a0, a1) -> hi, lo fp16 pieces (see above); register pairs are concatenated, never re-packed
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_f16x2(float x0, float x1, half2v& hi, half2v& lo) {
-  hi = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-  // lo = fp16((x - hi) * 2048) as ONE mixed-precision FMA per element, 2048 x - 2048 hi with the fp16 hi read in place
-  // (v_fma_mixlo/mixhi_f16 write one half of the destination and keep the other): 4 instructions per pair instead of 6
-  // (2 back-conversions, packed subtract, packed scale, pack).  Exact up to the final rounding, as before (x - hi is exact).
-  const f32x2 xs = f32x2{x0, x1} * 2048.f;
-  const float m2048 = -2048.f;
-  unsigned hw = __builtin_bit_cast(unsigned, hi), lw;
-  asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=&v"(lw) : "v"(hw), "s"(m2048), "v"(xs[0]));
-  asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw) : "v"(hw), "s"(m2048), "v"(xs[1]));
-  lo = __builtin_bit_cast(half2v, lw);
-}
-__device__ __forceinline__ half8 cat_h2(half2v a, half2v b, half2v c, half2v d) {
-  const half4v ab = __builtin_shufflevector(a, b, 0, 1, 2, 3), cd = __builtin_shufflevector(c, d, 0, 1, 2, 3);
-  return __builtin_shufflevector(ab, cd, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-__device__ __forceinline__ void split_f16x8(const f32x4 a0, const f32x4 a1, half8& hi, half8& lo) {
-  half2v h[4], l[4];
-  split_f16x2(a0[0], a0[1], h[0], l[0]);
-  split_f16x2(a0[2], a0[3], h[1], l[1]);
-  split_f16x2(a1[0], a1[1], h[2], l[2]);
-  split_f16x2(a1[2], a1[3], h[3], l[3]);
-  hi = cat_h2(h[0], h[1], h[2], h[3]);
-  lo = cat_h2(l[0], l[1], l[2], l[3]);
-}
-
-
 // s_waitcnt vmcnt(n) for a loop-unrolled n (the switch folds after unrolling)
 __device__ __forceinline__ void wait_vmcnt_upto(int n) {
   switch (n) {
@@ -95,9 +64,12 @@ __global__ void attn_vecs_kernel(const float* __restrict__ W, int w, int simi, i
 }
 
 // ---- question side: Qs [N][W4][JP][4], ct [N][JP], valid-j bits.  grid N, 256 threads
+// qh_wide: the fp16 split in the fragment order of attn_fwd_wide (attn_fwd_wide.hip) instead of [2][W4][JP][4]:
+// [wave v = c / (w/8)][stage = (j / 32) (w/256) + k-step][fragment = 2 ((j / 16) & 1) + {hi, lo}][lane = j % 16 + 16 kq][8],
+// the lane's 8 channels being 32 ks + 4 kq + (0..3) and 32 ks + 16 + 4 kq + (0..3) of the wave's w/8
 __global__ __launch_bounds__(256) void attn_prep_q_kernel(AttnShape s, AttnSaved sv, const float* __restrict__ hq,
                                                           const uint8_t* __restrict__ qmask,
-                                                          const float* __restrict__ bptr) {
+                                                          const float* __restrict__ bptr, int qh_wide) {
   __shared__ float s_rq[64];
   const int n = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int w = s.w;
@@ -151,6 +123,14 @@ __global__ __launch_bounds__(256) void attn_prep_q_kernel(AttnShape s, AttnSaved
     half2v h0, l0, h1, l1;
     split_f16x2(o[0], o[1], h0, l0);
     split_f16x2(o[2], o[3], h1, l1);
+    if (qh_wide) {
+      const int cw = w / 8, c = 4 * c4, v = c / cw, cin = c % cw, ks = cin / 32, r0 = cin % 32;
+      const int kq = (r0 % 16) / 4, e0 = r0 < 16 ? 0 : 4, jt = j / 16, nst = (cw / 32) * (s.JP / 32);
+      const size_t frag = (((size_t)v * nst + (size_t)(jt / 2) * (cw / 32) + ks) * 4 + 2 * (jt & 1)) * 512 + (size_t)(j % 16 + 16 * kq) * 8 + e0;
+      *reinterpret_cast<half4v*>(Qh + frag) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+      *reinterpret_cast<half4v*>(Qh + frag + 512) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
+      continue;
+    }
     *reinterpret_cast<half4v*>(Qh + (size_t)u * 4) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
     *reinterpret_cast<half4v*>(Qh + ((size_t)s.W4 * s.JP + u) * 4) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
   }
@@ -253,18 +233,6 @@ __global__ __launch_bounds__(64) void attn_balance_kernel(AttnShape s, AttnSaved
 }
 
 // ---- main kernel -----------------------------------------------------------
-struct AttnFwdArgs {
-  AttnShape s;
-  AttnSaved sv;
-  const float* hinfo;
-  float* a_logits;  // may be null
-  float* part;      // [N*K][nsplit][w+4] : m, l, mu, -, u[w]   (m: max of the softmax logits z, mu: max of amax)
-  const float* tscale;  // [N,T] or null: z[n,k,t] = amax[n,k,t] * tscale[n,t] (time_warp_att)
-  int ipw;          // 16-row kernel: items per workgroup
-  int dbg;          // FVTA_ATTN_DBG experiment bits (diagnostics only)
-  size_t hstride;   // elements between the row blocks of consecutive (n,k): T*w, or fvta_attn_desc.hinfo_stride (K == 1)
-  const uint32_t* wgtab;  // pair kernel: workgroup -> n | g << 16 | G_n << 24 (attn_balance_kernel), null: G workgroups for every n
-};
 
 // w = 4 * SCW * NSC * NW * NSLAB.  A workgroup is NW waves; a wave owns NSC
 // sub-chunks of SCW float4 columns per slab; lane = (c4l = lane % SCW,
@@ -695,7 +663,6 @@ struct BufTag {
 
 // Workgroup barrier for LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which on gfx9 is
 // s_waitcnt vmcnt(0): it would drain the row loads in flight at each barrier and serialise the prefetch.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // RMODE: which row-term vectors of the bilinear form are non-zero: 1 = Rh (simi 1), 2 = R2 (simi 2 and 4),
 // 3 = both (simi 3).
@@ -1016,25 +983,6 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_fwd_rows16(Attn
 // channel blocks b = r (mod 16), so the accumulator is w/256 float4 registers.  No barrier after the prologue, no
 // cross-wave traffic, rows read once; a (n, k, split) item is a wave's own tile stream and ends in the same (m, l, u)
 // partial as the kernels above.  grid: G workgroups per n, XCD-contiguous in n.
-// Sum of each of four values over the 16 lanes of its DPP row, every lane ending with the result: the butterfly of
-// row16_sum as FUSED v_add_f32_dpp (the compiler emits v_mov_b32_dpp + a packed add + s_nop per step: 31 issue slots for
-// what are 17 here).  The four values are interleaved, so a step's DPP read of a register comes three instructions after
-// the previous step wrote it (the hazard wants two wait states; the assembler does not check inside inline asm, hence
-// also the leading s_nop against whatever VALU instruction produced the inputs).
-__device__ __forceinline__ void row16_sum4(f32x4& v) {
-  float a = v[0], b = v[1], c = v[2], d = v[3];
-#define FVTA_DPP4(CTRL)                                                   \
-  "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"      \
-  "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"      \
-  "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"      \
-  "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
-  asm("s_nop 1\n\t" FVTA_DPP4("quad_perm:[1,0,3,2]") FVTA_DPP4("quad_perm:[2,3,0,1]") FVTA_DPP4("row_half_mirror")
-          FVTA_DPP4("row_mirror")
-      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-#undef FVTA_DPP4
-  v = f32x4{a, b, c, d};
-}
-
 template <int NBLK, int RMODE>
 __global__ __launch_bounds__(256, 1) void attn_fwd_wave16(AttnFwdArgs a, int G) {
   constexpr int NKS = NBLK / 2;  // K = 32 MFMA steps over the channels
@@ -1919,6 +1867,9 @@ static int launch_main(const AttnFwdArgs& a, hipStream_t stream) {
   return 0;
 }
 
+bool wide_covers(const AttnShape& s, int G);                                     // attn_fwd_wide.hip
+bool launch_attn_fwd_wide(const AttnFwdArgs& a, int G, hipStream_t stream);
+
 }  // namespace fvta
 
 using namespace fvta;
@@ -1991,7 +1942,15 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   AttnSaved sv = attn_saved_view(s, saved);
   hipLaunchKernelGGL(attn_vecs_kernel, dim3((s.w + 255) / 256), dim3(256), 0, stream, W, s.w, s.simi, s.feat_order,
                      sv.vecs);
-  hipLaunchKernelGGL(attn_prep_q_kernel, dim3(s.N, s.W4 * s.JP >= 4096 ? 8 : 1), dim3(256), 0, stream, s, sv, hq, qmask, b);
+  // wide rows (w = 2048: BASELINE.json configs[4]): the rows-stationary, question-streaming kernel of attn_fwd_wide.hip
+  const bool exact_kernel = attn_exact_mode() != 0;
+  const int wave16_mode = attn_wave16_mode();
+  int wideG = (256 + s.N - 1) / s.N;
+  if (wideG > s.K * s.nsplit) wideG = s.K * s.nsplit;
+  if (wideG < 1) wideG = 1;
+  const bool use_wide = !exact_kernel && wave16_mode != 0 && !a_logits && !tscale && !d->hinfo_stride && wide_covers(s, wideG);
+  hipLaunchKernelGGL(attn_prep_q_kernel, dim3(s.N, s.W4 * s.JP >= 4096 ? 8 : 1), dim3(256), 0, stream, s, sv, hq, qmask, b,
+                     use_wide ? 1 : 0);
   hipLaunchKernelGGL(attn_compact_kernel, dim3(s.N * s.K), dim3(256), 0, stream, s, sv, hmask);
   FVTA_CHECK_LAUNCH("attn_prep");
   if (a_logits && use_mask) {
@@ -2014,14 +1973,21 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   // (the bracket files the context attention only: the K = 1 question attention is a 15 us launch of the same kernel)
   const bool prof_it = (size_t)s.N * s.K * s.T >= 65536;
   if (prof_it) fvta_prof_begin(FVTA_PROF_ATTN_FWD_MAIN, stream);
-  const bool exact_kernel = attn_exact_mode() != 0;
   // (the full logit tensor is an inspection output: only the general kernel writes it)
   // (time_warp_att runs on the general kernel: the 16-row kernel's softmax logits are amax itself)
   const bool rows16 = s.JT == 1 && s.w >= 128 && s.w <= 1024 && !a_logits && !tscale && !d->hinfo_stride &&
                       !exact_kernel;
   // FVTA_ATTN_WAVE16: the one-wave-per-tile kernel for the shapes it covers (measurement switch)
-  const int wave16_mode = attn_wave16_mode();
-  if (rows16 && (wave16_mode == 2 || wave16_mode == 3) && s.simi != 4 && s.w >= 512) {  // two waves per tile (attn_fwd_pair16)
+  if (use_wide) {
+    const int nwg = s.N * wideG, maxg = s.K * s.nsplit;
+    if (use_mask && s.N <= 64 && s.N > 1 && nwg <= 4096 && maxg <= 255) {  // ragged albums: workgroups in proportion to the rows
+      uint32_t* tab = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) +
+                                                 fvta_align_up((size_t)s.N * s.K * (s.nsplit + 1) * (s.w + 4) * sizeof(float), 256));
+      hipLaunchKernelGGL(attn_balance_kernel, dim3(1), dim3(64), 0, stream, s, sv, nwg, maxg, tab);
+      a.wgtab = tab;
+    }
+    launch_attn_fwd_wide(a, wideG, stream);
+  } else if (rows16 && (wave16_mode == 2 || wave16_mode == 3) && s.simi != 4 && s.w >= 512) {  // two waves per tile (attn_fwd_pair16)
     const bool flags = wave16_mode == 3;
     int G = (256 + s.N - 1) / s.N;
     const int maxg = (s.K * s.nsplit + 3) / 4;

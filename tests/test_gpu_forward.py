@@ -362,3 +362,49 @@ def test_attention_wave16_kernel_randomised_differential(attn_select, mode):
         op.backward(*args, g, *grads_exact, accumulate=0)
         for name, a_, b_ in zip(("d_hinfo", "d_hq", "dW", "db"), grads_fast, grads_exact):
             _close(a_, b_.cpu(), rtol=2e-4, atol=2e-5, msg=tag + " " + name)
+
+
+def test_attention_wide_kernel_randomised_differential(attn_select):
+    """attn_fwd_wide (w = 2048: BASELINE.json configs[4]'s rows; the rows-stationary, question-streaming kernel) on random
+    shapes / maskings / stream lengths -- one- and two-pass question lengths, runs crossing stream boundaries, fully masked
+    and single-row streams, ragged last tiles -- against the exact-fp32 kernel: values, saved max-pooled logits and arg-max
+    positions; bitwise reproducible; the backward on ITS saved state against the backward on the exact kernel's."""
+    from fvta_memexqa_amd import ops
+    rng = np.random.RandomState(777)
+    cu = lambda t: None if t is None else t.cuda().contiguous()
+    w = 2048
+    for case in range(14):
+        N, K = int(rng.randint(1, 7)), int(rng.randint(1, 8))
+        T = int(rng.choice([5, 32, 33, 96, 150, 333, 700, 1300]))
+        JQ = int(rng.choice([1, 17, 32, 33, 47, 60, 64]))
+        simi = int(rng.choice([1, 2, 3]))
+        tanh = bool(rng.rand() < 0.5)
+        masked = bool(rng.rand() < 0.8)
+        h, q, W, b, hm, qm = _att_case(N, K, T, JQ, w, simi, tanh, masked, seed=5000 + case, p_valid=float(rng.choice([0.1, 0.6, 0.95])))
+        op = ops.FocalAttention(N, K, T, JQ, w, simi, tanh)
+        args = (cu(h), cu(q), cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm)), cu(W.reshape(-1)), cu(b))
+        attn_select.fast()
+        fast, _ = op.forward(*args)
+        fast, saved_fast = fast.cpu(), op.saved.clone()
+        again, _ = op.forward(*args)
+        tag = "case %d (N %d K %d T %d JQ %d simi %d tanh %s masked %s)" % (case, N, K, T, JQ, simi, tanh, masked)
+        assert torch.equal(again.cpu(), fast) and torch.equal(op.saved, saved_fast), tag + ": not reproducible"
+        g = torch.randn(N, w, generator=torch.Generator().manual_seed(case)).cuda()
+        grads_fast = [torch.zeros(N, K, T, w, device="cuda"), torch.zeros(N, JQ, w, device="cuda"),
+                      torch.zeros_like(args[4]), torch.zeros(1, device="cuda")]
+        op.backward(*args, g, *grads_fast, accumulate=0)
+        attn_select.exact()
+        exact, _ = op.forward(*args)
+        assert torch.isfinite(fast).all(), tag
+        _close(fast, exact.cpu(), rtol=5e-5, atol=5e-6, msg=tag)
+        nkt = N * K * T
+        amax_f = saved_fast[:4 * nkt].view(torch.float32).cpu()
+        amax_e = op.saved[:4 * nkt].view(torch.float32).cpu()
+        ok = torch.isfinite(amax_e) & (amax_e > -1e29)
+        np.testing.assert_allclose(amax_f[ok].numpy(), amax_e[ok].numpy(), rtol=5e-5, atol=5e-6, err_msg=tag + " amax")
+        grads_exact = [torch.zeros(N, K, T, w, device="cuda"), torch.zeros(N, JQ, w, device="cuda"),
+                       torch.zeros_like(args[4]), torch.zeros(1, device="cuda")]
+        op.backward(*args, g, *grads_exact, accumulate=0)
+        for name, a_, b_ in zip(("d_hinfo", "d_hq", "dW", "db"), grads_fast, grads_exact):
+            # (absolute tolerance relative to the tensor's scale: dW sums N K T rows of 2048 channels)
+            _close(a_, b_.cpu(), rtol=2e-4, atol=2e-5 * max(1.0, float(b_.abs().max())), msg=tag + " " + name)
