@@ -451,7 +451,9 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     att_bytes = (valid_rows * model.wp + spec.N * L.JQ * model.wp + spec.N * model.wp) * 4.0
     if args.graph == "fvta":   # (model.py's graph runs seven large 1-D attentions under the same bracket)
         kname = (("attn_fwd_pair16" if model.wp >= 512 and model.simi != 4 and os.environ.get("FVTA_ATTN_WAVE16", "3") in ("2", "3")
-                  else "attn_fwd_rows16") if (L.JQ <= 32 and 128 <= model.wp <= 1024) else "attn_fwd_main")
+                  else "attn_fwd_rows16") if (L.JQ <= 32 and 128 <= model.wp <= 1024) else
+                 ("attn_fwd_wide" if model.wp == 2048 and L.JQ <= 64 and model.simi != 4 and os.environ.get("FVTA_ATTN_WAVE16", "3") != "0"
+                  else "attn_fwd_main"))
         # (the library's profile bracket covers the context attention only, not the K = 1 question attention)
         hbm_roof("attention", kname + " (fvta_attn_fwd main kernel)", "attn_fwd_main", att_bytes,
                  traffic=("r04_attention_pmc.json", "attn_fwd_pair16"))

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void pad_zero_kernel(PlanView v, float* __rest
   const bool known = persist && v.dirty_out[b] == (int64_t)reinterpret_cast<uintptr_t>(first);
   const int hi = known ? min(v.dirty[b], Jb) : Jb;
   // (the update is behind the reads of the sequence's state: same wave, program order, and its predicate needs their data)
-  if (lane == 0 && hi >= 0) {
+  if (lane == 0) {
     v.dirty[b] = L;
     v.dirty_out[b] = (int64_t)reinterpret_cast<uintptr_t>(first);
   }

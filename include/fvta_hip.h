@@ -136,7 +136,13 @@ typedef struct fvta_lstm_desc {
                         * kernel writes both directions' sum at once, the read of dx go away */
   int32_t out_pads_persist; /* fvta_bilstm_fwd: 1 = the caller promises that nothing but this op writes `out` between forward
                         * calls on this plan memory: only the rows the previous call wrote and this one does not are zeroed
-                        * (rows t >= len are zero after every call either way) */
+                        * (rows t >= len are zero after every call either way).  Under this flag the forward WRITES the plan
+                        * (per sequence: how far the last forward wrote, into which `out`), although it takes it as const:
+                        * (1) one plan must not be used by two forwards at once (two streams would race on that state);
+                        * (2) the state is keyed by the output row's ADDRESS -- if `out` is freed and another buffer with
+                        *     other contents comes back at the same address while the plan memory is kept, stale rows are not
+                        *     zeroed: zero the plan memory (fvta_lstm_plan_bytes) whenever `out` is re-allocated, which also
+                        *     is the way to invalidate the state; (3) the plan memory must start zeroed. */
 } fvta_lstm_desc;
 
 size_t fvta_lstm_plan_bytes(const fvta_lstm_desc* d);
@@ -179,13 +185,13 @@ int fvta_bilstm_bwd(const fvta_lstm_desc* d, const void* plan, const float* x, c
                     float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
                     void* workspace, fvta_stream_t stream);
 
-/* The same with a second stream the caller lends for the call (bf16 engine; ignored otherwise, NULL = fvta_bilstm_bwd):
- * the work that does not sit on the recurrence's critical path -- dx and the weight gradient of a step group, final as
- * soon as that group's gate gradients are -- is launched on `side_stream` behind an event and joins `stream` again
- * before the call's last kernel, so the caller sees the same stream-ordered semantics on `stream`.  It runs on the CUs
- * the one-round step kernel leaves idle.  `side_stream` should not carry other work of the caller's during the call
- * and is best created with the lowest priority.  Results are bitwise those of fvta_bilstm_bwd (bf16 engine: dx too --
- * its two directions are added in a fixed order, forward first, by two launches in stream order; no atomics). */
+/* The same signature with a second stream.  `side_stream` is ACCEPTED AND UNUSED (kept for ABI stability): running dx and
+ * the weight gradient beside the recurrence measured slower, so everything runs on `stream`; results are bitwise those
+ * of fvta_bilstm_bwd.  How dx is summed (bf16 engines, no atomics anywhere): when the two directions share one input (no
+ * input dropout) ONE launch adds both directions in the same accumulators and writes every dx element once; the k-tile
+ * order of that sum is rotated per workgroup, so the result is deterministic for a given batch but its last bits depend
+ * on where a row's tile sits in the grid (a row moved to another position of the batch may round differently).  With a
+ * separate input per direction (fvta_lstm_plan_xdir) two launches write one dx copy each. */
 int fvta_bilstm_bwd_overlap(const fvta_lstm_desc* d, const void* plan, const float* x, const float* out,
                             const float* d_out, const float* kernel_fw, const float* kernel_bw, void* saved,
                             float* dx, float* dkernel_fw, float* dbias_fw, float* dkernel_bw, float* dbias_bw,
