@@ -1,7 +1,7 @@
 #!/bin/bash
 # builds diag/libfvta_hip_<src>_abl<bits>.so variants of the library with one source compiled -D<MACRO>=<bits>
-#   tools/r03_build_abl.sh 1 2 4                                    (lstm_wreg.hip, -DFVTA_WREG_ABL)
-#   SRC=embed MACRO=FVTA_EMB_ABL tools/r03_build_abl.sh 1 2 4       (embed.hip)
+#   tools/build_abl.sh 1 2 4                                    (lstm_wreg.hip, -DFVTA_WREG_ABL)
+#   SRC=embed MACRO=FVTA_EMB_ABL tools/build_abl.sh 1 2 4       (embed.hip)
 SRC=${SRC:-lstm_wreg}; MACRO=${MACRO:-FVTA_WREG_ABL}
 cd "$(dirname "$0")/../fvta_memexqa_amd/csrc" && mkdir -p diag
 for b in "$@"; do

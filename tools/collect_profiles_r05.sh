@@ -21,15 +21,15 @@ pmc() {  # pmc <dir> <script and args...>: separate passes per counter group (SQ
   python3 tools/pmc_summary.py $d/summary.json $d/sq $d/sq2 $d/fetch $d/write > $d/summary.txt
 }
 if [ "$2" = "full" ]; then
-  pmc $out/pmc_fwd tools/r03_wreg_ab.py;          cp $out/pmc_fwd/summary.json $out/lstm_pmc.json
-  pmc $out/pmc_bwd tools/r04_ring_ab.py;          cp $out/pmc_bwd/summary.json $out/lstm_bwd_pmc.json
-  pmc $out/pmc_bwd_ragged tools/r04_ring_ab.py 12864 30 200 512 ragged; cp $out/pmc_bwd_ragged/summary.json $out/lstm_bwd_ragged_pmc.json
+  pmc $out/pmc_fwd tools/lstm_fwd_ab.py;          cp $out/pmc_fwd/summary.json $out/lstm_pmc.json
+  pmc $out/pmc_bwd tools/lstm_bwd_ab.py;          cp $out/pmc_bwd/summary.json $out/lstm_bwd_pmc.json
+  pmc $out/pmc_bwd_ragged tools/lstm_bwd_ab.py 12864 30 200 512 ragged; cp $out/pmc_bwd_ragged/summary.json $out/lstm_bwd_ragged_pmc.json
   pmc $out/pmc_attn tools/bench_attn.py bwd;      cp $out/pmc_attn/summary.json $out/attention_pmc.json
   pmc $out/pmc_attn_wide tools/bench_attn_wide.py; cp $out/pmc_attn_wide/summary.json $out/attention_wide_pmc.json
   timeout 300 python3 tools/bench_attn_wide.py > $out/attention_wide.txt 2>/dev/null; timeout 300 python3 tools/bench_attn_wide.py exact >> $out/attention_wide.txt 2>/dev/null
   # one rank through the launcher: the collective path (RCCL communicator, flat-gradient all-reduce) on the one GPU there is
   FVTA_DIST_FORCE=1 timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --also off > $out/bench_rccl_one_rank.json 2>/dev/null
   timeout 600 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --also off > $out/bench_plain_same_box.json 2>/dev/null
-  FVTA_DIST_FORCE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29519 timeout 600 python3 tools/r04_rccl_probe.py > $out/rccl_probe.txt 2>/dev/null
+  FVTA_DIST_FORCE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29519 timeout 600 python3 tools/rccl_probe.py > $out/rccl_probe.txt 2>/dev/null
 fi
 head -30 $out/kernel_stats.csv | cut -c1-150

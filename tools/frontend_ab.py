@@ -1,6 +1,6 @@
 """The embedding front-end's kernels alone at the metric shape (385,920 tokens of 16 characters, 2,560 photos):
 HIP-event time per call of the char-CNN forward / backward and the photo transform forward / backward.
-  python tools/r03_frontend_ab.py [reps [char_emb_size]]"""
+  python tools/frontend_ab.py [reps [char_emb_size]]"""
 import sys
 import torch
 from fvta_memexqa_amd import ops

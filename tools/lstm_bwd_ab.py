@@ -1,6 +1,6 @@
 """Times the text-cell bi-LSTM backward STEP launches alone (the library's HIP-event bracket FVTA_PROF_LSTM_STEP_BWD) at
 the metric shape, plus dx and dW, for the library named by FVTA_LIB_PATH / the kernel set of FVTA_LSTM_WREG.
-  python tools/r04_ring_ab.py [B J din d [ragged]]"""
+  python tools/lstm_bwd_ab.py [B J din d [ragged]]"""
 import ctypes, os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 from fvta_memexqa_amd import _lib, ops

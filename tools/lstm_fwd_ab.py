@@ -23,8 +23,8 @@ ms = timeit(lambda: op.forward(x, out, k, b))
 tag = os.environ.get("FVTA_LSTM_WREG", "1")
 print("WREG=%s fwd %.3f ms  sum %.6f  abs %.6f  finite %s" % (tag, ms, out.double().sum().item(), out.double().abs().sum().item(),
       bool(torch.isfinite(out).all())))
-if os.environ.get("FVTA_AB_SAVE"): torch.save(out.cpu(), "/tmp/r03_wreg_out_%s.pt" % tag)
-other = "/tmp/r03_wreg_out_%s.pt" % ("0" if tag != "0" else "1")
+if os.environ.get("FVTA_AB_SAVE"): torch.save(out.cpu(), "/tmp/lstm_fwd_ab_out_%s.pt" % tag)
+other = "/tmp/lstm_fwd_ab_out_%s.pt" % ("0" if tag != "0" else "1")
 if os.path.exists(other):
     o2 = torch.load(other)
     diff = (out.cpu() - o2).abs()

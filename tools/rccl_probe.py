@@ -2,7 +2,7 @@
 process group's own stream exists?  Prints the measured concurrency ratio (1.0: concurrent, 2.0: serialised) before and
 after the first collectives, and the step time with the collectives (a) as shipped, (b) with RCCL's stream created
 BEFORE the model picks its side stream.
-  FVTA_DIST_FORCE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512 python tools/r04_rccl_probe.py [warm]"""
+  FVTA_DIST_FORCE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512 python tools/rccl_probe.py [warm]"""
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 from fvta_memexqa_amd import _lib, dist, ops
