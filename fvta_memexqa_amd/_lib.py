@@ -24,7 +24,8 @@ class AttnDesc(Structure):
 
 
 class LstmDesc(Structure):
-    _fields_ = [(n, c_int32) for n in ("B", "J", "in_", "d", "share_fw_bw", "precision", "training", "reserved", "dx_overwrite", "out_pads_persist")]
+    _fields_ = [(n, c_int32) for n in ("B", "J", "in_", "d", "share_fw_bw", "precision", "training", "reserved", "dx_overwrite", "out_pads_persist")] + \
+               [("out_skip", c_int64)]
 
 
 class TimewarpDesc(Structure):
@@ -53,6 +54,8 @@ _SIGS = {
     "fvta_attn_saved_bytes": (c_size_t, [POINTER(AttnDesc)]),
     "fvta_attn_fwd": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_attn_bwd": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P]),
+    "fvta_attn_fwd_shadow": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P]),
+    "fvta_attn_bwd_shadow": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P]),
     "fvta_attn_fwd_tw": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_attn_bwd_tw": (c_int, [POINTER(AttnDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, P, P]),
     "fvta_timewarp_bwd_att": (c_int, [POINTER(TimewarpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
@@ -67,6 +70,8 @@ _SIGS = {
     "fvta_bilstm_bwd": (c_int, [POINTER(LstmDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_bilstm_bwd_overlap": (c_int, [POINTER(LstmDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_bilstm_bwd_hint": (c_int, [POINTER(LstmDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_lstm_shadow_rows": (c_int, [POINTER(LstmDesc), P, P, c_int64, P, P]),
+    "fvta_rows_from_shadow": (c_int, [P, c_int64, c_int32, c_int64, P, P]),
     "fvta_lstm_last_state": (c_int, [POINTER(LstmDesc), P, P, c_int32, c_int32, P, P]),
     "fvta_lstm_last_state_bwd": (c_int, [POINTER(LstmDesc), P, P, c_int32, c_int32, P, P]),
     "fvta_scorer_ce_fwd": (c_int, [POINTER(ScorerDesc), P, P, P, P, P, P, P, P, P, P]),

@@ -124,6 +124,7 @@ struct AttnBwdArgs {
   const float* tscale;  // [N,T] or null (time_warp_att): the inner softmax ran on z = amax * tscale
   size_t hstride;       // elements between the row blocks of consecutive (n,k) of hinfo / d_hinfo (see AttnFwdArgs)
   int nt;               // bit 0: non-temporal stores of the d_hinfo rows (written once, read much later); bit 1: the h rows too
+  const unsigned long long* table;  // SH kernels: [2][N K T] addresses of the rows' bf16 halves (fvta_lstm_shadow_rows), hinfo is null
 };
 
 // TPR threads cover one row (16 B each, G float4 per thread when w > 1024);
@@ -134,8 +135,12 @@ struct AttnBwdArgs {
 // store -- the write stream of the kernel was one store round trip per row.  Without the load (and with the question
 // operand of the current j in registers, below) the rows' stores stream.
 // (16-row tiles with four workgroups per CU: 0.96 ms against 0.77 at the metric shape -- the 128-register budget spills)
-template <int TPR, int G, int TR, bool COS, bool ACC>
+// SH: the rows are read from the encoders' bf16 shadow (two half-rows per row, addressed through a.table: see
+// attn_fwd_shadow.hip) -- 8 bytes per thread and row instead of 16; the chunk's 2 x rows addresses are fetched after the
+// row sort and kept in LDS.  G == 1, no cosine.
+template <int TPR, int G, int TR, bool COS, bool ACC, bool SH = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
+  static_assert(!SH || (G == 1 && !COS && TPR >= 2), "shadow rows: bilinear shapes with one float4 per thread and row");
   constexpr int RH = 256 / TPR;
   constexpr int RPT = TR / RH;
   constexpr int WPR = TPR >= 64 ? TPR / 64 : 1;  // waves that share a row
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   __shared__ float s_self[TR];
   __shared__ float s_pr[TR], s_dx[TR];
   __shared__ int s_tt[TR], s_jj[TR];
+  __shared__ unsigned long long s_rp[SH ? 2 : 1][SH ? BWD_CHMAX : 1];
   // the workgroup's group of consecutive k: per-k scalars, and the start of each k's rows in the concatenated list
   __shared__ int s_kbase[17];
   __shared__ float s_kM[16], s_kMz[16], s_kcoef[16], s_kgu[16], s_kdss[16];
@@ -245,7 +251,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
   }
   __syncthreads();
 
-  const float* __restrict__ hbase = a.hinfo + (size_t)nk * a.hstride;
+  if constexpr (SH) {  // the sorted rows' addresses (independent loads: inside the sort's serial loop each one was a round trip)
+    const unsigned long long* __restrict__ tab0 = a.table + (size_t)nk * T;
+    const unsigned long long* __restrict__ tab1 = tab0 + (size_t)s.N * s.K * T;
+    for (int i = tid; i < nrows; i += 256) {
+      const int t = s_rows[i];
+      s_rp[0][i] = tab0[t];
+      s_rp[1][i] = tab1[t];
+    }
+    // (the main loop's first __syncthreads() orders these writes before the tiles' reads)
+  }
+  const float* __restrict__ hbase = SH ? nullptr : a.hinfo + (size_t)nk * a.hstride;
+  // SH: this thread's four channels lie in half `shalf` of a row, `soff` bytes into it
+  const int shalf = 4 * cq >= w / 2 ? 1 : 0, soff = 2 * (4 * cq - shalf * (w / 2));
   float* __restrict__ dhbase = a.d_hinfo + (size_t)nk * a.hstride;
   const float* __restrict__ Qs = a.sv.Qs + (size_t)n * s.W4 * JP * 4;
   constexpr bool cosine = COS;
@@ -280,7 +298,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
     }
   };
 
-  f32x4 hreg[RPT][G];
+  typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+  f32x4 hreg[SH ? 1 : RPT][G];
+  u32x2s hraw[SH ? RPT : 1];  // SH: the tile stays packed (half the registers), unpacked at each use
+  auto row_val = [&](int i, int g) {
+    if constexpr (SH) {
+      u32x2s raw = hraw[i];
+      asm volatile("" : "+v"(raw));  // (unpacked again at each use: the compiler would keep the fp32 copy live instead)
+      return f32x4{__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u), __uint_as_float(raw[1] << 16),
+                   __uint_as_float(raw[1] & 0xffff0000u)};
+    } else {
+      return hreg[i][g];
+    }
+  };
   for (int tb = 0; tb < nrows; tb += TR) {
     __syncthreads();
     if (tid < TR) {
@@ -290,19 +320,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
     }
     __syncthreads();
     float dot[RPT], nrm[RPT];
+    if constexpr (SH) {
+      // every row of the tile is requested before the first one is used (row_val's empty asm pins each use: in one loop
+      // with the loads the compiler waited vmcnt(0) row by row -- 32 dependent round trips per tile)
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        // (a GLOBAL pointer: through a generic one the load is a FLAT instruction, which counts on lgkmcnt too)
+        typedef const u32x2s __attribute__((address_space(1)))* grow8_ptr;
+        hraw[i] = *(grow8_ptr)(s_rp[shalf][min(tb + rh * RPT + i, nrows - 1)] + soff);  // (padding rows of a tile: the last row's address)
+      }
+    }
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
       const int t = s_tt[rh * RPT + i];
       float dsum = 0.f, nsum = 0.f;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        const f32x4* hp = reinterpret_cast<const f32x4*>(hbase + (size_t)max(t, 0) * w + 4 * (cq + g * TPR));
-        const f32x4 hv = (a.nt & 2) ? __builtin_nontemporal_load(hp) : *hp;  // unconditional, then zeroed
-        hreg[i][g] = t >= 0 ? hv : f32x4{0.f, 0.f, 0.f, 0.f};
-        const f32x4 pdt = hreg[i][g] * gv[g];
+        if constexpr (SH) {
+          hraw[i] = t >= 0 ? hraw[i] : u32x2s{0u, 0u};
+        } else {
+          const f32x4* hp = reinterpret_cast<const f32x4*>(hbase + (size_t)max(t, 0) * w + 4 * (cq + g * TPR));
+          const f32x4 hv = (a.nt & 2) ? __builtin_nontemporal_load(hp) : *hp;  // unconditional, then zeroed
+          hreg[i][g] = t >= 0 ? hv : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const f32x4 hcur = row_val(i, g);
+        const f32x4 pdt = hcur * gv[g];
         dsum += (pdt[0] + pdt[1]) + (pdt[2] + pdt[3]);
         if (cosine) {
-          const f32x4 hh = hreg[i][g] * hreg[i][g];
+          const f32x4 hh = hcur * hcur;
           nsum += (hh[0] + hh[1]) + (hh[2] + hh[3]);
         }
       }
@@ -405,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_main(AttnBwdArgs a) {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const int c4 = cq + g * TPR;
-        const f32x4 h = hreg[i][g];
+        const f32x4 h = row_val(i, g);
 #ifdef FVTA_ATTN_BWD_QS_PER_ROW  // (A/B: the per-row gather this replaced)
         const f32x4 qs = ld4b(Qs + ((size_t)c4 * JP + j) * 4);
 #else
@@ -717,13 +762,40 @@ extern "C" int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const 
                           accumulate, workspace, stream_);
 }
 
+static int attn_bwd_impl(const fvta_attn_desc* d, const float* hinfo, const uint64_t* table, const float* hq, const uint8_t* hmask,
+                         const uint8_t* qmask, const float* W, const float* b, const float* tscale,
+                         const float* d_h_a, const void* saved, float* d_hinfo, float* d_hq, float* dW, float* db,
+                         float* d_tscale, int accumulate, void* workspace, fvta_stream_t stream_);
+
 extern "C" int fvta_attn_bwd_tw(const fvta_attn_desc* d, const float* hinfo, const float* hq, const uint8_t* hmask,
                                 const uint8_t* qmask, const float* W, const float* b, const float* tscale,
                                 const float* d_h_a, const void* saved, float* d_hinfo, float* d_hq, float* dW, float* db,
                                 float* d_tscale, int accumulate, void* workspace, fvta_stream_t stream_) {
+  FVTA_CHECK_ARG(hinfo != nullptr, "attn_bwd: null pointer");
+  return attn_bwd_impl(d, hinfo, nullptr, hq, hmask, qmask, W, b, tscale, d_h_a, saved, d_hinfo, d_hq, dW, db, d_tscale,
+                       accumulate, workspace, stream_);
+}
+
+// The backward of fvta_attn_fwd_shadow: the rows come from the same table of bf16 half-row addresses; d_hinfo is the
+// fp32 [N,K,T,w] tensor as in fvta_attn_bwd.
+extern "C" int fvta_attn_bwd_shadow(const fvta_attn_desc* d, const uint64_t* table, const float* hq, const uint8_t* hmask,
+                                    const uint8_t* qmask, const float* W, const float* b, const float* d_h_a,
+                                    const void* saved, float* d_hinfo, float* d_hq, float* dW, float* db, int accumulate,
+                                    void* workspace, fvta_stream_t stream_) {
+  FVTA_CHECK_ARG(table != nullptr, "attn_bwd_shadow: null pointer");
+  FVTA_CHECK_ARG(d && d->JQ <= 32 && (d->w == 512 || d->w == 1024) && d->simi != 4 && !d->hinfo_stride,
+                 "attn_bwd_shadow: needs JQ <= 32, w = 512 or 1024, simiMatrix 1-3, no hinfo_stride");
+  return attn_bwd_impl(d, nullptr, table, hq, hmask, qmask, W, b, nullptr, d_h_a, saved, d_hinfo, d_hq, dW, db, nullptr,
+                       accumulate, workspace, stream_);
+}
+
+static int attn_bwd_impl(const fvta_attn_desc* d, const float* hinfo, const uint64_t* table, const float* hq, const uint8_t* hmask,
+                         const uint8_t* qmask, const float* W, const float* b, const float* tscale,
+                         const float* d_h_a, const void* saved, float* d_hinfo, float* d_hq, float* dW, float* db,
+                         float* d_tscale, int accumulate, void* workspace, fvta_stream_t stream_) {
   if (int e = fvta_attn_check_desc(d)) return e;
   FVTA_CHECK_ARG((tscale == nullptr) == (d_tscale == nullptr), "attn_bwd: tscale and d_tscale go together");
-  FVTA_CHECK_ARG(hinfo && hq && d_h_a && saved && d_hinfo && d_hq && workspace, "attn_bwd: null pointer");
+  FVTA_CHECK_ARG((hinfo || table) && hq && d_h_a && saved && d_hinfo && d_hq && workspace, "attn_bwd: null pointer");
   FVTA_CHECK_ARG(d->simi == 4 || (dW && db), "attn_bwd: dW/db required");
   FVTA_CHECK_ARG(!(tscale && d->hinfo_stride), "attn_bwd: tscale with a strided hinfo is not supported");
   hipStream_t stream = (hipStream_t)stream_;
@@ -747,6 +819,7 @@ extern "C" int fvta_attn_bwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   a.sv = sv;
   a.wk = wk;
   a.hinfo = hinfo;
+  a.table = reinterpret_cast<const unsigned long long*>(table);
   a.d_h_a = d_h_a;
   a.d_hinfo = d_hinfo;
   a.accumulate = accumulate;
@@ -762,6 +835,15 @@ extern "C" int fvta_attn_bwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   const dim3 grid(s.bsplit, s.N * s.ng);
   const bool prof_it = (size_t)s.N * s.K * s.T >= 65536;  // the context attention, see attn_fwd.hip
   if (prof_it) fvta_prof_begin(FVTA_PROF_ATTN_BWD_MAIN, stream);
+  if (table) {
+    if (s.w == 512) {
+      if (accumulate == 1) hipLaunchKernelGGL((attn_bwd_main<128, 1, 32, false, true, true>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((attn_bwd_main<128, 1, 32, false, false, true>), grid, dim3(256), 0, stream, a);
+    } else {
+      if (accumulate == 1) hipLaunchKernelGGL((attn_bwd_main<256, 1, 32, false, true, true>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((attn_bwd_main<256, 1, 32, false, false, true>), grid, dim3(256), 0, stream, a);
+    }
+  } else
   switch (s.w) {
 #define FVTA_BWD_LAUNCH2(TPR, G, TR, COS)                                                                             \
   do {                                                                                                              \

@@ -1869,6 +1869,9 @@ static int launch_main(const AttnFwdArgs& a, hipStream_t stream) {
 
 bool wide_covers(const AttnShape& s, int G);                                     // attn_fwd_wide.hip
 bool launch_attn_fwd_wide(const AttnFwdArgs& a, int G, hipStream_t stream);
+bool shadow_covers(const AttnShape& s);                                          // attn_fwd_shadow.hip
+void launch_attn_shadow_compact(const AttnShape& s, const AttnSaved& sv, const uint64_t* table, uint64_t* rowptr, hipStream_t stream);
+bool launch_attn_fwd_pair16h(const AttnFwdArgs& a, int G, const uint64_t* rowptr, hipStream_t stream);
 
 }  // namespace fvta
 
@@ -1918,7 +1921,9 @@ extern "C" size_t fvta_attn_workspace_bytes(const fvta_attn_desc* d) {
   if (fvta_attn_check_desc(d)) return 0;
   const AttnShape s = attn_shape(d, true);
   // forward: the split partials, then one more partial per (n,k) for the masked rows' share under time_warp_att
-  const size_t fwd = fvta_align_up((size_t)s.N * s.K * (s.nsplit + 1) * (s.w + 4) * sizeof(float), 256) + ATTN_WGTAB_BYTES;
+  // (+ the shadow forward's compacted row addresses: two words per row)
+  const size_t fwd = fvta_align_up((size_t)s.N * s.K * (s.nsplit + 1) * (s.w + 4) * sizeof(float), 256) + ATTN_WGTAB_BYTES +
+                     (size_t)2 * s.N * s.K * s.T * sizeof(uint64_t);
   const size_t bwd = fvta_attn_bwd_workspace_bytes(s);
   return fwd > bwd ? fwd : bwd;
 }
@@ -1929,11 +1934,33 @@ extern "C" int fvta_attn_fwd(const fvta_attn_desc* d, const float* hinfo, const 
   return fvta_attn_fwd_tw(d, hinfo, hq, hmask, qmask, W, b, nullptr, h_a, a_logits, saved, workspace, stream_);
 }
 
+static int attn_fwd_impl(const fvta_attn_desc* d, const float* hinfo, const uint64_t* table, const float* hq, const uint8_t* hmask,
+                         const uint8_t* qmask, const float* W, const float* b, const float* tscale, float* h_a,
+                         float* a_logits, void* saved, void* workspace, fvta_stream_t stream_);
+
 extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, const float* hq, const uint8_t* hmask,
                                 const uint8_t* qmask, const float* W, const float* b, const float* tscale, float* h_a,
                                 float* a_logits, void* saved, void* workspace, fvta_stream_t stream_) {
+  FVTA_CHECK_ARG(hinfo != nullptr, "attn_fwd: null pointer");
+  return attn_fwd_impl(d, hinfo, nullptr, hq, hmask, qmask, W, b, tscale, h_a, a_logits, saved, workspace, stream_);
+}
+
+// The same forward over the encoders' bf16 shadow rows: table[half][(n K + k) T + t] = address of the w/2 bf16 values that
+// are channels half w/2 .. of row (n, k, t) (fvta_lstm_shadow_rows; EVERY entry a readable address -- rows no encoder
+// writes point at w/2 zeros).  JQ <= 32, w = 512 / 1024, simiMatrix 1-3 only; results equal fvta_attn_fwd's on the
+// bf16-rounded rows up to the rounding of the fp16-split logits (tests/test_gpu_shadow.py).
+extern "C" int fvta_attn_fwd_shadow(const fvta_attn_desc* d, const uint64_t* table, const float* hq, const uint8_t* hmask,
+                                    const uint8_t* qmask, const float* W, const float* b, float* h_a, void* saved,
+                                    void* workspace, fvta_stream_t stream_) {
+  FVTA_CHECK_ARG(table != nullptr, "attn_fwd_shadow: null pointer");
+  return attn_fwd_impl(d, nullptr, table, hq, hmask, qmask, W, b, nullptr, h_a, nullptr, saved, workspace, stream_);
+}
+
+static int attn_fwd_impl(const fvta_attn_desc* d, const float* hinfo, const uint64_t* table, const float* hq, const uint8_t* hmask,
+                         const uint8_t* qmask, const float* W, const float* b, const float* tscale, float* h_a,
+                         float* a_logits, void* saved, void* workspace, fvta_stream_t stream_) {
   if (int e = fvta_attn_check_desc(d)) return e;
-  FVTA_CHECK_ARG(hinfo && hq && h_a && saved && workspace, "attn_fwd: null pointer");
+  FVTA_CHECK_ARG((hinfo || table) && hq && h_a && saved && workspace, "attn_fwd: null pointer");
   FVTA_CHECK_ARG(d->simi == 4 || (W && b), "attn_fwd: W and b required for simiMatrix 1-3");
   FVTA_CHECK_ARG(!(tscale && d->hinfo_stride), "attn_fwd: tscale with a strided hinfo is not supported");
   hipStream_t stream = (hipStream_t)stream_;
@@ -1948,7 +1975,9 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   int wideG = (256 + s.N - 1) / s.N;
   if (wideG > s.K * s.nsplit) wideG = s.K * s.nsplit;
   if (wideG < 1) wideG = 1;
-  const bool use_wide = !exact_kernel && wave16_mode != 0 && !a_logits && !tscale && !d->hinfo_stride && wide_covers(s, wideG);
+  const bool use_wide = !table && !exact_kernel && wave16_mode != 0 && !a_logits && !tscale && !d->hinfo_stride && wide_covers(s, wideG);
+  FVTA_CHECK_ARG(!table || (shadow_covers(s) && !d->hinfo_stride),
+                 "attn_fwd_shadow: needs JQ <= 32, w = 512 or 1024, simiMatrix 1-3, no hinfo_stride (JQ=%d w=%d simi=%d)", d->JQ, d->w, d->simi);
   hipLaunchKernelGGL(attn_prep_q_kernel, dim3(s.N, s.W4 * s.JP >= 4096 ? 8 : 1), dim3(256), 0, stream, s, sv, hq, qmask, b,
                      use_wide ? 1 : 0);
   hipLaunchKernelGGL(attn_compact_kernel, dim3(s.N * s.K), dim3(256), 0, stream, s, sv, hmask);
@@ -1978,7 +2007,22 @@ extern "C" int fvta_attn_fwd_tw(const fvta_attn_desc* d, const float* hinfo, con
   const bool rows16 = s.JT == 1 && s.w >= 128 && s.w <= 1024 && !a_logits && !tscale && !d->hinfo_stride &&
                       !exact_kernel;
   // FVTA_ATTN_WAVE16: the one-wave-per-tile kernel for the shapes it covers (measurement switch)
-  if (use_wide) {
+  if (table) {
+    int G = (256 + s.N - 1) / s.N;
+    const int maxg = (s.K * s.nsplit + 3) / 4;
+    if (G > maxg) G = maxg;
+    if (G < 1) G = 1;
+    const int nwg = s.N * G;
+    const size_t part_bytes = fvta_align_up((size_t)s.N * s.K * (s.nsplit + 1) * (s.w + 4) * sizeof(float), 256);
+    if (use_mask && s.N <= 64 && s.N > 1 && nwg <= 4096 && maxg <= 255) {
+      uint32_t* tab = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + part_bytes);
+      hipLaunchKernelGGL(attn_balance_kernel, dim3(1), dim3(64), 0, stream, s, sv, nwg, maxg, tab);
+      a.wgtab = tab;
+    }
+    uint64_t* rowptr = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + part_bytes + ATTN_WGTAB_BYTES);
+    launch_attn_shadow_compact(s, sv, table, rowptr, stream);
+    launch_attn_fwd_pair16h(a, G, rowptr, stream);
+  } else if (use_wide) {
     const int nwg = s.N * wideG, maxg = s.K * s.nsplit;
     if (use_mask && s.N <= 64 && s.N > 1 && nwg <= 4096 && maxg <= 255) {  // ragged albums: workgroups in proportion to the rows
       uint32_t* tab = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) +

@@ -241,9 +241,10 @@ __global__ void plan_fill_kernel(PlanView v, int B, int J, int in, int d) {
 // persist (desc.out_pads_persist: nobody but this op writes the output buffer between forward calls): only the rows the
 // LAST forward on this plan memory wrote and this one will not -- [len, dirty) -- are zeroed; the plan remembers per sequence
 // how far it has written into which buffer.  (A ragged metric-shape batch: 0.79 GB of zeros per step otherwise, 161 us.)
-__global__ __launch_bounds__(256) void pad_zero_kernel(PlanView v, float* __restrict__ out, int d, int persist, int B) {
+__global__ __launch_bounds__(256) void pad_zero_kernel(PlanView v, float* __restrict__ out, int d, int persist, int B, int64_t out_skip) {
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // a wave per sequence
   if (b >= B) return;
+  if (v.out_off[b] < out_skip) return;  // (desc.out_skip: this sequence's output rows are not stored at all)
   const int L = v.len[b], Jb = v.seq_J[b];
   const int64_t ld = v.hdr->out_ld;
   float* first = out + v.out_off[b];
@@ -640,7 +641,11 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
   a.J = d->J;
   a.in = d->in;
   a.d = d->d;
-  hipLaunchKernelGGL(pad_zero_kernel, dim3((d->B + 3) / 4), dim3(256), 0, stream, pv, out, d->d, d->out_pads_persist, d->B);
+  FVTA_CHECK_ARG(d->out_skip == 0 || (d->precision == FVTA_BF16 && d->out_skip > 0),
+                 "bilstm_fwd: out_skip needs the bf16 engine (the rows' readers take its bf16 shadow rows)");
+  a.out_skip = d->out_skip;
+  hipLaunchKernelGGL(pad_zero_kernel, dim3((d->B + 3) / 4), dim3(256), 0, stream, pv, out, d->d, d->out_pads_persist, d->B,
+                     (int64_t)d->out_skip);
   FVTA_CHECK_LAUNCH("pad_zero");
   const dim3 grid((d->B + MmaStep::BM - 1) / MmaStep::BM, d->d / 32, 2);
   const size_t sh = MmaStep::LDS_FLOATS * sizeof(float);
@@ -846,6 +851,52 @@ extern "C" int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, c
   }
   fvta_prof_end(FVTA_PROF_LSTM_DW + 16 * d->reserved, 1, stream);
   FVTA_CHECK_LAUNCH("lstm_dw_reduce");
+  return FVTA_OK;
+}
+
+// ---- the bf16 shadow rows of the output (fvta_lstm_shadow_rows / fvta_rows_from_shadow) --------------------------------
+// table[dir][row] = address of the d bf16 values hs[dir][t][i] that ARE the output half-row (dir) of arena row `row`, for
+// every active (dir, t, sorted i) whose output row lies below nrows; other entries are left as the caller initialised them
+__global__ __launch_bounds__(256) void shadow_rows_kernel(PlanView v, const bf16_t* __restrict__ hs, int B, int J, int d,
+                                                          int64_t nrows, unsigned long long* __restrict__ table) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (dir, t, i)
+  if (idx >= (size_t)2 * J * B) return;
+  const int64_t oo = v.oo[idx];
+  if (oo < 0) return;
+  const int dir = (int)(idx / ((size_t)J * B));
+  const int64_t row = oo / v.hdr->out_ld;
+  if (row >= nrows) return;
+  table[(size_t)dir * nrows + row] = (unsigned long long)reinterpret_cast<uintptr_t>(hs + idx * (size_t)d);
+}
+extern "C" int fvta_lstm_shadow_rows(const fvta_lstm_desc* d, const void* plan, const void* saved, int64_t nrows,
+                                     uint64_t* table, fvta_stream_t stream) {
+  if (int e = check_lstm_desc(d)) return e;
+  FVTA_CHECK_ARG(plan && saved && table && nrows > 0, "lstm_shadow_rows: null pointer / no rows");
+  FVTA_CHECK_ARG(d->precision == FVTA_BF16, "lstm_shadow_rows: the bf16 engine's shadow rows only");
+  PlanView pv = plan_view(d, const_cast<void*>(plan));
+  SavedView sv = saved_view(d, const_cast<void*>(saved));
+  const size_t n = (size_t)2 * d->J * d->B;
+  hipLaunchKernelGGL(shadow_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pv, sv.hs, d->B,
+                     d->J, d->d, nrows, reinterpret_cast<unsigned long long*>(table));
+  FVTA_CHECK_LAUNCH("lstm_shadow_rows");
+  return FVTA_OK;
+}
+// out[row][dir * d + c] = float(table[dir][row][c]) -- the fp32 rows an inspection output wants (vis tensors, tests)
+__global__ __launch_bounds__(256) void rows_from_shadow_kernel(const unsigned long long* __restrict__ table, int64_t nrows, int d,
+                                                               int64_t out_ld, float* __restrict__ out) {
+  const int64_t row = blockIdx.x;
+  for (int c = threadIdx.x; c < 2 * d; c += blockDim.x) {
+    const int dir = c / d;
+    const bf16_t* p = reinterpret_cast<const bf16_t*>((uintptr_t)table[(size_t)dir * nrows + row]);
+    out[row * out_ld + c] = bf2f(p[c - dir * d]);
+  }
+}
+extern "C" int fvta_rows_from_shadow(const uint64_t* table, int64_t nrows, int32_t d, int64_t out_ld, float* out,
+                                     fvta_stream_t stream) {
+  FVTA_CHECK_ARG(table && out && nrows > 0 && d > 0 && out_ld >= 2 * d, "rows_from_shadow: bad arguments");
+  hipLaunchKernelGGL(rows_from_shadow_kernel, dim3((unsigned)nrows), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const unsigned long long*>(table), nrows, d, out_ld, out);
+  FVTA_CHECK_LAUNCH("rows_from_shadow");
   return FVTA_OK;
 }
 

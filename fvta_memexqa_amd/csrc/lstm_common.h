@@ -156,6 +156,8 @@ struct StepArgs {
   int xm;   // bf16 engines: bf16 terms per operand value (1; 3 in the split engine, which saves fp32 gates in `gates`)
   int nt;   // bf16 engine: stream-once data (saved gates, cell states, fp32 h rows) with non-temporal stores (measured: no
             // effect on the forward step; 0)
+  int64_t out_skip;  // fvta_lstm_desc.out_skip: output half-rows at element offsets below this are NOT stored
+                     // (their readers take the bf16 shadow rows: fvta_lstm_shadow_rows)
 };
 
 struct GateBwdArgs {
@@ -251,7 +253,7 @@ __device__ __forceinline__ void lstm_gate_epilogue(const Mma& mma, const StepArg
         } else {
           a.cstate[((size_t)dir * a.B + i) * d + u] = c;
         }
-        if (!(a.dbg & 4)) a.out[s_oo[row] + u] = h;
+        if (!(a.dbg & 4) && s_oo[row] >= a.out_skip) a.out[s_oo[row] + u] = h;
         if (a.hs && !(a.dbg & 32)) a.hs[(trow + i) * d + u] = f2bf(h);  // bf16 shadow: next step's MFMA operand
       }
     }
@@ -352,7 +354,7 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
         const int lr = it * 8 + io_row;
         const int64_t oo = s_oo[wrow0 + lr];
         const f32x4 v = *reinterpret_cast<const f32x4*>(&pl[lr * LDP + 4 * io_c4]);
-        if (oo >= 0) {
+        if (oo >= a.out_skip) {   // (inactive rows are -1, out_skip >= 0)
           float* o = a.out + oo + u0 + 4 * io_c4;
           if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
             st16(o, v, a.nt != 0);

@@ -258,28 +258,17 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
   float* c_base = a.cs ? a.cs + trow * (size_t)d : a.cstate + (size_t)dir * a.B * d;
   f32x4 cp_next[C::PASSES], cp_cur[C::PASSES];
   int64_t oo_cur[C::PASSES];
-  // (the plan is read-only here: through the constant address space its wave-uniform reads ARE scalar loads; as plain
-  //  global reads the compiler made them vector loads -- 8 of a row tile's ~32 vector-memory instructions, and the CU's
-  //  address unit takes one wave-instruction per ~31 cycles whatever its width)
-  typedef const int64_t __attribute__((address_space(4)))* const_i64_ptr;
-  const const_i64_ptr oo_c = (const_i64_ptr)(a.plan.oo + trow);
-  auto prev_rows = [&](int m0p) {  // output offsets of the previous tile's rows: wave-uniform addresses, scalar cache
-#pragma unroll
-    for (int p = 0; p < C::PASSES; ++p) {
-      const int i0 = m0p + C::RW * wave + C::RPP * p;
-      int64_t o = oo_c[min(i0, a.B - 1)];
-#pragma unroll
-      for (int j = 1; j < C::RPP; ++j) {
-        const int64_t oj = oo_c[min(i0 + j, a.B - 1)];
-        o = (e_rsub == j) ? oj : o;
-      }
-      oo_cur[p] = o;
-    }
-  };
+  // The rows' output offsets travel with the previous cell states: ONE 8-byte vector load per pass and tile, issued a whole
+  // tile before its use (own_rows).  (As wave-uniform scalar loads at the top of the tile that stores -- RPP per pass, selected
+  // by row -- every wave sat out two scalar-cache round trips per tile behind an s_waitcnt lgkmcnt(0): 0.25 ms of the 3.8 ms
+  // text-cell forward.)
+  int64_t oo_next[C::PASSES];
+  const int64_t* __restrict__ oo_g = a.plan.oo + trow;
   auto own_rows = [&](int m0t) {
 #pragma unroll
     for (int p = 0; p < C::PASSES; ++p) {
       const int i = min(m0t + C::RW * wave + C::RPP * p + e_rsub, nact - 1);  // clamped: always a valid row
+      oo_next[p] = oo_g[i];
       if (t > 0)
         cp_next[p] = *reinterpret_cast<const f32x4*>(cprev_base + (size_t)i * d + u_lane);
       else
@@ -317,7 +306,7 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
       if (((abl & 8192) || i < nact) && !(abl & 16)) {
         if constexpr (!(abl & 128)) st16(c_base + (size_t)i * d + u_lane, cv, a.nt != 0);
         const int64_t oo = oo_cur[p];
-        if (((abl & 8192) || oo >= 0) && !(abl & 256)) {
+        if (((abl & 8192) || oo >= a.out_skip) && !(abl & 256)) {   // (inactive rows: -1; rows below out_skip: their readers take the shadow)
           float* o = a.out + oo + u_lane;
           if ((abl & 8192) || (reinterpret_cast<uintptr_t>(o) & 15) == 0) {
             st16(o, hv, a.nt != 0);
@@ -453,7 +442,6 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
       if constexpr (q == 0) {
         const unsigned long long r0 = WREG_CLOCK();
         own_rows(m0);
-        prev_rows(it > 0 ? prev_m0 : 0);
         st_rows += WREG_CLOCK() - r0;
       }
       mfma(q_c, std::integral_constant<int, 0>{}, fr[C::buf_of(q)].b);  // (step 0: the h slots hold zeros)
@@ -506,6 +494,7 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
 #pragma unroll
     for (int p = 0; p < C::PASSES; ++p) {
       cp_cur[p] = cp_next[p];
+      oo_cur[p] = oo_next[p];
     }
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) ap[ks] += tb_delta;
@@ -514,7 +503,6 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  prev_rows(prev_m0);
   static_for<0, C::NSTAGES>([&](auto s_c) { run_stage(s_c, prev_m0); });
   wait_vmcnt<0>();  // the ring's trailing DMA pieces must not outlive the workgroup's LDS allocation
 #ifdef FVTA_WREG_STAMP

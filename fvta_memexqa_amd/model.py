@@ -64,6 +64,7 @@ class Model(model_v2.Model):
             "catt": "choices_emb/bidrection_squash/%s", "qatt": "question_emb/bidrection_squash/%s"}
     N_CC = {"ch": "output/gchoice_trans_concat/%s", "q": "output/gq_trans_concat/%s"}
     N_TG = "attention/multi_layer_attention/%s/%s/%s"          # stream, one of mlp_q / mlp_h / preatt / final, W / b
+    SHADOW_OK = False            # the 1-D attentions / direct links below read the fp32 rows of the arena
     HAS_VIS_TENSORS = False      # no C / C_win / warp_h / hall here: Tester.step_vis fails as it does on the reference's model.py
 
     def __init__(self, config, scope="model", text_in=None, img_in=None, device=None):

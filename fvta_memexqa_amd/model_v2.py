@@ -18,6 +18,7 @@ Three entry levels, all through load_inputs():
   * the same index arrays as an `inputs` tree (synth.make_token_inputs);
   * the ENCODER INPUTS x* of model_v2.py:680-688 (embedded tokens / photo features + masks) -- the bench headline.
 """
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -118,6 +119,11 @@ class Model:
         self.use_eu_output = bool(_cfg(config, "use_eu_output", False))
         self.share_fw_bw = bool(_cfg(config, "share_fw_bw", True))
         self.precision = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3}[_cfg(config, "precision", "f32")]
+        # shadow rows (bf16 engine): the context tensor hall (model_v2.py:863-914) is never stored in fp32 -- the focal
+        # attention reads the bf16 rows the encoders keep for their own recurrence (ops.BiLstm.shadow_rows).  Per layout,
+        # where the shadow kernels cover the shape (_shadow_covers); config "shadow_rows", else FVTA_SHADOW_ROWS, else off
+        sr = _cfg(config, "shadow_rows", None)
+        self.shadow_rows = bool(int(os.environ.get("FVTA_SHADOW_ROWS", "0"))) if sr is None else bool(sr)
         self.wd = float(_cfg(config, "wd", None) or 0.0)                # --wd (main.py:105); None / 0.0: no l2 terms
         # d logits of softmax_cross_entropy_with_logits (model_v2.py:1088): True = what TF-1's kernel returns,
         # softmax - labels on every row, all-False label rows (padded rows of a short batch, :1270) included
@@ -173,7 +179,8 @@ class Model:
         self.img_in_p = (self.img_in + 7) // 8 * 8
         self.global_step = 0                                            # model_v2.py:366
         self.loss = self.yp = self.logits = None
-        self.att_logits = self.q_att_logits = self.hall = None
+        self.att_logits = self.q_att_logits = None
+        self._hall_layout = None
         self._layouts = {}
         self.max_layouts = int(_cfg(config, "max_cached_layouts", 4))
         # the side stream (photo cell, small launches that run beside the text cell) must own a hardware queue of
@@ -535,6 +542,11 @@ class Model:
         T = M * JMAX
         L.N, L.K, L.M, L.JMAX, L.T, L.JQ, L.C, L.JA = N, K, M, JMAX, T, JQ, C, JA
         seq_rows = self._plan_arena(L, ctx, training)
+        L.shadow = self._shadow_covers(L)
+        L.hall_fresh = True
+        if L.shadow:
+            L.shadow_tab = torch.zeros(2, L.row_hq, dtype=torch.int64, device=dev)
+            L.zero_half = torch.zeros(dp, dtype=torch.bfloat16, device=dev)     # the rows no encoder writes
         # ---- sequence groups (text cell / image cell)
         groups = {"text": [], "image": []}
         groups["text"].append(dict(name="q", count=N, J=JQ, rows=L.row_hq + torch.arange(N) * JQ))
@@ -596,13 +608,32 @@ class Model:
                               share_fw_bw=self.share_fw_bw, precision=self.precision, training=training,
                               prof_tag=0 if cell == "text" else 1, x_bw_delta=pos if G.dropout else 0,
                               dx_overwrite=True,   # backward() writes dx: no zero fill per step
-                              out_pads_persist=True)   # L.arena is written by this op only
+                              out_pads_persist=True,   # L.arena is written by this op only
+                              out_skip=L.row_hq * wp if L.shadow else 0)
             L.groups[cell] = G
         L.q_mask = torch.zeros(N, JQ, dtype=torch.uint8, device=dev)
         self._build_attention(L, training)
         L.y = torch.zeros(N, C, dtype=torch.uint8, device=dev)
         self._layouts[key] = L
         return L
+
+    SHADOW_OK = True     # (model.py's attentions read the fp32 rows)
+
+    def _shadow_covers(self, L):
+        """the shapes fvta_attn_fwd_shadow / fvta_attn_bwd_shadow take (include/fvta_hip.h)"""
+        return (self.SHADOW_OK and self.shadow_rows and self.precision == BF16 and not self.use_time_warp and
+                self.simi in (1, 2, 3) and self.wp in (512, 1024) and L.JQ <= 32)
+
+    @property
+    def hall(self):
+        """the context tensor of the last forward (vis output, model_v2.py:914): under shadow rows it is filled in here"""
+        L = self._hall_layout
+        if L is None:
+            return None
+        if L.shadow and not L.hall_fresh:
+            ops.rows_from_shadow(L.shadow_tab, L.row_hq, self.dp, self.wp, L.arena)
+            L.hall_fresh = True
+        return L.hall
 
     def _plan_arena(self, L, ctx, training):
         """Rows of the encoder output arena: [hall N*K*T | hq N*JQ | hchoices N*C*JA], the context tensor of
@@ -851,6 +882,9 @@ class Model:
         # the photo cell (few rows, one short latency-bound launch per photo) runs beside the text cell on a side
         # HIP stream: the two write disjoint rows of the arena and meet again before the attention.  It is
         # enqueued FIRST -- a side stream that waits for main after the text launches are queued runs after them.
+        if L.shadow:
+            L.shadow_tab.fill_(L.zero_half.data_ptr())
+            L.hall_fresh = False
         for cell, G in sorted(L.groups.items(), key=lambda kv: kv[0] != "image"):
             side = self._side if (cell == "image" and "text" in L.groups and not self.serial_photo_forward) else None
             if side is not None:
@@ -863,6 +897,8 @@ class Model:
                     G.drop_seed = ((self.dropout_seed * 0x9E3779B1 + self._dropout_calls * 2 + (cell == "image")) ^ self._dropout_rank_salt) & (2 ** 64 - 1)
                     ops.dropout_pair_fwd(G.x, G.x2, self.keep_prob, G.drop_seed)
                 G.op.forward(G.x2 if G.dropout else G.x, L.arena, kf, bf, kb, bb)   # encoders + context tensor
+                if L.shadow:
+                    G.op.shadow_rows(L.shadow_tab, L.row_hq)
         main.wait_stream(self._side)
         att, qatt = self._attend(L, want_logits)
         L.logits, L.yp, L.loss_t = ops.scorer_ce_fwd(L.gq, L.g1, L.lch, P.view(self.N_OUT_W), P.view(self.N_OUT_B),
@@ -870,7 +906,7 @@ class Model:
         if self.wd and L.has_y:                                              # :1094-1095: loss = add_n("losses")
             self._apply_wd(False, L.loss_t)
         self.logits, self.yp, self.loss = L.logits, L.yp, L.loss_t
-        self.hall = L.hall
+        self._hall_layout = L
         if want_logits:
             self.att_logits, self.q_att_logits = att, qatt
         return L.yp
@@ -893,7 +929,13 @@ class Model:
         L.ctx = ctx
         # :1020; time_warp_att: the softmax over t runs on amax * sum_t' C[n,t,t'] = amax * c[n,t] cnt(t) (:269-275)
         L.tscale = L.tw.scale if self.use_time_warp_att else None
-        L.g1, att = L.att.forward(ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, W, b, want_logits, tscale=L.tscale)
+        if L.shadow and not want_logits:
+            L.g1, att = L.att.forward_shadow(L.shadow_tab, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, W, b), None
+        else:
+            if L.shadow:     # the full logit tensor is an inspection output of the fp32-row kernel: fill the rows in
+                self._hall_layout = L
+                ctx = self.hall
+            L.g1, att = L.att.forward(ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, W, b, want_logits, tscale=L.tscale)
         if self.use_question_att:                                           # :1044
             Wq = P.view(self.N_QATT_W) if self.simi != 4 else None
             bq = P.view(self.N_QATT_B) if self.simi != 4 else None
@@ -992,6 +1034,9 @@ class Model:
                           P.view(self.N_TW_WH_B, True), P.view(self.N_TW_WC_W, True), P.view(self.N_TW_WC_B, True),
                           d_scale_att=L.d_tscale)
             T.op.last_state_bwd(L.d_lq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
+        elif L.shadow:
+            L.att.backward_shadow(L.shadow_tab, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, d_hall, d_hq,
+                                  daW, dab, accumulate=2)
         else:
             L.att.backward(L.hall, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, d_hall, d_hq, daW, dab,
                            accumulate=2)

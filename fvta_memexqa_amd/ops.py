@@ -101,15 +101,18 @@ class BiLstm:
     """
 
     def __init__(self, B, J, in_dim, d, x_off, out_off, seq_J, out_ld, share_fw_bw=True, precision=F32,
-                 training=False, prof_tag=0, x_bw_delta=0, dx_overwrite=False, out_pads_persist=False):
+                 training=False, prof_tag=0, x_bw_delta=0, dx_overwrite=False, out_pads_persist=False, out_skip=0):
         """x_bw_delta > 0: the backward direction reads x (writes dx) that many elements behind the forward direction's
         -- x = [x_fw | x_bw], the two dropped copies of DropoutWrapper's inputs (dropout_pair_fwd).
         dx_overwrite: backward() writes dx (zeros at padded positions) instead of adding to it: no memset by the caller.
-        out_pads_persist: the caller leaves `out` alone between forward calls: only rows that turn into padding are zeroed."""
+        out_pads_persist: the caller leaves `out` alone between forward calls: only rows that turn into padding are zeroed.
+        out_skip (bf16 engine): output half-rows at element offsets below it are not stored in fp32 -- their readers take
+        the bf16 shadow rows (shadow_rows; FocalAttention.forward_shadow / backward_shadow)."""
         self.x_bw_delta = int(x_bw_delta)
         self.lib = _lib.load()
         self.dev = require_gpu()
-        self.desc = LstmDesc(B, J, in_dim, d, int(share_fw_bw), precision, int(training), int(prof_tag), int(dx_overwrite), int(out_pads_persist))
+        self.desc = LstmDesc(B, J, in_dim, d, int(share_fw_bw), precision, int(training), int(prof_tag), int(dx_overwrite), int(out_pads_persist),
+                             int(out_skip))
         self.B, self.J, self.in_dim, self.d = B, J, in_dim, d
         self.x_off = x_off.to(self.dev, torch.int64).contiguous()
         self.out_off = out_off.to(self.dev, torch.int64).contiguous()
@@ -132,6 +135,13 @@ class BiLstm:
         check(self.lib.fvta_bilstm_fwd(ctypes.byref(self.desc), ptr(self.plan), ptr(_f32c(x)), ptr(_f32c(out)),
                                        ptr(_f32c(kernel_fw)), ptr(_f32c(bias_fw)), ptr(kernel_bw), ptr(bias_bw),
                                        ptr(self.saved), ptr(self.work), stream_ptr()), "fvta_bilstm_fwd")
+
+    def shadow_rows(self, table, nrows):
+        """table int64 [2, nrows] (device): the addresses of this call's bf16 output half-rows, by output row (out offset //
+        out_ld) -- only the rows t < len of this plan's sequences are written, see fvta_lstm_shadow_rows.  After forward()."""
+        assert table.dtype == torch.int64 and table.is_contiguous() and table.numel() == 2 * nrows
+        check(self.lib.fvta_lstm_shadow_rows(ctypes.byref(self.desc), ptr(self.plan), ptr(self.saved), int(nrows), ptr(table),
+                                             stream_ptr()), "fvta_lstm_shadow_rows")
 
     def set_active_hint(self, lens_host):
         """What the host knows about the lengths of the NEXT plan (a numpy / list of the B lengths, or None): the backward
@@ -163,6 +173,12 @@ class BiLstm:
     def last_state_bwd(self, d_dst, s0, count, d_out):
         check(self.lib.fvta_lstm_last_state_bwd(ctypes.byref(self.desc), ptr(self.plan), ptr(_f32c(d_dst)), s0, count,
                                                 ptr(d_out), stream_ptr()), "fvta_lstm_last_state_bwd")
+
+
+def rows_from_shadow(table, nrows, d, out_ld, out):
+    """out [nrows, out_ld] fp32 <- the bf16 rows behind a shadow table (inspection outputs, tests)"""
+    check(_lib.load().fvta_rows_from_shadow(ptr(table), int(nrows), int(d), int(out_ld), ptr(out), stream_ptr()),
+          "fvta_rows_from_shadow")
 
 
 def dropout_pair_fwd(x, x2, keep_prob, seed):
@@ -217,6 +233,20 @@ class FocalAttention:
                                         ptr(W), ptr(b), ptr(tscale), ptr(h_a), ptr(a_logits), ptr(self.saved),
                                         ptr(self.work), stream_ptr()), "fvta_attn_fwd")
         return h_a, a_logits
+
+    def forward_shadow(self, table, hq, hmask, qmask, W, b):
+        """forward() over the encoders' bf16 shadow rows: table int64 [2, N*K*T] (BiLstm.shadow_rows)"""
+        h_a = torch.empty(self.N, self.w, device=self.dev, dtype=torch.float32)
+        check(self.lib.fvta_attn_fwd_shadow(ctypes.byref(self.desc), ptr(table), ptr(_f32c(hq)), ptr(hmask), ptr(qmask),
+                                            ptr(W), ptr(b), ptr(h_a), ptr(self.saved), ptr(self.work), stream_ptr()),
+              "fvta_attn_fwd_shadow")
+        return h_a
+
+    def backward_shadow(self, table, hq, hmask, qmask, W, b, d_h_a, d_hinfo, d_hq, dW, db, accumulate):
+        check(self.lib.fvta_attn_bwd_shadow(ctypes.byref(self.desc), ptr(table), ptr(hq), ptr(hmask), ptr(qmask), ptr(W),
+                                            ptr(b), ptr(_f32c(d_h_a)), ptr(self.saved), ptr(d_hinfo), ptr(d_hq),
+                                            ptr(dW), ptr(db), int(accumulate), ptr(self.work), stream_ptr()),
+              "fvta_attn_bwd_shadow")
 
     def backward(self, hinfo, hq, hmask, qmask, W, b, d_h_a, d_hinfo, d_hq, dW, db, accumulate, tscale=None,
                  d_tscale=None):

@@ -95,6 +95,20 @@ int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const float* hq, 
                   const void* saved, float* d_hinfo, float* d_hq, float* dW, float* db, int accumulate,
                   void* workspace, fvta_stream_t stream);
 
+/* fvta_attn_fwd / fvta_attn_bwd over the encoders' bf16 SHADOW rows instead of an fp32 hinfo (model_v2.py:863-914's
+ * context tensor is the concatenation of the two directions' outputs the bi-LSTM has already written as bf16):
+ * table [2][N*K*T] device addresses, table[half][(n K + k) T + t] -> the w/2 bf16 values that are channels
+ * half * w/2 .. of row (n,k,t) (fvta_lstm_shadow_rows; EVERY entry must be readable: rows no encoder writes point at
+ * w/2 zeros).  JQ <= 32, w = 512 or 1024, simiMatrix 1-3, no hinfo_stride, no a_logits; FVTA_ERR_ARG otherwise.  Results
+ * are those of fvta_attn_fwd / fvta_attn_bwd run on the bf16-rounded rows.  `saved` / `workspace` sizes as above. */
+int fvta_attn_fwd_shadow(const fvta_attn_desc* d, const uint64_t* table, const float* hq, const uint8_t* hmask,
+                         const uint8_t* qmask, const float* W, const float* b, float* h_a, void* saved, void* workspace,
+                         fvta_stream_t stream);
+int fvta_attn_bwd_shadow(const fvta_attn_desc* d, const uint64_t* table, const float* hq, const uint8_t* hmask,
+                         const uint8_t* qmask, const float* W, const float* b, const float* d_h_a, const void* saved,
+                         float* d_hinfo, float* d_hq, float* dW, float* db, int accumulate, void* workspace,
+                         fvta_stream_t stream);
+
 /* attention_3d(..., time_warp_att=True, C=C): model_v2.py:269-275.  The max-pooled logits are multiplied by the
  * row sums of C before the softmax over t: tscale [N,T] = sum_t' C[n,t,t'] (with the model's time warp, c[n,t] cnt(t) =
  * fvta_timewarp_fwd's scale_out).  The softmax over K keeps the unscaled maxima.  The reference scales AFTER exp_mask,
@@ -143,6 +157,11 @@ typedef struct fvta_lstm_desc {
                         *     other contents comes back at the same address while the plan memory is kept, stale rows are not
                         *     zeroed: zero the plan memory (fvta_lstm_plan_bytes) whenever `out` is re-allocated, which also
                         *     is the way to invalidate the state; (3) the plan memory must start zeroed. */
+  int64_t out_skip;    /* fvta_bilstm_fwd (FVTA_BF16 only): output half-rows at element offsets BELOW this are not stored into
+                        * `out` (nor zeroed) -- their readers take the bf16 shadow rows the forward writes anyway
+                        * (fvta_lstm_shadow_rows; the focal attention through fvta_attn_fwd_shadow / fvta_attn_bwd_shadow).
+                        * 0: every row is stored.  The fp32 store of h is the single largest store of the forward step
+                        * (4 of its 18 bytes per row and unit; the step is store-bound: 119 -> 100 us per launch). */
 } fvta_lstm_desc;
 
 size_t fvta_lstm_plan_bytes(const fvta_lstm_desc* d);
@@ -211,6 +230,15 @@ int fvta_bilstm_bwd_hint(const fvta_lstm_desc* d, const void* plan, const float*
 
 /* Final states = concat(fw .h at t=len-1, bw .h at t=0) of sequences
  * [s0, s0+count): lq model_v2.py:697, lchoices 807-812.  dst [count, 2d]. */
+/* The bf16 shadow rows of a call's output (bf16 engine): table [2][nrows] of device addresses -- table[dir][row] points at
+ * the d bf16 values that are the output half-row `dir` of output row `row` (= element offset / out_ld) for every row this
+ * plan writes below nrows (rows t < len); entries of other rows are left untouched: initialise the table with the address of
+ * d zero bf16 values (the rows dynamic_rnn zeroes).  Valid until the next forward on `saved`.  model_v2.py:863-914's
+ * context tensor is then never materialised in fp32: fvta_attn_fwd_shadow / fvta_attn_bwd_shadow read these rows. */
+int fvta_lstm_shadow_rows(const fvta_lstm_desc* d, const void* plan, const void* saved, int64_t nrows, uint64_t* table,
+                          fvta_stream_t stream);
+/* out [nrows, out_ld] fp32 <- the rows behind such a table (inspection outputs: Tester.step_vis' hall, tests). */
+int fvta_rows_from_shadow(const uint64_t* table, int64_t nrows, int32_t d, int64_t out_ld, float* out, fvta_stream_t stream);
 int fvta_lstm_last_state(const fvta_lstm_desc* d, const void* plan, const float* out, int32_t s0,
                          int32_t count, float* dst, fvta_stream_t stream);
 /* d_out[...] += d_dst at the same places. */

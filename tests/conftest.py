@@ -24,3 +24,28 @@ def pytest_collection_modifyitems(config, items):
     first = [it for it in items if "test_gpu_dist" in it.nodeid]
     rest = [it for it in items if "test_gpu_dist" not in it.nodeid]
     items[:] = first + rest
+
+
+class _AttnSelect:
+    """fvta_attn_kernel_select for the duration of a test: exact() / fast(wave16) switch the focal-attention forward main
+    kernel inside the process (the library reads FVTA_ATTN_EXACT / FVTA_ATTN_WAVE16 once); the default returns afterwards."""
+
+    def __init__(self):
+        from fvta_memexqa_amd import _lib
+        self.lib = _lib.load()
+
+    def exact(self):
+        self.lib.fvta_attn_kernel_select(1, 0)
+
+    def fast(self, wave16=-1):
+        self.lib.fvta_attn_kernel_select(0, int(wave16))
+
+    def default(self):
+        self.lib.fvta_attn_kernel_select(-1, -1)
+
+
+@pytest.fixture
+def attn_select():
+    sel = _AttnSelect()
+    yield sel
+    sel.default()

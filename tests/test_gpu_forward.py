@@ -197,31 +197,6 @@ def test_attention_forward_is_bitwise_reproducible(w, JQ):
             assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1])
 
 
-class _AttnSelect:
-    """fvta_attn_kernel_select for the duration of a test: exact() / fast(wave16) switch the focal-attention forward main
-    kernel inside the process (the library reads FVTA_ATTN_EXACT / FVTA_ATTN_WAVE16 once); the default returns afterwards."""
-
-    def __init__(self):
-        from fvta_memexqa_amd import _lib
-        self.lib = _lib.load()
-
-    def exact(self):
-        self.lib.fvta_attn_kernel_select(1, 0)
-
-    def fast(self, wave16=-1):
-        self.lib.fvta_attn_kernel_select(0, int(wave16))
-
-    def default(self):
-        self.lib.fvta_attn_kernel_select(-1, -1)
-
-
-@pytest.fixture
-def attn_select():
-    sel = _AttnSelect()
-    yield sel
-    sel.default()
-
-
 def test_attention_fast_path_matches_exact_path(attn_select):
     """JQ <= 32, 128 <= w <= 1024 runs the fp16 3-term-split kernel; fvta_attn_kernel_select(1, .) routes to the fp32-MFMA kernel.
     The two must agree far inside the 1e-4 parity tolerance."""
