@@ -374,7 +374,13 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     dp = model.dp
     in_i = ((spec.text_in + 1 + 31) // 32) * 32
     fl_text = float((2 * (lens * 2.0 * (spec.text_in + dp) * 4 * dp - (lens > 0).float() * 2.0 * dp * 4 * dp)).sum().item())
-    by_fwd = float((2 * lens * (in_i * 2 + dp * 2 + dp * 4 * 3 + dp * 2 + 4 * dp * 2)).sum().item())
+    # per row and direction: x, h(t-1) read (bf16); c(t-1) read, c(t) written (fp32); h(t) written as the bf16 shadow row, and
+    # as fp32 for the rows whose readers take fp32 (under shadow rows: the question / choice sequences only); bf16 gates
+    shadow = bool(getattr(L, "shadow", False))
+    h32 = torch.ones_like(lens)
+    if shadow:
+        h32[T.segs[0]["count"] + T.segs[1]["count"]:] = 0.0      # (the text cell's sequences: q, choices, then the context streams)
+    by_fwd = float((2 * lens * (in_i * 2 + dp * 2 + dp * 4 * 2 + dp * 2 + 4 * dp * 2) + 2 * lens * h32 * dp * 4).sum().item())
     by_bwd = float((2 * lens * dp * 32).sum().item())
     by_dx = float((2 * lens * dp * 8 + lens * spec.text_in * 4).sum().item())
     is_bf = args.precision in ("bf16", "bf16x3")
@@ -448,18 +454,19 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     # ---- attention kernels against HBM: algorithmic bytes = valid rows * w * 4 + question + output; the
     # backward reads the rows and writes their gradient
     valid_rows = int(L.hall_mask.sum().item())
-    att_bytes = (valid_rows * model.wp + spec.N * L.JQ * model.wp + spec.N * model.wp) * 4.0
+    row_b = 2.0 if shadow else 4.0     # shadow rows: the attention reads the encoders' bf16 rows
+    att_bytes = valid_rows * model.wp * row_b + (spec.N * L.JQ * model.wp + spec.N * model.wp) * 4.0
     if args.graph == "fvta":   # (model.py's graph runs seven large 1-D attentions under the same bracket)
-        kname = (("attn_fwd_pair16" if model.wp >= 512 and model.simi != 4 and os.environ.get("FVTA_ATTN_WAVE16", "3") in ("2", "3")
+        kname = "attn_fwd_pair16h (bf16 shadow rows)" if shadow else (("attn_fwd_pair16" if model.wp >= 512 and model.simi != 4 and os.environ.get("FVTA_ATTN_WAVE16", "3") in ("2", "3")
                   else "attn_fwd_rows16") if (L.JQ <= 32 and 128 <= model.wp <= 1024) else
                  ("attn_fwd_wide" if model.wp == 2048 and L.JQ <= 64 and model.simi != 4 and os.environ.get("FVTA_ATTN_WAVE16", "3") != "0"
                   else "attn_fwd_main"))
         # (the library's profile bracket covers the context attention only, not the K = 1 question attention)
         hbm_roof("attention", kname + " (fvta_attn_fwd main kernel)", "attn_fwd_main", att_bytes,
-                 traffic=("r05_attention_pmc.json", "attn_fwd_pair16"))
+                 traffic=("r05_attention_pmc.json", "attn_fwd_pair16h" if shadow else "attn_fwd_pair16<"))
         if not args.forward_only:
-            hbm_roof("attention_bwd", "attn_bwd_main", "attn_bwd_main", 2.0 * valid_rows * model.wp * 4.0,
-                     traffic=("r05_attention_pmc.json", "attn_bwd_main"))
+            hbm_roof("attention_bwd", "attn_bwd_main", "attn_bwd_main", valid_rows * model.wp * (row_b + 4.0),
+                     traffic=("r05_attention_pmc.json", "attn_bwd_main<256, 1, 32, false, false, true>" if shadow else "attn_bwd_main<256, 1, 32, false, false>"))
     # the DOMINANT kernel of the step (largest bracketed time per step) is `roofline`; the rest are roofline_<name>
     kms = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
     order = sorted(roofs, key=lambda k: -roofs[k]["ms_per_step"])

@@ -283,6 +283,10 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
   const int io_row = mma.lane >> 3, io_c4 = mma.lane & 7;
   const float* __restrict__ cs_p = a.cs + (trow - a.B) * d;  // step t-1 (unused at t == 0)
   float* __restrict__ dcs = a.dc + (size_t)dir * a.B * d;
+  // (pinned in scalar registers: the compiler re-loaded the kernel argument in front of every pass's stores -- 32 scalar
+  //  loads per wave tile, each behind an s_waitcnt lgkmcnt(0))
+  bf16_t* dz_base = a.dzb + trow * (size_t)K;
+  asm volatile("" : "+s"(dz_base));
   auto wave_sync = [] {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -371,7 +375,7 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
       dco[e] = dc * fg;
     }
     if (i < nact && u < d && (!(abl & 2) || dco[0] == 1234.5f)) {
-      float* zp = reinterpret_cast<float*>(a.dzb + (trow + i) * (size_t)K + 4 * u);
+      float* zp = reinterpret_cast<float*>(dz_base + (size_t)i * K + 4 * u);
       *reinterpret_cast<f32x4*>(zp) = __builtin_bit_cast(f32x4, za);
       *reinterpret_cast<f32x4*>(zp + 4) = __builtin_bit_cast(f32x4, zb);
       if constexpr (XM == 3) {  // (hi, lo, hi) thirds of 4d bf16 = 2d floats

@@ -352,20 +352,12 @@ __global__ __launch_bounds__(64 * C::NW, 1) void lstm_bwd_ring_bf16(FusedBwdArgs
     return __builtin_amdgcn_raw_buffer_load_b128(r, vo, imm, 0);
   };
   int64_t oo_sel = 0;  // output offset of this lane's row of the tile being multiplied
-  // (the plan is read-only here: through the constant address space its wave-uniform reads are scalar loads -- as plain
-  //  global reads they would be vector loads, each select waiting vmcnt(0) and draining the whole DMA stream)
-  typedef const int64_t __attribute__((address_space(4)))* const_i64_ptr;
-  const const_i64_ptr oo_c = (const_i64_ptr)(a.plan.oo + trow);
-  auto row_offsets = [&](int m0) {
-    const int i0 = m0 + 8 * wave;
-    int64_t o = oo_c[min(i0, nact - 1)];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) {
-      const int64_t oj = oo_c[min(i0 + j, nact - 1)];  // clamped: always an active row
-      o = ((lane >> 3) == j) ? oj : o;
-    }
-    oo_sel = o;
-  };
+  // ONE 8-byte vector load per tile and lane, issued a whole tile ahead of its use (so that waiting for it drains nothing
+  // that has not landed anyway).  (As wave-uniform scalar loads, selected by row, at the head of the tile they belong to,
+  // every wave sat out eight scalar-cache round trips per tile, one s_waitcnt lgkmcnt(0) after the other.)
+  const int64_t* __restrict__ oo_g = a.plan.oo + trow;
+  int64_t oo_nxt = 0;
+  auto row_offsets_issue = [&](int m0n) { oo_nxt = oo_g[min(m0n + 8 * wave + (lane >> 3), nact - 1)]; };  // clamped: always an active row
   // epilogue operation n (0 .. 15) of a tile pass: 10 loads of the tile being multiplied (into `in`), 6 stores of the tile
   // whose gate gradient has just run (from zw / dco)
   unsigned zw[2][8];  // packed dz words of group g: [2 e] = (i, j), [2 e + 1] = (f, o) of unit e
@@ -485,6 +477,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void lstm_bwd_ring_bf16(FusedBwdArgs
   // ---- one tile pass: the MFMAs of tile `it` (its inputs -> inC), the gate gradient of the tile before (inP, rows m0p)
   auto body = [&](int it, const RingIn& inP, RingIn& inC, int m0p) {
     const int m0 = 32 * (rg + RG * it);
+    oo_sel = oo_nxt;  // (requested during the tile pass before)
     wb_static_for<0, C::NKS>([&](auto q_c) {
       constexpr int q = decltype(q_c)::value, n = q + C::PF;
       if constexpr (n % C::SLOT_KS == 0) {
@@ -492,7 +485,7 @@ __global__ __launch_bounds__(64 * C::NW, 1) void lstm_bwd_ring_bf16(FusedBwdArgs
         handover(std::integral_constant<int, s>{}, it + n / C::NKS, inC, m0, m0p);
       }
       fr[n % C::NB].f = *reinterpret_cast<const f32x4*>(ap[n % C::SLOT_KS] + ((n / C::SLOT_KS) % C::SLOTS) * C::SLOT_ELEMS);
-      if constexpr (q == 0) row_offsets(m0);
+      if constexpr (q == 0) row_offsets_issue(m0 + 32 * RG);
       wb_static_for<0, NCT>([&](auto ct_c) {
         constexpr int p = 2 * q + decltype(ct_c)::value;
         mfma(q_c, ct_c, fr[q % C::NB].b);
@@ -529,7 +522,9 @@ __global__ __launch_bounds__(64 * C::NW, 1) void lstm_bwd_ring_bf16(FusedBwdArgs
   for (int g = 0; g < 2; ++g)
 #pragma unroll
     for (int e = 0; e < 4; ++e) zw[g][2 * e] = zw[g][2 * e + 1] = 0u, dco[g][e] = 0.f;
-  row_offsets(m0_none);
+  row_offsets_issue(m0_none);
+  oo_sel = oo_nxt;
+  row_offsets_issue(32 * rg);  // the first tile's
   epi_pair(std::integral_constant<int, 1>{}, inB, m0_none, m0_none);
   asm volatile("" ::: "memory");
   wb_static_for<2, 8>([&](auto s_c) {

@@ -121,9 +121,9 @@ class Model:
         self.precision = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3}[_cfg(config, "precision", "f32")]
         # shadow rows (bf16 engine): the context tensor hall (model_v2.py:863-914) is never stored in fp32 -- the focal
         # attention reads the bf16 rows the encoders keep for their own recurrence (ops.BiLstm.shadow_rows).  Per layout,
-        # where the shadow kernels cover the shape (_shadow_covers); config "shadow_rows", else FVTA_SHADOW_ROWS, else off
+        # where the shadow kernels cover the shape (_shadow_covers); config "shadow_rows", else FVTA_SHADOW_ROWS, else ON
         sr = _cfg(config, "shadow_rows", None)
-        self.shadow_rows = bool(int(os.environ.get("FVTA_SHADOW_ROWS", "0"))) if sr is None else bool(sr)
+        self.shadow_rows = bool(int(os.environ.get("FVTA_SHADOW_ROWS", "1"))) if sr is None else bool(sr)
         self.wd = float(_cfg(config, "wd", None) or 0.0)                # --wd (main.py:105); None / 0.0: no l2 terms
         # d logits of softmax_cross_entropy_with_logits (model_v2.py:1088): True = what TF-1's kernel returns,
         # softmax - labels on every row, all-False label rows (padded rows of a short batch, :1270) included
