@@ -6,6 +6,7 @@
 // and the token's row (char part | word part) is written once, straight into the encoder input arena.
 #include "fvta_common.h"
 #include "gemm_f32.h"
+#include "attn_fwd_shared.h"  // split_f16x2: the fp16 (hi, lo') split of an fp32 value
 
 namespace fvta {
 
@@ -972,6 +973,170 @@ __global__ __launch_bounds__(256, 2) void embed_fwdw_mfma(EmbArgs a) {
 }
 template __global__ void embed_fwdw_mfma<100, 100>(EmbArgs);
 
+// The same convolution on the FP16 matrix pipe with the 3-term split of the focal attention's logits (attn_fwd.hip): every
+// value x = hi + 2^-11 lo' (hi = rtz_f16(x), lo' = f16((x - hi) 2^11)), product = hi hi + 2^-11 (hi lo' + lo' hi): three
+// v_mfma_f32_16x16x32_f16 (16 cycles each) per 32 k instead of eight v_mfma_f32_16x16x4_f32 (32 cycles each), <= 3 2^-22
+// |E| |filt| per product -- the fp32 kernel's own rounding is 2^-24 per product.  One workgroup = SEVEN waves = the seven
+// 16-filter slices: the token's character block is gathered, dropped and split ONCE (the wave-per-(token, slice) form above
+// re-staged it seven times: 45 KB of L2 reads per token), double-buffered in LDS as two fp16 arrays, and every wave multiplies
+// it with its slice's filter fragments (2 x 64 registers, resident for the whole launch).  A[p][kc] = E[p CD + kc]: the
+// windows overlap in memory, a lane's 8 consecutive k are 16 contiguous bytes of the block.  8.4 -> see DESIGN.md ms at the
+// published flag set's 394 k tokens.  grid (blocks), 448 threads.
+template <int CW, int CD>
+__global__ __launch_bounds__(448, 1) void embed_fwdw_f16x3(EmbArgs a) {
+  constexpr int KC = 5 * CD, NKS = (KC + 31) / 32;            // k-steps of 32
+  constexpr int EB = 15 * CD + 32 * NKS, EBP = (EB + 7) / 8 * 8;  // halves of a staged block (the last window's reach)
+  constexpr int NS = (CW + 15) / 16;                          // waves = filter slices
+  static_assert(CD % 4 == 0 && NS == 7, "seven slices of 16 filters; character rows are read 16 bytes at a time");
+  __shared__ __attribute__((aligned(16))) _Float16 s_hi[2][EBP], s_lo[2][EBP];
+  const fvta_embed_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int W = d.W, P = W - 4;
+  const int f = wv * 16 + j;
+  // the slice's filter fragments: B[k = 32 ks + 8 q + e][n = j] = filt[k][f] (k >= KC: zero)
+  half8 Bh[NKS], Bl[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    half2v h[4], l[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      // (unconditional loads of clamped addresses, then a select: under a branch each of the 128 loads was its own round trip)
+      const int k0 = 32 * ks + 8 * q + 2 * e2, fc = f < CW ? f : CW - 1;
+      const float y0 = a.filt[(size_t)(k0 < KC ? k0 : KC - 1) * CW + fc], y1 = a.filt[(size_t)(k0 + 1 < KC ? k0 + 1 : KC - 1) * CW + fc];
+      const float x0 = (k0 < KC && f < CW) ? y0 : 0.f, x1 = (k0 + 1 < KC && f < CW) ? y1 : 0.f;
+      split_f16x2(x0, x1, h[e2], l[e2]);
+    }
+    Bh[ks] = cat_h2(h[0], h[1], h[2], h[3]);
+    Bl[ks] = cat_h2(l[0], l[1], l[2], l[3]);
+  }
+  const float bias = f < CW ? a.bias[f] : 0.f;
+  for (int i = tid; i < 2 * EBP; i += 448) {  // (positions >= W and the reach beyond the block stay zero)
+    (&s_hi[0][0])[i] = (_Float16)0.f;
+    (&s_lo[0][0])[i] = (_Float16)0.f;
+  }
+  auto word_src = [&](int id) { return id < d.VW ? a.word_emb + (size_t)id * d.wdim : a.fixed_emb + (size_t)(id - d.VW) * d.wdim; };
+  // thread u < 16 CD / 4 gathers four channels of one character (clamped token: branch-free)
+  const int pos = tid / (CD / 4), c4 = tid % (CD / 4);
+  const bool stager = tid < 16 * CD / 4 && pos < W;
+  const int posc = pos < W ? pos : W - 1;
+  auto load_id = [&](int tok) {  // (every thread: clamped token and position, no branch)
+    const int t = tok < d.ntok ? tok : d.ntok - 1;
+    return a.char_ids[(size_t)t * W + posc];
+  };
+  auto load_E = [&](int cid) {
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (stager) v = *reinterpret_cast<const f32x4*>(a.char_emb + (size_t)cid * CD + 4 * c4);
+    return v;
+  };
+  // (the dropout mask is applied where the value is consumed: at the load, its wait drained the whole prefetch queue)
+  auto store_E = [&](int buf, f32x4 v, int tok) {
+    if (stager) {
+      if (a.drop_thr != 0ull) {
+        const int t = tok < d.ntok ? tok : d.ntok - 1;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] *= emb_ks(a, t, pos * CD + 4 * c4 + x, W * CD);
+      }
+      half2v h0, l0, h1, l1;
+      split_f16x2(v[0], v[1], h0, l0);
+      split_f16x2(v[2], v[3], h1, l1);
+      *reinterpret_cast<half4v*>(&s_hi[buf][pos * CD + 4 * c4]) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+      *reinterpret_cast<half4v*>(&s_lo[buf][pos * CD + 4 * c4]) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
+    }
+  };
+  const int step = gridDim.x;
+  int tok = blockIdx.x;
+  __syncthreads();  // the zero fill
+  store_E(0, load_E(load_id(tok)), tok);
+  // the gather (character ids, then their rows: two dependent round trips) runs PD tokens ahead of the multiplication,
+  // which takes a fraction of one round trip
+  constexpr int PD = 4;
+  f32x4 pre[PD];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) pre[i] = load_E(load_id(tok + (i + 1) * step));
+  int cid_n = load_id(tok + (PD + 1) * step);  // (the ids one more token ahead of the rows they address)
+  // the token's row address and word id travel PD tokens ahead too, the word's row (element tid) one token ahead: left to
+  // the token's own iteration, the word copy was two dependent round trips that every wave waited for at the barrier
+  // (the index is hidden from the compiler's uniformity analysis: it would move each freshly loaded id / offset into scalar
+  //  registers with v_readfirstlane -- behind an s_waitcnt vmcnt(0) in every iteration, a round trip that also drains the gather)
+  auto ctok = [&](int t) {
+    int c = t < d.ntok ? t : d.ntok - 1;
+    asm volatile("" : "+v"(c));
+    return c;
+  };
+  int64_t off_q[PD + 1];
+  int wid_q[PD + 1];
+#pragma unroll
+  for (int i = 0; i <= PD; ++i) {
+    off_q[i] = a.tok_off[ctok(tok + i * step)];
+    wid_q[i] = a.word_ids[ctok(tok + i * step)];
+  }
+  const int wcol = tid < d.wdim ? tid : 0;
+  float w_cur = word_src(wid_q[0])[wcol];
+  __syncthreads();
+  for (int it = 0; tok < d.ntok; tok += step, ++it) {
+    const int buf = it & 1;
+    const f32x4 e_n = pre[0];
+    const int64_t off = off_q[0];
+#pragma unroll
+    for (int i = 0; i + 1 < PD; ++i) pre[i] = pre[i + 1];
+#pragma unroll
+    for (int i = 0; i < PD; ++i) off_q[i] = off_q[i + 1], wid_q[i] = wid_q[i + 1];
+    pre[PD - 1] = load_E(cid_n);
+    cid_n = load_id(tok + (PD + 2) * step);
+    off_q[PD] = a.tok_off[ctok(tok + (PD + 1) * step)];
+    wid_q[PD] = a.word_ids[ctok(tok + (PD + 1) * step)];
+    const float w_nxt = word_src(wid_q[0])[wcol];
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};  // (three independent chains)
+    const _Float16* ah = &s_hi[buf][j * CD + 8 * q];  // window position p = j
+    const _Float16* al = &s_lo[buf][j * CD + 8 * q];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      // (8-byte aligned: 2 (100 p + 32 ks + 8 q) bytes)
+      const half4v h0 = *reinterpret_cast<const half4v*>(ah + 32 * ks), h1 = *reinterpret_cast<const half4v*>(ah + 32 * ks + 4);
+      const half4v l0 = *reinterpret_cast<const half4v*>(al + 32 * ks), l1 = *reinterpret_cast<const half4v*>(al + 32 * ks + 4);
+      const half8 Ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), Al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh[ks], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl[ks], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh[ks], acc2, 0, 0, 0);
+    }
+    acc1 += acc2;
+    // D[p = 4 q + r][f = j]: max / FIRST arg-max over the valid positions
+    float best = -INFINITY;
+    int bp = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = acc0[r] + acc1[r] * (1.f / 2048.f);
+      const int p = 4 * q + r;
+      if (p < P && v > best) {
+        best = v;
+        bp = p;
+      }
+    }
+#pragma unroll
+    for (int sh = 16; sh <= 32; sh <<= 1) {
+      const float ob = __shfl_xor(best, sh, 64);
+      const int op = __shfl_xor(bp, sh, 64);
+      if (ob > best || (ob == best && op < bp)) {
+        best = ob;
+        bp = op;
+      }
+    }
+    float* row = a.x + off;
+    if (q == 0 && f < CW) {
+      const float y = best + bias;
+      row[f] = y > 0.f ? y : 0.f;
+      a.argpos[(size_t)tok * CW + f] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
+    }
+    if (tid < d.wdim) row[CW + tid] = w_cur;  // the word part of the row (wdim <= 448: the launcher's condition -- a copy loop
+                                              // here made the compiler drain every prefetch at the end of each token)
+    w_cur = w_nxt;
+    store_E(buf ^ 1, e_n, tok + step);  // (that buffer's readers finished before the barrier that ended the previous token)
+    __syncthreads();
+  }
+}
+template __global__ void embed_fwdw_f16x3<100, 100>(EmbArgs);
+
 // Backward of the wide shape, in the SPARSE form (one window per token and filter carries gradient: 12x fewer MACs than
 // the GEMM form), split so that every accumulator lives in registers / LDS instead of a global slab:
 //  * embed_bwdw_filt: d filter / d bias.  grid (k chunks of 128, blocks); thread f keeps its 128 filter-gradient
@@ -988,6 +1153,9 @@ template __global__ void embed_fwdw_mfma<100, 100>(EmbArgs);
 #endif
 #ifndef FVTA_EMBW_FWD_WAVE
 #define FVTA_EMBW_FWD_WAVE 1
+#endif
+#ifndef FVTA_EMBW_F16X3
+#define FVTA_EMBW_F16X3 1   // the wide char-CNN on the fp16 matrix pipe with the 3-term split (0: exact-fp32 MFMA kernels)
 #endif
 constexpr int EMBW_KCH = 128;   // k values per chunk (registers)
 constexpr int EMBW_CS = 32;     // channels per slice
@@ -1277,6 +1445,156 @@ __global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_char_mfma(EmbArgs a)
   }
 }
 template __global__ void embed_bwdw_char_mfma<100>(EmbArgs);
+
+// embed_bwdw_char_mfma on the fp16 matrix pipe with the 3-term split (embed_fwdw_f16x3): the one-hot product over the
+// CW = 100 filters is 4 k-steps of 32 x 5 column tiles x 3 v_mfma_f32_16x16x32_f16 = 960 matrix-pipe cycles per token and
+// slice instead of 25 x 5 v_mfma_f32_16x16x4_f32 = 4000; everything around it (gradient row staging, the transposed T tile,
+// the per-wave char tables in LDS) is that kernel's.
+template <int CW>
+__global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_char_f16x3(EmbArgs a) {
+  using C = Emb5x8<CW>;
+  constexpr int CS = EMBM_CS, NCT = EMBM_NT;  // 5 CS = 125 local columns l = k CS + c in 8 tiles of 16
+  extern __shared__ __attribute__((aligned(16))) float s_dCall[];  // [4 waves][VC][CS]: a table per wave (one summation order)
+  constexpr int NK32 = (CW + 31) / 32;  // k-steps of 32 filters
+  __shared__ __attribute__((aligned(16))) float s_T[C::NW][NCT * 16 * 16], s_G[C::NW][32 * NK32];
+  __shared__ __attribute__((aligned(16))) uint8_t s_P[C::NW][32 * NK32];
+  __shared__ int s_ch[C::NW][16];
+  const fvta_embed_desc& d = a.d;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int W = d.W, cd = d.cdim;
+  const int c0 = blockIdx.x * CS, nc = min(CS, cd - c0);
+  float* s_dC = s_dCall + (size_t)wv * d.VC * CS;
+  for (int i = lane; i < d.VC * CS; i += 64) s_dC[i] = 0.f;
+  float* Tt = s_T[wv];
+  for (int i = lane; i < 32 * NK32; i += 64) s_G[wv][i] = 0.f;
+  for (int i = lane; i < 32 * NK32; i += 64) s_P[wv][i] = 255;
+  // the slice's filter fragments, fp16 (hi, lo'): B[k = 32 ks + 8 q + e][n = 16 ct + j] = filt[kc(l = 16 ct + j)][k], zero beyond
+  // the slice and the filters (unconditional loads of clamped addresses, then a select)
+  half8 Bh[NK32][NCT], Bl[NK32][NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int l = 16 * ct + j, k = l / CS, c = l % CS;
+    const bool ok = l < 5 * CS && c < nc;
+    const float* src = a.filt + (size_t)(ok ? k * cd + c0 + c : 0) * CW;
+#pragma unroll
+    for (int ks = 0; ks < NK32; ++ks) {
+      half2v h[4], lo[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const int f0 = 32 * ks + 8 * q + 2 * e2;
+        const float y0 = src[f0 < CW ? f0 : CW - 1], y1 = src[f0 + 1 < CW ? f0 + 1 : CW - 1];
+        split_f16x2((ok && f0 < CW) ? y0 : 0.f, (ok && f0 + 1 < CW) ? y1 : 0.f, h[e2], lo[e2]);
+      }
+      Bh[ks][ct] = cat_h2(h[0], h[1], h[2], h[3]);
+      Bl[ks][ct] = cat_h2(lo[0], lo[1], lo[2], lo[3]);
+    }
+  }
+  __syncthreads();
+  const int step = gridDim.y * C::NW;
+  const bool has2 = lane + 64 < CW;
+  const int lane2 = has2 ? 64 + lane : lane;
+  const int posc = lane < W ? lane : W - 1;
+  auto load_tok = [&](int tok, int& ap1, int& ap2, float& g1, float& g2, int& ch) {  // branch-free: clamped token
+    const int t = tok < d.ntok ? tok : d.ntok - 1;
+    const float* row = a.dx + a.tok_off[t];
+    ap1 = a.argpos[(size_t)t * CW + lane];
+    const int b2 = a.argpos[(size_t)t * CW + lane2];
+    g1 = row[lane];
+    g2 = row[lane2];
+    ap2 = has2 ? b2 : 255;
+    ch = a.char_ids[(size_t)t * W + posc];
+  };
+  // the lane's cells of dE[pos][c]: T index of k = 0 (column l = c, row pos), position (-1: no cell), channel
+  constexpr int NIT = (16 * CS + 63) / 64;
+  int tb[NIT], ps[NIT], cs_[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int it = lane + 64 * i, pos = it / CS, c = it % CS;
+    const bool ok = it < 16 * CS && c < nc;
+    tb[i] = ok ? c * 16 + pos : 0;
+    ps[i] = ok ? pos : -1;
+    cs_[i] = ok ? c : 0;
+  }
+  int tok = blockIdx.y * C::NW + wv;
+  int ap1, ap2, ch, ap1n, ap2n, chn;
+  float g1, g2, g1n, g2n;
+  load_tok(tok, ap1, ap2, g1, g2, ch);
+  for (; tok < d.ntok; tok += step) {
+    load_tok(tok + step, ap1n, ap2n, g1n, g2n, chn);
+    // stage the gradient row (filter f at [f]) and the word's characters
+    s_G[wv][lane] = ap1 == 255 ? 0.f : g1;
+    s_P[wv][lane] = (uint8_t)ap1;
+    if (has2) {
+      s_G[wv][64 + lane] = ap2 == 255 ? 0.f : g2;
+      s_P[wv][64 + lane] = (uint8_t)ap2;
+    }
+    if (lane < 16) s_ch[wv][lane] = lane < W ? ch : -1;
+    wave_lds_fence();
+    // T[p][l] = sum_f G[p][f] filt[kc(l)][f]: lane (p = j, k group q) builds its 8 consecutive filters of the one-hot G from the
+    // staged row, split (hi, lo'); three v_mfma_f32_16x16x32_f16 per k-step and column tile (see embed_fwdw_f16x3)
+    f32x4 accT[NCT], accX[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) accT[ct] = accX[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NK32; ++ks) {
+      const f32x4 G0 = *reinterpret_cast<const f32x4*>(&s_G[wv][32 * ks + 8 * q]), G1 = *reinterpret_cast<const f32x4*>(&s_G[wv][32 * ks + 8 * q + 4]);
+      const uint2 Pw = *reinterpret_cast<const uint2*>(&s_P[wv][32 * ks + 8 * q]);
+      half2v h[4], lo[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        const unsigned pw = e2 < 2 ? Pw.x : Pw.y;
+        const int pa = (int)((pw >> (16 * (e2 & 1))) & 255u), pb = (int)((pw >> (16 * (e2 & 1) + 8)) & 255u);
+        const float ga = e2 < 2 ? G0[2 * e2] : G1[2 * e2 - 4], gb = e2 < 2 ? G0[2 * e2 + 1] : G1[2 * e2 - 3];
+        split_f16x2(pa == j ? ga : 0.f, pb == j ? gb : 0.f, h[e2], lo[e2]);
+      }
+      const half8 Ah = cat_h2(h[0], h[1], h[2], h[3]), Al = cat_h2(lo[0], lo[1], lo[2], lo[3]);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        accT[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh[ks][ct], accT[ct], 0, 0, 0);
+        accX[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl[ks][ct], accX[ct], 0, 0, 0);
+        accX[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh[ks][ct], accX[ct], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) accT[ct] += accX[ct] * (1.f / 2048.f);
+    // T -> LDS as [l][p] (a lane's four rows p = 4 q + r are one 16-byte store), then dE[pos][c] = sum_k T[pos - k][k CS + c]
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(&Tt[(16 * ct + j) * 16 + 4 * q]) = accT[ct];
+    wave_lds_fence();
+    // (the lane's NIT cells (pos, c): indices precomputed, all 5 NIT reads of the tile in flight together)
+    float dv[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const float tv = Tt[tb[i] + (ps[i] >= k ? k * (16 * CS - 1) : 0)];
+        v += ps[i] >= k ? tv : 0.f;
+      }
+      dv[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int me = s_ch[wv][ps[i] & 15];
+      if (ps[i] >= 0 && me >= 0) lds_fadd(&s_dC[me * CS + cs_[i]], dv[i] * emb_ks(a, tok, ps[i] * cd + c0 + cs_[i], W * cd));
+    }
+    wave_lds_fence();
+    ap1 = ap1n; ap2 = ap2n; g1 = g1n; g2 = g2n; ch = chn;
+  }
+  __syncthreads();
+  const int KC = 5 * cd;
+  float* slab_c = a.slab + (size_t)blockIdx.y * ((size_t)KC * CW + CW + (size_t)d.VC * cd) + (size_t)KC * CW + CW;
+  for (int i = threadIdx.x; i < d.VC * CS; i += 256) {
+    const int v = i / CS, c = i % CS;
+    if (c < nc) {
+      float t = 0.f;
+      for (int w4 = 0; w4 < C::NW; ++w4) t += s_dCall[(size_t)w4 * d.VC * CS + i];  // wave order
+      slab_c[(size_t)v * cd + c0 + c] = t;
+    }
+  }
+}
+template __global__ void embed_bwdw_char_f16x3<100>(EmbArgs);
 
 // d filt / d bias of the wide shape on the matrix pipe (same shapes and slices as embed_bwdw_char_mfma).  One WAVE per token:
 //   dFilt[l = k CS + c][f] += sum_p E[p + k][c0 + c] G[p][f],   G[p][f] = g_f [argpos_f = p]
@@ -1825,6 +2143,10 @@ extern "C" int fvta_embed_fwd(const fvta_embed_desc* d, const int32_t* word_ids,
   if (FVTA_EMBW_FWD_WAVE && embed_mfma_ok(d) && d->cwdim == 100 && d->cdim == 100 && d->height == 5 && d->W >= 5) {
     // the published --char_emb_size 100: filters in registers, a wave per token (with or without dropout)
     const int nb = (d->ntok + 3) / 4 < 1024 ? (d->ntok + 3) / 4 : 1024;
+    if (FVTA_EMBW_F16X3 && d->W <= 16 && d->wdim <= 448) {  // the fp16 3-term-split form: a workgroup per token, the seven filter slices its waves
+      const int nbt = d->ntok < 256 ? d->ntok : 256;  // one workgroup per CU (its filter fragments are loaded once)
+      hipLaunchKernelGGL((embed_fwdw_f16x3<100, 100>), dim3(nbt), dim3(448), 0, (hipStream_t)stream_, a);
+    } else
     hipLaunchKernelGGL((embed_fwdw_mfma<100, 100>), dim3(7, nb), dim3(256), 0, (hipStream_t)stream_, a);
   } else if (embed_mfma_ok(d) && d->cwdim > 0 && embed_is_big(d) && a.drop_thr == 0ull) {
     hipLaunchKernelGGL(embed_fwd_kernel_mfma, dim3((d->ntok + 7) / 8), dim3(256), MmaEmb::LDS_FLOATS * sizeof(float),
@@ -1876,6 +2198,11 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
     if (FVTA_EMBW_CHAR_MFMA && d->cwdim == 100 && d->height == 5 && tabm <= 112 * 1024) {  // the matrix-pipe form
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char_mfma<100>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)tabm);
+      if (FVTA_EMBW_F16X3) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char_f16x3<100>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)tabm);
+        hipLaunchKernelGGL(embed_bwdw_char_f16x3<100>, dim3((d->cdim + EMBM_CS - 1) / EMBM_CS, blocks), dim3(256), tabm, stream, a);
+      } else
       hipLaunchKernelGGL(embed_bwdw_char_mfma<100>, dim3((d->cdim + EMBM_CS - 1) / EMBM_CS, blocks), dim3(256), tabm, stream, a);
     } else {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char), hipFuncAttributeMaxDynamicSharedMemorySize,

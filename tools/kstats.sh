@@ -8,7 +8,7 @@ f=$(find gpurun_out/$tag/ks -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/$tag/kernel_stats.csv
 python3 - "$f" <<'PY'
 import csv, sys
-for r in list(csv.DictReader(open(sys.argv[1])))[:int(20)]:
+for r in list(csv.DictReader(open(sys.argv[1])))[:int(60)]:
     print("%-90s calls %6s avg %10.1f us  %5s %%" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
 PY
 tail -3 gpurun_out/$tag/run.log
