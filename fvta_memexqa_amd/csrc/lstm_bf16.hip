@@ -294,7 +294,20 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
   struct In {
     f32x4 g0, g1, g2, g3, cp, dout, dcv;  // g0, g1: packed bf16 gates of four units; split engine: g0..g3 fp32 gates, one unit each
   };
-  auto ldnt = [](const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); };  // read once
+  // -DFVTA_TBWD_NT=bits (measurement): 1 the read-once streams (gates, c, d_out) with non-temporal loads (the default),
+  // 2 dz stores non-temporal, 4 dc stores non-temporal, 8 dc loads non-temporal
+#ifndef FVTA_TBWD_NT
+#define FVTA_TBWD_NT 1
+#endif
+  constexpr int ntb = FVTA_TBWD_NT;
+  auto ldnt = [](const float* p) {
+    if constexpr ((ntb & 1) != 0) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));  // read once
+    else return *reinterpret_cast<const f32x4*>(p);
+  };
+  auto st16 = [](float* p, const f32x4 v, bool nt) {
+    if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+    else *reinterpret_cast<f32x4*>(p) = v;
+  };
   // The wave tile's TM x TN planes of four passes each form ONE sequence of passes; the loads of pass P + EPD are requested
   // when pass P is done, also across plane boundaries (the loads do not depend on the plane's scratch): EPD passes of
   // 5 KB are in flight per wave all through the epilogue.
@@ -333,7 +346,8 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
       in.dout = f32x4{dp[0], dp[1], dp[2], dp[3]};  // an output row that is not 16-byte aligned
     // dc of a row that was not active at step t + 1 is zero by definition (the engine does not zero the buffer): an
     // unconditional load + select
-    const f32x4 dcl = *reinterpret_cast<const f32x4*>(dcs + (size_t)ic * d + uc);
+    const f32x4 dcl = (ntb & 8) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dcs + (size_t)ic * d + uc))
+                                : *reinterpret_cast<const f32x4*>(dcs + (size_t)ic * d + uc);
     in.dcv = (m0 + row) < nnext ? dcl : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto do_pass = [&](int P, const In& in) {
@@ -376,15 +390,15 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
     }
     if (i < nact && u < d && (!(abl & 2) || dco[0] == 1234.5f)) {
       float* zp = reinterpret_cast<float*>(dz_base + (size_t)i * K + 4 * u);
-      *reinterpret_cast<f32x4*>(zp) = __builtin_bit_cast(f32x4, za);
-      *reinterpret_cast<f32x4*>(zp + 4) = __builtin_bit_cast(f32x4, zb);
+      st16(zp, __builtin_bit_cast(f32x4, za), (ntb & 2) != 0);
+      st16(zp + 4, __builtin_bit_cast(f32x4, zb), (ntb & 2) != 0);
       if constexpr (XM == 3) {  // (hi, lo, hi) thirds of 4d bf16 = 2d floats
         *reinterpret_cast<f32x4*>(zp + 2 * d) = __builtin_bit_cast(f32x4, la);
         *reinterpret_cast<f32x4*>(zp + 2 * d + 4) = __builtin_bit_cast(f32x4, lb);
         *reinterpret_cast<f32x4*>(zp + 4 * d) = __builtin_bit_cast(f32x4, za);
         *reinterpret_cast<f32x4*>(zp + 4 * d + 4) = __builtin_bit_cast(f32x4, zb);
       }
-      *reinterpret_cast<f32x4*>(dcs + (size_t)i * d + u) = dco;
+      st16(dcs + (size_t)i * d + u, dco, (ntb & 4) != 0);
     }
   };
   In ins[EPD];

@@ -21,10 +21,11 @@ pmc() {  # pmc <dir> <script and args...>: separate passes per counter group (SQ
   python3 tools/pmc_summary.py $d/summary.json $d/sq $d/sq2 $d/fetch $d/write > $d/summary.txt
 }
 if [ "$2" = "full" ]; then
-  pmc $out/pmc_fwd tools/lstm_fwd_ab.py;          cp $out/pmc_fwd/summary.json $out/lstm_pmc.json
+  # (FVTA_AB_SKIP=1: the regime of the step -- the context sequences' fp32 rows are not stored, shadow rows)
+  export FVTA_AB_SKIP=1; pmc $out/pmc_fwd tools/lstm_fwd_ab.py; unset FVTA_AB_SKIP;  cp $out/pmc_fwd/summary.json $out/lstm_pmc.json
   pmc $out/pmc_bwd tools/lstm_bwd_ab.py;          cp $out/pmc_bwd/summary.json $out/lstm_bwd_pmc.json
   pmc $out/pmc_bwd_ragged tools/lstm_bwd_ab.py 12864 30 200 512 ragged; cp $out/pmc_bwd_ragged/summary.json $out/lstm_bwd_ragged_pmc.json
-  pmc $out/pmc_attn tools/bench_attn.py bwd;      cp $out/pmc_attn/summary.json $out/attention_pmc.json
+  pmc $out/pmc_attn tools/bench_attn_shadow.py;   cp $out/pmc_attn/summary.json $out/attention_pmc.json   # fp32-row and shadow-row kernels
   pmc $out/pmc_attn_wide tools/bench_attn_wide.py; cp $out/pmc_attn_wide/summary.json $out/attention_wide_pmc.json
   timeout 300 python3 tools/bench_attn_wide.py > $out/attention_wide.txt 2>/dev/null; timeout 300 python3 tools/bench_attn_wide.py exact >> $out/attention_wide.txt 2>/dev/null
   # one rank through the launcher: the collective path (RCCL communicator, flat-gradient all-reduce) on the one GPU there is
