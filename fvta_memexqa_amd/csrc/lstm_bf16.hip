@@ -481,7 +481,10 @@ void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
 // direction, so no atomics (617 MB of float atomics at the memory side's ~1.3 TB/s were 0.4 ms of this kernel's 1.28) and a
 // fixed summation order either way.
 // WN = 2: one 256-wide column tile when the input fits it (dz, K = 4d wide, is read once), 64-deep stages.
-template <int WN, int BK, int ST, bool BOTH = false>
+// NOACC: the launcher's promise that accumulate == 0, at compile time -- as a run-time `if (accumulate) old = load(dst)` every
+// row group's store sat behind an s_waitcnt vmcnt(0) that also waits for every EARLIER store of the wave: 56 store round trips
+// per wave tile, one after the other (the same pattern cost the attention backward 17 % in round 4).
+template <int WN, int BK, int ST, bool BOTH = false, bool NOACC = false>
 __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dx_bf16(FusedBwdArgs a, int dir, int accumulate) {
   typedef TileCfgT<WN, 2, 4, ST, BK> TileCfg;
   typedef MmaBT<WN, 2, 4, ST, BK> MmaB;
@@ -512,17 +515,23 @@ __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dx
   RowSrc<TileCfg::A_GLDS, BK> az1;
   if (BOTH) {
     constexpr int CPR = BK / 8;
+    // (two dependent gathers per DMA piece: every load unconditional on a clamped row and issued before the first use --
+    //  under `if (i < nact)` each pair was its own two round trips, A_GLDS of them in a row at the head of every workgroup)
+    int ord[TileCfg::A_GLDS], ln[TileCfg::A_GLDS];
+#pragma unroll
+    for (int j = 0; j < TileCfg::A_GLDS; ++j) {
+      const int U = (mma.wave_all * TileCfg::A_GLDS + j) * 64 + mma.lane;
+      ord[j] = a.plan.order[min(m0 + U / CPR, nact - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < TileCfg::A_GLDS; ++j) ln[j] = a.plan.len[ord[j]];
 #pragma unroll
     for (int j = 0; j < TileCfg::A_GLDS; ++j) {
       const int U = (mma.wave_all * TileCfg::A_GLDS + j) * 64 + mma.lane;
       const int row = U / CPR, c = (U % CPR) ^ row_swz<BK>(row);
       const int i = m0 + row;
-      unsigned v = GLDS_OOB;
-      if (i < nact) {
-        const int sb = a.plan.len[a.plan.order[i]] - 1 - t;  // the backward direction's step at this position (>= 0: i is active)
-        v = (unsigned)(((size_t)sb * a.B + i) * (size_t)(K * 2)) + 16u * c;
-      }
-      az1.voff[j] = v;
+      const int sb = ln[j] - 1 - t;  // the backward direction's step at this position (>= 0 where i is active)
+      az1.voff[j] = i < nact ? (unsigned)(((size_t)sb * a.B + i) * (size_t)(K * 2)) + 16u * c : GLDS_OOB;
     }
   }
   const int nkt = K / BK, nkt_all = both ? 2 * nkt : nkt;
@@ -576,7 +585,7 @@ __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dx
         ptr[it] = a.dx + s_xo[row] + n;
         ok[it] = m0 + row < nact && n < in;  // (in is a multiple of 4: a 4-column group is wholly inside or outside)
         old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ok[it] && accumulate && !(abl & 2)) {
+        if constexpr (!NOACC) if (ok[it] && accumulate && !(abl & 2)) {
           if ((reinterpret_cast<uintptr_t>(ptr[it]) & 15) == 0)
             old[it] = *reinterpret_cast<const f32x4*>(ptr[it]);
           else
@@ -627,8 +636,13 @@ void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
     if (dx_wide_both(a)) {
       FusedBwdArgs b = a;
       b.dx_both = 1;
-      allow_big_lds(lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true>, LDS);
-      hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true>), grid, dim3(512), LDS, s, b, 0, a.dx_accumulate);
+      if (!a.dx_accumulate) {
+        allow_big_lds(lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true, true>, LDS);
+        hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true, true>), grid, dim3(512), LDS, s, b, 0, 0);
+      } else {
+        allow_big_lds(lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true>, LDS);
+        hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true>), grid, dim3(512), LDS, s, b, 0, a.dx_accumulate);
+      }
       hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST>), grid, dim3(512), LDS, s, b, 1, a.dx_accumulate);  // (separate inputs: its own dx copy)
       return;
     }
