@@ -982,67 +982,86 @@ template __global__ void embed_fwdw_mfma<100, 100>(EmbArgs);
 // it with its slice's filter fragments (2 x 64 registers, resident for the whole launch).  A[p][kc] = E[p CD + kc]: the
 // windows overlap in memory, a lane's 8 consecutive k are 16 contiguous bytes of the block.  8.4 -> see DESIGN.md ms at the
 // published flag set's 394 k tokens.  grid (blocks), 448 threads.
-template <int CW, int CD>
-__global__ __launch_bounds__(448, 1) void embed_fwdw_f16x3(EmbArgs a) {
+template <int CW, int CD, int SPW>  // SPW: 16-filter slices per wave
+__global__ __launch_bounds__(64 * ((((CW + 15) / 16) + SPW - 1) / SPW), 1) void embed_fwdw_f16x3(EmbArgs a) {
   constexpr int KC = 5 * CD, NKS = (KC + 31) / 32;            // k-steps of 32
   constexpr int EB = 15 * CD + 32 * NKS, EBP = (EB + 7) / 8 * 8;  // halves of a staged block (the last window's reach)
-  constexpr int NS = (CW + 15) / 16;                          // waves = filter slices
-  static_assert(CD % 4 == 0 && NS == 7, "seven slices of 16 filters; character rows are read 16 bytes at a time");
+  constexpr int NS = (CW + 15) / 16, NWV = (NS + SPW - 1) / SPW, NT = 64 * NWV;  // filter slices, waves, threads
+  constexpr int NU = 16 * CD / 4, NL = (NU + NT - 1) / NT;    // 16-byte pieces of a character block, pieces per thread
+  static_assert(CD % 4 == 0, "character rows are read 16 bytes at a time");
   __shared__ __attribute__((aligned(16))) _Float16 s_hi[2][EBP], s_lo[2][EBP];
   const fvta_embed_desc& d = a.d;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int W = d.W, P = W - 4;
-  const int f = wv * 16 + j;
-  // the slice's filter fragments: B[k = 32 ks + 8 q + e][n = j] = filt[k][f] (k >= KC: zero)
-  half8 Bh[NKS], Bl[NKS];
+  // the wave's filter fragments: B[k = 32 ks + 8 q + e][n = j] = filt[k][f] (k >= KC, f >= CW: zero)
+  half8 Bh[SPW][NKS], Bl[SPW][NKS];
+  float bias[SPW];
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    half2v h[4], l[4];
+  for (int sl = 0; sl < SPW; ++sl) {
+    const int f = (wv * SPW + sl) * 16 + j, fc = f < CW ? f : CW - 1;
 #pragma unroll
-    for (int e2 = 0; e2 < 4; ++e2) {
-      // (unconditional loads of clamped addresses, then a select: under a branch each of the 128 loads was its own round trip)
-      const int k0 = 32 * ks + 8 * q + 2 * e2, fc = f < CW ? f : CW - 1;
-      const float y0 = a.filt[(size_t)(k0 < KC ? k0 : KC - 1) * CW + fc], y1 = a.filt[(size_t)(k0 + 1 < KC ? k0 + 1 : KC - 1) * CW + fc];
-      const float x0 = (k0 < KC && f < CW) ? y0 : 0.f, x1 = (k0 + 1 < KC && f < CW) ? y1 : 0.f;
-      split_f16x2(x0, x1, h[e2], l[e2]);
+    for (int ks = 0; ks < NKS; ++ks) {
+      half2v h[4], l[4];
+#pragma unroll
+      for (int e2 = 0; e2 < 4; ++e2) {
+        // (unconditional loads of clamped addresses, then a select: under a branch each of the loads was its own round trip)
+        const int k0 = 32 * ks + 8 * q + 2 * e2;
+        const float y0 = a.filt[(size_t)(k0 < KC ? k0 : KC - 1) * CW + fc], y1 = a.filt[(size_t)(k0 + 1 < KC ? k0 + 1 : KC - 1) * CW + fc];
+        const float x0 = (k0 < KC && f < CW) ? y0 : 0.f, x1 = (k0 + 1 < KC && f < CW) ? y1 : 0.f;
+        split_f16x2(x0, x1, h[e2], l[e2]);
+      }
+      Bh[sl][ks] = cat_h2(h[0], h[1], h[2], h[3]);
+      Bl[sl][ks] = cat_h2(l[0], l[1], l[2], l[3]);
     }
-    Bh[ks] = cat_h2(h[0], h[1], h[2], h[3]);
-    Bl[ks] = cat_h2(l[0], l[1], l[2], l[3]);
+    bias[sl] = a.bias[fc];
   }
-  const float bias = f < CW ? a.bias[f] : 0.f;
-  for (int i = tid; i < 2 * EBP; i += 448) {  // (positions >= W and the reach beyond the block stay zero)
+  for (int i = tid; i < 2 * EBP; i += NT) {  // (positions >= W and the reach beyond the block stay zero)
     (&s_hi[0][0])[i] = (_Float16)0.f;
     (&s_lo[0][0])[i] = (_Float16)0.f;
   }
   auto word_src = [&](int id) { return id < d.VW ? a.word_emb + (size_t)id * d.wdim : a.fixed_emb + (size_t)(id - d.VW) * d.wdim; };
-  // thread u < 16 CD / 4 gathers four channels of one character (clamped token: branch-free)
-  const int pos = tid / (CD / 4), c4 = tid % (CD / 4);
-  const bool stager = tid < 16 * CD / 4 && pos < W;
-  const int posc = pos < W ? pos : W - 1;
-  auto load_id = [&](int tok) {  // (every thread: clamped token and position, no branch)
+  // piece u = tid + NT i: four channels of one character (clamped token and position: branch-free)
+  int pos[NL], c4[NL], posc[NL];
+  bool stager[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int u = tid + NT * i;
+    pos[i] = u / (CD / 4), c4[i] = u % (CD / 4);
+    stager[i] = u < NU && pos[i] < W;
+    posc[i] = pos[i] < W ? pos[i] : W - 1;
+  }
+  struct Blk { f32x4 v[NL]; };
+  struct Ids { int c[NL]; };
+  auto load_id = [&](int tok) {
     const int t = tok < d.ntok ? tok : d.ntok - 1;
-    return a.char_ids[(size_t)t * W + posc];
+    Ids r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.c[i] = a.char_ids[(size_t)t * W + posc[i]];
+    return r;
   };
-  auto load_E = [&](int cid) {
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (stager) v = *reinterpret_cast<const f32x4*>(a.char_emb + (size_t)cid * CD + 4 * c4);
-    return v;
+  auto load_E = [&](const Ids& id) {
+    Blk b;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) b.v[i] = *reinterpret_cast<const f32x4*>(a.char_emb + (size_t)id.c[i] * CD + 4 * (stager[i] ? c4[i] : 0));
+    return b;
   };
   // (the dropout mask is applied where the value is consumed: at the load, its wait drained the whole prefetch queue)
-  auto store_E = [&](int buf, f32x4 v, int tok) {
-    if (stager) {
-      if (a.drop_thr != 0ull) {
-        const int t = tok < d.ntok ? tok : d.ntok - 1;
+  auto store_E = [&](int buf, const Blk& b, int tok) {
+    const int t = tok < d.ntok ? tok : d.ntok - 1;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) v[x] *= emb_ks(a, t, pos * CD + 4 * c4 + x, W * CD);
+    for (int i = 0; i < NL; ++i)
+      if (stager[i]) {
+        f32x4 v = b.v[i];
+        if (a.drop_thr != 0ull)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) v[x] *= emb_ks(a, t, pos[i] * CD + 4 * c4[i] + x, W * CD);
+        half2v h0, l0, h1, l1;
+        split_f16x2(v[0], v[1], h0, l0);
+        split_f16x2(v[2], v[3], h1, l1);
+        *reinterpret_cast<half4v*>(&s_hi[buf][pos[i] * CD + 4 * c4[i]]) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+        *reinterpret_cast<half4v*>(&s_lo[buf][pos[i] * CD + 4 * c4[i]]) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
       }
-      half2v h0, l0, h1, l1;
-      split_f16x2(v[0], v[1], h0, l0);
-      split_f16x2(v[2], v[3], h1, l1);
-      *reinterpret_cast<half4v*>(&s_hi[buf][pos * CD + 4 * c4]) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
-      *reinterpret_cast<half4v*>(&s_lo[buf][pos * CD + 4 * c4]) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
-    }
   };
   const int step = gridDim.x;
   int tok = blockIdx.x;
@@ -1051,10 +1070,10 @@ __global__ __launch_bounds__(448, 1) void embed_fwdw_f16x3(EmbArgs a) {
   // the gather (character ids, then their rows: two dependent round trips) runs PD tokens ahead of the multiplication,
   // which takes a fraction of one round trip
   constexpr int PD = 4;
-  f32x4 pre[PD];
+  Blk pre[PD];
 #pragma unroll
   for (int i = 0; i < PD; ++i) pre[i] = load_E(load_id(tok + (i + 1) * step));
-  int cid_n = load_id(tok + (PD + 1) * step);  // (the ids one more token ahead of the rows they address)
+  Ids cid_n = load_id(tok + (PD + 1) * step);  // (the ids one more token ahead of the rows they address)
   // the token's row address and word id travel PD tokens ahead too, the word's row (element tid) one token ahead: left to
   // the token's own iteration, the word copy was two dependent round trips that every wave waited for at the barrier
   // (the index is hidden from the compiler's uniformity analysis: it would move each freshly loaded id / offset into scalar
@@ -1076,7 +1095,7 @@ __global__ __launch_bounds__(448, 1) void embed_fwdw_f16x3(EmbArgs a) {
   __syncthreads();
   for (int it = 0; tok < d.ntok; tok += step, ++it) {
     const int buf = it & 1;
-    const f32x4 e_n = pre[0];
+    const Blk e_n = pre[0];
     const int64_t off = off_q[0];
 #pragma unroll
     for (int i = 0; i + 1 < PD; ++i) pre[i] = pre[i + 1];
@@ -1087,55 +1106,65 @@ __global__ __launch_bounds__(448, 1) void embed_fwdw_f16x3(EmbArgs a) {
     off_q[PD] = a.tok_off[ctok(tok + (PD + 1) * step)];
     wid_q[PD] = a.word_ids[ctok(tok + (PD + 1) * step)];
     const float w_nxt = word_src(wid_q[0])[wcol];
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};  // (three independent chains)
+    f32x4 acc[SPW][3];  // (three independent chains per slice: hi hi, hi lo', lo' hi)
+#pragma unroll
+    for (int sl = 0; sl < SPW; ++sl) acc[sl][0] = acc[sl][1] = acc[sl][2] = f32x4{0.f, 0.f, 0.f, 0.f};
     const _Float16* ah = &s_hi[buf][j * CD + 8 * q];  // window position p = j
     const _Float16* al = &s_lo[buf][j * CD + 8 * q];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      // (8-byte aligned: 2 (100 p + 32 ks + 8 q) bytes)
+      // (8-byte aligned: 2 (100 p + 32 ks + 8 q) bytes); ONE read of the A fragments feeds the wave's SPW slices
       const half4v h0 = *reinterpret_cast<const half4v*>(ah + 32 * ks), h1 = *reinterpret_cast<const half4v*>(ah + 32 * ks + 4);
       const half4v l0 = *reinterpret_cast<const half4v*>(al + 32 * ks), l1 = *reinterpret_cast<const half4v*>(al + 32 * ks + 4);
       const half8 Ah = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7), Al = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh[ks], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl[ks], acc1, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh[ks], acc2, 0, 0, 0);
-    }
-    acc1 += acc2;
-    // D[p = 4 q + r][f = j]: max / FIRST arg-max over the valid positions
-    float best = -INFINITY;
-    int bp = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = acc0[r] + acc1[r] * (1.f / 2048.f);
-      const int p = 4 * q + r;
-      if (p < P && v > best) {
-        best = v;
-        bp = p;
-      }
-    }
-#pragma unroll
-    for (int sh = 16; sh <= 32; sh <<= 1) {
-      const float ob = __shfl_xor(best, sh, 64);
-      const int op = __shfl_xor(bp, sh, 64);
-      if (ob > best || (ob == best && op < bp)) {
-        best = ob;
-        bp = op;
+      for (int sl = 0; sl < SPW; ++sl) {
+        // (a slice past the last filter multiplies zeros: a wave-uniform skip here would cut the unrolled loop into blocks)
+        acc[sl][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh[sl][ks], acc[sl][0], 0, 0, 0);
+        acc[sl][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl[sl][ks], acc[sl][1], 0, 0, 0);
+        acc[sl][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh[sl][ks], acc[sl][2], 0, 0, 0);
       }
     }
     float* row = a.x + off;
-    if (q == 0 && f < CW) {
-      const float y = best + bias;
-      row[f] = y > 0.f ? y : 0.f;
-      a.argpos[(size_t)tok * CW + f] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
+#pragma unroll
+    for (int sl = 0; sl < SPW; ++sl) {
+      const int f = (wv * SPW + sl) * 16 + j;
+      // D[p = 4 q + r][f = j]: max / FIRST arg-max over the valid positions
+      float best = -INFINITY;
+      int bp = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[sl][0][r] + (acc[sl][1][r] + acc[sl][2][r]) * (1.f / 2048.f);
+        const int p = 4 * q + r;
+        if (p < P && v > best) {
+          best = v;
+          bp = p;
+        }
+      }
+#pragma unroll
+      for (int sh = 16; sh <= 32; sh <<= 1) {
+        const float ob = __shfl_xor(best, sh, 64);
+        const int op = __shfl_xor(bp, sh, 64);
+        if (ob > best || (ob == best && op < bp)) {
+          best = ob;
+          bp = op;
+        }
+      }
+      if (q == 0 && f < CW) {
+        const float y = best + bias[sl];
+        row[f] = y > 0.f ? y : 0.f;
+        a.argpos[(size_t)tok * CW + f] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
+      }
     }
-    if (tid < d.wdim) row[CW + tid] = w_cur;  // the word part of the row (wdim <= 448: the launcher's condition -- a copy loop
-                                              // here made the compiler drain every prefetch at the end of each token)
+    if (tid < d.wdim) row[CW + tid] = w_cur;  // the word part of the row (wdim <= threads: the launcher's condition -- a copy
+                                              // loop here made the compiler drain every prefetch at the end of each token)
     w_cur = w_nxt;
     store_E(buf ^ 1, e_n, tok + step);  // (that buffer's readers finished before the barrier that ended the previous token)
     __syncthreads();
   }
 }
-template __global__ void embed_fwdw_f16x3<100, 100>(EmbArgs);
+template __global__ void embed_fwdw_f16x3<100, 100, 1>(EmbArgs);
+template __global__ void embed_fwdw_f16x3<100, 100, 2>(EmbArgs);
 
 // Backward of the wide shape, in the SPARSE form (one window per token and filter carries gradient: 12x fewer MACs than
 // the GEMM form), split so that every accumulator lives in registers / LDS instead of a global slab:
@@ -1153,6 +1182,10 @@ template __global__ void embed_fwdw_f16x3<100, 100>(EmbArgs);
 #endif
 #ifndef FVTA_EMBW_FWD_WAVE
 #define FVTA_EMBW_FWD_WAVE 1
+#endif
+#ifndef FVTA_EMBW_SPW
+#define FVTA_EMBW_SPW 1     // filter slices per wave of embed_fwdw_f16x3: 1 = seven waves (2.6 ms at the published flag set), 2 = four
+                            // waves with half the LDS reads but one wave per SIMD (3.3 ms: the kernel is not LDS-bound)
 #endif
 #ifndef FVTA_EMBW_F16X3
 #define FVTA_EMBW_F16X3 1   // the wide char-CNN on the fp16 matrix pipe with the 3-term split (0: exact-fp32 MFMA kernels)
@@ -2143,9 +2176,11 @@ extern "C" int fvta_embed_fwd(const fvta_embed_desc* d, const int32_t* word_ids,
   if (FVTA_EMBW_FWD_WAVE && embed_mfma_ok(d) && d->cwdim == 100 && d->cdim == 100 && d->height == 5 && d->W >= 5) {
     // the published --char_emb_size 100: filters in registers, a wave per token (with or without dropout)
     const int nb = (d->ntok + 3) / 4 < 1024 ? (d->ntok + 3) / 4 : 1024;
-    if (FVTA_EMBW_F16X3 && d->W <= 16 && d->wdim <= 448) {  // the fp16 3-term-split form: a workgroup per token, the seven filter slices its waves
+    if (FVTA_EMBW_F16X3 && d->W <= 16 && d->wdim <= 64 * ((7 + FVTA_EMBW_SPW - 1) / FVTA_EMBW_SPW)) {
+      // the fp16 3-term-split form: a workgroup per token, its waves the filter slices (FVTA_EMBW_SPW slices each)
       const int nbt = d->ntok < 256 ? d->ntok : 256;  // one workgroup per CU (its filter fragments are loaded once)
-      hipLaunchKernelGGL((embed_fwdw_f16x3<100, 100>), dim3(nbt), dim3(448), 0, (hipStream_t)stream_, a);
+      hipLaunchKernelGGL((embed_fwdw_f16x3<100, 100, FVTA_EMBW_SPW>), dim3(nbt), dim3(64 * ((7 + FVTA_EMBW_SPW - 1) / FVTA_EMBW_SPW)), 0,
+                         (hipStream_t)stream_, a);
     } else
     hipLaunchKernelGGL((embed_fwdw_mfma<100, 100>), dim3(7, nb), dim3(256), 0, (hipStream_t)stream_, a);
   } else if (embed_mfma_ok(d) && d->cwdim > 0 && embed_is_big(d) && a.drop_thr == 0ull) {
