@@ -1187,6 +1187,10 @@ template __global__ void embed_fwdw_f16x3<100, 100, 2>(EmbArgs);
 #define FVTA_EMBW_SPW 1     // filter slices per wave of embed_fwdw_f16x3: 1 = seven waves (2.6 ms at the published flag set), 2 = four
                             // waves with half the LDS reads but one wave per SIMD (3.3 ms: the kernel is not LDS-bound)
 #endif
+#ifndef FVTA_EMBW_ABL
+#define FVTA_EMBW_ABL 0   // timing ablations of the wide backward kernels (results garbage): d filt 1 no MFMA, 2 no word-row atomics,
+                          // 4 no character gather, 8 no gradient-row gather; d char_emb 16 no MFMA, 32 no fold / LDS adds, 64 no gathers
+#endif
 #ifndef FVTA_EMBW_F16X3
 #define FVTA_EMBW_F16X3 1   // the wide char-CNN on the fp16 matrix pipe with the 3-term split (0: exact-fp32 MFMA kernels)
 #endif
@@ -1530,6 +1534,10 @@ __global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_char_f16x3(EmbArgs a
   const int posc = lane < W ? lane : W - 1;
   auto load_tok = [&](int tok, int& ap1, int& ap2, float& g1, float& g2, int& ch) {  // branch-free: clamped token
     const int t = tok < d.ntok ? tok : d.ntok - 1;
+    if constexpr (FVTA_EMBW_ABL & 64) {
+      ap1 = lane & 7, ap2 = has2 ? (lane & 3) : 255, g1 = 0.5f, g2 = 0.25f, ch = lane & 15;
+      return;
+    }
     const float* row = a.dx + a.tok_off[t];
     ap1 = a.argpos[(size_t)t * CW + lane];
     const int b2 = a.argpos[(size_t)t * CW + lane2];
@@ -1584,6 +1592,7 @@ __global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_char_f16x3(EmbArgs a
       const half8 Ah = cat_h2(h[0], h[1], h[2], h[3]), Al = cat_h2(lo[0], lo[1], lo[2], lo[3]);
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
+        if constexpr (FVTA_EMBW_ABL & 16) { accT[ct][0] += (float)Ah[0] * (float)Bh[ks][ct][0] + (float)Al[1] * (float)Bl[ks][ct][1]; continue; }
         accT[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh[ks][ct], accT[ct], 0, 0, 0);
         accX[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl[ks][ct], accX[ct], 0, 0, 0);
         accX[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh[ks][ct], accX[ct], 0, 0, 0);
@@ -1597,6 +1606,7 @@ __global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_char_f16x3(EmbArgs a
     wave_lds_fence();
     // (the lane's NIT cells (pos, c): indices precomputed, all 5 NIT reads of the tile in flight together)
     float dv[NIT];
+    if constexpr (!(FVTA_EMBW_ABL & 32))
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       float v = 0.f;
@@ -1607,9 +1617,13 @@ __global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_char_f16x3(EmbArgs a
       }
       dv[i] = v;
     }
+    if constexpr (!(FVTA_EMBW_ABL & 32))
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
       const int me = s_ch[wv][ps[i] & 15];
+      if constexpr (FVTA_EMBW_ABL & 128) { if (ps[i] >= 0 && me >= 0 && dv[i] == 1234.5f) s_dC[me * CS + cs_[i]] = dv[i]; continue; }
+      // (folding a token's duplicate characters first and adding with a plain read-modify-write was measured: 6.43 ms against
+      //  6.19 with these LDS float adds, which by themselves cost 2.0 ms -- -DFVTA_EMBW_ABL=128)
       if (ps[i] >= 0 && me >= 0) lds_fadd(&s_dC[me * CS + cs_[i]], dv[i] * emb_ks(a, tok, ps[i] * cd + c0 + cs_[i], W * cd));
     }
     wave_lds_fence();
@@ -1671,7 +1685,7 @@ __global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_filt_mfma(EmbArgs a)
     for (int i = 0; i < NE; ++i) {
       const int it = lane + 64 * i, pos = it / CS, c = it % CS;
       float v = 0.f;
-      if (it < 16 * CS && pos < W && c < nc)
+      if (!(FVTA_EMBW_ABL & 4) && it < 16 * CS && pos < W && c < nc)
         v = a.char_emb[(size_t)a.char_ids[(size_t)t * W + pos] * cd + c0 + c] * emb_ks(a, t, pos * cd + c0 + c, W * cd);
       e[i] = v;
     }
@@ -1682,8 +1696,8 @@ __global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_filt_mfma(EmbArgs a)
 #pragma unroll
     for (int nt = 0; nt < NNT; ++nt) {
       const int f = 16 * nt + j, fc = f < CW ? f : CW - 1;
-      const int p = a.argpos[(size_t)t * CW + fc];
-      const float r = row[fc];
+      const int p = (FVTA_EMBW_ABL & 8) ? (f & 7) : a.argpos[(size_t)t * CW + fc];
+      const float r = (FVTA_EMBW_ABL & 8) ? 0.5f : row[fc];
       ap[nt] = f < CW ? p : 255;
       g[nt] = (f < CW && p != 255) ? r : 0.f;
     }
@@ -1704,7 +1718,7 @@ __global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_filt_mfma(EmbArgs a)
       g_c[nt] = g_n[nt];
       ap_c[nt] = ap_n[nt];
     }
-    if (blockIdx.x == 0) {  // the word rows ride along with the first slice
+    if (blockIdx.x == 0 && !(FVTA_EMBW_ABL & 2)) {  // the word rows ride along with the first slice
       const int id = a.word_ids[tok];
       if (id < d.VW) {
         const float* row = a.dx + a.tok_off[tok];
@@ -1730,7 +1744,10 @@ __global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_filt_mfma(EmbArgs a)
 #pragma unroll
       for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NNT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NNT; ++nt) {
+          if constexpr (FVTA_EMBW_ABL & 1) acc[mt][nt][ks] += av[mt] * bv[nt];
+          else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
     }
     wave_lds_fence();  // the block's readers are done before the next token overwrites it
   }

@@ -1,7 +1,8 @@
 """The embedding front-end's kernels alone at the metric shape (385,920 tokens of 16 characters, 2,560 photos):
 HIP-event time per call of the char-CNN forward / backward and the photo transform forward / backward.
   python tools/frontend_ab.py [reps [char_emb_size]]"""
-import sys
+import os, sys
+sys.path.insert(0, os.getcwd())
 import torch
 from fvta_memexqa_amd import ops
 
