@@ -1191,6 +1191,9 @@ template __global__ void embed_fwdw_f16x3<100, 100, 2>(EmbArgs);
 #define FVTA_EMBW_ABL 0   // timing ablations of the wide backward kernels (results garbage): d filt 1 no MFMA, 2 no word-row atomics,
                           // 4 no character gather, 8 no gradient-row gather; d char_emb 16 no MFMA, 32 no fold / LDS adds, 64 no gathers
 #endif
+#ifndef FVTA_EMBW_FILT_TOK
+#define FVTA_EMBW_FILT_TOK 1   // d filt of the wide shape as a workgroup per token (0: a wave per (token, slice))
+#endif
 #ifndef FVTA_EMBW_F16X3
 #define FVTA_EMBW_F16X3 1   // the wide char-CNN on the fp16 matrix pipe with the 3-term split (0: exact-fp32 MFMA kernels)
 #endif
@@ -1334,6 +1337,219 @@ __global__ __launch_bounds__(256) void embed_bwdw_char(EmbArgs a) {
     if (c < nc) slab_c[(size_t)v * cd + c0 + c] = s_dC[i];
   }
 }
+
+// d filt / d bias of the wide shape, a WORKGROUP per token (embed_bwdw_filt_mfma below runs a wave per (token, slice): seven
+// waves somewhere on the chip each gather the token's gradient row, arg-max positions and their 16 channels of its characters --
+// 1.7 of its 6.1 ms -- and its four waves per workgroup work on four different tokens).  Here the seven waves of a workgroup ARE
+// the seven 16-channel slices of ONE token: the character block (16 positions x cdim, dropped as in the forward), the gradient
+// row and the arg-max positions are gathered once, two to four tokens ahead in registers (embed_fwdw_f16x3's queue), and
+// double-buffered in LDS; wave v multiplies ITS slice -- dFilt[l = k 16 + c][f] += sum_p E[p + k][16 v + c] G[p][f], the same
+// 5 x 7 x 3 v_mfma_f32_16x16x4_f32 per token as before, exact -- and keeps its 80 x 112 accumulator tile for the whole launch;
+// no reduction across waves at the end (a slice belongs to one wave).  grid (blocks <= 256), 448 threads, slab part
+// [0, KC cw + cw) of block x.
+// X3: the product on the bf16 matrix pipe with a three-term split -- x = hi + lo, both bf16 (fp32's exponent range: the low
+// terms need no scaling), hi hi + hi lo + lo hi into ONE accumulator, ~2^-16 per product (the arg-max positions are inputs
+// here: nothing can flip) -- one k-step of v_mfma_f32_16x16x16_bf16 over the 16 window positions instead of three of
+// v_mfma_f32_16x16x4_f32: 105 x 16 matrix-pipe cycles per token and slice instead of 105 x 32.  The character block and the
+// gradient row are split ONCE, by the threads that stage them, and kept in LDS as packed (hi | lo << 16) words.
+template <int CW, int CD, bool X3>
+__global__ __launch_bounds__(448, 1) void embed_bwdw_filt_tok(EmbArgs a) {
+  constexpr int CS = 16, NMT = 5, NNT = (CW + 15) / 16, NKS = 3, NS = (CD + CS - 1) / CS;
+  typedef short bf4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  auto pack_hl = [](float x) {  // bf16(x) | bf16(x - bf16(x)) << 16, both rounded to nearest
+    const unsigned h = f2bf(x);
+    return h | ((unsigned)f2bf(x - bf2f((unsigned short)h)) << 16);
+  };
+  static_assert(NS == 7 && CD % 4 == 0, "seven slices of 16 channels");
+  constexpr int NU = 16 * CD / 4;                       // 16-byte pieces of a character block
+  __shared__ __attribute__((aligned(16))) float s_E[2][20 * CD];  // (positions 16 .. 19 stay zero: the reach of window position 15)
+  __shared__ float s_g[2][16 * NNT];
+  __shared__ unsigned s_gx[2][X3 ? 16 * NNT : 1];  // (X3: the gradient row as packed hi | lo)
+  __shared__ int s_ap[2][16 * NNT];
+  const fvta_embed_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int W = d.W;
+  const int c0 = wv * CS, nc = min(CS, CD - c0);
+  f32x4 acc[NMT][NNT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NNT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float accb[NNT];
+#pragma unroll
+  for (int nt = 0; nt < NNT; ++nt) accb[nt] = 0.f;
+  for (int i = tid; i < 2 * 20 * CD; i += 448) (&s_E[0][0])[i] = 0.f;
+  for (int i = tid; i < 2 * 16 * NNT; i += 448) {
+    (&s_g[0][0])[i] = 0.f;
+    (&s_ap[0][0])[i] = 255;
+    if constexpr (X3) (&s_gx[0][0])[i] = 0u;
+  }
+  // A operand: lane (row l = 16 mt + j = tap mt, channel j; k phase q) reads E[(4 ks + q) + mt][c0 + j]; channels beyond the
+  // slice multiply by zero
+  const bool a_ok = j < nc;
+  const int a0 = (X3 ? 4 * q : q) * CD + c0 + (a_ok ? j : 0);  // (X3: the lane's four window positions 4 q .. 4 q + 3)
+  // staging: thread u < NU gathers four channels of one character; thread u < CW one gradient value and its arg-max position
+  const int pos = tid / (CD / 4), c4 = tid % (CD / 4);
+  const bool stager = tid < NU && pos < W;
+  const int posc = pos < W ? pos : W - 1;
+  const int fcol = tid < CW ? tid : CW - 1;
+  auto ctok = [&](int t) {  // (hidden from the uniformity analysis: see embed_fwdw_f16x3)
+    int c = t < d.ntok ? t : d.ntok - 1;
+    asm volatile("" : "+v"(c));
+    return c;
+  };
+  auto load_id = [&](int tok) { return a.char_ids[(size_t)ctok(tok) * W + posc]; };
+  auto load_E = [&](int cid) {
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (stager) v = *reinterpret_cast<const f32x4*>(a.char_emb + (size_t)cid * CD + 4 * c4);
+    return v;
+  };
+  auto load_off = [&](int tok) { return a.tok_off[ctok(tok)]; };
+  auto load_ap = [&](int tok) { return (int)a.argpos[(size_t)ctok(tok) * CW + fcol]; };
+  auto store_tok = [&](int buf, f32x4 v, float g, int ap, int tok) {
+    if (stager) {
+      if (a.drop_thr != 0ull) {
+        const int t = tok < d.ntok ? tok : d.ntok - 1;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] *= emb_ks(a, t, pos * CD + 4 * c4 + x, W * CD);
+      }
+      if constexpr (X3)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) v[x] = __uint_as_float(pack_hl(v[x]));
+      *reinterpret_cast<f32x4*>(&s_E[buf][pos * CD + 4 * c4]) = v;
+    }
+    if (tid < CW) {
+      const float gm = ap == 255 ? 0.f : g;
+      s_g[buf][tid] = gm;
+      s_ap[buf][tid] = ap;
+      if constexpr (X3) s_gx[buf][tid] = pack_hl(gm);
+    }
+  };
+  const int step = gridDim.x;
+  int tok = blockIdx.x;
+  constexpr int PD = 3;
+  f32x4 e_q[PD + 1];
+  int64_t off_q[PD + 2];
+  int ap_q[PD + 1];
+  float g_q[PD + 1];
+  int wid_q[PD + 1];
+#pragma unroll
+  for (int i = 0; i <= PD + 1; ++i) off_q[i] = load_off(tok + i * step);
+#pragma unroll
+  for (int i = 0; i <= PD; ++i) {
+    e_q[i] = load_E(load_id(tok + i * step));
+    ap_q[i] = load_ap(tok + i * step);
+    g_q[i] = a.dx[off_q[i] + fcol];
+    wid_q[i] = a.word_ids[ctok(tok + i * step)];
+  }
+  int cid_n = load_id(tok + (PD + 1) * step);
+  // the word part of the gradient row (elements lane and 64 + lane: wdim <= 128, the launcher's condition) one token ahead --
+  // a copy loop with loads inside the token loop makes the compiler drain every prefetch at the loop's end
+  const int wc0 = lane < d.wdim ? lane : 0, wc1 = 64 + lane < d.wdim ? 64 + lane : 0;
+  float w0 = a.dx[off_q[0] + CW + wc0], w1 = a.dx[off_q[0] + CW + wc1];
+  __syncthreads();  // the zero fill
+  store_tok(0, e_q[0], g_q[0], ap_q[0], tok);
+  __syncthreads();
+  for (int it = 0; tok < d.ntok; tok += step, ++it) {
+    const int buf = it & 1;
+    const int wid = wid_q[0];
+    const float w0n = a.dx[off_q[1] + CW + wc0], w1n = a.dx[off_q[1] + CW + wc1];
+    // the queues move up one token; the new tail entries are requested now
+#pragma unroll
+    for (int i = 0; i < PD; ++i) e_q[i] = e_q[i + 1], ap_q[i] = ap_q[i + 1], g_q[i] = g_q[i + 1], wid_q[i] = wid_q[i + 1];
+#pragma unroll
+    for (int i = 0; i <= PD; ++i) off_q[i] = off_q[i + 1];
+    e_q[PD] = load_E(cid_n);
+    cid_n = load_id(tok + (PD + 2) * step);
+    ap_q[PD] = load_ap(tok + (PD + 1) * step);
+    g_q[PD] = a.dx[off_q[PD] + fcol];          // (its row address was requested a token ago)
+    off_q[PD + 1] = load_off(tok + (PD + 2) * step);
+    wid_q[PD] = a.word_ids[ctok(tok + (PD + 1) * step)];
+    // the wave's one-hot operand: filter f = 16 nt + j
+    float g_c[NNT];
+    int ap_c[NNT];
+#pragma unroll
+    for (int nt = 0; nt < NNT; ++nt) {
+      g_c[nt] = s_g[buf][16 * nt + j];
+      ap_c[nt] = s_ap[buf][16 * nt + j];
+    }
+    if (wv == 0 && q == 0)
+#pragma unroll
+      for (int nt = 0; nt < NNT; ++nt) accb[nt] += g_c[nt];
+    if (wv == NS - 1 && wid < d.VW) {  // the word rows ride along with the lightest slice
+      if (lane < d.wdim) atomicAdd(a.d_word_emb + (size_t)wid * d.wdim + lane, w0);
+      if (64 + lane < d.wdim) atomicAdd(a.d_word_emb + (size_t)wid * d.wdim + 64 + lane, w1);
+    }
+    w0 = w0n, w1 = w1n;
+    const float* Es = s_E[buf];
+    if constexpr (X3) {
+      bf4 Bh[NNT], Bl[NNT];
+#pragma unroll
+      for (int nt = 0; nt < NNT; ++nt) {
+        const unsigned gx = s_gx[buf][16 * nt + j], gh = gx & 0xffffu, gl = gx >> 16;
+        const int e = ap_c[nt] - 4 * q;  // the filter's arg-max position inside this lane's four (else: no contribution)
+        Bh[nt] = __builtin_bit_cast(bf4, u2{e == 0 ? gh : (e == 1 ? gh << 16 : 0u), e == 2 ? gh : (e == 3 ? gh << 16 : 0u)});
+        Bl[nt] = __builtin_bit_cast(bf4, u2{e == 0 ? gl : (e == 1 ? gl << 16 : 0u), e == 2 ? gl : (e == 3 ? gl << 16 : 0u)});
+      }
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) {
+        unsigned u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned w = __float_as_uint(Es[a0 + (e + mt) * CD]);
+          u[e] = a_ok ? w : 0u;
+        }
+        const bf4 Ah = __builtin_bit_cast(bf4, u2{(u[0] & 0xffffu) | (u[1] << 16), (u[2] & 0xffffu) | (u[3] << 16)});
+        const bf4 Al = __builtin_bit_cast(bf4, u2{(u[0] >> 16) | (u[1] & 0xffff0000u), (u[2] >> 16) | (u[3] & 0xffff0000u)});
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Ah, Bh[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Ah, Bl[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Al, Bh[nt], acc[mt][nt], 0, 0, 0);
+        }
+      }
+    } else
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      float av[NMT], bv[NNT];
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) {
+        const float v = Es[a0 + (4 * ks + mt) * CD];
+        av[mt] = a_ok ? v : 0.f;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NNT; ++nt) bv[nt] = ap_c[nt] == 4 * ks + q ? g_c[nt] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NNT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+    }
+    store_tok(buf ^ 1, e_q[0], g_q[0], ap_q[0], tok + step);  // (that buffer's readers finished before the last barrier)
+    __syncthreads();
+  }
+  // ---- the slab: tile (mt, nt), lane (j, q), element r: row l = 16 mt + 4 q + r = (tap mt, channel 4 q + r), filter f = 16 nt + j
+  const int KC = 5 * CD;
+  float* slab = a.slab + (size_t)blockIdx.x * ((size_t)KC * CW + CW + (size_t)d.VC * CD);
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NNT; ++nt) {
+      const int f = 16 * nt + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 4 * q + r;
+        if (c < nc && f < CW) slab[(size_t)(mt * CD + c0 + c) * CW + f] = acc[mt][nt][r];
+      }
+    }
+  if (wv == 0 && q == 0)
+#pragma unroll
+    for (int nt = 0; nt < NNT; ++nt)
+      if (16 * nt + j < CW) slab[(size_t)KC * CW + 16 * nt + j] = accb[nt];
+}
+template __global__ void embed_bwdw_filt_tok<100, 100, false>(EmbArgs);
+template __global__ void embed_bwdw_filt_tok<100, 100, true>(EmbArgs);
 
 // d char_emb of the wide shape on the matrix pipe (height 5, CW = 100 filters, W <= 16; any cdim in slices of EMBM_CS channels;
 // the counts below are those of 25-channel slices):
@@ -2240,9 +2456,14 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
     const int KC = d->height * d->cdim;
     if (FVTA_EMBW_CHAR_MFMA && d->cwdim == 100 && d->height == 5) {  // the matrix-pipe form
       constexpr int red_bytes = EMBM_NT * 7 * 64 * 16;
+      if (FVTA_EMBW_FILT_TOK && d->cdim == 100 && d->W <= 16 && d->wdim <= 128) {  // a workgroup per token, its waves the channel slices
+        if (FVTA_EMBW_F16X3) hipLaunchKernelGGL((embed_bwdw_filt_tok<100, 100, true>), dim3(blocks), dim3(448), 0, stream, a);
+        else hipLaunchKernelGGL((embed_bwdw_filt_tok<100, 100, false>), dim3(blocks), dim3(448), 0, stream, a);
+      } else {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_filt_mfma<100>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 red_bytes);
       hipLaunchKernelGGL(embed_bwdw_filt_mfma<100>, dim3((d->cdim + EMBM_CS - 1) / EMBM_CS, blocks), dim3(256), red_bytes, stream, a);
+      }
     } else
     hipLaunchKernelGGL(embed_bwdw_filt, dim3((KC + EMBW_KCH - 1) / EMBW_KCH, blocks), dim3(EMB_NT),
                        (size_t)d->W * d->cdim * sizeof(float), stream, a);

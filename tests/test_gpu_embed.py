@@ -63,7 +63,11 @@ def test_token_embed_forward_backward(B, J, W, cd, cw, wd, VW, VF, VC):
     op.backward(*args, cu(p["char_emb"]), filt, dx, dwe, dce, dfl, dbi)
     _close(dwe, p64["word_emb"].grad, atol=1e-4, msg="d word_emb")
     _close(dce, p64["char_emb"].grad, atol=1e-4, msg="d char_emb")
-    _close(dfl, p64["filt"].grad.reshape(5, cd, cw), atol=1e-4, msg="d filt")
+    # d filt of the wide shape (char_emb_size 100) runs on the bf16 matrix pipe with the three-term split of the bi-LSTM's
+    # bf16x3 engine (~2^-16 per product): that engine's bound -- rtol 1e-4 plus 3e-5 of the tensor's scale (a sum over every
+    # token of terms of that scale; tests/test_gpu_bf16.py) -- and never looser than the exact kernels' 1e-4
+    ref_dfl = p64["filt"].grad.reshape(5, cd, cw)
+    _close(dfl, ref_dfl, atol=max(1e-4, 3e-5 * float(ref_dfl.abs().max())) if cd > 8 else 1e-4, msg="d filt")
     _close(dbi, p64["bias"].grad, atol=1e-4, msg="d bias")
     assert p64["fixed"].grad is not None  # the oracle differentiates it; the library treats it as frozen (model_v2.py:590)
 
@@ -105,7 +109,8 @@ def test_token_embed_char_dropout(B, J, W, cd, cw, wd, VW, VF, VC):
     op.backward(*args, cu(p["char_emb"]), filt, dx, dwe, dce, dfl, dbi)
     _close(dwe, p64["word_emb"].grad, atol=1e-4, msg="d word_emb")
     _close(dce, p64["char_emb"].grad, atol=1e-4, msg="d char_emb")
-    _close(dfl, p64["filt"].grad.reshape(5, cd, cw), atol=1e-4, msg="d filt")
+    ref_dfl = p64["filt"].grad.reshape(5, cd, cw)    # (wide shape: the bf16x3 bound, see test_token_embed_forward_backward)
+    _close(dfl, ref_dfl, atol=max(1e-4, 3e-5 * float(ref_dfl.abs().max())) if cd > 8 else 1e-4, msg="d filt")
     _close(dbi, p64["bias"].grad, atol=1e-4, msg="d bias")
     # switched off again: the plain rows
     op.set_dropout(1.0, 0)
