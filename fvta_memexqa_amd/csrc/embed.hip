@@ -1191,6 +1191,9 @@ template __global__ void embed_fwdw_f16x3<100, 100, 2>(EmbArgs);
 #define FVTA_EMBW_ABL 0   // timing ablations of the wide backward kernels (results garbage): d filt 1 no MFMA, 2 no word-row atomics,
                           // 4 no character gather, 8 no gradient-row gather; d char_emb 16 no MFMA, 32 no fold / LDS adds, 64 no gathers
 #endif
+#ifndef FVTA_EMBW_CHAR_TOK
+#define FVTA_EMBW_CHAR_TOK 1   // d char_emb of the wide shape as a workgroup per token with the scatter on the matrix pipe
+#endif
 #ifndef FVTA_EMBW_FILT_TOK
 #define FVTA_EMBW_FILT_TOK 1   // d filt of the wide shape as a workgroup per token (0: a wave per (token, slice))
 #endif
@@ -1550,6 +1553,187 @@ __global__ __launch_bounds__(448, 1) void embed_bwdw_filt_tok(EmbArgs a) {
 }
 template __global__ void embed_bwdw_filt_tok<100, 100, false>(EmbArgs);
 template __global__ void embed_bwdw_filt_tok<100, 100, true>(EmbArgs);
+
+// d char_emb of the wide shape, a WORKGROUP per token, with NO transposed tile, NO 5-tap fold and NO LDS float adds (those three
+// were 3.7 of embed_bwdw_char_f16x3's 6.2 ms: -DFVTA_EMBW_ABL).  Two matrix products per token and 16-channel slice (wave):
+//  (1) dE[pos][c] = sum over (k, f) of Gs[pos][(k, f)] filt[k][c][f] with the SHIFTED one-hot Gs[pos][(k, f)] = g_f [argpos_f + k = pos]:
+//      the fold over the five taps is part of the contraction (K = 5 x 104: 17 k-steps of v_mfma_f32_16x16x32_f16 x 3, the fp16
+//      3-term split of embed_fwdw_f16x3; the slice's filter fragments in 136 registers for the launch).  Gs is the same for
+//      all seven slices: its fragments are built ONCE per token, k-steps dealt over the waves, and shared through LDS;
+//  (2) dChar[v][c] += sum_pos [ch[pos] = v] dE[pos][c]: the scatter into the character table as a product with the exact
+//      one-hot of the token's characters -- v_mfma_f32_16x16x16_f16, dE split (hi, lo') into two accumulators -- whose B operand
+//      is product (1)'s accumulator AS IT LIES (lane (c, q) holds positions 4 q .. 4 q + 3 in both layouts); the table slice
+//      [VC <= 128][16] stays in registers for the whole launch.
+// grid (blocks), 448 threads; slab part [KC cw + cw ..) of block x.
+template <int CW, int CD>
+__global__ __launch_bounds__(448, 1) void embed_bwdw_char_tok(EmbArgs a) {
+  constexpr int CS = 16, NS = (CD + CS - 1) / CS, FP = (CW + 7) / 8 * 8, KT = 5 * FP, NKS = (KT + 31) / 32, NVT = 8;
+  static_assert(NS == 7 && FP == 104 && NKS == 17, "seven slices of 16 channels, filters padded to 104 per tap");
+  typedef _Float16 half4v_ __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) char s_dyn_ct[];     // 2 x NKS x 2 x 64 x 16 bytes (68 KB: dynamic)
+  half8(*s_A)[NKS][2][64] = reinterpret_cast<half8(*)[NKS][2][64]>(s_dyn_ct);  // the shifted one-hot's fragments (hi, lo') of a token
+  // the last NBL low filter fragments of every wave live in LDS (read like the A fragments): with all 34 in registers the
+  // compiler spilled six of them to scratch and re-loaded them in the k loop behind s_waitcnt vmcnt(0)
+  constexpr int NBL = 7;
+  half8(*s_Bl)[NBL][64] = reinterpret_cast<half8(*)[NBL][64]>(s_dyn_ct + (size_t)2 * NKS * 2 * 64 * 16);  // [wave][NBL][64]
+  __shared__ __attribute__((aligned(16))) float s_g[2][FP + 8];
+  __shared__ __attribute__((aligned(16))) uint8_t s_ap[2][FP + 8];
+  __shared__ __attribute__((aligned(16))) int s_ch[3][16];
+  const fvta_embed_desc& d = a.d;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int W = d.W;
+  const int c0 = wv * CS, nc = min(CS, CD - c0);
+  // the slice's filter fragments: B[kappa = 32 ks + 8 q + e][n = j] = filt[k][c0 + j][f], (k, f) = (kappa / 104, kappa % 104)
+  half8 Bh[NKS], Bl[NKS - NBL];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int kap = 32 * ks + 8 * q, k = kap / FP, f0 = kap % FP;
+    const bool ok = k < 5 && j < nc;
+    const float* src = a.filt + (size_t)((ok ? k : 0) * CD + c0 + (j < nc ? j : 0)) * CW;
+    half2v h[4], l[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      const int fa = f0 + 2 * e2, fb = fa + 1;
+      const float ya = src[fa < CW ? fa : CW - 1], yb = src[fb < CW ? fb : CW - 1];   // unconditional, then a select
+      split_f16x2((ok && fa < CW) ? ya : 0.f, (ok && fb < CW) ? yb : 0.f, h[e2], l[e2]);
+    }
+    Bh[ks] = cat_h2(h[0], h[1], h[2], h[3]);
+    if (ks < NKS - NBL) Bl[ks] = cat_h2(l[0], l[1], l[2], l[3]);
+    else s_Bl[wv][ks - (NKS - NBL)][lane] = cat_h2(l[0], l[1], l[2], l[3]);
+  }
+  f32x4 tab[NVT];
+#pragma unroll
+  for (int mt = 0; mt < NVT; ++mt) tab[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 2 * (FP + 8); i += 448) {
+    (&s_g[0][0])[i] = 0.f;
+    (&s_ap[0][0])[i] = 255;
+  }
+  auto ctok = [&](int t) {  // (hidden from the uniformity analysis: see embed_fwdw_f16x3)
+    int c = t < d.ntok ? t : d.ntok - 1;
+    asm volatile("" : "+v"(c));
+    return c;
+  };
+  const int fcol = tid < CW ? tid : CW - 1, pcol = tid < W ? tid : W - 1;
+  // stage token `tok`'s gradient row, arg-max positions and characters (values already in registers)
+  auto stage = [&](int tokidx, float g, int ap, int ch) {
+    if (tid < CW) {
+      s_g[tokidx & 1][tid] = ap == 255 ? 0.f : g;
+      s_ap[tokidx & 1][tid] = (uint8_t)ap;
+    }
+    if (tid < 16) s_ch[tokidx % 3][tid] = tid < W ? ch : -1;
+  };
+  // build the fragments of the shifted one-hot of token `tokidx` (its g / ap staged before the last barrier): k-step ks by wave ks % 7
+  auto build = [&](int tokidx) {
+    const int b = tokidx & 1;
+#pragma unroll
+    for (int i = 0; i < (NKS + NS - 1) / NS; ++i) {
+      const int ks = wv + NS * i;
+      if (ks < NKS) {
+        const int kap = 32 * ks + 8 * q, k = kap / FP, f0 = kap % FP;   // (k = 5: the padding beyond 520 -- nothing matches)
+        const f32x4 G0 = *reinterpret_cast<const f32x4*>(&s_g[b][f0]), G1 = *reinterpret_cast<const f32x4*>(&s_g[b][f0 + 4]);
+        const uint2 Pw = *reinterpret_cast<const uint2*>(&s_ap[b][f0]);
+        half2v h[4], l[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+          const unsigned pw = e2 < 2 ? Pw.x : Pw.y;
+          const int pa = (int)((pw >> (16 * (e2 & 1))) & 255u), pb = (int)((pw >> (16 * (e2 & 1) + 8)) & 255u);
+          const float ga = e2 < 2 ? G0[2 * e2] : G1[2 * e2 - 4], gb = e2 < 2 ? G0[2 * e2 + 1] : G1[2 * e2 - 3];
+          split_f16x2((k < 5 && pa + k == j) ? ga : 0.f, (k < 5 && pb + k == j) ? gb : 0.f, h[e2], l[e2]);
+        }
+        s_A[b][ks][0][lane] = cat_h2(h[0], h[1], h[2], h[3]);
+        s_A[b][ks][1][lane] = cat_h2(l[0], l[1], l[2], l[3]);
+      }
+    }
+  };
+  const int step = gridDim.x;
+  int tok = blockIdx.x;
+  // prefetch queue: entry i = token tok + (2 + i) step (tokens tok and tok + step are staged in the prologue)
+  constexpr int PD = 2;
+  auto fetch = [&](int t, int64_t off, float& g, int& ap, int& ch) {
+    g = a.dx[off + fcol];
+    ap = a.argpos[(size_t)ctok(t) * CW + fcol];
+    ch = a.char_ids[(size_t)ctok(t) * W + pcol];
+  };
+  float g_q[PD];
+  int ap_q[PD], ch_q[PD];
+  int64_t off_q[PD + 1];
+  {
+    float g0, g1;
+    int ap0, ap1, ch0, ch1;
+    fetch(tok, a.tok_off[ctok(tok)], g0, ap0, ch0);
+    fetch(tok + step, a.tok_off[ctok(tok + step)], g1, ap1, ch1);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) fetch(tok + (2 + i) * step, a.tok_off[ctok(tok + (2 + i) * step)], g_q[i], ap_q[i], ch_q[i]);
+    off_q[PD] = a.tok_off[ctok(tok + (2 + PD) * step)];
+    __syncthreads();  // the fills
+    stage(0, g0, ap0, ch0);
+    stage(1, g1, ap1, ch1);
+    __syncthreads();
+    build(0);
+    __syncthreads();
+  }
+  for (int it = 0; tok < d.ntok; tok += step, ++it) {
+    const int buf = it & 1;
+    // the queue moves up: its head is token it + 2, staged at the end of this iteration
+    const float g_s = g_q[0];
+    const int ap_s = ap_q[0], ch_s = ch_q[0];
+#pragma unroll
+    for (int i = 0; i + 1 < PD; ++i) g_q[i] = g_q[i + 1], ap_q[i] = ap_q[i + 1], ch_q[i] = ch_q[i + 1];
+    fetch(tok + (2 + PD) * step, off_q[PD], g_q[PD - 1], ap_q[PD - 1], ch_q[PD - 1]);   // (its row address: requested a token ago)
+    off_q[PD] = a.tok_off[ctok(tok + (3 + PD) * step)];
+    // ---- (1) dE[pos = 4 q + r][c = j]
+    f32x4 aT = {0.f, 0.f, 0.f, 0.f}, aX = {0.f, 0.f, 0.f, 0.f}, aY = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const half8 Ah = s_A[buf][ks][0][lane], Al = s_A[buf][ks][1][lane];
+      aT = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh[ks], aT, 0, 0, 0);
+      half8 bl;
+      if constexpr (true) {
+        if (ks < NKS - NBL) bl = Bl[ks < NKS - NBL ? ks : 0];
+        else bl = s_Bl[wv][ks >= NKS - NBL ? ks - (NKS - NBL) : 0][lane];
+      }
+      aX = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, bl, aX, 0, 0, 0);
+      aY = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh[ks], aY, 0, 0, 0);
+      if (ks & 1) __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist all 34 fragment reads: 136 registers, spills)
+    }
+    f32x4 dE = aT + (aX + aY) * (1.f / 2048.f);
+    if (a.drop_thr != 0ull)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dE[r] *= emb_ks(a, tok, (4 * q + r) * CD + c0 + (j < nc ? j : 0), W * CD);
+    // ---- (2) the scatter: table[v][c] += sum_pos [ch[pos] = v] dE[pos][c]
+    half2v h0, l0, h1, l1;
+    split_f16x2(dE[0], dE[1], h0, l0);
+    split_f16x2(dE[2], dE[3], h1, l1);
+    const half4v_ Eh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3), El = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
+    const int4 chq = *reinterpret_cast<const int4*>(&s_ch[it % 3][4 * q]);   // the characters at positions 4 q .. 4 q + 3
+#pragma unroll
+    for (int mt = 0; mt < NVT; ++mt) {
+      const int v = 16 * mt + j;
+      const half4v_ oh = {(_Float16)(chq.x == v ? 1.f : 0.f), (_Float16)(chq.y == v ? 1.f : 0.f), (_Float16)(chq.z == v ? 1.f : 0.f),
+                          (_Float16)(chq.w == v ? 1.f : 0.f)};
+      // (the low half through a temporary: a second table of 32 registers spilled the filter fragments)
+      const f32x4 lo = __builtin_amdgcn_mfma_f32_16x16x16f16(oh, El, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      tab[mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(oh, Eh, tab[mt], 0, 0, 0);
+      tab[mt] += lo * (1.f / 2048.f);
+    }
+    // ---- the next tokens: fragments of token it + 1 (staged before the last barrier), staging of token it + 2
+    build(it + 1);
+    stage(it + 2, g_s, ap_s, ch_s);
+    __syncthreads();
+  }
+  // ---- the slab: table tile mt, lane (c = j, q), element r: character v = 16 mt + 4 q + r
+  const int KC = 5 * CD;
+  float* slab_c = a.slab + (size_t)blockIdx.x * ((size_t)KC * CW + CW + (size_t)d.VC * CD) + (size_t)KC * CW + CW;
+#pragma unroll
+  for (int mt = 0; mt < NVT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int v = 16 * mt + 4 * q + r;
+      if (v < d.VC && j < nc) slab_c[(size_t)v * CD + c0 + j] = tab[mt][r];
+    }
+}
+template __global__ void embed_bwdw_char_tok<100, 100>(EmbArgs);
 
 // d char_emb of the wide shape on the matrix pipe (height 5, CW = 100 filters, W <= 16; any cdim in slices of EMBM_CS channels;
 // the counts below are those of 25-channel slices):
@@ -2471,7 +2655,12 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
     if (FVTA_EMBW_CHAR_MFMA && d->cwdim == 100 && d->height == 5 && tabm <= 112 * 1024) {  // the matrix-pipe form
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char_mfma<100>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)tabm);
-      if (FVTA_EMBW_F16X3) {
+      if (FVTA_EMBW_F16X3 && FVTA_EMBW_CHAR_TOK && d->cdim == 100 && d->W <= 16 && d->VC <= 128) {
+        constexpr int frag_bytes = 2 * 17 * 2 * 64 * 16 + 7 * 7 * 64 * 16;  // the A fragments (two tokens) + the waves' low filter fragments
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char_tok<100, 100>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  frag_bytes);
+        hipLaunchKernelGGL((embed_bwdw_char_tok<100, 100>), dim3(blocks), dim3(448), frag_bytes, stream, a);  // a workgroup per token
+      } else if (FVTA_EMBW_F16X3) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char_f16x3<100>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)tabm);
         hipLaunchKernelGGL(embed_bwdw_char_f16x3<100>, dim3((d->cdim + EMBM_CS - 1) / EMBM_CS, blocks), dim3(256), tabm, stream, a);
