@@ -7,6 +7,11 @@
 #include "fvta_common.h"
 #include "gemm_f32.h"
 #include "attn_fwd_shared.h"  // split_f16x2: the fp16 (hi, lo') split of an fp32 value
+#ifndef FVTA_EMBW_ABL
+#define FVTA_EMBW_ABL 0   // timing ablations of the wide backward kernels (results garbage): d filt 1 no MFMA, 2 no word-row atomics,
+                          // 4 no character gather, 8 no gradient-row gather; d char_emb 16 no MFMA, 32 no fold / LDS adds, 64 no gathers, 128 no adds;
+                          // forward (f16x3) 256 no k loop, 512 no staging stores, 1024 no barrier
+#endif
 
 namespace fvta {
 
@@ -1112,7 +1117,7 @@ __global__ __launch_bounds__(64 * ((((CW + 15) / 16) + SPW - 1) / SPW), 1) void 
     const _Float16* ah = &s_hi[buf][j * CD + 8 * q];  // window position p = j
     const _Float16* al = &s_lo[buf][j * CD + 8 * q];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
+    for (int ks = 0; ks < ((FVTA_EMBW_ABL & 256) ? 0 : NKS); ++ks) {
       // (8-byte aligned: 2 (100 p + 32 ks + 8 q) bytes); ONE read of the A fragments feeds the wave's SPW slices
       const half4v h0 = *reinterpret_cast<const half4v*>(ah + 32 * ks), h1 = *reinterpret_cast<const half4v*>(ah + 32 * ks + 4);
       const half4v l0 = *reinterpret_cast<const half4v*>(al + 32 * ks), l1 = *reinterpret_cast<const half4v*>(al + 32 * ks + 4);
@@ -1159,8 +1164,8 @@ __global__ __launch_bounds__(64 * ((((CW + 15) / 16) + SPW - 1) / SPW), 1) void 
     if (tid < d.wdim) row[CW + tid] = w_cur;  // the word part of the row (wdim <= threads: the launcher's condition -- a copy
                                               // loop here made the compiler drain every prefetch at the end of each token)
     w_cur = w_nxt;
-    store_E(buf ^ 1, e_n, tok + step);  // (that buffer's readers finished before the barrier that ended the previous token)
-    __syncthreads();
+    if constexpr (!(FVTA_EMBW_ABL & 512)) store_E(buf ^ 1, e_n, tok + step);  // (that buffer's readers finished before the barrier that ended the previous token)
+    if constexpr (!(FVTA_EMBW_ABL & 1024)) __syncthreads();
   }
 }
 template __global__ void embed_fwdw_f16x3<100, 100, 1>(EmbArgs);
@@ -1186,10 +1191,6 @@ template __global__ void embed_fwdw_f16x3<100, 100, 2>(EmbArgs);
 #ifndef FVTA_EMBW_SPW
 #define FVTA_EMBW_SPW 1     // filter slices per wave of embed_fwdw_f16x3: 1 = seven waves (2.6 ms at the published flag set), 2 = four
                             // waves with half the LDS reads but one wave per SIMD (3.3 ms: the kernel is not LDS-bound)
-#endif
-#ifndef FVTA_EMBW_ABL
-#define FVTA_EMBW_ABL 0   // timing ablations of the wide backward kernels (results garbage): d filt 1 no MFMA, 2 no word-row atomics,
-                          // 4 no character gather, 8 no gradient-row gather; d char_emb 16 no MFMA, 32 no fold / LDS adds, 64 no gathers
 #endif
 #ifndef FVTA_EMBW_CHAR_TOK
 #define FVTA_EMBW_CHAR_TOK 1   // d char_emb of the wide shape as a workgroup per token with the scatter on the matrix pipe
