@@ -1427,7 +1427,13 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16(AttnFwdArgs a, int G_a
     // a partner that never arrives is a bug (a wedged wave).  The trap aborts the queue -- on ROCm that usually ends the
     // process, it is NOT a recoverable launch error -- which is still better than folding stale partials into amax /
     // jmax / h_a and training on them
-    if (!arrived) __builtin_trap();
+    if (!arrived) {
+      if (a.fault) {  // (host-mapped: visible to the host once the system-scope fence has drained)
+        __hip_atomic_store(a.fault, (int)ATTN_FAULT_PAIR_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+      }
+      __builtin_trap();
+    }
     // acquire: the partner's published area (plain LDS loads below) is read only after the poll has matched; workgroup
     // scope lowers to s_waitcnt lgkmcnt(0) and, unlike an empty asm, is a compiler fence for __shared__ accesses too
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1894,6 +1900,29 @@ extern "C" int fvta_attn_kernel_select(int32_t exact, int32_t wave16) {
   return FVTA_OK;
 }
 
+// The fault word of the forward kernels (attn_fwd_shared.h): four bytes of pinned, device-mapped host memory, allocated once.
+static int* g_attn_fault_host = nullptr;
+int* fvta::attn_fault_word() {
+  static int* dev = [] {
+    int* h = nullptr;
+    int* d = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h), sizeof(int), hipHostMallocMapped) != hipSuccess) return (int*)nullptr;
+    *h = 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0) != hipSuccess) return (int*)nullptr;
+    g_attn_fault_host = h;
+    return d;
+  }();
+  return dev;
+}
+// what an earlier launch left there (read without synchronising: reported by the first call that sees it)
+static int attn_check_fault() {
+  if (g_attn_fault_host && *reinterpret_cast<volatile int*>(g_attn_fault_host) == ATTN_FAULT_PAIR_WAIT) {
+    fvta_set_error("attn_fwd_pair16: a wave's partner never arrived at the tile hand-shake (the kernel trapped); results of that launch are invalid");
+    return FVTA_ERR_LAUNCH;
+  }
+  return FVTA_OK;
+}
+
 int fvta_attn_check_desc(const fvta_attn_desc* d) {
   FVTA_CHECK_ARG(d != nullptr, "attn: null descriptor");
   FVTA_CHECK_ARG(d->N > 0 && d->K > 0 && d->K <= 64 && d->T > 0, "attn: bad N/K/T (%d,%d,%d), need K<=64", d->N, d->K,
@@ -1960,6 +1989,7 @@ static int attn_fwd_impl(const fvta_attn_desc* d, const float* hinfo, const uint
                          const uint8_t* qmask, const float* W, const float* b, const float* tscale, float* h_a,
                          float* a_logits, void* saved, void* workspace, fvta_stream_t stream_) {
   if (int e = fvta_attn_check_desc(d)) return e;
+  if (int e = attn_check_fault()) return e;
   FVTA_CHECK_ARG((hinfo || table) && hq && h_a && saved && workspace, "attn_fwd: null pointer");
   FVTA_CHECK_ARG(d->simi == 4 || (W && b), "attn_fwd: W and b required for simiMatrix 1-3");
   FVTA_CHECK_ARG(!(tscale && d->hinfo_stride), "attn_fwd: tscale with a strided hinfo is not supported");
@@ -1996,6 +2026,7 @@ static int attn_fwd_impl(const fvta_attn_desc* d, const float* hinfo, const uint
   a.hstride = d->hinfo_stride ? (size_t)d->hinfo_stride : (size_t)s.T * s.w;
   a.ipw = 1;
   a.wgtab = nullptr;
+  a.fault = attn_fault_word();
   a.dbg = fvta_diag_env("FVTA_ATTN_DBG", 0);  // -DFVTA_DIAG builds only
   // (the phase stamps land 32 MiB into the workspace: only where the workspace reaches that far)
   if ((a.dbg & 16) && fvta_attn_workspace_bytes(d) < ((size_t)32 << 20) + 64 * 16 * 8) a.dbg &= ~16;

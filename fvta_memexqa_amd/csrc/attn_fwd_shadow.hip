@@ -218,7 +218,13 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_pair16h(AttnFwdArgs a, int G_
       }
       __builtin_amdgcn_s_sleep(2);
     }
-    if (!arrived) __builtin_trap();  // (a wedged partner wave: see attn_fwd_pair16)
+    if (!arrived) {  // (a wedged partner wave: see attn_fwd_pair16)
+      if (a.fault) {
+        __hip_atomic_store(a.fault, (int)ATTN_FAULT_PAIR_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+      }
+      __builtin_trap();
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   };
   auto post_flag = [&](int* flag, int v) {

@@ -71,6 +71,12 @@ struct AttnFwdArgs {
   int dbg;          // FVTA_ATTN_DBG experiment bits (diagnostics only)
   size_t hstride;   // elements between the row blocks of consecutive (n,k): T*w, or fvta_attn_desc.hinfo_stride (K == 1)
   const uint32_t* wgtab;  // pair kernel: workgroup -> n | g << 16 | G_n << 24 (attn_balance_kernel), null: G workgroups for every n
+  int* fault;             // host-mapped status word (attn_fault_word): a kernel that has to trap says why first
 };
+
+// Fault codes a forward kernel leaves in AttnFwdArgs::fault before it traps: the trap aborts the queue -- a process that
+// survives it (or the next call, whichever comes first) reads the word and reports instead of "unspecified launch failure".
+enum { ATTN_FAULT_PAIR_WAIT = 1 };
+int* attn_fault_word();   // attn_fwd.hip: the word (device-visible address of host memory), null if it cannot be had
 
 }  // namespace fvta

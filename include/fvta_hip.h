@@ -99,7 +99,7 @@ int fvta_attn_bwd(const fvta_attn_desc* d, const float* hinfo, const float* hq, 
  * context tensor is the concatenation of the two directions' outputs the bi-LSTM has already written as bf16):
  * table [2][N*K*T] device addresses, table[half][(n K + k) T + t] -> the w/2 bf16 values that are channels
  * half * w/2 .. of row (n,k,t) (fvta_lstm_shadow_rows; EVERY entry must be readable: rows no encoder writes point at
- * w/2 zeros).  JQ <= 32, w = 512 or 1024, simiMatrix 1-3, no hinfo_stride, no a_logits; FVTA_ERR_ARG otherwise.  Results
+ * w/2 zeros).  JQ <= 32, w = 512 or 1024, simiMatrix 1-3, no hinfo_stride, no a_logits; FVTA_ERR_INVALID_ARG otherwise.  Results
  * are those of fvta_attn_fwd / fvta_attn_bwd run on the bf16-rounded rows.  `saved` / `workspace` sizes as above. */
 int fvta_attn_fwd_shadow(const fvta_attn_desc* d, const uint64_t* table, const float* hq, const uint8_t* hmask,
                          const uint8_t* qmask, const float* W, const float* b, float* h_a, void* saved, void* workspace,
