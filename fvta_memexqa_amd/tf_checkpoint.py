@@ -140,32 +140,69 @@ def _gf2_apply(cols, v):
     return r
 
 
+_SHIFT_CACHE = {}
+
+
+def _shift_tables(L):
+    """the operator "advance the crc register over L zero bytes" as four 256-entry tables (one zero byte, then
+    square-and-multiply on L); cached per chunk length -- a checkpoint's tensors repeat a handful of sizes"""
+    t = _SHIFT_CACHE.get(L)
+    if t is None:
+        one = [_crc_raw(b"\0", 1 << i) for i in range(32)]
+        op, sq, e = [1 << i for i in range(32)], one, L
+        while e:
+            if e & 1:
+                op = [_gf2_apply(sq, col) for col in op]
+            sq = [_gf2_apply(sq, col) for col in sq]
+            e >>= 1
+        t = [[_gf2_apply(op, b << (8 * k)) for b in range(256)] for k in range(4)]
+        if len(_SHIFT_CACHE) < 64:
+            _SHIFT_CACHE[L] = t
+    return t
+
+
+def _native_crc32c():
+    """a C implementation when one is importable (crc32c / google_crc32c: neither is in this image): (data, crc) -> crc"""
+    try:
+        import crc32c as _m
+        return lambda data, crc: _m.crc32c(data, crc)
+    except Exception:
+        pass
+    try:
+        import google_crc32c as _g
+        return lambda data, crc: _g.extend(crc, bytes(data))
+    except Exception:
+        return None
+
+
+_NATIVE = _native_crc32c()
+
+
 def crc32c(data, crc=0):
     """CRC-32C (Castagnoli) of `data`, continuing from `crc`.  Long buffers (a checkpoint's LSTM kernels and optimiser
     slots are tens of MB) are cut into 4096 equal chunks whose registers advance TOGETHER, one numpy table lookup per
     byte position, and are then folded left to right: the register is linear over GF(2), so
     reg(A || B) = shift_len(B)(reg(A)) xor reg_0(B), with the shift by a chunk's length as four 256-entry tables."""
     import numpy as np
-    buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data.view(np.uint8).reshape(-1)
+    if isinstance(data, np.ndarray):
+        buf = np.ascontiguousarray(data).view(np.uint8).reshape(-1)      # (no copy when it is contiguous already)
+    else:
+        buf = np.frombuffer(data, dtype=np.uint8)                        # bytes / bytearray / memoryview: no copy
+    if _NATIVE is not None:
+        return _NATIVE(buf, crc)
     n, lanes = buf.size, 4096
     c = crc ^ 0xFFFFFFFF
     if n < 64 * lanes:
         return _crc_raw(buf.tobytes(), c) ^ 0xFFFFFFFF
     L = n // lanes
     tbl = np.array(_crc_table(), dtype=np.uint32)
-    body = buf[:L * lanes].reshape(lanes, L)
+    # byte position i of every lane as ONE contiguous row (a column of the [lanes, L] view is a 4096-element strided gather
+    # per step: the transposed copy is a single pass)
+    body = np.ascontiguousarray(buf[:L * lanes].reshape(lanes, L).T)
     reg = np.zeros(lanes, dtype=np.uint32)
     for i in range(L):                      # every lane's register from 0 over its own chunk
-        reg = tbl[(reg ^ body[:, i]) & 0xFF] ^ (reg >> np.uint32(8))
-    # the operator "advance the register over L zero bytes": one zero byte, then square-and-multiply on L
-    one = [_crc_raw(b"\0", 1 << i) for i in range(32)]
-    op, sq, e = [1 << i for i in range(32)], one, L
-    while e:
-        if e & 1:
-            op = [_gf2_apply(sq, col) for col in op]
-        sq = [_gf2_apply(sq, col) for col in sq]
-        e >>= 1
-    shift = [[_gf2_apply(op, b << (8 * k)) for b in range(256)] for k in range(4)]
+        reg = tbl[(reg ^ body[i]) & 0xFF] ^ (reg >> np.uint32(8))
+    shift = _shift_tables(L)
     for r in reg.tolist():
         c = shift[0][c & 0xFF] ^ shift[1][(c >> 8) & 0xFF] ^ shift[2][(c >> 16) & 0xFF] ^ shift[3][c >> 24] ^ r
     return _crc_raw(buf[L * lanes:].tobytes(), c) ^ 0xFFFFFFFF
