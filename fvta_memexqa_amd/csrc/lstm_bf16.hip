@@ -285,8 +285,11 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
   float* __restrict__ dcs = a.dc + (size_t)dir * a.B * d;
   // (pinned in scalar registers: the compiler re-loaded the kernel argument in front of every pass's stores -- 32 scalar
   //  loads per wave tile, each behind an s_waitcnt lgkmcnt(0))
-  bf16_t* dz_base = a.dzb + trow * (size_t)K;
+  // (as an INTEGER: an asm on the pointer itself makes it a generic pointer, and the stores through it FLAT instructions --
+  //  which count on lgkmcnt too, so that every wave_sync of the epilogue waited for the dz stores)
+  unsigned long long dz_base = (unsigned long long)reinterpret_cast<uintptr_t>(a.dzb + trow * (size_t)K);
   asm volatile("" : "+s"(dz_base));
+  typedef f32x4 __attribute__((address_space(1)))* gf4_ptr;
   auto wave_sync = [] {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -389,14 +392,19 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
       dco[e] = dc * fg;
     }
     if (i < nact && u < d && (!(abl & 2) || dco[0] == 1234.5f)) {
-      float* zp = reinterpret_cast<float*>(dz_base + (size_t)i * K + 4 * u);
-      st16(zp, __builtin_bit_cast(f32x4, za), (ntb & 2) != 0);
-      st16(zp + 4, __builtin_bit_cast(f32x4, zb), (ntb & 2) != 0);
-      if constexpr (XM == 3) {  // (hi, lo, hi) thirds of 4d bf16 = 2d floats
-        *reinterpret_cast<f32x4*>(zp + 2 * d) = __builtin_bit_cast(f32x4, la);
-        *reinterpret_cast<f32x4*>(zp + 2 * d + 4) = __builtin_bit_cast(f32x4, lb);
-        *reinterpret_cast<f32x4*>(zp + 4 * d) = __builtin_bit_cast(f32x4, za);
-        *reinterpret_cast<f32x4*>(zp + 4 * d + 4) = __builtin_bit_cast(f32x4, zb);
+      const gf4_ptr zp = (gf4_ptr)(dz_base + ((size_t)i * K + 4 * u) * sizeof(bf16_t));   // (16-byte units below)
+      if ((ntb & 2) != 0) {
+        __builtin_nontemporal_store(__builtin_bit_cast(f32x4, za), zp);
+        __builtin_nontemporal_store(__builtin_bit_cast(f32x4, zb), zp + 1);
+      } else {
+        zp[0] = __builtin_bit_cast(f32x4, za);
+        zp[1] = __builtin_bit_cast(f32x4, zb);
+      }
+      if constexpr (XM == 3) {  // (hi, lo, hi) thirds of 4d bf16 = 2d floats = d / 2 sixteen-byte units
+        zp[d / 2] = __builtin_bit_cast(f32x4, la);
+        zp[d / 2 + 1] = __builtin_bit_cast(f32x4, lb);
+        zp[d] = __builtin_bit_cast(f32x4, za);
+        zp[d + 1] = __builtin_bit_cast(f32x4, zb);
       }
       st16(dcs + (size_t)i * d + u, dco, (ntb & 4) != 0);
     }
