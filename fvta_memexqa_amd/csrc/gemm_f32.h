@@ -42,10 +42,13 @@ struct MmaF32 {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  // one BK-deep tile from LDS images As[BK][LDA], Bs[BK][LDB]
-  __device__ __forceinline__ void compute(const float* __restrict__ As, const float* __restrict__ Bs) {
-    const float* ap = As + hf * LDA + wm * (TM * 32) + l31;
-    const float* bp = Bs + hf * LDB + wn * (TN * 32) + l31;
+  // one BK-deep tile from LDS images As[BK][LDA], Bs[BK][LDB].  (LDS-typed pointers: picked out of an array of generic
+  // `float*` by the buffer index, the images were read with FLAT loads -- through the address-space check, and counted on
+  // vmcnt as well as lgkmcnt)
+  typedef float __attribute__((address_space(3))) lds_f;
+  __device__ __forceinline__ void compute(const lds_f* __restrict__ As, const lds_f* __restrict__ Bs) {
+    const lds_f* ap = As + hf * LDA + wm * (TM * 32) + l31;
+    const lds_f* bp = Bs + hf * LDB + wn * (TN * 32) + l31;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
@@ -86,12 +89,15 @@ struct StageKContig {
       if (UNITS % NT == 0 || u < UNITS) {
         bool ok;
         const float* src = f(u / (BK / 4), k0 + (u % (BK / 4)) * 4, ok);
-        const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+        // (every staging source is global memory; said explicitly: the address-provider lambdas return generic pointers, and
+        //  through those the loads were FLAT instructions -- which count on lgkmcnt too, so every wait for an LDS operand of
+        //  the k-loop also waited for the next tile's global loads)
+        const f32x4 t = *(const f32x4 __attribute__((address_space(1)))*)(uintptr_t)src;
         v[p] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   }
-  __device__ __forceinline__ void store(float* lds, int tid) const {
+  __device__ __forceinline__ void store(float __attribute__((address_space(3)))* lds, int tid) const {
 #pragma unroll
     for (int p = 0; p < PER; ++p) {
       const int u = tid + p * NT;
@@ -118,17 +124,20 @@ struct StageMNContig {
       if (UNITS % NT == 0 || u < UNITS) {
         bool ok;
         const float* src = f(k0 + u / (COLS / 4), (u % (COLS / 4)) * 4, ok);
-        const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+        // (every staging source is global memory; said explicitly: the address-provider lambdas return generic pointers, and
+        //  through those the loads were FLAT instructions -- which count on lgkmcnt too, so every wait for an LDS operand of
+        //  the k-loop also waited for the next tile's global loads)
+        const f32x4 t = *(const f32x4 __attribute__((address_space(1)))*)(uintptr_t)src;
         v[p] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   }
-  __device__ __forceinline__ void store(float* lds, int tid) const {
+  __device__ __forceinline__ void store(float __attribute__((address_space(3)))* lds, int tid) const {
 #pragma unroll
     for (int p = 0; p < PER; ++p) {
       const int u = tid + p * NT;
       if (UNITS % NT == 0 || u < UNITS)
-        *reinterpret_cast<f32x4*>(&lds[(u / (COLS / 4)) * LD + (u % (COLS / 4)) * 4]) = v[p];
+        *reinterpret_cast<f32x4 __attribute__((address_space(3)))*>(&lds[(u / (COLS / 4)) * LD + (u % (COLS / 4)) * 4]) = v[p];
     }
   }
 };
@@ -139,13 +148,15 @@ struct StageMNContig {
 template <class Mma, class SA, class SB, class FA, class FB>
 __device__ __forceinline__ void gemm_mainloop(Mma& mma, SA& sa, SB& sb, FA&& fa, FB&& fb, int k_begin,
                                               int k_end, float* smem, int tid) {
-  float* As[2] = {smem, smem + Mma::A_FLOATS};
-  float* Bs[2] = {smem + 2 * Mma::A_FLOATS, smem + 2 * Mma::A_FLOATS + Mma::B_FLOATS};
+  typedef float __attribute__((address_space(3))) lds_f;
+  lds_f* const base = (lds_f*)smem;  // (the two images of A, then the two of B: addressed by the buffer index, typed as LDS)
+  auto As = [&](int b) { return base + b * Mma::A_FLOATS; };
+  auto Bs = [&](int b) { return base + 2 * Mma::A_FLOATS + b * Mma::B_FLOATS; };
   if (k_begin >= k_end) return;
   sa.fetch(fa, k_begin, tid);
   sb.fetch(fb, k_begin, tid);
-  sa.store(As[0], tid);
-  sb.store(Bs[0], tid);
+  sa.store(As(0), tid);
+  sb.store(Bs(0), tid);
   __syncthreads();
   int cur = 0;
   for (int k0 = k_begin; k0 < k_end; k0 += Mma::BK) {
@@ -154,10 +165,10 @@ __device__ __forceinline__ void gemm_mainloop(Mma& mma, SA& sa, SB& sb, FA&& fa,
       sa.fetch(fa, k0 + Mma::BK, tid);
       sb.fetch(fb, k0 + Mma::BK, tid);
     }
-    mma.compute(As[cur], Bs[cur]);
+    mma.compute(As(cur), Bs(cur));
     if (more) {
-      sa.store(As[cur ^ 1], tid);
-      sb.store(Bs[cur ^ 1], tid);
+      sa.store(As(cur ^ 1), tid);
+      sb.store(Bs(cur ^ 1), tid);
     }
     __syncthreads();
     cur ^= 1;

@@ -887,7 +887,7 @@ __global__ __launch_bounds__(256) void rows_from_shadow_kernel(const unsigned lo
   const int64_t row = blockIdx.x;
   for (int c = threadIdx.x; c < 2 * d; c += blockDim.x) {
     const int dir = c / d;
-    const bf16_t* p = reinterpret_cast<const bf16_t*>((uintptr_t)table[(size_t)dir * nrows + row]);
+    const bf16_t __attribute__((address_space(1)))* p = (const bf16_t __attribute__((address_space(1)))*)table[(size_t)dir * nrows + row];  // (global, not flat)
     out[row * out_ld + c] = bf2f(p[c - dir * d]);
   }
 }
