@@ -534,23 +534,17 @@ static int wreg_cus() {
 // FVTA_LSTM_WREG (A/B measurements): bit 0 the weights-stationary forward, bit 1 the weights-stationary backward of steps
 // with few rows, bit 2 the pipelined weights-stationary backward (d = 512, every row count); default 7, 0: the tiled step
 // kernels for every shape
-// bit 3: the eight-wave K-split forward (lstm_wreg8.hip) for the shapes it is built for
-#ifndef FVTA_WREG_DEFAULT_MODE
-#define FVTA_WREG_DEFAULT_MODE 7
-#endif
-bool wreg8_shape(int in_i, int d);                                 // lstm_wreg8.hip
-bool launch_step_fwd_wreg8(const StepArgs& a, hipStream_t s);
 static int g_wreg_override = -1;  // fvta_lstm_kernel_select (tests, A/B measurements)
 int wreg_mode() {
   static const int env_mode = [] {
     const char* e = getenv("FVTA_LSTM_WREG");
-    return (e && e[0] >= '0' && e[0] <= '9') ? (atoi(e) & 15) : FVTA_WREG_DEFAULT_MODE;
+    return (e && e[0] >= '0' && e[0] <= '7') ? e[0] - '0' : 7;
   }();
   return g_wreg_override >= 0 ? g_wreg_override : env_mode;
 }
 int wreg_set_mode(int mode) {
   const int prev = wreg_mode();
-  g_wreg_override = mode < 0 ? -1 : (mode & 15);
+  g_wreg_override = mode < 0 ? -1 : (mode & 7);
   return prev;
 }
 
@@ -558,7 +552,6 @@ int wreg_nct(int in_i, int d) {
   if (!(wreg_mode() & 1)) return 0;
   const int nx = in_i / 16, nd = d / 16;
   if (in_i % 16 || d % 128) return 0;
-  if ((wreg_mode() & 8) && wreg8_shape(in_i, d)) return 1;  // (its weight shadow: 32 columns per wave)
   if (nd == 32 && (nx == 14 || nx == 8)) return 2;
   if (nd == 64 && (nx == 14 || nx == 8)) return 1;
   if (nd == 8 && (nx == 8 || nx == 2)) return 2;
@@ -595,7 +588,6 @@ bool launch_step_fwd_wreg(const StepArgs& a, hipStream_t s) {
   const int nct = wreg_nct(in_i, a.d);
   if (!nct || !a.Wf[0] || !a.hs) return false;
   const int nx = in_i / 16, nd = a.d / 16;
-  if ((wreg_mode() & 8) && launch_step_fwd_wreg8(a, s)) return true;
   if (nd == 32 && nx == 14) launch_wreg<WregCfg<14, 32, 2>>(a, s);
   else if (nd == 32 && nx == 8) launch_wreg<WregCfg<8, 32, 2>>(a, s);
   else if (nd == 64 && nx == 14) launch_wreg<WregCfg<14, 64, 1>>(a, s);
