@@ -39,3 +39,7 @@ s_ms, s_n = collect(2)
 print("lib=%s WREG=%s: step %.3f ms (%d launches, %.1f us each)  dx %.3f  dW %.3f  wall %.3f  finite %s" % (
     os.path.basename(os.environ.get("FVTA_LIB_PATH", "product")), os.environ.get("FVTA_LSTM_WREG", "-"), s_ms, s_n,
     1e3 * s_ms / max(1, s_n), collect(6)[0], collect(3)[0], wall, bool(torch.isfinite(dk).all())))
+# (dk accumulates over the 7 calls above; the checksum identifies the weight-gradient kernel's result bit by bit)
+print("dk sum %.10e  abs %.10e  db sum %.10e" % (dk.double().sum().item(), dk.double().abs().sum().item(), db.double().sum().item()))
+if os.environ.get("FVTA_AB_SAVE"): torch.save(dk.cpu(), "/tmp/lstm_bwd_ab_dk_%s.pt" % os.environ["FVTA_AB_SAVE"])
+if os.environ.get("FVTA_AB_CMP"): print("dk bitwise equal to %s: %s" % (os.environ["FVTA_AB_CMP"], torch.equal(dk.cpu(), torch.load("/tmp/lstm_bwd_ab_dk_%s.pt" % os.environ["FVTA_AB_CMP"]))))
