@@ -14,7 +14,8 @@ k = (torch.rand(din + d, 4 * d, device="cuda", generator=g) * 2 - 1) * 0.05
 b = torch.randn(4 * d, device="cuda", generator=g) * 0.1
 ar = torch.arange(B, dtype=torch.int64)
 op = ops.BiLstm(B, J, din, d, ar * J * din, ar * J * 2 * d, torch.full((B,), J, dtype=torch.int32), 2 * d,
-                share_fw_bw=True, precision=1, training=True)
+                share_fw_bw=True, precision=1, training=True,
+                dx_overwrite=bool(os.environ.get("FVTA_AB_DXOW")))   # FVTA_AB_DXOW=1: backward() writes dx (the model's setting)
 op.make_plan(lens)
 out = torch.zeros(B, J, 2 * d, device="cuda")
 dout = torch.randn(B, J, 2 * d, device="cuda", generator=g)
@@ -41,5 +42,9 @@ print("lib=%s WREG=%s: step %.3f ms (%d launches, %.1f us each)  dx %.3f  dW %.3
     1e3 * s_ms / max(1, s_n), collect(6)[0], collect(3)[0], wall, bool(torch.isfinite(dk).all())))
 # (dk accumulates over the 7 calls above; the checksum identifies the weight-gradient kernel's result bit by bit)
 print("dk sum %.10e  abs %.10e  db sum %.10e" % (dk.double().sum().item(), dk.double().abs().sum().item(), db.double().sum().item()))
-if os.environ.get("FVTA_AB_SAVE"): torch.save(dk.cpu(), "/tmp/lstm_bwd_ab_dk_%s.pt" % os.environ["FVTA_AB_SAVE"])
-if os.environ.get("FVTA_AB_CMP"): print("dk bitwise equal to %s: %s" % (os.environ["FVTA_AB_CMP"], torch.equal(dk.cpu(), torch.load("/tmp/lstm_bwd_ab_dk_%s.pt" % os.environ["FVTA_AB_CMP"]))))
+print("dx sum %.10e  abs %.10e" % (dx.double().sum().item(), dx.double().abs().sum().item()))
+if os.environ.get("FVTA_AB_SAVE"): torch.save((dk.cpu(), dx.cpu()), "/tmp/lstm_bwd_ab_dk_%s.pt" % os.environ["FVTA_AB_SAVE"])
+if os.environ.get("FVTA_AB_CMP"):
+    dk0, dx0 = torch.load("/tmp/lstm_bwd_ab_dk_%s.pt" % os.environ["FVTA_AB_CMP"])
+    print("against %s: dk bitwise equal %s, dx bitwise equal %s, max |dx diff| %.3e (max |dx| %.3f)" % (
+        os.environ["FVTA_AB_CMP"], torch.equal(dk.cpu(), dk0), torch.equal(dx.cpu(), dx0), (dx.cpu() - dx0).abs().max().item(), dx0.abs().max().item()))
