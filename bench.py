@@ -225,7 +225,7 @@ def pmc_traffic(fname, key):
             meta = json.load(open(os.path.join(HERE, "profiles", "pmc_meta.json"))).get(fname, {})
         except Exception:
             pass
-        note = "bytes per launch, profiles/%s (collected %s at commit %s)" % (fname, meta.get("date", "?"), meta.get("commit", "?"))
+        note = "profiles/%s@%s" % (fname, meta.get("commit", "?"))
         for k, v in d.items():
             if key in k:
                 return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"], note
@@ -251,7 +251,7 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
         kw["N"] = hi - lo
     spec = SynthSpec(**kw)
     cfg = dict(spec.cfg(), batch_size=spec.N, precision=args.precision, optimizer=args.optimizer,
-               init_lr=0.001 if args.optimizer == "adam" else 0.5)
+               init_lr=0.001 if args.optimizer == "adam" else 0.5, gc_freeze=(args.gc == "freeze"))
     if args.time_warp:
         cfg.update(use_time_warp=True, warp_type=args.time_warp)
     if args.side_priority is not None:
@@ -292,10 +292,10 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     global GC_MODE
     GC_MODE = args.gc
     import gc
-    if args.gc == "freeze":      # everything alive now is the model / the batch: nothing for a collector to find
-        gc.collect()
-        gc.freeze()
-        gc.disable()
+    # the collector is the TRAINER's business (Trainer.own_host, config `gc_freeze`, default on: what every user of
+    # Trainer.step / step_device gets); --gc default switches it off for the comparison case `also.headline_gc_default`
+    if args.gc == "freeze" and args.forward_only:
+        trainer.own_host()       # (the forward-only cases never call step_device)
     for i in range(args.warmup):
         step()
         torch.cuda.synchronize()
@@ -473,6 +473,12 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     # the DOMINANT kernel of the step (largest bracketed time per step) is `roofline`; the rest are roofline_<name>
     kms = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
     order = sorted(roofs, key=lambda k: -roofs[k]["ms_per_step"])
+    for r in roofs.values():         # the line stays short enough for the driver's record: the notes live in DESIGN.md section 5
+        r.pop("note", None)
+
+    def stats(v):
+        return dict(min=round(min(v), 3), median=round(statistics.median(v), 3), max=round(max(v), 3), argmax=v.index(max(v)))
+
     out = dict(
         metric="QA-pairs/sec (fwd+bwd) at B=64, 40 photos x 5 streams x 30 tok, h=512" if args.config == "metric" and not args.forward_only
         and args.graph == "fvta" else "QA-pairs/sec (model.py graph, %s, config %s)" % ("fwd" if args.forward_only else "fwd+bwd", args.config)
@@ -486,35 +492,34 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
                     + (", token-id entry (embedding front-end inside the step, char_emb_size %d)" % args.char_emb_size
                        if args.front_end else "")
                     + (", --use_time_warp --warp_type %d" % args.time_warp if args.time_warp else "")
-                    + (" -- model.py's soft-attention baseline graph (multi-layer + multi-modal + direct-link + choices + "
-                       "question attention) instead of the FVTA model" if args.graph == "model_py" else ""),
+                    + (" -- model.py's soft-attention baseline graph" if args.graph == "model_py" else ""),
                     qa_pairs_per_gpu=spec.N, albums=spec.A, photos=spec.P, text_streams=spec.S, tokens=spec.L, hidden=spec.d,
                     global_batch=spec.N * ws, K=L.K, T=L.T, JQ=L.JQ,
                     parallelism="dp%d (QA pairs sharded, flat-gradient all-reduce)" % ws),
         roofline=roofs[order[0]] if order else None,
-        roofline_is="roofline_%s: the bracketed kernel with the largest time per step" % order[0] if order else None,
+        roofline_is="roofline_%s" % order[0] if order else None,
     )
-    for k in order[1:]:
-        out["roofline_" + k] = roofs[k]
-    out["roofline_fracs"] = {k: [roofs[k]["frac"], roofs[k]["bound"]] for k in order}   # every bracketed kernel, dominant first
     out["host_enqueue_ms_per_step"] = round(host_enqueue / args.steps * 1e3, 3)
-    # the evidence behind ms_per_step: every step's device time (HIP events on the main stream) and host enqueue time,
-    # where their maxima fell, and what the host did meanwhile
-    out["step_ms"] = [round(v, 3) for v in step_ms]
-    out["step_ms_max"] = [round(max(step_ms), 3), step_ms.index(max(step_ms))]
-    out["host_step_ms"] = host_step_ms
-    out["host_step_ms_max"] = [max(host_step_ms), host_step_ms.index(max(host_step_ms))]
-    out["host_watch"] = dict(gc_mode=GC_MODE, gc_enabled=gc.isenabled(), gc_collections=gc_log[:32],
-                             gc_note="[generation, pause ms, ms since the timed region began]",
+    # the evidence behind ms_per_step: min / median / max (and where the maximum fell) of every step's device time (HIP events
+    # on the main stream) and host enqueue time, and what the host did meanwhile
+    out["step_ms"] = stats([round(v, 3) for v in step_ms])
+    out["host_step_ms"] = stats(host_step_ms)
+    out["host_watch"] = dict(gc_mode=GC_MODE, gc_enabled=gc.isenabled(), gc_collections=gc_log[:8],
                              minor_faults=ru1.ru_minflt - ru0.ru_minflt, major_faults=ru1.ru_majflt - ru0.ru_majflt,
                              vol_ctx_switches=ru1.ru_nvcsw - ru0.ru_nvcsw, invol_ctx_switches=ru1.ru_nivcsw - ru0.ru_nivcsw)
     out["side_stream_ratio"] = round(float(getattr(model, "side_stream_ratio", 0.0)), 3)   # < 1.4: the photo cell's stream runs beside the main one
-    out.update(process_group=pg, rank_seconds=[round(v, 4) for v in rank_elapsed], kernel_ms_per_step=kms,
-               kernel_ms_note="HIP-event brackets on the launch streams, over a second pass of the same %d steps right after the "
-                              "timed region (the timed region itself carries no brackets)" % args.steps)
+    out.update(process_group=pg, rank_seconds=[round(v, 4) for v in rank_elapsed])
+    # compact forms, read by main() into the line's LAST object (`evidence`): every bracketed kernel's time per step and every
+    # roofline as {frac, bound, avg_launch_ms, bytes | flops per launch, counter traffic}
+    out["kernel_ms_per_step"] = kms
+    out["rooflines"] = {k: dict(frac=roofs[k]["frac"], bound=roofs[k]["bound"], avg_launch_ms=roofs[k]["avg_launch_ms"],
+                                ms_per_step=roofs[k]["ms_per_step"],
+                                per_launch=round(roofs[k].get("algorithmic_bytes_per_call", roofs[k].get("algorithmic_flops_per_call", 0))
+                                                 * calls / max(1, roofs[k]["launches"])),
+                                traffic=round(roofs[k]["traffic"]) if roofs[k].get("traffic") else None, **({"mfma_frac": roofs[k]["mfma_frac"]} if "mfma_frac" in roofs[k] else {}))
+                        for k in order}
+    trainer.release_host()
     del trainer, model, L
-    gc.enable()
-    gc.unfreeze()
     gc.collect()
     torch.cuda.empty_cache()
     return out, kw
@@ -523,12 +528,14 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
 ALSO_CASES = [   # (name, command-line overrides, steps, warm-up: ~0.1-0.15 s of warm-up each, see --warmup)
     ("configs1_forward_fp32", ["--forward-only", "--precision", "f32"], 5, 6),
     ("configs1_forward_bf16", ["--forward-only"], 20, 40),
+    ("configs1_forward_bf16x3", ["--forward-only", "--precision", "bf16x3"], 8, 8),
     ("train_bf16x3", ["--precision", "bf16x3"], 4, 4),
     ("train_ragged_lengths", ["--variant", "ragged"], 20, 30),
     ("configs4_long_album", ["--config", "long_album"], 3, 2),
     ("token_id_entry", ["--front-end"], 10, 10),
     ("time_warp_5", ["--time-warp", "5"], 10, 10),
     ("published_flag_set", ["--front-end", "--char-emb-size", "100", "--time-warp", "5"], 6, 6),
+    ("headline_gc_default", ["--gc", "default"], 20, 10),       # the headline with CPython's collector left alone (Trainer gc_freeze off)
 ]
 
 
@@ -555,17 +562,16 @@ def also_helper():
             if pr.returncode or not line:
                 raise RuntimeError("exit code %d, %d JSON lines" % (pr.returncode, len(line)))
             r = json.loads(line[-1])
-            also[name] = dict(value=r["value"], unit=r["unit"], ms_per_step=r["ms_per_step"],
-                              ms_per_step_event_median=r["ms_per_step_event_median"], steps=steps, warmup=warm,
-                              dtype=r["dtype"], workload=r["config"]["workload"],
-                              shape={k: r["config"][k] for k in ("qa_pairs_per_gpu", "photos", "text_streams", "tokens", "hidden", "K", "T", "JQ")},
-                              kernel_ms_per_step=r["kernel_ms_per_step"], side_stream_ratio=r["side_stream_ratio"],
-                              host_enqueue_ms_per_step=r["host_enqueue_ms_per_step"], roofline_fracs=r["roofline_fracs"],
-                              step_ms=r["step_ms"], host_step_ms=r["host_step_ms"], step_ms_max=r["step_ms_max"],
-                              host_step_ms_max=r["host_step_ms_max"], host_watch=r["host_watch"],
-                              command="python bench.py " + " ".join(cmd[2:]), process_seconds=round(time.perf_counter() - t0, 1))
+            also[name] = dict(value=r["value"], ms_per_step=r["ms_per_step"], event_median=r["ms_per_step_event_median"],
+                              steps=steps, warmup=warm, dtype=r["dtype"], args=" ".join(over),
+                              kernel_ms={k.replace("lstm_step_", "").replace("_main", ""): round(v, 3)
+                                         for k, v in r["kernel_ms_per_step"].items() if v},
+                              rooflines={k: [v["frac"], v["avg_launch_ms"]] for k, v in r["rooflines"].items()},
+                              step_ms=[r["step_ms"][k] for k in ("min", "median", "max")],
+                              host_ms=r["host_enqueue_ms_per_step"],
+                              gc=[r["host_watch"]["gc_mode"], len(r["host_watch"]["gc_collections"]), r["host_watch"]["major_faults"]])
         except Exception as exc:   # a side measurement must not take the headline down
-            also[name] = dict(error=repr(exc), command="python bench.py " + " ".join(cmd[2:]))
+            also[name] = dict(error=repr(exc)[:200], args=" ".join(over))
     print(json.dumps(also), flush=True)
 
 
@@ -637,15 +643,24 @@ def main():
             out["also"] = json.loads(line)
         except Exception as exc:
             out["also"] = dict(error=repr(exc))
-        out["also_note"] = ("the other BASELINE.json configurations that fit one GPU, timed right after the headline by this same "
-                            "invocation, each in a fresh `python bench.py ... --also off` process (short runs: steps / warm-up as "
-                            "listed); same code path, same timing method")
+        out["also_note"] = "each case: a fresh `python bench.py <args> --also off` process right after the headline; rooflines = [frac of HBM (lstm_dw: of MFMA), avg_launch_ms]; step_ms = [min, median, max]"
     if ws == 1 and not args.no_cpu_baseline and args.graph == "fvta":
         log('timing the CPU oracle (%d threads of %d host CPUs)' % (args.cpu_threads, host_cores()))
         out["cpu_baseline"] = cpu_baseline(kw, args.cpu_sample, args.forward_only, args.cpu_threads)
     else:
         out["cpu_baseline"] = None
-    json_out.write(json.dumps(out) + "\n")
+    # LAST in the line (the driver's record keeps the line's tail): the numbers a reader needs, compact
+    roofs = out.pop("rooflines", {})
+    kms = out.pop("kernel_ms_per_step", {})
+    if args.also == "off":           # a child of the `also` orchestrator: its parent reads these two
+        out["rooflines"], out["kernel_ms_per_step"] = roofs, kms
+    ev = dict(headline=dict(ms_per_step=out["ms_per_step"], event_median=out["ms_per_step_event_median"], value=out["value"],
+                            kernel_ms_per_step=kms, rooflines=roofs))
+    for k in ("also", "also_note"):          # (the cases sit right in front of `evidence`, behind the CPU baseline)
+        if k in out:
+            out[k] = out.pop(k)
+    out["evidence"] = ev
+    json_out.write(json.dumps(out, separators=(",", ":")) + "\n")
     json_out.flush()
     dist.shutdown()
 

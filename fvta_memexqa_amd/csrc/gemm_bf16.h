@@ -211,13 +211,18 @@ typedef MmaBT<1> MmaB;
 template <int PER, int BK = 32>
 struct RowSrc {
   unsigned voff[PER];
+  // RPW < 64: a block tile whose 64-row wave tiles hold only RPW rows each (image row r = global row row0 + (r / 64) RPW +
+  // r % 64, rows r % 64 >= RPW read as zeros): the same 256-row MFMA tile over fewer rows, so that a grid of them covers
+  // more CUs (lstm_bwd_fused_bf16)
+  template <int RPW = 64>
   __device__ __forceinline__ void setup(int wave, int lane, int row0, int nrows, unsigned ld_bytes) {
     constexpr int CPR = BK / 8;  // 16-byte chunks per image row
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int U = (wave * PER + j) * 64 + lane;
       const int row = U / CPR, c = (U % CPR) ^ row_swz<BK>(row);
-      voff[j] = (row0 + row < nrows) ? (unsigned)(row0 + row) * ld_bytes + 16u * c : GLDS_OOB;
+      const int grow = RPW == 64 ? row0 + row : row0 + (row >> 6) * RPW + (row & 63);
+      voff[j] = (grow < nrows && (RPW == 64 || (row & 63) < RPW)) ? (unsigned)grow * ld_bytes + 16u * c : GLDS_OOB;
     }
   }
   __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, bf16_t* stage, int wave, unsigned soff) const {

@@ -237,8 +237,14 @@ __device__ __forceinline__ int kt_rot(int nkt) {
   const unsigned bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
   return FVTA_KT_ROT ? (int)((bid >> 3) * FVTA_KT_ROT % (unsigned)nkt) : 0;
 }
-template <int WN, int WM, int XM, int BK, int ST, int EPD_ = FVTA_BWD_EPD>  // XM = 3: the split engine (three bf16 terms per operand value, fp32 saved gates)
+// RPW (rows per 64-row wave tile, a multiple of 8): 64 = the plain 256-row block tile.  RPW < 64 (WM = 4 only): the block tile
+// covers 4 RPW rows -- tile row r is global row m0 + (r / 64) RPW + r % 64, rows r % 64 >= RPW are padding (zero operand rows,
+// their epilogue passes compiled out) -- so that the launch's grid fills the CUs: at the metric shape 58 tiles of 224 rows
+// x 2 column tiles x 2 directions = 232 workgroups instead of 204 of 256 rows on 256 CUs, each with 7/8 of the epilogue.
+template <int WN, int WM, int XM, int BK, int ST, int RPW = 64, int EPD_ = FVTA_BWD_EPD>  // XM = 3: the split engine (three bf16 terms per operand value, fp32 saved gates)
 __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t, int dir, int m0, int u0, bf16_t* smem_h) {
+  static_assert(RPW == 64 || (WM == 4 && RPW % 8 == 0 && RPW > 32 && RPW < 64), "rows per wave tile");
+  auto grow_of = [&](int r) { return RPW == 64 ? m0 + r : m0 + (r >> 6) * RPW + (r & 63); };  // tile row -> global sorted row
   typedef TileCfgT<WN, 2, WM, ST, BK> TileCfg;
   typedef MmaBT<WN, 2, WM, ST, BK> MmaB;
   int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + (size_t)TileCfg::STAGES * TileCfg::STAGE_ELEMS);
@@ -248,7 +254,7 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
   if (m0 >= nact) return;
   const int nnext = (t + 1 < a.J) ? a.plan.nactive[t + 1] : 0;
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
-  for (int r = tid; r < TileCfg::BM; r += TileCfg::NT) s_oo[r] = a.plan.oo[trow + min(m0 + r, nact - 1)];  // clamped: always a valid row
+  for (int r = tid; r < TileCfg::BM; r += TileCfg::NT) s_oo[r] = a.plan.oo[trow + min(grow_of(r), nact - 1)];  // clamped: always a valid row
   // compile-time ablations (timing experiments, -DFVTA_TBWD_ABL=bits; results are garbage): 1 no k-loop, 2 no epilogue
   // stores, 4 no epilogue loads
 #ifdef FVTA_TBWD_ABL
@@ -263,7 +269,7 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wb[dir] + (size_t)a.in_i * K, (unsigned)d * K * 2);  // the h rows of wb
     RowSrc<TileCfg::A_GLDS, BK> az;
     RowSrc<TileCfg::B_GLDS, BK> bw;
-    az.setup(mma.wave_all, mma.lane, m0, nnext, K * 2);
+    az.template setup<RPW>(mma.wave_all, mma.lane, m0, nnext, K * 2);
     bw.setup(mma.wave_all, mma.lane, u0, d, K * 2);
     // (a k-tile order rotated per workgroup, as in lstm_dx_bf16 and the pipelined kernel: 134.5 vs 132.3 us here)
     auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
@@ -324,8 +330,8 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
     const int pl = P >> 2, it = P & 3, ti = pl / MmaB::TN;
     const int u = plane_u(pl);
     const int lr = it * 8 + io_row, row = mma.wave * MmaB::WROWS + ti * 32 + lr;
-    const int ic = min(m0 + row, nact - 1);  // clamped: always a valid row
-    const int64_t oo = s_oo[min(row, nact - 1 - m0)];
+    const int ic = min(grow_of(row), nact - 1);  // clamped: always a valid row
+    const int64_t oo = s_oo[row];                 // (filled with the same clamp)
     const int uc = min(u, d - 4);            // (a plane past the last unit: loads a valid address, stores nothing)
     if constexpr (XM == 1) {
       const float* gp = reinterpret_cast<const float*>(a.gatesb + (trow + ic) * (size_t)N4 + 4 * uc);
@@ -351,12 +357,12 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
     // unconditional load + select
     const f32x4 dcl = (ntb & 8) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dcs + (size_t)ic * d + uc))
                                 : *reinterpret_cast<const f32x4*>(dcs + (size_t)ic * d + uc);
-    in.dcv = (m0 + row) < nnext ? dcl : f32x4{0.f, 0.f, 0.f, 0.f};
+    in.dcv = grow_of(row) < nnext ? dcl : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto do_pass = [&](int P, const In& in) {
     const int pl = P >> 2, it = P & 3, ti = pl / MmaB::TN;
     const int u = plane_u(pl);
-    const int lr = it * 8 + io_row, i = m0 + mma.wave * MmaB::WROWS + ti * 32 + lr;
+    const int lr = it * 8 + io_row, i = grow_of(mma.wave * MmaB::WROWS + ti * 32 + lr);
     const f32x4 dh4 = *reinterpret_cast<const f32x4*>(&pl_[lr * LDP + 4 * io_c4]);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 ga = __builtin_bit_cast(u32x4, in.g0), gb = __builtin_bit_cast(u32x4, in.g1);
@@ -410,6 +416,8 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
     }
   };
   In ins[EPD];
+  // (RPW < 64: the passes over a wave tile's padding rows -- rows (pl / TN) 32 + 8 it >= RPW -- do not exist)
+  auto pass_live = [](int P) constexpr { return ((P >> 2) / MmaB::TN) * 32 + (P & 3) * 8 < RPW; };
   bf_static_for<0, EPD>([&](auto P_c) { load_pass(decltype(P_c)::value, ins[decltype(P_c)::value]); });
   bf_static_for<0, NPASS>([&](auto P_c) {  // (compile-time indices: the pass buffers stay in registers)
     constexpr int P = decltype(P_c)::value;
@@ -420,16 +428,25 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
       for (int r = 0; r < 16; ++r) pl_[((r & 3) + 8 * (r >> 2) + 4 * mma.hf) * LDP + mma.l31] = mma.acc[ti][tj][r];
       wave_sync();
     }
-    do_pass(P, ins[P % EPD]);
-    if constexpr (P + EPD < NPASS) load_pass(P + EPD, ins[P % EPD]);
+    if constexpr (pass_live(P)) do_pass(P, ins[P % EPD]);
+    if constexpr (P + EPD < NPASS && pass_live(P + EPD)) load_pass(P + EPD, ins[P % EPD]);
   });
 }
 
-template <int WN, int WM = 4, int XM = 1, int BK = 32, int ST = 3>
+template <int WN, int WM = 4, int XM = 1, int BK = 32, int ST = 3, int RPW = 64>
 __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   typedef TileCfgT<WN, 2, WM, ST, BK> TileCfg;
-  lstm_bwd_tile_step<WN, WM, XM, BK, ST>(a, a.t, blockIdx.z, blockIdx.x * TileCfg::BM, blockIdx.y * TileCfg::BN, smem_h);
+  lstm_bwd_tile_step<WN, WM, XM, BK, ST, RPW>(a, a.t, blockIdx.z, blockIdx.x * (RPW == 64 ? TileCfg::BM : 4 * RPW), blockIdx.y * TileCfg::BN, smem_h);
+}
+
+static int bwd_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  return cus;
 }
 
 template <int XM>
@@ -454,6 +471,22 @@ static void launch_bwd_fused_xm(const FusedBwdArgs& a, hipStream_t s) {
     constexpr int BK = FVTA_BWD_BK, ST = BK == 64 ? 2 : 3;
     if ((4 * a.d * XM) % BK == 0) {
       constexpr int LDS = TileCfgT<2, 2, 4, ST, BK>::LDS_BYTES + 256 * 8;
+      // row tiles of 224 rows (RPW 56) when the 256-row tiles leave CUs idle that the 224-row tiles would use: one dispatch
+      // round either way (-DFVTA_BWD_RPW=64: off)
+#ifndef FVTA_BWD_RPW
+#define FVTA_BWD_RPW 56
+#endif
+      constexpr int RPW = FVTA_BWD_RPW;
+      if constexpr (RPW != 64) {
+        const int rows = a.nact_hint >= 0 ? a.nact_hint : a.B, percol = 2 * (a.d / 256), cus = bwd_cus();
+        const int t256 = (rows + 255) / 256 * percol, tr = (rows + 4 * RPW - 1) / (4 * RPW) * percol;
+        static const bool rpw_on = [] { const char* e = getenv("FVTA_BWD_RPW"); return !(e && e[0] == '6' && e[1] == '4'); }();  // A/B runs
+        if (rpw_on && t256 <= cus && tr <= cus && tr > t256) {
+          allow_big_lds(lstm_bwd_fused_bf16<2, 4, XM, BK, ST, RPW>, LDS);
+          hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4, XM, BK, ST, RPW>), dim3(pad8((a.B + 4 * RPW - 1) / (4 * RPW)), a.d / 256, 2), dim3(512), LDS, s, a);
+          return;
+        }
+      }
       allow_big_lds(lstm_bwd_fused_bf16<2, 4, XM, BK, ST>, LDS);
       hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4, XM, BK, ST>), dim3(pad8((a.B + 255) / 256), a.d / 256, 2), dim3(512), LDS, s, a);
       return;

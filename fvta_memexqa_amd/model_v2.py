@@ -953,6 +953,7 @@ class Model:
                                            L.yp, loss_scale, P.view(self.N_OUT_W, True), P.view(self.N_OUT_B, True),
                                            self.use_eu_output, self.scorer_tanh, self.tf_xent_grad)
         self._attend_bwd(L, dgq, dg1, dgch)
+        L.dg1 = dg1        # d loss / d g1 as the focal attention's backward saw it (scorer + question attention); inspection only
         main = torch.cuda.current_stream()
         token = getattr(L, "token", False)
         need_dx = need_dx or token          # the embedding parameters are trained through the encoder inputs

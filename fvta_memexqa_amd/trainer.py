@@ -47,11 +47,40 @@ class Trainer:
         lr = getattr(config, "init_lr", 0.5) if not isinstance(config, dict) else config.get("init_lr", 0.5)
         self.opt = AdamOptimizer(lr) if name == "adam" else AdadeltaOptimizer(lr)   # trainer.py:16-17
         self.need_dx = False   # gradients into the encoder inputs (for the embedding front-end)
+        # a generation-2 pass of CPython's collector over torch's / numpy's heaps is a host pause of tens of milliseconds --
+        # several device steps.  Once the model and the first batch exist there is nothing left for it to find, so the
+        # first step freezes what is alive and switches the collector off (`gc_freeze`, default on; release_host() undoes it)
+        gcf = getattr(config, "gc_freeze", True) if not isinstance(config, dict) else config.get("gc_freeze", True)
+        self.gc_freeze, self._owns_host = bool(gcf), False
+
+    def own_host(self):
+        """gc.collect(); gc.freeze(); gc.disable() -- once, at the first step (or by hand before an inference loop)."""
+        if not self._owns_host:
+            import gc
+            gc.collect()
+            gc.freeze()
+            gc.disable()
+            self._owns_host = True
+
+    def release_host(self):
+        if self._owns_host:
+            import gc
+            gc.enable()
+            gc.unfreeze()
+            self._owns_host = False
+
+    def __del__(self):
+        try:
+            self.release_host()
+        except Exception:
+            pass
 
     def step_device(self, layout):
         """One fwd+bwd+update on an already loaded batch; returns the loss as a DEVICE tensor
         (no host sync).  Under data parallelism: one all-reduce of the flat gradient bucket."""
         m = self.model
+        if self.gc_freeze and not self._owns_host:
+            self.own_host()
         m.zero_grad()
         m.forward(layout)
         m.backward(layout, loss_scale=1.0, need_dx=self.need_dx)

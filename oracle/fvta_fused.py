@@ -69,8 +69,22 @@ def simi_logits(h, q, W, b, simiMatrix, add_tanh, feat_order="v2"):
     return torch.tanh(x) if add_tanh else x
 
 
+def max_over_j(a, max_grad="split"):
+    """tf.reduce_max(a_logits, JQ axis) (model_v2.py:268 / 177).  Values are the same in both modes; the GRADIENT of an
+    exact tie differs: "split" is TensorFlow's (and torch.amax's): the tied cells share it equally; "first" is what the HIP
+    kernels do (deliberate deviation): the FIRST arg-max position takes all of it.  Tie = within 1e-12
+    relative of the maximum (identical rows give bit-identical logits on the GPU; a blocked CPU GEMM may differ in the last
+    fp64 bit between two copies of a row)."""
+    if max_grad == "split":
+        return a.amax(dim=-1)
+    assert max_grad == "first"
+    m = a.detach().amax(dim=-1, keepdim=True)
+    first = (a.detach() >= m - 1e-12 * m.abs()).to(torch.int8).argmax(dim=-1, keepdim=True)   # first maximal index
+    return torch.gather(a, -1, first).squeeze(-1)
+
+
 def attention(hinfo, hq, W=None, b=None, hinfo_mask=None, hq_mask=None, simiMatrix=1,
-              add_tanh=False, bidirect=False, feat_order="v2"):
+              add_tanh=False, bidirect=False, feat_order="v2", max_grad="split"):
     """model_v2.py:125-201 / model.py:117-186."""
     N, w = hinfo.shape[0], hinfo.shape[-1]
     h = hinfo.reshape(N, -1, w)
@@ -78,7 +92,7 @@ def attention(hinfo, hq, W=None, b=None, hinfo_mask=None, hq_mask=None, simiMatr
     if hinfo_mask is not None and hq_mask is not None:
         mask = hinfo_mask.reshape(N, -1)[:, :, None] & hq_mask[:, None, :]
         a = exp_mask(a, mask)
-    h_a = softsel(h, a.amax(dim=2))
+    h_a = softsel(h, max_over_j(a, max_grad))
     if bidirect:
         q_a = (softmax(a).unsqueeze(-1) * hq[:, None, :, :]).sum(-2).mean(1)
         h_a = torch.cat([h_a, q_a], 1)
@@ -86,19 +100,19 @@ def attention(hinfo, hq, W=None, b=None, hinfo_mask=None, hq_mask=None, simiMatr
 
 
 def attention_3d(hinfo, hq, W=None, b=None, hinfo_mask=None, hq_mask=None, simiMatrix=1,
-                 add_tanh=False, time_warp_att=False, C=None):
-    """model_v2.py:210-298."""
+                 add_tanh=False, time_warp_att=False, C=None, max_grad="split"):
+    """model_v2.py:210-298.  max_grad: see max_over_j (the max over T at :288 splits ties in both modes, as the kernels do)."""
     N, K, w = hinfo.shape[0], hinfo.shape[1], hinfo.shape[-1]
     h = hinfo.reshape(N, K, -1, w)
     a = simi_logits(h, hq[:, None], W, b, simiMatrix, add_tanh)          # [N,K,T,JQ]
     if hinfo_mask is not None and hq_mask is not None:
         mask = hinfo_mask.reshape(N, K, -1)[..., None] & hq_mask[:, None, None, :]
         a = exp_mask(a, mask)
-    amax = a.amax(dim=3)
+    amax = max_over_j(a, max_grad)
+    s = a.amax(dim=(3, 2)) if max_grad == "split" else amax.amax(dim=2)
     if time_warp_att:
         amax = (amax.unsqueeze(-1) * C[:, None]).sum(-1)
     u = softsel(h, amax)
-    s = a.amax(dim=(3, 2))
     return softsel(u, s), a
 
 

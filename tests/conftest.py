@@ -49,3 +49,14 @@ def attn_select():
     sel = _AttnSelect()
     yield sel
     sel.default()
+
+
+@pytest.fixture(autouse=True)
+def _collector_back_on():
+    """Trainer.step_device freezes and disables CPython's collector (Trainer.own_host) until the trainer goes away; a
+    failed test's traceback can keep its trainer alive: give every test the collector back."""
+    import gc
+    yield
+    if not gc.isenabled():
+        gc.enable()
+        gc.unfreeze()

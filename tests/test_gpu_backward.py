@@ -58,6 +58,65 @@ def test_attention_3d_backward_matches_autograd(N, K, T, JQ, w, simi, tanh, mask
         _close(dW, 2 * Wd.grad.reshape(-1), atol=3e-5, msg="dW accumulates")
 
 
+@pytest.mark.parametrize("N,K,T,JQ,w,simi,tanh", [(2, 3, 48, 10, 64, 2, True), (2, 2, 96, 30, 256, 1, False),
+                                                  (2, 6, 400, 30, 1024, 2, True), (1, 2, 64, 60, 2048, 3, True)])
+@pytest.mark.parametrize("exact", [False, True])
+def test_attention_3d_ties_among_valid_entries(N, K, T, JQ, w, simi, tanh, exact, attn_select):
+    """Genuine ties among VALID entries (model_v2.py:268, 278): every question position has an identical twin
+    (q[j + JQ/2] = q[j]: a tie in every row's max over j) and every context row has an identical twin in its modality
+    (h[t + T/2] = h[t]: the max over t is always a tie).  The kernels send the max-over-j gradient to the FIRST arg-max and
+    split the max-over-t gradient; TensorFlow's reduce_max (and the oracle's default, torch.amax) splits both.  Asserted:
+      * forward values are the same in both conventions, and the kernels' match;
+      * the kernels' gradients equal the oracle's under max_grad="first", element by element;
+      * against TF's split convention ONLY d_hq differs, and only by moving gradient between twins: the sum over each twin
+        pair is the split convention's (d_hinfo, dW, db are identical because twins have identical rows)."""
+    from fvta_memexqa_amd import ops
+    from oracle import fvta_fused as F
+    from tests.test_gpu_forward import _att_case
+    (attn_select.exact if exact else attn_select.fast)()
+    h, q, W, b, _, _ = _att_case(N, K, T, JQ, w, simi, tanh, False, seed=T + w + simi + 31)
+    h[:, :, T // 2:] = h[:, :, :T - T // 2].clone()
+    q[:, JQ // 2:] = q[:, :JQ - JQ // 2].clone()
+    hm = torch.ones(N, K, T, dtype=torch.bool)
+    qm = torch.ones(N, JQ, dtype=torch.bool)
+    hm[:, :, T - 3:] = False                 # (a few padded rows / positions, so that the masked path runs too)
+    qm[0, JQ - 1] = False
+    gout = torch.randn(N, w, generator=torch.Generator().manual_seed(7))
+    grads = {}
+    for mode in ("first", "split"):
+        leaves = [t.double().requires_grad_() for t in (h, q, W, b)]
+        ha, _ = F.attention_3d(*leaves, hm, qm, simiMatrix=simi, add_tanh=tanh, max_grad=mode)
+        (ha * gout.double()).sum().backward()
+        grads[mode] = (ha.detach(), [t.grad for t in leaves])
+    ref_ha, (rdh, rdq, rdW, rdb) = grads["first"]
+    _, (sdh, sdq, sdW, sdb) = grads["split"]
+    # (same values in both conventions -- up to the last fp64 bit: "first" picks ONE of two twins whose logits a blocked CPU
+    #  GEMM may round differently)
+    _close(grads["first"][0], grads["split"][0], rtol=1e-12, atol=1e-14, msg="h_a does not depend on the convention")
+    op = ops.FocalAttention(N, K, T, JQ, w, simi, tanh)
+    cu = lambda t: t.cuda().contiguous()
+    hc, qc, Wc, bc = cu(h), cu(q), cu(W.reshape(-1)), cu(b)
+    hmc, qmc = cu(ops.as_mask_u8(hm)), cu(ops.as_mask_u8(qm))
+    ha, _ = op.forward(hc, qc, hmc, qmc, Wc, bc)
+    _close(ha, ref_ha, msg="h_a")
+    dh, dq = torch.full_like(hc, float("nan")), torch.full_like(qc, float("nan"))
+    dW, db = torch.zeros_like(Wc), torch.zeros(1, device="cuda")
+    op.backward(hc, qc, hmc, qmc, Wc, bc, cu(gout), dh, dq, dW, db, accumulate=False)
+    _close(dh, rdh, msg="d_hinfo (first arg-max)")
+    _close(dq, rdq, msg="d_hq (first arg-max)")
+    _close(dW, rdW.reshape(-1), msg="dW")
+    _close(db, rdb, msg="db")
+    assert float(dh[:, :, T - 3:].abs().max()) == 0.0            # masked rows: exactly zero, whatever was in the buffer
+    # the difference to TF's convention, in numbers: the second twin of a pair gets nothing here and half there
+    J2 = JQ - JQ // 2
+    pair = lambda t: t[:, :JQ // 2] + t[:, J2:J2 + JQ // 2] if JQ % 2 == 0 else None
+    assert float((rdq - sdq).abs().max()) > 1e-3 * float(sdq.abs().max())       # the test DOES exercise ties
+    _close(rdh, sdh, rtol=1e-9, atol=1e-12, msg="d_hinfo does not depend on the convention")
+    _close(rdW, sdW, rtol=1e-9, atol=1e-12, msg="dW does not depend on the convention")
+    if JQ % 2 == 0:     # (album 0's last position is masked: that pair is no tie, and its sum is the first twin's in both conventions)
+        _close(pair(dq.cpu().double()), pair(sdq), msg="twin-pair sums of d_hq = TF's split convention")
+
+
 def test_attention_backward_fully_masked_rows_direct_term():
     """Fully masked (n,k): p = 1/T over all T; the direct term p*r*g still reaches d_hinfo."""
     from fvta_memexqa_amd import ops

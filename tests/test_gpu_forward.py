@@ -320,9 +320,15 @@ def test_attention_wave16_kernel_randomised_differential(attn_select, mode):
         tag = "case %d (N %d K %d T %d JQ %d w %d simi %d tanh %s masked %s)" % (case, N, K, T, JQ, w, simi, tanh, masked)
         assert torch.equal(again.cpu(), fast) and torch.equal(op.saved, saved_fast), tag + ": not reproducible"
         g = torch.randn(N, w, generator=torch.Generator().manual_seed(case)).cuda()
-        grads_fast = [torch.zeros(N, K, T, w, device="cuda"), torch.zeros(N, JQ, w, device="cuda"),
+        # (accumulate = 0 OVERWRITES d_hinfo / d_hq: NaN sentinels -- a valid row the kernel missed would stay NaN, a masked
+        #  row must come back exactly 0)
+        grads_fast = [torch.full((N, K, T, w), float("nan"), device="cuda"), torch.full((N, JQ, w), float("nan"), device="cuda"),
                       torch.zeros_like(args[4]), torch.zeros(1, device="cuda")]
         op.backward(*args, g, *grads_fast, accumulate=0)
+        assert torch.isfinite(grads_fast[0]).all() and torch.isfinite(grads_fast[1]).all(), tag + ": rows left unwritten"
+        if args[2] is not None:
+            dead = (args[2].view(N, K, T) == 0) & (args[2].view(N, K, T).any(2, keepdim=True)) & (args[3].view(N, 1, JQ).any(2, keepdim=True) != 0)
+            assert float(grads_fast[0][dead].abs().max() if dead.any() else 0.0) == 0.0, tag + ": masked rows of a live stream not zero"
         attn_select.exact()
         exact, _ = op.forward(*args)
         assert torch.isfinite(fast).all(), tag
@@ -332,7 +338,7 @@ def test_attention_wave16_kernel_randomised_differential(attn_select, mode):
         amax_e = op.saved[:4 * nkt].view(torch.float32).cpu()
         ok = torch.isfinite(amax_e) & (amax_e > -1e29)
         np.testing.assert_allclose(amax_f[ok].numpy(), amax_e[ok].numpy(), rtol=5e-5, atol=5e-6, err_msg=tag + " amax")
-        grads_exact = [torch.zeros(N, K, T, w, device="cuda"), torch.zeros(N, JQ, w, device="cuda"),
+        grads_exact = [torch.full((N, K, T, w), float("nan"), device="cuda"), torch.full((N, JQ, w), float("nan"), device="cuda"),
                        torch.zeros_like(args[4]), torch.zeros(1, device="cuda")]
         op.backward(*args, g, *grads_exact, accumulate=0)
         for name, a_, b_ in zip(("d_hinfo", "d_hq", "dW", "db"), grads_fast, grads_exact):
@@ -365,9 +371,15 @@ def test_attention_wide_kernel_randomised_differential(attn_select):
         tag = "case %d (N %d K %d T %d JQ %d simi %d tanh %s masked %s)" % (case, N, K, T, JQ, simi, tanh, masked)
         assert torch.equal(again.cpu(), fast) and torch.equal(op.saved, saved_fast), tag + ": not reproducible"
         g = torch.randn(N, w, generator=torch.Generator().manual_seed(case)).cuda()
-        grads_fast = [torch.zeros(N, K, T, w, device="cuda"), torch.zeros(N, JQ, w, device="cuda"),
+        # (accumulate = 0 OVERWRITES d_hinfo / d_hq: NaN sentinels -- a valid row the kernel missed would stay NaN, a masked
+        #  row must come back exactly 0)
+        grads_fast = [torch.full((N, K, T, w), float("nan"), device="cuda"), torch.full((N, JQ, w), float("nan"), device="cuda"),
                       torch.zeros_like(args[4]), torch.zeros(1, device="cuda")]
         op.backward(*args, g, *grads_fast, accumulate=0)
+        assert torch.isfinite(grads_fast[0]).all() and torch.isfinite(grads_fast[1]).all(), tag + ": rows left unwritten"
+        if args[2] is not None:
+            dead = (args[2].view(N, K, T) == 0) & (args[2].view(N, K, T).any(2, keepdim=True)) & (args[3].view(N, 1, JQ).any(2, keepdim=True) != 0)
+            assert float(grads_fast[0][dead].abs().max() if dead.any() else 0.0) == 0.0, tag + ": masked rows of a live stream not zero"
         attn_select.exact()
         exact, _ = op.forward(*args)
         assert torch.isfinite(fast).all(), tag
@@ -377,7 +389,7 @@ def test_attention_wide_kernel_randomised_differential(attn_select):
         amax_e = op.saved[:4 * nkt].view(torch.float32).cpu()
         ok = torch.isfinite(amax_e) & (amax_e > -1e29)
         np.testing.assert_allclose(amax_f[ok].numpy(), amax_e[ok].numpy(), rtol=5e-5, atol=5e-6, err_msg=tag + " amax")
-        grads_exact = [torch.zeros(N, K, T, w, device="cuda"), torch.zeros(N, JQ, w, device="cuda"),
+        grads_exact = [torch.full((N, K, T, w), float("nan"), device="cuda"), torch.full((N, JQ, w), float("nan"), device="cuda"),
                        torch.zeros_like(args[4]), torch.zeros(1, device="cuda")]
         op.backward(*args, g, *grads_exact, accumulate=0)
         for name, a_, b_ in zip(("d_hinfo", "d_hq", "dW", "db"), grads_fast, grads_exact):

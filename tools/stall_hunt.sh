@@ -20,7 +20,7 @@ for f in sorted(glob.glob('gpurun_out/stall/*.json')):
         print(f,'ERR',e); continue
     def show(name,r):
         hw=r.get('host_watch',{})
-        print('%-28s wall %.3f med %.3f host %.3f stepmax %s hostmax %s gc %s majflt %s minflt %s csw %s/%s'%(name,r['ms_per_step'],r['ms_per_step_event_median'],r['host_enqueue_ms_per_step'],r.get('step_ms_max'),r.get('host_step_ms_max'),[g for g in hw.get('gc_collections',[]) if g[0]==2 or g[1]>1.0],hw.get('major_faults'),hw.get('minor_faults'),hw.get('vol_ctx_switches'),hw.get('invol_ctx_switches')))
+        print('%-28s wall %.3f med %.3f host %.3f stepmax %s hostmax %s gc %s majflt %s minflt %s csw %s/%s'%(name,r['ms_per_step'],r['ms_per_step_event_median'],r['host_enqueue_ms_per_step'],r.get('step_ms'),r.get('host_step_ms'),[g for g in hw.get('gc_collections',[]) if g[0]==2 or g[1]>1.0],hw.get('major_faults'),hw.get('minor_faults'),hw.get('vol_ctx_switches'),hw.get('invol_ctx_switches')))
     show(os.path.basename(f),r)
     for k,v in (r.get('also') or {}).items():
         if 'error' in v: print('   ',k,v['error']); continue

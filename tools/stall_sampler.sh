@@ -30,5 +30,5 @@ for f in sorted(glob.glob('gpurun_out/stall2/*.json')):
     except Exception as e:
         print(f,'ERR',e); continue
     hw=r.get('host_watch',{})
-    print('%-24s wall %.3f med %.3f host %.3f stepmax %s hostmax %s csw %s/%s'%(os.path.basename(f),r['ms_per_step'],r['ms_per_step_event_median'],r['host_enqueue_ms_per_step'],r.get('step_ms_max'),r.get('host_step_ms_max'),hw.get('vol_ctx_switches'),hw.get('invol_ctx_switches')))
+    print('%-24s wall %.3f med %.3f host %.3f stepmax %s hostmax %s csw %s/%s'%(os.path.basename(f),r['ms_per_step'],r['ms_per_step_event_median'],r['host_enqueue_ms_per_step'],r.get('step_ms'),r.get('host_step_ms'),hw.get('vol_ctx_switches'),hw.get('invol_ctx_switches')))
 PY
