@@ -77,10 +77,17 @@ typedef TileCfgT<1> TileCfg;
 template <int BK>
 __device__ __forceinline__ constexpr int row_swz(int r) { return BK == 32 ? ((r >> 2) & 3) : ((r >> 1) & 7); }
 
-template <int WN, int TM_ = 2, int WM_ = 8 / TM_, int ST_ = 3, int BK_ = 32>
+// X2 (the split engine, precision bf16x3: "two stored terms, three products"): every operand value is stored as TWO bf16
+// terms, interleaved in groups of 32 -- element k of a row lies at il32(k) = (k / 32) * 64 + k % 32, its low term 32 elements
+// further -- so that a 64-element stage row is one contiguous 128-byte line holding [hi of 32 k | lo of the same 32 k].  A
+// k-step reads a_hi, a_lo, b_hi, b_lo ONCE and issues hi hi + hi lo + lo hi from those registers: 4 fragment sets per 3 MFMA
+// groups (the three-term form of round 2-5 -- [hi | hi | lo] x [hi | lo | hi] rows through the plain loop -- staged and read 6).
+template <int WN, int TM_ = 2, int WM_ = 8 / TM_, int ST_ = 3, int BK_ = 32, bool X2_ = false>
 struct MmaBT {
   typedef TileCfgT<WN, TM_, WM_, ST_, BK_> Cfg;
   static constexpr int BK = BK_;
+  static constexpr bool X2 = X2_;
+  static_assert(!X2_ || BK_ == 64, "split engine: 64-element stage rows (32 k of hi | lo)");
   static constexpr int TM = TM_, TN = 4, WAVES_M = Cfg::WAVES_M, WAVES_N = 1, BM = Cfg::BM, BN = Cfg::BN;  // WAVES_N: per wave column
   static constexpr int WROWS = 32 * TM;  // rows of a wave tile
   f32x16 acc[TM][TN];
@@ -111,6 +118,39 @@ struct MmaBT {
 
   // row images, BK-element rows, chunk c of row r stored at chunk c ^ row_swz<BK>(r)
   __device__ __forceinline__ void compute_rows(const bf16_t* __restrict__ As, const bf16_t* __restrict__ Bs) {
+    if constexpr (X2) {  // chunks 0..3 of a stage row: hi of 32 k, chunks 4..7: lo
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        Pack8 ah[TM], al[TM], bh[TN], bl[TN];
+        const int c = 2 * ks + hf;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int r = wave * WROWS + i * 32 + l31;
+          ah[i].f = *reinterpret_cast<const f32x4*>(As + r * 64 + ((c ^ row_swz<64>(r)) << 3));
+          al[i].f = *reinterpret_cast<const f32x4*>(As + r * 64 + (((c + 4) ^ row_swz<64>(r)) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int r = wn * 128 + j * 32 + l31;
+          bh[j].f = *reinterpret_cast<const f32x4*>(Bs + r * 64 + ((c ^ row_swz<64>(r)) << 3));
+          bl[j].f = *reinterpret_cast<const f32x4*>(Bs + r * 64 + (((c + 4) ^ row_swz<64>(r)) << 3));
+        }
+        // (term-major: the TM x TN independent accumulators between two MFMAs on the same one)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mfma(acc[i][j], al[i].b, bh[j].b);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mfma(acc[i][j], ah[i].b, bl[j].b);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mfma(acc[i][j], ah[i].b, bh[j].b);
+      }
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       Pack8 a[TM], b[TN];
@@ -202,6 +242,84 @@ struct MmaBT {
   __device__ __forceinline__ int col_of(int j) const { return wn * 128 + j * 32 + l31; }
 };
 typedef MmaBT<1> MmaB;
+
+// ---- the split engine's k-major tile (the weight gradient) ---------------------------------------
+// 256 x 256 output tile, 8 waves (4 x 2), wave tile 64 x 128 like MmaBT<2>.  Both operands are k-major in memory with their
+// columns in the il32 two-term layout, so a 256-column logical tile is 512 PHYSICAL columns: a stage is 16 k-rows (one
+// k-step of 16 sequence rows) x 512 columns x 2 operands = 32 KB, four stages.  Per stage a wave reads a_hi, a_lo (2 row
+// tiles) and b_hi, b_lo (4 column tiles) -- 12 fragments, 24 transposing reads -- for 24 MFMAs; the three-term form read 18
+// fragments per 24 MFMAs and staged 1.5x the bytes.
+struct DwX2Cfg {
+  static constexpr int TM = 2, WAVES_M = 4, NWAVES = 8, BM = 256, BN = 256, KR = 16, PCOLS = 512, STAGES = 4, NT = 512;
+  static constexpr int A_ELEMS = KR * PCOLS, B_ELEMS = KR * PCOLS, STAGE_ELEMS = A_ELEMS + B_ELEMS;
+  static constexpr int LDS_BYTES = STAGES * STAGE_ELEMS * 2;  // 131,072
+  static constexpr int A_GLDS = A_ELEMS * 2 / 1024 / NWAVES, B_GLDS = B_ELEMS * 2 / 1024 / NWAVES;  // 2 + 2
+};
+struct MmaX2K {
+  typedef DwX2Cfg Cfg;
+  static constexpr int TM = 2, TN = 4, WROWS = 64, BM = 256, BN = 256;
+  f32x16 acc[TM][TN];
+  int wave_all, wave, wn, lane, l31, hf;
+  __device__ __forceinline__ void init(int tid) {
+    wave_all = tid >> 6;
+    wave = wave_all % 4;
+    wn = wave_all / 4;
+    lane = tid & 63;
+    l31 = lane & 31;
+    hf = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  // image [16 k][512 physical columns], chunk c of k-row k stored at c ^ ((k & 3) << 2) (KMajorSrc<512, .>); the fragment of
+  // the 32 physical columns from pbase, k-rows 0..15 -- read exactly as MmaBT::tr_frag reads a 16-k block
+  __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* img, int pbase) const {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int k0 = 8 * (g >> 1) + q;
+    const int col = pbase + 16 * (g & 1) + 4 * p;
+    const int off = (((col >> 3) ^ (q << 2)) << 3) + (col & 7);
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + k0 * Cfg::PCOLS + off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + (k0 + 4) * Cfg::PCOLS + off));
+    Pack8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      r.s[e] = lo[e];
+      r.s[e + 4] = hi[e];
+    }
+    return r.b;
+  }
+  __device__ __forceinline__ void compute_kmajor(const bf16_t* __restrict__ As, const bf16_t* __restrict__ Bs) {
+    bf16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {  // logical row tile (wave, i) = physical columns 64 (2 wave + i) .. : [hi 32 | lo 32]
+      ah[i] = tr_frag(As, 64 * (2 * wave + i));
+      al[i] = tr_frag(As, 64 * (2 * wave + i) + 32);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bh[j] = tr_frag(Bs, 64 * (4 * wn + j));
+      bl[j] = tr_frag(Bs, 64 * (4 * wn + j) + 32);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+  }
+  __device__ __forceinline__ int row_of(int i, int r) const { return wave * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf; }
+  __device__ __forceinline__ int col_of(int j) const { return wn * 128 + j * 32 + l31; }
+};
 
 // ---- per-lane DMA source offsets ---------------------------------------------------------------
 // Row image of ROWS rows: wave-instruction n (0 .. ROWS/16-1) fills LDS chunks [64n, 64n+64): unit
@@ -358,7 +476,7 @@ __device__ __forceinline__ void glds_mainloop(Mma& mma, Issue&& issue, int ntile
     if (t + S - 1 < ntiles) issue(t + S - 1, a_stage(t + S - 1), a_stage(t + S - 1) + TileCfg::A_ELEMS);
     FVTA_LS(2);
     const bf16_t* As = a_stage(t);
-    if (KMAJOR)
+    if constexpr (KMAJOR)
       mma.compute_kmajor(As, As + TileCfg::A_ELEMS);
     else
       mma.compute_rows(As, As + TileCfg::A_ELEMS);

@@ -39,8 +39,9 @@ static void allow_big_lds(K kernel, int bytes) {  // > 64 KB of dynamic LDS must
 
 // ---- weight shadows in the internal row order [x rows | ones row | zero pad | h rows] -----------
 // kernel [in+d][N4] fp32 -> wb [in_i+d][xm N4] bf16, wt [N4][xm (in_i+d)] bf16.  grid (N4/32, (in_i+d)/32), 256 threads
-// xm = 3 (split engine): wt rows hold (hi, lo, hi) thirds per operand part -- [x: in_i | in_i | in_i][h: d | d | d], the
-// order the (hi, hi, lo) activation shadows pair with -- and wb rows (hi, hi, lo) thirds of N4, pairing with dz's (hi, lo, hi).
+// xm = 2 (split engine): two terms per value in the il32 layout (gemm_bf16.h) -- element e of a row at (e / 32) * 64 + e % 32,
+// its low term 32 further; a wt row is [x part: il32 of in_i][h part: il32 of d] (a k-tile is wholly x or wholly h).
+__device__ __forceinline__ int il32(int e) { return ((e >> 5) << 6) + (e & 31); }
 __global__ void cvt_weights_kernel(const float* __restrict__ W, bf16_t* __restrict__ wt, bf16_t* __restrict__ wb,
                                    int in, int in_i, int d, int xm) {
   __shared__ float tile[32][33];
@@ -55,10 +56,11 @@ __global__ void cvt_weights_kernel(const float* __restrict__ W, bf16_t* __restri
     const int c = 4 * (n % d) + n / d;  // column g*d+u -> 4u+g: dz rows are unit-major
     const bf16_t hi = f2bf(v);
     bf16_t* row = wb + (size_t)k * N4 * xm;
-    row[c] = hi;
-    if (xm == 3) {
-      row[N4 + c] = hi;
-      row[2 * N4 + c] = f2bf(v - bf2f(hi));
+    if (xm == 1) {
+      row[c] = hi;
+    } else {
+      row[il32(c)] = hi;
+      row[il32(c) + 32] = f2bf(v - bf2f(hi));
     }
   }
   __syncthreads();
@@ -69,11 +71,10 @@ __global__ void cvt_weights_kernel(const float* __restrict__ W, bf16_t* __restri
     bf16_t* row = wt + (size_t)(n0 + r) * Ki * xm;
     if (xm == 1) {
       row[k] = hi;
-    } else {  // part base, part width: the x part's thirds are in_i wide, the h part's d
-      const int base = k < in_i ? 0 : 3 * in_i, wd = k < in_i ? in_i : d, kk = k < in_i ? k : k - in_i;
-      row[base + kk] = hi;
-      row[base + wd + kk] = f2bf(v - bf2f(hi));
-      row[base + 2 * wd + kk] = hi;
+    } else {
+      const int base = k < in_i ? 0 : 2 * in_i, kk = k < in_i ? k : k - in_i;
+      row[base + il32(kk)] = hi;
+      row[base + il32(kk) + 32] = f2bf(v - bf2f(hi));
     }
   }
 }
@@ -86,7 +87,7 @@ void launch_cvt_weights_bf16(const float* W, bf16_t* wt, bf16_t* wb, int in, int
 // Sixteen lanes per (sorted row i, position pos), 16 bytes of the fp32 row per lane and pass: the row is read ONCE and
 // written to both places it is needed -- step pos of the forward direction and step len - 1 - pos of the backward
 // direction (reverse_sequence).
-// xm = 3 (split engine): the shadow row holds (hi, hi, lo) thirds of in_i.
+// xm = 2 (split engine): the shadow row holds two terms per value in the il32 layout.
 __global__ __launch_bounds__(256) void cvt_x_kernel(PlanView pv, const float* __restrict__ x, bf16_t* __restrict__ xs, int B,
                                                     int J, int in, int in_i, int xm) {
   const int pos = blockIdx.y;
@@ -121,13 +122,14 @@ __global__ __launch_bounds__(256) void cvt_x_kernel(PlanView pv, const float* __
       l[e] = (short)f2bf(v[e] - bf2f((bf16_t)o[e]));
       lb[e] = (short)f2bf(vb[e] - bf2f((bf16_t)ob[e]));
     }
-    *reinterpret_cast<bf16x4*>(dst_fw + c) = o;
-    *reinterpret_cast<bf16x4*>(dst_bw + c) = ob;
-    if (xm == 3) {
-      *reinterpret_cast<bf16x4*>(dst_fw + in_i + c) = o;
-      *reinterpret_cast<bf16x4*>(dst_bw + in_i + c) = ob;
-      *reinterpret_cast<bf16x4*>(dst_fw + 2 * in_i + c) = l;
-      *reinterpret_cast<bf16x4*>(dst_bw + 2 * in_i + c) = lb;
+    if (xm == 1) {
+      *reinterpret_cast<bf16x4*>(dst_fw + c) = o;
+      *reinterpret_cast<bf16x4*>(dst_bw + c) = ob;
+    } else {  // (c is a multiple of 4: the four values share an il32 group)
+      *reinterpret_cast<bf16x4*>(dst_fw + il32(c)) = o;
+      *reinterpret_cast<bf16x4*>(dst_bw + il32(c)) = ob;
+      *reinterpret_cast<bf16x4*>(dst_fw + il32(c) + 32) = l;
+      *reinterpret_cast<bf16x4*>(dst_bw + il32(c) + 32) = lb;
     }
   }
 }
@@ -142,8 +144,11 @@ void launch_cvt_x_bf16(const PlanView& pv, const float* x, bf16_t* xs, int B, in
 // epilogue.  It serves the shapes lstm_wreg.hip is not built for (launch_step_fwd_wreg returns false); at the metric
 // shape the weights-in-registers kernel runs instead.
 // grid (pad8(row tiles), d/32, 2), 256 threads, two workgroups per CU
-__global__ __launch_bounds__(256, 2) void lstm_step_fwd_bf16(StepArgs a) {
-  typedef TileCfgT<1> Cfg;
+// XM = 2 (split engine): 64-element stage rows (32 k of hi | lo), two stages of 48 KB, the plain loop
+template <int XM>
+__global__ __launch_bounds__(256, XM == 1 ? 2 : 1) void lstm_step_fwd_bf16(StepArgs a) {
+  typedef TileCfgT<1, 2, 4, XM == 1 ? 3 : 2, XM == 1 ? 32 : 64> Cfg;
+  constexpr int BK = Cfg::BK;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + Cfg::STAGES * Cfg::STAGE_ELEMS);  // [256], same array
   const int dir = blockIdx.z, t = a.t;
@@ -157,30 +162,31 @@ __global__ __launch_bounds__(256, 2) void lstm_step_fwd_bf16(StepArgs a) {
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
   for (int r = tid; r < Cfg::BM; r += Cfg::NT) s_oo[r] = (m0 + r < nact) ? a.plan.oo[trow + m0 + r] : -1;
 
-  MmaBT<1> mma;
+  MmaBT<1, 2, 4, Cfg::STAGES, BK, XM == 2> mma;
   mma.init(tid);
   const int u0 = ub;
   // A rows m0.. of xs[dir][t] (nact rows) and of hs[dir][t-1]; B rows = the 4 gate strips of wt
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xs + trow * in_k, (unsigned)nact * in_k * 2);
   const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (t > 0 ? trow - a.B : trow) * d_k, (unsigned)nact * d_k * 2);
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.Wt[dir], (unsigned)(4 * d) * Kk * 2);
-  RowSrc<Cfg::A_GLDS> ax, ah;
-  RowSrc<Cfg::B_GLDS> bw;
+  RowSrc<Cfg::A_GLDS, BK> ax, ah;
+  RowSrc<Cfg::B_GLDS, BK> bw;
   ax.setup(mma.wave_all, mma.lane, m0, nact, in_k * 2);
   ah.setup(mma.wave_all, mma.lane, m0, nact, d_k * 2);
 #pragma unroll
   for (int j = 0; j < Cfg::B_GLDS; ++j) {  // B row r = gate strip (r>>5)&3, unit ub + (r&31)
+    constexpr int CPR = BK / 8;
     const int U = (mma.wave_all * Cfg::B_GLDS + j) * 64 + mma.lane;
-    const int r = U >> 2, c = (U & 3) ^ ((r >> 2) & 3);
+    const int r = U / CPR, c = (U % CPR) ^ row_swz<BK>(r);
     bw.voff[j] = (unsigned)(((r >> 5) & 3) * d + ub + (r & 31)) * (unsigned)(Kk * 2) + 16u * c;
   }
-  const int nx = in_k / 32, nt = (t == 0) ? nx : nx + d_k / 32;
+  const int nx = in_k / BK, nt = (t == 0) ? nx : nx + d_k / BK;
   auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
     if (tile < nx)
-      ax.issue(rx, As, mma.wave_all, tile * 64);
+      ax.issue(rx, As, mma.wave_all, tile * (BK * 2));
     else
-      ah.issue(rh, As, mma.wave_all, (tile - nx) * 64);
-    bw.issue(rw, Bs, mma.wave_all, tile * 64);
+      ah.issue(rh, As, mma.wave_all, (tile - nx) * (BK * 2));
+    bw.issue(rw, Bs, mma.wave_all, tile * (BK * 2));
   };
   // c_{t-1} of the wave's rows, row-contiguous (16 B per lane), requested before the k-loop hides their latency
   f32x4 cprev[2][4];
@@ -194,17 +200,25 @@ __global__ __launch_bounds__(256, 2) void lstm_step_fwd_bf16(StepArgs a) {
         cprev[ti][it] = *reinterpret_cast<const f32x4*>(src + (size_t)i * d + u0 + 4 * (mma.lane & 7));
       }
   }
-  glds_mainloop_sp(mma, issue, nt, smem_h);
+  if constexpr (XM == 1)
+    glds_mainloop_sp(mma, issue, nt, smem_h);
+  else
+    glds_mainloop<false>(mma, issue, nt, smem_h);
   __syncthreads();  // s_oo visible; every wave is done with the stage buffers, which become the epilogue's scratch
   lstm_gate_epilogue_staged(mma, a, dir, m0, u0, nact, trow, s_oo, cprev, reinterpret_cast<char*>(smem_h) + mma.wave_all * 9216, t);
 }
 
-static constexpr int FWD_LDS = TileCfg::LDS_BYTES + 256 * 8;
-
 void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s) {
-  allow_big_lds(lstm_step_fwd_bf16, FWD_LDS);
   const dim3 grid(pad8((a.B + 255) / 256), a.d / 32, 2);
-  hipLaunchKernelGGL(lstm_step_fwd_bf16, grid, dim3(256), FWD_LDS, s, a);
+  if (a.xm == 1) {
+    constexpr int LDS = TileCfg::LDS_BYTES + 256 * 8;
+    allow_big_lds(lstm_step_fwd_bf16<1>, LDS);
+    hipLaunchKernelGGL(lstm_step_fwd_bf16<1>, grid, dim3(256), LDS, s, a);
+  } else {
+    constexpr int LDS = TileCfgT<1, 2, 4, 2, 64>::LDS_BYTES + 256 * 8;
+    allow_big_lds(lstm_step_fwd_bf16<2>, LDS);
+    hipLaunchKernelGGL(lstm_step_fwd_bf16<2>, grid, dim3(256), LDS, s, a);
+  }
 }
 
 
@@ -241,15 +255,15 @@ __device__ __forceinline__ int kt_rot(int nkt) {
 // covers 4 RPW rows -- tile row r is global row m0 + (r / 64) RPW + r % 64, rows r % 64 >= RPW are padding (zero operand rows,
 // their epilogue passes compiled out) -- so that the launch's grid fills the CUs: at the metric shape 58 tiles of 224 rows
 // x 2 column tiles x 2 directions = 232 workgroups instead of 204 of 256 rows on 256 CUs, each with 7/8 of the epilogue.
-template <int WN, int WM, int XM, int BK, int ST, int RPW = 64, int EPD_ = FVTA_BWD_EPD>  // XM = 3: the split engine (three bf16 terms per operand value, fp32 saved gates)
+template <int WN, int WM, int XM, int BK, int ST, int RPW = 64, int EPD_ = FVTA_BWD_EPD>  // XM = 2: the split engine (two stored bf16 terms per operand value, three products; fp32 saved gates)
 __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t, int dir, int m0, int u0, bf16_t* smem_h) {
   static_assert(RPW == 64 || (WM == 4 && RPW % 8 == 0 && RPW > 32 && RPW < 64), "rows per wave tile");
   auto grow_of = [&](int r) { return RPW == 64 ? m0 + r : m0 + (r >> 6) * RPW + (r & 63); };  // tile row -> global sorted row
   typedef TileCfgT<WN, 2, WM, ST, BK> TileCfg;
-  typedef MmaBT<WN, 2, WM, ST, BK> MmaB;
+  typedef MmaBT<WN, 2, WM, ST, BK, XM == 2> MmaB;
   int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + (size_t)TileCfg::STAGES * TileCfg::STAGE_ELEMS);
   const int tid = (int)threadIdx.x;
-  const int d = a.d, N4 = 4 * d, K = N4 * XM;  // K: the dz row (split engine: (hi, lo, hi) thirds of 4d)
+  const int d = a.d, N4 = 4 * d, K = N4 * XM;  // K: the dz row (split engine: two terms per value, il32 layout)
   const int nact = a.plan.nactive[t];
   if (m0 >= nact) return;
   const int nnext = (t + 1 < a.J) ? a.plan.nactive[t + 1] : 0;
@@ -386,7 +400,7 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
       const bf16_t hi_i = f2bf(dzi), hi_j = f2bf(dzj), hi_f = f2bf(dzf), hi_o = f2bf(dzo);
       const unsigned z0 = (unsigned)hi_i | ((unsigned)hi_j << 16), z1 = (unsigned)hi_f | ((unsigned)hi_o << 16);
       unsigned l0 = 0, l1 = 0;
-      if constexpr (XM == 3) {
+      if constexpr (XM == 2) {
         l0 = (unsigned)f2bf(dzi - bf2f(hi_i)) | ((unsigned)f2bf(dzj - bf2f(hi_j)) << 16);
         l1 = (unsigned)f2bf(dzf - bf2f(hi_f)) | ((unsigned)f2bf(dzo - bf2f(hi_o)) << 16);
       }
@@ -398,7 +412,10 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
       dco[e] = dc * fg;
     }
     if (i < nact && u < d && (!(abl & 2) || dco[0] == 1234.5f)) {
-      const gf4_ptr zp = (gf4_ptr)(dz_base + ((size_t)i * K + 4 * u) * sizeof(bf16_t));   // (16-byte units below)
+      // dz element 4u + g; split engine: il32 -- the lane's four units (16 elements, u a multiple of 4) share a group of 32:
+      // hi at 2 (4u) - (4u) % 32, i.e. ((4u) / 32) * 64 + (4u) % 32, lo 32 elements (four 16-byte units) further
+      const size_t e0 = XM == 1 ? (size_t)(4 * u) : (size_t)(((4 * u) >> 5) << 6) + ((4 * u) & 31);
+      const gf4_ptr zp = (gf4_ptr)(dz_base + ((size_t)i * K + e0) * sizeof(bf16_t));   // (16-byte units below)
       if ((ntb & 2) != 0) {
         __builtin_nontemporal_store(__builtin_bit_cast(f32x4, za), zp);
         __builtin_nontemporal_store(__builtin_bit_cast(f32x4, zb), zp + 1);
@@ -406,11 +423,9 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
         zp[0] = __builtin_bit_cast(f32x4, za);
         zp[1] = __builtin_bit_cast(f32x4, zb);
       }
-      if constexpr (XM == 3) {  // (hi, lo, hi) thirds of 4d bf16 = 2d floats = d / 2 sixteen-byte units
-        zp[d / 2] = __builtin_bit_cast(f32x4, la);
-        zp[d / 2 + 1] = __builtin_bit_cast(f32x4, lb);
-        zp[d] = __builtin_bit_cast(f32x4, za);
-        zp[d + 1] = __builtin_bit_cast(f32x4, zb);
+      if constexpr (XM == 2) {
+        zp[4] = __builtin_bit_cast(f32x4, la);
+        zp[5] = __builtin_bit_cast(f32x4, lb);
       }
       st16(dcs + (size_t)i * d + u, dco, (ntb & 4) != 0);
     }
@@ -434,7 +449,7 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
 }
 
 template <int WN, int WM = 4, int XM = 1, int BK = 32, int ST = 3, int RPW = 64>
-__global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
+__global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 && XM == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   typedef TileCfgT<WN, 2, WM, ST, BK> TileCfg;
   lstm_bwd_tile_step<WN, WM, XM, BK, ST, RPW>(a, a.t, blockIdx.z, blockIdx.x * (RPW == 64 ? TileCfg::BM : 4 * RPW), blockIdx.y * TileCfg::BN, smem_h);
@@ -451,53 +466,46 @@ static int bwd_cus() {
 
 template <int XM>
 static void launch_bwd_fused_xm(const FusedBwdArgs& a, hipStream_t s) {
+  // narrow tiles: 32-deep stages x 3; split engine: 64-element stage rows (32 k of hi | lo) x 2
+  constexpr int NBK = XM == 1 ? 32 : 64, NST = XM == 1 ? 3 : 2;
   if (a.B <= 64) {  // few sequences (the photo cell): row tiles of 64 / 128
-    constexpr int LDS = TileCfgT<1, 2, 1>::LDS_BYTES + 64 * 8;
-    allow_big_lds(lstm_bwd_fused_bf16<1, 1, XM>, LDS);
-    hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 1, XM>), dim3((a.B + 63) / 64, (a.d + 127) / 128, 2), dim3(64), LDS, s, a);
+    constexpr int LDS = TileCfgT<1, 2, 1, NST, NBK>::LDS_BYTES + 64 * 8;
+    allow_big_lds(lstm_bwd_fused_bf16<1, 1, XM, NBK, NST>, LDS);
+    hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 1, XM, NBK, NST>), dim3((a.B + 63) / 64, (a.d + 127) / 128, 2), dim3(64), LDS, s, a);
   } else if (a.B <= 128) {
-    constexpr int LDS = TileCfgT<1, 2, 2>::LDS_BYTES + 128 * 8;
-    allow_big_lds(lstm_bwd_fused_bf16<1, 2, XM>, LDS);
-    hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 2, XM>), dim3((a.B + 127) / 128, (a.d + 127) / 128, 2), dim3(128), LDS, s, a);
+    constexpr int LDS = TileCfgT<1, 2, 2, NST, NBK>::LDS_BYTES + 128 * 8;
+    allow_big_lds(lstm_bwd_fused_bf16<1, 2, XM, NBK, NST>, LDS);
+    hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 2, XM, NBK, NST>), dim3((a.B + 127) / 128, (a.d + 127) / 128, 2), dim3(128), LDS, s, a);
   } else if (a.d % 256 == 0 && !(a.nact_hint >= 0 && 4 * ((a.nact_hint + 255) / 256) <= 160)) {
     // 256 x 256 tile: dz (the A operand, K = 4d wide) is re-read d/256 instead of d/128 times.  NOT for a step whose
     // active rows (the host's lengths, when it has them: fvta_bilstm_bwd_hint) fill at most 160 of the CUs with such
     // tiles: a launch lasts as long as one workgroup's chain of 64 k-tiles plus its epilogue, and the 256 x 128 tiles, two
     // workgroups per CU, spread the same rows over twice as many (ragged batches: 7.06 -> 6.74 ms per step; dense
     // batches keep the wide tile: 5.48 vs 5.72 ms per backward)
-#ifndef FVTA_BWD_BK
-#define FVTA_BWD_BK 64
-#endif
-    constexpr int BK = FVTA_BWD_BK, ST = BK == 64 ? 2 : 3;
-    if ((4 * a.d * XM) % BK == 0) {
-      constexpr int LDS = TileCfgT<2, 2, 4, ST, BK>::LDS_BYTES + 256 * 8;
-      // row tiles of 224 rows (RPW 56) when the 256-row tiles leave CUs idle that the 224-row tiles would use: one dispatch
-      // round either way (-DFVTA_BWD_RPW=64: off)
+    constexpr int BK = 64, ST = 2;      // whole-line DMA pieces (gemm_bf16.h); 4d XM is a multiple of 64
+    constexpr int LDS = TileCfgT<2, 2, 4, ST, BK>::LDS_BYTES + 256 * 8;
+    // row tiles of 224 rows (RPW 56) when the 256-row tiles leave CUs idle that the 224-row tiles would use: one dispatch
+    // round either way (-DFVTA_BWD_RPW=64, or FVTA_BWD_RPW=64 in the environment: off)
 #ifndef FVTA_BWD_RPW
 #define FVTA_BWD_RPW 56
 #endif
-      constexpr int RPW = FVTA_BWD_RPW;
-      if constexpr (RPW != 64) {
-        const int rows = a.nact_hint >= 0 ? a.nact_hint : a.B, percol = 2 * (a.d / 256), cus = bwd_cus();
-        const int t256 = (rows + 255) / 256 * percol, tr = (rows + 4 * RPW - 1) / (4 * RPW) * percol;
-        static const bool rpw_on = [] { const char* e = getenv("FVTA_BWD_RPW"); return !(e && e[0] == '6' && e[1] == '4'); }();  // A/B runs
-        if (rpw_on && t256 <= cus && tr <= cus && tr > t256) {
-          allow_big_lds(lstm_bwd_fused_bf16<2, 4, XM, BK, ST, RPW>, LDS);
-          hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4, XM, BK, ST, RPW>), dim3(pad8((a.B + 4 * RPW - 1) / (4 * RPW)), a.d / 256, 2), dim3(512), LDS, s, a);
-          return;
-        }
+    constexpr int RPW = FVTA_BWD_RPW;
+    if constexpr (RPW != 64) {
+      const int rows = a.nact_hint >= 0 ? a.nact_hint : a.B, percol = 2 * (a.d / 256), cus = bwd_cus();
+      const int t256 = (rows + 255) / 256 * percol, tr = (rows + 4 * RPW - 1) / (4 * RPW) * percol;
+      static const bool rpw_on = [] { const char* e = getenv("FVTA_BWD_RPW"); return !(e && e[0] == '6' && e[1] == '4'); }();  // A/B runs
+      if (rpw_on && t256 <= cus && tr <= cus && tr > t256) {
+        allow_big_lds(lstm_bwd_fused_bf16<2, 4, XM, BK, ST, RPW>, LDS);
+        hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4, XM, BK, ST, RPW>), dim3(pad8((a.B + 4 * RPW - 1) / (4 * RPW)), a.d / 256, 2), dim3(512), LDS, s, a);
+        return;
       }
-      allow_big_lds(lstm_bwd_fused_bf16<2, 4, XM, BK, ST>, LDS);
-      hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4, XM, BK, ST>), dim3(pad8((a.B + 255) / 256), a.d / 256, 2), dim3(512), LDS, s, a);
-      return;
     }
-    constexpr int LDS = TileCfgT<2>::LDS_BYTES + 256 * 8;
-    allow_big_lds(lstm_bwd_fused_bf16<2, 4, XM>, LDS);
-    hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4, XM>), dim3(pad8((a.B + 255) / 256), a.d / 256, 2), dim3(512), LDS, s, a);
+    allow_big_lds(lstm_bwd_fused_bf16<2, 4, XM, BK, ST>, LDS);
+    hipLaunchKernelGGL((lstm_bwd_fused_bf16<2, 4, XM, BK, ST>), dim3(pad8((a.B + 255) / 256), a.d / 256, 2), dim3(512), LDS, s, a);
   } else {
-    constexpr int LDS = TileCfgT<1>::LDS_BYTES + 256 * 8;
-    allow_big_lds(lstm_bwd_fused_bf16<1, 4, XM>, LDS);
-    hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 4, XM>), dim3(pad8((a.B + 255) / 256), (a.d + 127) / 128, 2), dim3(256), LDS, s, a);
+    constexpr int LDS = TileCfgT<1, 2, 4, NST, NBK>::LDS_BYTES + 256 * 8;
+    allow_big_lds(lstm_bwd_fused_bf16<1, 4, XM, NBK, NST>, LDS);
+    hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 4, XM, NBK, NST>), dim3(pad8((a.B + 255) / 256), (a.d + 127) / 128, 2), dim3(256), LDS, s, a);
   }
 }
 
@@ -505,8 +513,8 @@ extern long long g_bwd_step_counts[3];  // lstm_wreg_bwd.hip
 void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
   if (launch_bwd_wreg(a, s)) return;  // few rows: the weights-stationary step
   if (a.B > 64) ++g_bwd_step_counts[0];  // (calls of more than 64 sequences: the photo cell's 64 rows are not what the roofline is quoted for)
-  if (a.xm == 3)
-    launch_bwd_fused_xm<3>(a, s);
+  if (a.xm == 2)
+    launch_bwd_fused_xm<2>(a, s);
   else
     launch_bwd_fused_xm<1>(a, s);
 }
@@ -525,10 +533,10 @@ void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
 // NOACC: the launcher's promise that accumulate == 0, at compile time -- as a run-time `if (accumulate) old = load(dst)` every
 // row group's store sat behind an s_waitcnt vmcnt(0) that also waits for every EARLIER store of the wave: 56 store round trips
 // per wave tile, one after the other (the same pattern cost the attention backward 17 % in round 4).
-template <int WN, int BK, int ST, bool BOTH = false, bool NOACC = false>
-__global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dx_bf16(FusedBwdArgs a, int dir, int accumulate) {
+template <int WN, int BK, int ST, bool BOTH = false, bool NOACC = false, int XM = 1>
+__global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 && XM == 1 ? 2 : 1)) void lstm_dx_bf16(FusedBwdArgs a, int dir, int accumulate) {
   typedef TileCfgT<WN, 2, 4, ST, BK> TileCfg;
-  typedef MmaBT<WN, 2, 4, ST, BK> MmaB;
+  typedef MmaBT<WN, 2, 4, ST, BK, XM == 2> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   const int tid = threadIdx.x;
   const int t = blockIdx.z;
@@ -662,15 +670,17 @@ static bool dx_wide_both(const FusedBwdArgs& a) {
 }
 bool dx_writes_whole_rows(const FusedBwdArgs& a) { return dx_wide_both(a); }
 
-void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
+template <int XM>
+static void launch_dx_xm(const FusedBwdArgs& a, hipStream_t s) {
   if (FVTA_DX_WIDE && a.in > 128 && a.in <= 256 && (4 * a.d * a.xm) % 64 == 0) {
 #ifndef FVTA_DX_BK
 #define FVTA_DX_BK 64
 #define FVTA_DX_ST 2
 #endif
+    static_assert(XM == 1 || FVTA_DX_BK == 64, "split engine: 64-element stage rows");
     typedef TileCfgT<2, 2, 4, FVTA_DX_ST, FVTA_DX_BK> Cfg;
     constexpr int LDS = Cfg::LDS_BYTES + 256 * 8;
-    allow_big_lds(lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST>, LDS);
+    allow_big_lds(lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, false, false, XM>, LDS);
     const dim3 grid(pad8((a.B + 255) / 256), 1, a.J);
     // both directions in one launch when one descriptor covers a direction's dz (the kernel falls back by itself when the
     // directions have separate inputs)
@@ -678,24 +688,32 @@ void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
       FusedBwdArgs b = a;
       b.dx_both = 1;
       if (!a.dx_accumulate) {
-        allow_big_lds(lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true, true>, LDS);
-        hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true, true>), grid, dim3(512), LDS, s, b, 0, 0);
+        allow_big_lds(lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true, true, XM>, LDS);
+        hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true, true, XM>), grid, dim3(512), LDS, s, b, 0, 0);
       } else {
-        allow_big_lds(lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true>, LDS);
-        hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true>), grid, dim3(512), LDS, s, b, 0, a.dx_accumulate);
+        allow_big_lds(lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true, false, XM>, LDS);
+        hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, true, false, XM>), grid, dim3(512), LDS, s, b, 0, a.dx_accumulate);
       }
-      hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST>), grid, dim3(512), LDS, s, b, 1, a.dx_accumulate);  // (separate inputs: its own dx copy)
+      hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, false, false, XM>), grid, dim3(512), LDS, s, b, 1, a.dx_accumulate);  // (separate inputs: its own dx copy)
       return;
     }
     for (int dir = 0; dir < 2; ++dir)
-      hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST>), grid, dim3(512), LDS, s, a, dir, a.dx_accumulate || dir);
+      hipLaunchKernelGGL((lstm_dx_bf16<2, FVTA_DX_BK, FVTA_DX_ST, false, false, XM>), grid, dim3(512), LDS, s, a, dir, a.dx_accumulate || dir);
     return;
   }
-  constexpr int LDS1 = TileCfg::LDS_BYTES + 256 * 8;
-  allow_big_lds(lstm_dx_bf16<1, 32, 3>, LDS1);
+  constexpr int NBK = XM == 1 ? 32 : 64, NST = XM == 1 ? 3 : 2;
+  constexpr int LDS1 = TileCfgT<1, 2, 4, NST, NBK>::LDS_BYTES + 256 * 8;
+  allow_big_lds(lstm_dx_bf16<1, NBK, NST, false, false, XM>, LDS1);
   const dim3 grid(pad8((a.B + 255) / 256), (a.in + 127) / 128, a.J);
   for (int dir = 0; dir < 2; ++dir)
-    hipLaunchKernelGGL((lstm_dx_bf16<1, 32, 3>), grid, dim3(256), LDS1, s, a, dir, a.dx_accumulate || dir);
+    hipLaunchKernelGGL((lstm_dx_bf16<1, NBK, NST, false, false, XM>), grid, dim3(256), LDS1, s, a, dir, a.dx_accumulate || dir);
+}
+
+void launch_dx_bf16(const FusedBwdArgs& a, hipStream_t s) {
+  if (a.xm == 2)
+    launch_dx_xm<2>(a, s);
+  else
+    launch_dx_xm<1>(a, s);
 }
 
 // -------------------------------------------------------- weight gradient --
@@ -739,11 +757,11 @@ __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dw
   sb.setup(mma.wave_all, mma.lane, n0, N4, (unsigned)N4 * 2);
   const int t_begin = split * a.tgroup, t_end = min(a.J, t_begin + a.tgroup);
   for (int t = t_begin; t < t_end; ++t) {
-    const int nact = a.plan.nactive[t] * a.xm;  // k-rows: a sequence row's xm terms are xm consecutive rows of both operands
+    const int nact = a.plan.nactive[t];  // k-rows = sequence rows
     if (nact == 0) break;
     if (!isx && t == 0) continue;  // h_{-1} = 0
-    const size_t trow = ((size_t)dir * a.J + t) * a.B * a.xm;
-    const bf16_t* A = isx ? a.xs + trow * in_i : a.hs + (trow - (size_t)a.B * a.xm) * d;
+    const size_t trow = ((size_t)dir * a.J + t) * a.B;
+    const bf16_t* A = isx ? a.xs + trow * in_i : a.hs + (trow - (size_t)a.B) * d;
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(A, (unsigned)nact * ncols * 2);
     const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + trow * (size_t)N4, (unsigned)nact * N4 * 2);
     auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
@@ -766,8 +784,69 @@ __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 ? 2 : 1)) void lstm_dw
     }
 }
 
+// The split engine's weight gradient (gemm_bf16.h: DwX2Cfg / MmaX2K): the same slices, tiles and slabs; both operands' rows are
+// il32 two-term rows, so a 256-column logical tile is 512 physical columns and a stage holds 16 sequence rows.
+__global__ __launch_bounds__(512, 1) void lstm_dw_x2(DwArgs a) {
+  typedef DwX2Cfg TileCfg;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
+  const int tid = threadIdx.x;
+  const int d = a.d, in_i = a.in_i, N4 = 4 * d;
+  const int xtiles = (in_i + TileCfg::BM - 1) / TileCfg::BM;
+  const int mtiles = xtiles + (d + TileCfg::BM - 1) / TileCfg::BM, ntiles = (N4 + TileCfg::BN - 1) / TileCfg::BN, per = mtiles * ntiles;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bz = xcd + 8 * (slot / per);  // slab index: dir * nsplit + split
+  const int tile_id = slot % per;
+  if (bz >= 2 * a.nsplit) return;
+  const int bx = tile_id % mtiles, by = tile_id / mtiles;
+  const bool isx = bx < xtiles;
+  const int col0 = isx ? bx * TileCfg::BM : (bx - xtiles) * TileCfg::BM;  // within x / h columns (logical)
+  const int ncols = isx ? in_i : d;
+  const int n0 = by * TileCfg::BN;
+  const int split = bz % a.nsplit, dir = bz / a.nsplit;
+  MmaX2K mma;
+  mma.init(tid);
+  KMajorSrc<TileCfg::PCOLS, TileCfg::A_GLDS> sa;
+  KMajorSrc<TileCfg::PCOLS, TileCfg::B_GLDS> sb;
+  sa.setup(mma.wave_all, mma.lane, 2 * col0, 2 * ncols, (unsigned)ncols * 4);   // physical columns: two per logical one
+  sb.setup(mma.wave_all, mma.lane, 2 * n0, 2 * N4, (unsigned)N4 * 4);
+  const int t_begin = split * a.tgroup, t_end = min(a.J, t_begin + a.tgroup);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int nact = a.plan.nactive[t];
+    if (nact == 0) break;
+    if (!isx && t == 0) continue;  // h_{-1} = 0
+    const size_t trow = ((size_t)dir * a.J + t) * a.B;
+    const bf16_t* A = isx ? a.xs + trow * (size_t)(2 * in_i) : a.hs + (trow - (size_t)a.B) * (size_t)(2 * d);
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(A, (unsigned)nact * ncols * 4);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dzb + trow * (size_t)(2 * N4), (unsigned)nact * N4 * 4);
+    auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
+      sa.issue(ra, As, mma.wave_all, (unsigned)tile * TileCfg::KR * ncols * 4u);
+      sb.issue(rz, Bs, mma.wave_all, (unsigned)tile * TileCfg::KR * N4 * 4u);
+    };
+    glds_mainloop<true>(mma, issue, (nact + TileCfg::KR - 1) / TileCfg::KR, smem_h);
+    __builtin_amdgcn_s_barrier();  // every wave is done with the ring before the next step refills it
+  }
+  float* slab = a.slabs + (size_t)bz * (in_i + d) * N4;
+  const int mrow0 = isx ? col0 : in_i + col0;
+#pragma unroll
+  for (int ti = 0; ti < MmaX2K::TM; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = mma.row_of(ti, r);
+      if (col0 + ml >= ncols) continue;
+#pragma unroll
+      for (int tj = 0; tj < MmaX2K::TN; ++tj)
+        if (n0 + mma.col_of(tj) < N4) slab[(size_t)(mrow0 + ml) * N4 + n0 + mma.col_of(tj)] = mma.acc[ti][tj][r];
+    }
+}
+
 void launch_dw_bf16(const DwArgs& a, hipStream_t s) {
   const int slices8 = (2 * a.nsplit + 7) / 8;  // slices per XCD
+  if (a.xm == 2) {  // (4d is a multiple of 128; a 256-column tile past the end stores nothing)
+    allow_big_lds(lstm_dw_x2, DwX2Cfg::LDS_BYTES);
+    const int per = ((a.in_i + 255) / 256 + (a.d + 255) / 256) * ((4 * a.d + 255) / 256);
+    hipLaunchKernelGGL(lstm_dw_x2, dim3(8 * per * slices8), dim3(512), DwX2Cfg::LDS_BYTES, s, a);
+    return;
+  }
   if ((4 * a.d) % 256 == 0) {
     constexpr int LDS2 = TileCfgT<2, 2, 4, dw_stages(2)>::LDS_BYTES;
     allow_big_lds(lstm_dw_bf16<2>, LDS2);
@@ -863,15 +942,109 @@ __global__ __launch_bounds__(256, 2) void test_gemm_bf16_kernel(int M, int N, in
     }
 }
 
+// rows of `len` fp32 values -> il32 two-term bf16 rows (2 len elements; len a multiple of 32)
+__global__ void cvt_f32_il32_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t rows, int len) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * (size_t)len) return;
+  const size_t r = i / len;
+  const int e = (int)(i % len);
+  const float v = src[i];
+  const bf16_t hi = f2bf(v);
+  bf16_t* row = dst + r * (size_t)(2 * len);
+  row[il32(e)] = hi;
+  row[il32(e) + 32] = f2bf(v - bf2f(hi));
+}
+
+// layouts 3 / 4: the split engine's row / k-major tiles on il32 two-term operands
+__global__ __launch_bounds__(256, 1) void test_gemm_x2_rows_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
+                                                                    const bf16_t* __restrict__ B, float* __restrict__ C) {
+  typedef TileCfgT<1, 2, 4, 2, 64> Cfg;
+  typedef MmaBT<1, 2, 4, 2, 64, true> Mma;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
+  const int m0 = blockIdx.x * Cfg::BM, n0 = blockIdx.y * Cfg::BN;
+  Mma mma;
+  mma.init(threadIdx.x);
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(A, (unsigned)M * K * 4), rb = make_rsrc(B, (unsigned)N * K * 4);
+  RowSrc<Cfg::A_GLDS, 64> sa;
+  RowSrc<Cfg::B_GLDS, 64> sb;
+  sa.setup(mma.wave_all, mma.lane, m0, M, K * 4);
+  sb.setup(mma.wave_all, mma.lane, n0, N, K * 4);
+  auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
+    sa.issue(ra, As, mma.wave_all, tile * 128);
+    sb.issue(rb, Bs, mma.wave_all, tile * 128);
+  };
+  glds_mainloop<false>(mma, issue, K / 32, smem_h);
+#pragma unroll
+  for (int ti = 0; ti < Mma::TM; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + mma.row_of(ti, r);
+#pragma unroll
+      for (int tj = 0; tj < Mma::TN; ++tj) {
+        const int n = n0 + mma.col_of(tj);
+        if (m < M && n < N) C[(size_t)m * N + n] = mma.acc[ti][tj][r];
+      }
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void test_gemm_x2_kmajor_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
+                                                                      const bf16_t* __restrict__ B, float* __restrict__ C) {
+  typedef DwX2Cfg Cfg;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
+  const int m0 = blockIdx.x * Cfg::BM, n0 = blockIdx.y * Cfg::BN;
+  MmaX2K mma;
+  mma.init(threadIdx.x);
+  const __amdgpu_buffer_rsrc_t ra = make_rsrc(A, (unsigned)K * M * 4), rb = make_rsrc(B, (unsigned)K * N * 4);
+  KMajorSrc<Cfg::PCOLS, Cfg::A_GLDS> sa;
+  KMajorSrc<Cfg::PCOLS, Cfg::B_GLDS> sb;
+  sa.setup(mma.wave_all, mma.lane, 2 * m0, 2 * M, (unsigned)M * 4);
+  sb.setup(mma.wave_all, mma.lane, 2 * n0, 2 * N, (unsigned)N * 4);
+  auto issue = [&](int tile, bf16_t* As, bf16_t* Bs) {
+    sa.issue(ra, As, mma.wave_all, (unsigned)tile * Cfg::KR * M * 4u);
+    sb.issue(rb, Bs, mma.wave_all, (unsigned)tile * Cfg::KR * N * 4u);
+  };
+  glds_mainloop<true>(mma, issue, (K + Cfg::KR - 1) / Cfg::KR, smem_h);
+#pragma unroll
+  for (int ti = 0; ti < MmaX2K::TM; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + mma.row_of(ti, r);
+#pragma unroll
+      for (int tj = 0; tj < MmaX2K::TN; ++tj) {
+        const int n = n0 + mma.col_of(tj);
+        if (m < M && n < N) C[(size_t)m * N + n] = mma.acc[ti][tj][r];
+      }
+    }
+}
+
 // Test hook only: rounds A and B to bf16 in stream-ordered temporaries (the one place the library allocates).
 // Row images need K % 32 == 0; k-major images take any K (rows past the end fall off the descriptor).
+// Layouts 3 / 4 (split engine): A [M,K], B [N,K] (3) or A [K,M], B [K,N] (4), every row converted to il32 two-term rows:
+// row lengths must be multiples of 32.
 int test_gemm_bf16(int layout, int M, int N, int K, const float* A, const float* B, float* C, hipStream_t s) {
-  if (layout != 1 && layout != 2) return FVTA_ERR_UNSUPPORTED;
-  if (layout == 1 && K % 32) return FVTA_ERR_UNSUPPORTED;
-  const size_t na = (size_t)M * K, nb = (size_t)N * K;
+  if (layout < 1 || layout > 4) return FVTA_ERR_UNSUPPORTED;
+  if ((layout == 1 || layout == 3) && K % 32) return FVTA_ERR_UNSUPPORTED;
+  if (layout == 4 && (M % 32 || N % 32)) return FVTA_ERR_UNSUPPORTED;
+  const size_t na = (size_t)M * K, nb = (size_t)N * K, xm = layout >= 3 ? 2 : 1;
   bf16_t *Ab = nullptr, *Bb = nullptr;
-  if (hipMallocAsync((void**)&Ab, na * 2, s) != hipSuccess || hipMallocAsync((void**)&Bb, nb * 2, s) != hipSuccess)
+  if (hipMallocAsync((void**)&Ab, na * 2 * xm, s) != hipSuccess || hipMallocAsync((void**)&Bb, nb * 2 * xm, s) != hipSuccess)
     return FVTA_ERR_LAUNCH;
+  if (layout >= 3) {
+    const int la = layout == 3 ? K : M, lb = layout == 3 ? K : N;
+    hipLaunchKernelGGL(cvt_f32_il32_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, s, A, Ab, na / la, la);
+    hipLaunchKernelGGL(cvt_f32_il32_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, B, Bb, nb / lb, lb);
+    if (layout == 3) {
+      constexpr int LDS = TileCfgT<1, 2, 4, 2, 64>::LDS_BYTES;
+      allow_big_lds(test_gemm_x2_rows_kernel, LDS);
+      hipLaunchKernelGGL(test_gemm_x2_rows_kernel, dim3((M + 255) / 256, (N + 127) / 128), dim3(256), LDS, s, M, N, K, Ab, Bb, C);
+    } else {
+      allow_big_lds(test_gemm_x2_kmajor_kernel, DwX2Cfg::LDS_BYTES);
+      hipLaunchKernelGGL(test_gemm_x2_kmajor_kernel, dim3((M + 255) / 256, (N + 255) / 256), dim3(512), DwX2Cfg::LDS_BYTES, s, M, N, K, Ab, Bb, C);
+    }
+    (void)hipFreeAsync(Ab, s);
+    (void)hipFreeAsync(Bb, s);
+    return FVTA_OK;
+  }
   hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, s, A, Ab, na);
   hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, B, Bb, nb);
   const dim3 grid((M + TileCfg::BM - 1) / TileCfg::BM, (N + TileCfg::BN - 1) / TileCfg::BN);

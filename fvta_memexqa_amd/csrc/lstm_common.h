@@ -51,14 +51,13 @@ static inline PlanView plan_view(const fvta_lstm_desc* d, void* p) {
   return v;
 }
 
-// the bf16 engines (FVTA_BF16, FVTA_BF16X3) share kernels and layouts; XM = 3 in the split engine: every MFMA operand
-// row holds three bf16 terms per value -- (hi, hi, lo) for the activation shadows xs / hs, (hi, lo, hi) for the forward
-// weights wt and for dz, (hi, hi, lo) for the backward weights wb -- so that the SAME GEMM kernels, run over a K extent
-// three times as long, sum hi hi + hi lo + lo hi.  The term order is chosen so that every GEMM pairs an (a, a, b)
-// operand with an (a, b, a) one: xs/hs x wt (forward), dz x wb (backward, dx), xs/hs x dz (weight gradient, where the
-// three terms of a row are three consecutive k-rows).
+// the bf16 engines (FVTA_BF16, FVTA_BF16X3) share kernels; xm = stored bf16 terms per operand value.  The split engine
+// (precision bf16x3) stores TWO -- hi = bf16(v), lo = bf16(v - hi) -- for every MFMA operand (xs, hs, wt, wb, dz, wf), in the
+// il32 layout (gemm_bf16.h: element e of a row at (e / 32) * 64 + e % 32, its lo term 32 elements further), and every k-step
+// multiplies THREE products from the four fragments it reads once: hi hi + hi lo + lo hi.  (Rounds 2-5 stored three terms
+// per value and ran the plain kernels over a K extent three times as long: 1.5x the bytes staged and read per product.)
 static inline bool lstm_is_bf(const fvta_lstm_desc* d) { return d->precision == FVTA_BF16 || d->precision == FVTA_BF16X3; }
-static inline int lstm_xm(const fvta_lstm_desc* d) { return d->precision == FVTA_BF16X3 ? 3 : 1; }
+static inline int lstm_xm(const fvta_lstm_desc* d) { return d->precision == FVTA_BF16X3 ? 2 : 1; }
 
 // bf16 engine: internal input width = in + a ones column (dbias) + zero pad to a multiple of 32, so that
 // every 32-deep k-tile is wholly x or wholly h
@@ -153,7 +152,7 @@ struct StepArgs {
   float* cstate;  // used when cs is null
   int t, B, J, in, d, Kp;
   int dbg;  // diagnostics only (-DFVTA_DIAG builds, FVTA_DEBUG_SKIP): fp32 engine ablations
-  int xm;   // bf16 engines: bf16 terms per operand value (1; 3 in the split engine, which saves fp32 gates in `gates`)
+  int xm;   // bf16 engines: stored bf16 terms per operand value (1; 2 in the split engine, which saves fp32 gates in `gates`)
   int nt;   // bf16 engine: stream-once data (saved gates, cell states, fp32 h rows) with non-temporal stores (measured: no
             // effect on the forward step; 0)
   int64_t out_skip;  // fvta_lstm_desc.out_skip: output half-rows at element offsets below this are NOT stored
@@ -194,7 +193,7 @@ struct DwArgs {
   const bf16_t* hs;
   float* slabs;
   int B, J, in, d, tgroup, nsplit, in_i;
-  int xm;  // bf16 terms per operand value: the weight gradient contracts over xm k-rows per sequence row
+  int xm;  // stored bf16 terms per operand value (2: the split engine's il32 columns, lstm_dw_x2)
 };
 
 #ifdef __HIPCC__
@@ -312,7 +311,7 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
     }
     float cv[16], hv[16];
     bf16x4 gv[16];
-    const bool x3 = a.xm == 3;
+    const bool x3 = a.xm == 2;  // the split engine
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float ig = fvta_sigmoid(mma.acc[ti][0][r] + bi);
@@ -366,14 +365,14 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
       wave_sync();
     }
     // ---- bf16 shadow of h_t (next step's MFMA operand): 4 lanes x 16 B per row, 16 rows per instruction.  Split engine:
-    // the row holds three terms per unit, [hi | hi | lo] in thirds of d
+    // two terms per unit in the il32 layout -- the plane's 32 units are one group: [hi 32 | lo 32] at 2 u0
     if (a.hs) {
       constexpr int LDH = 40;  // bf16 per staged row (32 + pad)
       const size_t hld = (size_t)d * a.xm;
 #pragma unroll
-      for (int term = 0; term < 3; ++term) {
+      for (int term = 0; term < 2; ++term) {
         if (term >= a.xm) break;
-        const bool lo = term == 2;
+        const bool lo = term == 1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const bf16_t hi = f2bf(hv[r]);
@@ -384,7 +383,7 @@ __device__ __forceinline__ void lstm_gate_epilogue_staged(const Mma& mma, const 
         for (int it = 0; it < 2; ++it) {
           const int lr = it * 16 + (lane >> 2), c8 = lane & 3, i = m0 + wrow0 + lr;
           const f32x4 v = *reinterpret_cast<const f32x4*>(&plh[lr * LDH + 8 * c8]);
-          if (i < nact) *reinterpret_cast<f32x4*>(a.hs + (trow + i) * hld + (size_t)term * d + u0 + 8 * c8) = v;
+          if (i < nact) *reinterpret_cast<f32x4*>(a.hs + (trow + i) * hld + (size_t)a.xm * u0 + 32 * term + 8 * c8) = v;
         }
         wave_sync();
       }

@@ -81,10 +81,10 @@ def test_gemm(A, B, layout, precision=F32):
     if layout == 0:
         M, K = A.shape
         N = B.shape[1]
-    elif layout == 1:
+    elif layout in (1, 3):      # row images (3: the split engine's two-term il32 rows)
         M, K = A.shape
         N = B.shape[0]
-    else:
+    else:                       # k-major images (4: split engine)
         K, M = A.shape
         N = B.shape[1]
     C = torch.empty(M, N, device=A.device, dtype=torch.float32)

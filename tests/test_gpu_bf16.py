@@ -35,6 +35,30 @@ def test_mfma_bf16_gemm_layouts(layout, shape):
     _close(C, ref, rtol=1e-5, atol=1e-4 * K ** 0.5)
 
 
+@pytest.mark.parametrize("layout", [3, 4])
+@pytest.mark.parametrize("shape", [(128, 128, 32), (200, 264, 96), (64, 40, 160), (712, 2048, 256), (300, 136, 1000), (448, 512, 12864)])
+def test_mfma_split_engine_gemm_layouts(layout, shape):
+    """The split engine's tiles (precision bf16x3: two stored bf16 terms per value in the il32 layout, three MFMA products
+    hi hi + hi lo + lo hi per k-step): full fp32 operands, result within 2^-16 of sum |a||b| -- layout 3 the row tile
+    (forward / backward / dx), layout 4 the k-major tile of the weight gradient."""
+    from fvta_memexqa_amd import ops
+    M, N, K = [(v + 31) // 32 * 32 for v in shape] if layout == 4 else [(v + 7) // 8 * 8 for v in shape]
+    if layout == 3:
+        K = (K + 31) // 32 * 32
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + layout)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    ref = A.double() @ B.double()
+    bound = (A.double().abs() @ B.double().abs()) * 2.0 ** -16 + 1e-6
+    Ad = (A if layout == 3 else A.t().contiguous()).cuda()
+    Bd = (B.t().contiguous() if layout == 3 else B).cuda()
+    C = ops.test_gemm(Ad, Bd, layout, precision=BF16).cpu().double()
+    assert bool(((C - ref).abs() <= bound).all()), "max error %.3g against a bound of %.3g" % (
+        float((C - ref).abs().max()), float(bound.max()))
+    # ... and far inside it in the mean: a dropped term (2^-9 per product) would show
+    assert float((C - ref).abs().mean() / ref.abs().mean()) < 2e-5
+
+
 # (shapes 3-6 run the weights-in-registers forward step kernel, csrc/lstm_wreg.hip: in_i / d = 128 / 128,
 #  224 / 512, 224 / 512 with separate fw / bw kernels, 32 / 128 with a ragged tail tile; the first two the tiled one.
 #  Every d = 512 shape runs the pipelined backward step lstm_bwd_ring_bf16; the last two give its workgroups two and

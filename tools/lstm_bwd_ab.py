@@ -14,7 +14,7 @@ k = (torch.rand(din + d, 4 * d, device="cuda", generator=g) * 2 - 1) * 0.05
 b = torch.randn(4 * d, device="cuda", generator=g) * 0.1
 ar = torch.arange(B, dtype=torch.int64)
 op = ops.BiLstm(B, J, din, d, ar * J * din, ar * J * 2 * d, torch.full((B,), J, dtype=torch.int32), 2 * d,
-                share_fw_bw=True, precision=1, training=True,
+                share_fw_bw=True, precision=int(os.environ.get("FVTA_AB_PREC", "1")), training=True,
                 dx_overwrite=bool(os.environ.get("FVTA_AB_DXOW")))   # FVTA_AB_DXOW=1: backward() writes dx (the model's setting)
 op.make_plan(lens)
 out = torch.zeros(B, J, 2 * d, device="cuda")
