@@ -663,9 +663,9 @@ extern "C" int fvta_bilstm_fwd(const fvta_lstm_desc* d, const void* plan, const 
       launch_cvt_weights_bf16(a.W[i], wv.wt[i], wv.wb[i], d->in, in_internal(d), d->d, a.xm, stream);
     a.Wt[0] = wv.wt[0];
     a.Wt[1] = d->share_fw_bw ? wv.wt[0] : wv.wt[1];
-    if (a.xm == 1 && wreg_nct(in_internal(d), d->d)) {
+    if (a.xm == 1 ? wreg_nct(in_internal(d), d->d) != 0 : wreg_x3_built(in_internal(d), d->d)) {
       for (int i = 0; i < ndir; ++i)
-        launch_cvt_weights_frag(a.W[i], a.bias[i], wv.wf[i], d->in, in_internal(d), d->d, stream);
+        launch_cvt_weights_frag(a.W[i], a.bias[i], wv.wf[i], d->in, in_internal(d), d->d, a.xm, stream);
       a.Wf[0] = wv.wf[0];
       a.Wf[1] = d->share_fw_bw ? wv.wf[0] : wv.wf[1];
     }

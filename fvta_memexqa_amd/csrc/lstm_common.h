@@ -129,7 +129,7 @@ static inline WorkView work_view(const fvta_lstm_desc* d, void* p) {
       w.wb[i] = c.take<bf16_t>((size_t)kpad8(d) * 4 * d->d * xm);
     }
     if (d->training) w.dzb = c.take<bf16_t>((size_t)2 * d->J * d->B * 4 * d->d * xm);
-    for (int i = 0; i < 2; ++i) w.wf[i] = c.take<bf16_t>((size_t)4 * d->d * kpad8(d));
+    for (int i = 0; i < 2; ++i) w.wf[i] = c.take<bf16_t>((size_t)4 * d->d * kpad8(d) * xm);
   }
   w.bytes = c.off;
   return w;
@@ -415,7 +415,8 @@ void launch_step_fwd_bf16(const StepArgs& a, hipStream_t s);
 // weights-in-registers forward step (lstm_wreg.hip): false = shape not built, the tiled kernel runs instead
 int wreg_nct(int in_i, int d);
 int wreg_mode();
-void launch_cvt_weights_frag(const float* W, const float* bias, bf16_t* wf, int in, int in_i, int d, hipStream_t s);
+bool wreg_x3_built(int in_i, int d);  // the split engine's weights-in-registers forward is built for this shape
+void launch_cvt_weights_frag(const float* W, const float* bias, bf16_t* wf, int in, int in_i, int d, int xm, hipStream_t s);
 bool launch_step_fwd_wreg(const StepArgs& a, hipStream_t s);
 struct FusedBwdArgs {
   PlanView plan;

@@ -44,54 +44,67 @@ __device__ __forceinline__ void static_for(F&& f) {
 // (An EIGHT-wave form of this kernel -- two waves per SIMD of 256 registers, 32 columns each, nine weight fragments per
 //  wave in LDS, ring of six slots -- was built and measured: 4.10 ms against 3.75 ms per text-cell forward; what it gains in
 //  issue slots it loses to the shallow ring and the 8-wave barriers.  DESIGN.md appendix.)
-template <int NX16_, int ND16_, int NCT_>
+// X3 (the split engine, precision bf16x3): every operand value is two bf16 terms (il32 layout, gemm_bf16.h).  A wave owns ONE
+// column tile (NCT = 1: 8 units x 4 gates) and keeps its hi AND lo weight fragments -- the register budget of two column
+// tiles -- a k-step reads a_hi and a_lo once and issues three MFMAs: hi hi into acc[0], hi lo + lo hi into acc[1] (summed
+// when the tile's pre-activations go to the slab).  A 128-element ring slot row is 64 k of [hi 32 | lo 32] pairs: four
+// k-steps per slot instead of eight.
+template <int NX16_, int ND16_, int NCT_, bool X3_ = false>
 struct WregCfg {
   static constexpr int NX16 = NX16_, ND16 = ND16_, NCT = NCT_, NW = 4;
+  static constexpr bool X3 = X3_;
+  static_assert(!X3_ || NCT_ == 1, "split engine: one column tile per wave (its hi and lo fragments fill the register file)");
+  static constexpr int NWF = X3 ? 2 : NCT;            // weight fragments per k-step
+  static constexpr int NP = X3 ? 3 : NCT;             // MFMAs per k-step = places for a gate stage
+  static constexpr int NACC = X3 ? 2 : NCT;           // accumulators
+  static constexpr int KS = X3 ? 4 : 8;               // k-steps per ring slot
   static constexpr int NK16 = NX16 + ND16;            // k-steps of 16
   static constexpr int NU = 8 * NCT, UB = NW * NU;    // units per wave / per workgroup
   static constexpr int RW = 32 / NW, DP = 8 / NW;     // rows of a tile whose gate math a wave does / DMA pieces per wave and slot
   static constexpr int D = 16 * ND16, IN_I = 16 * NX16;
+  static constexpr int XM = X3 ? 2 : 1;               // stored terms per value: operand rows are XM times as long
   static constexpr int CB = D / UB;                   // column blocks per direction
-  static constexpr int SX = (NX16 + 7) / 8, SH = ND16 / 8, S = SX + SH;  // ring slots per row tile (x part, h part)
-  static constexpr int XLAST = NX16 - 8 * (SX - 1);   // k-steps of the last x slot (1 .. 8)
+  static constexpr int SX = (NX16 + KS - 1) / KS, SH = ND16 / KS, S = SX + SH;  // ring slots per row tile (x part, h part)
+  static constexpr int XLAST = NX16 - KS * (SX - 1);  // k-steps of the last x slot (1 .. KS)
   // the ring holds RT whole tiles (so that a slot's LDS address is tile base + a compile-time offset); the DMA stream runs
   // LOOK slots ahead of the hand-over
   static constexpr int RT = S >= 12 ? 1 : 12 / S, RING = RT * S, LOOK = RING - 2;
-  static constexpr int SLOT_ELEMS = 32 * 128;         // bf16 per slot: 32 rows x 128 k
+  static constexpr int SLOT_ELEMS = 32 * 128;         // bf16 per slot: 32 rows x 128 elements
   static constexpr int TILE_ELEMS = S * SLOT_ELEMS;
-  static constexpr int W_AGPR_FRAGS = (256 - 16 * NCT) / 4;  // weight fragments kept in AGPRs (beside the accumulators)
+  static constexpr int W_AGPR_FRAGS = (256 - 16 * NACC) / 4;  // weight fragments kept in AGPRs (beside the accumulators)
   static constexpr int ZS = 4 * UB + 4;               // floats per row of the pre-activation slab
   // the LAST W_LDS_FRAGS weight fragments of a wave live in LDS (the space the ring and the slab leave), read one k-step
-  // ahead of their MFMAs: 28 registers per lane that the gate stages need at the widest shape
-  static constexpr int W_FRAGS = NK16 * NCT;
-  static constexpr int W_LDS_FRAGS = W_FRAGS > 84 ? 7 : 0, W_REG_FRAGS = W_FRAGS - W_LDS_FRAGS;
+  // ahead of their MFMAs: registers that the gate stages need at the widest shape
+  static constexpr int W_FRAGS = NK16 * NWF;
+  static constexpr int W_LDS_FRAGS = W_FRAGS > 84 ? (X3 ? 11 : 7) : 0, W_REG_FRAGS = W_FRAGS - W_LDS_FRAGS;
   static constexpr int Z_OFF = RING * SLOT_ELEMS * 2, WL_OFF = Z_OFF + 32 * ZS * 4;  // byte offsets of the slab / the weight tail
   static constexpr int LDS_BYTES = WL_OFF + NW * W_LDS_FRAGS * 1024;
   static_assert(LDS_BYTES <= 163840, "LDS");
   static constexpr int LPR = UB / 4, RPP = 64 / LPR, PASSES = RW / RPP;  // epilogue: lanes per row, rows per pass
   // k-step q of a tile: its ring slot, its position in the slot, its fragment buffer
-  static constexpr int slot_of(int q) { return q < NX16 ? q / 8 : SX + (q - NX16) / 8; }
-  static constexpr int ks_of(int q) { return q < NX16 ? q % 8 : (q - NX16) % 8; }
+  static constexpr int slot_of(int q) { return q < NX16 ? q / KS : SX + (q - NX16) / KS; }
+  static constexpr int ks_of(int q) { return q < NX16 ? q % KS : (q - NX16) % KS; }
   // A fragments are read PF k-steps ahead of their MFMAs into NB = PF + 1 rotating buffers; the k-step sequence of a tile
   // is padded to NV, a multiple of NB (the padding steps read and multiply nothing), so that the rotation continues
   // seamlessly into the next tile's first PF k-steps
   static constexpr int PF = NX16 >= 3 ? 3 : 2, NB = PF + 1, NV = (NK16 + NB - 1) / NB * NB;
   static constexpr int buf_of(int q) { return q % NB; }
-  // gate-math stages (see the kernel): per pass 1 read + 4 cells x CELL_STAGES + 1 store.  A k-step has NCT places for a
+  // gate-math stages (see the kernel): per pass 1 read + 4 cells x CELL_STAGES + 1 store.  A k-step has NP places for a
   // stage (one behind each of its MFMAs); stage st runs at place HLO + st * HW / NSTAGES -- from the k-step after the
   // hand-over of slot 1 (every wave's slab write lies before it); the second pass's first slab read must come before the
   // hand-over of the next tile's slot 0 (k-step NV - PF, which precedes this tile's slab write)
   static constexpr int CELL_STAGES = 7, PASS_STAGES = 2 + 4 * CELL_STAGES, NSTAGES = PASSES * PASS_STAGES;
-  static constexpr int QLO = SX > 1 ? 8 : NX16, HLO = NCT * QLO, HW = NCT * NK16 - HLO;
-  static constexpr int stage_begin(int h) { return h <= HLO ? 0 : (h >= NCT * NK16 ? NSTAGES : ((h - HLO) * NSTAGES + HW - 1) / HW); }
+  static constexpr int QLO = SX > 1 ? KS : NX16, HLO = NP * QLO, HW = NP * NK16 - HLO;
+  static constexpr int stage_begin(int h) { return h <= HLO ? 0 : (h >= NP * NK16 ? NSTAGES : ((h - HLO) * NSTAGES + HW - 1) / HW); }
   static constexpr int stage_place(int st) { return HLO + st * HW / NSTAGES; }
   // (the last slab read is cell 3's, requested at stage k = 2 of cell 2 of the last pass; shapes with too few k-steps for
   //  that put an extra barrier in front of the slab write instead)
-  static constexpr bool SLAB_SAFE = stage_place((PASSES - 1) * PASS_STAGES + 1 + 2 * CELL_STAGES + 2) / NCT <= NV - PF - 1;
+  static constexpr bool SLAB_SAFE = stage_place((PASSES - 1) * PASS_STAGES + 1 + 2 * CELL_STAGES + 2) / NP <= NV - PF - 1;
   static_assert(ND16 % 8 == 0, "hidden size must be a multiple of 128");
   static_assert(D % UB == 0, "column blocks");
   static_assert(W_REG_FRAGS * 4 <= 400, "weight slice must fit the register file");
   static_assert(NX16 >= PF, "the first slot holds the k-steps read ahead across a tile boundary");
+  static_assert(!X3 || NX16 % 2 == 0, "il32 groups: the input width is a multiple of 32");
   static_assert(PASSES >= 1 && PASSES <= 2 && LOOK >= 2 && RING <= 12, "geometry");
 };
 
@@ -100,22 +113,24 @@ struct WregCfg {
 // column tile ct, as ONE contiguous 1 KiB piece.  Column idx = 32 ct + (lane & 31) of the wave is gate idx / NU of unit
 // cb UB + wave NU + idx % NU; k = 16 ks + 8 (lane >> 5) + e in the internal row order [x | 1 | 1 | 0.. | h]; rows `in`
 // and `in + 1` hold the bias split in two bf16 terms.  One thread per (cb, wave, ks, ct, lane).
-template <int NCT>
+// X3: wf[cb][wave][ks][term][lane][8], ONE column tile per wave (NU = 8), term 0 = bf16(v), term 1 = bf16(v - bf16(v)); the
+// bias sits in row `in` alone (hi and lo terms like every weight; the input's ones column there has hi = 1, lo = 0).
+template <int NCT, bool X3 = false>
 __global__ void cvt_weights_frag_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                         bf16_t* __restrict__ wf, int in, int in_i, int d, int nk16) {
-  constexpr int NW = 4, NU = 8 * NCT, UB = NW * NU;
+  constexpr int NW = 4, NU = X3 ? 8 : 8 * NCT, UB = NW * NU;
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int CB = d / UB;
   const size_t total = (size_t)CB * NW * nk16 * NCT * 64;
   if (gid >= total) return;
   const int lane = (int)(gid & 63);
   size_t r = gid >> 6;
-  const int ct = (int)(r % NCT);
+  const int ct = (int)(r % NCT);   // X3: the term
   r /= NCT;
   const int ks = (int)(r % nk16);
   r /= nk16;
   const int wave = (int)(r % NW), cb = (int)(r / NW);
-  const int idx = ct * 32 + (lane & 31);
+  const int idx = (X3 ? 0 : ct * 32) + (lane & 31);
   const int n = (idx / NU) * d + cb * UB + wave * NU + idx % NU;  // kernel column g d + u
   const int N4 = 4 * d;
   bf16x8 o;
@@ -128,10 +143,10 @@ __global__ void cvt_weights_frag_kernel(const float* __restrict__ W, const float
     else if (k >= in_i)
       v = W[(size_t)(in + k - in_i) * N4 + n];
     else if (k == in)
-      v = bf2f(f2bf(bias[n]));
+      v = X3 ? bias[n] : bf2f(f2bf(bias[n]));
     else if (k == in + 1)
-      v = bias[n] - bf2f(f2bf(bias[n]));
-    o[e] = (short)f2bf(v);
+      v = X3 ? 0.f : bias[n] - bf2f(f2bf(bias[n]));
+    o[e] = (short)((X3 && ct == 1) ? f2bf(v - bf2f(f2bf(v))) : f2bf(v));
   }
   *reinterpret_cast<bf16x8*>(wf + gid * 8) = o;
 }
@@ -183,33 +198,35 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
   const unsigned long long st_t0 = WREG_CLOCK();
 
   // ---- the weight slice: NK16 x NCT fragments, static indices only (registers)
-  bf16x8_t w[C::NK16][NCT];
+  constexpr int NWF = C::NWF;  // weight fragments per k-step: the wave's column tiles, or (split engine) hi and lo of its one
+  bf16x8_t w[C::NK16][NWF];
   f32x4* wlds = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(smem) + C::WL_OFF) + wave * C::W_LDS_FRAGS * 64 + lane;
   {
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.Wf[dir]) + (size_t)(cb * C::NW + wave) * C::NK16 * NCT * 64 + lane;
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.Wf[dir]) + (size_t)(cb * C::NW + wave) * C::NK16 * NWF * 64 + lane;
 #pragma unroll
     for (int ks = 0; ks < C::NK16; ++ks)
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
+      for (int ct = 0; ct < NWF; ++ct) {
         Pack8 p;
-        p.f = (abl & 8) ? f32x4{0.f, 0.f, 0.f, 0.f} : src[(ks * NCT + ct) * 64];
-        if (ks * NCT + ct < C::W_REG_FRAGS)
+        p.f = (abl & 8) ? f32x4{0.f, 0.f, 0.f, 0.f} : src[(ks * NWF + ct) * 64];
+        if (ks * NWF + ct < C::W_REG_FRAGS)
           w[ks][ct] = p.b;
         else
-          wlds[(ks * NCT + ct - C::W_REG_FRAGS) * 64] = p.f;  // (read back by this wave only)
+          wlds[(ks * NWF + ct - C::W_REG_FRAGS) * 64] = p.f;  // (read back by this wave only)
       }
   }
 
   // ---- activation stream: per-lane source offsets of this wave's DP DMA pieces per slot (rows 4 DP wave .. )
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xs + trow * IN_I, (unsigned)nact * IN_I * 2);
+  constexpr int XB = IN_I * 2 * C::XM, HB = d * 2 * C::XM;  // bytes per operand row (split engine: two terms per value)
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.xs + trow * (IN_I * C::XM), (unsigned)nact * XB);
   const __amdgpu_buffer_rsrc_t rh =
-      make_rsrc(t > 0 ? a.hs + (trow - a.B) * d : a.hs, t > 0 ? (unsigned)nact * d * 2 : 0u);  // h_{-1} = 0
+      make_rsrc(t > 0 ? a.hs + (trow - a.B) * (d * C::XM) : a.hs, t > 0 ? (unsigned)nact * HB : 0u);  // h_{-1} = 0
   unsigned voff_x[C::DP], voff_h[C::DP];
 #pragma unroll
   for (int j = 0; j < C::DP; ++j) {
     const int r = 4 * (C::DP * wave + j) + (lane >> 4), c = (lane & 15) ^ (r & 15);
-    voff_x[j] = (unsigned)r * (IN_I * 2) + 16u * c;
-    voff_h[j] = (unsigned)r * (d * 2) + 16u * c;
+    voff_x[j] = (unsigned)r * XB + 16u * c;
+    voff_h[j] = (unsigned)r * HB + 16u * c;
   }
   // slot cs of the workgroup's tile number `ord` -> its place in the ring (tile ord % RT)
   auto issue = [&](auto cs_c, int ord) {
@@ -221,18 +238,18 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
     const unsigned m0c = 32u * (unsigned)(rg + RG * ord);
     bf16_t* dst = smem + (ord % C::RT) * C::TILE_ELEMS + cs * C::SLOT_ELEMS + (C::DP * wave) * 512;
     if constexpr (cs < C::SX) {
-      const unsigned rowb = m0c * (IN_I * 2) + cs * 256;
+      const unsigned rowb = m0c * XB + cs * 256;
 #pragma unroll
       for (int j = 0; j < C::DP; ++j) {
         unsigned v = voff_x[j] + rowb;
-        if constexpr (cs == C::SX - 1 && C::XLAST < 8) {  // the last x slot is narrower than 128 k: its tail chunks read zeros
+        if constexpr (cs == C::SX - 1 && C::XLAST < C::KS) {  // the last x slot is narrower than 128 elements: its tail chunks read zeros
           const int r = 4 * (C::DP * wave + j) + (lane >> 4), c = (lane & 15) ^ (r & 15);
-          v = (c < 2 * C::XLAST) ? v : GLDS_OOB;
+          v = (c < (16 / C::KS) * C::XLAST) ? v : GLDS_OOB;     // (16 / KS chunks per k-step; split engine: XLAST is even)
         }
         glds16(rx, dst + j * 512, v, 0);
       }
     } else {
-      const unsigned rowb = m0c * (d * 2) + (cs - C::SX) * 256;
+      const unsigned rowb = m0c * HB + (cs - C::SX) * 256;
 #pragma unroll
       for (int j = 0; j < C::DP; ++j) glds16(rh, dst + j * 512, voff_h[j] + rowb, 0);
     }
@@ -277,6 +294,7 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
   };
   f32x4 cv, hv;
   unsigned gpk[8];
+  f32x4 gf[C::X3 ? 4 : 1];  // split engine: the four cells' fp32 gates (i, j, f, o), saved unit-major
   f32x4 zg[4];  // the pass's pre-activations: gate g of the lane's four units (conflict-free 16-byte slab reads)
   float zjk, ti, tf, to, tj, ig, jg, fg, og, cc, te;
   auto read_pass = [&](auto p_c) {
@@ -315,8 +333,23 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
           }
         }
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        if constexpr (C::X3) {
+          // il32: the workgroup's 32 units are ONE group of the shadow row -- [hi 32 | lo 32] at element 2 cb UB
+          bf16_t* hp = a.hs + (trow + i) * (size_t)(2 * d) + 2 * cb * C::UB + 4 * e_q;
+          const unsigned h01 = pk_bf16(hv[0], hv[1]), h23 = pk_bf16(hv[2], hv[3]);
+          const float l0 = hv[0] - __uint_as_float(h01 << 16), l1 = hv[1] - __uint_as_float(h01 & 0xffff0000u);
+          const float l2 = hv[2] - __uint_as_float(h23 << 16), l3 = hv[3] - __uint_as_float(h23 & 0xffff0000u);
+          *reinterpret_cast<u32x2*>(hp) = u32x2{h01, h23};
+          *reinterpret_cast<u32x2*>(hp + 32) = u32x2{pk_bf16(l0, l1), pk_bf16(l2, l3)};
+          if (a.gates) {  // fp32 gates, unit-major [u][i,j,f,o]: 64 bytes per lane
+            float* gp = a.gates + (trow + i) * (size_t)(4 * d) + 4 * u_lane;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st16(gp + 4 * e, gf[e], a.nt != 0);
+          }
+        } else {
         if constexpr (!(abl & 512)) *reinterpret_cast<u32x2*>(a.hs + (trow + i) * (size_t)d + u_lane) = u32x2{pk_bf16(hv[0], hv[1]), pk_bf16(hv[2], hv[3])};
-        if (a.gatesb && !(abl & 1024)) {  // unit-major [u][i,j,f,o]
+        }
+        if (!C::X3 && a.gatesb && !(abl & 1024)) {  // unit-major [u][i,j,f,o]
           float* gp = reinterpret_cast<float*>(a.gatesb + (trow + i) * (size_t)(4 * d) + 4 * u_lane);
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
           st16(gp, __builtin_bit_cast(f32x4, u32x4{gpk[0], gpk[1], gpk[2], gpk[3]}), a.nt != 0);
@@ -354,6 +387,8 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
         float h = copysignf((1.0f - te) * __builtin_amdgcn_rcpf(1.0f + te), cc) * og;
         asm volatile("" : "+v"(h));
         hv[e] = h;
+      } else if constexpr (C::X3) {
+        gf[e] = f32x4{ig, jg, fg, og};
       } else {
         unsigned g0 = pk_bf16(ig, jg), g1 = pk_bf16(fg, og);
         asm volatile("" : "+v"(g0), "+v"(g1));
@@ -367,24 +402,32 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
   // matrix pipe reads either directly (the compiler's own allocation shuttles AGPR-resident operands through VGPRs, four
   // v_accvgpr_read per MFMA).  The asm statements are opaque to the hazard recogniser: an s_nop run covers the XDL write ->
   // VALU / LDS read distance before the accumulators are read.
-  f32x16 acc[NCT];
-  Pack8 wl[NCT];  // LDS-resident weight fragments of the NEXT k-step
-  auto mfma = [&](auto q_c, auto ct_c, const bf16x8_t afr) {
-    constexpr int q = decltype(q_c)::value, ct = decltype(ct_c)::value;
-    constexpr bool in_agpr = (q * NCT + ct) < C::W_AGPR_FRAGS;
+  f32x16 acc[C::NACC];
+  Pack8 wl[NWF];  // LDS-resident weight fragments of the NEXT k-step
+  // place pl of k-step q: which weight fragment wi, which accumulator ai, and whether it opens the accumulator.
+  //   bf16 engine: place = column tile (wi = ai = pl).   Split engine: place 0 = a_hi w_hi -> acc[0]; 1 = a_hi w_lo -> acc[1];
+  //   2 = a_lo w_hi -> acc[1] (the caller hands the matching A fragment)
+  auto mfma = [&](auto q_c, auto pl_c, const bf16x8_t afr) {
+    constexpr int q = decltype(q_c)::value, pl = decltype(pl_c)::value;
+    constexpr int wi = C::X3 ? (pl == 1 ? 1 : 0) : pl, ai = C::X3 ? (pl == 0 ? 0 : 1) : pl;
+    constexpr bool opens = q == 0 && (!C::X3 || pl < 2);
+    constexpr bool in_agpr = (q * NWF + wi) < C::W_AGPR_FRAGS;
     if constexpr ((abl & 2) != 0) return;
-    if constexpr (q * NCT + ct >= C::W_REG_FRAGS) {
-      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[ct]) : "v"(afr), "v"(wl[ct].b));
-    } else if constexpr (q == 0) {
-      if constexpr (in_agpr)
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[ct]) : "v"(afr), "a"(w[q][ct]));
+    if constexpr (q * NWF + wi >= C::W_REG_FRAGS) {
+      if constexpr (opens)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[ai]) : "v"(afr), "v"(wl[wi].b));
       else
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[ct]) : "v"(afr), "v"(w[q][ct]));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[ai]) : "v"(afr), "v"(wl[wi].b));
+    } else if constexpr (opens) {
+      if constexpr (in_agpr)
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[ai]) : "v"(afr), "a"(w[q][wi]));
+      else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[ai]) : "v"(afr), "v"(w[q][wi]));
     } else {
       if constexpr (in_agpr)
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[ct]) : "v"(afr), "a"(w[q][ct]));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[ai]) : "v"(afr), "a"(w[q][wi]));
       else
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[ct]) : "v"(afr), "v"(w[q][ct]));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[ai]) : "v"(afr), "v"(w[q][wi]));
     }
   };
 
@@ -394,10 +437,18 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
   // slot g - 1's last PF k-steps are still to come, and the matrix pipe never waits for a fresh LDS read.
   // ap[ks]: this lane's fragment address for position ks of a slot in the CURRENT tile's ring place (row l31, 16-byte
   // chunk (2 ks + hf) ^ (l31 & 15)); the slot is a compile-time offset on top.
-  const bf16_t* ap[8];
+  // split engine: position ks of a slot holds k-step ks's hi fragment at chunk 8 (ks / 2) + 2 (ks % 2) + hf of the row and its
+  // lo fragment four chunks further (apl)
+  const bf16_t* ap[C::KS];
+  const bf16_t* apl[C::X3 ? C::KS : 1];
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) ap[ks] = smem + l31 * 128 + (((2 * ks + hf) ^ (l31 & 15)) << 3);
+  for (int ks = 0; ks < C::KS; ++ks) {
+    const int ch = C::X3 ? 8 * (ks >> 1) + 2 * (ks & 1) + hf : 2 * ks + hf;
+    ap[ks] = smem + l31 * 128 + ((ch ^ (l31 & 15)) << 3);
+    if constexpr (C::X3) apl[ks] = smem + l31 * 128 + (((ch + 4) ^ (l31 & 15)) << 3);
+  }
   Pack8 fr[C::NB];
+  Pack8 frl[C::X3 ? C::NB : 1];  // split engine: the lo fragments
   auto handover = [&](auto s_c, int ord) {  // after it slot s_c of tile `ord` may be read
     constexpr int s = decltype(s_c)::value;
     const unsigned long long c0 = WREG_CLOCK();
@@ -416,7 +467,10 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
   handover(std::integral_constant<int, 0>{}, 0);
   const unsigned long long st_t1 = WREG_CLOCK();
 #pragma unroll
-  for (int q = 0; q < C::PF; ++q) fr[C::buf_of(q)].f = *reinterpret_cast<const f32x4*>(ap[q]);
+  for (int q = 0; q < C::PF; ++q) {
+    fr[C::buf_of(q)].f = *reinterpret_cast<const f32x4*>(ap[q]);
+    if constexpr (C::X3) frl[C::buf_of(q)].f = *reinterpret_cast<const f32x4*>(apl[q]);
+  }
   int prev_m0 = 1 << 30;  // no previous tile yet: the first tile's stages run on an undefined slab and store nothing
 #pragma unroll
   for (int p = 0; p < C::PASSES; ++p) {
@@ -433,9 +487,11 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
       if constexpr (n < C::NK16) {
         if constexpr (C::ks_of(n) == 0) handover(std::integral_constant<int, C::slot_of(n)>{}, it);
         fr[C::buf_of(n)].f = *reinterpret_cast<const f32x4*>(ap[C::ks_of(n)] + C::slot_of(n) * C::SLOT_ELEMS);
+        if constexpr (C::X3) frl[C::buf_of(n)].f = *reinterpret_cast<const f32x4*>(apl[C::ks_of(n)] + C::slot_of(n) * C::SLOT_ELEMS);
       } else if constexpr (n >= C::NV) {  // the next tile's first k-steps (past the workgroup's last tile: zeros nobody uses)
         if constexpr (n == C::NV) handover(std::integral_constant<int, 0>{}, it + 1);
         fr[C::buf_of(n - C::NV)].f = *reinterpret_cast<const f32x4*>(ap[n - C::NV] + tb_delta);
+        if constexpr (C::X3) frl[C::buf_of(n - C::NV)].f = *reinterpret_cast<const f32x4*>(apl[n - C::NV] + tb_delta);
       }
       if constexpr (q >= C::NK16) return;  // a padding step of the fragment rotation
       else {
@@ -444,20 +500,19 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
         own_rows(m0);
         st_rows += WREG_CLOCK() - r0;
       }
-      mfma(q_c, std::integral_constant<int, 0>{}, fr[C::buf_of(q)].b);  // (step 0: the h slots hold zeros)
-      if constexpr (C::stage_begin(NCT * q) < C::stage_begin(NCT * q + 1)) {
-        const unsigned long long g0 = WREG_CLOCK();
-        if constexpr (!(abl & 1)) static_for<C::stage_begin(NCT * q), C::stage_begin(NCT * q + 1)>([&](auto s_c) { run_stage(s_c, prev_m0); });
-        st_stage += WREG_CLOCK() - g0;
-      }
-      if constexpr (NCT > 1) {
-        mfma(q_c, std::integral_constant<int, 1>{}, fr[C::buf_of(q)].b);
-        if constexpr (C::stage_begin(NCT * q + 1) < C::stage_begin(NCT * q + 2)) {
+      // the k-step's NP MFMAs (step 0: the h slots hold zeros), the gate stages dealt to each place right behind it
+      static_for<0, C::NP>([&](auto pl_c) {
+        constexpr int pl = decltype(pl_c)::value;
+        if constexpr (C::X3 && pl == 2)
+          mfma(q_c, pl_c, frl[C::buf_of(q)].b);
+        else
+          mfma(q_c, pl_c, fr[C::buf_of(q)].b);
+        if constexpr (C::stage_begin(C::NP * q + pl) < C::stage_begin(C::NP * q + pl + 1)) {
           const unsigned long long g0 = WREG_CLOCK();
-          if constexpr (!(abl & 1)) static_for<C::stage_begin(NCT * q + 1), C::stage_begin(NCT * q + 2)>([&](auto s_c) { run_stage(s_c, prev_m0); });
+          if constexpr (!(abl & 1)) static_for<C::stage_begin(C::NP * q + pl), C::stage_begin(C::NP * q + pl + 1)>([&](auto s_c) { run_stage(s_c, prev_m0); });
           st_stage += WREG_CLOCK() - g0;
         }
-      }
+      });
       }
     };
     static_for<0, C::NV>([&](auto q_c) {
@@ -465,8 +520,8 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
       constexpr int q1 = decltype(q_c)::value + 1;
       if constexpr (q1 < C::NK16) {  // LDS-resident weight fragments of the next k-step
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-          if (q1 * NCT + ct >= C::W_REG_FRAGS) wl[ct].f = wlds[(q1 * NCT + ct - C::W_REG_FRAGS) * 64];
+        for (int ct = 0; ct < NWF; ++ct)
+          if (q1 * NWF + ct >= C::W_REG_FRAGS) wl[ct].f = wlds[(q1 * NWF + ct - C::W_REG_FRAGS) * 64];
       }
     });
     // the tile's pre-activations -> slab [row][gate][unit of the workgroup]
@@ -476,17 +531,23 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
-    if constexpr (NCT > 1)
-      asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[NCT - 1]));
+    if constexpr (C::NACC > 1)
+      asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[C::NACC - 1]));
     else
       asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]));
     if constexpr (!(abl & 64)) {
+    if constexpr (C::X3) {  // one column tile: hi hi + (hi lo + lo hi)
+      float* zc = zs + (l31 / C::NU) * C::UB + wave * C::NU + l31 % C::NU;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zc[((r & 3) + 8 * (r >> 2) + 4 * hf) * C::ZS] = acc[0][r] + acc[1][r];
+    } else {
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       const int idx = ct * 32 + l31;
       float* zc = zs + (idx / C::NU) * C::UB + wave * C::NU + idx % C::NU;
 #pragma unroll
       for (int r = 0; r < 16; ++r) zc[((r & 3) + 8 * (r >> 2) + 4 * hf) * C::ZS] = acc[ct][r];
+    }
     }
     }
     st_slab += WREG_CLOCK() - sl0;
@@ -497,7 +558,10 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
       oo_cur[p] = oo_next[p];
     }
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) ap[ks] += tb_delta;
+    for (int ks = 0; ks < C::KS; ++ks) {
+      ap[ks] += tb_delta;
+      if constexpr (C::X3) apl[ks] += tb_delta;
+    }
   }
   // ---- the last tile's gate math
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -557,11 +621,23 @@ int wreg_nct(int in_i, int d) {
   if (nd == 8 && (nx == 8 || nx == 2)) return 2;
   return 0;
 }
+// the split engine's shapes (one column tile per wave; d = 1024 does not fit: 156 fragments)
+bool wreg_x3_built(int in_i, int d) {
+  if (!(wreg_mode() & 1) || in_i % 32 || d % 128) return false;
+  const int nx = in_i / 16, nd = d / 16;
+  return (nd == 32 && (nx == 14 || nx == 8)) || (nd == 8 && (nx == 8 || nx == 2));
+}
 
-void launch_cvt_weights_frag(const float* W, const float* bias, bf16_t* wf, int in, int in_i, int d, hipStream_t s) {
+void launch_cvt_weights_frag(const float* W, const float* bias, bf16_t* wf, int in, int in_i, int d, int xm, hipStream_t s) {
+  const int nk16 = (in_i + d) / 16;
+  if (xm == 2) {
+    if (!wreg_x3_built(in_i, d)) return;
+    const size_t total = (size_t)d * nk16 * 8 * 2;  // one thread per 8 weights of the [4d][K] kernel, two terms
+    hipLaunchKernelGGL((cvt_weights_frag_kernel<2, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, bias, wf, in, in_i, d, nk16);
+    return;
+  }
   const int nct = wreg_nct(in_i, d);
   if (!nct) return;
-  const int nk16 = (in_i + d) / 16;
   const size_t total = (size_t)d * nk16 * 8;  // one thread per 8 weights of the [4d][K] kernel
   const unsigned grid = (unsigned)((total + 255) / 256);
   if (nct == 2)
@@ -585,6 +661,16 @@ static void launch_wreg(const StepArgs& a, hipStream_t s) {
 
 bool launch_step_fwd_wreg(const StepArgs& a, hipStream_t s) {
   const int in_i = a.Kp - a.d;
+  if (a.xm == 2) {  // the split engine
+    if (!wreg_x3_built(in_i, a.d) || !a.Wf[0] || !a.hs) return false;
+    const int nx = in_i / 16, nd = a.d / 16;
+    if (nd == 32 && nx == 14) launch_wreg<WregCfg<14, 32, 1, true>>(a, s);
+    else if (nd == 32 && nx == 8) launch_wreg<WregCfg<8, 32, 1, true>>(a, s);
+    else if (nd == 8 && nx == 8) launch_wreg<WregCfg<8, 8, 1, true>>(a, s);
+    else if (nd == 8 && nx == 2) launch_wreg<WregCfg<2, 8, 1, true>>(a, s);
+    else return false;
+    return true;
+  }
   const int nct = wreg_nct(in_i, a.d);
   if (!nct || !a.Wf[0] || !a.hs) return false;
   const int nx = in_i / 16, nd = a.d / 16;
