@@ -98,65 +98,6 @@ __global__ __launch_bounds__(EMB_NT) void embed_fwd_kernel(EmbArgs a) {
   }
 }
 
-// The reference's shape (height 5, char_emb_size 8, max_word_size <= 16) with everything static: a value of the
-// token's character block is read ONCE (LDS broadcast, 16 B at a time) and pushed into the <= 5 windows it belongs
-// to, 12 window accumulators in registers -- exactly P*40 FMAs per filter, no predicated slots.
-__global__ __launch_bounds__(EMB_NT) void embed_fwd_kernel_5x8(EmbArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_E[16 * 8];
-  const fvta_embed_desc& d = a.d;
-  const int tid = threadIdx.x;
-  const int W = d.W, P = W - 4;
-  float wf[5][8];
-  float bf = 0.f;
-  if (tid < d.cwdim) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) wf[k][c] = a.filt[(size_t)(k * 8 + c) * d.cwdim + tid];
-    bf = a.bias[tid];
-  }
-  for (int tok = blockIdx.x; tok < d.ntok; tok += gridDim.x) {
-    float* row = a.x + a.tok_off[tok];
-    __syncthreads();  // the previous token's readers of s_E are done
-    if (tid < W * 8) s_E[tid] = a.char_emb[(size_t)a.char_ids[(size_t)tok * W + (tid >> 3)] * 8 + (tid & 7)] * emb_ks(a, tok, tid, W * 8);
-    __syncthreads();
-    if (tid < d.cwdim) {
-      float acc[12];
-#pragma unroll
-      for (int p = 0; p < 12; ++p) acc[p] = 0.f;
-#pragma unroll
-      for (int pos = 0; pos < 16; ++pos) {
-        if (pos < W) {  // workgroup-uniform
-          const f32x4 e0 = *reinterpret_cast<const f32x4*>(&s_E[pos * 8]);
-          const f32x4 e1 = *reinterpret_cast<const f32x4*>(&s_E[pos * 8 + 4]);
-#pragma unroll
-          for (int k = 0; k < 5; ++k) {
-            const int p = pos - k;  // static after unrolling
-            if (p >= 0 && p < 12) {
-#pragma unroll
-              for (int c = 0; c < 4; ++c) acc[p] += e0[c] * wf[k][c] + e1[c] * wf[k][c + 4];
-            }
-          }
-        }
-      }
-      float best = acc[0];
-      int bp = 0;
-#pragma unroll
-      for (int p = 1; p < 12; ++p)
-        if (p < P && acc[p] > best) {  // first arg-max
-          best = acc[p];
-          bp = p;
-        }
-      const float y = best + bf;
-      row[tid] = y > 0.f ? y : 0.f;
-      a.argpos[(size_t)tok * d.cwdim + tid] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
-    }
-    const int id = a.word_ids[tok];
-    const float* src = id < d.VW ? a.word_emb + (size_t)id * d.wdim : a.fixed_emb + (size_t)(id - d.VW) * d.wdim;
-    for (int i = tid; i < d.wdim; i += EMB_NT) row[d.cwdim + i] = src[i];
-  }
-}
-
 // gradients of the char-CNN parameters per workgroup (fixed token order), word rows by atomics
 __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel(EmbArgs a) {
   __shared__ float s_E[EMB_MAXWC], s_dE[EMB_MAXWC];
@@ -233,137 +174,6 @@ __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel(EmbArgs a) {
     slab[KC * d.cwdim + tid] = accb;
   }
   for (int i = tid; i < d.VC * d.cdim; i += EMB_NT) slab[KC * d.cwdim + d.cwdim + i] = s_dC[i];
-}
-
-// backward for the reference's shape (height 5, cdim 8, W <= 16): see embed_fwd_kernel_5x8.  The gradient w.r.t. the
-// token's character block is a scatter of each active filter's 5 x 8 weights to its arg-max window; it is made
-// conflict-free and order-fixed by letting thread (group, k*8+c) walk the filters f = group, group+3, ... and
-// accumulate S[group][p_f][k*8+c] in ITS OWN LDS cell, then dE[pos][c] = sum_group sum_k S[group][pos-k][k*8+c].
-// Like the forward kernel: char table in LDS, token stream software-pipelined two deep (ids / offsets of token i+2,
-// then arg-max positions and the dx row of token i+1, in flight while token i is processed).  The scatter into the
-// workgroup's char-gradient table is done by the first position of each distinct character, which sums its later
-// duplicates in position order -- parallel over (position, channel), same fixed order as a serial walk.
-__global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_5x8(EmbArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_E[16 * 8 + 32], s_dE[16 * 8];
-  __shared__ float s_g[EMB_NT];
-  __shared__ int s_p[EMB_NT];
-  __shared__ int s_ch[16];
-  __shared__ float s_S[3][12][40];
-  extern __shared__ float s_dyn[];  // filt [40][cwdim], dC [VC][8], char_emb [VC][8]
-  const fvta_embed_desc& d = a.d;
-  const int tid = threadIdx.x, W = d.W, cw = d.cwdim;
-  float* s_filt = s_dyn;
-  float* s_dC = s_dyn + 40 * cw;
-  float* s_cemb = s_dC + d.VC * 8;
-  float acc[40];
-#pragma unroll
-  for (int i = 0; i < 40; ++i) acc[i] = 0.f;
-  float accb = 0.f;
-  for (int i = tid; i < 40 * cw; i += EMB_NT) s_filt[i] = a.filt[i];
-  for (int i = tid; i < d.VC * 8; i += EMB_NT) {
-    s_dC[i] = 0.f;
-    s_cemb[i] = a.char_emb[i];
-  }
-  if (tid < 32) s_E[128 + tid] = 0.f;  // slack behind the block: a window read may run 4 positions past W - 5 + 4
-  const int grp = tid / 40, kc = tid % 40;  // tid < 120: the S builders
-  const int step = gridDim.x;
-  auto load_ids = [&](int tok, int& ch, int& wid, int64_t& off) {
-    const bool ok = tok < d.ntok;
-    ch = (ok && tid < W * 8) ? a.char_ids[(size_t)tok * W + (tid >> 3)] : 0;
-    wid = ok ? a.word_ids[tok] : 0;
-    off = ok ? a.tok_off[tok] : 0;
-  };
-  // stage B: this thread's arg-max position + upstream gradient of the char part, and its element(s) of the word part
-  auto load_grad = [&](int tok, int64_t off, int& ap, float& g, float& w0, float& w1) {
-    ap = 255;
-    g = w0 = w1 = 0.f;
-    if (tok >= d.ntok) return;
-    const float* row = a.dx + off;
-    if (tid < cw) {
-      ap = a.argpos[(size_t)tok * cw + tid];
-      g = row[tid];
-    }
-    if (tid < d.wdim) w0 = row[cw + tid];
-    if (tid + EMB_NT < d.wdim) w1 = row[cw + tid + EMB_NT];
-  };
-  int tok = blockIdx.x;
-  int ch0, wid0, ch1, wid1, ch2, wid2, ap0, ap1;
-  int64_t off0, off1, off2;
-  float g0, g1, w0a, w0b, w1a, w1b;
-  load_ids(tok, ch0, wid0, off0);
-  load_ids(tok + step, ch1, wid1, off1);
-  load_grad(tok, off0, ap0, g0, w0a, w0b);
-  for (; tok < d.ntok; tok += step) {
-    load_ids(tok + 2 * step, ch2, wid2, off2);
-    load_grad(tok + step, off1, ap1, g1, w1a, w1b);
-    if (wid0 < d.VW) {
-      float* dst = a.d_word_emb + (size_t)wid0 * d.wdim;
-      if (tid < d.wdim) atomicAdd(dst + tid, w0a);
-      if (tid + EMB_NT < d.wdim) atomicAdd(dst + tid + EMB_NT, w0b);
-      for (int i = tid + 2 * EMB_NT; i < d.wdim; i += EMB_NT) atomicAdd(dst + i, a.dx[off0 + cw + i]);
-    }
-    __syncthreads();
-    if (tid < W * 8) {
-      if ((tid & 7) == 0) s_ch[tid >> 3] = ch0;
-      s_E[tid] = s_cemb[ch0 * 8 + (tid & 7)] * emb_ks(a, tok, tid, W * 8);
-    }
-    const float g = ap0 != 255 ? g0 : 0.f;
-    const int p = ap0 != 255 ? ap0 : 0;
-    s_g[tid] = g;
-    s_p[tid] = p;
-    for (int i = tid; i < 3 * 12 * 40; i += EMB_NT) (&s_S[0][0][0])[i] = 0.f;
-    __syncthreads();
-    if (tid < cw && g != 0.f) {  // d filt[:, :, f] += g * window(p) (40 contiguous values); d bias[f] += g
-      accb += g;
-      const float* e = s_E + p * 8;
-#pragma unroll
-      for (int i = 0; i < 10; ++i) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(e + 4 * i);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[4 * i + c] += g * v[c];
-      }
-    }
-    if (tid < 120)
-      for (int f = grp; f < cw; f += 3) {
-        const float gf = s_g[f];
-        if (gf != 0.f) s_S[grp][s_p[f]][kc] += gf * s_filt[kc * cw + f];
-      }
-    __syncthreads();
-    if (tid < W * 8) {
-      const int pos = tid >> 3, c = tid & 7;
-      float v = 0.f;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const int pp = pos - k;
-        if (pp >= 0 && pp < 12) v += (s_S[0][pp][k * 8 + c] + s_S[1][pp][k * 8 + c]) + s_S[2][pp][k * 8 + c];
-      }
-      s_dE[tid] = v * emb_ks(a, tok, tid, W * 8);
-    }
-    __syncthreads();
-    // into the workgroup's char table.  Two positions may hold the same character: the FIRST position of a character
-    // adds its own value and then those of its later duplicates, in position order (what a serial walk would do).
-    if (tid < W * 8) {
-      const int pos = tid >> 3, c = tid & 7, me = s_ch[pos];
-      bool first = true;
-      for (int q = 0; q < pos; ++q) first = first && (s_ch[q] != me);
-      if (first) {
-        float v = s_dC[me * 8 + c];
-        for (int q = pos; q < W; ++q)
-          if (s_ch[q] == me) v += s_dE[q * 8 + c];
-        s_dC[me * 8 + c] = v;
-      }
-    }
-    ch0 = ch1; wid0 = wid1; off0 = off1; ap0 = ap1; g0 = g1; w0a = w1a; w0b = w1b;
-    ch1 = ch2; wid1 = wid2; off1 = off2;
-  }
-  __syncthreads();
-  float* slab = a.slab + (size_t)blockIdx.x * (40 * cw + cw + d.VC * 8);
-  if (tid < cw) {
-#pragma unroll
-    for (int i = 0; i < 40; ++i) slab[(size_t)i * cw + tid] = acc[i];
-    slab[40 * cw + tid] = accb;
-  }
-  for (int i = tid; i < d.VC * 8; i += EMB_NT) slab[40 * cw + cw + i] = s_dC[i];
 }
 
 // ---- the reference's shape on the matrix pipe: one WAVE per token ------------------------------------------------------
@@ -755,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void embed_bwd_5x8_filt(EmbArgs a) {
 // ---- general shape (any height * cdim, e.g. README.MD:144's --char_emb_size 100: a 500-deep window) ------------
 // Correct and order-fixed, not fast: the filter does not fit registers or LDS, so it is streamed from L2
 // (coalesced over the filter index) and the workgroup's filter-gradient slab is accumulated in global memory by
-// its owner threads.  The reference's default shape never gets here (embed_*_kernel_5x8).
+// its owner threads.  The reference's default shape never gets here (embed_*_5x8_* below).
 __global__ __launch_bounds__(EMB_NT) void embed_fwd_kernel_big(EmbArgs a) {
   extern __shared__ float s_dyn[];  // E [W * cdim]
   const fvta_embed_desc& d = a.d;
@@ -793,192 +603,8 @@ __global__ __launch_bounds__(EMB_NT) void embed_fwd_kernel_big(EmbArgs a) {
 // ---- wide char embeddings on the matrix pipe (README.MD:144's --char_emb_size 100) ----------------------------------
 // With a 500-deep window the convolution IS a GEMM: rows (token, window position p), k = (kh, c) -- the window of
 // position p is the CONTIGUOUS slice E[tok][p*cdim .. p*cdim + height*cdim) of the token's character block -- columns
-// the filters.  Exact-fp32 MFMA tile engine of the LSTM's parity path (gemm_f32.h): 128 x 128 tile = 8 tokens x 16
-// positions (positions >= P are zero rows) x 128 filters; the A operand is gathered straight from the character table
-// (a few KB, L1 / L2 resident) through the char ids staged in LDS; the epilogue takes max / first arg-max over the
-// positions of a token (its 16 rows sit in one 32 x 32 accumulator tile: 8 rows per lane, the other 8 in lane ^ 32).
-// Needs W <= 16, cdim % 4 == 0, cwdim % 4 == 0, cwdim <= 128.
-typedef MmaF32<2, 2, 2, 2> MmaEmb;  // 128 x 128, four waves
-__global__ __launch_bounds__(256) void embed_fwd_kernel_mfma(EmbArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float s_gemm[];
-  __shared__ int s_chid[8 * 16];
-  const fvta_embed_desc& d = a.d;
-  const int tid = threadIdx.x;
-  const int tok0 = blockIdx.x * 8;
-  const int KC = d.height * d.cdim, P = d.W - d.height + 1, cd = d.cdim, cw = d.cwdim;
-  if (tid < 128) {
-    const int tk = tok0 + (tid >> 4), pos = tid & 15;
-    s_chid[tid] = (tk < d.ntok && pos < d.W) ? a.char_ids[(size_t)tk * d.W + pos] : -1;
-  }
-  __syncthreads();
-  MmaEmb mma;
-  mma.init(tid);
-  StageKContig<128, 16, 256, MmaEmb::LDA> sa;
-  StageMNContig<128, 16, 256, MmaEmb::LDB> sb;
-  auto fa = [&](int r, int k, bool& ok) -> const float* {  // row r = 16 * local token + p, k = kh * cdim + c (c % 4 == 0)
-    const int tl = r >> 4, pp = r & 15;
-    const int kh = k / cd, c = k - kh * cd;
-    const int pos = pp + kh;
-    const int ch = (k < KC && pp < P) ? s_chid[tl * 16 + (pos & 15)] : -1;   // pp < P => pos < W <= 16
-    ok = ch >= 0;
-    return a.char_emb + (size_t)(ok ? ch : 0) * cd + (ok ? c : 0);
-  };
-  auto fb = [&](int k, int c, bool& ok) -> const float* {  // filt [KC][cwdim]
-    ok = k < KC && c < cw;
-    return a.filt + (ok ? (size_t)k * cw + c : 0);
-  };
-  gemm_mainloop(mma, sa, sb, fa, fb, 0, (KC + 15) / 16 * 16, s_gemm, tid);
-#pragma unroll
-  for (int i = 0; i < MmaEmb::TM; ++i)
-#pragma unroll
-    for (int j = 0; j < MmaEmb::TN; ++j) {
-      const int f = mma.col_of(j);
-      const float bf = f < cw ? a.bias[f] : 0.f;
-#pragma unroll
-      for (int hs = 0; hs < 2; ++hs) {  // the tile's two tokens: accumulator registers 0..7 and 8..15
-        float best = -INFINITY;
-        int bp = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int r = hs * 8 + q;
-          const int pp = (r & 3) + 8 * ((r >> 2) & 1) + 4 * mma.hf;  // position inside the token, increasing with q
-          const float v = mma.acc[i][j][r];
-          if (pp < P && v > best) {
-            best = v;
-            bp = pp;
-          }
-        }
-        const float ob = __shfl_xor(best, 32, 64);
-        const int op = __shfl_xor(bp, 32, 64);
-        if (ob > best || (ob == best && op < bp)) {  // first arg-max over all positions
-          best = ob;
-          bp = op;
-        }
-        const int tok = tok0 + mma.wm * 4 + i * 2 + hs;
-        if (mma.hf == 0 && tok < d.ntok && f < cw) {
-          const float y = best + bf;
-          a.x[a.tok_off[tok] + f] = y > 0.f ? y : 0.f;
-          a.argpos[(size_t)tok * cw + f] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
-        }
-      }
-    }
-  // the word part of the 8 rows
-  for (int tl = 0; tl < 8; ++tl) {
-    const int tok = tok0 + tl;
-    if (tok >= d.ntok) break;
-    const int id = a.word_ids[tok];
-    const float* src = id < d.VW ? a.word_emb + (size_t)id * d.wdim : a.fixed_emb + (size_t)(id - d.VW) * d.wdim;
-    float* row = a.x + a.tok_off[tok];
-    for (int c = tid; c < d.wdim; c += 256) row[cw + c] = src[c];
-  }
-}
-
-// The same convolution with the FILTERS in registers (height 5, char_emb_size 100, CW = 100, W <= 16): one WAVE per token and
-// slice of 16 filters -- Y[p][f] = sum_kc E[p cd + kc] filt[kc][f] as 128 k-steps of ONE v_mfma_f32_16x16x4_f32 tile (16 window
-// positions x 16 filters; four partial accumulators break the dependent chain), the slice's filter fragments in 128 registers
-// for the whole launch (two waves per SIMD), the token's character block [16][cd] staged once in LDS and read as the A operand
-// 16 bytes at a time: k is permuted so that a lane's float4 E[p cd + 16 g + 4 q ..] feeds k-steps 4 g .. 4 g + 3 (the filter
-// fragments are loaded in the same order; kc >= 500 multiplies by zero).  Max / first arg-max over the positions: 4 per lane,
-// then across the four lane groups.  grid (ceil(CW / 16), blocks).  The tile engine above spends 0.75 x 0.78 of its tile on
-// padding and gathers its A operand element by element: 11.3 ms at the published flag set's token count.
-template <int CW, int CD>
-__global__ __launch_bounds__(256, 2) void embed_fwdw_mfma(EmbArgs a) {
-  constexpr int KC = 5 * CD, NG = (KC + 15) / 16, NW = 4, EB = 15 * CD + 16 * NG;  // floats of a staged block (the last window's reach)
-  constexpr int EBP = (EB + 3) / 4 * 4, NL4 = (16 * CD / 4 + 63) / 64;             // float4 loads per lane and token
-  static_assert(CD % 4 == 0, "character rows are read 16 bytes at a time");
-  __shared__ __attribute__((aligned(16))) float s_E[NW][EBP];
-  const fvta_embed_desc& d = a.d;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int j = lane & 15, q = lane >> 4;
-  const int W = d.W, P = W - 4;
-  const int f = blockIdx.x * 16 + j;
-  float Bf[4 * NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kc = 16 * g + 4 * q + i;
-      Bf[4 * g + i] = (kc < KC && f < CW) ? a.filt[(size_t)kc * CW + f] : 0.f;
-    }
-  const float bias = f < CW ? a.bias[f] : 0.f;
-  float* Es = s_E[wv];
-  for (int i = lane; i < EBP; i += 64) Es[i] = 0.f;  // (positions >= W and the reach beyond the block stay zero)
-  auto word_src = [&](int id) { return id < d.VW ? a.word_emb + (size_t)id * d.wdim : a.fixed_emb + (size_t)(id - d.VW) * d.wdim; };
-  auto load_E = [&](int tok, f32x4 (&e)[NL4]) {  // clamped token: branch-free
-    const int t = tok < d.ntok ? tok : d.ntok - 1;
-#pragma unroll
-    for (int i = 0; i < NL4; ++i) {
-      const int u = lane + 64 * i, pos = u / (CD / 4), c4 = u % (CD / 4);
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (u < 16 * CD / 4 && pos < W) {
-        v = *reinterpret_cast<const f32x4*>(a.char_emb + (size_t)a.char_ids[(size_t)t * W + pos] * CD + 4 * c4);
-        if (a.drop_thr != 0ull)
-#pragma unroll
-          for (int x = 0; x < 4; ++x) v[x] *= emb_ks(a, t, pos * CD + 4 * c4 + x, W * CD);
-      }
-      e[i] = v;
-    }
-  };
-  const int step = gridDim.y * NW;
-  int tok = blockIdx.y * NW + wv;
-  f32x4 e_n[NL4];
-  load_E(tok, e_n);
-  wave_lds_fence();
-  for (; tok < d.ntok; tok += step) {
-#pragma unroll
-    for (int i = 0; i < NL4; ++i) {
-      const int u = lane + 64 * i;
-      if (u < 16 * CD / 4) *reinterpret_cast<f32x4*>(Es + 4 * u) = e_n[i];
-    }
-    load_E(tok + step, e_n);
-    wave_lds_fence();
-    f32x4 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* ap = Es + j * CD + 4 * q;  // window position p = j
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 16 * g);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], Bf[4 * g + i], acc[i], 0, 0, 0);
-    }
-    // D[p = 4 q + r][f = j]: max / FIRST arg-max over the valid positions
-    float best = -INFINITY;
-    int bp = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
-      const int p = 4 * q + r;
-      if (p < P && v > best) {
-        best = v;
-        bp = p;
-      }
-    }
-#pragma unroll
-    for (int sh = 16; sh <= 32; sh <<= 1) {
-      const float ob = __shfl_xor(best, sh, 64);
-      const int op = __shfl_xor(bp, sh, 64);
-      if (ob > best || (ob == best && op < bp)) {
-        best = ob;
-        bp = op;
-      }
-    }
-    float* row = a.x + a.tok_off[tok];
-    if (q == 0 && f < CW) {
-      const float y = best + bias;
-      row[f] = y > 0.f ? y : 0.f;
-      a.argpos[(size_t)tok * CW + f] = y > 0.f ? (uint8_t)bp : (uint8_t)255;
-    }
-    if (blockIdx.x == 0) {  // the word part of the row rides along with the first slice
-      const float* src = word_src(a.word_ids[tok]);
-      for (int i = lane; i < d.wdim; i += 64) row[CW + i] = src[i];
-    }
-    wave_lds_fence();  // the block's readers are done before the next token overwrites it
-  }
-}
-template __global__ void embed_fwdw_mfma<100, 100>(EmbArgs);
-
-// The same convolution on the FP16 matrix pipe with the 3-term split of the focal attention's logits (attn_fwd.hip): every
+// the filters.
+// The convolution on the FP16 matrix pipe with the 3-term split of the focal attention's logits (attn_fwd.hip): every
 // value x = hi + 2^-11 lo' (hi = rtz_f16(x), lo' = f16((x - hi) 2^11)), product = hi hi + 2^-11 (hi lo' + lo' hi): three
 // v_mfma_f32_16x16x32_f16 (16 cycles each) per 32 k instead of eight v_mfma_f32_16x16x4_f32 (32 cycles each), <= 3 2^-22
 // |E| |filt| per product -- the fp32 kernel's own rounding is 2^-24 per product.  One workgroup = SEVEN waves = the seven
@@ -1171,178 +797,12 @@ __global__ __launch_bounds__(64 * ((((CW + 15) / 16) + SPW - 1) / SPW), 1) void 
 template __global__ void embed_fwdw_f16x3<100, 100, 1>(EmbArgs);
 template __global__ void embed_fwdw_f16x3<100, 100, 2>(EmbArgs);
 
-// Backward of the wide shape, in the SPARSE form (one window per token and filter carries gradient: 12x fewer MACs than
-// the GEMM form), split so that every accumulator lives in registers / LDS instead of a global slab:
-//  * embed_bwdw_filt: d filter / d bias.  grid (k chunks of 128, blocks); thread f keeps its 128 filter-gradient
-//    values of the chunk in registers and adds g_f * E[tok][argpos_f * cdim + k] from the token's character block in
-//    LDS (positions of different filters hit different banks: 100 * p mod 64 is injective for p < 12);
-//  * embed_bwdw_char: d E -> d char_emb.  grid (channel slices of 32, blocks); the filter slice of 32 channels
-//    ([height][32][cwdim], 64 KB) sits in LDS, thread (position group, channel) sums g_f * filt[pos - argpos_f][c][f]
-//    over the filters in fixed order, then the first position of every distinct character folds its duplicates and
-//    adds into the workgroup's char table slice.
-// Both write the SAME slab layout as the other kernels ([KC*cwdim | cwdim | VC*cdim] per block), so
-// embed_bwd_reduce_kernel finishes the job in a fixed order.
-#ifndef FVTA_EMBW_CHAR_MFMA
-#define FVTA_EMBW_CHAR_MFMA 1
-#endif
-#ifndef FVTA_EMBW_FWD_WAVE
-#define FVTA_EMBW_FWD_WAVE 1
-#endif
 #ifndef FVTA_EMBW_SPW
 #define FVTA_EMBW_SPW 1     // filter slices per wave of embed_fwdw_f16x3: 1 = seven waves (2.6 ms at the published flag set), 2 = four
                             // waves with half the LDS reads but one wave per SIMD (3.3 ms: the kernel is not LDS-bound)
 #endif
-#ifndef FVTA_EMBW_CHAR_TOK
-#define FVTA_EMBW_CHAR_TOK 1   // d char_emb of the wide shape as a workgroup per token with the scatter on the matrix pipe
-#endif
-#ifndef FVTA_EMBW_FILT_TOK
-#define FVTA_EMBW_FILT_TOK 1   // d filt of the wide shape as a workgroup per token (0: a wave per (token, slice))
-#endif
-#ifndef FVTA_EMBW_F16X3
-#define FVTA_EMBW_F16X3 1   // the wide char-CNN on the fp16 matrix pipe with the 3-term split (0: exact-fp32 MFMA kernels)
-#endif
-constexpr int EMBW_KCH = 128;   // k values per chunk (registers)
-constexpr int EMBW_CS = 32;     // channels per slice
-__global__ __launch_bounds__(EMB_NT) void embed_bwdw_filt(EmbArgs a) {
-  extern __shared__ float s_E[];  // [W * cdim]
-  const fvta_embed_desc& d = a.d;
-  const int tid = threadIdx.x, cw = d.cwdim, cd = d.cdim;
-  const int KC = d.height * cd, WC = d.W * cd;
-  const int k0 = blockIdx.x * EMBW_KCH;
-  float acc[EMBW_KCH];
-#pragma unroll
-  for (int i = 0; i < EMBW_KCH; ++i) acc[i] = 0.f;
-  float accb = 0.f;
-  for (int tok = blockIdx.y; tok < d.ntok; tok += gridDim.y) {
-    const float* row = a.dx + a.tok_off[tok];
-    if (blockIdx.x == 0) {  // the word rows ride along with the first chunk
-      const int id = a.word_ids[tok];
-      if (id < d.VW)
-        for (int i = tid; i < d.wdim; i += EMB_NT) atomicAdd(a.d_word_emb + (size_t)id * d.wdim + i, row[cw + i]);
-    }
-    float g = 0.f;
-    int p = 0;
-    if (tid < cw) {
-      const int ap = a.argpos[(size_t)tok * cw + tid];
-      if (ap != 255) {
-        g = row[tid];
-        p = ap;
-      }
-    }
-    __syncthreads();  // the previous token's readers of s_E are done
-    for (int i = tid; i < WC; i += EMB_NT)
-      s_E[i] = a.char_emb[(size_t)a.char_ids[(size_t)tok * d.W + i / cd] * cd + i % cd] * emb_ks(a, tok, i, WC);
-    __syncthreads();
-    if (g != 0.f) {
-      accb += g;
-      // branch-free: under `if (k0 + i < KC)` every element was a scalar branch around ONE LDS read and its FMA -- 128 exposed
-      // LDS latencies per token (~8 us).  The chunk's tail reads a clamped (valid) address and adds nothing.
-      const float* e = s_E + p * cd + k0;
-      const int nv = min(EMBW_KCH, KC - k0);  // valid elements of this chunk
-#pragma unroll
-      for (int i = 0; i < EMBW_KCH; ++i) acc[i] += (i < nv ? g : 0.f) * e[min(i, nv - 1)];
-    }
-  }
-  float* slab = a.slab + (size_t)blockIdx.y * ((size_t)KC * cw + cw + (size_t)d.VC * cd);
-  if (tid < cw) {
-#pragma unroll
-    for (int i = 0; i < EMBW_KCH; ++i)
-      if (k0 + i < KC) slab[(size_t)(k0 + i) * cw + tid] = acc[i];
-    if (blockIdx.x == 0) slab[(size_t)KC * cw + tid] = accb;
-  }
-}
 
-__global__ __launch_bounds__(256) void embed_bwdw_char(EmbArgs a) {
-  extern __shared__ float s_dyn[];  // filter slice [height][CS][cwdim], then dC [VC][CS], then dE [16][CS]
-  __shared__ float s_g[128];
-  __shared__ int s_p[128];
-  __shared__ int s_ch[16];
-  const fvta_embed_desc& d = a.d;
-  const int tid = threadIdx.x, cw = d.cwdim, cd = d.cdim, H = d.height, W = d.W;
-  const int c0 = blockIdx.x * EMBW_CS, nc = min(EMBW_CS, cd - c0);
-  const int ldf = cw + 1;                   // odd row length: the 32 channels of a wave read 32 different banks
-  float* s_f = s_dyn;                       // [H][CS][ldf]
-  float* s_dC = s_f + H * EMBW_CS * ldf;    // [VC][CS]
-  float* s_dE = s_dC + d.VC * EMBW_CS;      // [16][CS]
-  for (int i = tid; i < H * EMBW_CS * cw; i += 256) {
-    const int f = i % cw, cl = (i / cw) % EMBW_CS, kh = i / (cw * EMBW_CS);
-    s_f[(kh * EMBW_CS + cl) * ldf + f] = cl < nc ? a.filt[(size_t)(kh * cd + c0 + cl) * cw + f] : 0.f;
-  }
-  for (int i = tid; i < d.VC * EMBW_CS; i += 256) s_dC[i] = 0.f;
-  const int cl = tid & (EMBW_CS - 1), pg = tid >> 5;  // 8 position groups: positions pg and pg + 8
-  // this thread's share of a token's staging data (tid < 128: filter tid; tid < 16: char position tid), requested one
-  // token ahead: the dependent global loads (tok_off -> dx row, argpos, char ids) otherwise cost ~2 us per token
-  auto fetch = [&](int tok, float& g, int& p, int& ch) {
-    g = 0.f;
-    p = 0;
-    ch = -1;
-    if (tok >= d.ntok) return;
-    if (tid < cw) {
-      const int ap = a.argpos[(size_t)tok * cw + tid];
-      const float r = a.dx[a.tok_off[tok] + tid];
-      if (ap != 255) {
-        g = r;
-        p = ap;
-      }
-    }
-    if (tid < W) ch = a.char_ids[(size_t)tok * W + tid];
-  };
-  float g_n;
-  int p_n, ch_n;
-  fetch(blockIdx.y, g_n, p_n, ch_n);
-  for (int tok = blockIdx.y; tok < d.ntok; tok += gridDim.y) {
-    const float g_c = g_n;
-    const int p_c = p_n, ch_c = ch_n;
-    fetch(tok + gridDim.y, g_n, p_n, ch_n);
-    __syncthreads();
-    if (tid < 128) {
-      s_g[tid] = g_c;
-      s_p[tid] = p_c;
-    }
-    if (tid < 16) s_ch[tid] = ch_c;
-    __syncthreads();
-    float v0 = 0.f, v1 = 0.f;  // d E[pg][c], d E[pg + 8][c]
-    // branch-free (clamped row, zero weight) so that the loop unrolls and its LDS reads pipeline: with the test on g
-    // and on the window offsets as branches every iteration exposed ~4 dependent LDS latencies (400 cycles)
-    const float* fa = s_f + cl * ldf;
-#pragma unroll 4
-    for (int f = 0; f < cw; ++f) {  // filters in index order: d E has ONE summation order
-      const float g = s_g[f];
-      const int p = s_p[f];
-      const int ka = pg - p, kb = ka + 8;
-      const bool oa = (unsigned)ka < (unsigned)H, ob = (unsigned)kb < (unsigned)H;
-      v0 += (oa ? g : 0.f) * fa[(oa ? ka : 0) * (EMBW_CS * ldf) + f];
-      v1 += (ob ? g : 0.f) * fa[(ob ? kb : 0) * (EMBW_CS * ldf) + f];
-    }
-    s_dE[pg * EMBW_CS + cl] = v0 * emb_ks(a, tok, pg * cd + c0 + cl, W * cd);
-    s_dE[(pg + 8) * EMBW_CS + cl] = v1 * emb_ks(a, tok, (pg + 8) * cd + c0 + cl, W * cd);
-    __syncthreads();
-    // the first position of a character adds itself and its later duplicates (position order) to the table slice
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int pos = pg + 8 * h;
-      const int me = pos < W ? s_ch[pos] : -1;
-      if (me < 0) continue;
-      bool first = true;
-      for (int q = 0; q < pos; ++q) first = first && (s_ch[q] != me);
-      if (first) {
-        float v = s_dC[me * EMBW_CS + cl];
-        for (int q = pos; q < W; ++q)
-          if (s_ch[q] == me) v += s_dE[q * EMBW_CS + cl];
-        s_dC[me * EMBW_CS + cl] = v;
-      }
-    }
-  }
-  __syncthreads();
-  const int KC = H * cd;
-  float* slab_c = a.slab + (size_t)blockIdx.y * ((size_t)KC * cw + cw + (size_t)d.VC * cd) + (size_t)KC * cw + cw;
-  for (int i = tid; i < d.VC * EMBW_CS; i += 256) {
-    const int v = i / EMBW_CS, c = i % EMBW_CS;
-    if (c < nc) slab_c[(size_t)v * cd + c0 + c] = s_dC[i];
-  }
-}
-
-// d filt / d bias of the wide shape, a WORKGROUP per token (embed_bwdw_filt_mfma below runs a wave per (token, slice): seven
+// d filt / d bias of the wide shape, a WORKGROUP per token (round 4's form ran a wave per (token, slice): seven
 // waves somewhere on the chip each gather the token's gradient row, arg-max positions and their 16 channels of its characters --
 // 1.7 of its 6.1 ms -- and its four waves per workgroup work on four different tokens).  Here the seven waves of a workgroup ARE
 // the seven 16-channel slices of ONE token: the character block (16 positions x cdim, dropped as in the forward), the gradient
@@ -1552,11 +1012,10 @@ __global__ __launch_bounds__(448, 1) void embed_bwdw_filt_tok(EmbArgs a) {
     for (int nt = 0; nt < NNT; ++nt)
       if (16 * nt + j < CW) slab[(size_t)KC * CW + 16 * nt + j] = accb[nt];
 }
-template __global__ void embed_bwdw_filt_tok<100, 100, false>(EmbArgs);
 template __global__ void embed_bwdw_filt_tok<100, 100, true>(EmbArgs);
 
 // d char_emb of the wide shape, a WORKGROUP per token, with NO transposed tile, NO 5-tap fold and NO LDS float adds (those three
-// were 3.7 of embed_bwdw_char_f16x3's 6.2 ms: -DFVTA_EMBW_ABL).  Two matrix products per token and 16-channel slice (wave):
+// were 3.7 of the wave-per-(token, slice) form's 6.2 ms: -DFVTA_EMBW_ABL).  Two matrix products per token and 16-channel slice (wave):
 //  (1) dE[pos][c] = sum over (k, f) of Gs[pos][(k, f)] filt[k][c][f] with the SHIFTED one-hot Gs[pos][(k, f)] = g_f [argpos_f + k = pos]:
 //      the fold over the five taps is part of the contraction (K = 5 x 104: 17 k-steps of v_mfma_f32_16x16x32_f16 x 3, the fp16
 //      3-term split of embed_fwdw_f16x3; the slice's filter fragments in 136 registers for the launch).  Gs is the same for
@@ -1737,464 +1196,6 @@ __global__ __launch_bounds__(448, 1) void embed_bwdw_char_tok(EmbArgs a) {
 template __global__ void embed_bwdw_char_tok<100, 100>(EmbArgs);
 
 // d char_emb of the wide shape on the matrix pipe (height 5, CW = 100 filters, W <= 16; any cdim in slices of EMBM_CS channels;
-// the counts below are those of 25-channel slices):
-// embed_bwd_5x8_char's scheme with a channel slice in place of the 8 channels.  One WAVE per token: the scatter of each active
-// filter's 5 x CS weights to its arg-max window is the product T[p][l] = sum_f G[p][f] filt[kc(l)][f], l = k CS + c (125 of 128
-// columns), with the one-hot G[p][f] = g_f [argpos_f = p] built from the staged gradient row -- 25 k-steps x 8 column tiles
-// of v_mfma_f32_16x16x4_f32, the slice's filter fragments in 200 registers for the whole launch; T goes through a transposed
-// LDS tile, dE[pos][c] = sum_k T[pos - k][k CS + c], and is added into the workgroup's char-table slice (LDS float adds: 7 per
-// lane and token beside 200 MFMAs).  embed_bwdw_char (vector pipe, two filter reads + two broadcast reads per filter and
-// thread, two in three of them multiplied by zero) took 27.7 ms at char_emb_size 100; this one is bound by its 6400 cycles
-// of fp32 MFMA per token and slice.  grid (ceil(cdim / 25), blocks), 256 threads, slab part [KC cw + cw ..) of block y.
-// channels per slice: 16 (80 of 80 columns in 5 tiles, <= 256 registers: TWO waves per SIMD -- d filt 7.4 -> 6.1 ms, d char 8.0 ->
-// 7.6 at char_emb_size 100, although 7 slices of 5 tiles are 9 % more MFMAs than 4 of 8 at 25 channels, one wave per SIMD)
-#ifndef FVTA_EMBM_CS
-#define FVTA_EMBM_CS 16
-#endif
-constexpr int EMBM_CS = FVTA_EMBM_CS, EMBM_NT = (5 * EMBM_CS + 15) / 16, EMBM_OCC = EMBM_CS <= 16 ? 2 : 1;
-template <int CW>
-__global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_char_mfma(EmbArgs a) {
-  using C = Emb5x8<CW>;
-  constexpr int CS = EMBM_CS, NCT = EMBM_NT;  // 5 CS = 125 local columns l = k CS + c in 8 tiles of 16
-  extern __shared__ __attribute__((aligned(16))) float s_dCall[];  // [4 waves][VC][CS]: a table per wave (one summation order)
-  __shared__ __attribute__((aligned(16))) float s_T[C::NW][NCT * 16 * 16], s_G[C::NW][4 * C::GP];
-  __shared__ __attribute__((aligned(16))) uint8_t s_P[C::NW][4 * 32];
-  __shared__ int s_ch[C::NW][16];
-  const fvta_embed_desc& d = a.d;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int j = lane & 15, q = lane >> 4;
-  const int W = d.W, cd = d.cdim;
-  const int c0 = blockIdx.x * CS, nc = min(CS, cd - c0);
-  float* s_dC = s_dCall + (size_t)wv * d.VC * CS;
-  for (int i = lane; i < d.VC * CS; i += 64) s_dC[i] = 0.f;
-  float* Tt = s_T[wv];
-  for (int i = lane; i < 4 * C::GP; i += 64) s_G[wv][i] = 0.f;
-  for (int i = lane; i < 128; i += 64) s_P[wv][i] = 255;
-  // the slice's filter fragments: B[k = 4 ks + q][n = 16 ct + j] = filt[kc(l = 16 ct + j)][4 ks + q], zero beyond the slice
-  float Bf[C::NKS][NCT];
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct) {
-    const int l = 16 * ct + j, k = l / CS, c = l % CS;
-    const bool ok = l < 5 * CS && c < nc;
-    const float* src = a.filt + (size_t)(k * cd + c0 + c) * CW + q;
-#pragma unroll
-    for (int ks = 0; ks < C::NKS; ++ks) Bf[ks][ct] = ok ? src[4 * ks] : 0.f;
-  }
-  __syncthreads();
-  const int step = gridDim.y * C::NW;
-  const bool has2 = lane + 64 < CW;
-  const int lane2 = has2 ? 64 + lane : lane;
-  const int posc = lane < W ? lane : W - 1;
-  auto load_tok = [&](int tok, int& ap1, int& ap2, float& g1, float& g2, int& ch) {  // branch-free: clamped token
-    const int t = tok < d.ntok ? tok : d.ntok - 1;
-    const float* row = a.dx + a.tok_off[t];
-    ap1 = a.argpos[(size_t)t * CW + lane];
-    const int b2 = a.argpos[(size_t)t * CW + lane2];
-    g1 = row[lane];
-    g2 = row[lane2];
-    ap2 = has2 ? b2 : 255;
-    ch = a.char_ids[(size_t)t * W + posc];
-  };
-  // the lane's cells of dE[pos][c]: T index of k = 0 (column l = c, row pos), position (-1: no cell), channel
-  constexpr int NIT = (16 * CS + 63) / 64;
-  int tb[NIT], ps[NIT], cs_[NIT];
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int it = lane + 64 * i, pos = it / CS, c = it % CS;
-    const bool ok = it < 16 * CS && c < nc;
-    tb[i] = ok ? c * 16 + pos : 0;
-    ps[i] = ok ? pos : -1;
-    cs_[i] = ok ? c : 0;
-  }
-  int tok = blockIdx.y * C::NW + wv;
-  int ap1, ap2, ch, ap1n, ap2n, chn;
-  float g1, g2, g1n, g2n;
-  load_tok(tok, ap1, ap2, g1, g2, ch);
-  for (; tok < d.ntok; tok += step) {
-    load_tok(tok + step, ap1n, ap2n, g1n, g2n, chn);
-    // stage the gradient row in k-phase order (filter f at [(f & 3)][f >> 2]) and the word's characters
-    s_G[wv][(lane & 3) * C::GP + (lane >> 2)] = ap1 == 255 ? 0.f : g1;
-    s_P[wv][(lane & 3) * 32 + (lane >> 2)] = (uint8_t)ap1;
-    if (has2) {
-      s_G[wv][(lane & 3) * C::GP + 16 + (lane >> 2)] = ap2 == 255 ? 0.f : g2;
-      s_P[wv][(lane & 3) * 32 + 16 + (lane >> 2)] = (uint8_t)ap2;
-    }
-    if (lane < 16) s_ch[wv][lane] = lane < W ? ch : -1;
-    wave_lds_fence();
-    // T[p][l] = sum_f G[p][f] filt[kc(l)][f]: lane (p = j, k phase q) builds G from the staged row
-    uint32_t Pv[8];
-    {
-      const uint4 p0 = *reinterpret_cast<const uint4*>(&s_P[wv][q * 32]);
-      const uint4 p1 = *reinterpret_cast<const uint4*>(&s_P[wv][q * 32 + 16]);
-      Pv[0] = p0.x; Pv[1] = p0.y; Pv[2] = p0.z; Pv[3] = p0.w;
-      Pv[4] = p1.x; Pv[5] = p1.y; Pv[6] = p1.z; Pv[7] = p1.w;
-    }
-    f32x4 accT[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) accT[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int v = 0; v < C::GP / 4; ++v) {
-      const f32x4 Gv = *reinterpret_cast<const f32x4*>(&s_G[wv][q * C::GP + 4 * v]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ks = 4 * v + i;
-        if (ks < C::NKS) {
-          const int pb = (int)((Pv[v] >> (8 * i)) & 255u);
-          const float av = pb == j ? Gv[i] : 0.f;
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) accT[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Bf[ks][ct], accT[ct], 0, 0, 0);
-        }
-      }
-    }
-    // T -> LDS as [l][p] (a lane's four rows p = 4 q + r are one 16-byte store), then dE[pos][c] = sum_k T[pos - k][k CS + c]
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(&Tt[(16 * ct + j) * 16 + 4 * q]) = accT[ct];
-    wave_lds_fence();
-    // (the lane's NIT cells (pos, c): indices precomputed, all 5 NIT reads of the tile in flight together)
-    float dv[NIT];
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      float v = 0.f;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const float tv = Tt[tb[i] + (ps[i] >= k ? k * (16 * CS - 1) : 0)];
-        v += ps[i] >= k ? tv : 0.f;
-      }
-      dv[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int me = s_ch[wv][ps[i] & 15];
-      if (ps[i] >= 0 && me >= 0) lds_fadd(&s_dC[me * CS + cs_[i]], dv[i] * emb_ks(a, tok, ps[i] * cd + c0 + cs_[i], W * cd));
-    }
-    wave_lds_fence();
-    ap1 = ap1n; ap2 = ap2n; g1 = g1n; g2 = g2n; ch = chn;
-  }
-  __syncthreads();
-  const int KC = 5 * cd;
-  float* slab_c = a.slab + (size_t)blockIdx.y * ((size_t)KC * CW + CW + (size_t)d.VC * cd) + (size_t)KC * CW + CW;
-  for (int i = threadIdx.x; i < d.VC * CS; i += 256) {
-    const int v = i / CS, c = i % CS;
-    if (c < nc) {
-      float t = 0.f;
-      for (int w4 = 0; w4 < C::NW; ++w4) t += s_dCall[(size_t)w4 * d.VC * CS + i];  // wave order
-      slab_c[(size_t)v * cd + c0 + c] = t;
-    }
-  }
-}
-template __global__ void embed_bwdw_char_mfma<100>(EmbArgs);
-
-// embed_bwdw_char_mfma on the fp16 matrix pipe with the 3-term split (embed_fwdw_f16x3): the one-hot product over the
-// CW = 100 filters is 4 k-steps of 32 x 5 column tiles x 3 v_mfma_f32_16x16x32_f16 = 960 matrix-pipe cycles per token and
-// slice instead of 25 x 5 v_mfma_f32_16x16x4_f32 = 4000; everything around it (gradient row staging, the transposed T tile,
-// the per-wave char tables in LDS) is that kernel's.
-template <int CW>
-__global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_char_f16x3(EmbArgs a) {
-  using C = Emb5x8<CW>;
-  constexpr int CS = EMBM_CS, NCT = EMBM_NT;  // 5 CS = 125 local columns l = k CS + c in 8 tiles of 16
-  extern __shared__ __attribute__((aligned(16))) float s_dCall[];  // [4 waves][VC][CS]: a table per wave (one summation order)
-  constexpr int NK32 = (CW + 31) / 32;  // k-steps of 32 filters
-  __shared__ __attribute__((aligned(16))) float s_T[C::NW][NCT * 16 * 16], s_G[C::NW][32 * NK32];
-  __shared__ __attribute__((aligned(16))) uint8_t s_P[C::NW][32 * NK32];
-  __shared__ int s_ch[C::NW][16];
-  const fvta_embed_desc& d = a.d;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int j = lane & 15, q = lane >> 4;
-  const int W = d.W, cd = d.cdim;
-  const int c0 = blockIdx.x * CS, nc = min(CS, cd - c0);
-  float* s_dC = s_dCall + (size_t)wv * d.VC * CS;
-  for (int i = lane; i < d.VC * CS; i += 64) s_dC[i] = 0.f;
-  float* Tt = s_T[wv];
-  for (int i = lane; i < 32 * NK32; i += 64) s_G[wv][i] = 0.f;
-  for (int i = lane; i < 32 * NK32; i += 64) s_P[wv][i] = 255;
-  // the slice's filter fragments, fp16 (hi, lo'): B[k = 32 ks + 8 q + e][n = 16 ct + j] = filt[kc(l = 16 ct + j)][k], zero beyond
-  // the slice and the filters (unconditional loads of clamped addresses, then a select)
-  half8 Bh[NK32][NCT], Bl[NK32][NCT];
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct) {
-    const int l = 16 * ct + j, k = l / CS, c = l % CS;
-    const bool ok = l < 5 * CS && c < nc;
-    const float* src = a.filt + (size_t)(ok ? k * cd + c0 + c : 0) * CW;
-#pragma unroll
-    for (int ks = 0; ks < NK32; ++ks) {
-      half2v h[4], lo[4];
-#pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) {
-        const int f0 = 32 * ks + 8 * q + 2 * e2;
-        const float y0 = src[f0 < CW ? f0 : CW - 1], y1 = src[f0 + 1 < CW ? f0 + 1 : CW - 1];
-        split_f16x2((ok && f0 < CW) ? y0 : 0.f, (ok && f0 + 1 < CW) ? y1 : 0.f, h[e2], lo[e2]);
-      }
-      Bh[ks][ct] = cat_h2(h[0], h[1], h[2], h[3]);
-      Bl[ks][ct] = cat_h2(lo[0], lo[1], lo[2], lo[3]);
-    }
-  }
-  __syncthreads();
-  const int step = gridDim.y * C::NW;
-  const bool has2 = lane + 64 < CW;
-  const int lane2 = has2 ? 64 + lane : lane;
-  const int posc = lane < W ? lane : W - 1;
-  auto load_tok = [&](int tok, int& ap1, int& ap2, float& g1, float& g2, int& ch) {  // branch-free: clamped token
-    const int t = tok < d.ntok ? tok : d.ntok - 1;
-    if constexpr (FVTA_EMBW_ABL & 64) {
-      ap1 = lane & 7, ap2 = has2 ? (lane & 3) : 255, g1 = 0.5f, g2 = 0.25f, ch = lane & 15;
-      return;
-    }
-    const float* row = a.dx + a.tok_off[t];
-    ap1 = a.argpos[(size_t)t * CW + lane];
-    const int b2 = a.argpos[(size_t)t * CW + lane2];
-    g1 = row[lane];
-    g2 = row[lane2];
-    ap2 = has2 ? b2 : 255;
-    ch = a.char_ids[(size_t)t * W + posc];
-  };
-  // the lane's cells of dE[pos][c]: T index of k = 0 (column l = c, row pos), position (-1: no cell), channel
-  constexpr int NIT = (16 * CS + 63) / 64;
-  int tb[NIT], ps[NIT], cs_[NIT];
-#pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int it = lane + 64 * i, pos = it / CS, c = it % CS;
-    const bool ok = it < 16 * CS && c < nc;
-    tb[i] = ok ? c * 16 + pos : 0;
-    ps[i] = ok ? pos : -1;
-    cs_[i] = ok ? c : 0;
-  }
-  int tok = blockIdx.y * C::NW + wv;
-  int ap1, ap2, ch, ap1n, ap2n, chn;
-  float g1, g2, g1n, g2n;
-  load_tok(tok, ap1, ap2, g1, g2, ch);
-  for (; tok < d.ntok; tok += step) {
-    load_tok(tok + step, ap1n, ap2n, g1n, g2n, chn);
-    // stage the gradient row (filter f at [f]) and the word's characters
-    s_G[wv][lane] = ap1 == 255 ? 0.f : g1;
-    s_P[wv][lane] = (uint8_t)ap1;
-    if (has2) {
-      s_G[wv][64 + lane] = ap2 == 255 ? 0.f : g2;
-      s_P[wv][64 + lane] = (uint8_t)ap2;
-    }
-    if (lane < 16) s_ch[wv][lane] = lane < W ? ch : -1;
-    wave_lds_fence();
-    // T[p][l] = sum_f G[p][f] filt[kc(l)][f]: lane (p = j, k group q) builds its 8 consecutive filters of the one-hot G from the
-    // staged row, split (hi, lo'); three v_mfma_f32_16x16x32_f16 per k-step and column tile (see embed_fwdw_f16x3)
-    f32x4 accT[NCT], accX[NCT];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) accT[ct] = accX[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < NK32; ++ks) {
-      const f32x4 G0 = *reinterpret_cast<const f32x4*>(&s_G[wv][32 * ks + 8 * q]), G1 = *reinterpret_cast<const f32x4*>(&s_G[wv][32 * ks + 8 * q + 4]);
-      const uint2 Pw = *reinterpret_cast<const uint2*>(&s_P[wv][32 * ks + 8 * q]);
-      half2v h[4], lo[4];
-#pragma unroll
-      for (int e2 = 0; e2 < 4; ++e2) {
-        const unsigned pw = e2 < 2 ? Pw.x : Pw.y;
-        const int pa = (int)((pw >> (16 * (e2 & 1))) & 255u), pb = (int)((pw >> (16 * (e2 & 1) + 8)) & 255u);
-        const float ga = e2 < 2 ? G0[2 * e2] : G1[2 * e2 - 4], gb = e2 < 2 ? G0[2 * e2 + 1] : G1[2 * e2 - 3];
-        split_f16x2(pa == j ? ga : 0.f, pb == j ? gb : 0.f, h[e2], lo[e2]);
-      }
-      const half8 Ah = cat_h2(h[0], h[1], h[2], h[3]), Al = cat_h2(lo[0], lo[1], lo[2], lo[3]);
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        if constexpr (FVTA_EMBW_ABL & 16) { accT[ct][0] += (float)Ah[0] * (float)Bh[ks][ct][0] + (float)Al[1] * (float)Bl[ks][ct][1]; continue; }
-        accT[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh[ks][ct], accT[ct], 0, 0, 0);
-        accX[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl[ks][ct], accX[ct], 0, 0, 0);
-        accX[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh[ks][ct], accX[ct], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) accT[ct] += accX[ct] * (1.f / 2048.f);
-    // T -> LDS as [l][p] (a lane's four rows p = 4 q + r are one 16-byte store), then dE[pos][c] = sum_k T[pos - k][k CS + c]
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(&Tt[(16 * ct + j) * 16 + 4 * q]) = accT[ct];
-    wave_lds_fence();
-    // (the lane's NIT cells (pos, c): indices precomputed, all 5 NIT reads of the tile in flight together)
-    float dv[NIT];
-    if constexpr (!(FVTA_EMBW_ABL & 32))
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      float v = 0.f;
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const float tv = Tt[tb[i] + (ps[i] >= k ? k * (16 * CS - 1) : 0)];
-        v += ps[i] >= k ? tv : 0.f;
-      }
-      dv[i] = v;
-    }
-    if constexpr (!(FVTA_EMBW_ABL & 32))
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int me = s_ch[wv][ps[i] & 15];
-      if constexpr (FVTA_EMBW_ABL & 128) { if (ps[i] >= 0 && me >= 0 && dv[i] == 1234.5f) s_dC[me * CS + cs_[i]] = dv[i]; continue; }
-      // (folding a token's duplicate characters first and adding with a plain read-modify-write was measured: 6.43 ms against
-      //  6.19 with these LDS float adds, which by themselves cost 2.0 ms -- -DFVTA_EMBW_ABL=128)
-      if (ps[i] >= 0 && me >= 0) lds_fadd(&s_dC[me * CS + cs_[i]], dv[i] * emb_ks(a, tok, ps[i] * cd + c0 + cs_[i], W * cd));
-    }
-    wave_lds_fence();
-    ap1 = ap1n; ap2 = ap2n; g1 = g1n; g2 = g2n; ch = chn;
-  }
-  __syncthreads();
-  const int KC = 5 * cd;
-  float* slab_c = a.slab + (size_t)blockIdx.y * ((size_t)KC * CW + CW + (size_t)d.VC * cd) + (size_t)KC * CW + CW;
-  for (int i = threadIdx.x; i < d.VC * CS; i += 256) {
-    const int v = i / CS, c = i % CS;
-    if (c < nc) {
-      float t = 0.f;
-      for (int w4 = 0; w4 < C::NW; ++w4) t += s_dCall[(size_t)w4 * d.VC * CS + i];  // wave order
-      slab_c[(size_t)v * cd + c0 + c] = t;
-    }
-  }
-}
-template __global__ void embed_bwdw_char_f16x3<100>(EmbArgs);
-
-// d filt / d bias of the wide shape on the matrix pipe (same shapes and slices as embed_bwdw_char_mfma).  One WAVE per token:
-//   dFilt[l = k CS + c][f] += sum_p E[p + k][c0 + c] G[p][f],   G[p][f] = g_f [argpos_f = p]
-// as 8 row tiles x 7 filter tiles x 3 k-steps (arg-max positions 0 .. 11 at W <= 16) of v_mfma_f32_16x16x4_f32, the
-// slice's 128 x 112 accumulator tile in 224 registers of every wave for the whole launch; the token's (dropped) character
-// block slice goes through LDS, the one-hot operand is built from the gradient row in registers.  The four waves' tiles meet
-// in LDS in wave order at the end.  embed_bwdw_filt (vector pipe: 128 register accumulators per thread, one LDS read per FMA)
-// took 11.5 ms at char_emb_size 100.  grid (ceil(cdim / 25), blocks), 256 threads, slab part [0, KC cw + cw) of block y.
-template <int CW>
-__global__ __launch_bounds__(256, EMBM_OCC) void embed_bwdw_filt_mfma(EmbArgs a) {
-  constexpr int CS = EMBM_CS, NMT = EMBM_NT, NNT = (CW + 15) / 16, NKS = 3, NW = 4;
-  extern __shared__ __attribute__((aligned(16))) float s_red[];  // [NMT][NNT][64 lanes][4]: the waves' tiles summed at the end
-  __shared__ float s_E[NW][16 * CS];
-  const fvta_embed_desc& d = a.d;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int j = lane & 15, q = lane >> 4;
-  const int W = d.W, cd = d.cdim;
-  const int c0 = blockIdx.x * CS, nc = min(CS, cd - c0);
-  f32x4 acc[NMT][NNT];
-#pragma unroll
-  for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NNT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float accb[NNT];
-#pragma unroll
-  for (int nt = 0; nt < NNT; ++nt) accb[nt] = 0.f;
-  // A operand addresses: lane (row l = 16 mt + j, k phase q) reads E[(4 ks + q) + k(l)][c(l)]; rows l >= 5 CS and channels
-  // beyond the slice read a zero row (position 16 of the staged block)
-  int aoff[NMT];
-#pragma unroll
-  for (int mt = 0; mt < NMT; ++mt) {
-    const int l = 16 * mt + j, k = l / CS, c = l % CS;
-    aoff[mt] = (l < 5 * CS && c < nc) ? (k + q) * CS + c : -1;
-  }
-  constexpr int NE = (16 * CS + 63) / 64;  // staged values per lane and token
-  const int step = gridDim.y * NW;
-  float* Es = s_E[wv];
-  auto load_E = [&](int tok, float (&e)[NE]) {  // the token's character block slice (dropped as in the forward), clamped token
-    const int t = tok < d.ntok ? tok : d.ntok - 1;
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-      const int it = lane + 64 * i, pos = it / CS, c = it % CS;
-      float v = 0.f;
-      if (!(FVTA_EMBW_ABL & 4) && it < 16 * CS && pos < W && c < nc)
-        v = a.char_emb[(size_t)a.char_ids[(size_t)t * W + pos] * cd + c0 + c] * emb_ks(a, t, pos * cd + c0 + c, W * cd);
-      e[i] = v;
-    }
-  };
-  auto load_G = [&](int tok, float (&g)[NNT], int (&ap)[NNT]) {
-    const int t = tok < d.ntok ? tok : d.ntok - 1;
-    const float* row = a.dx + a.tok_off[t];
-#pragma unroll
-    for (int nt = 0; nt < NNT; ++nt) {
-      const int f = 16 * nt + j, fc = f < CW ? f : CW - 1;
-      const int p = (FVTA_EMBW_ABL & 8) ? (f & 7) : a.argpos[(size_t)t * CW + fc];
-      const float r = (FVTA_EMBW_ABL & 8) ? 0.5f : row[fc];
-      ap[nt] = f < CW ? p : 255;
-      g[nt] = (f < CW && p != 255) ? r : 0.f;
-    }
-  };
-  int tok = blockIdx.y * NW + wv;
-  float e_n[NE], g_n[NNT];
-  int ap_n[NNT];
-  load_E(tok, e_n);
-  load_G(tok, g_n, ap_n);
-  for (; tok < d.ntok; tok += step) {
-    float g_c[NNT];
-    int ap_c[NNT];
-#pragma unroll
-    for (int i = 0; i < NE; ++i)
-      if (lane + 64 * i < 16 * CS) Es[lane + 64 * i] = e_n[i];
-#pragma unroll
-    for (int nt = 0; nt < NNT; ++nt) {
-      g_c[nt] = g_n[nt];
-      ap_c[nt] = ap_n[nt];
-    }
-    if (blockIdx.x == 0 && !(FVTA_EMBW_ABL & 2)) {  // the word rows ride along with the first slice
-      const int id = a.word_ids[tok];
-      if (id < d.VW) {
-        const float* row = a.dx + a.tok_off[tok];
-        for (int i = lane; i < d.wdim; i += 64) atomicAdd(a.d_word_emb + (size_t)id * d.wdim + i, row[CW + i]);
-      }
-    }
-    load_E(tok + step, e_n);
-    load_G(tok + step, g_n, ap_n);
-    wave_lds_fence();
-    if (q == 0)
-#pragma unroll
-      for (int nt = 0; nt < NNT; ++nt) accb[nt] += g_c[nt];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      float av[NMT], bv[NNT];
-#pragma unroll
-      for (int mt = 0; mt < NMT; ++mt) {
-        const float v = Es[aoff[mt] >= 0 ? aoff[mt] + 4 * ks * CS : 0];
-        av[mt] = aoff[mt] >= 0 ? v : 0.f;
-      }
-#pragma unroll
-      for (int nt = 0; nt < NNT; ++nt) bv[nt] = ap_c[nt] == 4 * ks + q ? g_c[nt] : 0.f;
-#pragma unroll
-      for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NNT; ++nt) {
-          if constexpr (FVTA_EMBW_ABL & 1) acc[mt][nt][ks] += av[mt] * bv[nt];
-          else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
-        }
-    }
-    wave_lds_fence();  // the block's readers are done before the next token overwrites it
-  }
-  // ---- the four waves' tiles, in wave order, then the slab
-  f32x4* red = reinterpret_cast<f32x4*>(s_red);
-  for (int w4 = 0; w4 < NW; ++w4) {
-    if (wv == w4) {
-#pragma unroll
-      for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NNT; ++nt) {
-          f32x4* cell = red + (mt * NNT + nt) * 64 + lane;
-          *cell = w4 == 0 ? acc[mt][nt] : *cell + acc[mt][nt];
-        }
-    }
-    __syncthreads();
-  }
-  const int KC = 5 * cd;
-  float* slab = a.slab + (size_t)blockIdx.y * ((size_t)KC * CW + CW + (size_t)d.VC * cd);
-  // tile (mt, nt), lane (j, q), element r: row l = 16 mt + 4 q + r, filter f = 16 nt + j
-  for (int idx = threadIdx.x; idx < NMT * NNT * 64; idx += 256) {
-    const int ln = idx & 63, tile = idx >> 6, nt = tile % NNT, mt = tile / NNT;
-    const int f = 16 * nt + (ln & 15);
-    const f32x4 v = red[idx];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int l = 16 * mt + 4 * (ln >> 4) + r, k = l / CS, c = l % CS;
-      if (l < 5 * CS && c < nc && f < CW) slab[(size_t)(k * cd + c0 + c) * CW + f] = v[r];
-    }
-  }
-  if (blockIdx.x == 0) {  // d bias: lanes q = 0 of the four waves, wave order
-    __syncthreads();
-    float* sb = s_red;  // [NW][NNT * 16]
-    if (q == 0)
-#pragma unroll
-      for (int nt = 0; nt < NNT; ++nt) sb[wv * NNT * 16 + 16 * nt + j] = accb[nt];
-    __syncthreads();
-    for (int f = threadIdx.x; f < CW; f += 256) {
-      float t = 0.f;
-      for (int w4 = 0; w4 < NW; ++w4) t += sb[w4 * NNT * 16 + f];
-      slab[(size_t)KC * CW + f] = t;
-    }
-  }
-}
-template __global__ void embed_bwdw_filt_mfma<100>(EmbArgs);
-
 // the slab [KC*cwdim | cwdim | VC*cdim] of this workgroup is zeroed by the launcher and accumulated in place
 __global__ __launch_bounds__(EMB_NT) void embed_bwd_kernel_big(EmbArgs a) {
   extern __shared__ float s_dyn[];  // E [W*cdim], dE [W*cdim]
@@ -2550,12 +1551,16 @@ static bool embed_is_big(const fvta_embed_desc* d) {
   return d->cwdim > 0 && (d->height * d->cdim > EMB_MAXKC || d->W * d->cdim > EMB_MAXWC);
 }
 constexpr int EMB_BIG_BLOCKS = 256;
-static bool embed_mfma_ok(const fvta_embed_desc* d) {  // shapes the matrix-pipe char-CNN kernels take
+// the published flag set's char-CNN (README.MD:144: --char_emb_size 100, 100 filters of height 5): the matrix-pipe kernels
+// embed_fwdw_f16x3 / embed_bwdw_filt_tok / embed_bwdw_char_tok.  Every other deep window runs the general kernels
+// embed_fwd_kernel_big / embed_bwd_kernel_big (FVTA_EMBED_MFMA=0 sends the published shape there too: the A/B of the tests).
+static bool embed_wide_ok(const fvta_embed_desc* d) {
   static const bool off = [] {
     const char* e = getenv("FVTA_EMBED_MFMA");
     return e && e[0] == '0';
   }();
-  return !off && d->W <= 16 && d->cdim % 4 == 0 && d->cwdim % 4 == 0 && d->cwdim <= 128;
+  return !off && d->cwdim == 100 && d->cdim == 100 && d->height == 5 && d->W >= 5 && d->W <= 16 && d->wdim <= 128 &&
+         d->wdim <= 64 * ((7 + FVTA_EMBW_SPW - 1) / FVTA_EMBW_SPW) && d->VC <= 128;
 }
 
 // the reference's default shape (height 5, char_emb 8, 100 filters): wave-per-token kernels on the matrix pipe
@@ -2590,29 +1595,19 @@ extern "C" int fvta_embed_fwd(const fvta_embed_desc* d, const int32_t* word_ids,
   a.x = x; a.argpos = argpos;
   emb_set_dropout(a, d);
   const int blocks = d->ntok < 8192 ? d->ntok : 8192;
-  // (with dropout the matrix-pipe kernel, which gathers its A operand straight from the character table, is not used)
-  if (FVTA_EMBW_FWD_WAVE && embed_mfma_ok(d) && d->cwdim == 100 && d->cdim == 100 && d->height == 5 && d->W >= 5) {
-    // the published --char_emb_size 100: filters in registers, a wave per token (with or without dropout)
-    const int nb = (d->ntok + 3) / 4 < 1024 ? (d->ntok + 3) / 4 : 1024;
-    if (FVTA_EMBW_F16X3 && d->W <= 16 && d->wdim <= 64 * ((7 + FVTA_EMBW_SPW - 1) / FVTA_EMBW_SPW)) {
-      // the fp16 3-term-split form: a workgroup per token, its waves the filter slices (FVTA_EMBW_SPW slices each)
-      const int nbt = d->ntok < 256 ? d->ntok : 256;  // one workgroup per CU (its filter fragments are loaded once)
-      hipLaunchKernelGGL((embed_fwdw_f16x3<100, 100, FVTA_EMBW_SPW>), dim3(nbt), dim3(64 * ((7 + FVTA_EMBW_SPW - 1) / FVTA_EMBW_SPW)), 0,
-                         (hipStream_t)stream_, a);
-    } else
-    hipLaunchKernelGGL((embed_fwdw_mfma<100, 100>), dim3(7, nb), dim3(256), 0, (hipStream_t)stream_, a);
-  } else if (embed_mfma_ok(d) && d->cwdim > 0 && embed_is_big(d) && a.drop_thr == 0ull) {
-    hipLaunchKernelGGL(embed_fwd_kernel_mfma, dim3((d->ntok + 7) / 8), dim3(256), MmaEmb::LDS_FLOATS * sizeof(float),
+  if (embed_wide_ok(d)) {
+    // the published --char_emb_size 100 on the fp16 matrix pipe (3-term split): a workgroup per token, its waves the filter
+    // slices (FVTA_EMBW_SPW slices each); one workgroup per CU (its filter fragments are loaded once)
+    const int nbt = d->ntok < 256 ? d->ntok : 256;
+    hipLaunchKernelGGL((embed_fwdw_f16x3<100, 100, FVTA_EMBW_SPW>), dim3(nbt), dim3(64 * ((7 + FVTA_EMBW_SPW - 1) / FVTA_EMBW_SPW)), 0,
                        (hipStream_t)stream_, a);
-  } else if (embed_is_big(d)) {
+  } else if (embed_is_big(d)) {     // every other deep window: the general kernel
     const size_t dyn = (size_t)d->W * d->cdim * sizeof(float);
     hipLaunchKernelGGL(embed_fwd_kernel_big, dim3(blocks), dim3(EMB_NT), dyn, (hipStream_t)stream_, a);
   } else if (embed_wave_ok(d)) {
     const int nb = (d->ntok + 3) / 4 < EMB_WAVE_FWD_BLOCKS ? (d->ntok + 3) / 4 : EMB_WAVE_FWD_BLOCKS;
     hipLaunchKernelGGL(embed_fwd_5x8_mfma<100>, dim3(nb), dim3(256), (size_t)d->VC * 8 * sizeof(float), (hipStream_t)stream_, a);
-  } else if (d->cwdim > 0 && d->height == 5 && d->cdim == 8 && d->W <= 16)
-    hipLaunchKernelGGL(embed_fwd_kernel_5x8, dim3(blocks), dim3(EMB_NT), 0, (hipStream_t)stream_, a);
-  else
+  } else
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks), dim3(EMB_NT), 0, (hipStream_t)stream_, a);
   FVTA_CHECK_LAUNCH("embed_fwd");
   return FVTA_OK;
@@ -2635,43 +1630,15 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
   a.dx = dx; a.d_word_emb = d_word_emb; a.slab = (float*)workspace;
   emb_set_dropout(a, d);
   int blocks;
-  const size_t charw_lds = ((size_t)d->height * EMBW_CS * (d->cwdim + 1) + (size_t)d->VC * EMBW_CS + 16 * EMBW_CS) * sizeof(float);
-  if (embed_is_big(d) && embed_mfma_ok(d) && charw_lds <= 150 * 1024) {
+  if (embed_wide_ok(d)) {
+    // the published shape: a workgroup per token for both gradients (d filt / d bias: the bf16 three-term product; d char_emb:
+    // the tap fold and the table scatter as two chained matrix products); slabs reduced in a fixed order below
     blocks = d->ntok < EMB_BIG_BLOCKS ? d->ntok : EMB_BIG_BLOCKS;
-    const int KC = d->height * d->cdim;
-    if (FVTA_EMBW_CHAR_MFMA && d->cwdim == 100 && d->height == 5) {  // the matrix-pipe form
-      constexpr int red_bytes = EMBM_NT * 7 * 64 * 16;
-      if (FVTA_EMBW_FILT_TOK && d->cdim == 100 && d->W <= 16 && d->wdim <= 128) {  // a workgroup per token, its waves the channel slices
-        if (FVTA_EMBW_F16X3) hipLaunchKernelGGL((embed_bwdw_filt_tok<100, 100, true>), dim3(blocks), dim3(448), 0, stream, a);
-        else hipLaunchKernelGGL((embed_bwdw_filt_tok<100, 100, false>), dim3(blocks), dim3(448), 0, stream, a);
-      } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_filt_mfma<100>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                red_bytes);
-      hipLaunchKernelGGL(embed_bwdw_filt_mfma<100>, dim3((d->cdim + EMBM_CS - 1) / EMBM_CS, blocks), dim3(256), red_bytes, stream, a);
-      }
-    } else
-    hipLaunchKernelGGL(embed_bwdw_filt, dim3((KC + EMBW_KCH - 1) / EMBW_KCH, blocks), dim3(EMB_NT),
-                       (size_t)d->W * d->cdim * sizeof(float), stream, a);
-    const size_t tabm = (size_t)4 * d->VC * EMBM_CS * sizeof(float);  // a char-table slice per wave
-    if (FVTA_EMBW_CHAR_MFMA && d->cwdim == 100 && d->height == 5 && tabm <= 112 * 1024) {  // the matrix-pipe form
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char_mfma<100>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)tabm);
-      if (FVTA_EMBW_F16X3 && FVTA_EMBW_CHAR_TOK && d->cdim == 100 && d->W <= 16 && d->VC <= 128) {
-        constexpr int frag_bytes = 2 * 17 * 2 * 64 * 16 + 7 * 7 * 64 * 16;  // the A fragments (two tokens) + the waves' low filter fragments
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char_tok<100, 100>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  frag_bytes);
-        hipLaunchKernelGGL((embed_bwdw_char_tok<100, 100>), dim3(blocks), dim3(448), frag_bytes, stream, a);  // a workgroup per token
-      } else if (FVTA_EMBW_F16X3) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char_f16x3<100>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)tabm);
-        hipLaunchKernelGGL(embed_bwdw_char_f16x3<100>, dim3((d->cdim + EMBM_CS - 1) / EMBM_CS, blocks), dim3(256), tabm, stream, a);
-      } else
-      hipLaunchKernelGGL(embed_bwdw_char_mfma<100>, dim3((d->cdim + EMBM_CS - 1) / EMBM_CS, blocks), dim3(256), tabm, stream, a);
-    } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)charw_lds);
-      hipLaunchKernelGGL(embed_bwdw_char, dim3((d->cdim + EMBW_CS - 1) / EMBW_CS, blocks), dim3(256), charw_lds, stream, a);
-    }
+    hipLaunchKernelGGL((embed_bwdw_filt_tok<100, 100, true>), dim3(blocks), dim3(448), 0, stream, a);
+    constexpr int frag_bytes = 2 * 17 * 2 * 64 * 16 + 7 * 7 * 64 * 16;  // the A fragments (two tokens) + the waves' low filter fragments
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwdw_char_tok<100, 100>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              frag_bytes);
+    hipLaunchKernelGGL((embed_bwdw_char_tok<100, 100>), dim3(blocks), dim3(448), frag_bytes, stream, a);
   } else if (embed_is_big(d)) {
     blocks = d->ntok < EMB_BIG_BLOCKS ? d->ntok : EMB_BIG_BLOCKS;
     FVTA_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)blocks * embed_slab_floats(d) * sizeof(float), stream));
@@ -2688,8 +1655,7 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
     hipLaunchKernelGGL(embed_bwd_5x8_char<100>, dim3(blocks), dim3(256), 4 * tab, stream, a);
     blocks *= 4;
   } else {
-    const bool k5x8 = d->cwdim > 0 && d->height == 5 && d->cdim == 8 && d->W <= 16;
-    const size_t dyn = ((size_t)d->height * d->cdim * d->cwdim + (size_t)(k5x8 ? 2 : 1) * d->VC * d->cdim) * sizeof(float);
+    const size_t dyn = ((size_t)d->height * d->cdim * d->cwdim + (size_t)d->VC * d->cdim) * sizeof(float);
     // one dispatch round: as many workgroups as fit the 256 CUs at once (LDS bound; ~9 KB static), never more than the
     // slab workspace holds -- a second, partly filled round would run at the speed of the first
     int per_cu = (int)((160 * 1024) / (dyn + 9 * 1024));
@@ -2698,16 +1664,10 @@ extern "C" int fvta_embed_bwd(const fvta_embed_desc* d, const int32_t* word_ids,
     blocks = 256 * per_cu;
     if (blocks > EMB_BWD_BLOCKS) blocks = EMB_BWD_BLOCKS;
     if (blocks > d->ntok) blocks = d->ntok;
-    if (dyn > 32 * 1024) {
+    if (dyn > 32 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)dyn);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel_5x8),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    }
-    if (d->cwdim > 0 && d->height == 5 && d->cdim == 8 && d->W <= 16)
-      hipLaunchKernelGGL(embed_bwd_kernel_5x8, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
-    else
-      hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(EMB_NT), dyn, stream, a);
   }
   if (d->cwdim > 0) {
     const int nfilt = d->height * d->cdim * d->cwdim, nfb = nfilt + d->cwdim, nchar = d->VC * d->cdim;

@@ -28,13 +28,13 @@ def _case(seed, B, J, W, cd, cw, wd, VW, VF, VC):
                                                       (4, 6, 16, 100, 100, 100, 20, 30, 60),   # README.MD:144 flags
                                                       (40, 30, 16, 100, 100, 60, 30, 30, 70),  # ... with more tokens than waves: the token loops
                                                       (5, 7, 9, 100, 100, 40, 10, 10, 30),     # ... and short words (5 windows)
-                                                      (6, 9, 16, 100, 100, 140, 10, 10, 200),  # ... wdim > 128 and VC > 128: the wave-per-(token, slice) backward kernels
+                                                      (6, 9, 16, 100, 100, 140, 10, 10, 200),  # ... wdim > 128 and VC > 128: outside the published-shape kernels -> the general deep-window kernels (the tested fallback)
                                                       (3, 5, 21, 8, 64, 50, 9, 9, 20),          # W > 16: general kernels
                                                       (7, 9, 9, 8, 100, 60, 30, 20, 50),        # short words, 100 filters
                                                       (33, 30, 16, 8, 100, 100, 40, 2000, 256),
                                                       (1, 1, 16, 8, 100, 100, 5, 5, 30),        # one token: three idle waves
                                                       (2, 3, 5, 8, 100, 100, 10, 10, 20),       # W = height: one window
-                                                      (2, 5, 16, 8, 100, 140, 10, 10, 300),     # wdim > 128; VC > 256: register kernels
+                                                      (2, 5, 16, 8, 100, 140, 10, 10, 300),     # wdim > 128; VC > 256: the general kernels
                                                       (3, 5, 16, 8, 100, 140, 10, 10, 30)])     # wdim > 128 on the wave kernels
 def test_token_embed_forward_backward(B, J, W, cd, cw, wd, VW, VF, VC):
     from fvta_memexqa_amd import ops

@@ -327,7 +327,7 @@ def test_attention_wave16_kernel_randomised_differential(attn_select, mode):
         op.backward(*args, g, *grads_fast, accumulate=0)
         assert torch.isfinite(grads_fast[0]).all() and torch.isfinite(grads_fast[1]).all(), tag + ": rows left unwritten"
         if args[2] is not None:
-            dead = (args[2].view(N, K, T) == 0) & (args[2].view(N, K, T).any(2, keepdim=True)) & (args[3].view(N, 1, JQ).any(2, keepdim=True) != 0)
+            dead = (args[2].view(N, K, T) == 0) & (args[2].view(N, K, T) != 0).any(2, keepdim=True) & (args[3].view(N, 1, JQ) != 0).any(2, keepdim=True)
             assert float(grads_fast[0][dead].abs().max() if dead.any() else 0.0) == 0.0, tag + ": masked rows of a live stream not zero"
         attn_select.exact()
         exact, _ = op.forward(*args)
@@ -378,7 +378,7 @@ def test_attention_wide_kernel_randomised_differential(attn_select):
         op.backward(*args, g, *grads_fast, accumulate=0)
         assert torch.isfinite(grads_fast[0]).all() and torch.isfinite(grads_fast[1]).all(), tag + ": rows left unwritten"
         if args[2] is not None:
-            dead = (args[2].view(N, K, T) == 0) & (args[2].view(N, K, T).any(2, keepdim=True)) & (args[3].view(N, 1, JQ).any(2, keepdim=True) != 0)
+            dead = (args[2].view(N, K, T) == 0) & (args[2].view(N, K, T) != 0).any(2, keepdim=True) & (args[3].view(N, 1, JQ) != 0).any(2, keepdim=True)
             assert float(grads_fast[0][dead].abs().max() if dead.any() else 0.0) == 0.0, tag + ": masked rows of a live stream not zero"
         attn_select.exact()
         exact, _ = op.forward(*args)

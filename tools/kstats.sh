@@ -1,7 +1,8 @@
 #!/bin/bash
 # tools/kstats.sh <tag> <python script and args...>: rocprofv3 --kernel-trace --stats of one command, top kernels printed
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set: run through gpurun}" || exit 1
+export TMPDIR=/tmp
 tag=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$tag
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/ks -o ks -- python3 "$@" > gpurun_out/$tag/run.log 2> gpurun_out/$tag/run.err
 f=$(find gpurun_out/$tag/ks -name "*kernel_stats.csv" | head -1)
