@@ -81,6 +81,8 @@ _SIGS = {
     "fvta_timewarp_workspace_bytes": (c_size_t, [POINTER(TimewarpDesc)]),
     "fvta_timewarp_fwd": (c_int, [POINTER(TimewarpDesc), P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_timewarp_bwd": (c_int, [POINTER(TimewarpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_timewarp_fwd_shadow": (c_int, [POINTER(TimewarpDesc), P, P, P, P, P, P, P, P, P, P, P]),
+    "fvta_timewarp_bwd_shadow": (c_int, [POINTER(TimewarpDesc), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_embed_workspace_bytes": (c_size_t, [POINTER(EmbedDesc)]),
     "fvta_embed_fwd": (c_int, [POINTER(EmbedDesc), P, P, P, P, P, P, P, P, P, P, P]),
     "fvta_embed_bwd": (c_int, [POINTER(EmbedDesc), P, P, P, P, P, P, P, P, P, P, P, P, P]),

@@ -186,11 +186,19 @@ __global__ void fill_kernel(float* __restrict__ p, size_t n, float v) {
 // tile count; every n gets floor(share) >= 1 workgroups (at most maxg), the remainder goes one at a time to the n with
 // the most tiles per workgroup.  tab[wg] = n | g << 16 | G_n << 24 in n order (an n's workgroups stay XCD-contiguous),
 // 0xffffffff for workgroups left over.
-__global__ __launch_bounds__(64) void attn_balance_kernel(AttnShape s, AttnSaved sv, int nwg, int maxg, uint32_t* __restrict__ tab) {
+// run_cap > 0 (attn_fwd_wide, whose workgroup lists its run's 32-row tiles in LDS): if some album's share would make a
+// workgroup's run longer than run_cap tiles (a skewed batch near the limit: an album may get fewer workgroups than nwg / N),
+// the table is the plain deal instead -- n = wg / G, every album G = nwg / N workgroups -- which the host's bound
+// (wide_covers) covers; the kernel never sees a run it cannot hold.
+__global__ __launch_bounds__(64) void attn_balance_kernel(AttnShape s, AttnSaved sv, int nwg, int maxg, uint32_t* __restrict__ tab,
+                                                          int run_cap) {
   const int lane = threadIdx.x;
-  int tiles = 0;
+  int tiles = 0, tiles32 = 0;
   if (lane < s.N)
-    for (int k = 0; k < s.K; ++k) tiles += (sv.cnt[lane * s.K + k] + 15) >> 4;
+    for (int k = 0; k < s.K; ++k) {
+      tiles += (sv.cnt[lane * s.K + k] + 15) >> 4;
+      tiles32 += (sv.cnt[lane * s.K + k] + 31) >> 5;
+    }
   if (lane < s.N && tiles < 1) tiles = 1;
   int total = tiles;
 #pragma unroll
@@ -218,6 +226,14 @@ __global__ __launch_bounds__(64) void attn_balance_kernel(AttnShape s, AttnSaved
     const unsigned long long who = __ballot(can && key == best);
     if (lane == __ffsll((long long)who) - 1) G += give ? 1 : -1;
     used += give ? 1 : -1;
+  }
+  if (run_cap > 0) {  // (a run crosses at most K stream boundaries: one ragged tile each)
+    const bool over = lane < s.N && (tiles32 + G - 1) / G + s.K + 1 > run_cap;
+    if (__ballot(over) != 0ull) {
+      const int Gall = nwg / s.N;
+      for (int i = lane; i < nwg; i += 64) tab[i] = (uint32_t)(i / Gall) | ((uint32_t)(i % Gall) << 16) | ((uint32_t)Gall << 24);
+      return;
+    }
   }
   int first = G;  // exclusive prefix sum over n
 #pragma unroll
@@ -1874,6 +1890,7 @@ static int launch_main(const AttnFwdArgs& a, hipStream_t stream) {
 }
 
 bool wide_covers(const AttnShape& s, int G);                                     // attn_fwd_wide.hip
+int wide_max_run();                                                              // tiles a workgroup of attn_fwd_wide can list
 bool launch_attn_fwd_wide(const AttnFwdArgs& a, int G, hipStream_t stream);
 bool shadow_covers(const AttnShape& s);                                          // attn_fwd_shadow.hip
 void launch_attn_shadow_compact(const AttnShape& s, const AttnSaved& sv, const uint64_t* table, uint64_t* rowptr, hipStream_t stream);
@@ -2047,7 +2064,7 @@ static int attn_fwd_impl(const fvta_attn_desc* d, const float* hinfo, const uint
     const size_t part_bytes = fvta_align_up((size_t)s.N * s.K * (s.nsplit + 1) * (s.w + 4) * sizeof(float), 256);
     if (use_mask && s.N <= 64 && s.N > 1 && nwg <= 4096 && maxg <= 255) {
       uint32_t* tab = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + part_bytes);
-      hipLaunchKernelGGL(attn_balance_kernel, dim3(1), dim3(64), 0, stream, s, sv, nwg, maxg, tab);
+      hipLaunchKernelGGL(attn_balance_kernel, dim3(1), dim3(64), 0, stream, s, sv, nwg, maxg, tab, 0);
       a.wgtab = tab;
     }
     uint64_t* rowptr = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(workspace) + part_bytes + ATTN_WGTAB_BYTES);
@@ -2058,7 +2075,7 @@ static int attn_fwd_impl(const fvta_attn_desc* d, const float* hinfo, const uint
     if (use_mask && s.N <= 64 && s.N > 1 && nwg <= 4096 && maxg <= 255) {  // ragged albums: workgroups in proportion to the rows
       uint32_t* tab = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) +
                                                  fvta_align_up((size_t)s.N * s.K * (s.nsplit + 1) * (s.w + 4) * sizeof(float), 256));
-      hipLaunchKernelGGL(attn_balance_kernel, dim3(1), dim3(64), 0, stream, s, sv, nwg, maxg, tab);
+      hipLaunchKernelGGL(attn_balance_kernel, dim3(1), dim3(64), 0, stream, s, sv, nwg, maxg, tab, wide_max_run());
       a.wgtab = tab;
     }
     launch_attn_fwd_wide(a, wideG, stream);
@@ -2078,7 +2095,7 @@ static int attn_fwd_impl(const fvta_attn_desc* d, const float* hinfo, const uint
     if (use_mask && s.N <= 64 && s.N > 1 && nwg <= 4096 && maxg <= 255) {  // ragged albums: workgroups in proportion to the rows
       uint32_t* tab = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) +
                                                  fvta_align_up((size_t)s.N * s.K * (s.nsplit + 1) * (s.w + 4) * sizeof(float), 256));
-      hipLaunchKernelGGL(attn_balance_kernel, dim3(1), dim3(64), 0, stream, s, sv, nwg, maxg, tab);
+      hipLaunchKernelGGL(attn_balance_kernel, dim3(1), dim3(64), 0, stream, s, sv, nwg, maxg, tab, 0);
       a.wgtab = tab;
     }
 #define FVTA_P16K(NBH, RM, FL)                                                                                          \

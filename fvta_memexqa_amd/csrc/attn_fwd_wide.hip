@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_wide(AttnFwdArgs a, int G_all
     for (int il = g0; il < nitems_n; il += G)
       if (item_seg(il, sg)) rounds += sg.t1 - sg.t0;
   }
-  if (rounds > WIDE_MAXR) __builtin_trap();  // (the host's bound, wide_covers, rules this out)
+  if (rounds > WIDE_MAXR) __builtin_trap();  // (ruled out by the host's bound, wide_covers, and by attn_balance_kernel's run_cap)
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   if (tid == 0) {  // the run's tiles, listed once
     Seg sg = {0, 0, 0, 0, 0, 0};
@@ -413,6 +413,7 @@ __global__ __launch_bounds__(512, 1) void attn_fwd_wide(AttnFwdArgs a, int G_all
 }
 
 // host side: shapes covered, LDS, instantiation
+int wide_max_run() { return WIDE_MAXR; }
 bool wide_covers(const AttnShape& s, int G) {
   if (!(s.w == 2048 && s.JT <= 2 && s.simi != 4)) return false;
   const int t32 = (s.T + 31) / 32;

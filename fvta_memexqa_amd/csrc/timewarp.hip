@@ -39,7 +39,7 @@ struct TwWork {
 static TwWork tw_work(const fvta_timewarp_desc* d, void* p) {
   FvtaCarver c(p);
   TwWork w;
-  w.nwg = 1024;
+  w.nwg = 2048;   // wave slots of the fused kernels' dv partials: 256 CUs x 8 waves
   w.v = c.take<float>(d->w);
   w.s0 = c.take<float>(1);
   w.sq = c.take<float>(d->N);
@@ -270,6 +270,152 @@ __global__ __launch_bounds__(256) void tw_bwd_fused_kernel(fvta_timewarp_desc d,
   for (int g = 0; g < G4; ++g) *reinterpret_cast<f32x4*>(wk.dvp + (size_t)wv * d.w + 256 * g + 4 * lane) = dvacc[g];
 }
 
+// ---- the fused forms over the encoders' bf16 SHADOW ROWS (fvta_lstm_shadow_rows; the bf16 engine): the context tensor is
+// never stored in fp32, so the warp reads row (n,k,t) as two bf16 half-rows through the address table (table[0][row]: channels
+// [0, w/2), table[1][row]: [w/2, w); padding rows point at a zero half-row) and writes the WARPED rows as bf16 into a dense
+// buffer -- which the focal attention reads through a second, static table (fvta_attn_fwd_shadow / _bwd_shadow).  Per element:
+// 2 B read + 2 B written here and 2 B read by the attention, against 4 + 4 + 4 (and the 4 B the bi-LSTM no longer stores).
+// The backward reads the same bf16 rows and the attention's fp32 gradient of the warped rows.  w / 2 a multiple of 256
+// (a lane's 256-channel block lies in one half-row).
+typedef unsigned short tw_bf16;
+typedef tw_bf16 tw_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 tw_ld_bf4(unsigned long long addr, int elem) {
+  const tw_bf16x4 r = *(const tw_bf16x4 __attribute__((address_space(1)))*)(addr + (unsigned long long)elem * 2ull);   // (global, not flat)
+  return f32x4{__uint_as_float((unsigned)r[0] << 16), __uint_as_float((unsigned)r[1] << 16), __uint_as_float((unsigned)r[2] << 16),
+               __uint_as_float((unsigned)r[3] << 16)};
+}
+
+// The table entries of a position's 2 K half-rows come by ONE vector load (lane l < 2 K holds entry l: half l / K, stream l % K),
+// requested a whole position ahead and broadcast with v_readlane: no dependent scalar-load chain in front of the row loads.
+__device__ __forceinline__ unsigned long long tw_tab_load(const unsigned long long* __restrict__ table, size_t nkt, int K, int T, int pos,
+                                                          int lane) {
+  const int n = pos / T, t = pos % T;
+  const int k = lane % K, half = lane / K;
+  const size_t idx = (size_t)(half & 1) * nkt + ((size_t)n * K + k) * T + t;   // (lanes >= 2 K re-read an entry of the position)
+  return table[idx];
+}
+__device__ __forceinline__ unsigned long long tw_bcast64(unsigned long long v, int src) {
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, src), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int G4>
+__global__ __launch_bounds__(256) void tw_fwd_shadow_kernel(fvta_timewarp_desc d, int win, const unsigned long long* __restrict__ table,
+                                                            TwWork wk, float* __restrict__ c_out, float* __restrict__ scale,
+                                                            tw_bf16* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6), nwv = gridDim.x * 4;
+  const size_t nkt = (size_t)d.N * d.K * d.T;
+  const int dp = d.w / 2, npos = d.N * d.T;
+  f32x4 v[G4];
+#pragma unroll
+  for (int g = 0; g < G4; ++g) v[g] = ld4t(wk.v + 256 * g + 4 * lane);
+  const float s0 = wk.s0[0];
+  if (wv >= npos) return;
+  unsigned long long tab_cur = tw_tab_load(table, nkt, d.K, d.T, wv, lane);
+  for (int pos = wv; pos < npos; pos += nwv) {
+    const int n = pos / d.T, t = pos % d.T;
+    const unsigned long long tab_nxt = tw_tab_load(table, nkt, d.K, d.T, min(pos + nwv, npos - 1), lane);   // (clamped: always valid)
+    f32x4 h[TW_KMAX][G4];
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < TW_KMAX; ++k) {
+      const int kc = min(k, d.K - 1);   // (unconditional loads: streams k >= K re-read the last one and are not used)
+      const unsigned long long a0 = tw_bcast64(tab_cur, kc), a1 = tw_bcast64(tab_cur, d.K + kc);
+#pragma unroll
+      for (int g = 0; g < G4; ++g) h[k][g] = 256 * g < dp ? tw_ld_bf4(a0, 256 * g + 4 * lane) : tw_ld_bf4(a1, 256 * g - dp + 4 * lane);
+    }
+#pragma unroll
+    for (int k = 0; k < TW_KMAX; ++k)
+      if (k < d.K) {
+#pragma unroll
+        for (int g = 0; g < G4; ++g) {
+          const f32x4 p = h[k][g] * h[k][g] * v[g];
+          acc += (p[0] + p[1]) + (p[2] + p[3]);
+        }
+      }
+    acc = wave_sum(acc);
+    const float c = tanhf(acc + (float)d.K * (s0 + wk.sq[n]));
+    const float sc = c * tw_count(t, d.T, d.warp_type, win);
+    if (lane == 0) {
+      c_out[pos] = c;
+      scale[pos] = sc;
+    }
+#pragma unroll
+    for (int k = 0; k < TW_KMAX; ++k)
+      if (k < d.K) {
+        tw_bf16* row = out + (((size_t)n * d.K + k) * d.T + t) * d.w + 4 * lane;
+#pragma unroll
+        for (int g = 0; g < G4; ++g) {
+          const f32x4 o = h[k][g] * sc;
+          *reinterpret_cast<tw_bf16x4*>(row + 256 * g) = tw_bf16x4{f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+        }
+      }
+    tab_cur = tab_nxt;
+  }
+}
+
+template <int G4>
+__global__ __launch_bounds__(256) void tw_bwd_shadow_kernel(fvta_timewarp_desc d, int win, const unsigned long long* __restrict__ table,
+                                                            const float* __restrict__ d_warp, const float* __restrict__ c_saved,
+                                                            TwWork wk, float* __restrict__ d_hall) {
+  const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6), nwv = gridDim.x * 4;
+  const size_t nkt = (size_t)d.N * d.K * d.T;
+  const int dp = d.w / 2;
+  f32x4 v[G4], dvacc[G4];
+#pragma unroll
+  for (int g = 0; g < G4; ++g) {
+    v[g] = ld4t(wk.v + 256 * g + 4 * lane);
+    dvacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int npos = d.N * d.T;
+  unsigned long long tab_cur = wv < npos ? tw_tab_load(table, nkt, d.K, d.T, wv, lane) : 0ull;
+  for (int pos = wv; pos < npos; pos += nwv) {
+    const int n = pos / d.T, t = pos % d.T;
+    const unsigned long long tab_nxt = tw_tab_load(table, nkt, d.K, d.T, min(pos + nwv, npos - 1), lane);
+    f32x4 h[TW_KMAX][G4], gw[TW_KMAX][G4];
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < TW_KMAX; ++k) {
+      const int kc = min(k, d.K - 1);   // (unconditional loads)
+      const unsigned long long a0 = tw_bcast64(tab_cur, kc), a1 = tw_bcast64(tab_cur, d.K + kc);
+      const size_t ro = (((size_t)n * d.K + kc) * d.T + t) * d.w + 4 * lane;
+#pragma unroll
+      for (int g = 0; g < G4; ++g) {
+        h[k][g] = 256 * g < dp ? tw_ld_bf4(a0, 256 * g + 4 * lane) : tw_ld_bf4(a1, 256 * g - dp + 4 * lane);
+        gw[k][g] = ld4t(d_warp + ro + 256 * g);
+      }
+    }
+    tab_cur = tab_nxt;
+#pragma unroll
+    for (int k = 0; k < TW_KMAX; ++k)
+      if (k < d.K) {
+        float dk = 0.f;
+#pragma unroll
+        for (int g = 0; g < G4; ++g) {
+          const f32x4 p = h[k][g] * gw[k][g];
+          dk += (p[0] + p[1]) + (p[2] + p[3]);
+        }
+        acc += wave_sum(dk);
+      }
+    const float c = c_saved[pos], cnt = tw_count(t, d.T, d.warp_type, win);
+    const float dz = acc * cnt * (1.f - c * c);
+    const float sc = c * cnt;
+    if (lane == 0) wk.dz[pos] = dz;
+#pragma unroll
+    for (int k = 0; k < TW_KMAX; ++k)
+      if (k < d.K) {
+        float* row = d_hall + (((size_t)n * d.K + k) * d.T + t) * d.w + 4 * lane;
+#pragma unroll
+        for (int g = 0; g < G4; ++g) {
+          *reinterpret_cast<f32x4*>(row + 256 * g) = gw[k][g] * sc + h[k][g] * v[g] * (2.f * dz);
+          dvacc[g] += h[k][g] * h[k][g] * dz;
+        }
+      }
+  }
+#pragma unroll
+  for (int g = 0; g < G4; ++g) *reinterpret_cast<f32x4*>(wk.dvp + (size_t)wv * d.w + 256 * g + 4 * lane) = dvacc[g];
+}
+
 // dv[c] = sum over workgroups; dsq[n] = K sum_t dz.  grid w + N, 256 threads: one output per block, strided partial
 // sums folded by a fixed tree (a single thread walking all partials was a ~1000-deep chain of L2 latencies)
 __global__ __launch_bounds__(256) void tw_reduce_kernel(fvta_timewarp_desc d, TwWork wk) {
@@ -413,5 +559,60 @@ extern "C" int fvta_timewarp_bwd_att(const fvta_timewarp_desc* d, const float* h
   hipLaunchKernelGGL(tw_param_bwd_kernel, dim3(d->w), dim3(256), 0, s, *d, WH_W, WH_b, WC_W, lq, wk, d_lq, dWH_W, dWH_b,
                      dWC_W, dWC_b);
   FVTA_CHECK_LAUNCH("timewarp_bwd");
+  return FVTA_OK;
+}
+
+// ---- over the bf16 shadow rows (see tw_fwd_shadow_kernel) -----------------------------------------------------------------
+static int check_tw_shadow(const fvta_timewarp_desc* d) {
+  if (int e = check_tw(d)) return e;
+  FVTA_CHECK_ARG(d->w % 512 == 0 && d->w <= 1024 && d->K <= TW_KMAX,
+                 "timewarp (shadow rows): w = %d must be 512 or 1024 and K = %d at most %d", d->w, d->K, TW_KMAX);
+  return FVTA_OK;
+}
+
+extern "C" int fvta_timewarp_fwd_shadow(const fvta_timewarp_desc* d, const uint64_t* table, const float* lq, const float* WH_W,
+                                        const float* WH_b, const float* WC_W, const float* WC_b, uint16_t* warp_rows,
+                                        float* c_out, float* scale_out, void* workspace, fvta_stream_t stream_) {
+  if (int e = check_tw_shadow(d)) return e;
+  FVTA_CHECK_ARG(table && lq && WH_W && WH_b && WC_W && WC_b && warp_rows && c_out && scale_out && workspace,
+                 "timewarp_fwd_shadow: null pointer");
+  hipStream_t s = (hipStream_t)stream_;
+  TwWork wk = tw_work(d, workspace);
+  const int win = (int)ceilf(d->window_t);
+  hipLaunchKernelGGL(tw_vec_kernel, dim3((d->w + d->N + 1 + 3) / 4), dim3(256), 0, s, d->N, d->w, WH_W, WH_b, WC_W, WC_b, lq,
+                     wk);
+  const dim3 g(1024);   // (no per-wave partials in the forward: four waves per SIMD)
+  const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(table);
+  if (d->w == 512)
+    hipLaunchKernelGGL(tw_fwd_shadow_kernel<2>, g, dim3(256), 0, s, *d, win, tab, wk, c_out, scale_out, warp_rows);
+  else
+    hipLaunchKernelGGL(tw_fwd_shadow_kernel<4>, g, dim3(256), 0, s, *d, win, tab, wk, c_out, scale_out, warp_rows);
+  FVTA_CHECK_LAUNCH("timewarp_fwd_shadow");
+  return FVTA_OK;
+}
+
+extern "C" int fvta_timewarp_bwd_shadow(const fvta_timewarp_desc* d, const uint64_t* table, const float* lq, const float* WH_W,
+                                        const float* WH_b, const float* WC_W, const float* WC_b, const float* c_saved,
+                                        const float* d_warp, float* d_hall, float* d_lq, float* dWH_W, float* dWH_b,
+                                        float* dWC_W, float* dWC_b, void* workspace, fvta_stream_t stream_) {
+  if (int e = check_tw_shadow(d)) return e;
+  FVTA_CHECK_ARG(table && lq && WH_W && WH_b && WC_W && WC_b && c_saved && d_warp && d_hall && d_lq && dWH_W && dWH_b &&
+                     dWC_W && dWC_b && workspace,
+                 "timewarp_bwd_shadow: null pointer");
+  hipStream_t s = (hipStream_t)stream_;
+  TwWork wk = tw_work(d, workspace);
+  const int win = (int)ceilf(d->window_t);
+  hipLaunchKernelGGL(tw_vec_kernel, dim3((d->w + d->N + 1 + 3) / 4), dim3(256), 0, s, d->N, d->w, WH_W, WH_b, WC_W, WC_b, lq,
+                     wk);
+  const dim3 g(wk.nwg / 4);
+  const unsigned long long* tab = reinterpret_cast<const unsigned long long*>(table);
+  if (d->w == 512)
+    hipLaunchKernelGGL(tw_bwd_shadow_kernel<2>, g, dim3(256), 0, s, *d, win, tab, d_warp, c_saved, wk, d_hall);
+  else
+    hipLaunchKernelGGL(tw_bwd_shadow_kernel<4>, g, dim3(256), 0, s, *d, win, tab, d_warp, c_saved, wk, d_hall);
+  hipLaunchKernelGGL(tw_reduce_kernel, dim3(d->w + d->N), dim3(256), 0, s, *d, wk);
+  hipLaunchKernelGGL(tw_param_bwd_kernel, dim3(d->w), dim3(256), 0, s, *d, WH_W, WH_b, WC_W, lq, wk, d_lq, dWH_W, dWH_b,
+                     dWC_W, dWC_b);
+  FVTA_CHECK_LAUNCH("timewarp_bwd_shadow");
   return FVTA_OK;
 }

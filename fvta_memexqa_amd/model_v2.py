@@ -529,7 +529,9 @@ class Model:
             self._layouts[key] = self._layouts.pop(key)      # most recently used last
             return self._layouts[key]
         while len(self._layouts) >= self.max_layouts:         # real batches change shape (per-batch maxima): bounded cache
-            self._layouts.pop(next(iter(self._layouts)))
+            old = self._layouts.pop(next(iter(self._layouts)))
+            if self._hall_layout is old:                      # (an evicted layout's arena / saved buffers go with it)
+                self._hall_layout = None
         L = _Layout()
         dev, wp, dp = self.dev, self.wp, self.dp
         N, JQ = shapes["q"]
@@ -621,7 +623,9 @@ class Model:
 
     def _shadow_covers(self, L):
         """the shapes fvta_attn_fwd_shadow / fvta_attn_bwd_shadow take (include/fvta_hip.h)"""
-        return (self.SHADOW_OK and self.shadow_rows and self.precision == BF16 and not self.use_time_warp and
+        # (with the time warp: fvta_timewarp_fwd_shadow / _bwd_shadow warp the bf16 rows; time_warp_att keeps the fp32 rows)
+        return (self.SHADOW_OK and self.shadow_rows and self.precision == BF16 and
+                (not self.use_time_warp or (not self.use_time_warp_att and L.K <= 8)) and
                 self.simi in (1, 2, 3) and self.wp in (512, 1024) and L.JQ <= 32)
 
     @property
@@ -630,10 +634,31 @@ class Model:
         L = self._hall_layout
         if L is None:
             return None
+        ev = getattr(L, "fwd_done", None)
+        if ev is not None:       # ordered behind the forward that produced the rows, whatever stream the reader runs on
+            torch.cuda.current_stream().wait_event(ev)
         if L.shadow and not L.hall_fresh:
+            # (valid until the next forward on this layout overwrites the shadow rows: hall_fresh is reset there)
             ops.rows_from_shadow(L.shadow_tab, L.row_hq, self.dp, self.wp, L.arena)
             L.hall_fresh = True
         return L.hall
+
+    @property
+    def warp_h(self):
+        """the warped context tensor of the last forward (vis output, model_v2.py:1009); under shadow rows the bf16 rows are
+        converted into an fp32 buffer here, on demand"""
+        if getattr(self, "_warp_h", None) is not None:
+            return self._warp_h
+        L = getattr(self, "_warp_layout", None)
+        if L is None:
+            return None
+        ev = getattr(L, "fwd_done", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        if getattr(L, "warp_f32", None) is None:
+            L.warp_f32 = torch.zeros(L.N, L.K, L.T, self.wp, dtype=torch.float32, device=self.dev)
+        ops.rows_from_shadow(L.warp_tab, L.row_hq, self.dp, self.wp, L.warp_f32)
+        return L.warp_f32
 
     def _plan_arena(self, L, ctx, training):
         """Rows of the encoder output arena: [hall N*K*T | hq N*JQ | hchoices N*C*JA], the context tensor of
@@ -674,7 +699,13 @@ class Model:
         L.lch = torch.zeros(N, C, wp, dtype=torch.float32, device=dev)
         if self.use_time_warp:
             L.tw = ops.TimeWarp(N, K, T, wp, self.warp_type, self.window_t)
-            L.warp_h = torch.zeros(N, K, T, wp, dtype=torch.float32, device=dev)
+            if L.shadow:     # the warped rows as bf16, read by the attention through a static table of their addresses
+                L.warp_b = torch.zeros(N * K * T, wp, dtype=torch.bfloat16, device=dev)
+                base = L.warp_b.data_ptr() + torch.arange(N * K * T, dtype=torch.int64) * (wp * 2)
+                L.warp_tab = torch.stack([base, base + self.dp * 2]).to(dev).contiguous()
+                L.warp_h = None          # (the fp32 vis tensor is filled in on demand: Model.warp_h)
+            else:
+                L.warp_h = torch.zeros(N, K, T, wp, dtype=torch.float32, device=dev)
             L.d_warp = torch.zeros(N, K, T, wp, dtype=torch.float32, device=dev) if training else None
             L.d_lq = torch.zeros(N, wp, dtype=torch.float32, device=dev) if training else None
             L.d_tscale = torch.zeros(N, T, dtype=torch.float32, device=dev) if (training and self.use_time_warp_att) else None
@@ -907,6 +938,9 @@ class Model:
             self._apply_wd(False, L.loss_t)
         self.logits, self.yp, self.loss = L.logits, L.yp, L.loss_t
         self._hall_layout = L
+        if getattr(L, "fwd_done", None) is None:
+            L.fwd_done = torch.cuda.Event()
+        L.fwd_done.record(main)       # Model.hall waits for it (a reader on another stream)
         if want_logits:
             self.att_logits, self.q_att_logits = att, qatt
         return L.yp
@@ -920,21 +954,27 @@ class Model:
         W = P.view(self.N_ATT_W) if self.simi != 4 else None
         b = P.view(self.N_ATT_B) if self.simi != 4 else None
         ctx = L.hall
+        tab = L.shadow_tab if L.shadow else None       # the rows the attention reads, as an address table (shadow rows)
         if self.use_time_warp:                                              # :953-1009, WQ = lq (:970)
             T.op.last_state(L.arena, T.segs[0]["s0"], T.segs[0]["count"], L.lq)
-            L.tw.forward(L.hall, L.lq, P.view(self.N_TW_WH_W), P.view(self.N_TW_WH_B), P.view(self.N_TW_WC_W),
-                         P.view(self.N_TW_WC_B), L.warp_h)
-            ctx = self.warp_h = L.warp_h
+            tw_p = (P.view(self.N_TW_WH_W), P.view(self.N_TW_WH_B), P.view(self.N_TW_WC_W), P.view(self.N_TW_WC_B))
+            if L.shadow:     # bf16 rows in, warped bf16 rows out: the attention reads THOSE through their own table
+                L.tw.forward_shadow(L.shadow_tab, L.lq, *tw_p, L.warp_b)
+                tab, ctx = L.warp_tab, None
+                self._warp_h, self._warp_layout = None, L
+            else:
+                L.tw.forward(L.hall, L.lq, *tw_p, L.warp_h)
+                ctx = self._warp_h = L.warp_h
             self.C = L.tw.c                                                 # c[n,t]; the reference's C[n,t,t'] = c[n,t]
         L.ctx = ctx
         # :1020; time_warp_att: the softmax over t runs on amax * sum_t' C[n,t,t'] = amax * c[n,t] cnt(t) (:269-275)
         L.tscale = L.tw.scale if self.use_time_warp_att else None
         if L.shadow and not want_logits:
-            L.g1, att = L.att.forward_shadow(L.shadow_tab, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, W, b), None
+            L.g1, att = L.att.forward_shadow(tab, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, W, b), None
         else:
             if L.shadow:     # the full logit tensor is an inspection output of the fp32-row kernel: fill the rows in
                 self._hall_layout = L
-                ctx = self.hall
+                ctx = self.warp_h if self.use_time_warp else self.hall
             L.g1, att = L.att.forward(ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, W, b, want_logits, tscale=L.tscale)
         if self.use_question_att:                                           # :1044
             Wq = P.view(self.N_QATT_W) if self.simi != 4 else None
@@ -1025,15 +1065,19 @@ class Model:
         if self.use_time_warp:
             # attention gradient w.r.t. the warped tensor (masked rows zeroed: the warp backward walks every row),
             # then through the warp into the hall rows of the arena and into lq -> the question encoder's last state
-            if L.d_tscale is not None:
-                L.d_tscale.zero_()
-            L.att.backward(L.ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, L.d_warp, d_hq, daW, dab,
-                           accumulate=3, tscale=L.tscale, d_tscale=L.d_tscale)
+            tw_p = (P.view(self.N_TW_WH_W), P.view(self.N_TW_WH_B), P.view(self.N_TW_WC_W), P.view(self.N_TW_WC_B))
+            tw_g = (P.view(self.N_TW_WH_W, True), P.view(self.N_TW_WH_B, True), P.view(self.N_TW_WC_W, True), P.view(self.N_TW_WC_B, True))
             L.d_lq.zero_()
-            L.tw.backward(L.hall, L.lq, P.view(self.N_TW_WH_W), P.view(self.N_TW_WH_B), P.view(self.N_TW_WC_W),
-                          P.view(self.N_TW_WC_B), L.d_warp, d_hall, L.d_lq, P.view(self.N_TW_WH_W, True),
-                          P.view(self.N_TW_WH_B, True), P.view(self.N_TW_WC_W, True), P.view(self.N_TW_WC_B, True),
-                          d_scale_att=L.d_tscale)
+            if L.shadow:
+                L.att.backward_shadow(L.warp_tab, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, L.d_warp, d_hq,
+                                      daW, dab, accumulate=3)
+                L.tw.backward_shadow(L.shadow_tab, L.lq, *tw_p, L.d_warp, d_hall, L.d_lq, *tw_g)
+            else:
+                if L.d_tscale is not None:
+                    L.d_tscale.zero_()
+                L.att.backward(L.ctx, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, L.d_warp, d_hq, daW, dab,
+                               accumulate=3, tscale=L.tscale, d_tscale=L.d_tscale)
+                L.tw.backward(L.hall, L.lq, *tw_p, L.d_warp, d_hall, L.d_lq, *tw_g, d_scale_att=L.d_tscale)
             T.op.last_state_bwd(L.d_lq, T.segs[0]["s0"], T.segs[0]["count"], L.d_arena)
         elif L.shadow:
             L.att.backward_shadow(L.shadow_tab, L.hq, L.hall_mask.view(L.N, L.K, L.T), L.q_mask, aW, ab, dg1, d_hall, d_hq,

@@ -430,6 +430,20 @@ class TimeWarp:
                                              stream_ptr()), "fvta_timewarp_bwd")
 
 
+    def forward_shadow(self, table, lq, WH_W, WH_b, WC_W, WC_b, warp_rows):
+        """forward() over the encoders' bf16 shadow rows: table int64 [2, N*K*T] (BiLstm.shadow_rows), warp_rows bf16
+        [N*K*T, w] receives the warped rows (the focal attention reads them through a table of addresses into it)."""
+        check(self.lib.fvta_timewarp_fwd_shadow(ctypes.byref(self.desc), ptr(table), ptr(_f32c(lq)), ptr(WH_W), ptr(WH_b),
+                                                ptr(WC_W), ptr(WC_b), ptr(warp_rows), ptr(self.c), ptr(self.scale),
+                                                ptr(self.work), stream_ptr()), "fvta_timewarp_fwd_shadow")
+
+    def backward_shadow(self, table, lq, WH_W, WH_b, WC_W, WC_b, d_warp, d_hall, d_lq, dWH_W, dWH_b, dWC_W, dWC_b):
+        check(self.lib.fvta_timewarp_bwd_shadow(ctypes.byref(self.desc), ptr(table), ptr(lq), ptr(WH_W), ptr(WH_b), ptr(WC_W),
+                                                ptr(WC_b), ptr(self.c), ptr(_f32c(d_warp)), ptr(d_hall), ptr(d_lq),
+                                                ptr(dWH_W), ptr(dWH_b), ptr(dWC_W), ptr(dWC_b), ptr(self.work),
+                                                stream_ptr()), "fvta_timewarp_bwd_shadow")
+
+
 # ------------------------------------------------------- embedding front-end
 class TokenEmbed:
     """model_v2.py:524-620 for all text tokens of a batch: char-CNN + word lookup, rows written at tok_off.

@@ -309,6 +309,18 @@ int fvta_timewarp_bwd(const fvta_timewarp_desc* d, const float* hall, const floa
                       const float* WH_b, const float* WC_W, const float* WC_b, const float* c_saved,
                       const float* d_warp, float* d_hall, float* d_lq, float* dWH_W, float* dWH_b, float* dWC_W,
                       float* dWC_b, void* workspace, fvta_stream_t stream);
+/* The same warp over the bi-LSTM's bf16 SHADOW ROWS (fvta_lstm_shadow_rows; model_v2.py:953-1009 with the context tensor of
+ * 863-914 never stored in fp32): row (n,k,t) is read as two bf16 half-rows through table [2][N*K*T] (device addresses),
+ * warp_rows [N*K*T][w] receives the warped rows as bf16 -- the rows fvta_attn_fwd_shadow / fvta_attn_bwd_shadow then read
+ * through a table of addresses into warp_rows.  w = 512 or 1024, K <= 8.  The backward takes the attention's fp32 gradient
+ * of the warped rows (d_warp [N,K,T,w], zeros on masked rows) and overwrites d_hall; no time_warp_att term. */
+int fvta_timewarp_fwd_shadow(const fvta_timewarp_desc* d, const uint64_t* table, const float* lq, const float* WH_W,
+                             const float* WH_b, const float* WC_W, const float* WC_b, uint16_t* warp_rows, float* c_out,
+                             float* scale_out, void* workspace, fvta_stream_t stream);
+int fvta_timewarp_bwd_shadow(const fvta_timewarp_desc* d, const uint64_t* table, const float* lq, const float* WH_W,
+                             const float* WH_b, const float* WC_W, const float* WC_b, const float* c_saved,
+                             const float* d_warp, float* d_hall, float* d_lq, float* dWH_W, float* dWH_b, float* dWC_W,
+                             float* dWC_b, void* workspace, fvta_stream_t stream);
 
 /* The same with the attention's gradient w.r.t. the per-position scale (fvta_attn_bwd_tw's d_tscale, [N,T]; NULL =
  * fvta_timewarp_bwd): use_time_warp_att feeds c[n,t] cnt(t) into the attention as well (model_v2.py:1020). */

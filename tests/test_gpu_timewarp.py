@@ -148,3 +148,100 @@ def test_model_with_time_warp_att(warp_type):
             _close(torch.from_numpy(grads[k]).reshape(v.grad.shape), v.grad, rtol=2e-4, atol=2e-5)
     with pytest.raises(NameError):
         Model(dict(spec.cfg(), use_time_warp_att=True, batch_size=spec.N), text_in=spec.text_in, img_in=spec.img_in)
+
+
+@pytest.mark.parametrize("warp_type", [1, 3, 5])
+@pytest.mark.parametrize("N,K,T,w", [(2, 3, 17, 512), (3, 6, 50, 1024), (1, 8, 9, 512)])
+def test_timewarp_over_shadow_rows(warp_type, N, K, T, w):
+    """fvta_timewarp_fwd_shadow / _bwd_shadow (the bf16 engine: the context tensor is never stored in fp32) against the
+    fp32-row kernels on the SAME bf16-valued rows: c / scale equal, the warped rows = bf16 of the fp32 kernel's, and every
+    gradient equal up to summation order; rows whose table entries point at the shared zero half-row are zero rows."""
+    from fvta_memexqa_amd import ops
+    from tests.test_gpu_shadow import _shadow_table
+    g = torch.Generator().manual_seed(warp_type * 10 + T + w)
+    hb = (torch.randn(N * K * T, w, generator=g) * 0.5).clamp(-1, 1).bfloat16().cuda()
+    zero_rows = torch.arange(0, N * K * T, 7, device="cuda")
+    hb[zero_rows] = 0
+    table, keep = _shadow_table(hb, zero_rows, warp_type + T)
+    h32 = hb.float().view(N, K, T, w).contiguous()
+    cu = lambda t: t.cuda().contiguous()
+    lq = cu(torch.randn(N, w, generator=g) * 0.5)
+    WH = cu(torch.randn(2 * w, w, generator=g) * (0.3 / w ** 0.5))
+    WHb = cu(torch.randn(w, generator=g) * 0.1)
+    WC = cu(torch.randn(w, generator=g) * (0.5 / w ** 0.5))
+    WCb = cu(torch.randn(1, generator=g) * 0.1)
+    ref_op, op = ops.TimeWarp(N, K, T, w, warp_type, 2.3), ops.TimeWarp(N, K, T, w, warp_type, 2.3)
+    warp32 = torch.empty_like(h32)
+    ref_op.forward(h32, lq, WH, WHb, WC, WCb, warp32)
+    warp_b = torch.full((N * K * T, w), 7.0, dtype=torch.bfloat16, device="cuda")
+    op.forward_shadow(table, lq, WH, WHb, WC, WCb, warp_b)
+    np.testing.assert_allclose(op.c.cpu().numpy(), ref_op.c.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(op.scale.cpu().numpy(), ref_op.scale.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # bf16 of the same product (c differs in the last fp32 bits between the two reductions: allow one bf16 ulp)
+    np.testing.assert_allclose(warp_b.float().cpu().numpy(), warp32.view(-1, w).bfloat16().float().cpu().numpy(), rtol=2.0 ** -7, atol=1e-30)
+    assert float(warp_b[zero_rows].float().abs().max()) == 0.0
+    d_warp = cu(torch.randn(N, K, T, w, generator=g))
+    outs = []
+    for which in (0, 1):
+        d_hall = torch.full_like(h32, float("nan"))
+        d_lq = torch.zeros_like(lq)
+        grads = [torch.zeros_like(WH), torch.zeros_like(WHb), torch.zeros_like(WC), torch.zeros_like(WCb)]
+        if which == 0:
+            ref_op.backward(h32, lq, WH, WHb, WC, WCb, d_warp, d_hall, d_lq, *grads)
+        else:
+            op.backward_shadow(table, lq, WH, WHb, WC, WCb, d_warp, d_hall, d_lq, *grads)
+        outs.append([d_hall, d_lq] + grads)
+    for a, b, name in zip(outs[1], outs[0], ("d_hall", "d_lq", "dWH_W", "dWH_b", "dWC_W", "dWC_b")):
+        assert torch.isfinite(a).all(), name
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5 * max(1.0, float(b.abs().max())), err_msg=name)
+
+
+# (warp types 1 / 3 / 5 of the kernels themselves: test_timewarp_over_shadow_rows.  At the model level only the published type:
+#  type 1 scales every row by T, the attention's tanh saturates, and two bf16 runs a rounding apart no longer agree in the
+#  warp's own -- vanishing -- parameter gradients)
+@pytest.mark.parametrize("cfgname,N,warp_type", [("plumbing_w512", None, 5), ("metric", 2, 5)])
+def test_model_time_warp_on_shadow_rows_is_the_same_train_step(cfgname, N, warp_type):
+    """--use_time_warp under precision = bf16 with and without shadow rows (the published flag set's regime): the warp and the
+    attention read the encoders' bf16 rows instead of an fp32 context tensor -- yp / loss within the bf16 engine's tolerance of
+    the plain bf16 run, every gradient within a few percent (relative L2), the vis tensors hall / warp_h served on demand."""
+    from fvta_memexqa_amd.model_v2 import Model
+    from fvta_memexqa_amd.synth import CONFIGS, SynthSpec, make_inputs, make_params
+    cfg = dict(CONFIGS["plumbing"], d=256) if cfgname == "plumbing_w512" else dict(CONFIGS[cfgname])
+    if N:
+        cfg["N"] = N
+    spec = SynthSpec(dense=False, **cfg)
+    params, inputs = make_params(spec), make_inputs(spec)
+    g = torch.Generator().manual_seed(17)
+    w = spec.w
+    params.update(WH_W=torch.randn(2 * w, w, generator=g) * (0.3 / w ** 0.5), WH_b=torch.randn(w, generator=g) * 0.05,
+                  WC_W=torch.randn(w, 1, generator=g) * (0.5 / w ** 0.5), WC_b=torch.randn(1, generator=g) * 0.05)
+    res = {}
+    for shadow in (False, True):
+        model = Model(dict(spec.cfg(), batch_size=spec.N, precision="bf16", shadow_rows=shadow, use_time_warp=True,
+                           warp_type=warp_type, window_t=2.4), text_in=spec.text_in, img_in=spec.img_in)
+        model.set_oracle_params(params)
+        L = model.load_inputs(inputs, training=True)
+        assert L.shadow == shadow
+        model.zero_grad()
+        yp = model.forward(L).cpu().double()
+        model.backward(L, need_dx=True)
+        grads = {k: torch.from_numpy(np.asarray(v)).double() for k, v in model.get_oracle_grads().items()}
+        res[shadow] = dict(yp=yp, loss=model.loss.cpu().double(), grads=grads, hall=model.hall.clone(), warp=model.warp_h.clone(),
+                           c=model.C.clone())
+        model.forward(L, want_logits=True)
+        res[shadow]["yp2"] = model.yp.cpu().double()
+    a, b = res[True], res[False]
+    assert torch.equal(a["hall"], b["hall"].bfloat16().float()), "hall"
+    np.testing.assert_allclose(a["c"].cpu().numpy(), b["c"].cpu().numpy(), rtol=0, atol=2e-2)
+    np.testing.assert_allclose(a["warp"].cpu().numpy(), b["warp"].cpu().numpy(), rtol=3e-2, atol=3e-2 * float(b["warp"].abs().max()))
+    np.testing.assert_allclose(a["yp"].numpy(), b["yp"].numpy(), rtol=0, atol=1e-2)
+    np.testing.assert_allclose(a["yp2"].numpy(), a["yp"].numpy(), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(a["loss"].numpy(), b["loss"].numpy(), rtol=0, atol=1e-2)
+    for k, gb in b["grads"].items():
+        ga = a["grads"][k]
+        if float(gb.norm()) < 1e-6:
+            assert float(ga.abs().max()) < 1e-5, k
+            continue
+        err = float((ga - gb).norm() / (gb.norm() + 1e-30))
+        # (the attention logits' parameters hang off arg-max positions, and the warp's off a tanh of sums over every row)
+        assert err < (0.3 if (k.startswith("att_") or k.startswith("W")) else 5e-2), "grad %s: relative L2 %.4f" % (k, err)
