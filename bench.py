@@ -383,14 +383,21 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     h32 = torch.ones_like(lens)
     if shadow:
         h32[T.segs[0]["count"] + T.segs[1]["count"]:] = 0.0      # (the text cell's sequences: q, choices, then the context streams)
-    by_fwd = float((2 * lens * (in_i * 2 + dp * 2 + dp * 4 * 2 + dp * 2 + 4 * dp * 2) + 2 * lens * h32 * dp * 4).sum().item())
-    by_bwd = float((2 * lens * dp * 32).sum().item())
-    by_dx = float((2 * lens * dp * 8 + lens * spec.text_in * 4).sum().item())
+    x3 = args.precision == "bf16x3"      # the split engine: two stored bf16 terms per operand value, fp32 saved gates
+    if x3:   # x, h(t-1) read as (hi, lo); c read + written; h(t) written as (hi, lo) [+ fp32]; fp32 gates 16 B per unit
+        by_fwd = float((2 * lens * (in_i * 4 + dp * 4 + dp * 4 * 2 + dp * 4 + 4 * dp * 4) + 2 * lens * h32 * dp * 4).sum().item())
+        by_bwd = float((2 * lens * dp * 48).sum().item())      # gates 16, c 4, d_out 4, dc 4 + 4, dz (hi, lo) 16
+        by_dx = float((2 * lens * dp * 16 + lens * spec.text_in * 4).sum().item())
+    else:
+        by_fwd = float((2 * lens * (in_i * 2 + dp * 2 + dp * 4 * 2 + dp * 2 + 4 * dp * 2) + 2 * lens * h32 * dp * 4).sum().item())
+        by_bwd = float((2 * lens * dp * 32).sum().item())
+        by_dx = float((2 * lens * dp * 8 + lens * spec.text_in * 4).sum().item())
     is_bf = args.precision in ("bf16", "bf16x3")
     # the matrix pipe's peak for this engine, and the hardware flops per algorithmic flop (the split engine runs three
     # bf16 products per logical one)
     peak_tf, hw_mult = (PEAK_BF16_TFLOPS, 3.0 if args.precision == "bf16x3" else 1.0) if is_bf else (PEAK_F32_TFLOPS, 1.0)
-    wreg_fwd = args.precision == "bf16" and (dp, in_i) in ((512, 224), (512, 128), (1024, 224), (1024, 128), (128, 128), (128, 32))
+    wreg_fwd = ((args.precision == "bf16" and (dp, in_i) in ((512, 224), (512, 128), (1024, 224), (1024, 128), (128, 128), (128, 32)))
+                or (x3 and (dp, in_i) in ((512, 224), (512, 128), (128, 128), (128, 32))))
     # which kernel ran the backward step is the LIBRARY's word (fvta_lstm_bwd_kernel_counts), not re-derived here
     bwd_main = max(bwd_counts, key=lambda k: bwd_counts[k]) if sum(bwd_counts.values()) else "lstm_bwd_fused_bf16"
     ring_bwd = bwd_main == "lstm_bwd_ring_bf16"

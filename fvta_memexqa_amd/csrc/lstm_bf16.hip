@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, XM == 1 ? 2 : 1) void lstm_step_fwd_bf16(StepA
   if (m0 >= nact) return;
   const int tid = threadIdx.x;
   const int d = a.d, in_i = a.Kp - a.d;
-  const int in_k = in_i * a.xm, d_k = d * a.xm, Kk = a.Kp * a.xm;  // K extents of the x / h operand rows (split engine: three terms)
+  const int in_k = in_i * a.xm, d_k = d * a.xm, Kk = a.Kp * a.xm;  // K extents of the x / h operand rows (split engine: two stored terms)
   const size_t trow = ((size_t)dir * a.J + t) * a.B;
   for (int r = tid; r < Cfg::BM; r += Cfg::NT) s_oo[r] = (m0 + r < nact) ? a.plan.oo[trow + m0 + r] : -1;
 

@@ -187,3 +187,22 @@ def test_bench_also_helper_exits_quietly_without_go():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--also-helper"], input="", capture_output=True,
                        text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == ""
+
+
+def test_trainer_owns_and_releases_the_collector():
+    """Trainer.own_host (called by the first step_device under config gc_freeze, default on): CPython's collector frozen and
+    off while a trainer steps, back on when it releases the host or goes away; gc_freeze=False never touches it."""
+    import gc
+    from fvta_memexqa_amd.trainer import Trainer
+    assert gc.isenabled()
+    t = Trainer(object(), dict(init_lr=0.5))
+    assert t.gc_freeze and gc.isenabled()
+    t.own_host()
+    assert not gc.isenabled() and gc.get_freeze_count() > 0
+    t.own_host()                      # idempotent
+    t.release_host()
+    assert gc.isenabled() and gc.get_freeze_count() == 0
+    t.own_host()
+    del t                             # a trainer that goes away gives the collector back
+    assert gc.isenabled()
+    assert not Trainer(object(), dict(gc_freeze=False)).gc_freeze
