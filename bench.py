@@ -401,7 +401,8 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
     # which kernel ran the backward step is the LIBRARY's word (fvta_lstm_bwd_kernel_counts), not re-derived here
     bwd_main = max(bwd_counts, key=lambda k: bwd_counts[k]) if sum(bwd_counts.values()) else "lstm_bwd_fused_bf16"
     ring_bwd = bwd_main == "lstm_bwd_ring_bf16"
-    dense_metric = args.config == "metric" and args.variant == "dense" and not args.batch and args.graph == "fvta" and args.precision == "bf16"
+    dense_metric = (args.config == "metric" and args.variant == "dense" and not args.batch and args.graph == "fvta"
+                    and args.precision in ("bf16", "bf16x3") and not args.time_warp and not args.front_end)
     roofs = {}
 
     def hbm_roof(name, kernel, prof_key, bytes_per_call, flops_per_call=None, note=None, traffic=None):
@@ -441,7 +442,7 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
         mfma_roof("lstm_fwd", "lstm_step_fwd_f32", "lstm_step_fwd", fl_text)
     else:
         hbm_roof("lstm_fwd", "lstm_fwd_wreg_bf16 (forward step, weights in registers)" if wreg_fwd else "lstm_step_fwd_bf16",
-                 "lstm_step_fwd", by_fwd, fl_text, traffic=("r05_lstm_pmc.json", "lstm_fwd_wreg_bf16<fvta::WregCfg<14, 32, 2>"))
+                 "lstm_step_fwd", by_fwd, fl_text, traffic=(("r06_lstm_bf16x3_pmc.json", "lstm_fwd_wreg_bf16<fvta::WregCfg<14, 32, 1, true") if x3 else ("r06_lstm_pmc.json", "lstm_fwd_wreg_bf16<fvta::WregCfg<14, 32, 2,")))
         ms_p, n_p = prof["lstm_step_fwd_photo_cell"]
         if n_p and "lstm_fwd" in roofs:
             # rocprofv3 --stats averages per kernel SYMBOL: the photo cell (side stream, small launches) runs the same
@@ -457,9 +458,9 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
                  "lstm_step_bwd", by_bwd, fl_text * dp / (spec.text_in + dp),
                  note="algorithmic bytes: the gate gradient (32 B per row and unit: gates 8, c 4, d_out 4, dc 4 + 4, dz 8); the "
                       "re-read of dz(t+1) (8 B) is not counted; dx has its own bracket",
-                 traffic=("r05_lstm_bwd_pmc.json", "lstm_bwd_ring_bf16" if ring_bwd else "lstm_bwd_fused_bf16<2, 4, 1,"))
+                 traffic=(("r06_lstm_bf16x3_bwd_pmc.json", "lstm_bwd_fused_bf16<2, 4, 2,") if x3 else ("r06_lstm_bwd_pmc.json", "lstm_bwd_ring_bf16" if ring_bwd else "lstm_bwd_fused_bf16<2, 4, 1,")))
         hbm_roof("lstm_dx", "lstm_dx_bf16 (input gradient of all steps, both directions in one launch)", "lstm_dx", by_dx,
-                 fl_text * spec.text_in / (spec.text_in + dp), traffic=("r05_lstm_bwd_pmc.json", "lstm_dx_bf16<2, 64, 2, true>"))
+                 fl_text * spec.text_in / (spec.text_in + dp), traffic=(("r06_lstm_bf16x3_bwd_pmc.json", "lstm_dx_bf16<2, 64, 2, true, true, 2") if x3 else ("r06_lstm_bwd_pmc.json", "lstm_dx_bf16<2, 64, 2, true, true, 1")))
         mfma_roof("lstm_dw", "lstm_dw_bf16 (weight gradient: [x|h|1]^T dz over every row and step)", "lstm_dw", fl_text)
     # ---- attention kernels against HBM: algorithmic bytes = valid rows * w * 4 + question + output; the
     # backward reads the rows and writes their gradient
@@ -473,10 +474,10 @@ def run_case(args, lib, ws, rank, local, probe_gbs=None):
                   else "attn_fwd_main"))
         # (the library's profile bracket covers the context attention only, not the K = 1 question attention)
         hbm_roof("attention", kname + " (fvta_attn_fwd main kernel)", "attn_fwd_main", att_bytes,
-                 traffic=("r05_attention_pmc.json", "attn_fwd_pair16h" if shadow else "attn_fwd_pair16<"))
+                 traffic=("r06_attention_pmc.json", "attn_fwd_pair16h" if shadow else "attn_fwd_pair16<"))
         if not args.forward_only:
             hbm_roof("attention_bwd", "attn_bwd_main", "attn_bwd_main", valid_rows * model.wp * (row_b + 4.0),
-                     traffic=("r05_attention_pmc.json", "attn_bwd_main<256, 1, 32, false, false, true>" if shadow else "attn_bwd_main<256, 1, 32, false, false>"))
+                     traffic=("r06_attention_pmc.json", "attn_bwd_main<256, 1, 32, false, false, true>" if shadow else "attn_bwd_main<256, 1, 32, false, false, false>"))
     # the DOMINANT kernel of the step (largest bracketed time per step) is `roofline`; the rest are roofline_<name>
     kms = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
     order = sorted(roofs, key=lambda k: -roofs[k]["ms_per_step"])

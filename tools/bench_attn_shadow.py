@@ -12,6 +12,11 @@ q = torch.randn(N, JQ, w, device="cuda", generator=g) * 0.5
 W = torch.randn(2 * w, device="cuda", generator=g) * 0.1
 b = torch.zeros(1, device="cuda")
 hm = torch.ones(N, K, T, dtype=torch.uint8, device="cuda")
+# the row set of bench.py's dense metric shape (the one `algorithmic_bytes_per_call` is computed on): the LAST stream is the photo
+# stream, M rows of its T; FVTA_ATTN_ALL_ROWS=1: every row valid
+if not os.environ.get("FVTA_ATTN_ALL_ROWS") and K > 1:
+    hm[:, K - 1, M:] = 0
+print("valid rows: %d of %d" % (int(hm.sum().item()), N * K * T))
 qm = torch.ones(N, JQ, dtype=torch.uint8, device="cuda")
 op = ops.FocalAttention(N, K, T, JQ, w, 2, False)
 R, d = N * K * T, w // 2
