@@ -322,10 +322,6 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
         st16(dump + 1280, __builtin_bit_cast(f32x4, u32x4{gpk[4], gpk[5], gpk[6], gpk[7]}), false);
       } else
       if (((abl & 8192) || i < nact) && !(abl & 16)) {
-        // (abl & 16384, timing experiment: c / h shadow / gates stored BLOCKED by column block -- [cb][row][UB units], every
-        //  workgroup's stores contiguous -- instead of as 256-byte slices of 2-KB rows; the consumers do not know: garbage)
-        if constexpr ((abl & 16384) != 0) st16(c_base + ((size_t)cb * a.B + i) * C::UB + 4 * e_q, cv, a.nt != 0);
-        else
         if constexpr (!(abl & 128)) st16(c_base + (size_t)i * d + u_lane, cv, a.nt != 0);
         const int64_t oo = oo_cur[p];
         if (((abl & 8192) || oo >= a.out_skip) && !(abl & 256)) {   // (inactive rows: -1; rows below out_skip: their readers take the shadow)
@@ -350,14 +346,11 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void lstm_fwd_wreg_bf16(Step
 #pragma unroll
             for (int e = 0; e < 4; ++e) st16(gp + 4 * e, gf[e], a.nt != 0);
           }
-        } else if constexpr ((abl & 16384) != 0) {
-          *reinterpret_cast<u32x2*>(a.hs + trow * (size_t)d + ((size_t)cb * a.B + i) * C::UB + 4 * e_q) = u32x2{pk_bf16(hv[0], hv[1]), pk_bf16(hv[2], hv[3])};
         } else {
         if constexpr (!(abl & 512)) *reinterpret_cast<u32x2*>(a.hs + (trow + i) * (size_t)d + u_lane) = u32x2{pk_bf16(hv[0], hv[1]), pk_bf16(hv[2], hv[3])};
         }
         if (!C::X3 && a.gatesb && !(abl & 1024)) {  // unit-major [u][i,j,f,o]
-          float* gp = (abl & 16384) ? reinterpret_cast<float*>(a.gatesb + trow * (size_t)(4 * d) + ((size_t)cb * a.B + i) * (4 * C::UB) + 16 * e_q)
-                                    : reinterpret_cast<float*>(a.gatesb + (trow + i) * (size_t)(4 * d) + 4 * u_lane);
+          float* gp = reinterpret_cast<float*>(a.gatesb + (trow + i) * (size_t)(4 * d) + 4 * u_lane);
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
           st16(gp, __builtin_bit_cast(f32x4, u32x4{gpk[0], gpk[1], gpk[2], gpk[3]}), a.nt != 0);
           st16(gp + 4, __builtin_bit_cast(f32x4, u32x4{gpk[4], gpk[5], gpk[6], gpk[7]}), a.nt != 0);
