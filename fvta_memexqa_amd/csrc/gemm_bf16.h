@@ -55,15 +55,18 @@ __device__ __forceinline__ void wait_vmcnt() {
 // BK_ = k extent of a ring stage: 32 (64-byte rows; 1 KiB DMA pieces of 16 rows) or 64 (128-byte rows: a DMA piece is 8
 // rows x one whole 128-byte line -- the CU's address unit takes a wave-instruction per ~31 cycles whatever it touches, but a
 // piece of 16 half lines costs it more; row images only).
-template <int WN, int TM_ = 2, int WM_ = 8 / TM_, int ST_ = 3, int BK_ = 32>
+// TN_ = MFMA column tiles per wave (4: the 64 x 128 wave tile; 1: a 64 x 32 one -- WN = 4 waves of them side by side make the
+// 64 x 128 block tile of the split engine's photo-cell backward step: the same rows and columns as ONE 64 x 128 wave, but four
+// waves share the stage's DMA pieces and its MFMAs, so the step's chain of k-tiles is a quarter as long).
+template <int WN, int TM_ = 2, int WM_ = 8 / TM_, int ST_ = 3, int BK_ = 32, int TN_ = 4>
 struct TileCfgT {
   static_assert(TM_ == 2, "wave tile: two MFMA row tiles");
   static_assert(BK_ == 32 || BK_ == 64, "stage depth");
-  static constexpr int TM = TM_, WAVES_M = WM_, NWAVES = WAVES_M * WN;
+  static constexpr int TM = TM_, TN = TN_, WAVES_M = WM_, NWAVES = WAVES_M * WN;
   // ST_ = ring depth.  A k-loop's tile rate is (tiles in flight) / (load latency) -- a lone k-loop does not fill the
   // CU's load path -- so the weight-gradient GEMM (one 256 x 256 workgroup per CU, 32 KB per stage) runs a deeper ring;
   // the backward step measured no faster with four stages, and the 256 x 128 tile needs two workgroups per CU to fit.
-  static constexpr int BM = 32 * TM_ * WM_, BN = 128 * WN, BK = BK_, STAGES = ST_, NT = 64 * NWAVES;
+  static constexpr int BM = 32 * TM_ * WM_, BN = 32 * TN_ * WN, BK = BK_, STAGES = ST_, NT = 64 * NWAVES;
   static constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;  // per stage
   static constexpr int STAGE_ELEMS = A_ELEMS + B_ELEMS;
   static constexpr int LDS_BYTES = STAGES * STAGE_ELEMS * 2;        // 73,728 (WN = 1)
@@ -82,13 +85,13 @@ __device__ __forceinline__ constexpr int row_swz(int r) { return BK == 32 ? ((r 
 // further -- so that a 64-element stage row is one contiguous 128-byte line holding [hi of 32 k | lo of the same 32 k].  A
 // k-step reads a_hi, a_lo, b_hi, b_lo ONCE and issues hi hi + hi lo + lo hi from those registers: 4 fragment sets per 3 MFMA
 // groups (the three-term form of round 2-5 -- [hi | hi | lo] x [hi | lo | hi] rows through the plain loop -- staged and read 6).
-template <int WN, int TM_ = 2, int WM_ = 8 / TM_, int ST_ = 3, int BK_ = 32, bool X2_ = false>
+template <int WN, int TM_ = 2, int WM_ = 8 / TM_, int ST_ = 3, int BK_ = 32, bool X2_ = false, int TN_ = 4>
 struct MmaBT {
-  typedef TileCfgT<WN, TM_, WM_, ST_, BK_> Cfg;
+  typedef TileCfgT<WN, TM_, WM_, ST_, BK_, TN_> Cfg;
   static constexpr int BK = BK_;
   static constexpr bool X2 = X2_;
   static_assert(!X2_ || BK_ == 64, "split engine: 64-element stage rows (32 k of hi | lo)");
-  static constexpr int TM = TM_, TN = 4, WAVES_M = Cfg::WAVES_M, WAVES_N = 1, BM = Cfg::BM, BN = Cfg::BN;  // WAVES_N: per wave column
+  static constexpr int TM = TM_, TN = TN_, WCOLS = 32 * TN_, WAVES_M = Cfg::WAVES_M, WAVES_N = 1, BM = Cfg::BM, BN = Cfg::BN;  // WAVES_N: per wave column
   static constexpr int WROWS = 32 * TM;  // rows of a wave tile
   f32x16 acc[TM][TN];
   int wave_all, wave, wn, lane, l31, hf;  // wave = row of the WAVES_M x WN wave grid (the M position), wn = its column
@@ -131,7 +134,7 @@ struct MmaBT {
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int r = wn * 128 + j * 32 + l31;
+          const int r = wn * WCOLS + j * 32 + l31;
           bh[j].f = *reinterpret_cast<const f32x4*>(Bs + r * 64 + ((c ^ row_swz<64>(r)) << 3));
           bl[j].f = *reinterpret_cast<const f32x4*>(Bs + r * 64 + (((c + 4) ^ row_swz<64>(r)) << 3));
         }
@@ -162,7 +165,7 @@ struct MmaBT {
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int r = wn * 128 + j * 32 + l31;
+        const int r = wn * WCOLS + j * 32 + l31;
         b[j].f = *reinterpret_cast<const f32x4*>(Bs + r * BK + ((c ^ row_swz<BK>(r)) << 3));
       }
 #pragma unroll
@@ -189,7 +192,7 @@ struct MmaBT {
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int r = wn * 128 + j * 32 + l31;
+      const int r = wn * WCOLS + j * 32 + l31;
       Pack8 p;
       p.f = *reinterpret_cast<const f32x4*>(Bs + r * 32 + ((c ^ ((r >> 2) & 3)) << 3));
       f.b[j] = p.b;
@@ -230,7 +233,7 @@ struct MmaBT {
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = tr_frag<BM>(As, ks * 16, wave * WROWS + i * 32);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = tr_frag<BN>(Bs, ks * 16, wn * 128 + j * 32);
+      for (int j = 0; j < TN; ++j) b[j] = tr_frag<BN>(Bs, ks * 16, wn * WCOLS + j * 32);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -239,7 +242,7 @@ struct MmaBT {
   }
 
   __device__ __forceinline__ int row_of(int i, int r) const { return wave * WROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf; }
-  __device__ __forceinline__ int col_of(int j) const { return wn * 128 + j * 32 + l31; }
+  __device__ __forceinline__ int col_of(int j) const { return wn * WCOLS + j * 32 + l31; }
 };
 typedef MmaBT<1> MmaB;
 

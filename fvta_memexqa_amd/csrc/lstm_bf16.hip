@@ -255,12 +255,12 @@ __device__ __forceinline__ int kt_rot(int nkt) {
 // covers 4 RPW rows -- tile row r is global row m0 + (r / 64) RPW + r % 64, rows r % 64 >= RPW are padding (zero operand rows,
 // their epilogue passes compiled out) -- so that the launch's grid fills the CUs: at the metric shape 58 tiles of 224 rows
 // x 2 column tiles x 2 directions = 232 workgroups instead of 204 of 256 rows on 256 CUs, each with 7/8 of the epilogue.
-template <int WN, int WM, int XM, int BK, int ST, int RPW = 64, int EPD_ = FVTA_BWD_EPD>  // XM = 2: the split engine (two stored bf16 terms per operand value, three products; fp32 saved gates)
+template <int WN, int WM, int XM, int BK, int ST, int RPW = 64, int TN = 4, int EPD_ = FVTA_BWD_EPD>  // XM = 2: the split engine (two stored bf16 terms per operand value, three products; fp32 saved gates)
 __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t, int dir, int m0, int u0, bf16_t* smem_h) {
   static_assert(RPW == 64 || (WM == 4 && RPW % 8 == 0 && RPW > 32 && RPW < 64), "rows per wave tile");
   auto grow_of = [&](int r) { return RPW == 64 ? m0 + r : m0 + (r >> 6) * RPW + (r & 63); };  // tile row -> global sorted row
-  typedef TileCfgT<WN, 2, WM, ST, BK> TileCfg;
-  typedef MmaBT<WN, 2, WM, ST, BK, XM == 2> MmaB;
+  typedef TileCfgT<WN, 2, WM, ST, BK, TN> TileCfg;
+  typedef MmaBT<WN, 2, WM, ST, BK, XM == 2, TN> MmaB;
   int64_t* s_oo = reinterpret_cast<int64_t*>(smem_h + (size_t)TileCfg::STAGES * TileCfg::STAGE_ELEMS);
   const int tid = (int)threadIdx.x;
   const int d = a.d, N4 = 4 * d, K = N4 * XM;  // K: the dz row (split engine: two terms per value, il32 layout)
@@ -335,7 +335,7 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
   // when pass P is done, also across plane boundaries (the loads do not depend on the plane's scratch): EPD passes of
   // 5 KB are in flight per wave all through the epilogue.
   constexpr int EPD = EPD_, NPASS = MmaB::TM * MmaB::TN * 4;
-  auto plane_u = [&](int pl) { return u0 + mma.wn * 128 + (pl % MmaB::TN) * 32 + 4 * io_c4; };
+  auto plane_u = [&](int pl) { return u0 + mma.wn * MmaB::WCOLS + (pl % MmaB::TN) * 32 + 4 * io_c4; };
   auto load_pass = [&](int P, In& in) {
     if constexpr ((abl & 4) != 0) {
       in.g0 = in.g1 = in.g2 = in.g3 = in.cp = in.dout = in.dcv = f32x4{0.5f, 0.25f, 0.125f, 0.75f};
@@ -448,11 +448,11 @@ __device__ __forceinline__ void lstm_bwd_tile_step(const FusedBwdArgs& a, int t,
   });
 }
 
-template <int WN, int WM = 4, int XM = 1, int BK = 32, int ST = 3, int RPW = 64>
+template <int WN, int WM = 4, int XM = 1, int BK = 32, int ST = 3, int RPW = 64, int TN = 4>
 __global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 && XM == 1 ? 2 : 1)) void lstm_bwd_fused_bf16(FusedBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
-  typedef TileCfgT<WN, 2, WM, ST, BK> TileCfg;
-  lstm_bwd_tile_step<WN, WM, XM, BK, ST, RPW>(a, a.t, blockIdx.z, blockIdx.x * (RPW == 64 ? TileCfg::BM : 4 * RPW), blockIdx.y * TileCfg::BN, smem_h);
+  typedef TileCfgT<WN, 2, WM, ST, BK, TN> TileCfg;
+  lstm_bwd_tile_step<WN, WM, XM, BK, ST, RPW, TN>(a, a.t, blockIdx.z, blockIdx.x * (RPW == 64 ? TileCfg::BM : 4 * RPW), blockIdx.y * TileCfg::BN, smem_h);
 }
 
 static int bwd_cus() {
@@ -468,7 +468,14 @@ template <int XM>
 static void launch_bwd_fused_xm(const FusedBwdArgs& a, hipStream_t s) {
   // narrow tiles: 32-deep stages x 3; split engine: 64-element stage rows (32 k of hi | lo) x 2
   constexpr int NBK = XM == 1 ? 32 : 64, NST = XM == 1 ? 3 : 2;
-  if (a.B <= 64) {  // few sequences (the photo cell): row tiles of 64 / 128
+  if (XM == 2 && a.B <= 64 && a.d % 128 == 0) {
+    // the split engine's photo cell: the 64 x 128 tile on FOUR waves of 64 x 32 (TN = 1) -- one wave's chain of 64 k-tiles was
+    // 24 DMA pieces + 48 MFMAs per tile in ONE instruction stream (~360 us per step under the text cell, 40 steps: longer than the
+    // text cell's own backward); four waves share them
+    constexpr int LDS = TileCfgT<4, 2, 1, NST, NBK, 1>::LDS_BYTES + 64 * 8;
+    allow_big_lds(lstm_bwd_fused_bf16<4, 1, XM, NBK, NST, 64, 1>, LDS);
+    hipLaunchKernelGGL((lstm_bwd_fused_bf16<4, 1, XM, NBK, NST, 64, 1>), dim3((a.B + 63) / 64, a.d / 128, 2), dim3(256), LDS, s, a);
+  } else if (a.B <= 64) {  // few sequences (the photo cell): row tiles of 64 / 128
     constexpr int LDS = TileCfgT<1, 2, 1, NST, NBK>::LDS_BYTES + 64 * 8;
     allow_big_lds(lstm_bwd_fused_bf16<1, 1, XM, NBK, NST>, LDS);
     hipLaunchKernelGGL((lstm_bwd_fused_bf16<1, 1, XM, NBK, NST>), dim3((a.B + 63) / 64, (a.d + 127) / 128, 2), dim3(64), LDS, s, a);
@@ -533,10 +540,12 @@ void launch_bwd_fused_bf16(const FusedBwdArgs& a, hipStream_t s) {
 // NOACC: the launcher's promise that accumulate == 0, at compile time -- as a run-time `if (accumulate) old = load(dst)` every
 // row group's store sat behind an s_waitcnt vmcnt(0) that also waits for every EARLIER store of the wave: 56 store round trips
 // per wave tile, one after the other (the same pattern cost the attention backward 17 % in round 4).
-template <int WN, int BK, int ST, bool BOTH = false, bool NOACC = false, int XM = 1>
-__global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 && XM == 1 ? 2 : 1)) void lstm_dx_bf16(FusedBwdArgs a, int dir, int accumulate) {
-  typedef TileCfgT<WN, 2, 4, ST, BK> TileCfg;
-  typedef MmaBT<WN, 2, 4, ST, BK, XM == 2> MmaB;
+// WM / TN: the block tile's wave rows and a wave's column tiles (4 / 4; the split engine's photo cell: 1 / 1 with WN = 4 -- a
+// 64 x 128 tile on four waves, as in its backward step)
+template <int WN, int BK, int ST, bool BOTH = false, bool NOACC = false, int XM = 1, int WM = 4, int TN = 4>
+__global__ __launch_bounds__((TileCfgT<WN, 2, WM>::NT), (WN == 1 && XM == 1 ? 2 : 1)) void lstm_dx_bf16(FusedBwdArgs a, int dir, int accumulate) {
+  typedef TileCfgT<WN, 2, WM, ST, BK, TN> TileCfg;
+  typedef MmaBT<WN, 2, WM, ST, BK, XM == 2, TN> MmaB;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem_h[];
   const int tid = threadIdx.x;
   const int t = blockIdx.z;
@@ -619,7 +628,7 @@ __global__ __launch_bounds__((TileCfgT<WN>::NT), (WN == 1 && XM == 1 ? 2 : 1)) v
   for (int ti = 0; ti < MmaB::TM; ++ti)
 #pragma unroll
     for (int tj = 0; tj < MmaB::TN; ++tj) {
-      const int nb = n0 + mma.wn * 128 + tj * 32;  // first column of the plane
+      const int nb = n0 + mma.wn * MmaB::WCOLS + tj * 32;  // first column of the plane
       if (nb >= in) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) pl[((r & 3) + 8 * (r >> 2) + 4 * mma.hf) * LDP + mma.l31] = mma.acc[ti][tj][r];
@@ -702,6 +711,14 @@ static void launch_dx_xm(const FusedBwdArgs& a, hipStream_t s) {
     return;
   }
   constexpr int NBK = XM == 1 ? 32 : 64, NST = XM == 1 ? 3 : 2;
+  if (XM == 2 && a.B <= 64 && a.in <= 128) {  // the split engine's photo cell: a 64 x 128 tile on four waves (no DMA of 192 rows that do not exist)
+    constexpr int LDSP = TileCfgT<4, 2, 1, NST, NBK, 1>::LDS_BYTES + 64 * 8;
+    allow_big_lds(lstm_dx_bf16<4, NBK, NST, false, false, XM, 1, 1>, LDSP);
+    const dim3 gridp((a.B + 63) / 64, 1, a.J);
+    for (int dir = 0; dir < 2; ++dir)
+      hipLaunchKernelGGL((lstm_dx_bf16<4, NBK, NST, false, false, XM, 1, 1>), gridp, dim3(256), LDSP, s, a, dir, a.dx_accumulate || dir);
+    return;
+  }
   constexpr int LDS1 = TileCfgT<1, 2, 4, NST, NBK>::LDS_BYTES + 256 * 8;
   allow_big_lds(lstm_dx_bf16<1, NBK, NST, false, false, XM>, LDS1);
   const dim3 grid(pad8((a.B + 255) / 256), (a.in + 127) / 128, a.J);

@@ -204,7 +204,10 @@ def test_backward_with_host_lengths_hint_is_bitwise_the_same(monkeypatch):
 # ------------------------------------------------------------------ the split-bf16 engine (FVTA_BF16X3)
 @pytest.mark.parametrize("B,J,din,d,dense,share", [(5, 6, 8, 32, False, True), (300, 9, 12, 64, False, True),
                                                    (130, 5, 200, 128, True, False), (70, 17, 100, 64, False, False),
-                                                   (64, 30, 200, 512, False, True), (333, 12, 200, 1024, False, True)])
+                                                   (64, 30, 200, 512, False, True), (333, 12, 200, 1024, False, True),
+                                                   # the photo cell's regime (<= 64 sequences, input <= 128 wide, d = 512): the
+                                                   # backward step and the input gradient on the four-wave 64 x 128 tiles
+                                                   (40, 7, 100, 512, False, True), (64, 40, 100, 512, True, False)])
 def test_bilstm_bf16x3_meets_the_fp32_tolerances(B, J, din, d, dense, share):
     """precision = bf16x3: every MFMA operand split in two bf16 terms, three products per GEMM (hi hi + hi lo + lo hi),
     fp32 saved gates -- the bi-LSTM forward and every gradient against autograd of the fp64 oracle at north_star's
